@@ -1,0 +1,201 @@
+"""Procedural (platform-stable) weights and clips for parity tests and the bench.
+
+No dataset or checkpoint is reachable offline, so every
+parity case and the benchmark use weights drawn from numpy ``PCG64`` streams and
+clips drawn the same way.  Names and shapes follow the reference's state_dict
+(reference ``models/backbones/swin_backbone.py:194-239,
+385-405,530-531,707-711,838`` and ``models/head.py:54-55,23-26``).
+
+Two schemes:
+  * ``"init"``   mirrors the reference initialisation (``swin_backbone.py:1017-1024,
+    242``): N(0, 0.02) weights, zero biases, unit LayerNorm.
+  * ``"stress"`` fan-in scaled weights, non-zero biases, perturbed LayerNorm affine
+    and O(1) bias tables, so that every term of the arithmetic (bias adds, gates,
+    masks, LN affine) moves the output measurably.  This is the scheme parity is
+    judged on.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class SwinCfg:
+    """Constructor arguments of the reference trunk (``swin_backbone.py:760-783``)."""
+    patch: Tuple[int, int, int] = (2, 4, 4)
+    in_chans: int = 3
+    embed_dim: int = 96
+    depths: Tuple[int, ...] = (2, 2, 6, 2)
+    num_heads: Tuple[int, ...] = (3, 6, 12, 24)
+    window: Tuple[int, int, int] = (8, 7, 7)
+    mlp_ratio: int = 4
+    frag_biases: Tuple[bool, ...] = (True, True, True, False)
+
+    @property
+    def num_stages(self) -> int:
+        return len(self.depths)
+
+    def dim(self, stage: int) -> int:
+        return self.embed_dim * (2 ** stage)
+
+    @property
+    def num_features(self) -> int:
+        return self.dim(self.num_stages - 1)
+
+    @property
+    def table_len(self) -> int:
+        w = self.window
+        return (2 * w[0] - 1) * (2 * w[1] - 1) * (2 * w[2] - 1)
+
+
+SWIN_T_GRPB = SwinCfg()
+SWIN_T_PLAIN = SwinCfg(frag_biases=(False, False, False, False))
+SWIN_S_PLAIN = SwinCfg(depths=(2, 2, 18, 2), frag_biases=(False, False, False, False))
+# BASELINE.json config 5: a parameterisation the build defines (SURVEY.md §0 trap 7)
+SWIN_B_GRPB = SwinCfg(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32))
+
+
+def _gen(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def swin_param_shapes(cfg: SwinCfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict key -> shape, trunk only, in the reference's registration order."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    E = cfg.embed_dim
+    s["patch_embed.proj.weight"] = (E, cfg.in_chans) + tuple(cfg.patch)
+    s["patch_embed.proj.bias"] = (E,)
+    s["patch_embed.norm.weight"] = (E,)
+    s["patch_embed.norm.bias"] = (E,)
+    for i in range(cfg.num_stages):
+        C, nH = cfg.dim(i), cfg.num_heads[i]
+        for b in range(cfg.depths[i]):
+            p = f"layers.{i}.blocks.{b}."
+            s[p + "norm1.weight"] = (C,)
+            s[p + "norm1.bias"] = (C,)
+            s[p + "attn.relative_position_bias_table"] = (cfg.table_len, nH)
+            if cfg.frag_biases[i]:
+                s[p + "attn.fragment_position_bias_table"] = (cfg.table_len, nH)
+            s[p + "attn.qkv.weight"] = (3 * C, C)
+            s[p + "attn.qkv.bias"] = (3 * C,)
+            s[p + "attn.proj.weight"] = (C, C)
+            s[p + "attn.proj.bias"] = (C,)
+            s[p + "norm2.weight"] = (C,)
+            s[p + "norm2.bias"] = (C,)
+            s[p + "mlp.fc1.weight"] = (cfg.mlp_ratio * C, C)
+            s[p + "mlp.fc1.bias"] = (cfg.mlp_ratio * C,)
+            s[p + "mlp.fc2.weight"] = (C, cfg.mlp_ratio * C)
+            s[p + "mlp.fc2.bias"] = (C,)
+        if i < cfg.num_stages - 1:
+            p = f"layers.{i}.downsample."
+            s[p + "reduction.weight"] = (2 * C, 4 * C)
+            s[p + "norm.weight"] = (4 * C,)
+            s[p + "norm.bias"] = (4 * C,)
+    s["norm.weight"] = (cfg.num_features,)
+    s["norm.bias"] = (cfg.num_features,)
+    return s
+
+
+def vqa_head_param_shapes(in_channels=768, hidden=64) -> "OrderedDict[str, Tuple[int, ...]]":
+    return OrderedDict([
+        ("fc_hid.weight", (hidden, in_channels, 1, 1, 1)),
+        ("fc_hid.bias", (hidden,)),
+        ("fc_last.weight", (1, hidden, 1, 1, 1)),
+        ("fc_last.bias", (1,)),
+    ])
+
+
+def simple_head_param_shapes(in_channels=9472, hidden=128) -> "OrderedDict[str, Tuple[int, ...]]":
+    return OrderedDict([
+        ("quality.0.weight", (hidden, in_channels)),
+        ("quality.0.bias", (hidden,)),
+        ("quality.1.weight", (1, hidden)),
+        ("quality.1.bias", (1,)),
+    ])
+
+
+def _draw(name: str, shape, seed: int, scheme: str) -> np.ndarray:
+    g = _gen(seed, name)
+    leaf = name.rsplit(".", 1)[-1]
+    is_norm = (".norm" in name or name.startswith("norm.") or ".bn" in name
+               or "downsample.1." in name)
+    if scheme == "init":
+        if "position_bias_table" in name:
+            return (g.standard_normal(shape) * 0.02).astype(np.float32)
+        if is_norm:
+            return (np.ones(shape) if leaf == "weight" else np.zeros(shape)).astype(np.float32)
+        if leaf == "bias":
+            return np.zeros(shape, np.float32)
+        return np.clip(g.standard_normal(shape) * 0.02, -2.0, 2.0).astype(np.float32)
+    if scheme != "stress":
+        raise ValueError(f"unknown scheme {scheme!r}")
+    if "position_bias_table" in name:
+        return (g.standard_normal(shape) * 0.5).astype(np.float32)
+    if is_norm:
+        if leaf == "weight":
+            return (1.0 + 0.1 * g.standard_normal(shape)).astype(np.float32)
+        return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    if leaf == "bias":
+        return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+    return (g.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+
+
+def synth_params(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, scheme: str = "stress",
+                 prefix: str = "") -> "OrderedDict[str, np.ndarray]":
+    """Draw every tensor in ``shapes`` from its own PCG64 stream (keyed by name)."""
+    return OrderedDict((k, _draw(prefix + k, shp, seed, scheme)) for k, shp in shapes.items())
+
+
+def synth_swin_weights(cfg: SwinCfg = SWIN_T_GRPB, seed: int = 0, scheme: str = "stress"):
+    return synth_params(swin_param_shapes(cfg), seed, scheme)
+
+
+def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
+    return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
+
+
+def synth_simple_head_weights(in_channels=9472, hidden=128, seed: int = 0, scheme: str = "stress"):
+    return synth_params(simple_head_param_shapes(in_channels, hidden), seed, scheme, prefix="shead.")
+
+
+# ---------------------------------------------------------------------------------------
+# inputs
+# ---------------------------------------------------------------------------------------
+KVQ_MEAN = (123.675, 116.28, 103.53)      # reference fusion_datasets.py:953
+KVQ_STD = (58.395, 57.12, 57.375)         # reference fusion_datasets.py:954
+
+
+def synth_clip(seed: int, T=32, H=224, W=224, batch=1) -> np.ndarray:
+    """(batch,3,T,H,W) fp32 clip: i.i.d. uint8 pixels, normalised like the dataset
+    (reference ``fusion_datasets.py:1017-1020``)."""
+    g = _gen(seed, "clip")
+    px = g.integers(0, 256, size=(batch, 3, T, H, W), dtype=np.uint8).astype(np.float32)
+    mean = np.asarray(KVQ_MEAN, np.float32).reshape(1, 3, 1, 1, 1)
+    std = np.asarray(KVQ_STD, np.float32).reshape(1, 3, 1, 1, 1)
+    return (px - mean) / std
+
+
+def synth_video_u8(seed: int, T=256, H=540, W=960) -> np.ndarray:
+    """(3,T,H,W) uint8 post-decode frame stack (SURVEY.md §8d synthetic unit of work)."""
+    g = _gen(seed, "video")
+    return g.integers(0, 256, size=(3, T, H, W), dtype=np.uint8)
+
+
+def synth_fragment_offsets(seed: int, T: int, H: int, W: int, fragments_h=7, fragments_w=7,
+                           fsize_h=32, fsize_w=32, aligned=8):
+    """Offsets rnd_h, rnd_w of shape (Fh, Fw, T//aligned) with the reference's ranges
+    (``fusion_datasets.py:86-98``: U{0..hlength-fsize-1}, zeros when the cell is not larger
+    than the patch)."""
+    g = _gen(seed, "offsets")
+    nt = T // aligned
+    hl, wl = H // fragments_h, W // fragments_w
+    shape = (fragments_h, fragments_w, nt)
+    rh = g.integers(0, hl - fsize_h, size=shape, dtype=np.int64) if hl > fsize_h else np.zeros(shape, np.int64)
+    rw = g.integers(0, wl - fsize_w, size=shape, dtype=np.int64) if wl > fsize_w else np.zeros(shape, np.int64)
+    return rh.astype(np.int32), rw.astype(np.int32)

@@ -1,0 +1,122 @@
+"""ORACLE (test infrastructure): numpy restatement of the reference samplers and harness math.
+
+Reference lines restated (``/root/reference``):
+  datasets/fusion_datasets.py:22-121   get_spatial_fragments (grid-mini-patch sampler)
+  datasets/fusion_datasets.py:612-660  UnifiedFrameSampler
+  datasets/fusion_datasets.py:1017-1020 (v - mean) / std
+  trainer.py:192-201                   clip reshape (b,c,T,h,w) -> (b*nclips,c,T/nclips,h,w)
+  trainer.py:356-361                   rescale
+
+The reference draws its offsets from global RNG state inside the functions
+(``torch.randint`` :87-98, ``np.random.randint`` :632-635).  Parity needs the *same
+drawn offsets* (SURVEY.md §0 trap 6), so every function here takes the drawn offsets
+as explicit inputs; ``draw_*`` replays the reference's RNG calls for a seeded state.
+
+Pinned by ``tests/golden/make_golden.py`` against the imported reference.
+Only tests, smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def fragment_grid(res: int, fragments: int, fsize: int) -> np.ndarray:
+    """Cell origins min(res//F * i, res - fsize)  (fusion_datasets.py:64-69)."""
+    return np.asarray([min(res // fragments * i, res - fsize) for i in range(fragments)], np.int64)
+
+
+def draw_fragment_offsets(T: int, H: int, W: int, fragments_h=7, fragments_w=7, fsize_h=32, fsize_w=32,
+                          aligned=32, generator=None):
+    """Replays the reference's two ``torch.randint`` calls (non-'random' branch, :86-98)."""
+    import torch
+    nt = T // aligned
+    hl, wl = H // fragments_h, W // fragments_w
+    kw = {} if generator is None else {"generator": generator}
+    if hl > fsize_h:
+        rh = torch.randint(hl - fsize_h, (fragments_h, fragments_w, nt), **kw)
+    else:
+        rh = torch.zeros((fragments_h, fragments_w, nt)).int()
+    if wl > fsize_w:
+        rw = torch.randint(wl - fsize_w, (fragments_h, fragments_w, nt), **kw)
+    else:
+        rw = torch.zeros((fragments_h, fragments_w, nt)).int()
+    return rh.numpy().astype(np.int32), rw.numpy().astype(np.int32)
+
+
+def spatial_fragments(video: np.ndarray, rnd_h: np.ndarray, rnd_w: np.ndarray, fragments_h=7,
+                      fragments_w=7, fsize_h=32, fsize_w=32, aligned=32) -> np.ndarray:
+    """video (C,T,H,W) -> (C,T,Fh*fs,Fw*fs); patch (i,j) of t-block t is copied from
+    origin (hgrid[i]+rnd_h[i,j,t], wgrid[j]+rnd_w[i,j,t]).  The bilinear-upsample fallback
+    for inputs smaller than the canvas (:43-50) is not restated (inputs must be >= canvas)."""
+    C, T, H, W = video.shape
+    if T == 1:
+        aligned = 1
+    if min(H / (fragments_h * fsize_h), W / (fragments_w * fsize_w)) < 1:
+        raise NotImplementedError("upsample fallback (fusion_datasets.py:43-50) is out of the hot path")
+    assert T % aligned == 0, "Please provide match vclip and align index"
+    hg, wg = fragment_grid(H, fragments_h, fsize_h), fragment_grid(W, fragments_w, fsize_w)
+    out = np.zeros((C, T, fragments_h * fsize_h, fragments_w * fsize_w), video.dtype)
+    for i in range(fragments_h):
+        for j in range(fragments_w):
+            for t in range(T // aligned):
+                ho, wo = int(hg[i] + rnd_h[i, j, t]), int(wg[j] + rnd_w[i, j, t])
+                out[:, t * aligned:(t + 1) * aligned, i * fsize_h:(i + 1) * fsize_h,
+                    j * fsize_w:(j + 1) * fsize_w] = video[:, t * aligned:(t + 1) * aligned,
+                                                           ho:ho + fsize_h, wo:wo + fsize_w]
+    return out
+
+
+def normalize(video: np.ndarray, mean, std) -> np.ndarray:
+    """(C,T,H,W) float: (v - mean_c) / std_c, fp32 (fusion_datasets.py:1017-1020)."""
+    m = np.asarray(mean, np.float32).reshape(-1, 1, 1, 1)
+    s = np.asarray(std, np.float32).reshape(-1, 1, 1, 1)
+    return (video.astype(np.float32) - m) / s
+
+
+def draw_frame_offsets(num_frames: int, fsize_t: int, fragments_t: int, frame_interval: int,
+                       num_clips: int, rng=np.random):
+    """Replays ``np.random.randint(0, tlength - fsize_t*interval, size=fragments_t)`` per clip."""
+    tlength = num_frames // fragments_t
+    out = []
+    for _ in range(num_clips):
+        if tlength > fsize_t * frame_interval:
+            out.append(rng.randint(0, tlength - fsize_t * frame_interval, size=fragments_t))
+        else:
+            out.append(np.zeros(fragments_t, dtype=np.int32))
+    return np.stack(out)
+
+
+def frame_indices(num_frames: int, fsize_t: int, fragments_t: int, frame_interval: int,
+                  rnd_t: np.ndarray, start_index: int = 0) -> np.ndarray:
+    """rnd_t (num_clips, fragments_t) -> int32 indices (num_clips*fragments_t*fsize_t,)
+    = (arange(fsize_t)*interval + rnd + tgrid) mod num_frames  (drop_rate = 0)."""
+    tgrid = np.asarray([num_frames // fragments_t * i for i in range(fragments_t)], np.int64)
+    clips = []
+    for r in np.asarray(rnd_t).reshape(-1, fragments_t):
+        clips.append((np.arange(fsize_t)[None, :] * frame_interval + r[:, None] + tgrid[:, None]).reshape(-1))
+    return np.mod(np.concatenate(clips) + start_index, num_frames).astype(np.int32)
+
+
+def split_clips(x: np.ndarray, num_clips: int) -> np.ndarray:
+    """(b,c,T,h,w) -> (b*num_clips, c, T/num_clips, h, w)  (trainer.py:192-201)."""
+    b, c, T, h, w = x.shape
+    return (x.reshape(b, c, num_clips, T // num_clips, h, w).transpose(0, 2, 1, 3, 4, 5)
+            .reshape(b * num_clips, c, T // num_clips, h, w))
+
+
+def rescale(pr, gt=None) -> np.ndarray:
+    pr = np.asarray(pr, np.float64)
+    z = (pr - pr.mean()) / pr.std()
+    if gt is None:
+        return z
+    gt = np.asarray(gt, np.float64)
+    return z * gt.std() + gt.mean()
+
+
+def quality_metrics(preds, labels):
+    """SRCC, PLCC, KRCC, RMSE exactly as trainer.py:287-292 computes them."""
+    from scipy.stats import kendalltau, pearsonr, spearmanr
+    labels = np.asarray(labels, np.float64)
+    p = rescale(preds, labels)
+    return (float(spearmanr(labels, p)[0]), float(pearsonr(labels, p)[0]),
+            float(kendalltau(labels, p)[0]), float(np.sqrt(((labels - p) ** 2).mean())))

@@ -1,0 +1,256 @@
+"""Pin the oracle to the real reference and emit the committed golden fixtures.
+
+Runs ONLY in the build container (needs /root/reference).  For every case it
+  1. runs the imported reference module,
+  2. runs the oracle restatement on the same seeded inputs and asserts agreement
+     (bit-exact for index/integer work, <= 2e-5 abs for fp32),
+  3. stores the *reference's* outputs (or hashes / strided samples of them) in
+     ``tests/golden/*.npz`` — data only, no reference source.
+
+Inputs and weights are never stored: they are re-drawn from ``kvq_amd.utils.synth``
+PCG64 streams, which are platform-stable.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
+"""
+import hashlib
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+
+import kvq_amd  # noqa: F401  (import shim)
+from kvq_amd.utils import synth
+from oracle import sampler_oracle as SO
+from oracle import swin3d_oracle as O
+from _ref_import import import_reference
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def samples(t, n=2048):
+    """Strided subset + checksums of a tensor: small, but sensitive to any local error."""
+    a = np.asarray(t, np.float32).reshape(-1)
+    idx = np.unique(np.linspace(0, a.size - 1, min(n, a.size)).astype(np.int64))
+    return dict(idx=idx, val=a[idx], sum=np.float64(a.astype(np.float64).sum()),
+                asum=np.float64(np.abs(a.astype(np.float64)).sum()), shape=np.asarray(t.shape))
+
+
+def put(d, prefix, s):
+    for k, v in s.items():
+        d[f"{prefix}/{k}"] = v
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def sec_layout(ref):
+    """rel-pos index, fragment gate and shift mask: integer work, bit-exact."""
+    d = {}
+    attn = ref.swin.WindowAttention3D(96, (8, 7, 7), 3, qkv_bias=True, frag_bias=True)
+    rpi = attn.relative_position_index.numpy()
+    assert np.array_equal(rpi, O.rel_pos_index((8, 7, 7)))
+    d["rpi_877"] = rpi.astype(np.int16)
+    attn4 = ref.swin.WindowAttention3D(96, (4, 4, 4), 3, qkv_bias=True)
+    assert np.array_equal(attn4.relative_position_index.numpy(), O.rel_pos_index((4, 4, 4)))
+    d["rpi_444"] = attn4.relative_position_index.numpy().astype(np.int16)
+    cases = []
+    # (D,H,W) token grids: the four Swin-T stages at 32x224x224, T=96 stage 1, config-5 grids
+    # (64x256x256 -> 32,64,64 / 32,32,32 / 32,16,16 / 32,8,8), clamp / odd cases
+    for dims in [(16, 56, 56), (16, 28, 28), (16, 14, 14), (16, 7, 7), (48, 28, 28), (32, 64, 64),
+                 (32, 32, 32), (32, 16, 16), (32, 8, 8), (4, 20, 20), (4, 10, 10), (4, 5, 5),
+                 (4, 3, 3), (8, 16, 16), (10, 9, 23)]:
+        for window in [(8, 7, 7), (4, 4, 4)]:
+            for shifted in (False, True):
+                shift = tuple(w // 2 for w in window) if shifted else (0, 0, 0)
+                lay = O.window_layout(*dims, window, shift)
+                ws, ss = ref.swin.get_window_size(dims, window, shift)
+                assert (ws, ss) == (lay["ws"], lay["ss"])
+                Dp, Hp, Wp = lay["Dp"], lay["Hp"], lay["Wp"]
+                gpi = ref.swin.global_position_index(Dp, Hp, Wp, fragments=(1,) + ws[1:],
+                                                     window_size=ws, shift_size=ss, device="cpu")
+                g_ref = gpi.abs().sum(-1).numpy()
+                g = O.frag_gate(lay)
+                assert np.array_equal(g_ref, g), (dims, window, shift)
+                tag = "%d_%d_%d__%d%d%d__%d" % (dims + window + (int(shifted),))
+                d[f"gate/{tag}/sha"] = np.frombuffer(bytes.fromhex(sha(g_ref.astype(np.int8))), np.uint8)
+                d[f"gate/{tag}/max"] = np.int64(g_ref.max())
+                m = O.shift_mask(lay)
+                if any(s > 0 for s in ss):
+                    m_ref = ref.swin.compute_mask(Dp, Hp, Wp, ws, ss, "cpu").numpy()
+                    assert np.array_equal(m_ref, m), (dims, window, shift)
+                    d[f"mask/{tag}/sha"] = np.frombuffer(bytes.fromhex(sha((m_ref != 0).astype(np.int8))), np.uint8)
+                else:
+                    assert m is None
+                # window gather map == pad + roll + window_partition of an index tensor
+                D, H, W = dims
+                idx = torch.arange(D * H * W, dtype=torch.float32).reshape(1, D, H, W, 1) + 1
+                idx = torch.nn.functional.pad(idx, (0, 0, 0, Wp - W, 0, Hp - H, 0, Dp - D))
+                if any(s > 0 for s in ss):
+                    idx = torch.roll(idx, shifts=tuple(-s for s in ss), dims=(1, 2, 3))
+                src_ref = ref.swin.window_partition(idx, ws).reshape(-1).long().numpy() - 1
+                assert np.array_equal(src_ref, lay["src"]), (dims, window, shift)
+                d[f"src/{tag}/sha"] = np.frombuffer(bytes.fromhex(sha(src_ref.astype(np.int32))), np.uint8)
+                cases.append(tag)
+    d["cases"] = np.asarray(cases)
+    save("layout.npz", d)
+
+
+TRUNK_CASES = [
+    # name, cfg name, scheme, wseed, clip seed, B, T, H, W
+    ("t_grpb_stress_8x80", "SWIN_T_GRPB", "stress", 0, 11, 2, 8, 80, 80),
+    ("t_grpb_stress_16x64", "SWIN_T_GRPB", "stress", 0, 12, 1, 16, 64, 64),
+    ("t_plain_stress_16x96", "SWIN_T_PLAIN", "stress", 1, 13, 1, 16, 96, 96),
+    ("t_grpb_stress_10x50x70", "SWIN_T_GRPB", "stress", 2, 14, 1, 10, 50, 70),
+    ("t_grpb_stress_32x224", "SWIN_T_GRPB", "stress", 0, 15, 1, 32, 224, 224),
+    ("t_grpb_init_32x224", "SWIN_T_GRPB", "init", 3, 16, 1, 32, 224, 224),
+]
+
+
+def _ref_trunk(ref, cfg):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.swin.SwinTransformer3D(pretrained=None, use_checkpoint=False, embed_dim=cfg.embed_dim,
+                                       depths=list(cfg.depths), num_heads=list(cfg.num_heads),
+                                       window_size=cfg.window, frag_biases=list(cfg.frag_biases))
+    m.eval()
+    return m
+
+
+def sec_trunk(ref):
+    d = {}
+    names = []
+    for name, cfgn, scheme, wseed, cseed, B, T, H, W in TRUNK_CASES:
+        cfg = getattr(synth, cfgn)
+        wts = synth.synth_swin_weights(cfg, wseed, scheme)
+        hw = synth.synth_vqa_head_weights(cfg.num_features, 64, wseed, scheme)
+        m = _ref_trunk(ref, cfg)
+        missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=False)
+        assert not missing.unexpected_keys and all("relative_position_index" in k for k in missing.missing_keys)
+        head = ref.head.VQAHead(in_channels=cfg.num_features, hidden_channels=64).eval()
+        head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()})
+        x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B))
+        with torch.no_grad():
+            feat_ref = m({"technical": x})
+            score_ref = head(feat_ref)
+            feat, stages = O.swin3d_trunk(x, wts, cfg, return_stages=True)
+            score = O.vqa_head(feat, hw)
+        err = float((feat - feat_ref).abs().max())
+        serr = float((score - score_ref).abs().max())
+        print(f"{name}: feat {tuple(feat_ref.shape)} |oracle-ref| {err:.2e}  score {score_ref.flatten().tolist()} d {serr:.2e}")
+        assert err <= 2e-5 and serr <= 1e-6
+        put(d, f"{name}/feat", samples(feat_ref.numpy()))
+        d[f"{name}/score"] = score_ref.numpy()
+        d[f"{name}/meta"] = np.asarray([wseed, cseed, B, T, H, W])
+        d[f"{name}/cfg"] = np.asarray(cfgn)
+        d[f"{name}/scheme"] = np.asarray(scheme)
+        names.append(name)
+    d["cases"] = np.asarray(names)
+    save("trunk.npz", d)
+
+
+def sec_heads(ref):
+    d = {}
+    g = np.random.Generator(np.random.PCG64(77))
+    feat = g.standard_normal((3, 768, 4, 7, 7)).astype(np.float32)
+    hw = synth.synth_vqa_head_weights(768, 64, 5, "stress")
+    head = ref.head.VQAHead(in_channels=768, hidden_channels=64).eval()
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()})
+    with torch.no_grad():
+        s_ref = head(torch.from_numpy(feat)).numpy()
+    assert np.abs(O.vqa_head(torch.from_numpy(feat), hw).numpy() - s_ref).max() < 1e-6
+    d["vqa/score"] = s_ref
+    f2 = g.standard_normal((2, 8, 9472)).astype(np.float32)
+    sw = synth.synth_simple_head_weights(9472, 128, 5, "stress")
+    sh = ref.head.simpleVQAHead(9472, 128).eval()
+    sh.load_state_dict({k: torch.from_numpy(v) for k, v in sw.items()})
+    with torch.no_grad():
+        s2 = sh(torch.from_numpy(f2)).numpy()
+    assert np.abs(O.simple_vqa_head(torch.from_numpy(f2), sw).numpy() - s2).max() < 1e-5
+    d["simple/score"] = s2
+    save("heads.npz", d)
+
+
+def sec_sampler(ref):
+    import random as pyrandom
+    d = {}
+    fd = ref.fd
+    # (a) fragment sampler, KSVQE-style 9x9 grid and the bench's 7x7 grid, aligned 8
+    for tag, (T, H, W, Fh, Fw, fs, al, seed) in {
+        "k9": (16, 400, 720, 9, 9, 32, 8, 101),
+        "b7": (32, 270, 480, 7, 7, 32, 8, 102),
+        "tight": (8, 224, 230, 7, 7, 32, 4, 103),     # cell == patch on H -> zero offsets branch
+    }.items():
+        g = np.random.Generator(np.random.PCG64(seed))
+        video = g.integers(0, 256, size=(3, T, H, W)).astype(np.float32)
+        torch.manual_seed(seed)
+        out_ref = fd.get_spatial_fragments(torch.from_numpy(video), Fh, Fw, fs, fs, aligned=al).numpy()
+        torch.manual_seed(seed)
+        rh, rw = SO.draw_fragment_offsets(T, H, W, Fh, Fw, fs, fs, al)
+        out = SO.spatial_fragments(video, rh, rw, Fh, Fw, fs, fs, al)
+        assert np.array_equal(out, out_ref), tag
+        d[f"frag/{tag}/meta"] = np.asarray([T, H, W, Fh, Fw, fs, al, seed])
+        d[f"frag/{tag}/rnd_h"], d[f"frag/{tag}/rnd_w"] = rh, rw
+        d[f"frag/{tag}/sha"] = np.frombuffer(bytes.fromhex(sha(out_ref.astype(np.uint8))), np.uint8)
+        norm_ref = ((torch.from_numpy(out_ref).permute(1, 2, 3, 0) - torch.FloatTensor(synth.KVQ_MEAN))
+                    / torch.FloatTensor(synth.KVQ_STD)).permute(3, 0, 1, 2).numpy()   # fusion_datasets.py:1017-1020
+        assert np.array_equal(SO.normalize(out, synth.KVQ_MEAN, synth.KVQ_STD), norm_ref)
+        put(d, f"frag/{tag}/norm", samples(norm_ref, 1024))
+    # (b) temporal sampler: KSVQE val call (32, 3, 4) x1 clip and SimpleVQA (1, 8, 10, 1)
+    for tag, (n, fs_t, ft, iv, nc, seed) in {"ksvqe": (300, 32, 3, 4, 1, 7), "simple": (300, 1, 8, 10, 1, 8),
+                                               "short": (90, 32, 3, 4, 1, 9), "clips3": (500, 32, 1, 2, 3, 10)}.items():
+        np.random.seed(seed)
+        pyrandom.seed(seed)
+        ref_idx = fd.UnifiedFrameSampler(fs_t, ft, iv, nc)(n)
+        np.random.seed(seed)
+        rnd = SO.draw_frame_offsets(n, fs_t, ft, iv, nc)
+        idx = SO.frame_indices(n, fs_t, ft, iv, rnd)
+        assert np.array_equal(idx, ref_idx) and idx.dtype == ref_idx.dtype, tag
+        d[f"frames/{tag}/meta"] = np.asarray([n, fs_t, ft, iv, nc, seed])
+        d[f"frames/{tag}/rnd"] = rnd
+        d[f"frames/{tag}/idx"] = ref_idx
+    # (c) harness math: rescale + SRCC/PLCC/KRCC/RMSE on a fixed 900-vector (trainer.py:287-292)
+    g = np.random.Generator(np.random.PCG64(900))
+    labels = g.uniform(1, 5, 900)
+    preds = 0.3 * labels + g.standard_normal(900) * 0.2 - 1.0
+    tr = ref.trainer
+    p = tr.Trainer.rescale(None, list(preds), list(labels))
+    s, pl, k = tr.spearmanr(labels, p)[0], tr.pearsonr(labels, p)[0], tr.kendallr(labels, p)[0]
+    r = np.sqrt(((labels - p) ** 2).mean())
+    mine = SO.quality_metrics(preds, labels)
+    assert np.allclose(mine, (s, pl, k, r), rtol=0, atol=1e-12)
+    d["metrics/srcc_plcc_krcc_rmse"] = np.asarray([s, pl, k, r])
+    d["metrics/rescaled_head"] = np.asarray(p[:8])
+    # clip reshape (trainer.py:192-201)
+    x = torch.arange(2 * 3 * 12 * 2 * 2, dtype=torch.float32).reshape(2, 3, 12, 2, 2)
+    b, c, t, h, w = x.shape
+    xr = x.reshape(b, c, 3, t // 3, h, w).permute(0, 2, 1, 3, 4, 5).reshape(b * 3, c, t // 3, h, w)
+    assert np.array_equal(SO.split_clips(x.numpy(), 3), xr.numpy())
+    save("sampler.npz", d)
+
+
+SECTIONS = {"layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+
+
+def main():
+    want = sys.argv[1:] or list(SECTIONS)
+    ref = import_reference()
+    torch.set_grad_enabled(False)
+    for s in want:
+        SECTIONS[s](ref)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""CPU: the oracle restatement reproduces the reference's outputs stored in tests/golden/
+(fixtures made by tests/golden/make_golden.py from the imported reference)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import kvq_amd  # noqa: F401
+from kvq_amd.utils import synth
+from oracle import sampler_oracle as SO
+from oracle import swin3d_oracle as O
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_rel_pos_index(golden):
+    g = golden("layout.npz")
+    assert np.array_equal(O.rel_pos_index((8, 7, 7)), g["rpi_877"].astype(np.int64))
+    assert np.array_equal(O.rel_pos_index((4, 4, 4)), g["rpi_444"].astype(np.int64))
+    # clamped window: the reference slices the full table [:N,:N]
+    assert np.array_equal(O.rel_pos_index((8, 7, 7), 100), g["rpi_877"].astype(np.int64)[:100, :100])
+
+
+def test_layout_gate_mask_src(golden):
+    g = golden("layout.npz")
+    for tag in g["cases"]:
+        dims, win, shifted = tag.split("__")
+        D, H, W = map(int, dims.split("_"))
+        window = tuple(int(c) for c in win)
+        shift = tuple(w // 2 for w in window) if shifted == "1" else (0, 0, 0)
+        lay = O.window_layout(D, H, W, window, shift)
+        gate = O.frag_gate(lay)
+        assert np.array_equal(_sha(gate.astype(np.int8)), g[f"gate/{tag}/sha"]), tag
+        assert gate.max() == g[f"gate/{tag}/max"]
+        m = O.shift_mask(lay)
+        if f"mask/{tag}/sha" in g:
+            assert np.array_equal(_sha((m != 0).astype(np.int8)), g[f"mask/{tag}/sha"]), tag
+            assert set(np.unique(m)) <= {0.0, -100.0}
+        else:
+            assert m is None
+        assert np.array_equal(_sha(lay["src"].astype(np.int32)), g[f"src/{tag}/sha"]), tag
+
+
+def _check_samples(g, prefix, arr, atol):
+    a = np.asarray(arr, np.float32)
+    assert tuple(g[f"{prefix}/shape"]) == a.shape
+    flat = a.reshape(-1)
+    assert np.abs(flat[g[f"{prefix}/idx"]] - g[f"{prefix}/val"]).max() <= atol
+    assert abs(flat.astype(np.float64).sum() - g[f"{prefix}/sum"]) <= atol * flat.size
+    assert abs(np.abs(flat.astype(np.float64)).sum() - g[f"{prefix}/asum"]) <= atol * flat.size
+
+
+@pytest.mark.parametrize("case", ["t_grpb_stress_8x80", "t_grpb_stress_16x64", "t_plain_stress_16x96",
+                                  "t_grpb_stress_10x50x70"])
+def test_trunk_small(golden, case):
+    g = golden("trunk.npz")
+    wseed, cseed, B, T, H, W = (int(v) for v in g[f"{case}/meta"])
+    cfg = getattr(synth, str(g[f"{case}/cfg"]))
+    scheme = str(g[f"{case}/scheme"])
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B))
+    feat = O.swin3d_trunk(x, synth.synth_swin_weights(cfg, wseed, scheme), cfg)
+    _check_samples(g, f"{case}/feat", feat.numpy(), 2e-5)
+    score = O.vqa_head(feat, synth.synth_vqa_head_weights(cfg.num_features, 64, wseed, scheme))
+    assert np.abs(score.numpy() - g[f"{case}/score"]).max() <= 1e-6
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", ["t_grpb_stress_32x224", "t_grpb_init_32x224"])
+def test_trunk_full_size(golden, case):
+    test_trunk_small(golden, case)
+
+
+def test_heads(golden):
+    g = golden("heads.npz")
+    rng = np.random.Generator(np.random.PCG64(77))
+    feat = rng.standard_normal((3, 768, 4, 7, 7)).astype(np.float32)
+    s = O.vqa_head(torch.from_numpy(feat), synth.synth_vqa_head_weights(768, 64, 5, "stress"))
+    assert np.abs(s.numpy() - g["vqa/score"]).max() < 1e-6
+    f2 = rng.standard_normal((2, 8, 9472)).astype(np.float32)
+    s2 = O.simple_vqa_head(torch.from_numpy(f2), synth.synth_simple_head_weights(9472, 128, 5, "stress"))
+    assert np.abs(s2.numpy() - g["simple/score"]).max() < 1e-5
+
+
+def test_fragment_sampler(golden):
+    g = golden("sampler.npz")
+    for tag in ("k9", "b7", "tight"):
+        T, H, W, Fh, Fw, fs, al, seed = (int(v) for v in g[f"frag/{tag}/meta"])
+        video = np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(3, T, H, W)).astype(np.float32)
+        out = SO.spatial_fragments(video, g[f"frag/{tag}/rnd_h"], g[f"frag/{tag}/rnd_w"], Fh, Fw, fs, fs, al)
+        assert np.array_equal(_sha(out.astype(np.uint8)), g[f"frag/{tag}/sha"])
+        _check_samples(g, f"frag/{tag}/norm", SO.normalize(out, synth.KVQ_MEAN, synth.KVQ_STD), 0.0)
+        # replaying the reference's RNG calls reproduces the stored offsets
+        torch.manual_seed(seed)
+        rh, rw = SO.draw_fragment_offsets(T, H, W, Fh, Fw, fs, fs, al)
+        assert np.array_equal(rh, g[f"frag/{tag}/rnd_h"]) and np.array_equal(rw, g[f"frag/{tag}/rnd_w"])
+
+
+def test_fragment_sampler_rejects_misaligned():
+    v = np.zeros((3, 10, 224, 224), np.float32)
+    with pytest.raises(AssertionError, match="Please provide match vclip and align index"):
+        SO.spatial_fragments(v, np.zeros((7, 7, 1), np.int32), np.zeros((7, 7, 1), np.int32), aligned=8)
+
+
+def test_frame_sampler(golden):
+    g = golden("sampler.npz")
+    for tag in ("ksvqe", "simple", "short", "clips3"):
+        n, fs_t, ft, iv, nc, seed = (int(v) for v in g[f"frames/{tag}/meta"])
+        idx = SO.frame_indices(n, fs_t, ft, iv, g[f"frames/{tag}/rnd"])
+        assert idx.dtype == np.int32 and np.array_equal(idx, g[f"frames/{tag}/idx"])
+        np.random.seed(seed)
+        assert np.array_equal(SO.draw_frame_offsets(n, fs_t, ft, iv, nc), g[f"frames/{tag}/rnd"])
+
+
+def test_metrics(golden):
+    g = golden("sampler.npz")
+    rng = np.random.Generator(np.random.PCG64(900))
+    labels = rng.uniform(1, 5, 900)
+    preds = 0.3 * labels + rng.standard_normal(900) * 0.2 - 1.0
+    assert np.allclose(SO.quality_metrics(preds, labels), g["metrics/srcc_plcc_krcc_rmse"], rtol=0, atol=1e-12)
+    assert np.allclose(SO.rescale(preds, labels)[:8], g["metrics/rescaled_head"], rtol=0, atol=1e-12)
+
+
+def test_flops_model():
+    # 175.53 GFLOP per 32x224x224 Swin-T clip; Swin-B 64x256x256 = 1892.3 GFLOP
+    assert abs(O.swin_flops(synth.SWIN_T_GRPB, 32, 224, 224) / 1e9 - 175.53) < 0.01
+    assert abs(O.swin_flops(synth.SWIN_B_GRPB, 64, 256, 256) / 1e9 - 1892.3) < 0.1
