@@ -1,0 +1,217 @@
+/*
+ * kvq_hip.h — C ABI of libkvq_hip.so: the MI355X (gfx950) hot path of the KVQ per-video
+ * forward (fragment sampler -> Swin-3D(GRPB) trunk -> VQAHead; SimpleVQA head).
+ *
+ * The reference is pure PyTorch: there is no native FFI to mirror, so each entry point
+ * cites the reference *Python* call it replaces (file:line under /root/reference).
+ * The binding a maintainer adds on the reference side is a ctypes stub — INTEGRATION.md.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless marked "host"; the caller (PyTorch) owns all
+ *     buffers, the library borrows them for the duration of a call and never frees them;
+ *   - scratch is caller-provided (kvq_swin3d_workspace_bytes), except the small integer index
+ *     maps a plan owns (allocated in kvq_swin3d_plan_create, freed in kvq_swin3d_plan_destroy);
+ *   - every launch goes to the hipStream_t passed in (void* here so the header needs no HIP
+ *     include); calls are asynchronous, never synchronise the device, and are graph-capturable;
+ *   - return value: 0 = ok, <0 = KvqStatus; kvq_last_error() gives the message (thread-local);
+ *   - bf16 = raw uint16_t bit patterns (round-to-nearest-even of fp32).
+ *   - no exceptions / abort() cross this boundary.
+ */
+#ifndef KVQ_HIP_H
+#define KVQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVQ_ABI_VERSION 1
+#define KVQ_MAX_STAGES 4
+
+typedef enum {
+  KVQ_OK = 0,
+  KVQ_ERR_NULL = -1,        /* required pointer is NULL                    */
+  KVQ_ERR_SHAPE = -2,       /* unsupported / inconsistent shape            */
+  KVQ_ERR_UNSUPPORTED = -3, /* configuration outside what the kernels cover */
+  KVQ_ERR_WORKSPACE = -4,   /* workspace too small                         */
+  KVQ_ERR_HIP = -5          /* a HIP runtime call failed                   */
+} KvqStatus;
+
+int kvq_abi_version(void);
+const char* kvq_last_error(void);
+/* Name of the device the library sees ("" if none); fills at most n bytes. */
+int kvq_device_name(char* host_buf, int n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Trunk configuration = constructor kwargs of SwinTransformer3D
+ * (models/backbones/swin_backbone.py:760-783).  head_dim must be 32 (it is for every
+ * reference configuration: embed_dim*2^i / num_heads[i] == 32).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t patch[3];                  /* (2,4,4) */
+  int32_t in_chans;                  /* 3 */
+  int32_t embed_dim;                 /* 96 (tiny/small), 128 (base) */
+  int32_t num_stages;                /* 4 */
+  int32_t depths[KVQ_MAX_STAGES];    /* 2,2,6,2 */
+  int32_t num_heads[KVQ_MAX_STAGES]; /* 3,6,12,24 */
+  int32_t window[3];                 /* (8,7,7) */
+  int32_t mlp_ratio;                 /* 4 */
+  int32_t frag_bias[KVQ_MAX_STAGES]; /* 1,1,1,0 for the GRPB trunk; 0,0,0,0 for swin_3d_tiny */
+} KvqSwinCfg;
+
+/* Weights of one SwinTransformerBlock3D (swin_backbone.py:385-405).  GEMM weights are bf16
+ * [out][in] exactly as nn.Linear stores them; everything else fp32. */
+typedef struct {
+  const float* norm1_w;    /* [C] */
+  const float* norm1_b;
+  const float* rpb_table;  /* relative_position_bias_table  [table_len][nH] */
+  const float* fpb_table;  /* fragment_position_bias_table  [table_len][nH] or NULL */
+  const uint16_t* qkv_w;   /* [3C][C], rows = [q | k | v], each head-major */
+  const float* qkv_b;      /* [3C] */
+  const uint16_t* proj_w;  /* [C][C] */
+  const float* proj_b;
+  const float* norm2_w;
+  const float* norm2_b;
+  const uint16_t* fc1_w;   /* [4C][C] */
+  const float* fc1_b;
+  const uint16_t* fc2_w;   /* [C][4C] */
+  const float* fc2_b;
+} KvqSwinBlockW;
+
+typedef struct {            /* PatchMerging (swin_backbone.py:527-531) */
+  const float* norm_w;      /* [4C] */
+  const float* norm_b;
+  const uint16_t* red_w;    /* [2C][4C], no bias */
+} KvqSwinMergeW;
+
+typedef struct {
+  const uint16_t* embed_w;  /* patch_embed.proj.weight as bf16 [E][in*pd*ph*pw] */
+  const float* embed_b;     /* [E] */
+  const float* embed_ln_w;  /* patch_embed.norm */
+  const float* embed_ln_b;
+  const KvqSwinBlockW* blocks; /* host array, sum(depths) entries, stage-major */
+  KvqSwinMergeW merges[KVQ_MAX_STAGES - 1];
+  const float* norm_w;      /* final LayerNorm [C_out] */
+  const float* norm_b;
+} KvqSwinWeights;
+
+/* Opaque plan: all shape-dependent integer index maps (window gather/scatter with shift,
+ * padding and crop; per-token fragment ids and shift-mask regions; patch-merge neighbours)
+ * for one (cfg, B, T, H, W).  Replaces the lru_cached tensors of compute_mask
+ * (swin_backbone.py:559-586) and global_position_index (:21-50). */
+typedef struct KvqSwinPlan KvqSwinPlan;
+
+int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H, int W, KvqSwinPlan** out);
+void kvq_swin3d_plan_destroy(KvqSwinPlan* plan);
+size_t kvq_swin3d_workspace_bytes(const KvqSwinPlan* plan);
+/* Output geometry: C_out, D, H', W' of the (B, C_out, D, H', W') feature map. */
+int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
+
+/* SwinTransformer3D.forward (swin_backbone.py:1044-1080), multi=False, layer=-1.
+ *   x     fp32 (B,3,T,H,W) contiguous                      — batch['technical']
+ *   feat  fp32 channels-LAST (B, D, H', W', C_out); the host wrapper returns the
+ *         (B,C_out,D,H',W') permuted view, which is what the reference returns.
+ * When score != NULL the VQAHead (models/head.py:60-68) is applied too (see kvq_vqa_head). */
+int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, float* feat,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-kernel-class GPU time of the most recent profiled forward.  Profiling brackets every
+ * launch with hipEvents on the launch stream; enable with kvq_swin3d_profile(plan, 1). */
+enum {
+  KVQ_K_IM2COL = 0, KVQ_K_LAYERNORM, KVQ_K_GEMM_QKV, KVQ_K_ATTN, KVQ_K_GEMM_PROJ, KVQ_K_GEMM_FC1,
+  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_COUNT
+};
+int kvq_swin3d_profile(KvqSwinPlan* plan, int enable);
+/* Synchronises the recorded events (host blocks), fills ms[KVQ_K_COUNT] and launches[KVQ_K_COUNT]. */
+int kvq_swin3d_profile_read(KvqSwinPlan* plan, float* host_ms, int32_t* host_launches);
+
+/* ---------------------------------------------------------------------------------------------
+ * Individual kernels (exported for the parity tests; kvq_swin3d_forward is built from them).
+ * ------------------------------------------------------------------------------------------- */
+
+/* LayerNorm over gathered rows: nn.LayerNorm + F.pad + torch.roll + window_partition
+ * (swin_backbone.py:416-449), norm2 (:491), PatchMerging's 4-neighbour concat + norm (:546-552)
+ * and the final norm (:1066-1068).
+ *   x        fp32 [n_batch * rows_in][Cin]
+ *   map      int32 [rows_out][nparts] source row within a batch element, -1 = zero; NULL = identity
+ *   out row r of batch b = LN(concat_p x[b*rows_in + map[r][p]]) over nparts*Cin channels.
+ *   nparts==1 and map<0  -> the whole output row is 0 (pad AFTER the norm, :424);
+ *   nparts>1  and map<0  -> that part is 0 and takes part in the statistics (pad BEFORE, :544).
+ *   out_bf16 / out_f32: exactly one is non-NULL. */
+int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts, int n_batch, int rows_in,
+                       int rows_out, int Cin, const float* gamma, const float* beta, float eps,
+                       uint16_t* out_bf16, float* out_f32, void* stream);
+
+/* bf16 MFMA GEMM  acc[m][n] = sum_k A[m][k] * W[n][k]  (fp32 accumulate) with a fused epilogue. */
+typedef enum {
+  KVQ_EPI_BIAS_BF16 = 0,   /* out_bf16[m][n] = acc + bias                      (generic Linear)      */
+  KVQ_EPI_GELU_BF16 = 1,   /* out_bf16[m][n] = gelu_erf(acc + bias)            (Mlp.fc1+act, :84-85) */
+  KVQ_EPI_QKV_BF16 = 2,    /* head-major split: out[(which*nH+h)*M + m][e], q scaled (:253-260)      */
+  KVQ_EPI_RESID_F32 = 3,   /* out_f32[row(m)][n] += acc + bias, row(m) via scatter map (:472-488,509,514) */
+  KVQ_EPI_STORE_F32 = 4    /* out_f32[m][n] = acc (+ bias if non-NULL)         (reduction :553, embed) */
+} KvqEpilogue;
+
+typedef struct {
+  const uint16_t* A;     /* bf16 [M][K] */
+  const uint16_t* W;     /* bf16 [N][K] */
+  const float* bias;     /* [N] or NULL */
+  int32_t M, N, K;       /* N % 32 == 0, K % 32 == 0 */
+  int32_t epilogue;      /* KvqEpilogue */
+  uint16_t* out_bf16;
+  float* out_f32;
+  /* KVQ_EPI_QKV_BF16 */
+  int32_t num_heads;     /* N == 3*32*num_heads */
+  float q_scale;         /* head_dim^-0.5 */
+  /* KVQ_EPI_RESID_F32: output row of GEMM row m = b*rows_out + map[m % rows_in_map]; <0 = drop */
+  const int32_t* scatter_map; /* NULL = identity */
+  int32_t map_rows;      /* rows per batch element in the map (windowed rows)  */
+  int32_t out_rows;      /* rows per batch element in the output               */
+} KvqGemmArgs;
+
+int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
+
+/* WindowAttention3D core (swin_backbone.py:261-322) for head_dim 32: S = q k^T + bias, where
+ * bias = rpb*g + fpb*(1-g) (gated, :299-302) or rpb, + shift mask (0/-100, :583), softmax, @v.
+ *   qkv      bf16 head-major [3][nH][BW*N][32] (q pre-scaled)   — output of KVQ_EPI_QKV_BF16
+ *   tok      int32 [nW*N][2]: {bias code c = d*(2Wh-1)(2Ww-1)+h*(2Ww-1)+w of the token's
+ *            coordinate in the configured window raster, desc = fh | fw<<8 | region<<16}
+ *   rpb/fpb  fp32 [table_len][nH]; fpb NULL = no fragment gate
+ *   center   (Wd-1)*(2Wh-1)*(2Ww-1) + (Wh-1)*(2Ww-1) + (Ww-1)
+ *   out      bf16 [BW*N][nH*32]  (== (attn@v).transpose(1,2).reshape(B_,N,C), :322)        */
+int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* rpb, const float* fpb,
+                         int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
+                         uint16_t* out, void* stream);
+
+/* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
+ * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */
+int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd, int ph, int pw,
+                     uint16_t* out, void* stream);
+
+/* VQAHead.forward in eval mode (models/head.py:60-68): fp32 throughout.
+ *   feat  fp32 with explicit element strides (so both (B,C,D,H,W) and channels-last work)
+ *   score fp32 [B] = mean_tokens( w2 . gelu(W1 f + b1) + b2 ).  scratch: fp32 [B*L]. */
+int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l,
+                 int64_t stride_c, const float* w1, const float* b1, int hidden, const float* w2,
+                 const float* b2, float* scratch, float* score, void* stream);
+
+/* simpleVQAHead.forward (models/head.py:28-31): Linear(Cin->hidden) -> Linear(hidden->1), mean over
+ * frames.  feat fp32 [B][T][Cin]; score fp32 [B]; scratch fp32 [B*T]. */
+int kvq_simple_vqa_head(const float* feat, int B, int T, int Cin, const float* w1, const float* b1,
+                        int hidden, const float* w2, const float* b2, float* scratch, float* score,
+                        void* stream);
+
+/* get_spatial_fragments + (v-mean)/std (datasets/fusion_datasets.py:22-121, 1017-1020) with the
+ * drawn offsets as inputs (the reference draws them inside with torch.randint, :87-98).
+ *   video  uint8 or fp32 (C,T,H,W) on device (src_is_u8 selects)
+ *   hoff/woff int32 [Fh][Fw][T/aligned] absolute patch origins = grid + random offset
+ *   out    fp32 (C,T,Fh*fs_h,Fw*fs_w);  mean/std: host fp32 [C] (std==NULL -> no normalisation) */
+int kvq_fragment_gather(const void* video, int src_is_u8, int C, int T, int H, int W, const int32_t* hoff,
+                        const int32_t* woff, int Fh, int Fw, int fs_h, int fs_w, int aligned,
+                        const float* host_mean, const float* host_std, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVQ_HIP_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of include/kvq_hip.h (libkvq_hip.so).
+
+There is NO fallback: if the library is missing and cannot be built, or a call
+fails, this raises.  The product path never routes through PyTorch eager or the
+CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import _build
+
+MAX_STAGES = 4
+K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "gemm_fc2", "gemm_merge",
+           "gemm_embed"]
+K_COUNT = len(K_NAMES)
+
+EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32 = range(5)
+
+p_void = C.c_void_p
+
+
+class KvqSwinCfg(C.Structure):
+    _fields_ = [("patch", C.c_int32 * 3), ("in_chans", C.c_int32), ("embed_dim", C.c_int32),
+                ("num_stages", C.c_int32), ("depths", C.c_int32 * MAX_STAGES),
+                ("num_heads", C.c_int32 * MAX_STAGES), ("window", C.c_int32 * 3), ("mlp_ratio", C.c_int32),
+                ("frag_bias", C.c_int32 * MAX_STAGES)]
+
+
+class KvqSwinBlockW(C.Structure):
+    _fields_ = [(n, p_void) for n in ("norm1_w", "norm1_b", "rpb_table", "fpb_table", "qkv_w", "qkv_b", "proj_w",
+                                      "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class KvqSwinMergeW(C.Structure):
+    _fields_ = [(n, p_void) for n in ("norm_w", "norm_b", "red_w")]
+
+
+class KvqSwinWeights(C.Structure):
+    _fields_ = [("embed_w", p_void), ("embed_b", p_void), ("embed_ln_w", p_void), ("embed_ln_b", p_void),
+                ("blocks", C.POINTER(KvqSwinBlockW)), ("merges", KvqSwinMergeW * (MAX_STAGES - 1)),
+                ("norm_w", p_void), ("norm_b", p_void)]
+
+
+class KvqGemmArgs(C.Structure):
+    _fields_ = [("A", p_void), ("W", p_void), ("bias", p_void), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
+                ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
+                ("map_rows", C.c_int32), ("out_rows", C.c_int32)]
+
+
+# every symbol include/kvq_hip.h declares: name -> (restype, argtypes)
+i32, i64, f32, sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SYMBOLS = {
+    "kvq_abi_version": (i32, []),
+    "kvq_last_error": (C.c_char_p, []),
+    "kvq_device_name": (i32, [C.c_char_p, i32]),
+    "kvq_swin3d_plan_create": (i32, [C.POINTER(KvqSwinCfg), i32, i32, i32, i32, C.POINTER(p_void)]),
+    "kvq_swin3d_plan_destroy": (None, [p_void]),
+    "kvq_swin3d_workspace_bytes": (sz, [p_void]),
+    "kvq_swin3d_out_dims": (i32, [p_void, C.POINTER(i32 * 4)]),
+    "kvq_swin3d_forward": (i32, [p_void, C.POINTER(KvqSwinWeights), p_void, p_void, p_void, sz, p_void]),
+    "kvq_swin3d_profile": (i32, [p_void, i32]),
+    "kvq_swin3d_profile_read": (i32, [p_void, C.POINTER(f32 * K_COUNT), C.POINTER(i32 * K_COUNT)]),
+    "kvq_layernorm_rows": (i32, [p_void, p_void, i32, i32, i32, i32, i32, p_void, p_void, f32, p_void, p_void,
+                                 p_void]),
+    "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
+    "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, p_void,
+                                   p_void]),
+    "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
+    "kvq_vqa_head": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, i32, p_void, p_void, p_void,
+                           p_void, p_void]),
+    "kvq_simple_vqa_head": (i32, [p_void, i32, i32, i32, p_void, p_void, i32, p_void, p_void, p_void, p_void,
+                                  p_void]),
+    "kvq_fragment_gather": (i32, [p_void, i32, i32, i32, i32, i32, p_void, p_void, i32, i32, i32, i32, i32,
+                                  C.POINTER(f32), C.POINTER(f32), p_void, p_void]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class KvqError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (building first if missing/stale) libkvq_hip.so.  Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.is_stale():
+        try:
+            path = _build.build()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(_build.LIB):
+                raise KvqError(f"libkvq_hip.so is missing and could not be built: {e}") from e
+            path = _build.LIB   # stale but present (e.g. no hipcc on this box): use it
+    handle = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(handle, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if handle.kvq_abi_version() != 1:
+        raise KvqError("libkvq_hip.so ABI version mismatch")
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().kvq_last_error().decode("utf-8", "replace")
+        # the reference raises AssertionError for this one (fusion_datasets.py:60)
+        if "Please provide match vclip and align index" in msg:
+            raise AssertionError(msg)
+        raise KvqError(f"{what} failed (status {rc}): {msg}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,74 @@
+"""Build libkvq_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot; nothing is
+JIT-compiled at import time on the GPU box unless the library is missing or stale.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libkvq_hip.so")
+HEADER = os.path.join(os.path.dirname(PKG), "include", "kvq_hip.h")
+SOURCES = ["common.cpp", "gemm.hip", "ln.hip", "attn.hip", "misc.hip", "plan.hip", "conv.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libkvq_hip.so)")
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [HEADER, os.path.join(CSRC, "common.hpp")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    cc = _hipcc()
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        hdrs = [HEADER, os.path.join(CSRC, "common.hpp")]
+        if (not force and os.path.exists(obj)
+                and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
+            return obj
+        cmd = [cc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr[-2000:])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(sources()))) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

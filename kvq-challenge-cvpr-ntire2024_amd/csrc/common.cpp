@@ -1,0 +1,34 @@
+// Host-side error plumbing + misc C-ABI entry points.
+#include "common.hpp"
+
+#include <string.h>
+
+namespace kvq {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return KVQ_ERR_HIP;
+}
+}  // namespace kvq
+
+extern "C" int kvq_abi_version(void) { return KVQ_ABI_VERSION; }
+extern "C" const char* kvq_last_error(void) { return kvq::g_err; }
+
+extern "C" int kvq_device_name(char* buf, int n) {
+  if (!buf || n <= 0) return KVQ_ERR_NULL;
+  buf[0] = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return KVQ_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return KVQ_ERR_HIP;
+  snprintf(buf, n, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return KVQ_OK;
+}

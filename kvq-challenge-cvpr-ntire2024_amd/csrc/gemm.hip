@@ -1,0 +1,233 @@
+// bf16 MFMA GEMM with fused epilogues for the Swin-3D trunk (gfx950).
+//
+//   acc[m][n] = sum_k A[m][k] * W[n][k]      A bf16 [M][K], W bf16 [N][K] (nn.Linear layout), fp32 acc
+//
+// Replaces the reference's nn.Linear calls on the hot path (swin_backbone.py:254 qkv, :323 proj,
+// :84-87 fc1/fc2, :553 reduction, :726 patch-embed conv as an im2col GEMM) together with what
+// surrounds them: bias, exact GELU, the q scale + head split (:255-260), window_reverse + inverse
+// roll + crop + residual add (:472-488, :509, :514).
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid; block tile (64*MI) x (64*NI), wave tile
+// (32*MI) x (32*NI) built from v_mfma_f32_32x32x16_bf16; K staged through LDS in BK slices,
+// register-prefetched (global loads of slice t+1 are in flight while slice t is multiplied),
+// double-buffered so there is one barrier per slice.  LDS rows are padded by 16 B: with a pitch of
+// BK+8 bf16 the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots (pitch/16 B is
+// odd), i.e. the fragment reads are bank-conflict free.
+#include "common.hpp"
+
+namespace kvq {
+
+struct GemmParams {
+  const uint16_t* A;
+  const uint16_t* W;
+  const float* bias;
+  int M, N, K;
+  uint16_t* out_bf16;
+  float* out_f32;
+  int num_heads;
+  float q_scale;
+  const int32_t* scatter_map;
+  int map_rows, out_rows;
+};
+
+template <int MI, int NI, int BK, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr int PITCH = BK + 8;            // bf16 elements
+  constexpr int CPR = BK / 8;              // 16-B chunks per row
+  constexpr int A_CHUNKS = BM * CPR / 256; // per thread
+  constexpr int B_CHUNKS = BN * CPR / 256;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // 2 * (BM + BN) * PITCH bf16
+  uint16_t* As = lds;
+  uint16_t* Bs = lds + 2 * BM * PITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // blockIdx.x walks N fastest so that blocks sharing an A row-panel are adjacent in dispatch order.
+  const int nbn = (p.N + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const uint16_t* a_src[A_CHUNKS];
+  int a_dst[A_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < A_CHUNKS; ++i) {
+    int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
+    int gm = min(m0 + row, p.M - 1);
+    a_src[i] = p.A + (size_t)gm * p.K + kc * 8;
+    a_dst[i] = row * PITCH + kc * 8;
+  }
+  const uint16_t* b_src[B_CHUNKS];
+  int b_dst[B_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < B_CHUNKS; ++i) {
+    int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
+    int gn = min(n0 + row, p.N - 1);
+    b_src[i] = p.W + (size_t)gn * p.K + kc * 8;
+    b_dst[i] = row * PITCH + kc * 8;
+  }
+
+  u32x4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
+  auto load_slice = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = *reinterpret_cast<const u32x4*>(a_src[i] + k0);
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) b_reg[i] = *reinterpret_cast<const u32x4*>(b_src[i] + k0);
+  };
+  auto store_slice = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) *reinterpret_cast<u32x4*>(As + buf * BM * PITCH + a_dst[i]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) *reinterpret_cast<u32x4*>(Bs + buf * BN * PITCH + b_dst[i]) = b_reg[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // wave-uniform: which 32-column tiles of this wave exist at all (N % 32 == 0)
+  bool n_live[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) n_live[j] = (n0 + wn * 32 * NI + j * 32) < p.N;
+
+  const int nk = p.K / BK;
+  load_slice(0);
+  store_slice(0);
+  __syncthreads();
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_slice((kt + 1) * BK);
+    const uint16_t* as = As + buf * BM * PITCH + (wm * 32 * MI + frag_row) * PITCH + frag_k;
+    const uint16_t* bs = Bs + buf * BN * PITCH + (wn * 32 * NI + frag_row) * PITCH + frag_k;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * PITCH + kk * 16);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * PITCH + kk * 16);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          if (n_live[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_slice(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    if (!n_live[j]) continue;
+    const int n = n0 + wn * 32 * NI + j * 32 + col_in;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    // QKV: a 32-column tile is exactly one head of one of q/k/v
+    int C = 0, which = 0, head = 0;
+    float scale = 1.f;
+    if (EPI == KVQ_EPI_QKV_BF16) {
+      C = p.N / 3;
+      which = (n - col_in) / C;
+      head = ((n - col_in) % C) >> 5;
+      scale = which == 0 ? p.q_scale : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (EPI == KVQ_EPI_BIAS_BF16) {
+          p.out_bf16[(size_t)m * p.N + n] = f2bf(v);
+        } else if (EPI == KVQ_EPI_GELU_BF16) {
+          p.out_bf16[(size_t)m * p.N + n] = f2bf(gelu_erf(v));
+        } else if (EPI == KVQ_EPI_QKV_BF16) {
+          p.out_bf16[((size_t)(which * p.num_heads + head) * p.M + m) * 32 + col_in] = f2bf(v * scale);
+        } else if (EPI == KVQ_EPI_RESID_F32) {
+          long orow = m;
+          if (p.scatter_map) {
+            int b = m / p.map_rows, rr = m - b * p.map_rows;
+            int s = p.scatter_map[rr];
+            if (s < 0) continue;
+            orow = (long)b * p.out_rows + s;
+          }
+          float* o = p.out_f32 + (size_t)orow * p.N + n;
+          *o = *o + v;
+        } else {  // KVQ_EPI_STORE_F32
+          p.out_f32[(size_t)m * p.N + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MI, int NI, int BK, int EPI>
+static int launch_one(const GemmParams& p, hipStream_t st) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr size_t lds_bytes = 2 * (BM + BN) * (BK + 8) * sizeof(uint16_t);
+  auto kern = gemm_bf16_kernel<MI, NI, BK, EPI>;
+  static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
+  if (!attr_set && lds_bytes > 64 * 1024) {
+    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN)), block(256);
+  hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
+  KVQ_CHECK_LAUNCH("gemm_bf16_kernel");
+  return KVQ_OK;
+}
+
+template <int EPI>
+static int launch_gemm(const GemmParams& p, hipStream_t st) {
+  const long blocks128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+  const bool big = blocks128 >= 512;     // >= 2 tiles per CU: use the 128x128 tile
+  const bool k64 = (p.K % 64) == 0;
+  if (big) return k64 ? launch_one<2, 2, 64, EPI>(p, st) : launch_one<2, 2, 32, EPI>(p, st);
+  return k64 ? launch_one<1, 1, 64, EPI>(p, st) : launch_one<1, 1, 32, EPI>(p, st);
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(a && a->A && a->W, KVQ_ERR_NULL, "kvq_gemm_bf16: NULL A/W");
+  KVQ_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 32 == 0 && a->K % 32 == 0, KVQ_ERR_SHAPE,
+              "kvq_gemm_bf16: need M>0, N%%32==0, K%%32==0 (got M=%d N=%d K=%d)", a->M, a->N, a->K);
+  GemmParams p{a->A, a->W, a->bias, a->M, a->N, a->K, a->out_bf16, a->out_f32, a->num_heads, a->q_scale,
+               a->scatter_map, a->map_rows, a->out_rows};
+  hipStream_t st = (hipStream_t)stream;
+  switch (a->epilogue) {
+    case KVQ_EPI_BIAS_BF16:
+      KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
+      return launch_gemm<KVQ_EPI_BIAS_BF16>(p, st);
+    case KVQ_EPI_GELU_BF16:
+      KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
+      return launch_gemm<KVQ_EPI_GELU_BF16>(p, st);
+    case KVQ_EPI_QKV_BF16:
+      KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
+      KVQ_REQUIRE(a->num_heads > 0 && a->N == 96 * a->num_heads, KVQ_ERR_SHAPE,
+                  "kvq_gemm_bf16: QKV epilogue needs N == 3*32*num_heads (N=%d nH=%d)", a->N, a->num_heads);
+      return launch_gemm<KVQ_EPI_QKV_BF16>(p, st);
+    case KVQ_EPI_RESID_F32:
+      KVQ_REQUIRE(a->out_f32, KVQ_ERR_NULL, "kvq_gemm_bf16: out_f32 NULL");
+      KVQ_REQUIRE(!a->scatter_map || (a->map_rows > 0 && a->out_rows > 0), KVQ_ERR_SHAPE,
+                  "kvq_gemm_bf16: scatter map needs map_rows/out_rows");
+      return launch_gemm<KVQ_EPI_RESID_F32>(p, st);
+    case KVQ_EPI_STORE_F32:
+      KVQ_REQUIRE(a->out_f32, KVQ_ERR_NULL, "kvq_gemm_bf16: out_f32 NULL");
+      return launch_gemm<KVQ_EPI_STORE_F32>(p, st);
+    default:
+      set_error("kvq_gemm_bf16: unknown epilogue %d", a->epilogue);
+      return KVQ_ERR_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,130 @@
+// LayerNorm over gathered rows (gfx950): HBM-bound, one row per lane group.
+//
+// Replaces, in one pass over the fp32 residual stream:
+//   norm1 + F.pad + torch.roll(-shift) + window_partition   (swin_backbone.py:416-449)
+//   norm2                                                   (:491)
+//   PatchMerging's 4-neighbour concat + norm                (:546-552)
+//   the final norm                                          (:1066-1068)
+// The output row r of batch element b is LN(concat_p x[b*rows_in + map[r][p]]).  Statistics are
+// two-pass in registers (mean, then centred sum of squares), fp32, biased variance, eps inside the
+// rsqrt — the same formula torch's LayerNorm uses.  A row is owned by G = 16/32/64 lanes (picked
+// so that every lane holds at least one float4); reductions are wavefront shuffles (xor butterflies).
+#include "common.hpp"
+
+namespace kvq {
+
+struct LnParams {
+  const float* x;
+  const int32_t* map;
+  int nparts, n_batch, rows_in, rows_out, Cin;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  uint16_t* out_bf16;
+  float* out_f32;
+};
+
+template <int G, int NV>  // G lanes per row, NV float4 per lane (NV*G*4 >= C)
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
+  const int C = p.nparts * p.Cin;
+  const int lane_in = threadIdx.x % G;
+  const long row = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const long total = (long)p.n_batch * p.rows_out;
+  const bool live = row < total;          // keep every lane in the shuffles
+  const long rr = live ? row : total - 1;
+  const int b = (int)(rr / p.rows_out), r = (int)(rr - (long)b * p.rows_out);
+
+  f32x4 v[NV];
+  bool all_pad = (p.map != nullptr) && (p.nparts == 1) && (p.map[r] < 0);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * G + lane_in) * 4;
+    v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < C && !all_pad) {
+      const int part = c / p.Cin, cc = c - part * p.Cin;   // Cin % 4 == 0: a float4 never straddles parts
+      const int s = p.map ? p.map[r * p.nparts + part] : r;
+      if (s >= 0) v[i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)b * p.rows_in + s) * p.Cin + cc);
+    }
+    sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, G);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * G + lane_in) * 4;
+    if (c < C) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = v[i][k] - mean;
+        sq += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, G);
+  const float rstd = rsqrtf(sq / (float)C + p.eps);
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * G + lane_in) * 4;
+    if (c >= C) continue;
+    f32x4 y;
+    if (all_pad) {
+      y = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[k] + be[k];
+    }
+    if (p.out_bf16) {
+      u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+      *reinterpret_cast<u32x2*>(p.out_bf16 + (size_t)row * C + c) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * C + c) = y;
+    }
+  }
+}
+
+template <int G, int NV>
+static int launch_ln(const LnParams& p, hipStream_t st) {
+  const long total = (long)p.n_batch * p.rows_out;
+  const int rows_per_block = 256 / G;
+  dim3 grid((unsigned)((total + rows_per_block - 1) / rows_per_block)), block(256);
+  hipLaunchKernelGGL((layernorm_rows_kernel<G, NV>), grid, block, 0, st, p);
+  KVQ_CHECK_LAUNCH("layernorm_rows_kernel");
+  return KVQ_OK;
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts, int n_batch, int rows_in,
+                                  int rows_out, int Cin, const float* gamma, const float* beta, float eps,
+                                  uint16_t* out_bf16, float* out_f32, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && gamma && beta, KVQ_ERR_NULL, "kvq_layernorm_rows: NULL input");
+  KVQ_REQUIRE((out_bf16 != nullptr) != (out_f32 != nullptr), KVQ_ERR_NULL,
+              "kvq_layernorm_rows: exactly one of out_bf16/out_f32 must be set");
+  KVQ_REQUIRE(nparts >= 1 && n_batch > 0 && rows_in > 0 && rows_out > 0 && Cin > 0 && Cin % 4 == 0,
+              KVQ_ERR_SHAPE, "kvq_layernorm_rows: bad shape (nparts=%d n_batch=%d rows=%d/%d Cin=%d)", nparts,
+              n_batch, rows_in, rows_out, Cin);
+  KVQ_REQUIRE(map || (nparts == 1 && rows_in == rows_out), KVQ_ERR_SHAPE,
+              "kvq_layernorm_rows: identity map needs nparts==1 and rows_in==rows_out");
+  const int C = nparts * Cin;
+  LnParams p{x, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_bf16, out_f32};
+  hipStream_t st = (hipStream_t)stream;
+  const int nvec = C / 4;
+  if (nvec <= 16) return launch_ln<16, 1>(p, st);
+  if (nvec <= 32) return launch_ln<32, 1>(p, st);
+  if (nvec <= 64) return launch_ln<64, 1>(p, st);
+  if (nvec <= 128) return launch_ln<64, 2>(p, st);
+  if (nvec <= 192) return launch_ln<64, 3>(p, st);
+  if (nvec <= 256) return launch_ln<64, 4>(p, st);
+  if (nvec <= 512) return launch_ln<64, 8>(p, st);
+  if (nvec <= 1024) return launch_ln<64, 16>(p, st);
+  set_error("kvq_layernorm_rows: C=%d > 4096 unsupported", C);
+  return KVQ_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,237 @@
+// HBM-bound helpers around the trunk: patch-embed im2col, the two score heads, the fragment sampler.
+#include "common.hpp"
+
+namespace kvq {
+
+// ------------------------------------------------------------------------------------------------
+// PatchEmbed3D im2col (swin_backbone.py:715-726).  One thread = one (token, c, kd, kh) run of pw
+// consecutive input pixels -> pw consecutive bf16 of the GEMM row.  Row layout (c,kd,kh,kw) equals
+// Conv3d weight.flatten(1).  Out-of-range (zero-padded tail) pixels read as 0.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int Cin, int T, int H,
+                                                           int W, int pd, int ph, int pw, int D, int Hh, int Ww,
+                                                           uint16_t* __restrict__ out) {
+  const int runs_per_tok = Cin * pd * ph;
+  const long total = (long)B * D * Hh * Ww * runs_per_tok;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // consecutive threads walk w' fastest so that global reads along W coalesce
+    long t = i;
+    const int wq = (int)(t % Ww); t /= Ww;
+    const int kh = (int)(t % ph); t /= ph;
+    const int hq = (int)(t % Hh); t /= Hh;
+    const int kd = (int)(t % pd); t /= pd;
+    const int dq = (int)(t % D); t /= D;
+    const int c = (int)(t % Cin);
+    const int b = (int)(t / Cin);
+    const int tt = dq * pd + kd, hh = hq * ph + kh, w0 = wq * pw;
+    const size_t tok = (((size_t)b * D + dq) * Hh + hq) * Ww + wq;
+    uint16_t* o = out + tok * (size_t)(runs_per_tok * pw) + ((size_t)(c * pd + kd) * ph + kh) * pw;
+    const bool in = tt < T && hh < H;
+    const float* src = x + (((size_t)b * Cin + c) * T + tt) * (size_t)H * W + (size_t)hh * W + w0;
+    for (int k = 0; k < pw; ++k) o[k] = f2bf((in && w0 + k < W) ? src[k] : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// VQAHead (models/head.py:60-68, eval): per token  s = w2 . gelu(W1 f + b1) + b2 ; score = mean_tokens.
+// fp32 FMA throughout (0.08 GFLOP/clip — not worth the bf16 rounding at the very end of the net).
+// One wave handles HEAD_TOK tokens: feature rows in registers, W1 streamed from L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int HEAD_TOK = 4;
+
+__global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __restrict__ feat, int B, int L, int C,
+                                                             long sb, long sl, long sc, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, int hidden,
+                                                             const float* __restrict__ w2, float b2_unused,
+                                                             float* __restrict__ tok_score) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long tok0 = wave_id * HEAD_TOK;
+  const long total = (long)B * L;
+  if (tok0 >= total) return;
+  float acc[HEAD_TOK];
+#pragma unroll
+  for (int t = 0; t < HEAD_TOK; ++t) acc[t] = 0.f;
+  for (int j = 0; j < hidden; ++j) {
+    float d[HEAD_TOK];
+#pragma unroll
+    for (int t = 0; t < HEAD_TOK; ++t) d[t] = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float wv = w1[(size_t)j * C + c];
+#pragma unroll
+      for (int t = 0; t < HEAD_TOK; ++t) {
+        const long tk = min(tok0 + t, total - 1);
+        const long b = tk / L, l = tk - b * L;
+        d[t] = fmaf(feat[b * sb + l * sl + c * sc], wv, d[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < HEAD_TOK; ++t) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) d[t] += __shfl_xor(d[t], o);
+      acc[t] = fmaf(w2[j], gelu_erf(d[t] + b1[j]), acc[t]);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < HEAD_TOK; ++t)
+      if (tok0 + t < total) tok_score[tok0 + t] = acc[t];
+  }
+}
+
+// score[b] = mean_l tok_score[b*L + l] + b2   (deterministic tree, one block per batch element)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, int L, const float* b2,
+                                                        float* __restrict__ out) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) s += v[(size_t)b * L + l];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = red[0] / (float)L + (b2 ? b2[0] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// simpleVQAHead (models/head.py:28-31): Linear(Cin->hidden) -> Linear(hidden->1) per frame, no activation.
+// One block per (b, t) frame row: 256 threads split Cin, each accumulates all hidden dots?  hidden=128,
+// Cin=9472: W1 is 4.8 MB fp32 and is re-read per frame from L2; 8 frames/video -> negligible.
+// Thread j<hidden computes its dot product with a block-cooperative, LDS-staged feature row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void simple_head_frame_kernel(const float* __restrict__ feat, int Cin,
+                                                                const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, int hidden,
+                                                                const float* __restrict__ w2,
+                                                                float* __restrict__ frame_score) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* f = feat + (size_t)row * Cin;
+  float acc = 0.f;
+  for (int j = wave; j < hidden; j += 4) {
+    float d = 0.f;
+    for (int c = lane; c < Cin; c += 64) d = fmaf(f[c], w1[(size_t)j * Cin + c], d);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    acc = fmaf(w2[j], d + b1[j], acc);
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) frame_score[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fragment sampler (fusion_datasets.py:22-121 + :1017-1020): grid-mini-patch gather + normalise.
+// One thread = 4 consecutive output pixels of one output row; patch origins come from hoff/woff.
+// ------------------------------------------------------------------------------------------------
+struct FragParams {
+  const void* video;
+  int src_is_u8, C, T, H, W;
+  const int32_t* hoff;
+  const int32_t* woff;
+  int Fh, Fw, fsh, fsw, aligned;
+  float mean[4], std[4];
+  int normalise;
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p) {
+  const int OH = p.Fh * p.fsh, OW = p.Fw * p.fsw;
+  const int nt = p.T / p.aligned;
+  const long total = (long)p.C * p.T * OH * OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); r /= OH;
+    const int t = (int)(r % p.T);
+    const int c = (int)(r / p.T);
+    const int fi = oy / p.fsh, fj = ox / p.fsw;
+    const int tb = t / p.aligned;
+    const int o = (fi * p.Fw + fj) * nt + tb;
+    const int sy = p.hoff[o] + (oy - fi * p.fsh), sx = p.woff[o] + (ox - fj * p.fsw);
+    const size_t src = (((size_t)c * p.T + t) * p.H + sy) * p.W + sx;
+    float v = p.src_is_u8 ? (float)reinterpret_cast<const uint8_t*>(p.video)[src]
+                          : reinterpret_cast<const float*>(p.video)[src];
+    if (p.normalise) v = (v - p.mean[c]) / p.std[c];   // IEEE fp32 divide: bit-equal to the reference's (v-mean)/std
+    p.out[i] = v;
+  }
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd, int ph, int pw,
+                                uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && out, KVQ_ERR_NULL, "kvq_patch_im2col: NULL pointer");
+  KVQ_REQUIRE(B > 0 && Cin > 0 && T > 0 && H > 0 && W > 0 && pd > 0 && ph > 0 && pw > 0, KVQ_ERR_SHAPE,
+              "kvq_patch_im2col: bad shape");
+  const int D = ceil_div(T, pd), Hh = ceil_div(H, ph), Ww = ceil_div(W, pw);
+  const long total = (long)B * D * Hh * Ww * Cin * pd * ph;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(patch_im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, Cin, T, H, W, pd, ph,
+                     pw, D, Hh, Ww, out);
+  KVQ_CHECK_LAUNCH("patch_im2col_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l,
+                            int64_t stride_c, const float* w1, const float* b1, int hidden, const float* w2,
+                            const float* b2, float* scratch, float* score, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(feat && w1 && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head: NULL pointer");
+  KVQ_REQUIRE(B > 0 && L > 0 && C > 0 && hidden > 0, KVQ_ERR_SHAPE, "kvq_vqa_head: bad shape");
+  const long waves = ((long)B * L + HEAD_TOK - 1) / HEAD_TOK;
+  const int grid = (int)((waves + 3) / 4);
+  hipLaunchKernelGGL(vqa_head_token_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, B, L, C,
+                     (long)stride_b, (long)stride_l, (long)stride_c, w1, b1, hidden, w2, 0.f, scratch);
+  KVQ_CHECK_LAUNCH("vqa_head_token_kernel");
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scratch, L, b2, score);
+  KVQ_CHECK_LAUNCH("mean_rows_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_simple_vqa_head(const float* feat, int B, int T, int Cin, const float* w1, const float* b1,
+                                   int hidden, const float* w2, const float* b2, float* scratch, float* score,
+                                   void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(feat && w1 && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_simple_vqa_head: NULL pointer");
+  KVQ_REQUIRE(B > 0 && T > 0 && Cin > 0 && hidden > 0, KVQ_ERR_SHAPE, "kvq_simple_vqa_head: bad shape");
+  hipLaunchKernelGGL(simple_head_frame_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, feat, Cin, w1, b1,
+                     hidden, w2, scratch);
+  KVQ_CHECK_LAUNCH("simple_head_frame_kernel");
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scratch, T, b2, score);
+  KVQ_CHECK_LAUNCH("mean_rows_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_fragment_gather(const void* video, int src_is_u8, int C, int T, int H, int W,
+                                   const int32_t* hoff, const int32_t* woff, int Fh, int Fw, int fs_h, int fs_w,
+                                   int aligned, const float* host_mean, const float* host_std, float* out,
+                                   void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(video && hoff && woff && out, KVQ_ERR_NULL, "kvq_fragment_gather: NULL pointer");
+  KVQ_REQUIRE(C > 0 && C <= 4 && T > 0 && Fh > 0 && Fw > 0 && fs_h > 0 && fs_w > 0 && aligned > 0, KVQ_ERR_SHAPE,
+              "kvq_fragment_gather: bad shape");
+  // reference: assert dur_t % aligned == 0, "Please provide match vclip and align index" (fusion_datasets.py:60)
+  KVQ_REQUIRE(T % aligned == 0, KVQ_ERR_SHAPE, "Please provide match vclip and align index");
+  KVQ_REQUIRE(H >= Fh * fs_h && W >= Fw * fs_w, KVQ_ERR_UNSUPPORTED,
+              "kvq_fragment_gather: source %dx%d smaller than the %dx%d canvas (upsample fallback not in the hot path)",
+              H, W, Fh * fs_h, Fw * fs_w);
+  FragParams p{};
+  p.video = video; p.src_is_u8 = src_is_u8; p.C = C; p.T = T; p.H = H; p.W = W;
+  p.hoff = hoff; p.woff = woff; p.Fh = Fh; p.Fw = Fw; p.fsh = fs_h; p.fsw = fs_w; p.aligned = aligned;
+  p.normalise = host_std != nullptr;
+  for (int c = 0; c < C; ++c) {
+    p.mean[c] = host_mean ? host_mean[c] : 0.f;
+    p.std[c] = host_std ? host_std[c] : 1.f;
+  }
+  p.out = out;
+  const long total = (long)C * T * Fh * fs_h * Fw * fs_w;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(fragment_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("fragment_gather_kernel");
+  return KVQ_OK;
+}

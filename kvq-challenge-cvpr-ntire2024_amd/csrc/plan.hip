@@ -1,0 +1,368 @@
+// Host side of the trunk: shape plan (integer index maps) + the launch sequence of
+// SwinTransformer3D.forward (swin_backbone.py:1044-1080) over the kernels in this library.
+//
+// The plan replaces the reference's lru_cached helper tensors:
+//   compute_mask            (swin_backbone.py:559-586)  -> per-token region id (1 byte)
+//   global_position_index   (:21-50)                    -> per-token fragment ids (2 bytes)
+//   relative_position_index (:213-235)                  -> per-token linear position code
+//   pad + roll + window_partition / window_reverse + roll + crop (:418-488) -> one gather map
+//   PatchMerging's strided slices + pad (:542-550)      -> one 4-neighbour map
+// A (nW,N,N,3) int64 tensor (472 MB at stage 0) becomes 8 bytes per token.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace kvq {
+
+struct StageGeom {
+  int D, H, W, C, nH, depth;
+  int L;
+  // index [0] = un-shifted blocks, [1] = shifted blocks
+  int ws[3], ss[3];
+  int Dp, Hp, Wp, nW, N, Lp;
+  bool shifted_any;
+  int32_t* d_src[2];  // [Lp] source token or -1
+  int32_t* d_tok[2];  // [nW*N][2]
+  int32_t* d_merge;   // [L_next][4] or nullptr
+  int Dn, Hn, Wn;     // dims after the merge
+};
+
+struct ProfEvent {
+  int kind;
+  hipEvent_t a, b;
+};
+
+}  // namespace kvq
+
+struct KvqSwinPlan {
+  KvqSwinCfg cfg;
+  int B, T, H, W;
+  int D0, H0, W0, K0;
+  std::vector<kvq::StageGeom> st;
+  std::vector<void*> owned;      // device allocations to free
+  size_t ws_bytes;
+  size_t off_x0, off_x1, off_ln, off_big, off_o;
+  int table_len, center;
+  // profiling
+  bool profile;
+  std::vector<kvq::ProfEvent> events;
+  size_t ev_used;
+};
+
+namespace kvq {
+
+// ATen legacy 'nearest' source index (UpSampleKernel nearest_idx): float32 scale, floorf, clamp.
+static int nearest_src(int dst, int in_size, int out_size) {
+  if (out_size == in_size) return dst;
+  if (out_size == 2 * in_size) return dst >> 1;
+  const float scale = (float)in_size / (float)out_size;
+  const int s = (int)floorf((float)dst * scale);
+  return s < in_size - 1 ? s : in_size - 1;
+}
+
+static int axis_region(int s, int P, int w, int sft) {
+  if (sft == 0) return 2;          // the last slice(-0, None) repaints the whole axis
+  if (s >= P - sft) return 2;
+  if (s >= P - w) return 1;
+  return 0;
+}
+
+static int upload(KvqSwinPlan* pl, const std::vector<int32_t>& h, int32_t** out) {
+  void* d = nullptr;
+  KVQ_CHECK_HIP(hipMalloc(&d, h.size() * sizeof(int32_t)));
+  pl->owned.push_back(d);
+  KVQ_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  *out = (int32_t*)d;
+  return KVQ_OK;
+}
+
+static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
+  const KvqSwinCfg& cfg = pl->cfg;
+  const int dims[3] = {g.D, g.H, g.W};
+  int ws[3], ss[3];
+  for (int a = 0; a < 3; ++a) {
+    const bool clamp = dims[a] <= cfg.window[a];
+    ws[a] = clamp ? dims[a] : cfg.window[a];
+    ss[a] = (clamp || par == 0) ? 0 : cfg.window[a] / 2;
+  }
+  if (par == 0) {
+    memcpy(g.ws, ws, sizeof(ws));
+    g.Dp = round_up(g.D, ws[0]); g.Hp = round_up(g.H, ws[1]); g.Wp = round_up(g.W, ws[2]);
+    g.N = ws[0] * ws[1] * ws[2];
+    g.nW = (g.Dp / ws[0]) * (g.Hp / ws[1]) * (g.Wp / ws[2]);
+    g.Lp = g.nW * g.N;
+  } else {
+    memcpy(g.ss, ss, sizeof(ss));
+    g.shifted_any = ss[0] > 0 || ss[1] > 0 || ss[2] > 0;
+  }
+  const int nd = g.Dp / ws[0], nh = g.Hp / ws[1], nw = g.Wp / ws[2];
+  const int Wh = cfg.window[1], Ww = cfg.window[2];
+  std::vector<int32_t> src((size_t)g.Lp), tok((size_t)g.Lp * 2);
+  size_t r = 0;
+  for (int wd = 0; wd < nd; ++wd)
+    for (int wh = 0; wh < nh; ++wh)
+      for (int ww = 0; ww < nw; ++ww) {
+        int n = 0;
+        for (int ld = 0; ld < ws[0]; ++ld)
+          for (int lh = 0; lh < ws[1]; ++lh)
+            for (int lw = 0; lw < ws[2]; ++lw, ++n, ++r) {
+              const int sd = wd * ws[0] + ld, sh = wh * ws[1] + lh, sw = ww * ws[2] + lw;
+              const int ud = (sd + ss[0]) % g.Dp, uh = (sh + ss[1]) % g.Hp, uw = (sw + ss[2]) % g.Wp;
+              const bool valid = ud < g.D && uh < g.H && uw < g.W;
+              src[r] = valid ? (ud * g.H + uh) * g.W + uw : -1;
+              // bias code: raster coordinate of index n in the CONFIGURED window (reference slices
+              // relative_position_index[:N,:N], swin_backbone.py:263-264)
+              const int cd = n / (Wh * Ww), ch = (n / Ww) % Wh, cw = n % Ww;
+              const int code = cd * (2 * Wh - 1) * (2 * Ww - 1) + ch * (2 * Ww - 1) + cw;
+              const int fh = nearest_src(uh, ws[1], g.Hp), fw = nearest_src(uw, ws[2], g.Wp);
+              const int region = axis_region(sd, g.Dp, ws[0], ss[0]) * 9 + axis_region(sh, g.Hp, ws[1], ss[1]) * 3 +
+                                 axis_region(sw, g.Wp, ws[2], ss[2]);
+              tok[2 * r] = code;
+              tok[2 * r + 1] = (fh & 0xff) | ((fw & 0xff) << 8) | ((region & 0xff) << 16);
+            }
+      }
+  int rc = upload(pl, src, &g.d_src[par]);
+  if (rc) return rc;
+  return upload(pl, tok, &g.d_tok[par]);
+}
+
+static int build_merge_map(KvqSwinPlan* pl, StageGeom& g) {
+  g.Dn = g.D; g.Hn = (g.H + 1) / 2; g.Wn = (g.W + 1) / 2;
+  std::vector<int32_t> m((size_t)g.Dn * g.Hn * g.Wn * 4);
+  size_t r = 0;
+  for (int d = 0; d < g.D; ++d)
+    for (int h2 = 0; h2 < g.Hn; ++h2)
+      for (int w2 = 0; w2 < g.Wn; ++w2, ++r) {
+        // concat order x0(0,0) x1(+h) x2(+w) x3(+h,+w)  (swin_backbone.py:546-550)
+        const int hh[4] = {2 * h2, 2 * h2 + 1, 2 * h2, 2 * h2 + 1};
+        const int wv[4] = {2 * w2, 2 * w2, 2 * w2 + 1, 2 * w2 + 1};
+        for (int p = 0; p < 4; ++p)
+          m[4 * r + p] = (hh[p] < g.H && wv[p] < g.W) ? (d * g.H + hh[p]) * g.W + wv[p] : -1;
+      }
+  return upload(pl, m, &g.d_merge);
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace kvq
+
+extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H, int W, KvqSwinPlan** out) {
+  using namespace kvq;
+  KVQ_REQUIRE(cfg && out, KVQ_ERR_NULL, "kvq_swin3d_plan_create: NULL pointer");
+  KVQ_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, KVQ_ERR_SHAPE, "kvq_swin3d_plan_create: bad input shape");
+  KVQ_REQUIRE(cfg->num_stages >= 1 && cfg->num_stages <= KVQ_MAX_STAGES, KVQ_ERR_UNSUPPORTED, "num_stages %d",
+              cfg->num_stages);
+  KVQ_REQUIRE(cfg->embed_dim % 32 == 0 && (cfg->in_chans * cfg->patch[0] * cfg->patch[1] * cfg->patch[2]) % 32 == 0,
+              KVQ_ERR_UNSUPPORTED, "embed_dim and in_chans*prod(patch) must be multiples of 32");
+  KVQ_REQUIRE(cfg->window[0] * cfg->window[1] * cfg->window[2] <= 400, KVQ_ERR_UNSUPPORTED,
+              "window of more than 400 tokens unsupported");
+  for (int i = 0; i < cfg->num_stages; ++i)
+    KVQ_REQUIRE(cfg->num_heads[i] * 32 == (cfg->embed_dim << i), KVQ_ERR_UNSUPPORTED,
+                "stage %d: head_dim must be 32 (C=%d, heads=%d)", i, cfg->embed_dim << i, cfg->num_heads[i]);
+  KvqSwinPlan* pl = new KvqSwinPlan();
+  pl->cfg = *cfg; pl->B = B; pl->T = T; pl->H = H; pl->W = W;
+  pl->profile = false; pl->ev_used = 0;
+  pl->D0 = ceil_div(T, cfg->patch[0]); pl->H0 = ceil_div(H, cfg->patch[1]); pl->W0 = ceil_div(W, cfg->patch[2]);
+  pl->K0 = cfg->in_chans * cfg->patch[0] * cfg->patch[1] * cfg->patch[2];
+  const int Wd = cfg->window[0], Wh = cfg->window[1], Ww = cfg->window[2];
+  pl->table_len = (2 * Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1);
+  pl->center = (Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1) + (Wh - 1) * (2 * Ww - 1) + (Ww - 1);
+  int D = pl->D0, Hh = pl->H0, Wv = pl->W0;
+  size_t max_x = 0, max_ln = 0, max_big = (size_t)B * D * Hh * Wv * pl->K0, max_o = 0;
+  for (int i = 0; i < cfg->num_stages; ++i) {
+    StageGeom g{};
+    g.D = D; g.H = Hh; g.W = Wv; g.C = cfg->embed_dim << i; g.nH = cfg->num_heads[i]; g.depth = cfg->depths[i];
+    g.L = D * Hh * Wv;
+    int rc = build_stage_maps(pl, g, 0);
+    if (!rc) rc = build_stage_maps(pl, g, 1);
+    if (!rc && i < cfg->num_stages - 1) rc = build_merge_map(pl, g);
+    if (rc) { kvq_swin3d_plan_destroy(pl); return rc; }
+    const size_t BL = (size_t)B * g.L, BLp = (size_t)B * g.Lp;
+    max_x = std::max(max_x, BL * g.C);
+    max_ln = std::max(max_ln, std::max(BLp * g.C, BL * g.C));
+    max_big = std::max(max_big, std::max(BLp * 3 * g.C, BL * (size_t)cfg->mlp_ratio * g.C));
+    max_o = std::max(max_o, BLp * g.C);
+    pl->st.push_back(g);
+    if (i < cfg->num_stages - 1) { Hh = g.Hn; Wv = g.Wn; }
+  }
+  size_t off = 0;
+  pl->off_x0 = off; off += align_up(max_x * 4);
+  pl->off_x1 = off; off += align_up(max_x * 4);
+  pl->off_ln = off; off += align_up(max_ln * 2);
+  pl->off_big = off; off += align_up(max_big * 2);
+  pl->off_o = off; off += align_up(max_o * 2);
+  pl->ws_bytes = off;
+  *out = pl;
+  return KVQ_OK;
+}
+
+extern "C" void kvq_swin3d_plan_destroy(KvqSwinPlan* pl) {
+  if (!pl) return;
+  for (void* d : pl->owned) (void)hipFree(d);
+  for (auto& e : pl->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  delete pl;
+}
+
+extern "C" size_t kvq_swin3d_workspace_bytes(const KvqSwinPlan* pl) { return pl ? pl->ws_bytes : 0; }
+
+extern "C" int kvq_swin3d_out_dims(const KvqSwinPlan* pl, int32_t out4[4]) {
+  using namespace kvq;
+  KVQ_REQUIRE(pl && out4, KVQ_ERR_NULL, "kvq_swin3d_out_dims: NULL");
+  const StageGeom& g = pl->st.back();
+  out4[0] = g.C; out4[1] = g.D; out4[2] = g.H; out4[3] = g.W;
+  return KVQ_OK;
+}
+
+extern "C" int kvq_swin3d_profile(KvqSwinPlan* pl, int enable) {
+  using namespace kvq;
+  KVQ_REQUIRE(pl, KVQ_ERR_NULL, "kvq_swin3d_profile: NULL");
+  pl->profile = enable != 0;
+  pl->ev_used = 0;
+  return KVQ_OK;
+}
+
+extern "C" int kvq_swin3d_profile_read(KvqSwinPlan* pl, float* ms, int32_t* launches) {
+  using namespace kvq;
+  KVQ_REQUIRE(pl && ms && launches, KVQ_ERR_NULL, "kvq_swin3d_profile_read: NULL");
+  for (int k = 0; k < KVQ_K_COUNT; ++k) { ms[k] = 0.f; launches[k] = 0; }
+  for (size_t i = 0; i < pl->ev_used; ++i) {
+    ProfEvent& e = pl->events[i];
+    KVQ_CHECK_HIP(hipEventSynchronize(e.b));
+    float t = 0.f;
+    KVQ_CHECK_HIP(hipEventElapsedTime(&t, e.a, e.b));
+    ms[e.kind] += t;
+    launches[e.kind] += 1;
+  }
+  pl->ev_used = 0;
+  return KVQ_OK;
+}
+
+namespace kvq {
+
+// RAII-less bracket: records start/stop events on the launch stream when profiling is on.
+struct Bracket {
+  KvqSwinPlan* pl;
+  hipStream_t st;
+  ProfEvent* e;
+  Bracket(KvqSwinPlan* p, hipStream_t s, int kind) : pl(p), st(s), e(nullptr) {
+    if (!pl->profile) return;
+    if (pl->ev_used == pl->events.size()) {
+      ProfEvent n{kind, nullptr, nullptr};
+      if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+      pl->events.push_back(n);
+    }
+    e = &pl->events[pl->ev_used++];
+    e->kind = kind;
+    (void)hipEventRecord(e->a, st);
+  }
+  ~Bracket() {
+    if (e) (void)hipEventRecord(e->b, st);
+  }
+};
+
+static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, const uint16_t* Wt, const float* bias,
+                int M, int N, int K, int epi, uint16_t* obf, float* of32, int nH = 0, float qs = 1.f,
+                const int32_t* map = nullptr, int map_rows = 0, int out_rows = 0) {
+  KvqGemmArgs a{};
+  a.A = A; a.W = Wt; a.bias = bias; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_bf16 = obf; a.out_f32 = of32;
+  a.num_heads = nH; a.q_scale = qs; a.scatter_map = map; a.map_rows = map_rows; a.out_rows = out_rows;
+  Bracket br(pl, st, kind);
+  return kvq_gemm_bf16(&a, st);
+}
+
+static int ln(KvqSwinPlan* pl, hipStream_t st, const float* x, const int32_t* map, int nparts, int rows_in,
+              int rows_out, int Cin, const float* g, const float* b, uint16_t* obf, float* of32) {
+  Bracket br(pl, st, KVQ_K_LAYERNORM);
+  return kvq_layernorm_rows(x, map, nparts, pl->B, rows_in, rows_out, Cin, g, b, 1e-5f, obf, of32, st);
+}
+
+}  // namespace kvq
+
+#define KVQ_TRY(expr)      \
+  do {                     \
+    int _rc = (expr);      \
+    if (_rc) return _rc;   \
+  } while (0)
+
+extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float* x, float* feat,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(cpl && w && x && feat && workspace, KVQ_ERR_NULL, "kvq_swin3d_forward: NULL pointer");
+  KVQ_REQUIRE(w->blocks && w->embed_w && w->embed_b && w->norm_w && w->norm_b, KVQ_ERR_NULL,
+              "kvq_swin3d_forward: incomplete weights");
+  KvqSwinPlan* pl = const_cast<KvqSwinPlan*>(cpl);   // profiling state only
+  KVQ_REQUIRE(workspace_bytes >= pl->ws_bytes, KVQ_ERR_WORKSPACE, "kvq_swin3d_forward: workspace %zu < %zu bytes",
+              workspace_bytes, pl->ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const KvqSwinCfg& cfg = pl->cfg;
+  const int B = pl->B;
+  unsigned char* ws = (unsigned char*)workspace;
+  float* xa = (float*)(ws + pl->off_x0);
+  float* xb = (float*)(ws + pl->off_x1);
+  uint16_t* bln = (uint16_t*)(ws + pl->off_ln);
+  uint16_t* bbig = (uint16_t*)(ws + pl->off_big);
+  uint16_t* bo = (uint16_t*)(ws + pl->off_o);
+  pl->ev_used = pl->profile ? pl->ev_used : 0;
+
+  // ---- PatchEmbed3D: im2col -> GEMM(+bias) -> LayerNorm  (swin_backbone.py:715-733) ----
+  const int L0 = pl->D0 * pl->H0 * pl->W0, E = cfg.embed_dim;
+  {
+    Bracket br(pl, st, KVQ_K_IM2COL);
+    KVQ_TRY(kvq_patch_im2col(x, B, cfg.in_chans, pl->T, pl->H, pl->W, cfg.patch[0], cfg.patch[1], cfg.patch[2], bbig,
+                             st));
+  }
+  KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_EMBED, bbig, w->embed_w, w->embed_b, B * L0, E, pl->K0, KVQ_EPI_STORE_F32, nullptr,
+               xb));
+  float* cur = xa;
+  float* oth = xb;
+  if (w->embed_ln_w) {
+    KVQ_TRY(ln(pl, st, xb, nullptr, 1, L0, L0, E, w->embed_ln_w, w->embed_ln_b, nullptr, xa));
+  } else {
+    cur = xb; oth = xa;
+  }
+
+  int blk = 0;
+  for (int i = 0; i < cfg.num_stages; ++i) {
+    const StageGeom& g = pl->st[i];
+    const int C = g.C, M = B * g.Lp, ML = B * g.L;
+    for (int b = 0; b < g.depth; ++b, ++blk) {
+      const KvqSwinBlockW& bw = w->blocks[blk];
+      KVQ_REQUIRE(bw.norm1_w && bw.rpb_table && bw.qkv_w && bw.proj_w && bw.fc1_w && bw.fc2_w, KVQ_ERR_NULL,
+                  "kvq_swin3d_forward: block %d weights incomplete", blk);
+      const int par = (b & 1) && g.shifted_any ? 1 : 0;
+      // norm1 + pad + roll + window_partition
+      KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
+                   0.17677669529663687f /* 32^-0.5 */));
+      {
+        Bracket br(pl, st, KVQ_K_ATTN);
+        KVQ_TRY(kvq_window_attention(bbig, g.d_tok[par], bw.rpb_table, cfg.frag_bias[i] ? bw.fpb_table : nullptr,
+                                     pl->table_len, pl->center, B * g.nW, g.nW, g.N, g.nH, par, bo, st));
+      }
+      // proj + window_reverse + roll back + crop + residual
+      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,
+                   g.d_src[par], g.Lp, g.L));
+      // norm2 + fc1 + GELU + fc2 + residual
+      KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm2_w, bw.norm2_b, bln, nullptr));
+      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_FC1, bln, bw.fc1_w, bw.fc1_b, ML, cfg.mlp_ratio * C, C, KVQ_EPI_GELU_BF16, bbig,
+                   nullptr));
+      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_FC2, bbig, bw.fc2_w, bw.fc2_b, ML, C, cfg.mlp_ratio * C, KVQ_EPI_RESID_F32,
+                   nullptr, cur));
+    }
+    if (i < cfg.num_stages - 1) {
+      const KvqSwinMergeW& mw = w->merges[i];
+      KVQ_REQUIRE(mw.norm_w && mw.norm_b && mw.red_w, KVQ_ERR_NULL, "kvq_swin3d_forward: merge %d weights missing", i);
+      const int Ln = g.Dn * g.Hn * g.Wn;
+      KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr));
+      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
+                   oth));
+      float* t = cur; cur = oth; oth = t;
+    }
+  }
+  const StageGeom& gl = pl->st.back();
+  KVQ_TRY(ln(pl, st, cur, nullptr, 1, gl.L, gl.L, gl.C, w->norm_w, w->norm_b, nullptr, feat));
+  return KVQ_OK;
+}

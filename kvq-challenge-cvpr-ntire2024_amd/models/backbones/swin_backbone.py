@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's ``models/backbones/swin_backbone.py`` trunk API.
+
+Same class/constructor/forward/state_dict surface as the reference's ``SwinTransformer3D``
+(``swin_backbone.py:736-1085``; factories ``swin_3d_tiny/small`` ``:1088-1095``), but the
+modules only *hold parameters*: ``forward`` hands raw device pointers to
+``kvq_swin3d_forward`` in libkvq_hip.so.  There is no PyTorch compute path.
+
+state_dict keys are the reference's, including the
+``attn.relative_position_index`` buffers, so reference checkpoints load with
+``load_state_dict`` unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import _abi
+from ..._abi import KvqSwinBlockW, KvqSwinCfg, KvqSwinWeights, check, current_stream, lib, ptr
+
+
+def _rel_pos_index(window) -> torch.Tensor:
+    """The registered buffer of WindowAttention3D (swin_backbone.py:213-235); kept only for
+    state_dict compatibility — the kernels derive it from per-token position codes."""
+    Wd, Wh, Ww = window
+    n = torch.arange(Wd * Wh * Ww)
+    c = torch.stack([n // (Wh * Ww), (n // Ww) % Wh, n % Ww])
+    d = c[:, :, None] - c[:, None, :]
+    return ((d[0] + Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1) + (d[1] + Wh - 1) * (2 * Ww - 1) + d[2] + Ww - 1)
+
+
+class _Affine(nn.Module):
+    """weight(+bias) holder standing in for nn.Linear / nn.LayerNorm / nn.Conv3d."""
+
+    def __init__(self, wshape, bshape=None, ones=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(wshape) if ones else torch.zeros(wshape))
+        if bshape is not None:
+            self.bias = nn.Parameter(torch.zeros(bshape))
+        else:
+            self.register_parameter("bias", None)
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, window, num_heads, frag_bias, qkv_bias=True):
+        super().__init__()
+        tl = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(tl, num_heads))
+        if frag_bias:
+            self.fragment_position_bias_table = nn.Parameter(torch.zeros(tl, num_heads))
+        self.register_buffer("relative_position_index", _rel_pos_index(window))
+        self.qkv = _Affine((3 * dim, dim), (3 * dim,) if qkv_bias else None)
+        self.proj = _Affine((dim, dim), (dim,))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = _Affine((hidden, dim), (hidden,))
+        self.fc2 = _Affine((dim, hidden), (dim,))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, window, num_heads, mlp_ratio, frag_bias, qkv_bias=True):
+        super().__init__()
+        self.norm1 = _Affine((dim,), (dim,), ones=True)
+        self.attn = _Attn(dim, window, num_heads, frag_bias, qkv_bias)
+        self.norm2 = _Affine((dim,), (dim,), ones=True)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _Merge(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = _Affine((2 * dim, 4 * dim))
+        self.norm = _Affine((4 * dim,), (4 * dim,), ones=True)
+
+
+class _Layer(nn.Module):
+    def __init__(self, dim, depth, window, num_heads, mlp_ratio, frag_bias, downsample, qkv_bias=True):
+        super().__init__()
+        self.blocks = nn.ModuleList([_Block(dim, window, num_heads, mlp_ratio, frag_bias, qkv_bias)
+                                     for _ in range(depth)])
+        self.downsample = _Merge(dim) if downsample else None
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch, in_chans, embed_dim, norm):
+        super().__init__()
+        self.proj = _Affine((embed_dim, in_chans) + tuple(patch), (embed_dim,))
+        self.norm = _Affine((embed_dim,), (embed_dim,), ones=True) if norm else None
+
+
+class SwinTransformer3D(nn.Module):
+    """Drop-in for the reference class of the same name (inference forward only).
+
+    Constructor kwargs follow ``swin_backbone.py:760-783``.  ``pretrained`` accepts a path to a
+    checkpoint in the reference's ``load_swin`` format (``:933-1006``) or None; the reference's
+    import-time/default path side effect is NOT reproduced: a missing file is an
+    error only if a path is given explicitly.
+    """
+
+    def __init__(self, pretrained=None, pretrained2d=False, patch_size=(2, 4, 4), in_chans=3, embed_dim=96,
+                 depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=(8, 7, 7), mlp_ratio=4.0,
+                 qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1,
+                 norm_layer=nn.LayerNorm, patch_norm=True, frozen_stages=-1, use_checkpoint=True,
+                 jump_attention=(False, False, False, False), frag_biases=(True, True, True, False),
+                 base_x_size=(32, 224, 224)):
+        super().__init__()
+        if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
+            raise NotImplementedError("per-stage window sizes are not used by any reference config")
+        if qk_scale is not None or any(jump_attention) or not qkv_bias:
+            raise NotImplementedError("qk_scale / jump_attention / qkv_bias=False are not on the hot path")
+        if int(mlp_ratio) != mlp_ratio:
+            raise NotImplementedError("non-integer mlp_ratio")
+        self.pretrained, self.pretrained2d = pretrained, pretrained2d
+        self.num_layers = len(depths)
+        self.embed_dim, self.patch_norm, self.frozen_stages = embed_dim, patch_norm, frozen_stages
+        self.window_size, self.patch_size, self.base_x_size = tuple(window_size), tuple(patch_size), base_x_size
+        self.depths, self.heads = tuple(depths), tuple(num_heads)
+        self.mlp_ratio, self.in_chans = int(mlp_ratio), in_chans
+        self.frag_biases = tuple(bool(f) for f in frag_biases)
+        self.patch_embed = _PatchEmbed(self.patch_size, in_chans, embed_dim, patch_norm)
+        self.layers = nn.ModuleList([
+            _Layer(int(embed_dim * 2 ** i), depths[i], self.window_size, num_heads[i], mlp_ratio,
+                   self.frag_biases[i], downsample=i < self.num_layers - 1) for i in range(self.num_layers)])
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.norm = _Affine((self.num_features,), (self.num_features,), ones=True)
+        self._plans: Dict[Tuple, Tuple] = {}
+        self._wcache = None
+        self.init_weights()
+
+    # ------------------------------------------------------------------ weights
+    def init_weights(self, pretrained=None):
+        """trunc_normal(0.02) Linear weights, zero biases, unit LayerNorm, trunc_normal tables
+        (swin_backbone.py:1017-1024, :242); then optionally ``load_swin``."""
+        if pretrained:
+            self.pretrained = pretrained
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                leaf = name.rsplit(".", 1)[-1]
+                if "relative_position_bias_table" in name:
+                    nn.init.trunc_normal_(p, std=0.02)
+                elif "fragment_position_bias_table" in name:
+                    p.zero_()
+                elif "norm" in name:
+                    p.fill_(1.0) if leaf == "weight" else p.zero_()
+                elif name.startswith("patch_embed.proj"):
+                    # nn.Conv3d default init is kaiming-uniform in the reference; any finite init will do
+                    nn.init.trunc_normal_(p, std=0.02) if leaf == "weight" else p.zero_()
+                elif leaf == "weight":
+                    nn.init.trunc_normal_(p, std=0.02)
+                else:
+                    p.zero_()
+        if isinstance(self.pretrained, str):
+            if self.pretrained2d:
+                raise NotImplementedError("2D->3D inflation (swin_backbone.py:858-931) is a checkpoint-format "
+                                          "row (SURVEY.md §8 f3), not built yet")
+            self.load_swin(self.pretrained)
+        elif self.pretrained is not None:
+            raise TypeError("pretrained must be a str or None")
+
+    def load_swin(self, load_path, strict=False):
+        """Reference ``load_swin`` (swin_backbone.py:933-1006): strip the 9-char ``backbone.`` prefix,
+        fork every relative_position_bias_table into fragment_position_bias_table, drop
+        shape-mismatched keys."""
+        state = torch.load(load_path, map_location="cpu")["state_dict"]
+        clean = {}
+        for k, v in state.items():
+            if "backbone" in k:
+                ck = k[9:]
+                clean[ck] = v
+                if "relative_position_bias_table" in ck:
+                    clean.setdefault(ck.replace("relative_position_bias_table", "fragment_position_bias_table"), v)
+        own = self.state_dict()
+        clean = {k: v for k, v in clean.items() if k not in own or own[k].shape == v.shape}
+        return self.load_state_dict(clean, strict=strict)
+
+    def cfg_struct(self) -> KvqSwinCfg:
+        c = KvqSwinCfg()
+        c.patch[:] = self.patch_size
+        c.in_chans, c.embed_dim, c.num_stages = self.in_chans, self.embed_dim, self.num_layers
+        for i in range(self.num_layers):
+            c.depths[i], c.num_heads[i], c.frag_bias[i] = self.depths[i], self.heads[i], int(self.frag_biases[i])
+        c.window[:] = self.window_size
+        c.mlp_ratio = self.mlp_ratio
+        return c
+
+    def _weights(self, device) -> KvqSwinWeights:
+        """bf16 copies of the GEMM weights + a KvqSwinWeights of raw pointers; rebuilt whenever a
+        parameter was modified in place or moved (tracked through tensor versions / data_ptr)."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._wcache is not None and self._wcache[0] == sig:
+            return self._wcache[1]
+        keep = []
+
+        def f32(p):
+            t = p.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return ptr(t)
+
+        def bf16(p, shape=None):
+            t = p.detach().to(device=device, dtype=torch.float32)
+            t = (t.reshape(shape) if shape is not None else t).to(torch.bfloat16).contiguous()
+            keep.append(t)
+            return ptr(t)
+
+        w = KvqSwinWeights()
+        pe = self.patch_embed
+        w.embed_w = bf16(pe.proj.weight, (self.embed_dim, -1))
+        w.embed_b = f32(pe.proj.bias)
+        if pe.norm is not None:
+            w.embed_ln_w, w.embed_ln_b = f32(pe.norm.weight), f32(pe.norm.bias)
+        nblk = sum(self.depths)
+        blocks = (KvqSwinBlockW * nblk)()
+        k = 0
+        for i, layer in enumerate(self.layers):
+            for blk in layer.blocks:
+                b = blocks[k]
+                k += 1
+                b.norm1_w, b.norm1_b = f32(blk.norm1.weight), f32(blk.norm1.bias)
+                b.rpb_table = f32(blk.attn.relative_position_bias_table)
+                if hasattr(blk.attn, "fragment_position_bias_table"):
+                    b.fpb_table = f32(blk.attn.fragment_position_bias_table)
+                b.qkv_w, b.qkv_b = bf16(blk.attn.qkv.weight), f32(blk.attn.qkv.bias)
+                b.proj_w, b.proj_b = bf16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
+                b.norm2_w, b.norm2_b = f32(blk.norm2.weight), f32(blk.norm2.bias)
+                b.fc1_w, b.fc1_b = bf16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
+                b.fc2_w, b.fc2_b = bf16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+            if layer.downsample is not None:
+                m = w.merges[i]
+                m.norm_w, m.norm_b = f32(layer.downsample.norm.weight), f32(layer.downsample.norm.bias)
+                m.red_w = bf16(layer.downsample.reduction.weight)
+        w.blocks = C.cast(blocks, C.POINTER(KvqSwinBlockW))
+        w.norm_w, w.norm_b = f32(self.norm.weight), f32(self.norm.bias)
+        keep.append(blocks)
+        self._wcache = (sig, w, keep)
+        return w
+
+    def _plan(self, B, T, H, W, device):
+        key = (B, T, H, W, str(device))
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        handle = C.c_void_p()
+        cfg = self.cfg_struct()
+        check(lib().kvq_swin3d_plan_create(C.byref(cfg), B, T, H, W, C.byref(handle)), "kvq_swin3d_plan_create")
+        dims = (C.c_int32 * 4)()
+        check(lib().kvq_swin3d_out_dims(handle, C.byref(dims)), "kvq_swin3d_out_dims")
+        nbytes = lib().kvq_swin3d_workspace_bytes(handle)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        entry = (handle, tuple(dims), ws)
+        self._plans[key] = entry
+        return entry
+
+    def __del__(self):
+        try:
+            for handle, _, _ in self._plans.values():
+                lib().kvq_swin3d_plan_destroy(handle)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
+        """``batch['technical']``: fp32 (B,3,T,H,W) on a HIP device -> (B, C_out, T/2, H/32, W/32)."""
+        if multi or layer > -1 or adaptive_window_size:
+            raise NotImplementedError("multi / layer taps / adaptive windows: SURVEY.md §8 row f4 (no caller sets them)")
+        x = batch["technical"]
+        if not x.is_cuda:
+            raise _abi.KvqError("SwinTransformer3D.forward needs the clip on a HIP device; there is no CPU path")
+        x = x.to(torch.float32).contiguous()
+        B, _, T, H, W = x.shape
+        handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device)
+        w = self._weights(x.device)
+        feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
+        check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), current_stream()),
+              "kvq_swin3d_forward")
+        return feat.permute(0, 4, 1, 2, 3)      # channels-last storage, reference's (B,C,D,H,W) view
+
+    # profiling hooks used by bench.py ------------------------------------------------------
+    def profile(self, B, T, H, W, device, enable: bool):
+        handle, _, _ = self._plan(B, T, H, W, device)
+        check(lib().kvq_swin3d_profile(handle, int(enable)), "kvq_swin3d_profile")
+
+    def profile_read(self, B, T, H, W, device):
+        handle, _, _ = self._plan(B, T, H, W, device)
+        ms = (C.c_float * _abi.K_COUNT)()
+        n = (C.c_int32 * _abi.K_COUNT)()
+        check(lib().kvq_swin3d_profile_read(handle, C.byref(ms), C.byref(n)), "kvq_swin3d_profile_read")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_abi.K_NAMES)}
+
+
+def swin_3d_tiny(**kwargs):
+    """``swin_backbone.py:1088-1090``: no fragment tables (the gate is computed but unused)."""
+    return SwinTransformer3D(depths=[2, 2, 6, 2], frag_biases=[0, 0, 0, 0], **kwargs)
+
+
+def swin_3d_small(**kwargs):
+    return SwinTransformer3D(depths=[2, 2, 18, 2], frag_biases=[0, 0, 0, 0], **kwargs)

@@ -169,31 +169,46 @@ def window_attention(xw: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, num
                      window, layout, chunk: int = 64) -> torch.Tensor:
     """xw (B*nW,N,C) -> (B*nW,N,C).  Implements SURVEY.md App. A item 3."""
     BW, N, C = xw.shape
-    nW, hd = layout["nW"], C // num_heads
+    hd = C // num_heads
     qkv = F.linear(xw, p[pre + "qkv.weight"], p[pre + "qkv.bias"]).reshape(BW, N, 3, num_heads, hd)
     q = qkv[:, :, 0].permute(0, 2, 1, 3) * (hd ** -0.5)
     k = qkv[:, :, 1].permute(0, 2, 1, 3)
     v = qkv[:, :, 2].permute(0, 2, 1, 3)
+    out = attention_core(q, k, v, p[pre + "relative_position_bias_table"],
+                         p.get(pre + "fragment_position_bias_table"), window, layout, chunk)
+    return F.linear(out, p[pre + "proj.weight"], p[pre + "proj.bias"])
+
+
+def attention_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], window, layout) -> torch.Tensor:
+    """(nW,nH,N,N) additive term: gated table bias (+ shift mask)."""
+    N, nW, nH = layout["N"], layout["nW"], rpb_table.shape[1]
     rpi = _t(rel_pos_index(window, N)).reshape(-1)
-    rpb = p[pre + "relative_position_bias_table"][rpi].reshape(N, N, num_heads).permute(2, 0, 1)
-    fkey = pre + "fragment_position_bias_table"
+    rpb = rpb_table[rpi].reshape(N, N, nH).permute(2, 0, 1)
     g = _t(frag_gate(layout)).to(torch.float32)                     # (nW,N,N)
-    if fkey in p:
-        fpb = p[fkey][rpi].reshape(N, N, num_heads).permute(2, 0, 1)
-        bias = rpb[None] * g[:, None] + fpb[None] * (1.0 - g[:, None])   # (nW,nH,N,N)
+    if fpb_table is not None:
+        fpb = fpb_table[rpi].reshape(N, N, nH).permute(2, 0, 1)
+        bias = rpb[None] * g[:, None] + fpb[None] * (1.0 - g[:, None])
     else:
         bias = rpb[None].expand(nW, -1, -1, -1)
     m = shift_mask(layout)
     if m is not None:
         bias = bias + _t(m)[:, None]
-    out = torch.empty(BW, N, C, dtype=xw.dtype)
+    return bias
+
+
+def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 64) -> torch.Tensor:
+    """q (pre-scaled), k, v: (B*nW, nH, N, hd) -> (B*nW, N, nH*hd)."""
+    BW, nH, N, hd = q.shape
+    nW = layout["nW"]
+    bias = attention_bias(rpb_table, fpb_table, window, layout)
+    out = torch.empty(BW, N, nH * hd, dtype=q.dtype)
     widx = torch.arange(BW) % nW
     for s in range(0, BW, chunk):
         e = min(BW, s + chunk)
         a = q[s:e] @ k[s:e].transpose(-2, -1) + bias[widx[s:e]]
         a = torch.softmax(a, dim=-1)
-        out[s:e] = (a @ v[s:e]).transpose(1, 2).reshape(e - s, N, C)
-    return F.linear(out, p[pre + "proj.weight"], p[pre + "proj.bias"])
+        out[s:e] = (a @ v[s:e]).transpose(1, 2).reshape(e - s, N, nH * hd)
+    return out
 
 
 def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift) -> torch.Tensor:

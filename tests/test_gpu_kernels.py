@@ -1,0 +1,299 @@
+"""GPU parity, kernel by kernel: every C-ABI entry point against the CPU oracle on the same
+seeded inputs.  Tolerances are stated per test: integer/byte work is bit-exact; bf16-operand
+MFMA work is compared against fp32 math on the *same bf16-rounded operands*."""
+import numpy as np
+import pytest
+import torch
+
+import kvq_amd  # noqa: F401
+from kvq_amd import _abi, kernels
+from kvq_amd.utils import synth
+from oracle import sampler_oracle as SO
+from oracle import swin3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def bf(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 -> fp32 (the rounding the kernels apply to MFMA operands)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+def test_library_loads_on_gpu():
+    assert torch.cuda.is_available()
+    name = kernels.device_name()
+    assert "gfx950" in name, name
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(200, 96, 96), (1000, 288, 96), (130, 768, 3072), (8960, 1152, 384),
+                                    (3136, 64, 768), (64 * 9 + 5, 2304, 768)])
+def test_gemm_store_and_bias(M, N, K):
+    g = rng(M + N + K)
+    A = bf(torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)))
+    W = bf(torch.from_numpy(g.standard_normal((N, K)).astype(np.float32)))
+    b = torch.from_numpy(g.standard_normal(N).astype(np.float32))
+    ref = A.double() @ W.double().t() + b.double()
+    out = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_STORE_F32)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-4 * np.sqrt(K), err       # fp32 accumulation order only
+    out_bf = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_BIAS_BF16)
+    assert (out_bf.float().cpu().double() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
+    out_g = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_GELU_BF16)
+    ref_g = torch.nn.functional.gelu(ref.float())
+    assert (out_g.float().cpu() - ref_g).abs().max().item() <= 2 ** -8 * ref_g.abs().max().item() + 1e-3
+
+
+def test_gemm_no_bias_and_asymmetric_layout():
+    # A = I (padded) with an asymmetric W catches a transposed C-write or swapped operands
+    M = N = K = 128
+    A = torch.eye(M)
+    W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125
+    out = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), None, _abi.EPI_STORE_F32)
+    assert torch.equal(out.cpu(), W.t().contiguous())
+
+
+def test_gemm_qkv_epilogue():
+    g = rng(5)
+    nH, M, C = 3, 392 * 2, 96
+    A = bf(torch.from_numpy(g.standard_normal((M, C)).astype(np.float32)))
+    W = bf(torch.from_numpy(g.standard_normal((3 * C, C)).astype(np.float32) * 0.2))
+    b = torch.from_numpy(g.standard_normal(3 * C).astype(np.float32))
+    scale = 32 ** -0.5
+    out = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_QKV_BF16, num_heads=nH,
+                       q_scale=scale)
+    ref = (A @ W.t() + b).reshape(M, 3, nH, 32).permute(1, 2, 0, 3).clone()
+    ref[0] *= scale
+    assert out.shape == (3, nH, M, 32)
+    assert (out.float().cpu() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
+
+
+def test_gemm_residual_scatter():
+    g = rng(6)
+    lay = O.window_layout(4, 10, 9, (8, 7, 7), (4, 3, 3))       # padded + shifted: rows dropped and permuted
+    Lp, L, B, C = lay["nW"] * lay["N"], 4 * 10 * 9, 2, 96
+    A = bf(torch.from_numpy(g.standard_normal((B * Lp, C)).astype(np.float32)))
+    W = bf(torch.from_numpy(g.standard_normal((C, C)).astype(np.float32) * 0.2))
+    b = torch.from_numpy(g.standard_normal(C).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((B * L, C)).astype(np.float32))
+    src = torch.from_numpy(lay["src"].astype(np.int32))
+    xd = dev(x.clone())
+    kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_RESID_F32, out=xd,
+                 scatter_map=dev(src), map_rows=Lp, out_rows=L)
+    y = (A @ W.t() + b).reshape(B, Lp, C)
+    ref = x.reshape(B, L, C) + O.scatter_windows(y, lay, B, 4, 10, 9).reshape(B, L, C)
+    assert (xd.cpu().reshape(B, L, C) - ref).abs().max().item() <= 1e-4
+    # identity map
+    x2 = dev(x[:300].clone())
+    A2 = A[:300]
+    kernels.gemm(dev(A2, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_RESID_F32, out=x2)
+    assert (x2.cpu() - (x[:300] + A2 @ W.t() + b)).abs().max().item() <= 1e-4
+
+
+def test_gemm_rejects_bad_shapes():
+    A = torch.zeros(8, 40, dtype=torch.bfloat16, device=DEV)
+    W = torch.zeros(32, 40, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_abi.KvqError, match="K%32"):
+        kernels.gemm(A, W, None, _abi.EPI_STORE_F32)
+
+
+# -------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("C", [96, 128, 192, 384, 768, 1024])
+def test_layernorm_identity(C):
+    g = rng(C)
+    x = torch.from_numpy((g.standard_normal((777, C)) * 3 + 1.5).astype(np.float32))
+    ga = torch.from_numpy((1 + 0.1 * g.standard_normal(C)).astype(np.float32))
+    be = torch.from_numpy((0.1 * g.standard_normal(C)).astype(np.float32))
+    ref = torch.nn.functional.layer_norm(x, (C,), ga, be)
+    out = kernels.layernorm_rows(dev(x), dev(ga), dev(be), out_dtype=torch.float32)
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5
+    out_bf = kernels.layernorm_rows(dev(x), dev(ga), dev(be), out_dtype=torch.bfloat16)
+    assert torch.equal(out_bf.cpu(), out.cpu().to(torch.bfloat16))      # same values, RNE rounding
+
+
+@pytest.mark.parametrize("dims,shift", [((8, 14, 14), (0, 0, 0)), ((8, 14, 14), (4, 3, 3)), ((4, 10, 9), (4, 3, 3)),
+                                        ((10, 9, 23), (4, 3, 3))])
+def test_layernorm_window_gather(dims, shift):
+    D, H, W = dims
+    g = rng(sum(dims))
+    C, B = 96, 2
+    x = torch.from_numpy(g.standard_normal((B, D, H, W, C)).astype(np.float32))
+    ga = torch.from_numpy((1 + 0.1 * g.standard_normal(C)).astype(np.float32))
+    be = torch.from_numpy((0.1 * g.standard_normal(C)).astype(np.float32))
+    lay = O.window_layout(D, H, W, (8, 7, 7), shift)
+    ref = O.gather_windows(torch.nn.functional.layer_norm(x, (C,), ga, be), lay).reshape(-1, C)
+    src = dev(torch.from_numpy(lay["src"].astype(np.int32)))
+    out = kernels.layernorm_rows(dev(x.reshape(-1, C)), dev(ga), dev(be), index_map=src, n_batch=B,
+                                 rows_out=lay["nW"] * lay["N"], out_dtype=torch.float32)
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5
+    pad = torch.from_numpy(np.tile(lay["src"] < 0, B))
+    assert torch.all(out.cpu()[pad] == 0)            # pad AFTER the norm: exact zeros, not beta
+
+
+def test_layernorm_merge_gather_odd_dims():
+    g = rng(9)
+    B, D, H, W, C = 2, 3, 5, 7, 96
+    x = torch.from_numpy(g.standard_normal((B, D, H, W, C)).astype(np.float32))
+    p = {"m.norm.weight": torch.from_numpy((1 + 0.1 * g.standard_normal(4 * C)).astype(np.float32)),
+         "m.norm.bias": torch.from_numpy((0.1 * g.standard_normal(4 * C)).astype(np.float32)),
+         "m.reduction.weight": torch.eye(4 * C)}
+    ref = O.patch_merge(x, p, "m.").reshape(-1, 4 * C)          # identity reduction -> the normalised concat
+    Hn, Wn = 3, 4
+    mp = np.full((D, Hn, Wn, 4), -1, np.int32)
+    for d in range(D):
+        for h2 in range(Hn):
+            for w2 in range(Wn):
+                for part, (dh, dw) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+                    hh, ww = 2 * h2 + dh, 2 * w2 + dw
+                    if hh < H and ww < W:
+                        mp[d, h2, w2, part] = (d * H + hh) * W + ww
+    out = kernels.layernorm_rows(dev(x.reshape(-1, C)), dev(p["m.norm.weight"]), dev(p["m.norm.bias"]),
+                                 index_map=dev(torch.from_numpy(mp.reshape(-1, 4))), nparts=4, n_batch=B,
+                                 rows_out=D * Hn * Wn, out_dtype=torch.float32)
+    assert (out.cpu() - ref).abs().max().item() <= 3e-5
+
+
+# ------------------------------------------------------------------------------- window attention
+def _tok_table(lay, window):
+    N, nW = lay["N"], lay["nW"]
+    Wd, Wh, Ww = window
+    n = np.arange(N)
+    code = (n // (Wh * Ww)) * (2 * Wh - 1) * (2 * Ww - 1) + ((n // Ww) % Wh) * (2 * Ww - 1) + n % Ww
+    desc = lay["frag"][:, 0] | (lay["frag"][:, 1] << 8) | (lay["region"] << 16)
+    tok = np.stack([np.tile(code, nW), desc], -1).astype(np.int32)
+    center = (Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1) + (Wh - 1) * (2 * Ww - 1) + (Ww - 1)
+    return tok, center
+
+
+@pytest.mark.parametrize("dims,window,shifted,gated,nH", [
+    ((8, 14, 14), (8, 7, 7), False, True, 3),
+    ((8, 14, 14), (8, 7, 7), True, True, 3),
+    ((16, 7, 7), (8, 7, 7), True, False, 2),      # stage-3 like: spatial shift clamped away, no fragment table
+    ((4, 10, 9), (8, 7, 7), True, True, 1),       # clamped depth (N=196) + padding
+    ((8, 8, 8), (4, 4, 4), True, False, 2),       # swin_tiny_grpb_m window
+    ((8, 14, 14), (8, 7, 7), False, False, 6),
+])
+def test_window_attention(dims, window, shifted, gated, nH):
+    g = rng(sum(dims) + nH)
+    shift = tuple(w // 2 for w in window) if shifted else (0, 0, 0)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, B = lay["N"], lay["nW"], 2
+    BW = B * nW
+    tl = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+    q = bf(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)) * 0.6)
+    k = bf(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)))
+    v = bf(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)))
+    rpb = torch.from_numpy(g.standard_normal((tl, nH)).astype(np.float32))
+    fpb = torch.from_numpy(g.standard_normal((tl, nH)).astype(np.float32)) if gated else None
+    ref = O.attention_core(q, k, v, rpb, fpb, window, lay).reshape(BW * N, nH * 32)
+    tok, center = _tok_table(lay, window)
+    qkv = torch.stack([q, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, BW * N, 32).contiguous()
+    use_mask = any(s > 0 for s in lay["ss"])
+    out = kernels.window_attention(dev(qkv, torch.bfloat16), dev(torch.from_numpy(tok)), dev(rpb),
+                                   None if fpb is None else dev(fpb), center, nW, N, use_mask)
+    err = (out.float().cpu() - ref).abs().max().item()
+    # P and the output are rounded to bf16: 2^-8 relative on O(1) values
+    assert err <= 2.5e-2, err
+    assert (out.float().cpu() - ref).abs().mean().item() <= 2e-3
+
+
+def test_window_attention_softmax_extremes():
+    """One key dominating by > 80 in the logits, and the -100 mask, must not produce NaN/Inf."""
+    g = rng(3)
+    lay = O.window_layout(8, 14, 14, (8, 7, 7), (4, 3, 3))
+    N, nW, nH = lay["N"], lay["nW"], 1
+    q = torch.zeros(nW, nH, N, 32)
+    k = torch.zeros(nW, nH, N, 32)
+    q[:, :, :, 0] = 16.0
+    k[:, :, 17, 0] = 6.0
+    v = bf(torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32)))
+    rpb = torch.zeros(2535, 1)
+    ref = O.attention_core(q, k, v, rpb, None, (8, 7, 7), lay).reshape(nW * N, 32)
+    tok, center = _tok_table(lay, (8, 7, 7))
+    qkv = torch.stack([q, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, nW * N, 32).contiguous()
+    out = kernels.window_attention(dev(qkv, torch.bfloat16), dev(torch.from_numpy(tok)), dev(rpb), None, center, nW,
+                                   N, True).float().cpu()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 2.5e-2
+
+
+def test_window_attention_rejects_large_window():
+    with pytest.raises(_abi.KvqError, match="unsupported"):
+        kernels.window_attention(torch.zeros(3, 1, 512, 32, dtype=torch.bfloat16, device=DEV),
+                                 torch.zeros(512, 2, dtype=torch.int32, device=DEV),
+                                 torch.zeros(10, 1, device=DEV), None, 0, 1, 512, False)
+
+
+# ------------------------------------------------------------------------- embed / heads / sampler
+@pytest.mark.parametrize("shape", [(2, 3, 8, 32, 32), (1, 3, 7, 30, 27)])
+def test_patch_im2col(shape):
+    g = rng(sum(shape))
+    x = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+    B, Cin, T, H, W = shape
+    out = kernels.patch_im2col(dev(x), (2, 4, 4)).float().cpu()
+    xp = torch.nn.functional.pad(x, (0, (-W) % 4, 0, (-H) % 4, 0, (-T) % 2))
+    D, Hh, Ww = xp.shape[2] // 2, xp.shape[3] // 4, xp.shape[4] // 4
+    ref = xp.reshape(B, Cin, D, 2, Hh, 4, Ww, 4).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * D * Hh * Ww, -1)
+    assert torch.equal(out, bf(ref))
+
+
+def test_vqa_head_layouts():
+    g = rng(77)
+    feat = torch.from_numpy(g.standard_normal((3, 768, 4, 7, 7)).astype(np.float32))
+    hw = synth.synth_vqa_head_weights(768, 64, 5, "stress")
+    ref = O.vqa_head(feat, hw)
+    w = {k: dev(torch.from_numpy(v)) for k, v in hw.items()}
+    args = (w["fc_hid.weight"].reshape(64, 768), w["fc_hid.bias"], w["fc_last.weight"].reshape(-1), w["fc_last.bias"])
+    out_cf = kernels.vqa_head(dev(feat), *args)                                         # (B,C,D,H,W) contiguous
+    cl = dev(feat).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)          # channels-last view
+    out_cl = kernels.vqa_head(cl, *args)
+    assert (out_cf.cpu() - ref).abs().max().item() <= 2e-5
+    assert (out_cl.cpu() - ref).abs().max().item() <= 2e-5
+
+
+def test_simple_vqa_head():
+    g = rng(78)
+    feat = torch.from_numpy(g.standard_normal((2, 8, 9472)).astype(np.float32))
+    hw = synth.synth_simple_head_weights(9472, 128, 5, "stress")
+    ref = O.simple_vqa_head(feat, hw)
+    w = {k: dev(torch.from_numpy(v)) for k, v in hw.items()}
+    out = kernels.simple_vqa_head(dev(feat), w["quality.0.weight"], w["quality.0.bias"],
+                                  w["quality.1.weight"].reshape(-1), w["quality.1.bias"])
+    assert (out.cpu() - ref).abs().max().item() <= 5e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("T,H,W,Fh,Fw,fs,al", [(16, 400, 720, 9, 9, 32, 8), (32, 270, 480, 7, 7, 32, 8),
+                                               (8, 224, 230, 7, 7, 32, 4)])
+def test_fragment_gather_bit_exact(T, H, W, Fh, Fw, fs, al):
+    g = rng(T + H)
+    video = g.integers(0, 256, size=(3, T, H, W), dtype=np.uint8)
+    rh, rw = synth.synth_fragment_offsets(T, T, H, W, Fh, Fw, fs, fs, al)
+    ref_raw = SO.spatial_fragments(video.astype(np.float32), rh, rw, Fh, Fw, fs, fs, al)
+    ref = SO.normalize(ref_raw, synth.KVQ_MEAN, synth.KVQ_STD)
+    hoff = rh + SO.fragment_grid(H, Fh, fs)[:, None, None].astype(np.int32)
+    woff = rw + SO.fragment_grid(W, Fw, fs)[None, :, None].astype(np.int32)
+    args = (dev(torch.from_numpy(hoff)), dev(torch.from_numpy(woff)), Fh, Fw, fs, fs, al)
+    out_u8 = kernels.fragment_gather(dev(torch.from_numpy(video)), *args, mean=synth.KVQ_MEAN, std=synth.KVQ_STD)
+    out_f32 = kernels.fragment_gather(dev(torch.from_numpy(video.astype(np.float32))), *args, mean=synth.KVQ_MEAN,
+                                      std=synth.KVQ_STD)
+    raw = kernels.fragment_gather(dev(torch.from_numpy(video)), *args)
+    assert np.array_equal(raw.cpu().numpy(), ref_raw)
+    assert np.array_equal(out_u8.cpu().numpy(), ref)          # (v-mean)/std in fp32: bit-exact
+    assert np.array_equal(out_f32.cpu().numpy(), ref)
+
+
+def test_fragment_gather_reference_assert():
+    v = torch.zeros(3, 10, 224, 224, dtype=torch.uint8, device=DEV)
+    z = torch.zeros(7, 7, 1, dtype=torch.int32, device=DEV)
+    with pytest.raises(AssertionError, match="Please provide match vclip and align index"):
+        kernels.fragment_gather(v, z, z, 7, 7, 32, 32, 8)
