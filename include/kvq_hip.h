@@ -14,7 +14,8 @@
  *   - every launch goes to the hipStream_t passed in (void* here so the header needs no HIP
  *     include); calls are asynchronous, never synchronise the device, and are graph-capturable;
  *   - return value: 0 = ok, <0 = KvqStatus; kvq_last_error() gives the message (thread-local);
- *   - bf16 = raw uint16_t bit patterns (round-to-nearest-even of fp32).
+ *   - 16-bit operands (bf16 or fp16, see KvqDtype) travel as raw uint16_t bit patterns
+ *     (round-to-nearest-even of fp32).
  *   - no exceptions / abort() cross this boundary.
  */
 #ifndef KVQ_HIP_H
@@ -27,8 +28,13 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 1
+#define KVQ_ABI_VERSION 2
 #define KVQ_MAX_STAGES 4
+
+/* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
+ * agree).  Same MFMA rate and bytes; fp16 (11-bit mantissa, saturating conversions) is the default of
+ * the host wrapper because it holds the 1e-3 MOS parity gate where bf16 (8-bit mantissa) does not. */
+typedef enum { KVQ_DT_BF16 = 0, KVQ_DT_FP16 = 1 } KvqDtype;
 
 typedef enum {
   KVQ_OK = 0,
@@ -103,7 +109,8 @@ typedef struct {
  * (swin_backbone.py:559-586) and global_position_index (:21-50). */
 typedef struct KvqSwinPlan KvqSwinPlan;
 
-int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H, int W, KvqSwinPlan** out);
+int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H, int W, int dtype /*KvqDtype*/,
+                           KvqSwinPlan** out);
 void kvq_swin3d_plan_destroy(KvqSwinPlan* plan);
 size_t kvq_swin3d_workspace_bytes(const KvqSwinPlan* plan);
 /* Output geometry: C_out, D, H', W' of the (B, C_out, D, H', W') feature map. */
@@ -123,9 +130,17 @@ enum {
   KVQ_K_IM2COL = 0, KVQ_K_LAYERNORM, KVQ_K_GEMM_QKV, KVQ_K_ATTN, KVQ_K_GEMM_PROJ, KVQ_K_GEMM_FC1,
   KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_COUNT
 };
+typedef struct {
+  int32_t kind;     /* KVQ_K_*                                                                    */
+  int32_t variant;  /* kernel instantiation: GEMM (MI*100+BK)*10+epilogue; attention 2*gated+mask */
+  float ms;         /* hipEventElapsedTime around the launch, on the launch stream                */
+  double flops;     /* algorithmic flops of the launch (2MNK; attention 4*rows*N*C)               */
+  double bytes;     /* algorithmic HBM bytes of the launch (operands read once, result written once) */
+} KvqProfRecord;
 int kvq_swin3d_profile(KvqSwinPlan* plan, int enable);
-/* Synchronises the recorded events (host blocks), fills ms[KVQ_K_COUNT] and launches[KVQ_K_COUNT]. */
-int kvq_swin3d_profile_read(KvqSwinPlan* plan, float* host_ms, int32_t* host_launches);
+/* Synchronises the recorded events (host blocks) and copies up to max_records per-launch records
+ * (in launch order) of every forward issued since profiling was enabled / last read. */
+int kvq_swin3d_profile_read(KvqSwinPlan* plan, KvqProfRecord* host_out, int max_records, int* n_records);
 
 /* ---------------------------------------------------------------------------------------------
  * Individual kernels (exported for the parity tests; kvq_swin3d_forward is built from them).
@@ -139,10 +154,10 @@ int kvq_swin3d_profile_read(KvqSwinPlan* plan, float* host_ms, int32_t* host_lau
  *   out row r of batch b = LN(concat_p x[b*rows_in + map[r][p]]) over nparts*Cin channels.
  *   nparts==1 and map<0  -> the whole output row is 0 (pad AFTER the norm, :424);
  *   nparts>1  and map<0  -> that part is 0 and takes part in the statistics (pad BEFORE, :544).
- *   out_bf16 / out_f32: exactly one is non-NULL. */
+ *   out_h (16-bit, type = dtype) / out_f32: exactly one is non-NULL. */
 int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts, int n_batch, int rows_in,
                        int rows_out, int Cin, const float* gamma, const float* beta, float eps,
-                       uint16_t* out_bf16, float* out_f32, void* stream);
+                       uint16_t* out_h, int dtype, float* out_f32, void* stream);
 
 /* bf16 MFMA GEMM  acc[m][n] = sum_k A[m][k] * W[n][k]  (fp32 accumulate) with a fused epilogue. */
 typedef enum {
@@ -168,6 +183,7 @@ typedef struct {
   const int32_t* scatter_map; /* NULL = identity */
   int32_t map_rows;      /* rows per batch element in the map (windowed rows)  */
   int32_t out_rows;      /* rows per batch element in the output               */
+  int32_t dtype;         /* KvqDtype of A, W and out_bf16                      */
 } KvqGemmArgs;
 
 int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
@@ -182,12 +198,12 @@ int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
  *   out      bf16 [BW*N][nH*32]  (== (attn@v).transpose(1,2).reshape(B_,N,C), :322)        */
 int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* rpb, const float* fpb,
                          int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
-                         uint16_t* out, void* stream);
+                         int dtype, uint16_t* out, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */
 int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd, int ph, int pw,
-                     uint16_t* out, void* stream);
+                     int dtype, uint16_t* out, void* stream);
 
 /* VQAHead.forward in eval mode (models/head.py:60-68): fp32 throughout.
  *   feat  fp32 with explicit element strides (so both (B,C,D,H,W) and channels-last work)

@@ -18,6 +18,24 @@ K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "
 K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32 = range(5)
+DT_BF16, DT_FP16 = 0, 1
+ABI_VERSION = 2
+
+
+def dtype_code(dt) -> int:
+    """torch dtype / name -> KvqDtype."""
+    import torch
+    is_int = isinstance(dt, int) and not isinstance(dt, bool)
+    if (is_int and dt == DT_FP16) or (not is_int and dt in (torch.float16, "fp16", "float16")):
+        return DT_FP16
+    if (is_int and dt == DT_BF16) or (not is_int and dt in (torch.bfloat16, "bf16", "bfloat16")):
+        return DT_BF16
+    raise ValueError(f"16-bit operand dtype must be fp16 or bf16, got {dt!r}")
+
+
+def torch_dtype(code: int):
+    import torch
+    return torch.float16 if code == DT_FP16 else torch.bfloat16
 
 p_void = C.c_void_p
 
@@ -48,7 +66,12 @@ class KvqGemmArgs(C.Structure):
     _fields_ = [("A", p_void), ("W", p_void), ("bias", p_void), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
-                ("map_rows", C.c_int32), ("out_rows", C.c_int32)]
+                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32)]
+
+
+class KvqProfRecord(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("variant", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
 
 
 # every symbol include/kvq_hip.h declares: name -> (restype, argtypes)
@@ -57,19 +80,19 @@ SYMBOLS = {
     "kvq_abi_version": (i32, []),
     "kvq_last_error": (C.c_char_p, []),
     "kvq_device_name": (i32, [C.c_char_p, i32]),
-    "kvq_swin3d_plan_create": (i32, [C.POINTER(KvqSwinCfg), i32, i32, i32, i32, C.POINTER(p_void)]),
+    "kvq_swin3d_plan_create": (i32, [C.POINTER(KvqSwinCfg), i32, i32, i32, i32, i32, C.POINTER(p_void)]),
     "kvq_swin3d_plan_destroy": (None, [p_void]),
     "kvq_swin3d_workspace_bytes": (sz, [p_void]),
     "kvq_swin3d_out_dims": (i32, [p_void, C.POINTER(i32 * 4)]),
     "kvq_swin3d_forward": (i32, [p_void, C.POINTER(KvqSwinWeights), p_void, p_void, p_void, sz, p_void]),
     "kvq_swin3d_profile": (i32, [p_void, i32]),
-    "kvq_swin3d_profile_read": (i32, [p_void, C.POINTER(f32 * K_COUNT), C.POINTER(i32 * K_COUNT)]),
-    "kvq_layernorm_rows": (i32, [p_void, p_void, i32, i32, i32, i32, i32, p_void, p_void, f32, p_void, p_void,
+    "kvq_swin3d_profile_read": (i32, [p_void, C.POINTER(KvqProfRecord), i32, C.POINTER(i32)]),
+    "kvq_layernorm_rows": (i32, [p_void, p_void, i32, i32, i32, i32, i32, p_void, p_void, f32, p_void, i32, p_void,
                                  p_void]),
     "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
-    "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, p_void,
+    "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
                                    p_void]),
-    "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
+    "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_vqa_head": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, i32, p_void, p_void, p_void,
                            p_void, p_void]),
     "kvq_simple_vqa_head": (i32, [p_void, i32, i32, i32, p_void, p_void, i32, p_void, p_void, p_void, p_void,
@@ -90,6 +113,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64; import it FIRST so that this process has exactly one HIP
+    # runtime (ours resolves to the already-loaded soname).  Loading the system runtime first leaves
+    # two runtimes in the process, and streams / device pointers are not interchangeable between them.
+    import torch  # noqa: F401
     path = _build.LIB
     if _build.is_stale():
         try:
@@ -102,7 +129,7 @@ def lib() -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(handle, name)      # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if handle.kvq_abi_version() != 1:
+    if handle.kvq_abi_version() != ABI_VERSION:
         raise KvqError("libkvq_hip.so ABI version mismatch")
     _lib = handle
     return handle

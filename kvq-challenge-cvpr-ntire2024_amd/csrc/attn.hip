@@ -37,7 +37,7 @@ struct AttnParams {
 
 __device__ __forceinline__ int k_slot(int row, int g) { return row * 4 + (g ^ ((-(row >> 3)) & 3)); }
 
-template <bool GATED, bool MASK>
+template <typename E, bool GATED, bool MASK>
 __global__ __launch_bounds__(ATT_WAVES * 64) void window_attention_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Ks = reinterpret_cast<u32x4*>(smem);                                   // [416*4] 16-B slots
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void window_attention_kernel(AttnPa
     const int q0 = qt * 16;
     const int qrow = min(q0 + j, N - 1);
     // B operand of S^T = K Q^T: lane (j,g) holds Q[q0+j][8g..8g+7]
-    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qrow * 32 + g * 8);
+    using V8 = typename E::v8;
+    const V8 qf = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + g * 8);
     const int2 tq = tokL[qrow];
     const int cq = tq.x + p.center;
     const unsigned fq = (unsigned)tq.y & 0xffffu, rq = (unsigned)tq.y >> 16;
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void window_attention_kernel(AttnPa
     for (int t = 0; t < ATT_NT; ++t) {
       // A operand: MFMA row i = j  <->  key 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3)
       const int krow = 32 * (t >> 1) + 8 * (j >> 2) + 4 * (t & 1) + (j & 3);
-      const bf16x8 kf = __builtin_bit_cast(bf16x8, Ks[k_slot(krow, g)]);
-      S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const V8 kf = __builtin_bit_cast(V8, Ks[k_slot(krow, g)]);
+      S[t] = E::mfma16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r;
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void window_attention_kernel(AttnPa
       float e[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = exp2f(S[t][r] * kLog2e - mb);
-      P[t][0] = pack_bf2(e[0], e[1]);
-      P[t][1] = pack_bf2(e[2], e[3]);
-      sum += (bf2f((uint16_t)(P[t][0] & 0xffffu)) + bf2f((uint16_t)(P[t][0] >> 16))) +
-             (bf2f((uint16_t)(P[t][1] & 0xffffu)) + bf2f((uint16_t)(P[t][1] >> 16)));
+      P[t][0] = E::pack2(e[0], e[1]);
+      P[t][1] = E::pack2(e[2], e[3]);
+      sum += (E::to_f32((uint16_t)(P[t][0] & 0xffffu)) + E::to_f32((uint16_t)(P[t][0] >> 16))) +
+             (E::to_f32((uint16_t)(P[t][1] & 0xffffu)) + E::to_f32((uint16_t)(P[t][1] >> 16)));
       __builtin_amdgcn_sched_barrier(0);
     }
     sum += __shfl_xor(sum, 16);
@@ -151,11 +152,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void window_attention_kernel(AttnPa
 #pragma unroll
     for (int s = 0; s < ATT_NT / 2; ++s) {
       const u32x4 pa = {P[2 * s][0], P[2 * s][1], P[2 * s + 1][0], P[2 * s + 1][1]};
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, pa);
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vt + j * ATT_VPITCH + 32 * s + 8 * g);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vt + (j + 16) * ATT_VPITCH + 32 * s + 8 * g);
-      O0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v0, O0, 0, 0, 0);
-      O1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v1, O1, 0, 0, 0);
+      const V8 pf = __builtin_bit_cast(V8, pa);
+      const V8 v0 = *reinterpret_cast<const V8*>(Vt + j * ATT_VPITCH + 32 * s + 8 * g);
+      const V8 v1 = *reinterpret_cast<const V8*>(Vt + (j + 16) * ATT_VPITCH + 32 * s + 8 * g);
+      O0 = E::mfma16(pf, v0, O0);
+      O1 = E::mfma16(pf, v1, O1);
     }
     // ---- normalise + store.  O layout: col = feature j (+16), row = query 4g + r ----
 #pragma unroll
@@ -164,16 +165,16 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void window_attention_kernel(AttnPa
       const float inv = 1.0f / __shfl(sum, qq);
       if (q0 + qq < N) {
         uint16_t* o = p.out + ((size_t)bw * N + q0 + qq) * C + h * 32 + j;
-        o[0] = f2bf(O0[r] * inv);
-        o[16] = f2bf(O1[r] * inv);
+        o[0] = E::cvt(O0[r] * inv);
+        o[16] = E::cvt(O1[r] * inv);
       }
     }
   }
 }
 
-template <bool GATED, bool MASK>
+template <typename E, bool GATED, bool MASK>
 static int launch_attn(const AttnParams& p, size_t lds, hipStream_t st) {
-  auto kern = window_attention_kernel<GATED, MASK>;
+  auto kern = window_attention_kernel<E, GATED, MASK>;
   static size_t attr_bytes = 0;   // per instantiation: opt in to > 64 KiB of dynamic LDS once
   if (lds > attr_bytes) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -190,7 +191,7 @@ static int launch_attn(const AttnParams& p, size_t lds, hipStream_t st) {
 
 extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* rpb, const float* fpb,
                                     int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
-                                    uint16_t* out, void* stream) {
+                                    int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(qkv && tok && rpb && out, KVQ_ERR_NULL, "kvq_window_attention: NULL pointer");
   KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && table_len > 0, KVQ_ERR_SHAPE,
@@ -203,8 +204,15 @@ extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, con
   AttnParams p{qkv, tok, rpb, fpb, table_len, center, BW, nW, N, num_heads, use_mask, out};
   hipStream_t st = (hipStream_t)stream;
   const bool gated = fpb != nullptr, mask = use_mask != 0;
-  if (gated && mask) return launch_attn<true, true>(p, lds, st);
-  if (gated) return launch_attn<true, false>(p, lds, st);
-  if (mask) return launch_attn<false, true>(p, lds, st);
-  return launch_attn<false, false>(p, lds, st);
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention: dtype %d", dtype);
+  if (dtype == KVQ_DT_FP16) {
+    if (gated && mask) return launch_attn<Fp16, true, true>(p, lds, st);
+    if (gated) return launch_attn<Fp16, true, false>(p, lds, st);
+    if (mask) return launch_attn<Fp16, false, true>(p, lds, st);
+    return launch_attn<Fp16, false, false>(p, lds, st);
+  }
+  if (gated && mask) return launch_attn<Bf16, true, true>(p, lds, st);
+  if (gated) return launch_attn<Bf16, true, false>(p, lds, st);
+  if (mask) return launch_attn<Bf16, false, true>(p, lds, st);
+  return launch_attn<Bf16, false, false>(p, lds, st);
 }

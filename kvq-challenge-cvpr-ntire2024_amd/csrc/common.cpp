@@ -25,10 +25,13 @@ extern "C" const char* kvq_last_error(void) { return kvq::g_err; }
 extern "C" int kvq_device_name(char* buf, int n) {
   if (!buf || n <= 0) return KVQ_ERR_NULL;
   buf[0] = 0;
+  int count = 0;
+  KVQ_CHECK_HIP(hipGetDeviceCount(&count));
+  KVQ_REQUIRE(count > 0, KVQ_ERR_HIP, "kvq_device_name: no HIP device visible");
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return KVQ_ERR_HIP;
+  KVQ_CHECK_HIP(hipGetDevice(&dev));
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return KVQ_ERR_HIP;
+  KVQ_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
   snprintf(buf, n, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
   return KVQ_OK;
 }

@@ -52,10 +52,53 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
+// ---- 16-bit MFMA operand types.  KVQ_DT_BF16 / KVQ_DT_FP16 select one of these at run time; both
+// feed the same-rate MFMA (v_mfma_f32_*_bf16 / _f16) and move the same bytes.  fp16's 11-bit
+// mantissa is what holds the 1e-3 MOS parity gate on O(1)-logit weights;
+// conversions saturate at +-65504 instead of producing inf.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+struct Bf16 {
+  using v8 = bf16x8;
+  static __device__ __forceinline__ uint16_t cvt(float f) { return f2bf(f); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
+  static __device__ __forceinline__ float to_f32(uint16_t u) { return bf2f(u); }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+struct Fp16 {
+  using v8 = f16x8;
+  static __device__ __forceinline__ float sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+  static __device__ __forceinline__ uint16_t cvt(float f) {
+    _Float16 h = (_Float16)sat(f);
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    f16x2 v = {(_Float16)sat(lo), (_Float16)sat(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
 // exact GELU (erf), as nn.GELU() default (swin_backbone.py:72, head.py:56)
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+
+// tile variant the GEMM dispatcher picks for a shape: (MI==NI) * 100 + BK  (gemm.hip)
+int gemm_variant(int M, int N, int K);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

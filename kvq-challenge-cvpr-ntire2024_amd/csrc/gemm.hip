@@ -1,6 +1,6 @@
-// bf16 MFMA GEMM with fused epilogues for the Swin-3D trunk (gfx950).
+// 16-bit-operand MFMA GEMM with fused epilogues for the Swin-3D trunk (gfx950).
 //
-//   acc[m][n] = sum_k A[m][k] * W[n][k]      A bf16 [M][K], W bf16 [N][K] (nn.Linear layout), fp32 acc
+//   acc[m][n] = sum_k A[m][k] * W[n][k]      A [M][K], W [N][K] (nn.Linear layout) bf16|fp16, fp32 acc
 //
 // Replaces the reference's nn.Linear calls on the hot path (swin_backbone.py:254 qkv, :323 proj,
 // :84-87 fc1/fc2, :553 reduction, :726 patch-embed conv as an im2col GEMM) together with what
@@ -8,11 +8,11 @@
 // roll + crop + residual add (:472-488, :509, :514).
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid; block tile (64*MI) x (64*NI), wave tile
-// (32*MI) x (32*NI) built from v_mfma_f32_32x32x16_bf16; K staged through LDS in BK slices,
+// (32*MI) x (32*NI) built from v_mfma_f32_32x32x16_{bf16,f16}; K staged through LDS in BK slices,
 // register-prefetched (global loads of slice t+1 are in flight while slice t is multiplied),
 // double-buffered so there is one barrier per slice.  LDS rows are padded by 16 B: with a pitch of
-// BK+8 bf16 the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots (pitch/16 B is
-// odd), i.e. the fragment reads are bank-conflict free.
+// BK+8 elements the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots (pitch/16 B
+// is odd), i.e. the fragment reads are bank-conflict free.
 #include "common.hpp"
 
 namespace kvq {
@@ -22,7 +22,7 @@ struct GemmParams {
   const uint16_t* W;
   const float* bias;
   int M, N, K;
-  uint16_t* out_bf16;
+  uint16_t* out_h;
   float* out_f32;
   int num_heads;
   float q_scale;
@@ -30,16 +30,17 @@ struct GemmParams {
   int map_rows, out_rows;
 };
 
-template <int MI, int NI, int BK, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+template <typename E, int MI, int NI, int BK, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr int PITCH = BK + 8;            // bf16 elements
+  constexpr int PITCH = BK + 8;            // 16-bit elements
   constexpr int CPR = BK / 8;              // 16-B chunks per row
   constexpr int A_CHUNKS = BM * CPR / 256; // per thread
   constexpr int B_CHUNKS = BN * CPR / 256;
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // 2 * (BM + BN) * PITCH bf16
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // 2 * (BM + BN) * PITCH elements
   uint16_t* As = lds;
   uint16_t* Bs = lds + 2 * BM * PITCH;
+  using V8 = typename E::v8;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -108,16 +109,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const uint16_t* bs = Bs + buf * BN * PITCH + (wn * 32 * NI + frag_row) * PITCH + frag_k;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 af[MI], bfr[NI];
+      V8 af[MI], bfr[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * PITCH + kk * 16);
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(as + i * 32 * PITCH + kk * 16);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * PITCH + kk * 16);
+      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const V8*>(bs + j * 32 * PITCH + kk * 16);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          if (n_live[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          if (n_live[j]) acc[i][j] = E::mfma32(af[i], bfr[j], acc[i][j]);
     }
     if (kt + 1 < nk) store_slice(buf ^ 1);
     __syncthreads();
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int n = n0 + wn * 32 * NI + j * 32 + col_in;
     const float bias = p.bias ? p.bias[n] : 0.f;
     // QKV: a 32-column tile is exactly one head of one of q/k/v
-    int C = 0, which = 0, head = 0;
+    int which = 0, head = 0;
     float scale = 1.f;
     if (EPI == KVQ_EPI_QKV_BF16) {
-      C = p.N / 3;
+      const int C = p.N / 3;
       which = (n - col_in) / C;
       head = ((n - col_in) % C) >> 5;
       scale = which == 0 ? p.q_scale : 1.f;
@@ -147,11 +148,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         if (m >= p.M) continue;
         float v = acc[i][j][r] + bias;
         if (EPI == KVQ_EPI_BIAS_BF16) {
-          p.out_bf16[(size_t)m * p.N + n] = f2bf(v);
+          p.out_h[(size_t)m * p.N + n] = E::cvt(v);
         } else if (EPI == KVQ_EPI_GELU_BF16) {
-          p.out_bf16[(size_t)m * p.N + n] = f2bf(gelu_erf(v));
+          p.out_h[(size_t)m * p.N + n] = E::cvt(gelu_erf(v));
         } else if (EPI == KVQ_EPI_QKV_BF16) {
-          p.out_bf16[((size_t)(which * p.num_heads + head) * p.M + m) * 32 + col_in] = f2bf(v * scale);
+          p.out_h[((size_t)(which * p.num_heads + head) * p.M + m) * 32 + col_in] = E::cvt(v * scale);
         } else if (EPI == KVQ_EPI_RESID_F32) {
           long orow = m;
           if (p.scatter_map) {
@@ -170,11 +171,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-template <int MI, int NI, int BK, int EPI>
+template <typename E, int MI, int NI, int BK, int EPI>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr size_t lds_bytes = 2 * (BM + BN) * (BK + 8) * sizeof(uint16_t);
-  auto kern = gemm_bf16_kernel<MI, NI, BK, EPI>;
+  auto kern = gemm_kernel<E, MI, NI, BK, EPI>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -183,17 +184,28 @@ static int launch_one(const GemmParams& p, hipStream_t st) {
   }
   dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN)), block(256);
   hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
-  KVQ_CHECK_LAUNCH("gemm_bf16_kernel");
+  KVQ_CHECK_LAUNCH("gemm_kernel");
   return KVQ_OK;
 }
 
-template <int EPI>
-static int launch_gemm(const GemmParams& p, hipStream_t st) {
-  const long blocks128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+int gemm_variant(int M, int N, int K) {
+  const long blocks128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
   const bool big = blocks128 >= 512;     // >= 2 tiles per CU: use the 128x128 tile
-  const bool k64 = (p.K % 64) == 0;
-  if (big) return k64 ? launch_one<2, 2, 64, EPI>(p, st) : launch_one<2, 2, 32, EPI>(p, st);
-  return k64 ? launch_one<1, 1, 64, EPI>(p, st) : launch_one<1, 1, 32, EPI>(p, st);
+  return (big ? 2 : 1) * 100 + ((K % 64) == 0 ? 64 : 32);
+}
+
+template <typename E, int EPI>
+static int launch_gemm(const GemmParams& p, hipStream_t st) {
+  const int var = gemm_variant(p.M, p.N, p.K);
+  const bool big = var / 100 == 2;
+  const bool k64 = var % 100 == 64;
+  if (big) return k64 ? launch_one<E, 2, 2, 64, EPI>(p, st) : launch_one<E, 2, 2, 32, EPI>(p, st);
+  return k64 ? launch_one<E, 1, 1, 64, EPI>(p, st) : launch_one<E, 1, 1, 32, EPI>(p, st);
+}
+
+template <int EPI>
+static int launch_dt(int dtype, const GemmParams& p, hipStream_t st) {
+  return dtype == KVQ_DT_FP16 ? launch_gemm<Fp16, EPI>(p, st) : launch_gemm<Bf16, EPI>(p, st);
 }
 
 }  // namespace kvq
@@ -203,29 +215,31 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   KVQ_REQUIRE(a && a->A && a->W, KVQ_ERR_NULL, "kvq_gemm_bf16: NULL A/W");
   KVQ_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 32 == 0 && a->K % 32 == 0, KVQ_ERR_SHAPE,
               "kvq_gemm_bf16: need M>0, N%%32==0, K%%32==0 (got M=%d N=%d K=%d)", a->M, a->N, a->K);
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED,
+              "kvq_gemm_bf16: unknown dtype %d", a->dtype);
   GemmParams p{a->A, a->W, a->bias, a->M, a->N, a->K, a->out_bf16, a->out_f32, a->num_heads, a->q_scale,
                a->scatter_map, a->map_rows, a->out_rows};
   hipStream_t st = (hipStream_t)stream;
   switch (a->epilogue) {
     case KVQ_EPI_BIAS_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
-      return launch_gemm<KVQ_EPI_BIAS_BF16>(p, st);
+      return launch_dt<KVQ_EPI_BIAS_BF16>(a->dtype, p, st);
     case KVQ_EPI_GELU_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
-      return launch_gemm<KVQ_EPI_GELU_BF16>(p, st);
+      return launch_dt<KVQ_EPI_GELU_BF16>(a->dtype, p, st);
     case KVQ_EPI_QKV_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
       KVQ_REQUIRE(a->num_heads > 0 && a->N == 96 * a->num_heads, KVQ_ERR_SHAPE,
                   "kvq_gemm_bf16: QKV epilogue needs N == 3*32*num_heads (N=%d nH=%d)", a->N, a->num_heads);
-      return launch_gemm<KVQ_EPI_QKV_BF16>(p, st);
+      return launch_dt<KVQ_EPI_QKV_BF16>(a->dtype, p, st);
     case KVQ_EPI_RESID_F32:
       KVQ_REQUIRE(a->out_f32, KVQ_ERR_NULL, "kvq_gemm_bf16: out_f32 NULL");
       KVQ_REQUIRE(!a->scatter_map || (a->map_rows > 0 && a->out_rows > 0), KVQ_ERR_SHAPE,
                   "kvq_gemm_bf16: scatter map needs map_rows/out_rows");
-      return launch_gemm<KVQ_EPI_RESID_F32>(p, st);
+      return launch_dt<KVQ_EPI_RESID_F32>(a->dtype, p, st);
     case KVQ_EPI_STORE_F32:
       KVQ_REQUIRE(a->out_f32, KVQ_ERR_NULL, "kvq_gemm_bf16: out_f32 NULL");
-      return launch_gemm<KVQ_EPI_STORE_F32>(p, st);
+      return launch_dt<KVQ_EPI_STORE_F32>(a->dtype, p, st);
     default:
       set_error("kvq_gemm_bf16: unknown epilogue %d", a->epilogue);
       return KVQ_ERR_UNSUPPORTED;

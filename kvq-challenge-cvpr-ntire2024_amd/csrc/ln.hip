@@ -20,11 +20,11 @@ struct LnParams {
   const float* gamma;
   const float* beta;
   float eps;
-  uint16_t* out_bf16;
+  uint16_t* out_h;
   float* out_f32;
 };
 
-template <int G, int NV>  // G lanes per row, NV float4 per lane (NV*G*4 >= C)
+template <typename E, int G, int NV>  // G lanes per row, NV float4 per lane (NV*G*4 >= C)
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
   const int C = p.nparts * p.Cin;
   const int lane_in = threadIdx.x % G;
@@ -80,51 +80,57 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[k] + be[k];
     }
-    if (p.out_bf16) {
-      u32x2 o = {pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-      *reinterpret_cast<u32x2*>(p.out_bf16 + (size_t)row * C + c) = o;
+    if (p.out_h) {
+      u32x2 o = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3])};
+      *reinterpret_cast<u32x2*>(p.out_h + (size_t)row * C + c) = o;
     } else {
       *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * C + c) = y;
     }
   }
 }
 
-template <int G, int NV>
-static int launch_ln(const LnParams& p, hipStream_t st) {
+template <typename E, int G, int NV>
+static int launch_ln_e(const LnParams& p, hipStream_t st) {
   const long total = (long)p.n_batch * p.rows_out;
   const int rows_per_block = 256 / G;
   dim3 grid((unsigned)((total + rows_per_block - 1) / rows_per_block)), block(256);
-  hipLaunchKernelGGL((layernorm_rows_kernel<G, NV>), grid, block, 0, st, p);
+  hipLaunchKernelGGL((layernorm_rows_kernel<E, G, NV>), grid, block, 0, st, p);
   KVQ_CHECK_LAUNCH("layernorm_rows_kernel");
   return KVQ_OK;
+}
+
+template <int G, int NV>
+static int launch_ln(const LnParams& p, int dtype, hipStream_t st) {
+  return dtype == KVQ_DT_FP16 ? launch_ln_e<Fp16, G, NV>(p, st) : launch_ln_e<Bf16, G, NV>(p, st);
 }
 
 }  // namespace kvq
 
 extern "C" int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts, int n_batch, int rows_in,
                                   int rows_out, int Cin, const float* gamma, const float* beta, float eps,
-                                  uint16_t* out_bf16, float* out_f32, void* stream) {
+                                  uint16_t* out_h, int dtype, float* out_f32, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(x && gamma && beta, KVQ_ERR_NULL, "kvq_layernorm_rows: NULL input");
-  KVQ_REQUIRE((out_bf16 != nullptr) != (out_f32 != nullptr), KVQ_ERR_NULL,
-              "kvq_layernorm_rows: exactly one of out_bf16/out_f32 must be set");
+  KVQ_REQUIRE((out_h != nullptr) != (out_f32 != nullptr), KVQ_ERR_NULL,
+              "kvq_layernorm_rows: exactly one of out_h/out_f32 must be set");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_layernorm_rows: dtype %d", dtype);
   KVQ_REQUIRE(nparts >= 1 && n_batch > 0 && rows_in > 0 && rows_out > 0 && Cin > 0 && Cin % 4 == 0,
               KVQ_ERR_SHAPE, "kvq_layernorm_rows: bad shape (nparts=%d n_batch=%d rows=%d/%d Cin=%d)", nparts,
               n_batch, rows_in, rows_out, Cin);
   KVQ_REQUIRE(map || (nparts == 1 && rows_in == rows_out), KVQ_ERR_SHAPE,
               "kvq_layernorm_rows: identity map needs nparts==1 and rows_in==rows_out");
   const int C = nparts * Cin;
-  LnParams p{x, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_bf16, out_f32};
+  LnParams p{x, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_h, out_f32};
   hipStream_t st = (hipStream_t)stream;
   const int nvec = C / 4;
-  if (nvec <= 16) return launch_ln<16, 1>(p, st);
-  if (nvec <= 32) return launch_ln<32, 1>(p, st);
-  if (nvec <= 64) return launch_ln<64, 1>(p, st);
-  if (nvec <= 128) return launch_ln<64, 2>(p, st);
-  if (nvec <= 192) return launch_ln<64, 3>(p, st);
-  if (nvec <= 256) return launch_ln<64, 4>(p, st);
-  if (nvec <= 512) return launch_ln<64, 8>(p, st);
-  if (nvec <= 1024) return launch_ln<64, 16>(p, st);
+  if (nvec <= 16) return launch_ln<16, 1>(p, dtype, st);
+  if (nvec <= 32) return launch_ln<32, 1>(p, dtype, st);
+  if (nvec <= 64) return launch_ln<64, 1>(p, dtype, st);
+  if (nvec <= 128) return launch_ln<64, 2>(p, dtype, st);
+  if (nvec <= 192) return launch_ln<64, 3>(p, dtype, st);
+  if (nvec <= 256) return launch_ln<64, 4>(p, dtype, st);
+  if (nvec <= 512) return launch_ln<64, 8>(p, dtype, st);
+  if (nvec <= 1024) return launch_ln<64, 16>(p, dtype, st);
   set_error("kvq_layernorm_rows: C=%d > 4096 unsupported", C);
   return KVQ_ERR_UNSUPPORTED;
 }

@@ -8,6 +8,7 @@ namespace kvq {
 // consecutive input pixels -> pw consecutive bf16 of the GEMM row.  Row layout (c,kd,kh,kw) equals
 // Conv3d weight.flatten(1).  Out-of-range (zero-padded tail) pixels read as 0.
 // ------------------------------------------------------------------------------------------------
+template <typename E>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int Cin, int T, int H,
                                                            int W, int pd, int ph, int pw, int D, int Hh, int Ww,
                                                            uint16_t* __restrict__ out) {
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     uint16_t* o = out + tok * (size_t)(runs_per_tok * pw) + ((size_t)(c * pd + kd) * ph + kh) * pw;
     const bool in = tt < T && hh < H;
     const float* src = x + (((size_t)b * Cin + c) * T + tt) * (size_t)H * W + (size_t)hh * W + w0;
-    for (int k = 0; k < pw; ++k) o[k] = f2bf((in && w0 + k < W) ? src[k] : 0.f);
+    for (int k = 0; k < pw; ++k) o[k] = E::cvt((in && w0 + k < W) ? src[k] : 0.f);
   }
 }
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p) {
 }  // namespace kvq
 
 extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd, int ph, int pw,
-                                uint16_t* out, void* stream) {
+                                int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(x && out, KVQ_ERR_NULL, "kvq_patch_im2col: NULL pointer");
   KVQ_REQUIRE(B > 0 && Cin > 0 && T > 0 && H > 0 && W > 0 && pd > 0 && ph > 0 && pw > 0, KVQ_ERR_SHAPE,
@@ -171,8 +172,13 @@ extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, in
   const int D = ceil_div(T, pd), Hh = ceil_div(H, ph), Ww = ceil_div(W, pw);
   const long total = (long)B * D * Hh * Ww * Cin * pd * ph;
   const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-  hipLaunchKernelGGL(patch_im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, Cin, T, H, W, pd, ph,
-                     pw, D, Hh, Ww, out);
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_patch_im2col: dtype %d", dtype);
+  if (dtype == KVQ_DT_FP16)
+    hipLaunchKernelGGL(patch_im2col_kernel<Fp16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, Cin, T, H, W,
+                       pd, ph, pw, D, Hh, Ww, out);
+  else
+    hipLaunchKernelGGL(patch_im2col_kernel<Bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, Cin, T, H, W,
+                       pd, ph, pw, D, Hh, Ww, out);
   KVQ_CHECK_LAUNCH("patch_im2col_kernel");
   return KVQ_OK;
 }

@@ -31,7 +31,8 @@ struct StageGeom {
 };
 
 struct ProfEvent {
-  int kind;
+  int kind, variant;
+  double flops, bytes;   // ALGORITHMIC work of the launch
   hipEvent_t a, b;
 };
 
@@ -39,7 +40,7 @@ struct ProfEvent {
 
 struct KvqSwinPlan {
   KvqSwinCfg cfg;
-  int B, T, H, W;
+  int B, T, H, W, dtype;
   int D0, H0, W0, K0;
   std::vector<kvq::StageGeom> st;
   std::vector<void*> owned;      // device allocations to free
@@ -149,12 +150,14 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace kvq
 
-extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H, int W, KvqSwinPlan** out) {
+extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H, int W, int dtype,
+                                      KvqSwinPlan** out) {
   using namespace kvq;
   KVQ_REQUIRE(cfg && out, KVQ_ERR_NULL, "kvq_swin3d_plan_create: NULL pointer");
   KVQ_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, KVQ_ERR_SHAPE, "kvq_swin3d_plan_create: bad input shape");
   KVQ_REQUIRE(cfg->num_stages >= 1 && cfg->num_stages <= KVQ_MAX_STAGES, KVQ_ERR_UNSUPPORTED, "num_stages %d",
               cfg->num_stages);
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "unknown dtype %d", dtype);
   KVQ_REQUIRE(cfg->embed_dim % 32 == 0 && (cfg->in_chans * cfg->patch[0] * cfg->patch[1] * cfg->patch[2]) % 32 == 0,
               KVQ_ERR_UNSUPPORTED, "embed_dim and in_chans*prod(patch) must be multiples of 32");
   KVQ_REQUIRE(cfg->window[0] * cfg->window[1] * cfg->window[2] <= 400, KVQ_ERR_UNSUPPORTED,
@@ -163,7 +166,7 @@ extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H
     KVQ_REQUIRE(cfg->num_heads[i] * 32 == (cfg->embed_dim << i), KVQ_ERR_UNSUPPORTED,
                 "stage %d: head_dim must be 32 (C=%d, heads=%d)", i, cfg->embed_dim << i, cfg->num_heads[i]);
   KvqSwinPlan* pl = new KvqSwinPlan();
-  pl->cfg = *cfg; pl->B = B; pl->T = T; pl->H = H; pl->W = W;
+  pl->cfg = *cfg; pl->B = B; pl->T = T; pl->H = H; pl->W = W; pl->dtype = dtype;
   pl->profile = false; pl->ev_used = 0;
   pl->D0 = ceil_div(T, cfg->patch[0]); pl->H0 = ceil_div(H, cfg->patch[1]); pl->W0 = ceil_div(W, cfg->patch[2]);
   pl->K0 = cfg->in_chans * cfg->patch[0] * cfg->patch[1] * cfg->patch[2];
@@ -224,18 +227,18 @@ extern "C" int kvq_swin3d_profile(KvqSwinPlan* pl, int enable) {
   return KVQ_OK;
 }
 
-extern "C" int kvq_swin3d_profile_read(KvqSwinPlan* pl, float* ms, int32_t* launches) {
+extern "C" int kvq_swin3d_profile_read(KvqSwinPlan* pl, KvqProfRecord* out, int max_records, int* n_records) {
   using namespace kvq;
-  KVQ_REQUIRE(pl && ms && launches, KVQ_ERR_NULL, "kvq_swin3d_profile_read: NULL");
-  for (int k = 0; k < KVQ_K_COUNT; ++k) { ms[k] = 0.f; launches[k] = 0; }
-  for (size_t i = 0; i < pl->ev_used; ++i) {
+  KVQ_REQUIRE(pl && out && n_records, KVQ_ERR_NULL, "kvq_swin3d_profile_read: NULL");
+  int n = 0;
+  for (size_t i = 0; i < pl->ev_used && n < max_records; ++i, ++n) {
     ProfEvent& e = pl->events[i];
     KVQ_CHECK_HIP(hipEventSynchronize(e.b));
     float t = 0.f;
     KVQ_CHECK_HIP(hipEventElapsedTime(&t, e.a, e.b));
-    ms[e.kind] += t;
-    launches[e.kind] += 1;
+    out[n].kind = e.kind; out[n].variant = e.variant; out[n].ms = t; out[n].flops = e.flops; out[n].bytes = e.bytes;
   }
+  *n_records = n;
   pl->ev_used = 0;
   return KVQ_OK;
 }
@@ -247,15 +250,16 @@ struct Bracket {
   KvqSwinPlan* pl;
   hipStream_t st;
   ProfEvent* e;
-  Bracket(KvqSwinPlan* p, hipStream_t s, int kind) : pl(p), st(s), e(nullptr) {
+  Bracket(KvqSwinPlan* p, hipStream_t s, int kind, int variant, double flops, double bytes)
+      : pl(p), st(s), e(nullptr) {
     if (!pl->profile) return;
     if (pl->ev_used == pl->events.size()) {
-      ProfEvent n{kind, nullptr, nullptr};
+      ProfEvent n{kind, variant, 0.0, 0.0, nullptr, nullptr};
       if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
       pl->events.push_back(n);
     }
     e = &pl->events[pl->ev_used++];
-    e->kind = kind;
+    e->kind = kind; e->variant = variant; e->flops = flops; e->bytes = bytes;
     (void)hipEventRecord(e->a, st);
   }
   ~Bracket() {
@@ -269,14 +273,19 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
   KvqGemmArgs a{};
   a.A = A; a.W = Wt; a.bias = bias; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_bf16 = obf; a.out_f32 = of32;
   a.num_heads = nH; a.q_scale = qs; a.scatter_map = map; a.map_rows = map_rows; a.out_rows = out_rows;
-  Bracket br(pl, st, kind);
+  a.dtype = pl->dtype;
+  // algorithmic bytes: A + W once, output once (fp32 residual epilogues read-modify-write)
+  const double out_b = (epi == KVQ_EPI_RESID_F32) ? 8.0 : (epi == KVQ_EPI_STORE_F32 ? 4.0 : 2.0);
+  Bracket br(pl, st, kind, gemm_variant(M, N, K) * 10 + epi, 2.0 * M * N * K,
+             2.0 * ((double)M * K + (double)N * K) + out_b * M * N);
   return kvq_gemm_bf16(&a, st);
 }
 
 static int ln(KvqSwinPlan* pl, hipStream_t st, const float* x, const int32_t* map, int nparts, int rows_in,
               int rows_out, int Cin, const float* g, const float* b, uint16_t* obf, float* of32) {
-  Bracket br(pl, st, KVQ_K_LAYERNORM);
-  return kvq_layernorm_rows(x, map, nparts, pl->B, rows_in, rows_out, Cin, g, b, 1e-5f, obf, of32, st);
+  const double elems = (double)pl->B * rows_out * nparts * Cin;
+  Bracket br(pl, st, KVQ_K_LAYERNORM, of32 ? 1 : 0, 0.0, elems * (4.0 + (of32 ? 4.0 : 2.0)));
+  return kvq_layernorm_rows(x, map, nparts, pl->B, rows_in, rows_out, Cin, g, b, 1e-5f, obf, pl->dtype, of32, st);
 }
 
 }  // namespace kvq
@@ -310,9 +319,10 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
   // ---- PatchEmbed3D: im2col -> GEMM(+bias) -> LayerNorm  (swin_backbone.py:715-733) ----
   const int L0 = pl->D0 * pl->H0 * pl->W0, E = cfg.embed_dim;
   {
-    Bracket br(pl, st, KVQ_K_IM2COL);
-    KVQ_TRY(kvq_patch_im2col(x, B, cfg.in_chans, pl->T, pl->H, pl->W, cfg.patch[0], cfg.patch[1], cfg.patch[2], bbig,
-                             st));
+    const double px = (double)B * pl->D0 * pl->H0 * pl->W0 * pl->K0;
+    Bracket br(pl, st, KVQ_K_IM2COL, 0, 0.0, px * 6.0);
+    KVQ_TRY(kvq_patch_im2col(x, B, cfg.in_chans, pl->T, pl->H, pl->W, cfg.patch[0], cfg.patch[1], cfg.patch[2], pl->dtype,
+                             bbig, st));
   }
   KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_EMBED, bbig, w->embed_w, w->embed_b, B * L0, E, pl->K0, KVQ_EPI_STORE_F32, nullptr,
                xb));
@@ -338,9 +348,11 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                    0.17677669529663687f /* 32^-0.5 */));
       {
-        Bracket br(pl, st, KVQ_K_ATTN);
+        // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
+        Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);
         KVQ_TRY(kvq_window_attention(bbig, g.d_tok[par], bw.rpb_table, cfg.frag_bias[i] ? bw.fpb_table : nullptr,
-                                     pl->table_len, pl->center, B * g.nW, g.nW, g.N, g.nH, par, bo, st));
+                                     pl->table_len, pl->center, B * g.nW, g.nW, g.N, g.nH, par, pl->dtype, bo,
+                                     st));
       }
       // proj + window_reverse + roll back + crop + residual
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,

@@ -1,7 +1,8 @@
 """Thin per-kernel wrappers over the C-ABI (torch tensors in, torch tensors out).
 
 Used by the parity tests (each kernel against the oracle) and by the modules.  PyTorch is
-only the owner of device memory and the provider of the current HIP stream here.
+only the owner of device memory and the provider of the current HIP stream here.  The 16-bit
+MFMA operand type (fp16 | bf16) is taken from the tensors' dtype.
 """
 from __future__ import annotations
 
@@ -11,7 +12,9 @@ from typing import Optional, Sequence
 import torch
 
 from . import _abi
-from ._abi import check, current_stream, lib, ptr
+from ._abi import check, current_stream, dtype_code, lib, ptr
+
+HALF_TYPES = (torch.float16, torch.bfloat16)
 
 
 def _need_gpu(*ts):
@@ -27,70 +30,76 @@ def device_name() -> str:
 
 
 def layernorm_rows(x: torch.Tensor, gamma, beta, *, index_map: Optional[torch.Tensor] = None, nparts=1,
-                   n_batch=1, rows_out: Optional[int] = None, out_dtype=torch.bfloat16, eps=1e-5):
-    """x fp32 [n_batch*rows_in, Cin]; index_map int32 [rows_out, nparts] (or None = identity)."""
+                   n_batch=1, rows_out: Optional[int] = None, out_dtype=torch.float16, eps=1e-5):
+    """x fp32 [n_batch*rows_in, Cin]; index_map int32 [rows_out, nparts] (or None = identity).
+    out_dtype: torch.float16 / torch.bfloat16 (MFMA operand) or torch.float32."""
     _need_gpu(x, gamma, beta, index_map)
     assert x.dtype == torch.float32 and x.is_contiguous()
     rows_in = x.shape[0] // n_batch
     Cin = x.shape[1]
     rows_out = rows_in if rows_out is None else rows_out
     out = torch.empty(n_batch * rows_out, nparts * Cin, dtype=out_dtype, device=x.device)
-    bf = out_dtype == torch.bfloat16
+    half = out_dtype in HALF_TYPES
     check(lib().kvq_layernorm_rows(ptr(x), ptr(index_map), nparts, n_batch, rows_in, rows_out, Cin, ptr(gamma),
-                                   ptr(beta), eps, ptr(out) if bf else None, None if bf else ptr(out),
+                                   ptr(beta), eps, ptr(out) if half else None,
+                                   dtype_code(out_dtype) if half else 0, None if half else ptr(out),
                                    current_stream()), "kvq_layernorm_rows")
     return out
 
 
 def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int, *, out=None,
          num_heads=0, q_scale=1.0, scatter_map=None, map_rows=0, out_rows=0):
-    """A bf16 [M,K], W bf16 [N,K].  Returns the output tensor (allocated unless ``out`` is given)."""
+    """A [M,K], W [N,K], both fp16 or both bf16.  Returns the output tensor (allocated unless given)."""
     _need_gpu(A, W, bias, out, scatter_map)
-    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.is_contiguous() and W.is_contiguous()
+    assert A.dtype in HALF_TYPES and W.dtype == A.dtype and A.is_contiguous() and W.is_contiguous()
     M, K = A.shape
     N = W.shape[0]
     if out is None:
         if epilogue == _abi.EPI_QKV_BF16:
-            out = torch.empty(3, num_heads, M, 32, dtype=torch.bfloat16, device=A.device)
+            out = torch.empty(3, num_heads, M, 32, dtype=A.dtype, device=A.device)
         elif epilogue in (_abi.EPI_BIAS_BF16, _abi.EPI_GELU_BF16):
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
+            out = torch.empty(M, N, dtype=A.dtype, device=A.device)
         elif epilogue == _abi.EPI_STORE_F32:
             out = torch.empty(M, N, dtype=torch.float32, device=A.device)
         else:
             raise ValueError("RESID epilogue accumulates into an existing tensor: pass out=")
     a = _abi.KvqGemmArgs()
     a.A, a.W, a.bias, a.M, a.N, a.K, a.epilogue = ptr(A), ptr(W), ptr(bias), M, N, K, epilogue
-    if out.dtype == torch.bfloat16:
+    if out.dtype in HALF_TYPES:
+        assert out.dtype == A.dtype
         a.out_bf16 = ptr(out)
     else:
         a.out_f32 = ptr(out)
     a.num_heads, a.q_scale = num_heads, q_scale
     a.scatter_map, a.map_rows, a.out_rows = ptr(scatter_map), map_rows, out_rows
+    a.dtype = dtype_code(A.dtype)
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
     return out
 
 
 def window_attention(qkv: torch.Tensor, tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor],
                      center: int, nW: int, N: int, use_mask: bool):
-    """qkv bf16 [3,nH,BW*N,32] (q pre-scaled), tok int32 [nW*N,2]; returns bf16 [BW*N, nH*32]."""
+    """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled), tok int32 [nW*N,2]; returns [BW*N, nH*32]."""
     _need_gpu(qkv, tok, rpb, fpb)
+    assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
-    out = torch.empty(BW * N, nH * 32, dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
     check(lib().kvq_window_attention(ptr(qkv), ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, BW, nW, N, nH,
-                                     int(use_mask), ptr(out), current_stream()), "kvq_window_attention")
+                                     int(use_mask), dtype_code(qkv.dtype), ptr(out), current_stream()),
+          "kvq_window_attention")
     return out
 
 
-def patch_im2col(x: torch.Tensor, patch: Sequence[int]):
+def patch_im2col(x: torch.Tensor, patch: Sequence[int], out_dtype=torch.float16):
     _need_gpu(x)
     assert x.dtype == torch.float32 and x.is_contiguous()
     B, Cin, T, H, W = x.shape
     pd, ph, pw = patch
     D, Hh, Ww = -(-T // pd), -(-H // ph), -(-W // pw)
-    out = torch.empty(B * D * Hh * Ww, Cin * pd * ph * pw, dtype=torch.bfloat16, device=x.device)
-    check(lib().kvq_patch_im2col(ptr(x), B, Cin, T, H, W, pd, ph, pw, ptr(out), current_stream()),
-          "kvq_patch_im2col")
+    out = torch.empty(B * D * Hh * Ww, Cin * pd * ph * pw, dtype=out_dtype, device=x.device)
+    check(lib().kvq_patch_im2col(ptr(x), B, Cin, T, H, W, pd, ph, pw, dtype_code(out_dtype), ptr(out),
+                                 current_stream()), "kvq_patch_im2col")
     return out
 
 
@@ -134,8 +143,8 @@ def fragment_gather(video: torch.Tensor, hoff: torch.Tensor, woff: torch.Tensor,
                       device=video.device)
     m = (C.c_float * Cc)(*mean) if mean is not None else None
     s = (C.c_float * Cc)(*std) if std is not None else None
-    check(lib().kvq_fragment_gather(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W,
-                                    ptr(hoff.contiguous()), ptr(woff.contiguous()), fragments_h, fragments_w,
-                                    fsize_h, fsize_w, aligned, m, s, ptr(out), current_stream()),
-          "kvq_fragment_gather")
+    hoff, woff = hoff.contiguous(), woff.contiguous()
+    check(lib().kvq_fragment_gather(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W, ptr(hoff), ptr(woff),
+                                    fragments_h, fragments_w, fsize_h, fsize_w, aligned, m, s, ptr(out),
+                                    current_stream()), "kvq_fragment_gather")
     return out

@@ -107,8 +107,12 @@ class SwinTransformer3D(nn.Module):
                  qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1,
                  norm_layer=nn.LayerNorm, patch_norm=True, frozen_stages=-1, use_checkpoint=True,
                  jump_attention=(False, False, False, False), frag_biases=(True, True, True, False),
-                 base_x_size=(32, 224, 224)):
+                 base_x_size=(32, 224, 224), operand_dtype=None):
         super().__init__()
+        # 16-bit MFMA operand type (extension over the reference signature): "fp16" (default; holds the
+        # 1e-3 MOS parity gate) or "bf16".  Env KVQ_OPERAND_DTYPE overrides the default.
+        import os
+        self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
         if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
             raise NotImplementedError("per-stage window sizes are not used by any reference config")
         if qk_scale is not None or any(jump_attention) or not qkv_bias:
@@ -191,19 +195,23 @@ class SwinTransformer3D(nn.Module):
     def _weights(self, device) -> KvqSwinWeights:
         """bf16 copies of the GEMM weights + a KvqSwinWeights of raw pointers; rebuilt whenever a
         parameter was modified in place or moved (tracked through tensor versions / data_ptr)."""
-        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        sig = (self.operand_dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._wcache is not None and self._wcache[0] == sig:
             return self._wcache[1]
         keep = []
+        half = _abi.torch_dtype(self.operand_dtype)
 
         def f32(p):
             t = p.detach().to(device=device, dtype=torch.float32).contiguous()
             keep.append(t)
             return ptr(t)
 
-        def bf16(p, shape=None):
+        def bf16(p, shape=None):       # GEMM weight in the 16-bit operand type (fp16 saturates, never inf)
             t = p.detach().to(device=device, dtype=torch.float32)
-            t = (t.reshape(shape) if shape is not None else t).to(torch.bfloat16).contiguous()
+            t = t.reshape(shape) if shape is not None else t
+            if half == torch.float16:
+                t = t.clamp(-65504.0, 65504.0)
+            t = t.to(half).contiguous()
             keep.append(t)
             return ptr(t)
 
@@ -240,13 +248,14 @@ class SwinTransformer3D(nn.Module):
         return w
 
     def _plan(self, B, T, H, W, device):
-        key = (B, T, H, W, str(device))
+        key = (B, T, H, W, str(device), self.operand_dtype)
         hit = self._plans.get(key)
         if hit is not None:
             return hit
         handle = C.c_void_p()
         cfg = self.cfg_struct()
-        check(lib().kvq_swin3d_plan_create(C.byref(cfg), B, T, H, W, C.byref(handle)), "kvq_swin3d_plan_create")
+        check(lib().kvq_swin3d_plan_create(C.byref(cfg), B, T, H, W, self.operand_dtype, C.byref(handle)),
+              "kvq_swin3d_plan_create")
         dims = (C.c_int32 * 4)()
         check(lib().kvq_swin3d_out_dims(handle, C.byref(dims)), "kvq_swin3d_out_dims")
         nbytes = lib().kvq_swin3d_workspace_bytes(handle)
@@ -286,10 +295,26 @@ class SwinTransformer3D(nn.Module):
 
     def profile_read(self, B, T, H, W, device):
         handle, _, _ = self._plan(B, T, H, W, device)
-        ms = (C.c_float * _abi.K_COUNT)()
-        n = (C.c_int32 * _abi.K_COUNT)()
-        check(lib().kvq_swin3d_profile_read(handle, C.byref(ms), C.byref(n)), "kvq_swin3d_profile_read")
-        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_abi.K_NAMES)}
+        cap = 65536
+        recs = (_abi.KvqProfRecord * cap)()
+        n = C.c_int32(0)
+        check(lib().kvq_swin3d_profile_read(handle, recs, cap, C.byref(n)), "kvq_swin3d_profile_read")
+        ename = "kvq::Fp16" if self.operand_dtype == _abi.DT_FP16 else "kvq::Bf16"
+        out = []
+        for r in recs[: n.value]:
+            kind = _abi.K_NAMES[r.kind]
+            if kind.startswith("gemm"):
+                tile, epi = divmod(r.variant, 10)
+                mi, bk = divmod(tile, 100)
+                sym = f"gemm_kernel<{ename}, {mi}, {mi}, {bk}, {epi}>"
+            elif kind == "attn":
+                sym = f"window_attention_kernel<{ename}, {str(bool(r.variant & 2)).lower()}, {str(bool(r.variant & 1)).lower()}>"
+            elif kind == "layernorm":
+                sym = "layernorm_rows_kernel"
+            else:
+                sym = "patch_im2col_kernel"
+            out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
+        return out
 
 
 def swin_3d_tiny(**kwargs):

@@ -133,12 +133,27 @@ def _t(a) -> torch.Tensor:
     return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
 
 
-def patch_embed(x: torch.Tensor, p: Dict[str, torch.Tensor], patch=(2, 4, 4)) -> torch.Tensor:
+def _ident(t: torch.Tensor) -> torch.Tensor:
+    return t
+
+
+def operand_rounding(dtype):
+    """Rounding applied to MFMA operands by the HIP path (None -> exact fp32 reference arithmetic).
+    With a dtype, the oracle becomes an *emulation* of the kernels' 16-bit operand rounding (same
+    rounding points, fp32 accumulation) used to separate kernel bugs from format precision."""
+    if dtype is None:
+        return _ident
+    if dtype == torch.float16:
+        return lambda t: t.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+    return lambda t: t.to(dtype).to(torch.float32)
+
+
+def patch_embed(x: torch.Tensor, p: Dict[str, torch.Tensor], patch=(2, 4, 4), q=_ident) -> torch.Tensor:
     """(B,3,T,H,W) -> channels-last tokens (B,D,H',W',E); zero pad at the end of each axis."""
     pd, ph, pw = patch
     _, _, T, H, W = x.shape
     x = F.pad(x, (0, (-W) % pw, 0, (-H) % ph, 0, (-T) % pd))
-    y = F.conv3d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=patch)
+    y = F.conv3d(q(x), q(p["patch_embed.proj.weight"]), p["patch_embed.proj.bias"], stride=patch)
     y = y.permute(0, 2, 3, 4, 1)
     if "patch_embed.norm.weight" in p:
         y = F.layer_norm(y, (y.shape[-1],), p["patch_embed.norm.weight"], p["patch_embed.norm.bias"])
@@ -166,17 +181,17 @@ def scatter_windows(o: torch.Tensor, layout, B: int, D: int, H: int, W: int) -> 
 
 
 def window_attention(xw: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, num_heads: int,
-                     window, layout, chunk: int = 64) -> torch.Tensor:
-    """xw (B*nW,N,C) -> (B*nW,N,C).  Implements SURVEY.md App. A item 3."""
+                     window, layout, chunk: int = 64, q=_ident) -> torch.Tensor:
+    """xw (B*nW,N,C) -> (B*nW,N,C).  Implements SURVEY.md App. A item 3.  ``q`` = operand rounding."""
     BW, N, C = xw.shape
     hd = C // num_heads
-    qkv = F.linear(xw, p[pre + "qkv.weight"], p[pre + "qkv.bias"]).reshape(BW, N, 3, num_heads, hd)
-    q = qkv[:, :, 0].permute(0, 2, 1, 3) * (hd ** -0.5)
-    k = qkv[:, :, 1].permute(0, 2, 1, 3)
-    v = qkv[:, :, 2].permute(0, 2, 1, 3)
-    out = attention_core(q, k, v, p[pre + "relative_position_bias_table"],
-                         p.get(pre + "fragment_position_bias_table"), window, layout, chunk)
-    return F.linear(out, p[pre + "proj.weight"], p[pre + "proj.bias"])
+    qkv = F.linear(xw, q(p[pre + "qkv.weight"]), p[pre + "qkv.bias"]).reshape(BW, N, 3, num_heads, hd)
+    qq = q(qkv[:, :, 0].permute(0, 2, 1, 3) * (hd ** -0.5))
+    k = q(qkv[:, :, 1].permute(0, 2, 1, 3))
+    v = q(qkv[:, :, 2].permute(0, 2, 1, 3))
+    out = q(attention_core(qq, k, v, p[pre + "relative_position_bias_table"],
+                           p.get(pre + "fragment_position_bias_table"), window, layout, chunk, q))
+    return F.linear(out, q(p[pre + "proj.weight"]), p[pre + "proj.bias"])
 
 
 def attention_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], window, layout) -> torch.Tensor:
@@ -196,8 +211,9 @@ def attention_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], w
     return bias
 
 
-def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 64) -> torch.Tensor:
-    """q (pre-scaled), k, v: (B*nW, nH, N, hd) -> (B*nW, N, nH*hd)."""
+def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 64, rq=_ident) -> torch.Tensor:
+    """q (pre-scaled), k, v: (B*nW, nH, N, hd) -> (B*nW, N, nH*hd).  ``rq`` rounds the un-normalised
+    probabilities the way the kernel does (P is an MFMA operand); identity = exact softmax."""
     BW, nH, N, hd = q.shape
     nW = layout["nW"]
     bias = attention_bias(rpb_table, fpb_table, window, layout)
@@ -206,46 +222,54 @@ def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 6
     for s in range(0, BW, chunk):
         e = min(BW, s + chunk)
         a = q[s:e] @ k[s:e].transpose(-2, -1) + bias[widx[s:e]]
-        a = torch.softmax(a, dim=-1)
-        out[s:e] = (a @ v[s:e]).transpose(1, 2).reshape(e - s, N, nH * hd)
+        if rq is _ident:
+            a = torch.softmax(a, dim=-1)
+            o = a @ v[s:e]
+        else:
+            pe = rq(torch.exp(a - a.max(-1, keepdim=True).values))
+            o = (pe @ v[s:e]) / pe.sum(-1, keepdim=True)
+        out[s:e] = o.transpose(1, 2).reshape(e - s, N, nH * hd)
     return out
 
 
-def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift) -> torch.Tensor:
-    """x (B,D,H,W,C) channels-last residual stream."""
+def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift, q=_ident) -> torch.Tensor:
+    """x (B,D,H,W,C) channels-last residual stream (always fp32)."""
     B, D, H, W, C = x.shape
     lay = window_layout(D, H, W, window, shift)
-    h = F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"])
-    o = window_attention(gather_windows(h, lay), p, pre + "attn.", num_heads, window, lay)
+    h = q(F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
+    o = window_attention(gather_windows(h, lay), p, pre + "attn.", num_heads, window, lay, q=q)
     x = x + scatter_windows(o, lay, B, D, H, W)
-    h = F.layer_norm(x, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"])
-    h = F.linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])
-    h = F.gelu(h)
-    h = F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+    h = q(F.layer_norm(x, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
+    h = F.linear(h, q(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"])
+    h = q(F.gelu(h))
+    h = F.linear(h, q(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"])
     return x + h
 
 
-def patch_merge(x: torch.Tensor, p, pre: str) -> torch.Tensor:
+def patch_merge(x: torch.Tensor, p, pre: str, q=_ident) -> torch.Tensor:
     B, D, H, W, C = x.shape
     x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
     cat = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
-    cat = F.layer_norm(cat, (4 * C,), p[pre + "norm.weight"], p[pre + "norm.bias"])
-    return F.linear(cat, p[pre + "reduction.weight"])
+    cat = q(F.layer_norm(cat, (4 * C,), p[pre + "norm.weight"], p[pre + "norm.bias"]))
+    return F.linear(cat, q(p[pre + "reduction.weight"]))
 
 
-def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False):
+def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, operand_dtype=None):
     """x (B,3,T,H,W) fp32 -> (B,C_out,D,H/32,W/32) like the reference trunk.  ``cfg`` is a
-    ``kvq_amd.utils.synth.SwinCfg``-shaped object (patch, depths, num_heads, window)."""
+    ``kvq_amd.utils.synth.SwinCfg``-shaped object (patch, depths, num_heads, window).
+    ``operand_dtype`` None = the reference's fp32 arithmetic (this is THE oracle); torch.float16 /
+    torch.bfloat16 = emulate the HIP path's MFMA-operand rounding (diagnostic only)."""
     p = {k: _t(v).float() for k, v in params.items()}
+    q = operand_rounding(operand_dtype)
     shift = tuple(w // 2 for w in cfg.window)
-    y = patch_embed(x.float(), p, cfg.patch)
+    y = patch_embed(x.float(), p, cfg.patch, q)
     stages = [y]
     for i in range(len(cfg.depths)):
         for b in range(cfg.depths[i]):
             y = swin_block(y, p, f"layers.{i}.blocks.{b}.", cfg.num_heads[i], cfg.window,
-                           (0, 0, 0) if b % 2 == 0 else shift)
+                           (0, 0, 0) if b % 2 == 0 else shift, q)
         if i < len(cfg.depths) - 1:
-            y = patch_merge(y, p, f"layers.{i}.downsample.")
+            y = patch_merge(y, p, f"layers.{i}.downsample.", q)
         stages.append(y)
     y = F.layer_norm(y, (y.shape[-1],), p["norm.weight"], p["norm.bias"])
     out = y.permute(0, 4, 1, 2, 3).contiguous()

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in kvq_hip.h but not exported"
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
-    assert handle.kvq_abi_version() == 1
+    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header_sizes():
@@ -31,6 +31,8 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_abi.KvqSwinCfg) == 4 * (3 + 1 + 1 + 1 + 4 + 4 + 3 + 1 + 4)
     assert C.sizeof(_abi.KvqSwinBlockW) == 14 * 8
     assert C.sizeof(_abi.KvqSwinWeights) == 4 * 8 + 8 + 3 * 3 * 8 + 2 * 8
+    assert C.sizeof(_abi.KvqGemmArgs) == 88
+    assert _abi.dtype_code('bf16') == 0 and _abi.dtype_code(torch.float16) == 1
 
 
 def test_error_paths_without_gpu():
@@ -40,7 +42,7 @@ def test_error_paths_without_gpu():
     import ctypes as C
     cfg = _abi.KvqSwinCfg()
     out = C.c_void_p()
-    rc = handle.kvq_swin3d_plan_create(C.byref(cfg), 1, 32, 224, 224, C.byref(out))
+    rc = handle.kvq_swin3d_plan_create(C.byref(cfg), 1, 32, 224, 224, _abi.DT_FP16, C.byref(out))
     assert rc == -3          # num_stages == 0 -> unsupported, reported not crashed
     with pytest.raises(_abi.KvqError):
         _abi.check(rc, "plan")

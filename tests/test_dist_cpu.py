@@ -1,0 +1,52 @@
+"""CPU, world_size 2 over gloo: the N>1 sharding + score all-gather path of bench.py / test.py."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import sys, torch
+    sys.path.insert(0, %r)
+    import kvq_amd
+    from kvq_amd import dist as kd
+    rank, local_rank, world = kd.init(backend="gloo")
+    for n in (900, 7, 2, 1, 113):
+        idx = kd.shard_indices(n, rank, world)
+        assert len(idx) == -(-n // world)
+        local = torch.tensor([float(i) * 0.5 + 1.0 for i in idx])      # score of item i = i/2 + 1
+        full = kd.gather_scores(local, n, rank, world)
+        assert torch.equal(full, torch.arange(n, dtype=torch.float32) * 0.5 + 1.0), (n, full)
+    t = kd.max_over_ranks(1.0 + rank, "cpu")
+    assert t == float(world)
+    kd.barrier()
+    print("OK", rank)
+""") % ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_and_gather_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o[-2000:]
+
+
+def test_single_process_is_identity():
+    import torch
+    import kvq_amd  # noqa: F401
+    from kvq_amd import dist as kd
+    assert kd.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    x = torch.arange(5, dtype=torch.float32)
+    assert torch.equal(kd.gather_scores(x, 5, 0, 1), x)

@@ -19,9 +19,21 @@ def rng(seed):
     return np.random.Generator(np.random.PCG64(seed))
 
 
-def bf(t: torch.Tensor) -> torch.Tensor:
-    """fp32 -> bf16 -> fp32 (the rounding the kernels apply to MFMA operands)."""
-    return t.to(torch.bfloat16).to(torch.float32)
+HALVES = [torch.float16, torch.bfloat16]
+EPS = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}     # half-ulp relative rounding error
+
+
+@pytest.fixture(params=HALVES, ids=["fp16", "bf16"])
+def half(request):
+    return request.param
+
+
+def rnd(t: torch.Tensor, half=torch.bfloat16) -> torch.Tensor:
+    """fp32 -> 16-bit -> fp32 (the rounding the kernels apply to MFMA operands)."""
+    return t.to(half).to(torch.float32)
+
+
+bf = rnd
 
 
 def dev(a, dtype=None):
@@ -38,57 +50,57 @@ def test_library_loads_on_gpu():
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(200, 96, 96), (1000, 288, 96), (130, 768, 3072), (8960, 1152, 384),
                                     (3136, 64, 768), (64 * 9 + 5, 2304, 768)])
-def test_gemm_store_and_bias(M, N, K):
+def test_gemm_store_and_bias(M, N, K, half):
     g = rng(M + N + K)
-    A = bf(torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)))
-    W = bf(torch.from_numpy(g.standard_normal((N, K)).astype(np.float32)))
+    A = rnd(torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)), half)
+    W = rnd(torch.from_numpy(g.standard_normal((N, K)).astype(np.float32)), half)
     b = torch.from_numpy(g.standard_normal(N).astype(np.float32))
     ref = A.double() @ W.double().t() + b.double()
-    out = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_STORE_F32)
+    out = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_STORE_F32)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-4 * np.sqrt(K), err       # fp32 accumulation order only
-    out_bf = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_BIAS_BF16)
-    assert (out_bf.float().cpu().double() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
-    out_g = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_GELU_BF16)
+    out_bf = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_BIAS_BF16)
+    assert (out_bf.float().cpu().double() - ref).abs().max().item() <= EPS[half] * ref.abs().max().item() + 1e-4
+    out_g = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_GELU_BF16)
     ref_g = torch.nn.functional.gelu(ref.float())
-    assert (out_g.float().cpu() - ref_g).abs().max().item() <= 2 ** -8 * ref_g.abs().max().item() + 1e-3
+    assert (out_g.float().cpu() - ref_g).abs().max().item() <= EPS[half] * ref_g.abs().max().item() + 1e-4
 
 
-def test_gemm_no_bias_and_asymmetric_layout():
+def test_gemm_no_bias_and_asymmetric_layout(half):
     # A = I (padded) with an asymmetric W catches a transposed C-write or swapped operands
     M = N = K = 128
     A = torch.eye(M)
     W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125
-    out = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), None, _abi.EPI_STORE_F32)
+    out = kernels.gemm(dev(A, half), dev(W, half), None, _abi.EPI_STORE_F32)
     assert torch.equal(out.cpu(), W.t().contiguous())
 
 
-def test_gemm_qkv_epilogue():
+def test_gemm_qkv_epilogue(half):
     g = rng(5)
     nH, M, C = 3, 392 * 2, 96
-    A = bf(torch.from_numpy(g.standard_normal((M, C)).astype(np.float32)))
-    W = bf(torch.from_numpy(g.standard_normal((3 * C, C)).astype(np.float32) * 0.2))
+    A = rnd(torch.from_numpy(g.standard_normal((M, C)).astype(np.float32)), half)
+    W = rnd(torch.from_numpy(g.standard_normal((3 * C, C)).astype(np.float32) * 0.2), half)
     b = torch.from_numpy(g.standard_normal(3 * C).astype(np.float32))
     scale = 32 ** -0.5
-    out = kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_QKV_BF16, num_heads=nH,
+    out = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_QKV_BF16, num_heads=nH,
                        q_scale=scale)
     ref = (A @ W.t() + b).reshape(M, 3, nH, 32).permute(1, 2, 0, 3).clone()
     ref[0] *= scale
     assert out.shape == (3, nH, M, 32)
-    assert (out.float().cpu() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
+    assert (out.float().cpu() - ref).abs().max().item() <= EPS[half] * ref.abs().max().item() + 1e-4
 
 
-def test_gemm_residual_scatter():
+def test_gemm_residual_scatter(half):
     g = rng(6)
     lay = O.window_layout(4, 10, 9, (8, 7, 7), (4, 3, 3))       # padded + shifted: rows dropped and permuted
     Lp, L, B, C = lay["nW"] * lay["N"], 4 * 10 * 9, 2, 96
-    A = bf(torch.from_numpy(g.standard_normal((B * Lp, C)).astype(np.float32)))
-    W = bf(torch.from_numpy(g.standard_normal((C, C)).astype(np.float32) * 0.2))
+    A = rnd(torch.from_numpy(g.standard_normal((B * Lp, C)).astype(np.float32)), half)
+    W = rnd(torch.from_numpy(g.standard_normal((C, C)).astype(np.float32) * 0.2), half)
     b = torch.from_numpy(g.standard_normal(C).astype(np.float32))
     x = torch.from_numpy(g.standard_normal((B * L, C)).astype(np.float32))
     src = torch.from_numpy(lay["src"].astype(np.int32))
     xd = dev(x.clone())
-    kernels.gemm(dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_RESID_F32, out=xd,
+    kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_RESID_F32, out=xd,
                  scatter_map=dev(src), map_rows=Lp, out_rows=L)
     y = (A @ W.t() + b).reshape(B, Lp, C)
     ref = x.reshape(B, L, C) + O.scatter_windows(y, lay, B, 4, 10, 9).reshape(B, L, C)
@@ -96,20 +108,20 @@ def test_gemm_residual_scatter():
     # identity map
     x2 = dev(x[:300].clone())
     A2 = A[:300]
-    kernels.gemm(dev(A2, torch.bfloat16), dev(W, torch.bfloat16), dev(b), _abi.EPI_RESID_F32, out=x2)
+    kernels.gemm(dev(A2, half), dev(W, half), dev(b), _abi.EPI_RESID_F32, out=x2)
     assert (x2.cpu() - (x[:300] + A2 @ W.t() + b)).abs().max().item() <= 1e-4
 
 
 def test_gemm_rejects_bad_shapes():
-    A = torch.zeros(8, 40, dtype=torch.bfloat16, device=DEV)
-    W = torch.zeros(32, 40, dtype=torch.bfloat16, device=DEV)
+    A = torch.zeros(8, 40, dtype=torch.float16, device=DEV)
+    W = torch.zeros(32, 40, dtype=torch.float16, device=DEV)
     with pytest.raises(_abi.KvqError, match="K%32"):
         kernels.gemm(A, W, None, _abi.EPI_STORE_F32)
 
 
 # -------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("C", [96, 128, 192, 384, 768, 1024])
-def test_layernorm_identity(C):
+def test_layernorm_identity(C, half):
     g = rng(C)
     x = torch.from_numpy((g.standard_normal((777, C)) * 3 + 1.5).astype(np.float32))
     ga = torch.from_numpy((1 + 0.1 * g.standard_normal(C)).astype(np.float32))
@@ -117,8 +129,8 @@ def test_layernorm_identity(C):
     ref = torch.nn.functional.layer_norm(x, (C,), ga, be)
     out = kernels.layernorm_rows(dev(x), dev(ga), dev(be), out_dtype=torch.float32)
     assert (out.cpu() - ref).abs().max().item() <= 2e-5
-    out_bf = kernels.layernorm_rows(dev(x), dev(ga), dev(be), out_dtype=torch.bfloat16)
-    assert torch.equal(out_bf.cpu(), out.cpu().to(torch.bfloat16))      # same values, RNE rounding
+    out_h = kernels.layernorm_rows(dev(x), dev(ga), dev(be), out_dtype=half)
+    assert torch.equal(out_h.cpu(), out.cpu().to(half))      # same values, RNE rounding
 
 
 @pytest.mark.parametrize("dims,shift", [((8, 14, 14), (0, 0, 0)), ((8, 14, 14), (4, 3, 3)), ((4, 10, 9), (4, 3, 3)),
@@ -183,31 +195,31 @@ def _tok_table(lay, window):
     ((8, 8, 8), (4, 4, 4), True, False, 2),       # swin_tiny_grpb_m window
     ((8, 14, 14), (8, 7, 7), False, False, 6),
 ])
-def test_window_attention(dims, window, shifted, gated, nH):
+def test_window_attention(dims, window, shifted, gated, nH, half):
     g = rng(sum(dims) + nH)
     shift = tuple(w // 2 for w in window) if shifted else (0, 0, 0)
     lay = O.window_layout(*dims, window, shift)
     N, nW, B = lay["N"], lay["nW"], 2
     BW = B * nW
     tl = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
-    q = bf(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)) * 0.6)
-    k = bf(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)))
-    v = bf(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)))
+    q = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)) * 0.6, half)
+    k = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)), half)
+    v = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)), half)
     rpb = torch.from_numpy(g.standard_normal((tl, nH)).astype(np.float32))
     fpb = torch.from_numpy(g.standard_normal((tl, nH)).astype(np.float32)) if gated else None
     ref = O.attention_core(q, k, v, rpb, fpb, window, lay).reshape(BW * N, nH * 32)
     tok, center = _tok_table(lay, window)
     qkv = torch.stack([q, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, BW * N, 32).contiguous()
     use_mask = any(s > 0 for s in lay["ss"])
-    out = kernels.window_attention(dev(qkv, torch.bfloat16), dev(torch.from_numpy(tok)), dev(rpb),
+    out = kernels.window_attention(dev(qkv, half), dev(torch.from_numpy(tok)), dev(rpb),
                                    None if fpb is None else dev(fpb), center, nW, N, use_mask)
     err = (out.float().cpu() - ref).abs().max().item()
-    # P and the output are rounded to bf16: 2^-8 relative on O(1) values
-    assert err <= 2.5e-2, err
-    assert (out.float().cpu() - ref).abs().mean().item() <= 2e-3
+    # P and the output are rounded to 16 bits: EPS relative on O(1) values (|v| up to ~4.5)
+    assert err <= 6.4 * EPS[half], err
+    assert (out.float().cpu() - ref).abs().mean().item() <= 0.5 * EPS[half]
 
 
-def test_window_attention_softmax_extremes():
+def test_window_attention_softmax_extremes(half):
     """One key dominating by > 80 in the logits, and the -100 mask, must not produce NaN/Inf."""
     g = rng(3)
     lay = O.window_layout(8, 14, 14, (8, 7, 7), (4, 3, 3))
@@ -216,35 +228,35 @@ def test_window_attention_softmax_extremes():
     k = torch.zeros(nW, nH, N, 32)
     q[:, :, :, 0] = 16.0
     k[:, :, 17, 0] = 6.0
-    v = bf(torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32)))
+    v = rnd(torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32)), half)
     rpb = torch.zeros(2535, 1)
     ref = O.attention_core(q, k, v, rpb, None, (8, 7, 7), lay).reshape(nW * N, 32)
     tok, center = _tok_table(lay, (8, 7, 7))
     qkv = torch.stack([q, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, nW * N, 32).contiguous()
-    out = kernels.window_attention(dev(qkv, torch.bfloat16), dev(torch.from_numpy(tok)), dev(rpb), None, center, nW,
+    out = kernels.window_attention(dev(qkv, half), dev(torch.from_numpy(tok)), dev(rpb), None, center, nW,
                                    N, True).float().cpu()
     assert torch.isfinite(out).all()
-    assert (out - ref).abs().max().item() <= 2.5e-2
+    assert (out - ref).abs().max().item() <= 6.4 * EPS[half]
 
 
 def test_window_attention_rejects_large_window():
     with pytest.raises(_abi.KvqError, match="unsupported"):
-        kernels.window_attention(torch.zeros(3, 1, 512, 32, dtype=torch.bfloat16, device=DEV),
+        kernels.window_attention(torch.zeros(3, 1, 512, 32, dtype=torch.float16, device=DEV),
                                  torch.zeros(512, 2, dtype=torch.int32, device=DEV),
                                  torch.zeros(10, 1, device=DEV), None, 0, 1, 512, False)
 
 
 # ------------------------------------------------------------------------- embed / heads / sampler
 @pytest.mark.parametrize("shape", [(2, 3, 8, 32, 32), (1, 3, 7, 30, 27)])
-def test_patch_im2col(shape):
+def test_patch_im2col(shape, half):
     g = rng(sum(shape))
     x = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
     B, Cin, T, H, W = shape
-    out = kernels.patch_im2col(dev(x), (2, 4, 4)).float().cpu()
+    out = kernels.patch_im2col(dev(x), (2, 4, 4), out_dtype=half).float().cpu()
     xp = torch.nn.functional.pad(x, (0, (-W) % 4, 0, (-H) % 4, 0, (-T) % 2))
     D, Hh, Ww = xp.shape[2] // 2, xp.shape[3] // 4, xp.shape[4] // 4
     ref = xp.reshape(B, Cin, D, 2, Hh, 4, Ww, 4).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * D * Hh * Ww, -1)
-    assert torch.equal(out, bf(ref))
+    assert torch.equal(out, rnd(ref, half))
 
 
 def test_vqa_head_layouts():
