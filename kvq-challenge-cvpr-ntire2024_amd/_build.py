@@ -17,6 +17,9 @@ HEADER = os.path.join(os.path.dirname(PKG), "include", "kvq_hip.h")
 SOURCES = ["common.cpp", "gemm.hip", "ln.hip", "attn.hip", "misc.hip", "plan.hip", "conv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
+# attn.hip is VALU-bound: SLP packing of adjacent f32 ops into v_pk_* costs more v_mov than it saves, and
+# NaN-honouring fmaxf inserts a canonicalising v_max per MFMA output (no NaN can arise: -inf only).
+EXTRA = {"attn.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 
 
 def _hipcc() -> str:
@@ -51,7 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj
-        cmd = [cc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), [])
+               + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")

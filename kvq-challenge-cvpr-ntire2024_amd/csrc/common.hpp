@@ -63,6 +63,7 @@ struct Bf16 {
   using v8 = bf16x8;
   static __device__ __forceinline__ uint16_t cvt(float f) { return f2bf(f); }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
+  static __device__ __forceinline__ uint32_t pack2_raw(float lo, float hi) { return pack_bf2(lo, hi); }
   static __device__ __forceinline__ float to_f32(uint16_t u) { return bf2f(u); }
   static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -83,6 +84,11 @@ struct Fp16 {
     f16x2 v = {(_Float16)sat(lo), (_Float16)sat(hi)};
     return __builtin_bit_cast(uint32_t, v);
   }
+  // no saturation: for values known to be in range (softmax probabilities) -> one v_cvt_pk_f16_f32
+  static __device__ __forceinline__ uint32_t pack2_raw(float lo, float hi) {
+    f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+  }
   static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
   static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -95,6 +101,21 @@ struct Fp16 {
 // exact GELU (erf), as nn.GELU() default (swin_backbone.py:72, head.py:56)
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// GELU for the GEMM epilogue: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. fp32-roundoff
+// class and ~4 orders below the 16-bit rounding applied to the result) — 1 rcp + 1 exp + 7 fma instead
+// of the ~35-instruction libm erff.  The fp32 score head keeps the libm erff (gelu_erf).
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
 // tile variant the GEMM dispatcher picks for a shape: (MI==NI) * 100 + BK  (gemm.hip)

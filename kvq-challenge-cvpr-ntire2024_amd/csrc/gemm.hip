@@ -125,56 +125,82 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Each wave transposes its accumulators through a private LDS slab (32 rows x 32*NI fp32, reusing the
+  // A/B slices: the K loop ended with a barrier) so that a lane owns 4 CONSECUTIVE columns of one row:
+  // bias/activation run on float4s and the global stores are 8-16 B per lane, >= 128 B contiguous per
+  // row, instead of 64 two-byte stores per lane.
+  constexpr int SW = 32 * NI;                                   // slab width (floats)
+  float* slab = reinterpret_cast<float*>(lds) + wave * 32 * SW;
   const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+  constexpr int CPRW = SW / 4;                                   // float4 chunks per slab row
+  constexpr int ROWS_PER_IT = 64 / CPRW;
+  const int ch = lane % CPRW, rsub = lane / CPRW;
+  const int nbase = n0 + wn * SW;
+  const int n = nbase + ch * 4;
+  const bool col_live = n < p.N;                                 // N % 32 == 0 and 4 | 32: whole chunk in or out
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && col_live) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+  int which = 0, head = 0, e0 = 0;
+  float scale = 1.f;
+  if (EPI == KVQ_EPI_QKV_BF16 && col_live) {                     // a 32-column tile = one head of q|k|v
+    const int C = p.N / 3;
+    which = n / C;
+    head = (n % C) >> 5;
+    e0 = n & 31;
+    scale = which == 0 ? p.q_scale : 1.f;
+  }
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    if (!n_live[j]) continue;
-    const int n = n0 + wn * 32 * NI + j * 32 + col_in;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    // QKV: a 32-column tile is exactly one head of one of q/k/v
-    int which = 0, head = 0;
-    float scale = 1.f;
-    if (EPI == KVQ_EPI_QKV_BF16) {
-      const int C = p.N / 3;
-      which = (n - col_in) / C;
-      head = ((n - col_in) % C) >> 5;
-      scale = which == 0 ? p.q_scale : 1.f;
-    }
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        if (EPI == KVQ_EPI_BIAS_BF16) {
-          p.out_h[(size_t)m * p.N + n] = E::cvt(v);
-        } else if (EPI == KVQ_EPI_GELU_BF16) {
-          p.out_h[(size_t)m * p.N + n] = E::cvt(gelu_erf(v));
-        } else if (EPI == KVQ_EPI_QKV_BF16) {
-          p.out_h[((size_t)(which * p.num_heads + head) * p.M + m) * 32 + col_in] = E::cvt(v * scale);
-        } else if (EPI == KVQ_EPI_RESID_F32) {
-          long orow = m;
-          if (p.scatter_map) {
-            int b = m / p.map_rows, rr = m - b * p.map_rows;
-            int s = p.scatter_map[rr];
-            if (s < 0) continue;
-            orow = (long)b * p.out_rows + s;
-          }
-          float* o = p.out_f32 + (size_t)orow * p.N + n;
-          *o = *o + v;
-        } else {  // KVQ_EPI_STORE_F32
-          p.out_f32[(size_t)m * p.N + n] = v;
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + row_hi) * SW + j * 32 + col_in] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / ROWS_PER_IT; ++it) {
+      const int rl = it * ROWS_PER_IT + rsub;
+      const int m = m0 + wm * 32 * MI + i * 32 + rl;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * SW + ch * 4);
+      if (m >= p.M || !col_live) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += bias4[k];
+      if (EPI == KVQ_EPI_BIAS_BF16) {
+        u32x2 o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
+      } else if (EPI == KVQ_EPI_GELU_BF16) {
+        u32x2 o = {E::pack2(gelu_fast(v[0]), gelu_fast(v[1])), E::pack2(gelu_fast(v[2]), gelu_fast(v[3]))};
+        *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
+      } else if (EPI == KVQ_EPI_QKV_BF16) {
+        u32x2 o = {E::pack2(v[0] * scale, v[1] * scale), E::pack2(v[2] * scale, v[3] * scale)};
+        *reinterpret_cast<u32x2*>(p.out_h + ((size_t)(which * p.num_heads + head) * p.M + m) * 32 + e0) = o;
+      } else if (EPI == KVQ_EPI_RESID_F32) {
+        long orow = m;
+        if (p.scatter_map) {
+          const int b = m / p.map_rows, rr = m - b * p.map_rows;
+          const int s = p.scatter_map[rr];
+          if (s < 0) continue;
+          orow = (long)b * p.out_rows + s;
         }
+        f32x4* o = reinterpret_cast<f32x4*>(p.out_f32 + (size_t)orow * p.N + n);
+        f32x4 x = *o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] += v[k];
+        *o = x;
+      } else {  // KVQ_EPI_STORE_F32
+        *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n) = v;
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 template <typename E, int MI, int NI, int BK, int EPI>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr size_t lds_bytes = 2 * (BM + BN) * (BK + 8) * sizeof(uint16_t);
+  constexpr size_t main_bytes = 2 * (BM + BN) * (BK + 8) * sizeof(uint16_t);
+  constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
+  constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   auto kern = gemm_kernel<E, MI, NI, BK, EPI>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {

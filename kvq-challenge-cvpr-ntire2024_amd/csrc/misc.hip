@@ -35,43 +35,54 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // VQAHead (models/head.py:60-68, eval): per token  s = w2 . gelu(W1 f + b1) + b2 ; score = mean_tokens.
-// fp32 FMA throughout (0.08 GFLOP/clip — not worth the bf16 rounding at the very end of the net).
-// One wave handles HEAD_TOK tokens: feature rows in registers, W1 streamed from L2.
+// fp32 FMA throughout (0.08 GFLOP/clip — not worth a 16-bit rounding at the very end of the net).
+// Lane j owns hidden unit j: W1 is passed TRANSPOSED ([C][hidden]) so the 64 lanes read one coalesced
+// 256-B row per channel; the token's feature value is a wave-uniform (broadcast) load.  A wave carries
+// HEAD_TOK tokens to amortise the W1 stream (L2-resident, 196 KB); one shuffle reduction per token.
 // ------------------------------------------------------------------------------------------------
 constexpr int HEAD_TOK = 4;
 
 __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __restrict__ feat, int B, int L, int C,
-                                                             long sb, long sl, long sc, const float* __restrict__ w1,
+                                                             long sb, long sl, long sc, const float* __restrict__ w1t,
                                                              const float* __restrict__ b1, int hidden,
-                                                             const float* __restrict__ w2, float b2_unused,
+                                                             const float* __restrict__ w2,
                                                              float* __restrict__ tok_score) {
   const int lane = threadIdx.x & 63;
   const long wave_id = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long tok0 = wave_id * HEAD_TOK;
   const long total = (long)B * L;
   if (tok0 >= total) return;
+  const float* row[HEAD_TOK];
+#pragma unroll
+  for (int t = 0; t < HEAD_TOK; ++t) {
+    const long tk = min(tok0 + t, total - 1);
+    const long b = tk / L, l = tk - b * L;
+    row[t] = feat + b * sb + l * sl;
+  }
   float acc[HEAD_TOK];
 #pragma unroll
   for (int t = 0; t < HEAD_TOK; ++t) acc[t] = 0.f;
-  for (int j = 0; j < hidden; ++j) {
+  for (int j0 = 0; j0 < hidden; j0 += 64) {
+    const int j = j0 + lane;
+    const bool live = j < hidden;
+    const int jc = live ? j : hidden - 1;
     float d[HEAD_TOK];
 #pragma unroll
     for (int t = 0; t < HEAD_TOK; ++t) d[t] = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float wv = w1[(size_t)j * C + c];
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const float wv = w1t[(size_t)c * hidden + jc];
 #pragma unroll
-      for (int t = 0; t < HEAD_TOK; ++t) {
-        const long tk = min(tok0 + t, total - 1);
-        const long b = tk / L, l = tk - b * L;
-        d[t] = fmaf(feat[b * sb + l * sl + c * sc], wv, d[t]);
-      }
+      for (int t = 0; t < HEAD_TOK; ++t) d[t] = fmaf(row[t][c * sc], wv, d[t]);
     }
+    const float bj = b1[jc], wj = live ? w2[jc] : 0.f;
 #pragma unroll
-    for (int t = 0; t < HEAD_TOK; ++t) {
+    for (int t = 0; t < HEAD_TOK; ++t) acc[t] = fmaf(wj, gelu_erf(d[t] + bj), acc[t]);
+  }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) d[t] += __shfl_xor(d[t], o);
-      acc[t] = fmaf(w2[j], gelu_erf(d[t] + b1[j]), acc[t]);
-    }
+  for (int t = 0; t < HEAD_TOK; ++t) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[t] += __shfl_xor(acc[t], o);
   }
   if (lane == 0) {
 #pragma unroll
@@ -184,15 +195,15 @@ extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, in
 }
 
 extern "C" int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l,
-                            int64_t stride_c, const float* w1, const float* b1, int hidden, const float* w2,
+                            int64_t stride_c, const float* w1t, const float* b1, int hidden, const float* w2,
                             const float* b2, float* scratch, float* score, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(feat && w1 && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head: NULL pointer");
+  KVQ_REQUIRE(feat && w1t && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head: NULL pointer");
   KVQ_REQUIRE(B > 0 && L > 0 && C > 0 && hidden > 0, KVQ_ERR_SHAPE, "kvq_vqa_head: bad shape");
   const long waves = ((long)B * L + HEAD_TOK - 1) / HEAD_TOK;
   const int grid = (int)((waves + 3) / 4);
   hipLaunchKernelGGL(vqa_head_token_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, B, L, C,
-                     (long)stride_b, (long)stride_l, (long)stride_c, w1, b1, hidden, w2, 0.f, scratch);
+                     (long)stride_b, (long)stride_l, (long)stride_c, w1t, b1, hidden, w2, scratch);
   KVQ_CHECK_LAUNCH("vqa_head_token_kernel");
   hipLaunchKernelGGL(mean_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scratch, L, b2, score);
   KVQ_CHECK_LAUNCH("mean_rows_kernel");

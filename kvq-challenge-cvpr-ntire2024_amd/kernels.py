@@ -114,9 +114,10 @@ def vqa_head(feat: torch.Tensor, w1, b1, w2, b2):
         feat = feat.contiguous()
         sb, sc, sd, sh, sw = feat.stride()
     hidden = w1.shape[0]
+    w1t = w1.t().contiguous()                   # [C][hidden]: what the kernel streams (kvq_hip.h)
     scratch = torch.empty(B * L, dtype=torch.float32, device=feat.device)
     score = torch.empty(B, dtype=torch.float32, device=feat.device)
-    check(lib().kvq_vqa_head(ptr(feat), B, L, Cc, sb, sw, sc, ptr(w1), ptr(b1), hidden, ptr(w2), ptr(b2),
+    check(lib().kvq_vqa_head(ptr(feat), B, L, Cc, sb, sw, sc, ptr(w1t), ptr(b1), hidden, ptr(w2), ptr(b2),
                              ptr(scratch), ptr(score), current_stream()), "kvq_vqa_head")
     return score.reshape(B, 1)
 
