@@ -1,0 +1,117 @@
+"""Host-side mirror of the sampler half of the reference's ``datasets/fusion_datasets.py``.
+
+  get_spatial_fragments   (:22-121)   grid-mini-patch sampler -> ``kvq_fragment_gather`` (HIP)
+  UnifiedFrameSampler     (:612-660)  temporal index sampler (host integers, numpy)
+  ViewDecompositionDataset_KVQ (:930-1051)  dict assembly for the ``technical`` view
+  SyntheticKVQDataset     build-only: seeded post-decode frame stacks (no dataset/decoder is reachable
+                          offline — SURVEY.md §8d); same dict keys.
+
+The reference draws its random offsets inside the functions from global RNG state
+(``torch.randint`` :87-98, ``np.random.randint`` :632-635).  The same calls are made here, in the
+same order, so a seeded run draws the same offsets (SURVEY.md §0 trap 6); every function also accepts
+the offsets explicitly, which is what the parity tests use.
+Video *decode* (decord / cv2, :379-431) is outside the hot path: frames enter
+as uint8/fp32 (C,T,H,W) tensors.
+"""
+from __future__ import annotations
+
+import random as _pyrandom
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import kernels
+
+KVQ_MEAN = (123.675, 116.28, 103.53)
+KVQ_STD = (58.395, 57.12, 57.375)
+
+
+def _grid(res: int, fragments: int, fsize: int):
+    return [min(res // fragments * i, res - fsize) for i in range(fragments)]
+
+
+def get_spatial_fragments(video, fragments_h=7, fragments_w=7, fsize_h=32, fsize_w=32, aligned=32, nfrags=1,
+                          random=False, random_upsample=False, fallback_type="upsample", rnd_h=None, rnd_w=None,
+                          mean=None, std=None, **kwargs):
+    """video (C,T,H,W) uint8|fp32 on a HIP device -> fp32 (C,T,Fh*fs,Fw*fs).
+
+    ``rnd_h``/``rnd_w`` (Fh,Fw,T//aligned): offsets inside each grid cell; drawn with the reference's
+    ``torch.randint`` calls when omitted.  ``mean``/``std`` fuse the dataset's normalisation (:1017-1020)."""
+    if random or random_upsample:
+        raise NotImplementedError("'random' / 'random_upsample' sampling is deprecated in the reference (:75)")
+    if video.shape[1] == 1:
+        aligned = 1
+    T, H, W = video.shape[-3:]
+    if min(H / (fragments_h * fsize_h), W / (fragments_w * fsize_w)) < 1:
+        raise NotImplementedError("bilinear upsample fallback for sources smaller than the canvas (:43-50)")
+    assert T % aligned == 0, "Please provide match vclip and align index"
+    nt = T // aligned
+    hl, wl = H // fragments_h, W // fragments_w
+    if rnd_h is None:
+        rnd_h = (torch.randint(hl - fsize_h, (fragments_h, fragments_w, nt)) if hl > fsize_h
+                 else torch.zeros((fragments_h, fragments_w, nt)).int())
+    if rnd_w is None:
+        rnd_w = (torch.randint(wl - fsize_w, (fragments_h, fragments_w, nt)) if wl > fsize_w
+                 else torch.zeros((fragments_h, fragments_w, nt)).int())
+    rnd_h = torch.as_tensor(np.asarray(rnd_h)) if not torch.is_tensor(rnd_h) else rnd_h
+    rnd_w = torch.as_tensor(np.asarray(rnd_w)) if not torch.is_tensor(rnd_w) else rnd_w
+    hoff = (rnd_h.cpu().long() + torch.tensor(_grid(H, fragments_h, fsize_h)).view(-1, 1, 1)).int()
+    woff = (rnd_w.cpu().long() + torch.tensor(_grid(W, fragments_w, fsize_w)).view(1, -1, 1)).int()
+    return kernels.fragment_gather(video.contiguous(), hoff.to(video.device), woff.to(video.device), fragments_h,
+                                   fragments_w, fsize_h, fsize_w, aligned, mean=mean, std=std)
+
+
+class UnifiedFrameSampler:
+    """Reference ``UnifiedFrameSampler`` (:612-660): same constructor, same RNG calls, same indices."""
+
+    def __init__(self, fsize_t, fragments_t, frame_interval=1, num_clips=1, drop_rate=0.0):
+        self.fragments_t, self.fsize_t = fragments_t, fsize_t
+        self.size_t = fragments_t * fsize_t
+        self.frame_interval, self.num_clips, self.drop_rate = frame_interval, num_clips, drop_rate
+
+    def get_frame_indices(self, num_frames, train=False):
+        tgrids = np.array([num_frames // self.fragments_t * i for i in range(self.fragments_t)], dtype=np.int32)
+        tlength = num_frames // self.fragments_t
+        if tlength > self.fsize_t * self.frame_interval:
+            rnd_t = np.random.randint(0, tlength - self.fsize_t * self.frame_interval, size=len(tgrids))
+        else:
+            rnd_t = np.zeros(len(tgrids), dtype=np.int32)
+        ranges_t = np.arange(self.fsize_t)[None, :] * self.frame_interval + rnd_t[:, None] + tgrids[:, None]
+        drop = _pyrandom.sample(list(range(self.fragments_t)), int(self.fragments_t * self.drop_rate))
+        return np.concatenate([rt for i, rt in enumerate(ranges_t) if i not in drop])
+
+    def __call__(self, total_frames, train=False, start_index=0):
+        inds = np.concatenate([self.get_frame_indices(total_frames) for _ in range(self.num_clips)])
+        return np.mod(inds + start_index, total_frames).astype(np.int32)
+
+
+class SyntheticKVQDataset(torch.utils.data.Dataset):
+    """Seeded stand-in for ``ViewDecompositionDataset_KVQ``: item i is a uint8 frame stack drawn from
+    PCG64(1234+i) sampled into the ``technical`` view on the GPU.  ``args``:
+    ``num_videos, frames, height, width, labels (optional list), sample_types.technical.{fragments_h,
+    fragments_w, fsize_h, fsize_w, aligned, clip_len, frame_interval, num_clips}``."""
+
+    def __init__(self, opt, namelist=None, device="cuda:0"):
+        self.opt, self.device = opt, torch.device(device)
+        self.n = int(opt.get("num_videos", 8))
+        self.frames, self.h, self.w = int(opt.get("frames", 256)), int(opt.get("height", 540)), int(opt.get("width", 960))
+        self.sopt = dict(opt["sample_types"]["technical"])
+        s = self.sopt
+        self.sampler = UnifiedFrameSampler(s["clip_len"], 1, s.get("frame_interval", 1), s.get("num_clips", 1))
+        g = np.random.Generator(np.random.PCG64(4321))
+        self.labels = list(opt.get("labels") or g.uniform(1.0, 5.0, self.n))
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from ..utils import synth
+        s = self.sopt
+        frames = torch.from_numpy(synth.synth_video_u8(1234 + i, self.frames, self.h, self.w))
+        inds = self.sampler(self.frames)
+        clip = frames[:, torch.from_numpy(inds.astype(np.int64))].to(self.device)
+        tech = get_spatial_fragments(clip, s["fragments_h"], s["fragments_w"], s["fsize_h"], s["fsize_w"],
+                                     aligned=s.get("aligned", 8), mean=KVQ_MEAN, std=KVQ_STD)
+        return {"technical": tech, "num_clips": {"technical": s.get("num_clips", 1)}, "frame_inds": inds,
+                "label": float(self.labels[i]), "name": f"synthetic_{i:05d}", "video_name": f"synthetic_{i:05d}.mp4"}

@@ -1,0 +1,110 @@
+"""Inference harness mirroring the reference's ``trainer.py`` (``Trainer`` :39-361, inference half) and
+the score all-gather of ``trainer_ddp.py:259-267``.
+
+Differences that are deliberate:
+  * ``inferece()`` exists (``test.py:37`` calls it; the reference's ``trainer.py`` lacks it): it runs
+    ``inferece_test()`` and, when labels are present, also prints the ``inferece_val()`` metrics;
+  * one process per GPU (``torch.distributed.run``) instead of ``nn.DataParallel``: videos are sharded
+    ``videos[rank::world]`` and ONE all-gather of the score vector runs at the end;
+  * scores stay on the device until the end (no per-video ``.item()`` sync, ``trainer.py:329``).
+Training (optimizer, losses, EMA, checkpoints) is out of scope: this is an inference engine.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import datasets as _datasets
+from . import dist as kd
+from .models.model import VQA_Network
+
+
+class Trainer:
+    def __init__(self, args, config):
+        self.args, self.config = args, config
+        self.rank, self.local_rank, self.world = kd.init()
+        gpu_ids = [int(i) for i in str(getattr(args, "gpu_id", "0")).split(",") if i != ""]
+        dev = gpu_ids[0] if self.world == 1 and gpu_ids else self.local_rank
+        self.device = torch.device(f"cuda:{dev}")
+        torch.cuda.set_device(self.device)
+        self.key_list = self.config["model"]["type"].split(",")
+        self.build_datasets()
+        self.build_models()
+
+    def build_models(self):
+        self.model = VQA_Network(self.config).to(self.device).eval()
+        path = self.config.get("load_path")
+        if path:
+            state = torch.load(path, map_location="cpu")
+            state = state.get("state_dict", state)
+            # DataParallel / DDP checkpoints carry a 'module.' prefix (trainer.py:62-74, trainer_ddp.py:74-79)
+            state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
+            print("load:", self.model.load_state_dict(state, strict=False))
+
+    def build_datasets(self):
+        cfg = self.config["data"]["val"]
+        cls = getattr(_datasets, cfg["type"])
+        self.val_dataset = cls(cfg["args"], None, device=self.device) if cfg["type"].startswith("Synthetic") \
+            else cls(cfg["args"], None)
+
+    # ------------------------------------------------------------------------------------------
+    def _forward_video(self, data):
+        """clip reshape (trainer.py:306-319) + model forward (:320-327) -> device tensor of clip scores."""
+        for key in list(data):
+            if key in self.key_list or key == "technical":
+                x = data[key]
+                if not torch.is_tensor(x) or x.dim() not in (4, 5):
+                    continue
+                x = x.to(self.device)
+                if x.dim() == 4:
+                    x = x.unsqueeze(0)
+                b, c, t, h, w = x.shape
+                nc = int(data.get("num_clips", {}).get(key, 1)) if isinstance(data.get("num_clips"), dict) else 1
+                data[key] = (x.reshape(b, c, nc, t // nc, h, w).permute(0, 2, 1, 3, 4, 5)
+                             .reshape(b * nc, c, t // nc, h, w).contiguous())
+        with torch.no_grad():
+            return self.model(inputs=data, reduce_scores=True)
+
+    def _score_all(self):
+        n = len(self.val_dataset)
+        mine = kd.shard_indices(n, self.rank, self.world)
+        local = torch.empty(len(mine), dtype=torch.float32, device=self.device)
+        for j, i in enumerate(mine):
+            pred = self._forward_video(self.val_dataset[i])
+            local[j] = pred.float().mean()                    # pred.mean(0) over clips (trainer.py:282)
+        return kd.gather_scores(local, n, self.rank, self.world).cpu().numpy()
+
+    def inferece_test(self):
+        scores = self._score_all()
+        if self.rank == 0:
+            with open("output.txt", "w") as f:
+                for i, s in enumerate(scores):
+                    f.write(f"{self._name(i)},{float(s)}\n")           # 'video_name,score' (trainer.py:331-334)
+        return scores
+
+    def _name(self, i):
+        names = getattr(self.val_dataset, "video_names", None)
+        return names[i] if names else f"synthetic_{i:05d}.mp4"
+
+    def inferece_val(self, scores=None):
+        from scipy.stats import kendalltau, pearsonr, spearmanr
+        scores = self._score_all() if scores is None else scores
+        labels = np.asarray(getattr(self.val_dataset, "labels"), np.float64)
+        preds = self.rescale(list(scores), list(labels))
+        s, p, k = spearmanr(labels, preds)[0], pearsonr(labels, preds)[0], kendalltau(labels, preds)[0]
+        r = np.sqrt(((labels - preds) ** 2).mean())
+        if self.rank == 0:
+            print("SRCC{}PLCC{}KRCC{}RMSE{}".format(s, p, k, r))          # trainer.py:294
+        return s, p, k, r
+
+    def inferece(self):
+        scores = self.inferece_test()
+        if getattr(self.val_dataset, "labels", None) is not None and len(scores) > 2:
+            self.inferece_val(scores)
+        return scores
+
+    def rescale(self, pr, gt=None):
+        pr = np.asarray(pr, np.float64)
+        if gt is None:
+            return (pr - np.mean(pr)) / np.std(pr)
+        return ((pr - np.mean(pr)) / np.std(pr)) * np.std(gt) + np.mean(gt)
