@@ -32,7 +32,10 @@ constexpr int ATT_VPITCH = 400;         // 16-bit elems per V^T row: 800 B = 50 
 constexpr int ATT_VT_BYTES = 32 * ATT_VPITCH * 2 + 64;
 constexpr int ATT_OFF_VT = ATT_KROWS * 64;
 constexpr int ATT_OFF_TOK = ATT_OFF_VT + ATT_VT_BYTES;
-constexpr int ATT_OFF_CTR = ATT_OFF_TOK + ATT_KROWS * 16;
+// token descriptors are skewed by one 16-B entry per 8 keys (entry of key k at k + k/8): the four lane
+// groups of a wave read keys 8 apart, which would otherwise sit exactly 128 B apart = on the same banks
+constexpr int ATT_TOK_ENTRIES = ATT_KROWS + ATT_KROWS / 8;
+constexpr int ATT_OFF_CTR = ATT_OFF_TOK + ATT_TOK_ENTRIES * 16;
 constexpr int ATT_OFF_TAB = ATT_OFF_CTR + 16;
 
 struct AttnParams {
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
       const int2 g2 = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * N + n) * 2);
       t = make_int4(g2.x * 8, g2.y & 0xffff, (g2.y >> 16) & 0xff, 0);
     }
-    tokL[n] = t;
+    tokL[n + (n >> 3)] = t;
   }
   for (int i = tid; i < p.table_len; i += ATT_WAVES * 64) {
     const float r = p.rpb[(size_t)i * p.nH + h];
@@ -124,39 +127,68 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
     const int qrow = min(q0 + j, N - 1);
     // B operand of S^T = K Q^T: lane (j,g) holds Q[q0+j][8g..8g+7]
     const V8 qf = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + g * 8);
-    const int4 tq = tokL[qrow];
+    const int4 tq = tokL[qrow + (qrow >> 3)];
     const int cqb = tq.x + p.center * 8 + ATT_OFF_TAB;      // byte address of tab[cq + center - 0]
     const unsigned fq = (unsigned)tq.y;
     const int rq = tq.z;
 
+    // Software pipeline over the 26 key tiles: the descriptor read (tile t+2) and the dependent table
+    // gather (tile t+1) are issued before tile t's arithmetic, so two LDS round trips are in flight
+    // behind ~60 VALU instructions instead of being waited for back to back.
+#define ATT_KEY0(t) (32 * ((t) >> 1) + 4 * ((t) & 1))
+#define ATT_TOKIDX(t, r) (ATT_KEY0(t) + (ATT_KEY0(t) >> 3) + (r))     /* + 9*g folded into tokg */
+    const int4* tokg = tokL + 9 * g;
+    int4 tkC[4], tkN[4];
+    float2 tbC[4], tbN[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tkC[r] = tokg[ATT_TOKIDX(0, r)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tkN[r] = tokg[ATT_TOKIDX(1, r)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tbC[r] = *reinterpret_cast<const float2*>(smem + (cqb - tkC[r].x));
     f32x4 S[ATT_NT];
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < ATT_NT; ++t) {
-      // ---- bias tile first (this lane's keys: 32*(t>>1) + 8g + 4*(t&1) + r), then S = K Q^T + bias ----
-      const int key0 = 32 * (t >> 1) + 4 * (t & 1);          // + 8g + r
-      f32x4 b4;
+      const int key0 = ATT_KEY0(t);                            // this lane's keys: key0 + 8g + r
+      int4 tkNN[4];
+      if (t + 1 < ATT_NT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int4 tk = tokL[key0 + 8 * g + r];
-        const float2 b2 = *reinterpret_cast<const float2*>(smem + (cqb - tk.x));
-        float bias = b2.x;
-        if (GATED) bias = fmaf((float)__builtin_amdgcn_sad_u8(fq, (unsigned)tk.y, 0u), b2.y, b2.x);
-        if (MASK) bias += (tk.z != rq) ? -100.0f : 0.0f;
-        b4[r] = bias;
+        for (int r = 0; r < 4; ++r) tbN[r] = *reinterpret_cast<const float2*>(smem + (cqb - tkN[r].x));
+      }
+      if (t + 2 < ATT_NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tkNN[r] = tokg[ATT_TOKIDX(t + 2 < ATT_NT ? t + 2 : 0, r)];
       }
       // A operand: MFMA row i = j  <->  key 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3)
       const int krow = key0 + 8 * (j >> 2) + (j & 3);
       const V8 kf = __builtin_bit_cast(V8, Ks[k_slot(krow, g)]);
+      // ---- bias tile first, then S = K Q^T + bias (the bias rides in as the MFMA C operand) ----
+      f32x4 b4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float bias = tbC[r].x;
+        if (GATED) bias = fmaf((float)__builtin_amdgcn_sad_u8(fq, (unsigned)tkC[r].y, 0u), tbC[r].y, tbC[r].x);
+        if (MASK) bias += (tkC[r].z != rq) ? -100.0f : 0.0f;
+        b4[r] = bias;
+      }
       S[t] = E::mfma16(kf, qf, b4);
       if (!FULL || t >= ATT_NT - 2) {   // tiles that can hold keys >= N: exclude them from the softmax
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[t][r] = (key0 + 8 * g + r) < N ? S[t][r] : -INFINITY;
       }
       mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
-      // keep the compiler from hoisting all 104 LDS gathers ahead of their use (that spills):
+      // bound live ranges: without it the compiler hoists all 104 gathers ahead of their use and spills
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tkC[r] = tkN[r];
+        tbC[r] = tbN[r];
+        tkN[r] = tkNN[r];
+      }
     }
+#undef ATT_KEY0
+#undef ATT_TOKIDX
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     // ---- exp + pack: the packed pairs are the P*V A-fragments (p in [0,1]: no saturation needed) ----

@@ -8,11 +8,8 @@
 // roll + crop + residual add (:472-488, :509, :514).
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid; block tile (64*MI) x (64*NI), wave tile
-// (32*MI) x (32*NI) built from v_mfma_f32_32x32x16_{bf16,f16}; K staged through LDS in BK slices,
-// register-prefetched (global loads of slice t+1 are in flight while slice t is multiplied),
-// double-buffered so there is one barrier per slice.  LDS rows are padded by 16 B: with a pitch of
-// BK+8 elements the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots (pitch/16 B
-// is odd), i.e. the fragment reads are bank-conflict free.
+// (32*MI) x (32*NI) built from v_mfma_f32_32x32x16_{bf16,f16}; K streamed through a 4-slice LDS ring
+// by LDS-DMA with counted waits (see the kernel comment).
 #include "common.hpp"
 
 namespace kvq {
@@ -30,58 +27,60 @@ struct GemmParams {
   int map_rows, out_rows;
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+#define KVQ_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// K loop: a 4-deep LDS ring of BK=32 slices filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane,
+// no VGPR round trip, no ds_write), three slices in flight while one is multiplied.  The waits are COUNTED
+// (s_waitcnt vmcnt(2*NL): only the slice about to be read must have landed) and the barrier is the raw
+// s_barrier, so the younger slices' DMAs stay in flight across it; one barrier per slice covers both the
+// RAW (slice t landed for every wave) and the WAR (everybody finished slice t-1 before its buffer is
+// refilled with slice t+3).  LDS rows are 64 B (no padding: the DMA image is lane-linear); the 16-B chunk
+// c of row r lives at chunk c ^ ((r>>2)&3) — applied on the SOURCE address of the DMA and on the
+// fragment read — which makes the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots.
 template <typename E, int MI, int NI, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr int PITCH = BK + 8;            // 16-bit elements
-  constexpr int CPR = BK / 8;              // 16-B chunks per row
-  constexpr int A_CHUNKS = BM * CPR / 256; // per thread
-  constexpr int B_CHUNKS = BN * CPR / 256;
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // 2 * (BM + BN) * PITCH elements
-  uint16_t* As = lds;
-  uint16_t* Bs = lds + 2 * BM * PITCH;
+  static_assert(BK == 32, "ring slices are 32 deep");
+  constexpr int BM = 64 * MI, BN = 64 * NI, NST = 4;
+  constexpr int A_BYTES = BM * 64, ST_BYTES = (BM + BN) * 64;
+  constexpr int A_PER = BM * 4 / 256, B_PER = BN * 4 / 256, NL = A_PER + B_PER;   // DMAs per thread per slice
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // blockIdx.x walks N fastest so that blocks sharing an A row-panel are adjacent in dispatch order.
   const int nbn = (p.N + BN - 1) / BN;
   const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
-  const uint16_t* a_src[A_CHUNKS];
-  int a_dst[A_CHUNKS];
+  // DMA assignment: 16-B chunk q = i*256 + tid of the slice image: row q>>2, physical chunk q&3
+  const uint16_t* a_src[A_PER];
+  const uint16_t* b_src[B_PER];
 #pragma unroll
-  for (int i = 0; i < A_CHUNKS; ++i) {
-    int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
-    int gm = min(m0 + row, p.M - 1);
-    a_src[i] = p.A + (size_t)gm * p.K + kc * 8;
-    a_dst[i] = row * PITCH + kc * 8;
+  for (int i = 0; i < A_PER; ++i) {
+    const int q = i * 256 + tid, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
   }
-  const uint16_t* b_src[B_CHUNKS];
-  int b_dst[B_CHUNKS];
 #pragma unroll
-  for (int i = 0; i < B_CHUNKS; ++i) {
-    int c = tid + 256 * i, row = c / CPR, kc = c % CPR;
-    int gn = min(n0 + row, p.N - 1);
-    b_src[i] = p.W + (size_t)gn * p.K + kc * 8;
-    b_dst[i] = row * PITCH + kc * 8;
+  for (int i = 0; i < B_PER; ++i) {
+    const int q = i * 256 + tid, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
-
-  u32x4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
-  auto load_slice = [&](int k0) {
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt & (NST - 1)) * ST_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = *reinterpret_cast<const u32x4*>(a_src[i] + k0);
+    for (int i = 0; i < A_PER; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16,
+                                       0, 0);
 #pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) b_reg[i] = *reinterpret_cast<const u32x4*>(b_src[i] + k0);
-  };
-  auto store_slice = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) *reinterpret_cast<u32x4*>(As + buf * BM * PITCH + a_dst[i]) = a_reg[i];
-#pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) *reinterpret_cast<u32x4*>(Bs + buf * BN * PITCH + b_dst[i]) = b_reg[i];
+    for (int i = 0; i < B_PER; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + kt * BK),
+                                       (lds_ptr_t)(st + A_BYTES + (i * 256 + wave * 64) * 16), 16, 0, 0);
   };
 
   f32x16 acc[MI][NI];
@@ -98,31 +97,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   for (int j = 0; j < NI; ++j) n_live[j] = (n0 + wn * 32 * NI + j * 32) < p.N;
 
   const int nk = p.K / BK;
-  load_slice(0);
-  store_slice(0);
-  __syncthreads();
-  const int frag_row = lane & 31, frag_k = (lane >> 5) * 8;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_slice((kt + 1) * BK);
-    const uint16_t* as = As + buf * BM * PITCH + (wm * 32 * MI + frag_row) * PITCH + frag_k;
-    const uint16_t* bs = Bs + buf * BN * PITCH + (wn * 32 * NI + frag_row) * PITCH + frag_k;
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  const int frow = lane & 31, fkg = lane >> 5;
+  // per-lane fragment byte offsets inside a slice (swizzled), one per kk
+  int a_off[MI][2], b_off[NI][2];
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * 32 * MI + i * 32 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = row * 64 + (((kk * 2 + fkg) ^ ((row >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = wn * 32 * NI + j * 32 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = A_BYTES + row * 64 + (((kk * 2 + fkg) ^ ((row >> 2) & 3)) << 4);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // slice kt must have landed; up to two younger slices stay in flight
+    const int younger = nk - 1 - kt;
+    if (younger >= 2) {
+      if (NL == 4) KVQ_WAIT_VMCNT(8); else KVQ_WAIT_VMCNT(4);
+    } else if (younger == 1) {
+      if (NL == 4) KVQ_WAIT_VMCNT(4); else KVQ_WAIT_VMCNT(2);
+    } else {
+      KVQ_WAIT_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 3 < nk) issue(kt + 3);
+    const unsigned char* st = lds + (kt & (NST - 1)) * ST_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
       V8 af[MI], bfr[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(as + i * 32 * PITCH + kk * 16);
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(st + a_off[i][kk]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const V8*>(bs + j * 32 * PITCH + kk * 16);
+      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const V8*>(st + b_off[j][kk]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          if (n_live[j]) acc[i][j] = E::mfma32(af[i], bfr[j], acc[i][j]);
+          acc[i][j] = E::mfma32(af[i], bfr[j], acc[i][j]);   // columns >= N multiply clamped rows: discarded below
     }
-    if (kt + 1 < nk) store_slice(buf ^ 1);
-    __syncthreads();
   }
+  __syncthreads();   // everybody is done with the ring before the epilogue slabs overwrite it
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // Each wave transposes its accumulators through a private LDS slab (32 rows x 32*NI fp32, reusing the
@@ -130,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // bias/activation run on float4s and the global stores are 8-16 B per lane, >= 128 B contiguous per
   // row, instead of 64 two-byte stores per lane.
   constexpr int SW = 32 * NI;                                   // slab width (floats)
-  float* slab = reinterpret_cast<float*>(lds) + wave * 32 * SW;
+  float* slab = reinterpret_cast<float*>(lds) + wave * 32 * SW;   // (lds is unsigned char[] here)
   const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
   constexpr int CPRW = SW / 4;                                   // float4 chunks per slab row
   constexpr int ROWS_PER_IT = 64 / CPRW;
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 template <typename E, int MI, int NI, int BK, int EPI>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr size_t main_bytes = 2 * (BM + BN) * (BK + 8) * sizeof(uint16_t);
+  constexpr size_t main_bytes = 4 * (BM + BN) * 64;                    // 4-slice ring of 64-B rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   auto kern = gemm_kernel<E, MI, NI, BK, EPI>;
@@ -217,16 +237,14 @@ static int launch_one(const GemmParams& p, hipStream_t st) {
 int gemm_variant(int M, int N, int K) {
   const long blocks128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
   const bool big = blocks128 >= 512;     // >= 2 tiles per CU: use the 128x128 tile
-  return (big ? 2 : 1) * 100 + ((K % 64) == 0 ? 64 : 32);
+  return (big ? 2 : 1) * 100 + 32;
 }
 
 template <typename E, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t st) {
   const int var = gemm_variant(p.M, p.N, p.K);
   const bool big = var / 100 == 2;
-  const bool k64 = var % 100 == 64;
-  if (big) return k64 ? launch_one<E, 2, 2, 64, EPI>(p, st) : launch_one<E, 2, 2, 32, EPI>(p, st);
-  return k64 ? launch_one<E, 1, 1, 64, EPI>(p, st) : launch_one<E, 1, 1, 32, EPI>(p, st);
+  return big ? launch_one<E, 2, 2, 32, EPI>(p, st) : launch_one<E, 1, 1, 32, EPI>(p, st);
 }
 
 template <int EPI>

@@ -4,33 +4,38 @@
 namespace kvq {
 
 // ------------------------------------------------------------------------------------------------
-// PatchEmbed3D im2col (swin_backbone.py:715-726).  One thread = one (token, c, kd, kh) run of pw
-// consecutive input pixels -> pw consecutive bf16 of the GEMM row.  Row layout (c,kd,kh,kw) equals
-// Conv3d weight.flatten(1).  Out-of-range (zero-padded tail) pixels read as 0.
+// PatchEmbed3D im2col (swin_backbone.py:715-726).  One workgroup = one (b, d', h') row of W' tokens:
+// it reads the Cin*pd*ph source rows (each W contiguous floats -> coalesced float4 loads), converts and
+// transposes them through LDS, and writes the W' GEMM rows (Cin*pd*ph*pw 16-bit values each) as one
+// contiguous run with 16-B stores.  Row layout (c,kd,kh,kw) equals Conv3d weight.flatten(1);
+// out-of-range (zero-padded tail) pixels read as 0.
 // ------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int Cin, int T, int H,
                                                            int W, int pd, int ph, int pw, int D, int Hh, int Ww,
                                                            uint16_t* __restrict__ out) {
-  const int runs_per_tok = Cin * pd * ph;
-  const long total = (long)B * D * Hh * Ww * runs_per_tok;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    // consecutive threads walk w' fastest so that global reads along W coalesce
-    long t = i;
-    const int wq = (int)(t % Ww); t /= Ww;
-    const int kh = (int)(t % ph); t /= ph;
-    const int hq = (int)(t % Hh); t /= Hh;
-    const int kd = (int)(t % pd); t /= pd;
-    const int dq = (int)(t % D); t /= D;
-    const int c = (int)(t % Cin);
-    const int b = (int)(t / Cin);
-    const int tt = dq * pd + kd, hh = hq * ph + kh, w0 = wq * pw;
-    const size_t tok = (((size_t)b * D + dq) * Hh + hq) * Ww + wq;
-    uint16_t* o = out + tok * (size_t)(runs_per_tok * pw) + ((size_t)(c * pd + kd) * ph + kh) * pw;
-    const bool in = tt < T && hh < H;
-    const float* src = x + (((size_t)b * Cin + c) * T + tt) * (size_t)H * W + (size_t)hh * W + w0;
-    for (int k = 0; k < pw; ++k) o[k] = E::cvt((in && w0 + k < W) ? src[k] : 0.f);
+  extern __shared__ __attribute__((aligned(16))) uint16_t tile[];   // [Ww][K] in the output order
+  const int K = Cin * pd * ph * pw;
+  const int runs = Cin * pd * ph;                 // source rows feeding this token row
+  int blk = blockIdx.x;
+  const int hq = blk % Hh; blk /= Hh;
+  const int dq = blk % D;
+  const int b = blk / D;
+  const int Wpad = Ww * pw;
+  // gather: element (run, col) of the source rows -> tile[col / pw][run * pw + col % pw]
+  for (int i = threadIdx.x; i < runs * Wpad; i += blockDim.x) {
+    const int run = i / Wpad, col = i - run * Wpad;
+    const int kh = run % ph, kd = (run / ph) % pd, c = run / (ph * pd);
+    const int tt = dq * pd + kd, hh = hq * ph + kh;
+    float v = 0.f;
+    if (tt < T && hh < H && col < W) v = x[(((size_t)b * Cin + c) * T + tt) * (size_t)H * W + (size_t)hh * W + col];
+    tile[(col / pw) * K + run * pw + (col % pw)] = E::cvt(v);
   }
+  __syncthreads();
+  uint16_t* o = out + ((((size_t)b * D + dq) * Hh + hq) * Ww) * (size_t)K;
+  const int n16 = Ww * K / 8;                       // K % 32 == 0 -> whole 16-B chunks
+  for (int i = threadIdx.x; i < n16; i += blockDim.x)
+    reinterpret_cast<u32x4*>(o)[i] = reinterpret_cast<const u32x4*>(tile)[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -181,14 +186,17 @@ extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, in
   KVQ_REQUIRE(B > 0 && Cin > 0 && T > 0 && H > 0 && W > 0 && pd > 0 && ph > 0 && pw > 0, KVQ_ERR_SHAPE,
               "kvq_patch_im2col: bad shape");
   const int D = ceil_div(T, pd), Hh = ceil_div(H, ph), Ww = ceil_div(W, pw);
-  const long total = (long)B * D * Hh * Ww * Cin * pd * ph;
-  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  const int K = Cin * pd * ph * pw;
+  const size_t lds = (size_t)Ww * K * sizeof(uint16_t);
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_patch_im2col: dtype %d", dtype);
+  KVQ_REQUIRE(K % 8 == 0 && lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED,
+              "kvq_patch_im2col: need K%%8==0 and a token row (%d x %d) of at most 64 KiB", Ww, K);
+  const int grid = B * D * Hh;
   if (dtype == KVQ_DT_FP16)
-    hipLaunchKernelGGL(patch_im2col_kernel<Fp16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, Cin, T, H, W,
+    hipLaunchKernelGGL(patch_im2col_kernel<Fp16>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, B, Cin, T, H, W,
                        pd, ph, pw, D, Hh, Ww, out);
   else
-    hipLaunchKernelGGL(patch_im2col_kernel<Bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, Cin, T, H, W,
+    hipLaunchKernelGGL(patch_im2col_kernel<Bf16>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, B, Cin, T, H, W,
                        pd, ph, pw, D, Hh, Ww, out);
   KVQ_CHECK_LAUNCH("patch_im2col_kernel");
   return KVQ_OK;

@@ -98,7 +98,9 @@ class SyntheticKVQDataset(torch.utils.data.Dataset):
         self.frames, self.h, self.w = int(opt.get("frames", 256)), int(opt.get("height", 540)), int(opt.get("width", 960))
         self.sopt = dict(opt["sample_types"]["technical"])
         s = self.sopt
-        self.sampler = UnifiedFrameSampler(s["clip_len"], 1, s.get("frame_interval", 1), s.get("num_clips", 1))
+        # the reference passes (clip_len, num_clips, frame_interval) positionally (fusion_datasets.py:962-964):
+        # num_clips lands in fragments_t, so T = clip_len * num_clips frames, split into clips by the harness
+        self.sampler = UnifiedFrameSampler(s["clip_len"], s.get("num_clips", 1), s.get("frame_interval", 1))
         g = np.random.Generator(np.random.PCG64(4321))
         self.labels = list(opt.get("labels") or g.uniform(1.0, 5.0, self.n))
 

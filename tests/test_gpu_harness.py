@@ -35,7 +35,7 @@ def test_cli_drop_in_scores_match_oracle(tmp_path):
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "kwai_swin_grpb_synthetic_test.yml")))
     a = cfg["data"]["val"]["args"]
     a.update(num_videos=3, frames=64, height=300, width=400)
-    a["sample_types"]["technical"].update(clip_len=64, num_clips=2)
+    a["sample_types"]["technical"].update(clip_len=32, num_clips=2)
     yml = tmp_path / "t.yml"
     yml.write_text(yaml.safe_dump(cfg))
     env = dict(os.environ, PYTHONPATH=ROOT)
