@@ -187,6 +187,10 @@ typedef struct {
 } KvqGemmArgs;
 
 int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
+/* Diagnostic: while dev_buf != NULL every GEMM block b < max_blocks writes uint64 stamps
+ * dev_buf[8*b + {0:start, 1:first slice landed, 2:K loop done, 3:epilogue done}] (shader clock) and
+ * [4] = XCC id << 32 | HW_ID.  Pass NULL to switch it off. */
+int kvq_debug_gemm_trace(void* dev_buf, int max_blocks);
 
 /* WindowAttention3D core (swin_backbone.py:261-322) for head_dim 32: S = q k^T + bias, where
  * bias = rpb*g + fpb*(1-g) (gated, :299-302) or rpb, + shift mask (0/-100, :583), softmax, @v.

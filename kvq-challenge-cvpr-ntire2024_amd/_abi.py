@@ -90,6 +90,7 @@ SYMBOLS = {
     "kvq_layernorm_rows": (i32, [p_void, p_void, i32, i32, i32, i32, i32, p_void, p_void, f32, p_void, i32, p_void,
                                  p_void]),
     "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
+    "kvq_debug_gemm_trace": (i32, [p_void, i32]),
     "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
                                    p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),

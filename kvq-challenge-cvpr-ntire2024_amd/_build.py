@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj
-        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), [])
+        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), []) + os.environ.get("KVQ_EXTRA_HIPCC_FLAGS", "").split()
                + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -25,25 +25,31 @@ struct GemmParams {
   float q_scale;
   const int32_t* scatter_map;
   int map_rows, out_rows;
+  unsigned long long* trace;   // diagnostic: per-block s_memtime stamps (kvq_debug_gemm_trace), else NULL
+  int trace_blocks;
 };
 
+#ifndef KVQ_GEMM_NST
+#define KVQ_GEMM_NST 3      // slices in the LDS ring: 48 KB per 128x128 block -> 3 blocks/CU (measured: 4 -> 3.66 ms,
+                            // 3 -> 3.53 ms, 2 -> 3.50 ms per step: co-residency beats DMA depth)
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
 #define KVQ_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// K loop: a 4-deep LDS ring of BK=32 slices filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane,
-// no VGPR round trip, no ds_write), three slices in flight while one is multiplied.  The waits are COUNTED
-// (s_waitcnt vmcnt(2*NL): only the slice about to be read must have landed) and the barrier is the raw
+// K loop: an NST-deep LDS ring of BK=32 slices filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane,
+// no VGPR round trip, no ds_write), NST-1 slices in flight while one is multiplied.  The waits are COUNTED
+// (s_waitcnt vmcnt((NST-2)*NL): only the slice about to be read must have landed) and the barrier is the raw
 // s_barrier, so the younger slices' DMAs stay in flight across it; one barrier per slice covers both the
 // RAW (slice t landed for every wave) and the WAR (everybody finished slice t-1 before its buffer is
-// refilled with slice t+3).  LDS rows are 64 B (no padding: the DMA image is lane-linear); the 16-B chunk
+// refilled with slice t+NST-1).  LDS rows are 64 B (no padding: the DMA image is lane-linear); the 16-B chunk
 // c of row r lives at chunk c ^ ((r>>2)&3) — applied on the SOURCE address of the DMA and on the
 // fragment read — which makes the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots.
 template <typename E, int MI, int NI, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   static_assert(BK == 32, "ring slices are 32 deep");
-  constexpr int BM = 64 * MI, BN = 64 * NI, NST = 4;
+  constexpr int BM = 64 * MI, BN = 64 * NI, NST = KVQ_GEMM_NST;
   constexpr int A_BYTES = BM * 64, ST_BYTES = (BM + BN) * 64;
   constexpr int A_PER = BM * 4 / 256, B_PER = BN * 4 / 256, NL = A_PER + B_PER;   // DMAs per thread per slice
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
   auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt & (NST - 1)) * ST_BYTES;
+    unsigned char* st = lds + (kt % NST) * ST_BYTES;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16,
@@ -96,10 +102,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int j = 0; j < NI; ++j) n_live[j] = (n0 + wn * 32 * NI + j * 32) < p.N;
 
+  const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
+  if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
   const int nk = p.K / BK;
   issue(0);
   if (nk > 1) issue(1);
-  if (nk > 2) issue(2);
+  if (NST > 3 && nk > 2) issue(2);
   const int frow = lane & 31, fkg = lane >> 5;
   // per-lane fragment byte offsets inside a slice (swizzled), one per kk
   int a_off[MI][2], b_off[NI][2];
@@ -118,16 +126,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     // slice kt must have landed; up to two younger slices stay in flight
     const int younger = nk - 1 - kt;
-    if (younger >= 2) {
+    if (NST > 3 && younger >= 2) {
       if (NL == 4) KVQ_WAIT_VMCNT(8); else KVQ_WAIT_VMCNT(4);
-    } else if (younger == 1) {
+    } else if (younger >= 1) {
       if (NL == 4) KVQ_WAIT_VMCNT(4); else KVQ_WAIT_VMCNT(2);
     } else {
       KVQ_WAIT_VMCNT(0);
     }
     __builtin_amdgcn_s_barrier();
-    if (kt + 3 < nk) issue(kt + 3);
-    const unsigned char* st = lds + (kt & (NST - 1)) * ST_BYTES;
+    if (tr && kt == 0) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
+    if (kt + NST - 1 < nk) issue(kt + NST - 1);
+    const unsigned char* st = lds + (kt % NST) * ST_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       V8 af[MI], bfr[NI];
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
   }
   __syncthreads();   // everybody is done with the ring before the epilogue slabs overwrite it
+  if (tr) p.trace[blockIdx.x * 8 + 2] = __builtin_readcyclecounter();
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // Each wave transposes its accumulators through a private LDS slab (32 rows x 32*NI fp32, reusing the
@@ -213,12 +223,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (tr) {
+    p.trace[blockIdx.x * 8 + 3] = __builtin_readcyclecounter();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    p.trace[blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
+  }
 }
 
 template <typename E, int MI, int NI, int BK, int EPI>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr size_t main_bytes = 4 * (BM + BN) * 64;                    // 4-slice ring of 64-B rows
+  constexpr size_t main_bytes = KVQ_GEMM_NST * (BM + BN) * 64;         // ring of 64-B rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   auto kern = gemm_kernel<E, MI, NI, BK, EPI>;
@@ -254,6 +272,15 @@ static int launch_dt(int dtype, const GemmParams& p, hipStream_t st) {
 
 }  // namespace kvq
 
+static unsigned long long* g_trace = nullptr;
+static int g_trace_blocks = 0;
+
+extern "C" int kvq_debug_gemm_trace(void* dev_buf, int max_blocks) {
+  g_trace = (unsigned long long*)dev_buf;
+  g_trace_blocks = dev_buf ? max_blocks : 0;
+  return KVQ_OK;
+}
+
 extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(a && a->A && a->W, KVQ_ERR_NULL, "kvq_gemm_bf16: NULL A/W");
@@ -262,7 +289,7 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED,
               "kvq_gemm_bf16: unknown dtype %d", a->dtype);
   GemmParams p{a->A, a->W, a->bias, a->M, a->N, a->K, a->out_bf16, a->out_f32, a->num_heads, a->q_scale,
-               a->scatter_map, a->map_rows, a->out_rows};
+               a->scatter_map, a->map_rows, a->out_rows, g_trace, g_trace_blocks};
   hipStream_t st = (hipStream_t)stream;
   switch (a->epilogue) {
     case KVQ_EPI_BIAS_BF16:
