@@ -165,14 +165,15 @@ typedef enum {
   KVQ_EPI_GELU_BF16 = 1,   /* out_bf16[m][n] = gelu_erf(acc + bias)            (Mlp.fc1+act, :84-85) */
   KVQ_EPI_QKV_BF16 = 2,    /* head-major split: out[(which*nH+h)*M + m][e], q scaled (:253-260)      */
   KVQ_EPI_RESID_F32 = 3,   /* out_f32[row(m)][n] += acc + bias, row(m) via scatter map (:472-488,509,514) */
-  KVQ_EPI_STORE_F32 = 4    /* out_f32[m][n] = acc (+ bias if non-NULL)         (reduction :553, embed) */
+  KVQ_EPI_STORE_F32 = 4,   /* out_f32[m][n] = acc (+ bias if non-NULL)         (reduction :553, embed) */
+  KVQ_EPI_RELU_BF16 = 5    /* out_bf16[m][n] = relu(acc + bias [+ resid_bf16[m][n]])   conv+BN(+identity)+ReLU */
 } KvqEpilogue;
 
 typedef struct {
   const uint16_t* A;     /* bf16 [M][K] */
   const uint16_t* W;     /* bf16 [N][K] */
   const float* bias;     /* [N] or NULL */
-  int32_t M, N, K;       /* N % 32 == 0, K % 32 == 0 */
+  int32_t M, N, K;       /* N % 8 == 0 (QKV: N == 96*num_heads), K % 32 == 0 */
   int32_t epilogue;      /* KvqEpilogue */
   uint16_t* out_bf16;
   float* out_f32;
@@ -184,6 +185,7 @@ typedef struct {
   int32_t map_rows;      /* rows per batch element in the map (windowed rows)  */
   int32_t out_rows;      /* rows per batch element in the output               */
   int32_t dtype;         /* KvqDtype of A, W and out_bf16                      */
+  const uint16_t* resid_bf16; /* KVQ_EPI_RELU_BF16: optional [M][N] identity branch, same dtype */
 } KvqGemmArgs;
 
 int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
@@ -231,6 +233,26 @@ int kvq_simple_vqa_head(const float* feat, int B, int T, int Cin, const float* w
 int kvq_fragment_gather(const void* video, int src_is_u8, int C, int T, int H, int W, const int32_t* hoff,
                         const int32_t* woff, int Fh, int Fw, int fs_h, int fs_w, int aligned,
                         const float* host_mean, const float* host_std, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution front-ends (2D ResNet-50 of SimpleVQA, simpleVQA_model.py:220-264; SlowFast-R50 3D convs,
+ * SlowFast_features.py:137-165).  Activations are channels-last 16-bit (B,D,H,W,C); conv = im2col -> GEMM
+ * (BatchNorm folded on the host, ReLU / identity add = KVQ_EPI_RELU_BF16); 1x1x1 stride-1 convs need no im2col.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Gather conv patches: x with explicit ELEMENT strides5 = {b,c,d,h,w} over dims5 = {B,C,D,H,W} (fp32 when
+ * src_f32, else the 16-bit dtype) -> out [B*Do*Ho*Wo][Kpad], columns ordered (kd,kh,kw,c) and zero padded
+ * from K = kd*kh*kw*C to Kpad (a multiple of 32).  Zero padding of the borders as nn.ConvNd(padding=pad3). */
+int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_t strides5[5], const int32_t dims5[5],
+                  const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int Kpad,
+                  uint16_t* out, void* stream);
+/* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
+int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
+                const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream);
+/* avgpool + global_std_pool2d (simpleVQA_model.py:8-11, 242-252): x 16-bit [rows][HW][C] -> fp32
+ * out[row*out_stride + mean_off + c] = mean, out[row*out_stride + std_off + c] = UNBIASED std (std_off < 0: skip). */
+int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW, int C, float* out, int64_t out_stride,
+                      int mean_off, int std_off, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "
            "gemm_embed"]
 K_COUNT = len(K_NAMES)
 
-EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32 = range(5)
+EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16 = range(6)
 DT_BF16, DT_FP16 = 0, 1
 ABI_VERSION = 2
 
@@ -66,7 +66,7 @@ class KvqGemmArgs(C.Structure):
     _fields_ = [("A", p_void), ("W", p_void), ("bias", p_void), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
-                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32)]
+                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void)]
 
 
 class KvqProfRecord(C.Structure):
@@ -98,6 +98,11 @@ SYMBOLS = {
                            p_void, p_void]),
     "kvq_simple_vqa_head": (i32, [p_void, i32, i32, i32, p_void, p_void, i32, p_void, p_void, p_void, p_void,
                                   p_void]),
+    "kvq_im2col_nd": (i32, [p_void, i32, i32, C.POINTER(i64 * 5), C.POINTER(i32 * 5), C.POINTER(i32 * 3),
+                            C.POINTER(i32 * 3), C.POINTER(i32 * 3), i32, p_void, p_void]),
+    "kvq_pool_nd": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
+                          i32, p_void, p_void]),
+    "kvq_mean_std_pool": (i32, [p_void, i32, i32, i32, i32, p_void, i64, i32, i32, p_void]),
     "kvq_fragment_gather": (i32, [p_void, i32, i32, i32, i32, i32, p_void, p_void, i32, i32, i32, i32, i32,
                                   C.POINTER(f32), C.POINTER(f32), p_void, p_void]),
 }

@@ -1,0 +1,216 @@
+// Convolution front-ends for the 2D ResNet-50 (SimpleVQA spatial branch, simpleVQA_model.py:220-264)
+// and the SlowFast-R50 3D-conv motion branch (SlowFast_features.py:137-165): activations are
+// channels-last 16-bit (N,D,H,W,C); a convolution is an im2col gather (HBM-bound) feeding the MFMA GEMM
+// of gemm.hip (BatchNorm folded into weight/bias on the host, ReLU / residual add in the GEMM epilogue);
+// 1x1x1 stride-1 convolutions skip the gather entirely.  Pooling and the SimpleVQA mean/std pooling are
+// plain HBM-bound reductions.
+#include "common.hpp"
+
+namespace kvq {
+
+struct Im2colParams {
+  const void* x;
+  int src_f32;                       // 1: fp32 source (network input), 0: 16-bit source of type E
+  long sb, sc, sd, sh, sw;           // element strides of the source
+  int B, C, D, H, W;
+  int kd, kh, kw, sdd, shh, sww, pd, ph, pw;
+  int Do, Ho, Wo, K, Kpad;
+  uint16_t* out;                     // [B*Do*Ho*Wo][Kpad], column order (kd,kh,kw,c), zero padded to Kpad
+};
+
+template <typename E>
+__global__ __launch_bounds__(256) void im2col_nd_kernel(Im2colParams p) {
+  const int chunks = p.Kpad / 8;
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo * chunks;
+  const bool vec = !p.src_f32 && (p.C % 8 == 0) && p.sc == 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks);
+    long r = i / chunks;
+    const int wo = (int)(r % p.Wo); r /= p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int dO = (int)(r % p.Do);
+    const int b = (int)(r / p.Do);
+    u32x4 o = {0u, 0u, 0u, 0u};
+    const int col0 = ch * 8;
+    if (vec) {
+      if (col0 < p.K) {
+        const int c = col0 % p.C;
+        int t = col0 / p.C;
+        const int kw = t % p.kw; t /= p.kw;
+        const int kh = t % p.kh;
+        const int kd = t / p.kh;
+        const int d = dO * p.sdd - p.pd + kd, h = ho * p.shh - p.ph + kh, w = wo * p.sww - p.pw + kw;
+        if (d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W)
+          o = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.x) + b * p.sb + d * p.sd + h * p.sh +
+                                              w * p.sw + c);
+      }
+    } else {
+      uint16_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int col = col0 + k;
+        float f = 0.f;
+        uint16_t raw = 0;
+        if (col < p.K) {
+          const int c = col % p.C;
+          int t = col / p.C;
+          const int kw = t % p.kw; t /= p.kw;
+          const int kh = t % p.kh;
+          const int kd = t / p.kh;
+          const int d = dO * p.sdd - p.pd + kd, h = ho * p.shh - p.ph + kh, w = wo * p.sww - p.pw + kw;
+          if (d >= 0 && d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W) {
+            const long off = b * p.sb + c * p.sc + d * p.sd + h * p.sh + w * p.sw;
+            if (p.src_f32) f = reinterpret_cast<const float*>(p.x)[off];
+            else raw = reinterpret_cast<const uint16_t*>(p.x)[off];
+          }
+        }
+        v[k] = p.src_f32 ? E::cvt(f) : raw;
+      }
+      o = (u32x4){(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                  (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
+    }
+    reinterpret_cast<u32x4*>(p.out)[i] = o;
+  }
+}
+
+struct PoolParams {
+  const uint16_t* x;     // (B,D,H,W,C) channels-last 16-bit
+  uint16_t* out;         // (B,Do,Ho,Wo,C)
+  int B, C, D, H, W, kd, kh, kw, sdd, shh, sww, pd, ph, pw, Do, Ho, Wo, is_max;
+};
+
+// max: padding never wins (-inf); avg: divides by the full window (count_include_pad=True, the
+// nn.AvgPool3d default; the SlowFast head pools use no padding anyway).
+template <typename E>
+__global__ __launch_bounds__(256) void pool_nd_kernel(PoolParams p) {
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo * p.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % p.C);
+    long r = i / p.C;
+    const int wo = (int)(r % p.Wo); r /= p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int dO = (int)(r % p.Do);
+    const int b = (int)(r / p.Do);
+    float acc = p.is_max ? -INFINITY : 0.f;
+    for (int kd = 0; kd < p.kd; ++kd)
+      for (int kh = 0; kh < p.kh; ++kh)
+        for (int kw = 0; kw < p.kw; ++kw) {
+          const int d = dO * p.sdd - p.pd + kd, h = ho * p.shh - p.ph + kh, w = wo * p.sww - p.pw + kw;
+          if (d < 0 || d >= p.D || h < 0 || h >= p.H || w < 0 || w >= p.W) continue;
+          const float v = E::to_f32(p.x[((((size_t)b * p.D + d) * p.H + h) * p.W + w) * p.C + c]);
+          acc = p.is_max ? fmaxf(acc, v) : acc + v;
+        }
+    if (!p.is_max) acc /= (float)(p.kd * p.kh * p.kw);
+    p.out[i] = E::cvt(acc);
+  }
+}
+
+// SimpleVQA pooling (simpleVQA_model.py:8-11, 242-252): per (frame, channel) mean and UNBIASED std over
+// the H*W positions of a channels-last map; two passes in fp32.  grid (rows, ceil(C/64)), block 256 =
+// 64 channels x 4 position groups.
+template <typename E>
+__global__ __launch_bounds__(256) void mean_std_pool_kernel(const uint16_t* __restrict__ x, int HW, int C,
+                                                            float* __restrict__ out, long out_stride, int mean_off,
+                                                            int std_off) {
+  __shared__ float red[4][64];
+  const int row = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const bool live = c < C;
+  const uint16_t* xr = x + (size_t)row * HW * C;
+  float s = 0.f;
+  if (live)
+    for (int i = grp; i < HW; i += 4) s += E::to_f32(xr[(size_t)i * C + c]);
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = ((red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63]) +
+                      (red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63])) / (float)HW;
+  __syncthreads();
+  float q = 0.f;
+  if (live)
+    for (int i = grp; i < HW; i += 4) {
+      const float d = E::to_f32(xr[(size_t)i * C + c]) - mean;
+      q += d * d;
+    }
+  red[grp][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (grp == 0 && live) {
+    const float ss = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[(size_t)row * out_stride + mean_off + c] = mean;
+    if (std_off >= 0) out[(size_t)row * out_stride + std_off + c] = sqrtf(ss / (float)(HW - 1));
+  }
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_t strides5[5], const int32_t dims5[5],
+                             const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int Kpad,
+                             uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && out && strides5 && dims5 && kernel3 && stride3 && pad3, KVQ_ERR_NULL, "kvq_im2col_nd: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_im2col_nd: dtype %d", dtype);
+  Im2colParams p{};
+  p.x = x; p.src_f32 = src_f32;
+  p.sb = strides5[0]; p.sc = strides5[1]; p.sd = strides5[2]; p.sh = strides5[3]; p.sw = strides5[4];
+  p.B = dims5[0]; p.C = dims5[1]; p.D = dims5[2]; p.H = dims5[3]; p.W = dims5[4];
+  p.kd = kernel3[0]; p.kh = kernel3[1]; p.kw = kernel3[2];
+  p.sdd = stride3[0]; p.shh = stride3[1]; p.sww = stride3[2];
+  p.pd = pad3[0]; p.ph = pad3[1]; p.pw = pad3[2];
+  KVQ_REQUIRE(p.B > 0 && p.C > 0 && p.D > 0 && p.H > 0 && p.W > 0 && p.kd > 0 && p.kh > 0 && p.kw > 0 && p.sdd > 0 &&
+                  p.shh > 0 && p.sww > 0,
+              KVQ_ERR_SHAPE, "kvq_im2col_nd: bad shape");
+  p.Do = (p.D + 2 * p.pd - p.kd) / p.sdd + 1;
+  p.Ho = (p.H + 2 * p.ph - p.kh) / p.shh + 1;
+  p.Wo = (p.W + 2 * p.pw - p.kw) / p.sww + 1;
+  p.K = p.kd * p.kh * p.kw * p.C;
+  KVQ_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0 && Kpad >= p.K && Kpad % 32 == 0, KVQ_ERR_SHAPE,
+              "kvq_im2col_nd: Kpad=%d must be a multiple of 32 and >= K=%d", Kpad, p.K);
+  p.Kpad = Kpad; p.out = out;
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo * (Kpad / 8);
+  const int grid = (int)((total + 255) / 256 < 131072 ? (total + 255) / 256 : 131072);
+  if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(im2col_nd_kernel<Fp16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(im2col_nd_kernel<Bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("im2col_nd_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
+                           const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && out && dims5 && kernel3 && stride3 && pad3, KVQ_ERR_NULL, "kvq_pool_nd: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_pool_nd: dtype %d", dtype);
+  PoolParams p{};
+  p.x = x; p.out = out;
+  p.B = dims5[0]; p.C = dims5[1]; p.D = dims5[2]; p.H = dims5[3]; p.W = dims5[4];
+  p.kd = kernel3[0]; p.kh = kernel3[1]; p.kw = kernel3[2];
+  p.sdd = stride3[0]; p.shh = stride3[1]; p.sww = stride3[2];
+  p.pd = pad3[0]; p.ph = pad3[1]; p.pw = pad3[2];
+  p.is_max = is_max;
+  KVQ_REQUIRE(p.B > 0 && p.C > 0 && p.kd > 0 && p.kh > 0 && p.kw > 0 && p.sdd > 0 && p.shh > 0 && p.sww > 0,
+              KVQ_ERR_SHAPE, "kvq_pool_nd: bad shape");
+  p.Do = (p.D + 2 * p.pd - p.kd) / p.sdd + 1;
+  p.Ho = (p.H + 2 * p.ph - p.kh) / p.shh + 1;
+  p.Wo = (p.W + 2 * p.pw - p.kw) / p.sww + 1;
+  KVQ_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0, KVQ_ERR_SHAPE, "kvq_pool_nd: empty output");
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo * p.C;
+  const int grid = (int)((total + 255) / 256 < 131072 ? (total + 255) / 256 : 131072);
+  if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(pool_nd_kernel<Fp16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(pool_nd_kernel<Bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("pool_nd_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW, int C, float* out, int64_t out_stride,
+                                 int mean_off, int std_off, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && out, KVQ_ERR_NULL, "kvq_mean_std_pool: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mean_std_pool: dtype %d", dtype);
+  KVQ_REQUIRE(rows > 0 && HW > 0 && C > 0 && (std_off < 0 || HW > 1), KVQ_ERR_SHAPE, "kvq_mean_std_pool: bad shape");
+  dim3 grid(rows, ceil_div(C, 64));
+  if (dtype == KVQ_DT_FP16)
+    hipLaunchKernelGGL(mean_std_pool_kernel<Fp16>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, out,
+                       (long)out_stride, mean_off, std_off);
+  else
+    hipLaunchKernelGGL(mean_std_pool_kernel<Bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, out,
+                       (long)out_stride, mean_off, std_off);
+  KVQ_CHECK_LAUNCH("mean_std_pool_kernel");
+  return KVQ_OK;
+}

@@ -25,6 +25,7 @@ struct GemmParams {
   float q_scale;
   const int32_t* scatter_map;
   int map_rows, out_rows;
+  const uint16_t* resid_h;     // KVQ_EPI_RELU_BF16: optional 16-bit [M][N] identity branch
   unsigned long long* trace;   // diagnostic: per-block s_memtime stamps (kvq_debug_gemm_trace), else NULL
   int trace_blocks;
 };
@@ -97,10 +98,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // wave-uniform: which 32-column tiles of this wave exist at all (N % 32 == 0)
-  bool n_live[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) n_live[j] = (n0 + wn * 32 * NI + j * 32) < p.N;
 
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
   if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
@@ -167,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int ch = lane % CPRW, rsub = lane / CPRW;
   const int nbase = n0 + wn * SW;
   const int n = nbase + ch * 4;
-  const bool col_live = n < p.N;                                 // N % 32 == 0 and 4 | 32: whole chunk in or out
+  const bool col_live = n < p.N;                                 // N % 4 == 0: a float4 chunk is wholly in or out
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (p.bias && col_live) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
   int which = 0, head = 0, e0 = 0;
@@ -200,6 +197,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
       } else if (EPI == KVQ_EPI_GELU_BF16) {
         u32x2 o = {E::pack2(gelu_fast(v[0]), gelu_fast(v[1])), E::pack2(gelu_fast(v[2]), gelu_fast(v[3]))};
+        *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
+      } else if (EPI == KVQ_EPI_RELU_BF16) {     // conv + folded BN (+ identity) + ReLU (simpleVQA_model.py:104-124)
+        if (p.resid_h) {
+          const u32x2 rr = *reinterpret_cast<const u32x2*>(p.resid_h + (size_t)m * p.N + n);
+          v[0] += E::to_f32((uint16_t)(rr[0] & 0xffffu)); v[1] += E::to_f32((uint16_t)(rr[0] >> 16));
+          v[2] += E::to_f32((uint16_t)(rr[1] & 0xffffu)); v[3] += E::to_f32((uint16_t)(rr[1] >> 16));
+        }
+        u32x2 o = {E::pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), E::pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))};
         *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
       } else if (EPI == KVQ_EPI_QKV_BF16) {
         u32x2 o = {E::pack2(v[0] * scale, v[1] * scale), E::pack2(v[2] * scale, v[3] * scale)};
@@ -284,12 +289,12 @@ extern "C" int kvq_debug_gemm_trace(void* dev_buf, int max_blocks) {
 extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(a && a->A && a->W, KVQ_ERR_NULL, "kvq_gemm_bf16: NULL A/W");
-  KVQ_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 32 == 0 && a->K % 32 == 0, KVQ_ERR_SHAPE,
-              "kvq_gemm_bf16: need M>0, N%%32==0, K%%32==0 (got M=%d N=%d K=%d)", a->M, a->N, a->K);
+  KVQ_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 8 == 0 && a->K % 32 == 0, KVQ_ERR_SHAPE,
+              "kvq_gemm_bf16: need M>0, N%%8==0, K%%32==0 (got M=%d N=%d K=%d)", a->M, a->N, a->K);
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED,
               "kvq_gemm_bf16: unknown dtype %d", a->dtype);
   GemmParams p{a->A, a->W, a->bias, a->M, a->N, a->K, a->out_bf16, a->out_f32, a->num_heads, a->q_scale,
-               a->scatter_map, a->map_rows, a->out_rows, g_trace, g_trace_blocks};
+               a->scatter_map, a->map_rows, a->out_rows, a->resid_bf16, g_trace, g_trace_blocks};
   hipStream_t st = (hipStream_t)stream;
   switch (a->epilogue) {
     case KVQ_EPI_BIAS_BF16:
@@ -298,6 +303,9 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
     case KVQ_EPI_GELU_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
       return launch_dt<KVQ_EPI_GELU_BF16>(a->dtype, p, st);
+    case KVQ_EPI_RELU_BF16:
+      KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
+      return launch_dt<KVQ_EPI_RELU_BF16>(a->dtype, p, st);
     case KVQ_EPI_QKV_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
       KVQ_REQUIRE(a->num_heads > 0 && a->N == 96 * a->num_heads, KVQ_ERR_SHAPE,

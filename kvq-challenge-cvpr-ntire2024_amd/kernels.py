@@ -149,3 +149,67 @@ def fragment_gather(video: torch.Tensor, hoff: torch.Tensor, woff: torch.Tensor,
                                     fragments_h, fragments_w, fsize_h, fsize_w, aligned, m, s, ptr(out),
                                     current_stream()), "kvq_fragment_gather")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution front-ends (channels-last 16-bit activations (B,D,H,W,C))
+# ------------------------------------------------------------------------------------------------
+def _i32x(vals):
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def conv_out_dims(dims, kernel, stride, pad):
+    return tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip(dims, kernel, stride, pad))
+
+
+def im2col_nd(x: torch.Tensor, dims5, strides5, kernel, stride, pad, out_dtype, k_pad=None):
+    """x: device tensor (fp32 network input or 16-bit activation) addressed through ELEMENT strides5 =
+    (b,c,d,h,w) over dims5 = (B,C,D,H,W).  Returns ([B*Do*Ho*Wo, Kpad] 16-bit, (Do,Ho,Wo))."""
+    _need_gpu(x)
+    B, Cc, D, H, W = dims5
+    Do, Ho, Wo = conv_out_dims((D, H, W), kernel, stride, pad)
+    K = kernel[0] * kernel[1] * kernel[2] * Cc
+    k_pad = -(-K // 32) * 32 if k_pad is None else k_pad
+    out = torch.empty(B * Do * Ho * Wo, k_pad, dtype=out_dtype, device=x.device)
+    st = (C.c_int64 * 5)(*[int(s) for s in strides5])
+    check(lib().kvq_im2col_nd(ptr(x), int(x.dtype == torch.float32), dtype_code(out_dtype), C.byref(st),
+                              C.byref(_i32x(dims5)), C.byref(_i32x(kernel)), C.byref(_i32x(stride)),
+                              C.byref(_i32x(pad)), k_pad, ptr(out), current_stream()), "kvq_im2col_nd")
+    return out, (Do, Ho, Wo)
+
+
+def pool_nd(x: torch.Tensor, kernel, stride, pad, is_max: bool):
+    """x (B,D,H,W,C) channels-last 16-bit, contiguous."""
+    _need_gpu(x)
+    assert x.dtype in HALF_TYPES and x.is_contiguous() and x.dim() == 5
+    B, D, H, W, Cc = x.shape
+    Do, Ho, Wo = conv_out_dims((D, H, W), kernel, stride, pad)
+    out = torch.empty(B, Do, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    check(lib().kvq_pool_nd(ptr(x), dtype_code(x.dtype), C.byref(_i32x((B, Cc, D, H, W))), C.byref(_i32x(kernel)),
+                            C.byref(_i32x(stride)), C.byref(_i32x(pad)), int(is_max), ptr(out), current_stream()),
+          "kvq_pool_nd")
+    return out
+
+
+def mean_std_pool(x: torch.Tensor, out: torch.Tensor, mean_off: int, std_off: int):
+    """x 16-bit [rows, HW, C]; writes fp32 mean/unbiased-std into out[row, mean_off:+C] / out[row, std_off:+C]."""
+    _need_gpu(x, out)
+    assert x.dtype in HALF_TYPES and x.is_contiguous() and out.dtype == torch.float32 and out.stride(-1) == 1
+    rows, HW, Cc = x.shape
+    check(lib().kvq_mean_std_pool(ptr(x), dtype_code(x.dtype), rows, HW, Cc, ptr(out), out.stride(0), mean_off, std_off,
+                                  current_stream()), "kvq_mean_std_pool")
+    return out
+
+
+def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None):
+    """out[M,N] = (relu)(A @ W^T + bias (+ resid)), 16-bit in/out."""
+    _need_gpu(A, W, bias, resid)
+    M, N = A.shape[0], W.shape[0]
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    a = _abi.KvqGemmArgs()
+    a.A, a.W, a.bias, a.M, a.N, a.K = ptr(A), ptr(W), ptr(bias), M, N, A.shape[1]
+    a.epilogue = _abi.EPI_RELU_BF16 if relu else _abi.EPI_BIAS_BF16
+    assert resid is None or relu, "identity add is fused with the ReLU epilogue only"
+    a.out_bf16, a.resid_bf16, a.dtype = ptr(out), ptr(resid), dtype_code(A.dtype)
+    check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
+    return out

@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's ``models/backbones/simpleVQA_model.py`` ``ResNet`` (:128-264):
+2D ResNet-50 on the video frames with (avg, std) pooling after layer2/3/4, concatenated with the
+pre-extracted SlowFast features -> (B, T, 9472).  Same module tree / state_dict keys as the reference
+(torchvision layout incl. BatchNorm buffers and the unused ``quality`` regressor);
+forward = im2col + MFMA GEMM (BatchNorm folded, ReLU / identity add in the epilogue) + pooling kernels
+of libkvq_hip.so on channels-last 16-bit activations.  No PyTorch compute path."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from ... import _abi, kernels
+from .swin_backbone import _Affine
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps = 1e-5
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, pad=0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")     # simpleVQA_model.py:171
+        self.kernel, self.stride, self.pad = k, stride, pad
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1, self.bn1 = _Conv(inplanes, planes, 1), _BN(planes)
+        self.conv2, self.bn2 = _Conv(planes, planes, 3, stride, 1), _BN(planes)
+        self.conv3, self.bn3 = _Conv(planes, planes * 4, 1), _BN(planes * 4)
+        self.downsample = (nn.Sequential(_Conv(inplanes, planes * 4, 1, stride), _BN(planes * 4))
+                           if downsample else None)
+        self.stride = stride
+
+
+def _fold(conv: _Conv, bn: _BN, half, device):
+    """BatchNorm (eval) folded into the conv: w' = w*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps);
+    weight reordered to the im2col column order (kh,kw,c), zero padded to a multiple of 32, 16-bit."""
+    w = conv.weight.detach().to(device=device, dtype=torch.float32)
+    scale = bn.weight.detach().to(device, torch.float32) / torch.sqrt(bn.running_var.to(device, torch.float32) + bn.eps)
+    bias = bn.bias.detach().to(device, torch.float32) - bn.running_mean.to(device, torch.float32) * scale
+    w = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    K = w.shape[1]
+    kpad = -(-K // 32) * 32
+    if kpad != K:
+        w = torch.nn.functional.pad(w, (0, kpad - K))
+    if half == torch.float16:
+        w = w.clamp(-65504.0, 65504.0)
+    return w.to(half).contiguous(), bias.contiguous()
+
+
+class ResNet(nn.Module):
+    def __init__(self, block=Bottleneck, layers=(3, 4, 6, 3), operand_dtype=None, **kwargs):
+        super().__init__()
+        self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
+        self.inplanes = 64
+        self.conv1, self.bn1 = _Conv(3, 64, 7, 2, 3), _BN(64)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        # unused by forward but part of the reference's state_dict (simpleVQA_model.py:167)
+        self.quality = nn.Sequential(_Affine((128, 4096 + 2048 + 1024 + 2048 + 256), (128,)), _Affine((1, 128), (1,)))
+        self._wcache = None
+
+    def _make_layer(self, planes, blocks, stride):
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample=(stride != 1 or self.inplanes != planes * 4))]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def _weights(self, device):
+        sig = (self.operand_dtype,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) +
+                                            list(self.buffers()))
+        if self._wcache is not None and self._wcache[0] == sig:
+            return self._wcache[1]
+        half = _abi.torch_dtype(self.operand_dtype)
+        w = {"stem": _fold(self.conv1, self.bn1, half, device)}
+        for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
+            for bi, blk in enumerate(layer):
+                k = f"l{li}.{bi}."
+                w[k + "1"] = _fold(blk.conv1, blk.bn1, half, device)
+                w[k + "2"] = _fold(blk.conv2, blk.bn2, half, device)
+                w[k + "3"] = _fold(blk.conv3, blk.bn3, half, device)
+                if blk.downsample is not None:
+                    w[k + "d"] = _fold(blk.downsample[0], blk.downsample[1], half, device)
+        self._wcache = (sig, w)
+        return w
+
+    # ---- conv on channels-last 16-bit (N,H,W,C) ---------------------------------------------------
+    @staticmethod
+    def _conv(x, wb, k, stride, pad, relu, resid=None):
+        n, h, w_, c = x.shape
+        wt, bias = wb
+        if k == 1 and stride == 1:
+            a, (ho, wo) = x.reshape(n * h * w_, c), (h, w_)
+        else:
+            a, (_, ho, wo) = kernels.im2col_nd(x, (n, c, 1, h, w_), (h * w_ * c, 1, 0, w_ * c, c), (1, k, k),
+                                               (1, stride, stride), (0, pad, pad), x.dtype, wt.shape[1])
+        r = None if resid is None else resid.reshape(n * ho * wo, -1)
+        return kernels.conv_gemm(a, wt, bias, relu, r).reshape(n, ho, wo, wt.shape[0])
+
+    def _bottleneck(self, x, w, key, blk):
+        out = self._conv(x, w[key + "1"], 1, 1, 0, True)
+        out = self._conv(out, w[key + "2"], 3, blk.stride, 1, True)
+        identity = x if blk.downsample is None else self._conv(x, w[key + "d"], 1, blk.stride, 0, False)
+        return self._conv(out, w[key + "3"], 1, 1, 0, True, resid=identity)       # relu(bn3(conv3) + identity)
+
+    def forward(self, batch, multi=None, layer=None):
+        x = batch["simpleVQA"]
+        if not x.is_cuda:
+            raise _abi.KvqError("ResNet.forward needs the frames on a HIP device; there is no CPU path")
+        x = x.to(torch.float32).contiguous()
+        b, c, T, h1, w1 = x.shape
+        feat3d = batch["feat"].to(x.device, torch.float32).reshape(b * T, -1)
+        w = self._weights(x.device)
+        half = _abi.torch_dtype(self.operand_dtype)
+        n = b * T
+        # stem 7x7/2 reads the fp32 (b,c,T,h,w) input directly: frame index = (b, t) through the strides
+        wt, bias = w["stem"]
+        a, (_, ho, wo) = self._stem_im2col(x, half, wt.shape[1])
+        y = kernels.conv_gemm(a, wt, bias, True).reshape(n, ho, wo, 64)
+        y = kernels.pool_nd(y.unsqueeze(1), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).squeeze(1)        # maxpool 3x3/2
+        out = torch.empty(n, 7168 + feat3d.shape[1], dtype=torch.float32, device=x.device)
+        off = 0
+        for li, layer_mod in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
+            for bi, blk in enumerate(layer_mod):
+                y = self._bottleneck(y, w, f"l{li}.{bi}.", blk)
+            if li >= 2:                                                    # avgpool + global_std_pool2d (:242-252)
+                nn_, hh, ww, cc = y.shape
+                kernels.mean_std_pool(y.reshape(nn_, hh * ww, cc), out, off, off + cc)
+                off += 2 * cc
+        out[:, off:] = feat3d                                                # x_3D_features (:256)
+        return out.reshape(b, T, -1)
+
+    @staticmethod
+    def _stem_im2col(x, half, kpad):
+        b, c, T, h, w_ = x.shape
+        # frames are (b, t) pairs: im2col's batch stride walks t, so run it per batch element when b > 1
+        if b == 1:
+            return kernels.im2col_nd(x, (T, c, 1, h, w_), (h * w_, T * h * w_, 0, w_, 1), (1, 7, 7), (1, 2, 2), (0, 3, 3),
+                                     half, kpad)
+        parts = [kernels.im2col_nd(x[i], (T, c, 1, h, w_), (h * w_, T * h * w_, 0, w_, 1), (1, 7, 7), (1, 2, 2),
+                                   (0, 3, 3), half, kpad) for i in range(b)]
+        return torch.cat([p[0] for p in parts]), parts[0][1]
+
+
+def resnet50(pretrained=False, progress=True, **kwargs):
+    """``simpleVQA_model.py:307-325``.  ImageNet weights are a network download in the reference
+    (``model_zoo.load_url``); offline this returns the randomly initialised network — load a checkpoint
+    with ``load_state_dict`` (keys are the reference's)."""
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)

@@ -119,9 +119,45 @@ def simple_head_param_shapes(in_channels=9472, hidden=128) -> "OrderedDict[str, 
     ])
 
 
+def resnet50_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict of the reference's simpleVQA ResNet-50 (simpleVQA_model.py:128-218), buffers included."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def bn(prefix, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{prefix}.{leaf}"] = (c,)
+        s[f"{prefix}.num_batches_tracked"] = ()
+
+    s["conv1.weight"] = (64, 3, 7, 7)
+    bn("bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], 1):
+        for bi in range(blocks):
+            p = f"layer{li}.{bi}"
+            s[p + ".conv1.weight"] = (planes, inplanes, 1, 1); bn(p + ".bn1", planes)
+            s[p + ".conv2.weight"] = (planes, planes, 3, 3); bn(p + ".bn2", planes)
+            s[p + ".conv3.weight"] = (planes * 4, planes, 1, 1); bn(p + ".bn3", planes * 4)
+            if bi == 0:
+                s[p + ".downsample.0.weight"] = (planes * 4, inplanes, 1, 1); bn(p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    s["quality.0.weight"] = (128, 9472); s["quality.0.bias"] = (128,)
+    s["quality.1.weight"] = (1, 128); s["quality.1.bias"] = (1,)
+    return s
+
+
+def synth_resnet50_weights(seed: int = 0, scheme: str = "stress"):
+    return synth_params(resnet50_param_shapes(), seed, scheme, prefix="resnet.")
+
+
 def _draw(name: str, shape, seed: int, scheme: str) -> np.ndarray:
     g = _gen(seed, name)
     leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, np.int64)
+    if leaf == "running_mean":
+        return (0.1 * g.standard_normal(shape)).astype(np.float32) if scheme == "stress" else np.zeros(shape, np.float32)
+    if leaf == "running_var":
+        return g.uniform(0.5, 1.5, shape).astype(np.float32) if scheme == "stress" else np.ones(shape, np.float32)
     is_norm = (".norm" in name or name.startswith("norm.") or ".bn" in name
                or "downsample.1." in name)
     if scheme == "init":

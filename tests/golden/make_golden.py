@@ -241,7 +241,36 @@ def sec_sampler(ref):
     save("sampler.npz", d)
 
 
-SECTIONS = {"layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+def sec_resnet(ref):
+    """SimpleVQA spatial branch (2D ResNet-50 + avg/std pooling + feature concat) and the whole
+    VQA_Network(simpleVQA) score on seeded weights."""
+    from oracle import resnet_oracle as RO
+    d = {}
+    g = np.random.Generator(np.random.PCG64(55))
+    for name, (B, T, H, W) in {"r50_2x96": (1, 2, 96, 96), "r50_b2_3x64x80": (2, 3, 64, 80)}.items():
+        wts = synth.synth_resnet50_weights(4, "stress")
+        hw = synth.synth_simple_head_weights(9472, 128, 4, "stress")
+        m = ref.simple.ResNet(ref.simple.Bottleneck, [3, 4, 6, 3]).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in wts.items()})
+        head = ref.head.simpleVQAHead(9472, 128).eval()
+        head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()})
+        frames = torch.from_numpy(g.standard_normal((B, 3, T, H, W)).astype(np.float32))
+        feat3d = torch.from_numpy(g.standard_normal((B, T, 2304)).astype(np.float32))
+        with torch.no_grad():
+            f_ref = m({"simpleVQA": frames, "feat": feat3d})
+            s_ref = head(f_ref)
+            f = RO.simplevqa_features(frames, feat3d, wts)
+            s = O.simple_vqa_head(f, hw)
+        err = float((f - f_ref).abs().max() / f_ref.abs().max())
+        print(f"{name}: feat {tuple(f_ref.shape)} rel |oracle-ref| {err:.2e} score {s_ref.flatten().tolist()} d {float((s - s_ref).abs().max()):.2e}")
+        assert err <= 1e-5 and float((s - s_ref).abs().max()) <= 1e-4
+        d[f"{name}/feat"] = f_ref.numpy()
+        d[f"{name}/score"] = s_ref.numpy()
+        d[f"{name}/meta"] = np.asarray([B, T, H, W])
+    save("resnet.npz", d)
+
+
+SECTIONS = {"resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

@@ -1,0 +1,122 @@
+"""SimpleVQA spatial branch (BASELINE config C1): oracle vs the reference's golden outputs on CPU; the
+HIP conv path (im2col + MFMA GEMM + pooling kernels) vs the oracle / golden on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import kvq_amd  # noqa: F401
+from kvq_amd.utils import synth
+from oracle import resnet_oracle as RO
+from oracle import swin3d_oracle as O
+
+CASES = ["r50_2x96", "r50_b2_3x64x80"]
+
+
+def _inputs(golden):
+    g = golden("resnet.npz")
+    rng = np.random.Generator(np.random.PCG64(55))
+    out = {}
+    for name in CASES:                      # same draw order as make_golden.sec_resnet
+        B, T, H, W = (int(v) for v in g[f"{name}/meta"])
+        frames = torch.from_numpy(rng.standard_normal((B, 3, T, H, W)).astype(np.float32))
+        feat3d = torch.from_numpy(rng.standard_normal((B, T, 2304)).astype(np.float32))
+        out[name] = (frames, feat3d, g[f"{name}/feat"], g[f"{name}/score"])
+    return out
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_resnet_oracle_matches_reference_golden(golden, case):
+    frames, feat3d, f_ref, s_ref = _inputs(golden)[case]
+    f = RO.simplevqa_features(frames, feat3d, synth.synth_resnet50_weights(4, "stress"))
+    assert np.abs(f.numpy() - f_ref).max() <= 1e-5 * np.abs(f_ref).max()
+    s = O.simple_vqa_head(f, synth.synth_simple_head_weights(9472, 128, 4, "stress"))
+    assert np.abs(s.numpy() - s_ref).max() <= 1e-4
+
+
+def test_resnet_state_dict_surface():
+    from kvq_amd.models.backbones.simpleVQA_model import resnet50
+    sd = resnet50().state_dict()
+    shapes = synth.resnet50_param_shapes()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("half", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("spec", [
+    # B,C,D,H,W, kernel, stride, pad
+    (2, 64, 1, 14, 14, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (2, 64, 1, 15, 13, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (1, 8, 6, 9, 9, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (1, 16, 8, 7, 7, (7, 1, 1), (4, 1, 1), (3, 0, 0)),
+    (1, 256, 1, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+])
+def test_im2col_nd_channels_last(spec, half):
+    from kvq_amd import kernels
+    B, C, D, H, W, k, s, p = spec
+    g = np.random.Generator(np.random.PCG64(sum(spec[:5])))
+    x = torch.from_numpy(g.standard_normal((B, D, H, W, C)).astype(np.float32)).to(half)
+    cols, (Do, Ho, Wo) = kernels.im2col_nd(x.cuda(), (B, C, D, H, W), (D * H * W * C, 1, H * W * C, W * C, C), k, s, p, half)
+    xp = torch.nn.functional.pad(x.float().permute(0, 4, 1, 2, 3), (p[2], p[2], p[1], p[1], p[0], p[0]))
+    u = xp.unfold(2, k[0], s[0]).unfold(3, k[1], s[1]).unfold(4, k[2], s[2])       # B,C,Do,Ho,Wo,kd,kh,kw
+    ref = u.permute(0, 2, 3, 4, 5, 6, 7, 1).reshape(B * Do * Ho * Wo, -1)          # (kd,kh,kw,c) columns
+    K = ref.shape[1]
+    assert cols.shape == (B * Do * Ho * Wo, -(-K // 32) * 32)
+    assert torch.equal(cols[:, :K].float().cpu(), ref) and torch.all(cols[:, K:] == 0)
+
+
+@gpu
+def test_im2col_nd_fp32_stem_strides():
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(3))
+    x = torch.from_numpy(g.standard_normal((1, 3, 4, 20, 22)).astype(np.float32))        # (b,c,T,h,w)
+    T, h, w = 4, 20, 22
+    cols, (_, Ho, Wo) = kernels.im2col_nd(x.cuda(), (T, 3, 1, h, w), (h * w, T * h * w, 0, w, 1), (1, 7, 7), (1, 2, 2),
+                                          (0, 3, 3), torch.float16)
+    fr = x[0].permute(1, 0, 2, 3)                                                         # frames (T,3,h,w)
+    ref = torch.nn.functional.unfold(fr, 7, padding=3, stride=2)                           # (T, 3*49, L) cols (c,kh,kw)
+    ref = ref.reshape(T, 3, 49, -1).permute(0, 3, 2, 1).reshape(T * Ho * Wo, 147)          # -> (kh,kw,c)
+    assert torch.equal(cols[:, :147].float().cpu(), ref.half().float()) and cols.shape[1] == 160
+
+
+@gpu
+def test_pool_and_mean_std():
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(4))
+    x = torch.from_numpy(g.standard_normal((2, 3, 13, 15, 40)).astype(np.float32)).half()
+    mp = kernels.pool_nd(x.cuda(), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).float().cpu()
+    ref = torch.nn.functional.max_pool3d(x.float().permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1)).permute(0, 2, 3, 4, 1)
+    assert torch.equal(mp, ref)
+    ap = kernels.pool_nd(x.cuda(), (3, 13, 15), (1, 1, 1), (0, 0, 0), False).float().cpu()
+    ref = x.float().mean((1, 2, 3), keepdim=True)
+    assert (ap - ref).abs().max().item() <= 2e-3
+    y = x[:, 0].reshape(2, 13 * 15, 40)
+    out = torch.zeros(2, 100, device="cuda")
+    kernels.mean_std_pool(y.contiguous().cuda(), out, 5, 50)
+    assert (out[:, 5:45].cpu() - y.float().mean(1)).abs().max().item() <= 1e-5
+    assert (out[:, 50:90].cpu() - y.float().std(1)).abs().max().item() <= 1e-5     # unbiased, like torch.std
+
+
+@gpu
+@pytest.mark.parametrize("case", CASES)
+def test_simplevqa_network_vs_reference_golden(golden, case):
+    from kvq_amd.models import VQA_Network
+    frames, feat3d, f_ref, s_ref = _inputs(golden)[case]
+    net = VQA_Network({"model": {"args": {"simpleVQA": {"backbone": None, "head": {"in_channels": 9472,
+                                                                                    "hidden_channels": 128}}}}})
+    sd = {f"simpleVQA_backbone.{k}": torch.from_numpy(np.asarray(v)) for k, v in synth.synth_resnet50_weights(4, "stress").items()}
+    sd.update({f"simpleVQA_head.{k}": torch.from_numpy(v) for k, v in synth.synth_simple_head_weights(9472, 128, 4, "stress").items()})
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        score, feats = net(inputs={"simpleVQA": frames.cuda(), "feat": feat3d.cuda()}, reduce_scores=True,
+                           return_pooled_feats=True)
+    f = feats["simpleVQA"].cpu().numpy()
+    assert f.shape == f_ref.shape
+    rel = np.linalg.norm(f[..., :7168] - f_ref[..., :7168]) / np.linalg.norm(f_ref[..., :7168])
+    assert rel <= 5e-3, rel                                  # 53 conv layers on fp16 operands, fp32 accumulate
+    assert np.array_equal(f[..., 7168:], f_ref[..., 7168:])  # the SlowFast features pass through untouched
+    assert np.abs(score.cpu().numpy() - s_ref).max() <= 1e-3, (score, s_ref)
