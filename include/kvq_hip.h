@@ -186,6 +186,8 @@ typedef struct {
   int32_t out_rows;      /* rows per batch element in the output               */
   int32_t dtype;         /* KvqDtype of A, W and out_bf16                      */
   const uint16_t* resid_bf16; /* KVQ_EPI_RELU_BF16: optional [M][N] identity branch, same dtype */
+  const float* resid_f32;     /* KVQ_EPI_RELU_BF16: optional fp32 [M][N] identity branch; with this epilogue a
+                                 non-NULL out_f32 additionally receives the fp32 (un-rounded) result */
 } KvqGemmArgs;
 
 int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);

@@ -66,7 +66,7 @@ class KvqGemmArgs(C.Structure):
     _fields_ = [("A", p_void), ("W", p_void), ("bias", p_void), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
-                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void)]
+                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void)]
 
 
 class KvqProfRecord(C.Structure):

@@ -26,6 +26,7 @@ struct GemmParams {
   const int32_t* scatter_map;
   int map_rows, out_rows;
   const uint16_t* resid_h;     // KVQ_EPI_RELU_BF16: optional 16-bit [M][N] identity branch
+  const float* resid_f32;      // KVQ_EPI_RELU_BF16: optional fp32 [M][N] identity branch (residual stream kept in fp32)
   unsigned long long* trace;   // diagnostic: per-block s_memtime stamps (kvq_debug_gemm_trace), else NULL
   int trace_blocks;
 };
@@ -204,7 +205,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
           v[0] += E::to_f32((uint16_t)(rr[0] & 0xffffu)); v[1] += E::to_f32((uint16_t)(rr[0] >> 16));
           v[2] += E::to_f32((uint16_t)(rr[1] & 0xffffu)); v[3] += E::to_f32((uint16_t)(rr[1] >> 16));
         }
-        u32x2 o = {E::pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), E::pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))};
+        if (p.resid_f32) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.resid_f32 + (size_t)m * p.N + n);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] += rr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n) = v;   // fp32 copy for the identity path
+        u32x2 o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
         *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
       } else if (EPI == KVQ_EPI_QKV_BF16) {
         u32x2 o = {E::pack2(v[0] * scale, v[1] * scale), E::pack2(v[2] * scale, v[3] * scale)};
@@ -294,7 +303,7 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED,
               "kvq_gemm_bf16: unknown dtype %d", a->dtype);
   GemmParams p{a->A, a->W, a->bias, a->M, a->N, a->K, a->out_bf16, a->out_f32, a->num_heads, a->q_scale,
-               a->scatter_map, a->map_rows, a->out_rows, a->resid_bf16, g_trace, g_trace_blocks};
+               a->scatter_map, a->map_rows, a->out_rows, a->resid_bf16, a->resid_f32, g_trace, g_trace_blocks};
   hipStream_t st = (hipStream_t)stream;
   switch (a->epilogue) {
     case KVQ_EPI_BIAS_BF16:

@@ -201,15 +201,19 @@ def mean_std_pool(x: torch.Tensor, out: torch.Tensor, mean_off: int, std_off: in
     return out
 
 
-def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None):
-    """out[M,N] = (relu)(A @ W^T + bias (+ resid)), 16-bit in/out."""
-    _need_gpu(A, W, bias, resid)
+def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None, resid_f32=None, want_f32=False):
+    """out[M,N] = (relu)(A @ W^T + bias (+ resid)), 16-bit operands.  ``resid`` 16-bit / ``resid_f32`` fp32
+    identity branch (ReLU epilogue only).  Returns the 16-bit output, or (16-bit, fp32 copy) when
+    ``want_f32`` — the fp32 copy keeps a residual stream un-rounded between blocks."""
+    _need_gpu(A, W, bias, resid, resid_f32)
     M, N = A.shape[0], W.shape[0]
     out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    out32 = torch.empty(M, N, dtype=torch.float32, device=A.device) if want_f32 else None
     a = _abi.KvqGemmArgs()
     a.A, a.W, a.bias, a.M, a.N, a.K = ptr(A), ptr(W), ptr(bias), M, N, A.shape[1]
     a.epilogue = _abi.EPI_RELU_BF16 if relu else _abi.EPI_BIAS_BF16
-    assert resid is None or relu, "identity add is fused with the ReLU epilogue only"
-    a.out_bf16, a.resid_bf16, a.dtype = ptr(out), ptr(resid), dtype_code(A.dtype)
+    assert relu or (resid is None and resid_f32 is None and not want_f32), "identity add / fp32 copy: ReLU epilogue only"
+    a.out_bf16, a.out_f32, a.resid_bf16, a.resid_f32 = ptr(out), ptr(out32), ptr(resid), ptr(resid_f32)
+    a.dtype = dtype_code(A.dtype)
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
-    return out
+    return (out, out32) if want_f32 else out

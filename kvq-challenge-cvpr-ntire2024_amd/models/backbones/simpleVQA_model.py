@@ -104,22 +104,34 @@ class ResNet(nn.Module):
 
     # ---- conv on channels-last 16-bit (N,H,W,C) ---------------------------------------------------
     @staticmethod
-    def _conv(x, wb, k, stride, pad, relu, resid=None):
+    def _cols(x, k, stride, pad, kpad):
         n, h, w_, c = x.shape
-        wt, bias = wb
         if k == 1 and stride == 1:
-            a, (ho, wo) = x.reshape(n * h * w_, c), (h, w_)
-        else:
-            a, (_, ho, wo) = kernels.im2col_nd(x, (n, c, 1, h, w_), (h * w_ * c, 1, 0, w_ * c, c), (1, k, k),
-                                               (1, stride, stride), (0, pad, pad), x.dtype, wt.shape[1])
-        r = None if resid is None else resid.reshape(n * ho * wo, -1)
-        return kernels.conv_gemm(a, wt, bias, relu, r).reshape(n, ho, wo, wt.shape[0])
+            return x.reshape(n * h * w_, c), (h, w_)
+        a, (_, ho, wo) = kernels.im2col_nd(x, (n, c, 1, h, w_), (h * w_ * c, 1, 0, w_ * c, c), (1, k, k),
+                                           (1, stride, stride), (0, pad, pad), x.dtype, kpad)
+        return a, (ho, wo)
 
-    def _bottleneck(self, x, w, key, blk):
-        out = self._conv(x, w[key + "1"], 1, 1, 0, True)
-        out = self._conv(out, w[key + "2"], 3, blk.stride, 1, True)
-        identity = x if blk.downsample is None else self._conv(x, w[key + "d"], 1, blk.stride, 0, False)
-        return self._conv(out, w[key + "3"], 1, 1, 0, True, resid=identity)       # relu(bn3(conv3) + identity)
+    def _conv_relu(self, x, wb, k, stride, pad):
+        a, (ho, wo) = self._cols(x, k, stride, pad, wb[0].shape[1])
+        return kernels.conv_gemm(a, wb[0], wb[1], True).reshape(x.shape[0], ho, wo, wb[0].shape[0])
+
+    def _bottleneck(self, x16, x32, w, key, blk):
+        """x16: 16-bit activation feeding the convs; x32: the same tensor un-rounded (fp32) for the identity
+        path — the residual stream stays fp32 between blocks, like the Swin trunk's."""
+        n = x16.shape[0]
+        out = self._conv_relu(x16, w[key + "1"], 1, 1, 0)
+        out = self._conv_relu(out, w[key + "2"], 3, blk.stride, 1)
+        if blk.downsample is None:
+            identity = x32.reshape(-1, x32.shape[-1])
+        else:                                                   # 1x1/stride conv + BN, no ReLU, kept in fp32
+            wd, bd = w[key + "d"]
+            a, _ = self._cols(x16, 1, blk.stride, 0, wd.shape[1])
+            identity = kernels.gemm(a, wd, bd, _abi.EPI_STORE_F32)
+        ho, wo = out.shape[1], out.shape[2]
+        w3, b3 = w[key + "3"]
+        y16, y32 = kernels.conv_gemm(out.reshape(n * ho * wo, -1), w3, b3, True, resid_f32=identity, want_f32=True)
+        return y16.reshape(n, ho, wo, -1), y32.reshape(n, ho, wo, -1)        # relu(bn3(conv3) + identity)
 
     def forward(self, batch, multi=None, layer=None):
         x = batch["simpleVQA"]
@@ -138,9 +150,10 @@ class ResNet(nn.Module):
         y = kernels.pool_nd(y.unsqueeze(1), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).squeeze(1)        # maxpool 3x3/2
         out = torch.empty(n, 7168 + feat3d.shape[1], dtype=torch.float32, device=x.device)
         off = 0
+        y32 = None
         for li, layer_mod in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
             for bi, blk in enumerate(layer_mod):
-                y = self._bottleneck(y, w, f"l{li}.{bi}.", blk)
+                y, y32 = self._bottleneck(y, y32, w, f"l{li}.{bi}.", blk)
             if li >= 2:                                                    # avgpool + global_std_pool2d (:242-252)
                 nn_, hh, ww, cc = y.shape
                 kernels.mean_std_pool(y.reshape(nn_, hh * ww, cc), out, off, off + cc)
