@@ -1,0 +1,179 @@
+"""SlowFast-R50 (8x8) motion feature extractor on libkvq_hip.so — the reference's ``slowfast`` module of
+``SlowFast_features.py:137-165`` (blocks 0-4 of ``pytorchvideo.models.hub.slowfast_r50`` + the head's
+pools).  pytorchvideo is not vendored / pinned / installed: the architecture below is the
+published SlowFast-R50 8x8; parameter names follow pytorchvideo's module tree under
+``feature_extraction.`` so that a real ``slowfast_r50`` state_dict loads by name.  **Parity unpinned.**
+
+Execution: channels-last 16-bit activations (B,D,H,W,C); every Conv3d = ``kvq_im2col_nd`` gather + MFMA GEMM
+with BatchNorm folded and ReLU / identity add in the epilogue (1x1x1 stride-1 convs skip the gather); the
+residual stream between bottlenecks stays fp32; pools = ``kvq_pool_nd`` / ``kvq_mean_std_pool``."""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ... import _abi, kernels
+
+DEPTHS = (3, 4, 6, 3)
+SLOW = dict(inner=(64, 128, 256, 512), out=(256, 512, 1024, 2048), ka=(1, 1, 3, 3))
+FAST = dict(inner=(8, 16, 32, 64), out=(32, 64, 128, 256), ka=(3, 3, 3, 3))
+SPATIAL_STRIDE = (1, 2, 2, 2)
+FAST_C = (8, 32, 64, 128)          # fast-pathway channels entering fusion 0..3
+
+
+def conv_table():
+    """name -> (weight shape, stride3, pad3): every Conv3d (+ its norm's name) in execution order."""
+    t = OrderedDict()
+    fe = "feature_extraction."
+    t[fe + "0.multipathway_blocks.0"] = ((64, 3, 1, 7, 7), (1, 2, 2), (0, 3, 3), "conv", "norm")
+    t[fe + "0.multipathway_blocks.1"] = ((8, 3, 5, 7, 7), (1, 2, 2), (2, 3, 3), "conv", "norm")
+    for st in range(4):
+        t[fe + f"{st}.multipathway_fusion"] = ((2 * FAST_C[st], FAST_C[st], 7, 1, 1), (4, 1, 1), (3, 0, 0),
+                                               "conv_fast_to_slow", "norm")
+    slow_in = (64 + 16, 256 + 64, 512 + 128, 1024 + 256)
+    for si in range(4):
+        for pi, (cfg, cin0) in enumerate(((SLOW, slow_in[si]), (FAST, FAST_C[si]))):
+            cin = cin0
+            for bi in range(DEPTHS[si]):
+                pre = fe + f"{si + 1}.multipathway_blocks.{pi}.res_blocks.{bi}"
+                inner, cout, ka = cfg["inner"][si], cfg["out"][si], cfg["ka"][si]
+                s = SPATIAL_STRIDE[si] if bi == 0 else 1
+                if bi == 0:
+                    t[pre + "#1"] = ((cout, cin, 1, 1, 1), (1, s, s), (0, 0, 0), "branch1_conv", "branch1_norm")
+                t[pre + ".branch2#a"] = ((inner, cin, ka, 1, 1), (1, 1, 1), (ka // 2, 0, 0), "conv_a", "norm_a")
+                t[pre + ".branch2#b"] = ((inner, inner, 1, 3, 3), (1, s, s), (0, 1, 1), "conv_b", "norm_b")
+                t[pre + ".branch2#c"] = ((cout, inner, 1, 1, 1), (1, 1, 1), (0, 0, 0), "conv_c", "norm_c")
+                cin = cout
+    return t
+
+
+def _set_nested(root: nn.Module, dotted: str, value, buffer=False):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, nn.Module())
+        m = getattr(m, p)
+    if buffer:
+        m.register_buffer(parts[-1], value)
+    else:
+        m.register_parameter(parts[-1], value)
+
+
+def pack_pathway_output(frames, device=None):
+    """Reference ``pack_pathway_output`` (SlowFast_features.py:112-135): [slow, fast]."""
+    idx = torch.linspace(0, frames.shape[2] - 1, frames.shape[2] // 4).long().to(frames.device)
+    slow = torch.index_select(frames, 2, idx)
+    return [slow if device is None else slow.to(device), frames if device is None else frames.to(device)]
+
+
+class slowfast(nn.Module):  # noqa: N801  (reference spelling)
+    def __init__(self, operand_dtype=None):
+        super().__init__()
+        self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
+        self.table = conv_table()
+        for key, (wshape, _, _, cname, nname) in self.table.items():
+            base = key.split("#")[0]
+            w = torch.empty(wshape)
+            nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+            _set_nested(self, f"{base}.{cname}.weight", nn.Parameter(w))
+            c = wshape[0]
+            _set_nested(self, f"{base}.{nname}.weight", nn.Parameter(torch.ones(c)))
+            _set_nested(self, f"{base}.{nname}.bias", nn.Parameter(torch.zeros(c)))
+            _set_nested(self, f"{base}.{nname}.running_mean", torch.zeros(c), buffer=True)
+            _set_nested(self, f"{base}.{nname}.running_var", torch.ones(c), buffer=True)
+            _set_nested(self, f"{base}.{nname}.num_batches_tracked", torch.tensor(0, dtype=torch.long), buffer=True)
+        self._wcache = None
+
+    # ---- weights: BatchNorm folded, (kd,kh,kw,c) column order, K padded to 32, 16-bit -----------------
+    def _weights(self, device):
+        sd = self.state_dict()
+        sig = (self.operand_dtype,) + tuple((t.data_ptr(), t._version) for t in sd.values())
+        if self._wcache is not None and self._wcache[0] == sig:
+            return self._wcache[1]
+        half = _abi.torch_dtype(self.operand_dtype)
+        out = {}
+        for key, (wshape, stride, pad, cname, nname) in self.table.items():
+            base = key.split("#")[0]
+            w = sd[f"{base}.{cname}.weight"].to(device, torch.float32)
+            g, b = sd[f"{base}.{nname}.weight"].to(device, torch.float32), sd[f"{base}.{nname}.bias"].to(device, torch.float32)
+            mu, var = sd[f"{base}.{nname}.running_mean"].to(device, torch.float32), sd[f"{base}.{nname}.running_var"].to(device, torch.float32)
+            scale = g / torch.sqrt(var + 1e-5)
+            w = (w * scale.view(-1, 1, 1, 1, 1)).permute(0, 2, 3, 4, 1).reshape(wshape[0], -1)
+            kpad = -(-w.shape[1] // 32) * 32
+            if kpad != w.shape[1]:
+                w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
+            if half == torch.float16:
+                w = w.clamp(-65504.0, 65504.0)
+            out[key] = (w.to(half).contiguous(), (b - mu * scale).contiguous(), tuple(wshape[2:]), stride, pad)
+        self._wcache = (sig, out)
+        return out
+
+    # ---- conv on channels-last 16-bit (B,D,H,W,C) -----------------------------------------------------
+    @staticmethod
+    def _cols(x, spec):
+        wt, _, k, stride, pad = spec
+        B, D, H, W, C = x.shape
+        if k == (1, 1, 1) and stride == (1, 1, 1) and C % 32 == 0:
+            return x.reshape(-1, C), (D, H, W)
+        return kernels.im2col_nd(x, (B, C, D, H, W), (D * H * W * C, 1, H * W * C, W * C, C), k, stride, pad, x.dtype,
+                                 wt.shape[1])
+
+    def _conv_relu(self, x, spec):
+        a, (d, h, w) = self._cols(x, spec)
+        return kernels.conv_gemm(a, spec[0], spec[1], True).reshape(x.shape[0], d, h, w, spec[0].shape[0])
+
+    def _res_block(self, x16, x32, W, pre, first):
+        out = self._conv_relu(x16, W[pre + ".branch2#a"])
+        out = self._conv_relu(out, W[pre + ".branch2#b"])
+        if first:                                             # projection shortcut: conv + BN, no ReLU, fp32
+            spec = W[pre + "#1"]
+            a, _ = self._cols(x16, spec)
+            identity = kernels.gemm(a, spec[0], spec[1], _abi.EPI_STORE_F32)
+        else:
+            identity = x32.reshape(-1, x32.shape[-1])
+        spec = W[pre + ".branch2#c"]
+        a, (d, h, w) = self._cols(out, spec)
+        y16, y32 = kernels.conv_gemm(a, spec[0], spec[1], True, resid_f32=identity, want_f32=True)
+        shape = (x16.shape[0], d, h, w, spec[0].shape[0])
+        return y16.reshape(shape), y32.reshape(shape)
+
+    def _stem(self, x, spec, half):
+        B, C, T, H, W = x.shape
+        wt, bias, k, stride, pad = spec
+        a, (d, h, w) = kernels.im2col_nd(x, (B, C, T, H, W), (C * T * H * W, T * H * W, H * W, W, 1), k, stride, pad, half,
+                                         wt.shape[1])
+        y = kernels.conv_gemm(a, wt, bias, True).reshape(B, d, h, w, wt.shape[0])
+        return kernels.pool_nd(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), True)
+
+    def forward(self, x):
+        """x = [slow (B,3,T/4,H,W), fast (B,3,T,H,W)] fp32 on a HIP device (``pack_pathway_output``)
+        -> (slow_feature (B,2048,1,1,1), fast_feature (B,256,1,1,1))."""
+        slow_in, fast_in = x
+        if not fast_in.is_cuda:
+            raise _abi.KvqError("slowfast.forward needs the clips on a HIP device; there is no CPU path")
+        W = self._weights(fast_in.device)
+        half = _abi.torch_dtype(self.operand_dtype)
+        fe = "feature_extraction."
+        slow = self._stem(slow_in.float().contiguous(), W[fe + "0.multipathway_blocks.0"], half)
+        fast = self._stem(fast_in.float().contiguous(), W[fe + "0.multipathway_blocks.1"], half)
+        slow = torch.cat([slow, self._conv_relu(fast, W[fe + "0.multipathway_fusion"])], dim=-1)
+        s32 = f32 = None
+        for si in range(4):
+            for bi in range(DEPTHS[si]):
+                slow, s32 = self._res_block(slow, s32, W, fe + f"{si + 1}.multipathway_blocks.0.res_blocks.{bi}", bi == 0)
+            for bi in range(DEPTHS[si]):
+                fast, f32 = self._res_block(fast, f32, W, fe + f"{si + 1}.multipathway_blocks.1.res_blocks.{bi}", bi == 0)
+            if si < 3:
+                slow = torch.cat([slow, self._conv_relu(fast, W[fe + f"{si + 1}.multipathway_fusion"])], dim=-1)
+        # AvgPool3d((8,7,7)) / ((32,7,7)) + AdaptiveAvgPool3d(1): a global mean over the remaining grid
+        outs = []
+        for y in (slow, fast):
+            B, D, H, Wd, C = y.shape
+            o = torch.empty(B, C, dtype=torch.float32, device=y.device)
+            kernels.mean_std_pool(y.reshape(B, D * H * Wd, C), o, 0, -1)
+            outs.append(o.reshape(B, C, 1, 1, 1))
+        return outs[0], outs[1]

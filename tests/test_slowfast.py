@@ -1,0 +1,53 @@
+"""SlowFast-R50 motion branch.  Parity is UNPINNED against the reference (pytorchvideo is absent,
+SURVEY.md §8c): what is tested is (CPU) the wrapper semantics + architecture invariants of the oracle,
+(GPU) HIP == oracle."""
+import numpy as np
+import pytest
+import torch
+
+import kvq_amd  # noqa: F401
+from kvq_amd.utils import synth
+from oracle import slowfast_oracle as SF
+
+
+def test_pathway_packing_matches_reference_indices():
+    x = torch.arange(32, dtype=torch.float32).reshape(1, 1, 32, 1, 1).expand(1, 3, 32, 1, 1)
+    slow, fast = SF.pack_pathway_output(x)
+    # reference: linspace(0, 31, 8).long() = [0,4,8,13,17,22,26,31]  
+    assert slow[0, 0, :, 0, 0].tolist() == [0, 4, 8, 13, 17, 22, 26, 31] and fast.shape[2] == 32
+    from kvq_amd.models.backbones.slowfast_model import pack_pathway_output
+    s2, f2 = pack_pathway_output(x)
+    assert torch.equal(s2, slow) and torch.equal(f2, fast)
+
+
+def test_architecture_invariants():
+    sh = SF.param_shapes()
+    n = sum(int(np.prod(v)) for k, v in sh.items() if "running" not in k and "num_batches" not in k)
+    # SlowFast-R50 8x8: 34.57 M parameters incl. the 2304->400 classifier (0.92 M) the reference drops
+    assert abs(n + 2304 * 400 + 400 - 34.57e6) < 0.02e6, n
+    from kvq_amd.models.backbones.slowfast_model import slowfast
+    sd = slowfast().state_dict()
+    assert set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+    w = synth.synth_params(sh, 3, "stress", prefix="sf.")
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).standard_normal((1, 3, 8, 32, 32)).astype(np.float32))
+    with torch.no_grad():
+        s, f = SF.slowfast_features(x, w)
+    assert s.shape == (1, 2048, 1, 1, 1) and f.shape == (1, 256, 1, 1, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 16, 64, 64), (2, 3, 8, 96, 64)])
+def test_hip_slowfast_matches_oracle(shape):
+    from kvq_amd.models.backbones.slowfast_model import pack_pathway_output, slowfast
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(sum(shape))).standard_normal(shape).astype(np.float32))
+    m = slowfast()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    m = m.cuda().eval()
+    with torch.no_grad():
+        s_ref, f_ref = SF.slowfast_features(x, w)
+        s, f = m(pack_pathway_output(x.cuda()))
+    assert s.shape == s_ref.shape and f.shape == f_ref.shape
+    for got, ref in ((s, s_ref), (f, f_ref)):
+        rel = ((got.cpu() - ref).norm() / ref.norm()).item()
+        assert rel <= 5e-3, rel          # ~100 conv layers on fp16 operands, fp32 accumulate / residual stream
