@@ -32,7 +32,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU per step (C2: 4)")
     ap.add_argument("--dtype", default=os.environ.get("KVQ_OPERAND_DTYPE", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=6)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="split each step's batch over this many HIP streams (independent clips: the VALU-bound "
+                         "attention of one half can overlap the MFMA-bound GEMMs of the other)")
     ap.add_argument("--profile-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -60,7 +63,8 @@ def cpu_baseline(cfg, wts, hw, n_clips):
     import torch
     from kvq_amd.utils import synth
     from oracle import swin3d_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 32 threads is the measured optimum on the 256-thread host (8: 3.13, 32: 2.78, 64: 3.38, 128: 8.7 s/clip)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     x = torch.from_numpy(synth.synth_clip(1000, 32, 224, 224, batch=1))
     with torch.no_grad():
         O.vqa_head(O.swin3d_trunk(x[:, :, :8, :64, :64].contiguous(), wts, cfg), hw)    # warm the allocator/threads
@@ -100,15 +104,35 @@ def main():
     x = torch.from_numpy(synth.synth_clip(1234 + rank, 32, 224, 224, batch=B)).to(device)
     inputs = {"technical": x}
     scores = torch.zeros(args.steps, B, device=device)
+    nstream = max(1, args.streams)
+    side = [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
+    parts = [{"technical": t.contiguous()} for t in x.chunk(nstream)]
+
+    def forward():
+        """one step = the whole batch once; with --streams > 1 the clips are split over HIP streams"""
+        if nstream == 1:
+            return net(inputs=inputs, reduce_scores=True).reshape(-1)
+        main = torch.cuda.current_stream()
+        outs = [None] * nstream
+        for st in side:
+            st.wait_stream(main)
+        for i, st in enumerate(side):
+            with torch.cuda.stream(st):
+                outs[i + 1] = net(inputs=parts[i + 1], reduce_scores=True).reshape(-1)
+        outs[0] = net(inputs=parts[0], reduce_scores=True).reshape(-1)
+        for st in side:
+            main.wait_stream(st)
+        return torch.cat(outs)
+
     with torch.no_grad():
         for _ in range(args.warmup):
-            net(inputs=inputs, reduce_scores=True)
+            forward()
         torch.cuda.synchronize()
         kd.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(args.steps):
-            scores[s] = net(inputs=inputs, reduce_scores=True).reshape(-1)
+            scores[s] = forward()
         # the path's one exchange step: all-gather of the per-rank score vectors (trainer_ddp.py:259-267)
         local = scores.reshape(-1)
         allscores = kd.gather_scores(local, local.numel() * world, rank, world) if world > 1 else local
@@ -160,7 +184,8 @@ def main():
             "data": "synthetic (PCG64 clips + procedurally generated 'stress' weights, resident in HBM)",
             "config": {"workload": "C2: KSVQE Swin3D-T(GRPB) trunk + VQAHead, 3x32x224x224 clips, video = 8 clips",
                        "clips_per_gpu_per_step": B, "operand_dtype": args.dtype, "accumulate": "fp32",
-                       "sharding": f"videos[rank::{world}], one all-gather of scores at the end"},
+                       "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
+                       "streams": nstream},
             "clips_per_s": clips / dt,
             "model_tflops": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3,
             "score_checksum": float(allscores.double().sum().item()),

@@ -10,6 +10,8 @@
 // Structure: 256 threads = 4 waves in a 2x2 grid; block tile (64*MI) x (64*NI), wave tile
 // (32*MI) x (32*NI) built from v_mfma_f32_32x32x16_{bf16,f16}; K streamed through a 4-slice LDS ring
 // by LDS-DMA with counted waits (see the kernel comment).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace kvq {

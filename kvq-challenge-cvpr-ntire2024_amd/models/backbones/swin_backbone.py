@@ -248,7 +248,8 @@ class SwinTransformer3D(nn.Module):
         return w
 
     def _plan(self, B, T, H, W, device):
-        key = (B, T, H, W, str(device), self.operand_dtype)
+        # one plan + workspace per (shape, stream): forwards issued on different streams may overlap
+        key = (B, T, H, W, str(device), self.operand_dtype, current_stream())
         hit = self._plans.get(key)
         if hit is not None:
             return hit
