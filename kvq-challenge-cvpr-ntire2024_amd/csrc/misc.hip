@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
 // 256-B row per channel; the token's feature value is a wave-uniform (broadcast) load.  A wave carries
 // HEAD_TOK tokens to amortise the W1 stream (L2-resident, 196 KB); one shuffle reduction per token.
 // ------------------------------------------------------------------------------------------------
-constexpr int HEAD_TOK = 4;
+constexpr int HEAD_TOK = 2;
 
 __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __restrict__ feat, int B, int L, int C,
                                                              long sb, long sl, long sc, const float* __restrict__ w1t,
@@ -74,11 +74,30 @@ __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __rest
     float d[HEAD_TOK];
 #pragma unroll
     for (int t = 0; t < HEAD_TOK; ++t) d[t] = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) {
-      const float wv = w1t[(size_t)c * hidden + jc];
+    if (sc == 1 && (C & 7) == 0) {
+      // channels-last features: 8 channels per step, the 8 W1 rows and the tokens' float4 pairs are all
+      // independent loads (16 in flight per wave) — this loop is L2-latency bound, not bandwidth bound
+      for (int c0 = 0; c0 < C; c0 += 8) {
+        float wv[8];
 #pragma unroll
-      for (int t = 0; t < HEAD_TOK; ++t) d[t] = fmaf(row[t][c * sc], wv, d[t]);
+        for (int k = 0; k < 8; ++k) wv[k] = w1t[(size_t)(c0 + k) * hidden + jc];
+#pragma unroll
+        for (int t = 0; t < HEAD_TOK; ++t) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(row[t] + c0);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(row[t] + c0 + 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[t] = fmaf(a[k], wv[k], d[t]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[t] = fmaf(b[k], wv[4 + k], d[t]);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int c = 0; c < C; ++c) {
+        const float wv = w1t[(size_t)c * hidden + jc];
+#pragma unroll
+        for (int t = 0; t < HEAD_TOK; ++t) d[t] = fmaf(row[t][c * sc], wv, d[t]);
+      }
     }
     const float bj = b1[jc], wj = live ? w2[jc] : 0.f;
 #pragma unroll
