@@ -63,9 +63,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // blockIdx.x walks N fastest so that blocks sharing an A row-panel are adjacent in dispatch order.
+  // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2.  Give
+  // every XCD a CONTIGUOUS range of the logical tile index (N fastest), so the N-tiles that re-read one A
+  // row-panel share an L2 instead of fetching it once per XCD (bijective also when nwg % 8 != 0).
   const int nbn = (p.N + BN - 1) / BN;
-  const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+  const int bm = lid / nbn, bn = lid % nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
   // DMA assignment: 16-B chunk q = i*256 + tid of the slice image: row q>>2, physical chunk q&3
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
 
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
+  (void)bn;
   if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
   const int nk = p.K / BK;
   issue(0);
