@@ -236,6 +236,14 @@ int kvq_fragment_gather(const void* video, int src_is_u8, int C, int T, int H, i
                         const int32_t* woff, int Fh, int Fw, int fs_h, int fs_w, int aligned,
                         const float* host_mean, const float* host_std, float* out, void* stream);
 
+/* torchvision Resize on a tensor (= bilinear, align_corners=False, no antialias; get_resize_function,
+ * fusion_datasets.py:229-241) + crop + (v-mean)/std: get_resized_video (:244-252), get_resizecrop_video
+ * (:299-316).  video u8|fp32 (C,T,H,W) -> resized to (rh,rw) -> crop [cy:cy+oh, cx:cx+ow] -> out fp32
+ * (C,T,oh,ow).  round_u8: round+clamp to 0..255 before normalising (what torchvision does to integer tensors). */
+int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int T, int H, int W, int rh, int rw, int cy,
+                        int cx, int oh, int ow, int round_u8, const float* host_mean, const float* host_std,
+                        float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution front-ends (2D ResNet-50 of SimpleVQA, simpleVQA_model.py:220-264; SlowFast-R50 3D convs,
  * SlowFast_features.py:137-165).  Activations are channels-last 16-bit (B,D,H,W,C); conv = im2col -> GEMM

@@ -98,6 +98,8 @@ SYMBOLS = {
                            p_void, p_void]),
     "kvq_simple_vqa_head": (i32, [p_void, i32, i32, i32, p_void, p_void, i32, p_void, p_void, p_void, p_void,
                                   p_void]),
+    "kvq_resize_bilinear": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32),
+                                  C.POINTER(f32), p_void, p_void]),
     "kvq_im2col_nd": (i32, [p_void, i32, i32, C.POINTER(i64 * 5), C.POINTER(i32 * 5), C.POINTER(i32 * 3),
                             C.POINTER(i32 * 3), C.POINTER(i32 * 3), i32, p_void, p_void]),
     "kvq_pool_nd": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),

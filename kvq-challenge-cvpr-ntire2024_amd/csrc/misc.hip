@@ -196,7 +196,74 @@ __global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bilinear resize (+ crop + normalise): torchvision.transforms.Resize on a tensor == F.interpolate(
+// mode="bilinear", align_corners=False, antialias=False) (get_resize_function, fusion_datasets.py:229-241),
+// the centre crop of get_resizecrop_video (:299-316) and the dataset's (v-mean)/std (:903) in one pass.
+// Source index as ATen: src = max(0, scale*(dst+0.5)-0.5), scale = in/out in fp32.
+// ------------------------------------------------------------------------------------------------
+struct ResizeParams {
+  const void* video;
+  int src_is_u8, C, T, H, W, rh, rw, cy, cx, oh, ow, round_u8, normalise;
+  float mean[4], std[4];
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(ResizeParams p) {
+  const long total = (long)p.C * p.T * p.oh * p.ow;
+  const float sy = (float)p.H / (float)p.rh, sx = (float)p.W / (float)p.rw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int ox = (int)(r % p.ow); r /= p.ow;
+    const int oy = (int)(r % p.oh); r /= p.oh;
+    const int t = (int)(r % p.T);
+    const int c = (int)(r / p.T);
+    const float fy = fmaxf(sy * ((float)(oy + p.cy) + 0.5f) - 0.5f, 0.f);
+    const float fx = fmaxf(sx * ((float)(ox + p.cx) + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.H - 1 ? 1 : 0), x1 = x0 + (x0 < p.W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const size_t base = ((size_t)c * p.T + t) * (size_t)p.H * p.W;
+    float v00, v01, v10, v11;
+    if (p.src_is_u8) {
+      const uint8_t* s = reinterpret_cast<const uint8_t*>(p.video) + base;
+      v00 = s[(size_t)y0 * p.W + x0]; v01 = s[(size_t)y0 * p.W + x1];
+      v10 = s[(size_t)y1 * p.W + x0]; v11 = s[(size_t)y1 * p.W + x1];
+    } else {
+      const float* s = reinterpret_cast<const float*>(p.video) + base;
+      v00 = s[(size_t)y0 * p.W + x0]; v01 = s[(size_t)y0 * p.W + x1];
+      v10 = s[(size_t)y1 * p.W + x0]; v11 = s[(size_t)y1 * p.W + x1];
+    }
+    float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    if (p.round_u8) v = fminf(fmaxf(rintf(v), 0.f), 255.f);      // torchvision rounds when the tensor is integer
+    if (p.normalise) v = (v - p.mean[c]) / p.std[c];
+    p.out[i] = v;
+  }
+}
+
 }  // namespace kvq
+
+extern "C" int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int T, int H, int W, int rh, int rw, int cy,
+                                   int cx, int oh, int ow, int round_u8, const float* host_mean, const float* host_std,
+                                   float* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(video && out, KVQ_ERR_NULL, "kvq_resize_bilinear: NULL pointer");
+  KVQ_REQUIRE(C > 0 && C <= 4 && T > 0 && H > 0 && W > 0 && rh > 0 && rw > 0 && oh > 0 && ow > 0 && cy >= 0 && cx >= 0 &&
+                  cy + oh <= rh && cx + ow <= rw,
+              KVQ_ERR_SHAPE, "kvq_resize_bilinear: bad shape / crop outside the resized frame");
+  ResizeParams p{};
+  p.video = video; p.src_is_u8 = src_is_u8; p.C = C; p.T = T; p.H = H; p.W = W; p.rh = rh; p.rw = rw; p.cy = cy; p.cx = cx;
+  p.oh = oh; p.ow = ow; p.round_u8 = round_u8; p.normalise = host_std != nullptr; p.out = out;
+  for (int c = 0; c < C; ++c) {
+    p.mean[c] = host_mean ? host_mean[c] : 0.f;
+    p.std[c] = host_std ? host_std[c] : 1.f;
+  }
+  const long total = (long)C * T * oh * ow;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("resize_bilinear_kernel");
+  return KVQ_OK;
+}
 
 extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd, int ph, int pw,
                                 int dtype, uint16_t* out, void* stream) {

@@ -1,2 +1,4 @@
 from .fusion_datasets import *  # noqa: F401,F403
-from .fusion_datasets import SyntheticKVQDataset, UnifiedFrameSampler, get_spatial_fragments  # noqa: F401
+from .fusion_datasets import (KVQ_MEAN, KVQ_STD, SIMPLEVQA_MEAN, SIMPLEVQA_STD, SyntheticKVQDataset,  # noqa: F401
+                              SyntheticSimpleVQADataset, UnifiedFrameSampler, get_resizecrop_video,
+                              get_resized_video, get_single_view, get_spatial_fragments)

@@ -62,6 +62,101 @@ def get_spatial_fragments(video, fragments_h=7, fragments_w=7, fsize_h=32, fsize
                                    fragments_w, fsize_h, fsize_w, aligned, mean=mean, std=std)
 
 
+def get_resized_video(video, size_h=224, size_w=224, random_crop=False, arp=False, mean=None, std=None, **kwargs):
+    """Reference ``get_resized_video`` (:244-252) on the GPU: (C,T,H,W) -> (C,T,size_h,size_w), bilinear."""
+    if random_crop:
+        raise NotImplementedError("RandomResizedCrop is a training augmentation")
+    if arp:
+        ratio = video.shape[-2] / video.shape[-1]
+        if ratio > 1:
+            size_h = int(ratio * size_w)
+        elif ratio < 1:
+            size_w = int(size_h / ratio)
+    return kernels.resize_bilinear(video.contiguous(), size_h, size_w, mean=mean, std=std)
+
+
+def get_resizecrop_video(video, resize=520, crop=448, phase="test", mean=None, std=None, **kwargs):
+    """Reference ``get_resizecrop_video`` (:299-316), test phase: resize to (resize,resize) then the centre
+    crop [r//2-crop//2 : r//2+crop//2] — fused with the normalisation in one kernel."""
+    if phase == "train":
+        raise NotImplementedError("random crop is a training augmentation")
+    o = resize // 2 - crop // 2
+    n = (resize // 2 + crop // 2) - o
+    return kernels.resize_bilinear(video.contiguous(), resize, resize, crop=(o, o, n, n), mean=mean, std=std)
+
+
+def get_single_view(video, sample_type="aesthetic", **kwargs):
+    """Reference ``get_single_view`` (:350-361)."""
+    if sample_type.startswith("aesthetic"):
+        return get_resized_video(video, **kwargs)
+    if sample_type.startswith("technical"):
+        return get_spatial_fragments(video, **kwargs)
+    if sample_type.startswith("simpleVQA"):
+        return get_resizecrop_video(video, **kwargs)
+    raise NotImplementedError
+
+
+SIMPLEVQA_MEAN = (0.485, 0.456, 0.406)      # applied to 0-255 pixels WITHOUT /255, as the reference does
+SIMPLEVQA_STD = (0.229, 0.224, 0.225)       # (fusion_datasets.py:811-812, 903; SURVEY App. D-7)
+
+
+class SyntheticSimpleVQADataset(torch.utils.data.Dataset):
+    """Seeded stand-in for ``ViewDecompositionDataset_add_forSimpleVQA`` (:786-927): ``simpleVQA`` view =
+    8 frames (clip_len 8 x frame_interval 10... positional quirk as in the reference) resized 520 -> centre
+    crop 448, normalised with the reference's constants; ``feat`` = the (8, 2304) SlowFast features, read from
+    ``data_prefix_3D/<video_name>/feature_{i}_{slow,fast}_feature.npy`` (:878-890) or, when
+    ``compute_feat`` is set, produced in-process by the HIP SlowFast branch (BASELINE config C3)."""
+
+    def __init__(self, opt, namelist=None, device="cuda:0"):
+        self.opt, self.device = opt, torch.device(device)
+        self.n = int(opt.get("num_videos", 4))
+        self.frames, self.h, self.w = int(opt.get("frames", 256)), int(opt.get("height", 540)), int(opt.get("width", 960))
+        self.sopt = dict(opt["sample_types"]["simpleVQA"])
+        s = self.sopt
+        # reference: UnifiedFrameSampler(clip_len // t_frag, t_frag, frame_interval, num_clips) (:836-841)
+        self.sampler = UnifiedFrameSampler(s["clip_len"] // s["t_frag"], s["t_frag"], s["frame_interval"], s["num_clips"])
+        self.data_prefix_3D = opt.get("data_prefix_3D")
+        self.slowfast = opt.get("compute_feat")
+        g = np.random.Generator(np.random.PCG64(4321))
+        self.labels = list(opt.get("labels") or g.uniform(1.0, 5.0, self.n))
+
+    def __len__(self):
+        return self.n
+
+    def _feat(self, i, frames_u8):
+        import os
+        name = f"synthetic_{i:05d}"
+        if self.data_prefix_3D and os.path.isdir(os.path.join(self.data_prefix_3D, name)):
+            rows = []
+            for k in range(8):
+                slow = np.load(os.path.join(self.data_prefix_3D, name, f"feature_{k}_slow_feature.npy")).squeeze()
+                fast = np.load(os.path.join(self.data_prefix_3D, name, f"feature_{k}_fast_feature.npy")).squeeze()
+                rows.append(np.concatenate([slow, fast]))
+            return torch.from_numpy(np.stack(rows)).float()
+        if self.slowfast is not None:          # 8 clips x 32 frames @224^2, mean .45 / std .225 (SlowFast_features.py:173-174)
+            from ..models.backbones.slowfast_model import pack_pathway_output
+            rows = []
+            with torch.no_grad():
+                for k in range(8):
+                    clip = frames_u8[:, k * 32:(k + 1) * 32].to(self.device)
+                    x = kernels.resize_bilinear(clip.contiguous(), 224, 224, mean=(0.45 * 255,) * 3, std=(0.225 * 255,) * 3)
+                    slow, fast = self.slowfast(pack_pathway_output(x.unsqueeze(0)))
+                    rows.append(torch.cat([slow.reshape(-1), fast.reshape(-1)]))
+            return torch.stack(rows)
+        return torch.zeros(8, 2304)
+
+    def __getitem__(self, i):
+        from ..utils import synth
+        frames = torch.from_numpy(synth.synth_video_u8(1234 + i, self.frames, self.h, self.w))
+        inds = self.sampler(self.frames)
+        clip = frames[:, torch.from_numpy(inds.astype(np.int64))].to(self.device)
+        view = get_resizecrop_video(clip, self.sopt["resize"], self.sopt["crop"], "test", mean=SIMPLEVQA_MEAN,
+                                    std=SIMPLEVQA_STD)
+        return {"simpleVQA": view, "feat": self._feat(i, frames).unsqueeze(0), "num_clips": {"simpleVQA": self.sopt["num_clips"]},
+                "frame_inds": inds, "label": float(self.labels[i]), "name": f"synthetic_{i:05d}",
+                "video_name": f"synthetic_{i:05d}.mp4"}
+
+
 class UnifiedFrameSampler:
     """Reference ``UnifiedFrameSampler`` (:612-660): same constructor, same RNG calls, same indices."""
 

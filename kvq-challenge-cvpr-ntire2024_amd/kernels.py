@@ -219,3 +219,18 @@ def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None, re
     a.dtype = dtype_code(A.dtype)
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
     return (out, out32) if want_f32 else out
+
+
+def resize_bilinear(video: torch.Tensor, rh: int, rw: int, crop=None, mean=None, std=None, round_u8=None):
+    """video u8|fp32 (C,T,H,W) -> bilinear resize to (rh,rw) [-> crop (cy,cx,oh,ow)] [-> (v-mean)/std], fp32."""
+    _need_gpu(video)
+    assert video.dtype in (torch.uint8, torch.float32) and video.is_contiguous()
+    Cc, T, H, W = video.shape
+    cy, cx, oh, ow = crop if crop is not None else (0, 0, rh, rw)
+    out = torch.empty(Cc, T, oh, ow, dtype=torch.float32, device=video.device)
+    m = (C.c_float * Cc)(*mean) if mean is not None else None
+    s = (C.c_float * Cc)(*std) if std is not None else None
+    rnd = int(video.dtype == torch.uint8) if round_u8 is None else int(round_u8)
+    check(lib().kvq_resize_bilinear(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W, rh, rw, cy, cx, oh, ow,
+                                    rnd, m, s, ptr(out), current_stream()), "kvq_resize_bilinear")
+    return out

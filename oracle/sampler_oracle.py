@@ -120,3 +120,25 @@ def quality_metrics(preds, labels):
     p = rescale(preds, labels)
     return (float(spearmanr(labels, p)[0]), float(pearsonr(labels, p)[0]),
             float(kendalltau(labels, p)[0]), float(np.sqrt(((labels - p) ** 2).mean())))
+
+
+def resize_bilinear(video: np.ndarray, rh: int, rw: int, round_u8: bool = False) -> np.ndarray:
+    """(C,T,H,W) -> (C,T,rh,rw).  **Parity unpinned**: the reference resizes with
+    ``torchvision.transforms.Resize`` (fusion_datasets.py:229-252), and torchvision is absent here
+    (un-pinned in requirements.txt: ``torchvision`` without version next to ``torch~=1.10``).  Restated as
+    what torchvision's tensor path does: ``F.interpolate(mode="bilinear", align_corners=False)``, no
+    antialias (the torch 1.10-era default for tensors), rounding back for integer inputs."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(video)).float()
+    out = torch.nn.functional.interpolate(t.permute(1, 0, 2, 3), size=(rh, rw), mode="bilinear", align_corners=False)
+    out = out.permute(1, 0, 2, 3)
+    if round_u8:
+        out = out.round().clamp(0, 255)
+    return out.numpy()
+
+
+def resizecrop(video: np.ndarray, resize: int = 520, crop: int = 448) -> np.ndarray:
+    """test-phase ``get_resizecrop_video`` (fusion_datasets.py:299-316): resize to (resize,resize), centre crop."""
+    r = resize_bilinear(video, resize, resize, round_u8=(video.dtype == np.uint8))
+    h, w = r.shape[-2:]
+    return r[..., h // 2 - crop // 2: h // 2 + crop // 2, w // 2 - crop // 2: w // 2 + crop // 2]

@@ -76,3 +76,27 @@ def test_cli_drop_in_scores_match_oracle(tmp_path):
     raw = tech.numpy() * np.asarray(KVQ_STD, np.float32).reshape(3, 1, 1, 1) + np.asarray(KVQ_MEAN, np.float32).reshape(3, 1, 1, 1)
     assert np.abs(np.round(raw) - raw).max() < 1e-3 and raw.min() >= -0.01 and raw.max() <= 255.01
     assert frames.shape == (3, 64, 300, 400)
+
+
+@pytest.mark.parametrize("shape,rs", [((3, 4, 100, 180), (112, 112)), ((3, 2, 300, 260), (224, 224)), ((3, 3, 64, 64), (150, 97))])
+def test_resize_bilinear_matches_interpolate(shape, rs):
+    """Parity unpinned vs torchvision (absent); equals F.interpolate(bilinear, align_corners=False)."""
+    from kvq_amd.datasets import get_resized_video
+    g = np.random.Generator(np.random.PCG64(sum(shape)))
+    v = g.integers(0, 256, size=shape).astype(np.float32)
+    ref = SO.resize_bilinear(v, *rs)
+    out = get_resized_video(torch.from_numpy(v).cuda(), rs[0], rs[1]).cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-4 * 255
+    out8 = get_resized_video(torch.from_numpy(v.astype(np.uint8)).cuda(), rs[0], rs[1]).cpu().numpy()
+    ref8 = SO.resize_bilinear(v.astype(np.uint8), *rs, round_u8=True)
+    assert (np.abs(out8 - ref8) > 0.5).mean() <= 1e-4        # identical up to .5 rounding ties
+
+
+def test_resizecrop_simplevqa_view():
+    from kvq_amd.datasets import SIMPLEVQA_MEAN, SIMPLEVQA_STD, get_resizecrop_video
+    g = np.random.Generator(np.random.PCG64(5))
+    v = g.integers(0, 256, size=(3, 2, 270, 480)).astype(np.float32)
+    ref = SO.normalize(SO.resizecrop(v, 520, 448), SIMPLEVQA_MEAN, SIMPLEVQA_STD)
+    out = get_resizecrop_video(torch.from_numpy(v).cuda(), 520, 448, "test", mean=SIMPLEVQA_MEAN, std=SIMPLEVQA_STD)
+    assert out.shape == (3, 2, 448, 448)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-4 * 255 / 0.224
