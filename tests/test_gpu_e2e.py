@@ -149,3 +149,44 @@ def test_no_cpu_fallback():
 def test_native_library_is_the_loaded_one():
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libkvq_hip.so" in maps
+
+
+def test_config5_swin_b_padded_windows_vs_oracle():
+    """BASELINE config 5 parameterisation (Swin3D-B: embed 128, heads 4/8/16/32, depths 2/2/18/2, SURVEY §0
+    trap 7) at a reduced clip whose grids need window padding at every stage (32 -> 35, 16 -> 21, ...),
+    through the same VideoBackbone constructor kwargs; fp16; vs the oracle on the box."""
+    from kvq_amd.models.backbones.swin_backbone import SwinTransformer3D
+    from kvq_amd.models.head import VQAHead
+    cfg = synth.SWIN_B_GRPB
+    wts = synth.synth_swin_weights(cfg, 31, "stress")
+    hw = synth.synth_vqa_head_weights(cfg.num_features, 64, 31, "stress")
+    bb = SwinTransformer3D(embed_dim=128, depths=list(cfg.depths), num_heads=list(cfg.num_heads))
+    missing = bb.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=False)
+    assert not missing.unexpected_keys
+    head = VQAHead(in_channels=cfg.num_features, hidden_channels=64)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()})
+    bb, head = bb.to(DEV).eval(), head.to(DEV).eval()
+    x = torch.from_numpy(synth.synth_clip(77, 16, 128, 128, batch=1))
+    with torch.no_grad():
+        feat = bb({"technical": x.to(DEV)})
+        score = head(feat).cpu()
+        f_ref = O.swin3d_trunk(x, wts, cfg)
+        s_ref = O.vqa_head(f_ref, hw)
+    assert feat.shape == f_ref.shape == (1, 1024, 8, 4, 4)
+    rel = ((feat.cpu() - f_ref).norm() / f_ref.norm()).item()
+    assert rel <= 6e-3, rel
+    assert (score - s_ref).abs().max().item() <= SCORE_TOL, (score, s_ref)
+
+
+def test_config3_trunk_and_slowfast_on_the_same_clips():
+    """BASELINE config 3: the Swin trunk and the SlowFast motion branch consume the same 32x224x224 clips in
+    one process (no disk round trip of .npy features); both outputs finite and shaped as the reference's."""
+    from kvq_amd.models.backbones.slowfast_model import pack_pathway_output, slowfast
+    net, _ = build_network("SWIN_T_GRPB", 0, "stress")
+    sf = slowfast().to(DEV).eval()
+    x = torch.from_numpy(synth.synth_clip(8, 32, 224, 224, batch=2)).to(DEV)
+    with torch.no_grad():
+        s = net(inputs={"technical": x}, reduce_scores=True)
+        slow, fast = sf(pack_pathway_output(x))
+    assert s.shape == (2, 1) and slow.shape == (2, 2048, 1, 1, 1) and fast.shape == (2, 256, 1, 1, 1)
+    assert torch.isfinite(s).all() and torch.isfinite(slow).all() and torch.isfinite(fast).all()
