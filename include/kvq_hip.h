@@ -74,6 +74,9 @@ typedef struct {
   const float* norm1_b;
   const float* rpb_table;  /* relative_position_bias_table  [table_len][nH] */
   const float* fpb_table;  /* fragment_position_bias_table  [table_len][nH] or NULL */
+  const float* bias_pack;  /* optional, derived: [nH][TLe][2], TLe = table_len rounded up to even,
+                              = {fpb (rpb if no fpb), rpb-fpb (0)}: a head's table stages into LDS as one
+                              contiguous 16-B aligned copy; NULL = gather from the raw tables */
   const uint16_t* qkv_w;   /* [3C][C], rows = [q | k | v], each head-major */
   const float* qkv_b;      /* [3C] */
   const uint16_t* proj_w;  /* [C][C] */
@@ -202,10 +205,11 @@ int kvq_debug_gemm_trace(void* dev_buf, int max_blocks);
  *   tok      int32 [nW*N][2]: {bias code c = d*(2Wh-1)(2Ww-1)+h*(2Ww-1)+w of the token's
  *            coordinate in the configured window raster, desc = fh | fw<<8 | region<<16}
  *   rpb/fpb  fp32 [table_len][nH]; fpb NULL = no fragment gate
+ *   bias_pack optional fp32 [nH][TLe][2] = {fpb|rpb, rpb-fpb|0}, TLe = table_len rounded up to even; else NULL
  *   center   (Wd-1)*(2Wh-1)*(2Ww-1) + (Wh-1)*(2Ww-1) + (Ww-1)
  *   out      bf16 [BW*N][nH*32]  (== (attn@v).transpose(1,2).reshape(B_,N,C), :322)        */
 int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* rpb, const float* fpb,
-                         int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
+                         const float* bias_pack, int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
                          int dtype, uint16_t* out, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail

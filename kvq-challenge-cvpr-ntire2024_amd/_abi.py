@@ -48,7 +48,7 @@ class KvqSwinCfg(C.Structure):
 
 
 class KvqSwinBlockW(C.Structure):
-    _fields_ = [(n, p_void) for n in ("norm1_w", "norm1_b", "rpb_table", "fpb_table", "qkv_w", "qkv_b", "proj_w",
+    _fields_ = [(n, p_void) for n in ("norm1_w", "norm1_b", "rpb_table", "fpb_table", "bias_pack", "qkv_w", "qkv_b", "proj_w",
                                       "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
@@ -91,7 +91,7 @@ SYMBOLS = {
                                  p_void]),
     "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
     "kvq_debug_gemm_trace": (i32, [p_void, i32]),
-    "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
+    "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
                                    p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_vqa_head": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, i32, p_void, p_void, p_void,

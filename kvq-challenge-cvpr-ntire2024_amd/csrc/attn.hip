@@ -43,9 +43,16 @@ struct AttnParams {
   const int32_t* tok;
   const float* rpb;
   const float* fpb;
+  const float* pack;           // optional [nH][table_len][2] = {fpb|rpb, rpb-fpb}: coalesced staging
   int table_len, center, BW, nW, N, nH, use_mask;
   uint16_t* out;
+  unsigned long long* trace;   // diagnostic stamps: [0] start, [1] staging done, [2] end
+  int trace_blocks;
 };
+
+// LDS addressed by a plain 32-bit byte offset (address space 3): no generic-pointer base add per access
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef const __attribute__((address_space(3))) f32x2* lds_f2_t;
 
 __device__ __forceinline__ int k_slot(int row, int g) { return row * 4 + (g ^ ((-(row >> 3)) & 3)); }
 
@@ -63,6 +70,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
 
   const int tid = threadIdx.x;
   const int unit = blockIdx.x;
+  const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
+  if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
   const int bw = unit / p.nH, h = unit - bw * p.nH;
   const int N = p.N;
   const size_t Mtot = (size_t)p.BW * N;
@@ -99,6 +108,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
     }
     tokL[n + (n >> 3)] = t;
   }
+  if (p.pack) {                                   // host-packed table: one contiguous 8*table_len-byte copy
+    const int tl2 = (p.table_len + 1) >> 1;       // heads are padded to an even entry count: 16-B aligned rows
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.pack) + (size_t)h * tl2;
+    f32x4* dst = reinterpret_cast<f32x4*>(tab);
+    for (int i = tid; i < tl2; i += ATT_WAVES * 64) dst[i] = src[i];
+  } else
   for (int i = tid; i < p.table_len; i += ATT_WAVES * 64) {
     const float r = p.rpb[(size_t)i * p.nH + h];
     if (GATED) {
@@ -109,6 +124,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
     }
   }
   __syncthreads();
+  if (tr) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
 
   const int lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
@@ -139,13 +155,17 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
 #define ATT_TOKIDX(t, r) (ATT_KEY0(t) + (ATT_KEY0(t) >> 3) + (r))     /* + 9*g folded into tokg */
     const int4* tokg = tokL + 9 * g;
     int4 tkC[4], tkN[4];
-    float2 tbC[4], tbN[4];
+    f32x2 tbC[4], tbN[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) tkC[r] = tokg[ATT_TOKIDX(0, r)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) tkN[r] = tokg[ATT_TOKIDX(1, r)];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tbC[r] = *reinterpret_cast<const float2*>(smem + (cqb - tkC[r].x));
+    for (int r = 0; r < 4; ++r) tbC[r] = *reinterpret_cast<lds_f2_t>((uintptr_t)(unsigned)(cqb - tkC[r].x));
+    // K fragments are prefetched one tile ahead too: LDS returns in order, so a fragment read issued in the
+    // same iteration as the gathers would make its s_waitcnt drain them all.
+    const int krow0 = 8 * (j >> 2) + (j & 3);                  // + key0(t): MFMA row j <-> key (see header)
+    V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(0) + krow0, g)]), kfN = kfC;
     f32x4 S[ATT_NT];
     float mx = -INFINITY;
 #pragma unroll
@@ -154,25 +174,26 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
       int4 tkNN[4];
       if (t + 1 < ATT_NT) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tbN[r] = *reinterpret_cast<const float2*>(smem + (cqb - tkN[r].x));
+        for (int r = 0; r < 4; ++r) tbN[r] = *reinterpret_cast<lds_f2_t>((uintptr_t)(unsigned)(cqb - tkN[r].x));
       }
       if (t + 2 < ATT_NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) tkNN[r] = tokg[ATT_TOKIDX(t + 2 < ATT_NT ? t + 2 : 0, r)];
       }
-      // A operand: MFMA row i = j  <->  key 32*(t>>1) + 8*(i>>2) + 4*(t&1) + (i&3)
-      const int krow = key0 + 8 * (j >> 2) + (j & 3);
-      const V8 kf = __builtin_bit_cast(V8, Ks[k_slot(krow, g)]);
+      if (t + 1 < ATT_NT) kfN = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(t + 1 < ATT_NT ? t + 1 : 0) + krow0, g)]);
       // ---- bias tile first, then S = K Q^T + bias (the bias rides in as the MFMA C operand) ----
       f32x4 b4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float bias = tbC[r].x;
-        if (GATED) bias = fmaf((float)__builtin_amdgcn_sad_u8(fq, (unsigned)tkC[r].y, 0u), tbC[r].y, tbC[r].x);
-        if (MASK) bias += (tkC[r].z != rq) ? -100.0f : 0.0f;
+        float bias = tbC[r][0];
+        if (GATED) bias = fmaf((float)__builtin_amdgcn_sad_u8(fq, (unsigned)tkC[r].y, 0u), tbC[r][1], tbC[r][0]);
+        // shift mask (compute_mask's -100, swin_backbone.py:583): a masked score sits ~100 below the row max, its
+        // probability (< e^-87) is below fp32's normal range in the reference too — the -100 REPLACES the bias
+        // term instead of being added to it (one select instead of select + add).
+        if (MASK) bias = (tkC[r].z != rq) ? -100.0f : bias;
         b4[r] = bias;
       }
-      S[t] = E::mfma16(kf, qf, b4);
+      S[t] = E::mfma16(kfC, qf, b4);
       if (!FULL || t >= ATT_NT - 2) {   // tiles that can hold keys >= N: exclude them from the softmax
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[t][r] = (key0 + 8 * g + r) < N ? S[t][r] : -INFINITY;
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
         tbC[r] = tbN[r];
         tkN[r] = tkNN[r];
       }
+      kfC = kfN;
     }
 #undef ATT_KEY0
 #undef ATT_TOKIDX
@@ -226,6 +248,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
       }
     }
   }
+  if (tr) {
+    __builtin_amdgcn_s_waitcnt(0);
+    p.trace[blockIdx.x * 8 + 2] = __builtin_readcyclecounter();
+  }
 }
 
 template <typename E, bool GATED, bool MASK, bool FULL>
@@ -251,7 +277,7 @@ static int launch_attn(const AttnParams& p, size_t lds, hipStream_t st) {
 }  // namespace kvq
 
 extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* rpb, const float* fpb,
-                                    int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
+                                    const float* bias_pack, int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
                                     int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(qkv && tok && rpb && out, KVQ_ERR_NULL, "kvq_window_attention: NULL pointer");
@@ -259,10 +285,12 @@ extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, con
               "kvq_window_attention: bad shape BW=%d nW=%d nH=%d table_len=%d", BW, nW, num_heads, table_len);
   KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED,
               "kvq_window_attention: window of %d tokens unsupported (1..400)", N);
-  const size_t lds = (size_t)ATT_OFF_TAB + (size_t)table_len * 8;
+  const size_t lds = (size_t)ATT_OFF_TAB + (size_t)((table_len + 1) & ~1) * 8;
   KVQ_REQUIRE(lds <= 80 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_window_attention: bias table of %d entries exceeds LDS",
               table_len);
-  AttnParams p{qkv, tok, rpb, fpb, table_len, center, BW, nW, N, num_heads, use_mask, out};
+  KVQ_REQUIRE(!bias_pack || ((size_t)bias_pack & 15) == 0, KVQ_ERR_SHAPE,
+              "kvq_window_attention: bias_pack must be 16-byte aligned");
+  AttnParams p{qkv, tok, rpb, fpb, bias_pack, table_len, center, BW, nW, N, num_heads, use_mask, out, g_trace, g_trace_blocks};
   hipStream_t st = (hipStream_t)stream;
   const bool gated = fpb != nullptr, mask = use_mask != 0;
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention: dtype %d", dtype);

@@ -118,6 +118,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// diagnostic stamp buffer (kvq_debug_gemm_trace): 8 uint64 per workgroup, NULL = off
+extern unsigned long long* g_trace;
+extern int g_trace_blocks;
+
 // tile variant the GEMM dispatcher picks for a shape: (MI==NI) * 100 + BK  (gemm.hip)
 int gemm_variant(int M, int N, int K);
 

@@ -293,8 +293,12 @@ static int launch_dt(int dtype, const GemmParams& p, hipStream_t st) {
 
 }  // namespace kvq
 
-static unsigned long long* g_trace = nullptr;
-static int g_trace_blocks = 0;
+namespace kvq {
+unsigned long long* g_trace = nullptr;     // shared with attn.hip (declared in common.hpp)
+int g_trace_blocks = 0;
+}
+using kvq::g_trace;
+using kvq::g_trace_blocks;
 
 extern "C" int kvq_debug_gemm_trace(void* dev_buf, int max_blocks) {
   g_trace = (unsigned long long*)dev_buf;

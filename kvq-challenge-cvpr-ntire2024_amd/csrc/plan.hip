@@ -351,6 +351,7 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);
         KVQ_TRY(kvq_window_attention(bbig, g.d_tok[par], bw.rpb_table, cfg.frag_bias[i] ? bw.fpb_table : nullptr,
+                                     bw.bias_pack,
                                      pl->table_len, pl->center, B * g.nW, g.nW, g.N, g.nH, par, pl->dtype, bo,
                                      st));
       }

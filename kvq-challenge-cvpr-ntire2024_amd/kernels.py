@@ -78,14 +78,14 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
 
 
 def window_attention(qkv: torch.Tensor, tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor],
-                     center: int, nW: int, N: int, use_mask: bool):
+                     center: int, nW: int, N: int, use_mask: bool, bias_pack: Optional[torch.Tensor] = None):
     """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled), tok int32 [nW*N,2]; returns [BW*N, nH*32]."""
     _need_gpu(qkv, tok, rpb, fpb)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
     out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
-    check(lib().kvq_window_attention(ptr(qkv), ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, BW, nW, N, nH,
+    check(lib().kvq_window_attention(ptr(qkv), ptr(tok), ptr(rpb), ptr(fpb), ptr(bias_pack), rpb.shape[0], center, BW, nW, N, nH,
                                      int(use_mask), dtype_code(qkv.dtype), ptr(out), current_stream()),
           "kvq_window_attention")
     return out

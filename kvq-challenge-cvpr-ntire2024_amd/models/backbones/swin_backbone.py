@@ -230,8 +230,19 @@ class SwinTransformer3D(nn.Module):
                 k += 1
                 b.norm1_w, b.norm1_b = f32(blk.norm1.weight), f32(blk.norm1.bias)
                 b.rpb_table = f32(blk.attn.relative_position_bias_table)
+                r = blk.attn.relative_position_bias_table.detach().to(device=device, dtype=torch.float32)
                 if hasattr(blk.attn, "fragment_position_bias_table"):
                     b.fpb_table = f32(blk.attn.fragment_position_bias_table)
+                    fr = blk.attn.fragment_position_bias_table.detach().to(device=device, dtype=torch.float32)
+                    pack = torch.stack([fr, r - fr], -1)
+                else:
+                    pack = torch.stack([r, torch.zeros_like(r)], -1)
+                pack = pack.permute(1, 0, 2)                     # [nH][table_len][2]
+                if pack.shape[1] & 1:                            # even entry count -> 16-B aligned head rows
+                    pack = torch.nn.functional.pad(pack, (0, 0, 0, 1))
+                pack = pack.contiguous()
+                keep.append(pack)
+                b.bias_pack = ptr(pack)
                 b.qkv_w, b.qkv_b = bf16(blk.attn.qkv.weight), f32(blk.attn.qkv.bias)
                 b.proj_w, b.proj_b = bf16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
                 b.norm2_w, b.norm2_b = f32(blk.norm2.weight), f32(blk.norm2.bias)
