@@ -193,12 +193,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
         if (MASK) bias = (tkC[r].z != rq) ? -100.0f : bias;
         b4[r] = bias;
       }
-      S[t] = E::mfma16(kfC, qf, b4);
-      if (!FULL || t >= ATT_NT - 2) {   // tiles that can hold keys >= N: exclude them from the softmax
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[t][r] = (key0 + 8 * g + r) < N ? S[t][r] : -INFINITY;
-      }
-      mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
+      S[t] = E::mfma16(kfC, qf, b4);   // consumed only after the loop: no MFMA-latency stall per tile
       // bound live ranges: without it the compiler hoists all 104 gathers ahead of their use and spills
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -211,6 +206,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
     }
 #undef ATT_KEY0
 #undef ATT_TOKIDX
+#pragma unroll
+    for (int t = 0; t < ATT_NT; ++t) {
+      if (!FULL || t >= ATT_NT - 2) {   // tiles that can hold keys >= N: exclude them from the softmax
+        const int key0 = 32 * (t >> 1) + 4 * (t & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[t][r] = (key0 + 8 * g + r) < N ? S[t][r] : -INFINITY;
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     // ---- exp + pack: the packed pairs are the P*V A-fragments (p in [0,1]: no saturation needed) ----
