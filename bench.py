@@ -96,7 +96,8 @@ def main():
     rank, local_rank, world = kd.init()
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    device = torch.device("cuda", local_rank)
+    # KVQ_BENCH_ONE_GPU=1 (tests): all ranks share cuda:0 so the N>1 code path can run on a 1-GPU box
+    device = torch.device("cuda", 0 if os.environ.get("KVQ_BENCH_ONE_GPU") else local_rank)
     torch.cuda.set_device(device)
     net, cfg, wts, hw = build_net(args.dtype, device)
     B = args.batch

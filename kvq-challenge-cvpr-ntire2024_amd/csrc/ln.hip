@@ -8,7 +8,8 @@
 // The output row r of batch element b is LN(concat_p x[b*rows_in + map[r][p]]).  Statistics are
 // two-pass in registers (mean, then centred sum of squares), fp32, biased variance, eps inside the
 // rsqrt — the same formula torch's LayerNorm uses.  A row is owned by G = 16/32/64 lanes (picked
-// so that every lane holds at least one float4); reductions are wavefront shuffles (xor butterflies).
+// so that every lane holds at least one float4); reductions are wavefront shuffles (xor butterflies);
+// a lane group carries R consecutive rows with all their loads issued up front (memory-level parallelism).
 #include "common.hpp"
 
 namespace kvq {
@@ -24,77 +25,88 @@ struct LnParams {
   float* out_f32;
 };
 
-template <typename E, int G, int NV>  // G lanes per row, NV float4 per lane (NV*G*4 >= C)
+template <typename E, int G, int NV, int R>  // G lanes per row, NV float4 per lane (NV*G*4 >= C), R rows per group
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
   const int C = p.nparts * p.Cin;
   const int lane_in = threadIdx.x % G;
-  const long row = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const long row0 = ((long)blockIdx.x * (256 / G) + threadIdx.x / G) * R;
   const long total = (long)p.n_batch * p.rows_out;
-  const bool live = row < total;          // keep every lane in the shuffles
-  const long rr = live ? row : total - 1;
-  const int b = (int)(rr / p.rows_out), r = (int)(rr - (long)b * p.rows_out);
 
-  f32x4 v[NV];
-  bool all_pad = (p.map != nullptr) && (p.nparts == 1) && (p.map[r] < 0);
-  float sum = 0.f;
+  // all R rows' loads are issued before any reduction: R*NV independent 16-B loads in flight per lane
+  f32x4 v[R][NV];
+  bool all_pad[R];
+  long rowi[R];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * G + lane_in) * 4;
-    v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (c < C && !all_pad) {
-      const int part = c / p.Cin, cc = c - part * p.Cin;   // Cin % 4 == 0: a float4 never straddles parts
-      const int s = p.map ? p.map[r * p.nparts + part] : r;
-      if (s >= 0) v[i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)b * p.rows_in + s) * p.Cin + cc);
-    }
-    sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-  }
+  for (int j = 0; j < R; ++j) {
+    rowi[j] = row0 + j < total ? row0 + j : total - 1;          // clamp: every lane stays in the shuffles
+    const int b = (int)(rowi[j] / p.rows_out), r = (int)(rowi[j] - (long)b * p.rows_out);
+    all_pad[j] = (p.map != nullptr) && (p.nparts == 1) && (p.map[r] < 0);
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, G);
-  const float mean = sum / (float)C;
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * G + lane_in) * 4;
-    if (c < C) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float d = v[i][k] - mean;
-        sq += d * d;
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * G + lane_in) * 4;
+      v[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < C && !all_pad[j]) {
+        const int part = c / p.Cin, cc = c - part * p.Cin;   // Cin % 4 == 0: a float4 never straddles parts
+        const int s = p.map ? p.map[r * p.nparts + part] : r;
+        if (s >= 0) v[j][i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)b * p.rows_in + s) * p.Cin + cc);
       }
     }
   }
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, G);
-  const float rstd = rsqrtf(sq / (float)C + p.eps);
-  if (!live) return;
+  for (int j = 0; j < R; ++j) {
+    float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * G + lane_in) * 4;
-    if (c >= C) continue;
-    f32x4 y;
-    if (all_pad) {
-      y = (f32x4){0.f, 0.f, 0.f, 0.f};
-    } else {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+    for (int i = 0; i < NV; ++i) sum += (v[j][i][0] + v[j][i][1]) + (v[j][i][2] + v[j][i][3]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[k] + be[k];
+    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, G);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * G + lane_in) * 4;
+      if (c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d = v[j][i][k] - mean;
+          sq += d * d;
+        }
+      }
     }
-    if (p.out_h) {
-      u32x2 o = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3])};
-      *reinterpret_cast<u32x2*>(p.out_h + (size_t)row * C + c) = o;
-    } else {
-      *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * C + c) = y;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, G);
+    const float rstd = rsqrtf(sq / (float)C + p.eps);
+    if (row0 + j >= total) continue;
+    const long row = row0 + j;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * G + lane_in) * 4;
+      if (c >= C) continue;
+      f32x4 y;
+      if (all_pad[j]) {
+        y = (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c);     // L1/L2-resident, reloaded per row
+        const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = (v[j][i][k] - mean) * rstd * gm[k] + be[k];
+      }
+      if (p.out_h) {
+        u32x2 o = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3])};
+        *reinterpret_cast<u32x2*>(p.out_h + (size_t)row * C + c) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * C + c) = y;
+      }
     }
   }
 }
 
 template <typename E, int G, int NV>
 static int launch_ln_e(const LnParams& p, hipStream_t st) {
+  constexpr int R = NV <= 1 ? 4 : (NV <= 2 ? 2 : 1);       // ~4 float4 loads in flight per lane; more only adds VGPRs
   const long total = (long)p.n_batch * p.rows_out;
-  const int rows_per_block = 256 / G;
+  const int rows_per_block = (256 / G) * R;
   dim3 grid((unsigned)((total + rows_per_block - 1) / rows_per_block)), block(256);
-  hipLaunchKernelGGL((layernorm_rows_kernel<E, G, NV>), grid, block, 0, st, p);
+  hipLaunchKernelGGL((layernorm_rows_kernel<E, G, NV, R>), grid, block, 0, st, p);
   KVQ_CHECK_LAUNCH("layernorm_rows_kernel");
   return KVQ_OK;
 }

@@ -25,7 +25,7 @@ def init(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("KVQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -46,8 +46,12 @@ def gather_scores(local: torch.Tensor, n_items: int, rank: int, world: int) -> t
     assert local.numel() == per
     if world == 1:
         return local[:n_items].clone()
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:       # CPU-only backend (tests): stage through the host
+        local = local.cpu()
     out = torch.empty(world * per, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
+    out = out.to(dev)
     # out[r*per + i] is item (r + i*world) % n; undo, keeping the first occurrence of every item
     full = torch.empty(n_items, dtype=local.dtype, device=local.device)
     src = torch.arange(world * per, device=local.device)
@@ -65,6 +69,6 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -100,3 +100,26 @@ def test_resizecrop_simplevqa_view():
     out = get_resizecrop_video(torch.from_numpy(v).cuda(), 520, 448, "test", mean=SIMPLEVQA_MEAN, std=SIMPLEVQA_STD)
     assert out.shape == (3, 2, 448, 448)
     assert np.abs(out.cpu().numpy() - ref).max() <= 2e-4 * 255 / 0.224
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
+    """bench.py's N>1 path (rank env, barrier, max-over-ranks, score all-gather, rank-0 JSON) with two
+    processes sharing this box's single GPU over gloo (RCCL needs one GPU per rank)."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", KVQ_DIST_BACKEND="gloo",
+               KVQ_BENCH_ONE_GPU="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--profile-steps", "0", "--batch", "2"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=tmp_path,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(line) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and d["value"] > 0
+    assert abs(d["clips_per_s"] - 2 * 3 * 2 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["clips_per_s"]
