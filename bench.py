@@ -169,6 +169,14 @@ def main():
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        # HBM traffic of that kernel: PMC counters from a SEPARATE rocprofv3 --pmc pass (tools/pmc_traffic.py ->
+        # profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction), per launch like `achieved`
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name)
+            if pmc:
+                roof["traffic"] = pmc["fetch_bytes"] + pmc["write_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         roof.update({"kernel": name, "launches_per_step": top["n"] / args.profile_steps,
                      "avg_launch_us": 1e3 * top["ms"] / top["n"],
                      "share_of_gpu_time": top["ms"] / total_ms,

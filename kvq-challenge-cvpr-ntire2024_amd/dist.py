@@ -53,8 +53,8 @@ def gather_scores(local: torch.Tensor, n_items: int, rank: int, world: int) -> t
     dist.all_gather_into_tensor(out, local.contiguous())
     out = out.to(dev)
     # out[r*per + i] is item (r + i*world) % n; undo, keeping the first occurrence of every item
-    full = torch.empty(n_items, dtype=local.dtype, device=local.device)
-    src = torch.arange(world * per, device=local.device)
+    full = torch.empty(n_items, dtype=out.dtype, device=dev)
+    src = torch.arange(world * per, device=dev)
     item = (src // per + (src % per) * world)
     keep = item < n_items
     full[item[keep]] = out[keep]
