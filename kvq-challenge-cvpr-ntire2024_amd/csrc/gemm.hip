@@ -161,20 +161,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // Each wave transposes its accumulators through a private LDS slab (32 rows x 32*NI fp32, reusing the
-  // A/B slices: the K loop ended with a barrier) so that a lane owns 4 CONSECUTIVE columns of one row:
-  // bias/activation run on float4s and the global stores are 8-16 B per lane, >= 128 B contiguous per
-  // row, instead of 64 two-byte stores per lane.
+  // ring: the K loop ended with a barrier) so that a lane owns CW CONSECUTIVE columns of one row: bias /
+  // activation run on float4s and every global store is a full dwordx4 (8 x 16-bit or 4 x fp32 per lane,
+  // >= 128 B contiguous per row).  Narrower stores are issue-bound: 16 dwordx2 per lane cost ~9k cycles of a
+  // 128x128 tile's life, twice the 8 dwordx4 that carry the same bytes.
+  constexpr bool OUT16 = EPI == KVQ_EPI_BIAS_BF16 || EPI == KVQ_EPI_GELU_BF16 || EPI == KVQ_EPI_RELU_BF16 ||
+                         EPI == KVQ_EPI_QKV_BF16;
+  constexpr int CW = OUT16 ? 8 : 4;                              // columns per lane (N % 8 == 0)
   constexpr int SW = 32 * NI;                                   // slab width (floats)
-  float* slab = reinterpret_cast<float*>(lds) + wave * 32 * SW;   // (lds is unsigned char[] here)
+  float* slab = reinterpret_cast<float*>(lds) + wave * 32 * SW;
   const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
-  constexpr int CPRW = SW / 4;                                   // float4 chunks per slab row
+  constexpr int CPRW = SW / CW;                                  // lane chunks per slab row
   constexpr int ROWS_PER_IT = 64 / CPRW;
   const int ch = lane % CPRW, rsub = lane / CPRW;
-  const int nbase = n0 + wn * SW;
-  const int n = nbase + ch * 4;
-  const bool col_live = n < p.N;                                 // N % 4 == 0: a float4 chunk is wholly in or out
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias && col_live) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+  const int n = n0 + wn * SW + ch * CW;
+  const bool col_live = n < p.N;                                 // N % 8 == 0: a chunk is wholly in or out
+  float bias[CW];
+#pragma unroll
+  for (int k = 0; k < CW; ++k) bias[k] = 0.f;
+  if (p.bias && col_live) {
+#pragma unroll
+    for (int q = 0; q < CW / 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bias[4 * q + k] = b4[k];
+    }
+  }
   int which = 0, head = 0, e0 = 0;
   float scale = 1.f;
   if (EPI == KVQ_EPI_QKV_BF16 && col_live) {                     // a 32-column tile = one head of q|k|v
@@ -196,35 +208,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int it = 0; it < 32 / ROWS_PER_IT; ++it) {
       const int rl = it * ROWS_PER_IT + rsub;
       const int m = m0 + wm * 32 * MI + i * 32 + rl;
-      f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * SW + ch * 4);
+      float v[CW];
+#pragma unroll
+      for (int q = 0; q < CW / 4; ++q) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(slab + rl * SW + ch * CW + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 * q + k] = s4[k] + bias[4 * q + k];
+      }
       if (m >= p.M || !col_live) continue;
+      if (OUT16) {
+        uint16_t* dst = p.out_h + (size_t)m * p.N + n;
+        if (EPI == KVQ_EPI_GELU_BF16) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += bias4[k];
-      if (EPI == KVQ_EPI_BIAS_BF16) {
-        u32x2 o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
-      } else if (EPI == KVQ_EPI_GELU_BF16) {
-        u32x2 o = {E::pack2(gelu_fast(v[0]), gelu_fast(v[1])), E::pack2(gelu_fast(v[2]), gelu_fast(v[3]))};
-        *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
-      } else if (EPI == KVQ_EPI_RELU_BF16) {     // conv + folded BN (+ identity) + ReLU (simpleVQA_model.py:104-124)
-        if (p.resid_h) {
-          const u32x2 rr = *reinterpret_cast<const u32x2*>(p.resid_h + (size_t)m * p.N + n);
-          v[0] += E::to_f32((uint16_t)(rr[0] & 0xffffu)); v[1] += E::to_f32((uint16_t)(rr[0] >> 16));
-          v[2] += E::to_f32((uint16_t)(rr[1] & 0xffffu)); v[3] += E::to_f32((uint16_t)(rr[1] >> 16));
+          for (int k = 0; k < CW; ++k) v[k] = gelu_fast(v[k]);
+        } else if (EPI == KVQ_EPI_RELU_BF16) {   // conv + folded BN (+ identity) + ReLU (simpleVQA_model.py:104-124)
+          if (p.resid_h) {
+            const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid_h + (size_t)m * p.N + n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[2 * k] += E::to_f32((uint16_t)(rr[k] & 0xffffu));
+              v[2 * k + 1] += E::to_f32((uint16_t)(rr[k] >> 16));
+            }
+          }
+          if (p.resid_f32) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(p.resid_f32 + (size_t)m * p.N + n + 4 * q);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[4 * q + k] += rr[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < CW; ++k) v[k] = fmaxf(v[k], 0.f);
+          if (p.out_f32) {                       // fp32 copy for the identity path
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n + 4 * q) =
+                  (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+          }
+        } else if (EPI == KVQ_EPI_QKV_BF16) {
+#pragma unroll
+          for (int k = 0; k < CW; ++k) v[k] *= scale;
+          dst = p.out_h + ((size_t)(which * p.num_heads + head) * p.M + m) * 32 + e0;
         }
-        if (p.resid_f32) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.resid_f32 + (size_t)m * p.N + n);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] += rr[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n) = v;   // fp32 copy for the identity path
-        u32x2 o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(p.out_h + (size_t)m * p.N + n) = o;
-      } else if (EPI == KVQ_EPI_QKV_BF16) {
-        u32x2 o = {E::pack2(v[0] * scale, v[1] * scale), E::pack2(v[2] * scale, v[3] * scale)};
-        *reinterpret_cast<u32x2*>(p.out_h + ((size_t)(which * p.num_heads + head) * p.M + m) * 32 + e0) = o;
+        const u32x4 o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4 % CW], v[5 % CW]),
+                         E::pack2(v[6 % CW], v[7 % CW])};
+        *reinterpret_cast<u32x4*>(dst) = o;
       } else if (EPI == KVQ_EPI_RESID_F32) {
         long orow = m;
         if (p.scatter_map) {
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int k = 0; k < 4; ++k) x[k] += v[k];
         *o = x;
       } else {  // KVQ_EPI_STORE_F32
-        *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n) = v;
+        *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n) = (f32x4){v[0], v[1], v[2], v[3]};
       }
     }
     __builtin_amdgcn_wave_barrier();

@@ -29,6 +29,11 @@ def run(M, N, K, epi, nH=0):
     print("   start times of blocks (ticks, every 128th):", start[order][::128][:12])
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for e in (_abi.EPI_BIAS_BF16, _abi.EPI_GELU_BF16, _abi.EPI_STORE_F32):
+            run(200704, 384, 96, e)
+            run(12544, 1536, 384, e)
+        sys.exit(0)
     run(12544, 1536, 384, _abi.EPI_GELU_BF16)
     run(12544, 384, 1536, _abi.EPI_RESID_F32)
     run(200704, 384, 96, _abi.EPI_GELU_BF16)
