@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 2
+#define KVQ_ABI_VERSION 3
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -87,6 +87,9 @@ typedef struct {
   const float* fc1_b;
   const uint16_t* fc2_w;   /* [C][4C] */
   const float* fc2_b;
+  const void* tail_pack;   /* optional, derived: kvq_block_tail_pack image of (proj, norm2, fc1, fc2).  Non-NULL (and
+                              C in {96,128,192}) -> proj+residual+norm2+Mlp+residual run as ONE launch
+                              (kvq_block_tail); NULL -> GEMM/LayerNorm launches */
 } KvqSwinBlockW;
 
 typedef struct {            /* PatchMerging (swin_backbone.py:527-531) */
@@ -131,7 +134,7 @@ int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const f
  * launch with hipEvents on the launch stream; enable with kvq_swin3d_profile(plan, 1). */
 enum {
   KVQ_K_IM2COL = 0, KVQ_K_LAYERNORM, KVQ_K_GEMM_QKV, KVQ_K_ATTN, KVQ_K_GEMM_PROJ, KVQ_K_GEMM_FC1,
-  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_COUNT
+  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_TAIL, KVQ_K_COUNT
 };
 typedef struct {
   int32_t kind;     /* KVQ_K_*                                                                    */
@@ -198,6 +201,36 @@ int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
  * dev_buf[8*b + {0:start, 1:first slice landed, 2:K loop done, 3:epilogue done}] (shader clock) and
  * [4] = XCC id << 32 | HW_ID.  Pass NULL to switch it off. */
 int kvq_debug_gemm_trace(void* dev_buf, int max_blocks);
+
+/* Fused post-attention half of SwinTransformerBlock3D, one launch, token-per-lane MFMA (csrc/tail.hip):
+ *   x <- x + window_reverse(roll(proj(attn)))        (swin_backbone.py:323, :472-488, :509)
+ *   x <- x + fc2(GELU(fc1(norm2(x))))                (:490-491, :514; Mlp :84-87)
+ *   optionally next_ln <- window_partition(roll(norm1_next(x)))   (:416-449 of the next block)
+ * The hidden activations, proj output and norm2 output stay in registers.  Weights come as the image
+ * kvq_block_tail_pack builds (MFMA-fragment-major panels, k order of fc1/fc2 permuted to the accumulator
+ * layout, followed by the fp32 bias / norm vectors). */
+typedef struct {
+  const void* attn;            /* 16-bit [M][C], window order (kvq_window_attention output)              */
+  float* x;                    /* fp32 [n_batch*out_rows][C] residual stream, updated in place           */
+  const int32_t* scatter_map;  /* window row -> token within the batch element, <0 = padding; NULL = id. */
+  int32_t map_rows, out_rows;  /* rows per batch element in the map / in x                               */
+  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192}; hidden % 32 == 0  */
+  const void* pack;            /* kvq_block_tail_pack image                                              */
+  const float* next_norm_w;    /* the following four: only with next_ln != NULL                          */
+  const float* next_norm_b;
+  const int32_t* next_dst;     /* token -> row of the next block's window order (a bijection: no padding) */
+  void* next_ln;               /* 16-bit [n_batch*next_rows][C]                                          */
+  int32_t next_rows;
+  float eps;                   /* 1e-5                                                                   */
+  int32_t dtype;               /* KvqDtype of attn, the packed weights and next_ln                        */
+} KvqBlockTailArgs;
+int kvq_block_tail_supported(int C, int hidden);                 /* 1 / 0 */
+size_t kvq_block_tail_pack_bytes(int C, int hidden);             /* 0 when unsupported */
+/* proj_w [C][C], fc1_w [hidden][C], fc2_w [C][hidden]: 16-bit nn.Linear layouts; the rest fp32. */
+int kvq_block_tail_pack(const void* proj_w, const float* proj_b, const float* norm2_w, const float* norm2_b,
+                        const void* fc1_w, const float* fc1_b, const void* fc2_w, const float* fc2_b, int C, int hidden,
+                        void* pack, void* stream);
+int kvq_block_tail(const KvqBlockTailArgs* host_args, void* stream);
 
 /* WindowAttention3D core (swin_backbone.py:261-322) for head_dim 32: S = q k^T + bias, where
  * bias = rpb*g + fpb*(1-g) (gated, :299-302) or rpb, + shift mask (0/-100, :583), softmax, @v.

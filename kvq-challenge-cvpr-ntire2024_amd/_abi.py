@@ -14,12 +14,12 @@ from . import _build
 
 MAX_STAGES = 4
 K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "gemm_fc2", "gemm_merge",
-           "gemm_embed"]
+           "gemm_embed", "tail"]
 K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16 = range(6)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def dtype_code(dt) -> int:
@@ -49,7 +49,7 @@ class KvqSwinCfg(C.Structure):
 
 class KvqSwinBlockW(C.Structure):
     _fields_ = [(n, p_void) for n in ("norm1_w", "norm1_b", "rpb_table", "fpb_table", "bias_pack", "qkv_w", "qkv_b", "proj_w",
-                                      "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                      "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "tail_pack")]
 
 
 class KvqSwinMergeW(C.Structure):
@@ -67,6 +67,13 @@ class KvqGemmArgs(C.Structure):
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
                 ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void)]
+
+
+class KvqBlockTailArgs(C.Structure):
+    _fields_ = [("attn", p_void), ("x", p_void), ("scatter_map", p_void), ("map_rows", C.c_int32),
+                ("out_rows", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("pack", p_void),
+                ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void),
+                ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
 
 
 class KvqProfRecord(C.Structure):
@@ -91,6 +98,11 @@ SYMBOLS = {
                                  p_void]),
     "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
     "kvq_debug_gemm_trace": (i32, [p_void, i32]),
+    "kvq_block_tail_supported": (i32, [i32, i32]),
+    "kvq_block_tail_pack_bytes": (sz, [i32, i32]),
+    "kvq_block_tail_pack": (i32, [p_void, p_void, p_void, p_void, p_void, p_void, p_void, p_void, i32, i32, p_void,
+                                  p_void]),
+    "kvq_block_tail": (i32, [C.POINTER(KvqBlockTailArgs), p_void]),
     "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
                                    p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),

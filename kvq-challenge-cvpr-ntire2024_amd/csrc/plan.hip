@@ -25,6 +25,7 @@ struct StageGeom {
   int Dp, Hp, Wp, nW, N, Lp;
   bool shifted_any;
   int32_t* d_src[2];  // [Lp] source token or -1
+  int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row); only when Lp == L (no padding), else nullptr
   int32_t* d_tok[2];  // [nW*N][2]
   int32_t* d_merge;   // [L_next][4] or nullptr
   int Dn, Hn, Wn;     // dims after the merge
@@ -127,6 +128,13 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
       }
   int rc = upload(pl, src, &g.d_src[par]);
   if (rc) return rc;
+  g.d_dst[par] = nullptr;
+  if (g.Lp == g.L) {
+    std::vector<int32_t> dst((size_t)g.L);
+    for (int i = 0; i < g.Lp; ++i) dst[src[i]] = i;
+    rc = upload(pl, dst, &g.d_dst[par]);
+    if (rc) return rc;
+  }
   return upload(pl, tok, &g.d_tok[par]);
 }
 
@@ -338,13 +346,15 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
   for (int i = 0; i < cfg.num_stages; ++i) {
     const StageGeom& g = pl->st[i];
     const int C = g.C, M = B * g.Lp, ML = B * g.L;
+    bool ln1_ready = false;   // the previous block's tail already wrote this block's norm1 rows
     for (int b = 0; b < g.depth; ++b, ++blk) {
       const KvqSwinBlockW& bw = w->blocks[blk];
       KVQ_REQUIRE(bw.norm1_w && bw.rpb_table && bw.qkv_w && bw.proj_w && bw.fc1_w && bw.fc2_w, KVQ_ERR_NULL,
                   "kvq_swin3d_forward: block %d weights incomplete", blk);
       const int par = (b & 1) && g.shifted_any ? 1 : 0;
       // norm1 + pad + roll + window_partition
-      KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+      if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+      ln1_ready = false;
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                    0.17677669529663687f /* 32^-0.5 */));
       {
@@ -354,6 +364,25 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
                                      bw.bias_pack,
                                      pl->table_len, pl->center, B * g.nW, g.nW, g.N, g.nH, par, pl->dtype, bo,
                                      st));
+      }
+      const int hidden = cfg.mlp_ratio * C;
+      if (bw.tail_pack && kvq_block_tail_supported(C, hidden)) {
+        // proj + window_reverse + roll back + crop + residual + norm2 + Mlp + residual [+ the next block's norm1]
+        KvqBlockTailArgs ta{};
+        ta.attn = bo; ta.x = cur; ta.scatter_map = g.d_src[par]; ta.map_rows = g.Lp; ta.out_rows = g.L;
+        ta.M = M; ta.C = C; ta.hidden = hidden; ta.pack = bw.tail_pack; ta.eps = 1e-5f; ta.dtype = pl->dtype;
+        const int npar = ((b + 1) & 1) && g.shifted_any ? 1 : 0;
+        if (b + 1 < g.depth && g.d_dst[npar]) {
+          const KvqSwinBlockW& nb = w->blocks[blk + 1];
+          KVQ_REQUIRE(nb.norm1_w && nb.norm1_b, KVQ_ERR_NULL, "kvq_swin3d_forward: block %d norm1 missing", blk + 1);
+          ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = g.d_dst[npar]; ta.next_ln = bln;
+          ta.next_rows = g.Lp;
+          ln1_ready = true;
+        }
+        Bracket br(pl, st, KVQ_K_TAIL, (C / 32) * 10 + (ln1_ready ? 1 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden,
+                   (double)M * C * 2.0 + (double)ML * C * (8.0 + (ln1_ready ? 2.0 : 0.0)));
+        KVQ_TRY(kvq_block_tail(&ta, st));
+        continue;
       }
       // proj + window_reverse + roll back + crop + residual
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,

@@ -234,3 +234,39 @@ def resize_bilinear(video: torch.Tensor, rh: int, rw: int, crop=None, mean=None,
     check(lib().kvq_resize_bilinear(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W, rh, rw, cy, cx, oh, ow,
                                     rnd, m, s, ptr(out), current_stream()), "kvq_resize_bilinear")
     return out
+
+
+def block_tail_pack(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b):
+    """Weight image of the fused proj+norm2+Mlp launch (include/kvq_hip.h: kvq_block_tail_pack)."""
+    _need_gpu(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b)
+    assert proj_w.dtype in HALF_TYPES and fc1_w.dtype == proj_w.dtype and fc2_w.dtype == proj_w.dtype
+    Cc, hidden = proj_w.shape[0], fc1_w.shape[0]
+    nbytes = lib().kvq_block_tail_pack_bytes(Cc, hidden)
+    if not nbytes:
+        raise _abi.KvqError(f"kvq_block_tail: unsupported width C={Cc}, hidden={hidden}")
+    pack = torch.empty(nbytes, dtype=torch.uint8, device=proj_w.device)
+    check(lib().kvq_block_tail_pack(ptr(proj_w.contiguous()), ptr(proj_b), ptr(norm2_w), ptr(norm2_b),
+                                    ptr(fc1_w.contiguous()), ptr(fc1_b), ptr(fc2_w.contiguous()), ptr(fc2_b), Cc, hidden,
+                                    ptr(pack), current_stream()), "kvq_block_tail_pack")
+    return pack
+
+
+def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: int, *, scatter_map=None, map_rows=0,
+               out_rows=0, next_norm=None, next_dst=None, next_rows=0, eps=1e-5):
+    """x (fp32 [n_batch*out_rows, C], in place) += proj(attn) scattered; x += Mlp(norm2(x)).
+    ``next_norm=(gamma, beta)`` + ``next_dst`` additionally returns norm1_next(x) in the next window order."""
+    _need_gpu(attn, x, pack, scatter_map, next_dst)
+    assert attn.dtype in HALF_TYPES and attn.is_contiguous() and x.dtype == torch.float32 and x.is_contiguous()
+    M, Cc = attn.shape
+    a = _abi.KvqBlockTailArgs()
+    a.attn, a.x, a.scatter_map = ptr(attn), ptr(x), ptr(scatter_map)
+    a.map_rows, a.out_rows = (map_rows, out_rows) if scatter_map is not None else (M, M)
+    a.M, a.C, a.hidden, a.pack, a.eps, a.dtype = M, Cc, hidden, ptr(pack), eps, dtype_code(attn.dtype)
+    nxt = None
+    if next_norm is not None:
+        n_batch = x.shape[0] // a.out_rows
+        nxt = torch.empty(n_batch * next_rows, Cc, dtype=attn.dtype, device=x.device)
+        a.next_norm_w, a.next_norm_b, a.next_dst, a.next_ln, a.next_rows = (ptr(next_norm[0]), ptr(next_norm[1]),
+                                                                            ptr(next_dst), ptr(nxt), next_rows)
+    check(lib().kvq_block_tail(C.byref(a), current_stream()), "kvq_block_tail")
+    return nxt

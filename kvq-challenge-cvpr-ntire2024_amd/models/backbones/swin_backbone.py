@@ -113,6 +113,8 @@ class SwinTransformer3D(nn.Module):
         # 1e-3 MOS parity gate) or "bf16".  Env KVQ_OPERAND_DTYPE overrides the default.
         import os
         self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
+        # proj+norm2+Mlp as one launch where the width allows it (C <= 192); KVQ_FUSED_TAIL=0 keeps the GEMM chain
+        self.fused_tail = os.environ.get("KVQ_FUSED_TAIL", "1") != "0"
         if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
             raise NotImplementedError("per-stage window sizes are not used by any reference config")
         if qk_scale is not None or any(jump_attention) or not qkv_bias:
@@ -195,7 +197,7 @@ class SwinTransformer3D(nn.Module):
     def _weights(self, device) -> KvqSwinWeights:
         """bf16 copies of the GEMM weights + a KvqSwinWeights of raw pointers; rebuilt whenever a
         parameter was modified in place or moved (tracked through tensor versions / data_ptr)."""
-        sig = (self.operand_dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        sig = (self.operand_dtype, self.fused_tail) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._wcache is not None and self._wcache[0] == sig:
             return self._wcache[1]
         keep = []
@@ -248,6 +250,14 @@ class SwinTransformer3D(nn.Module):
                 b.norm2_w, b.norm2_b = f32(blk.norm2.weight), f32(blk.norm2.bias)
                 b.fc1_w, b.fc1_b = bf16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
                 b.fc2_w, b.fc2_b = bf16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+                Cb, hid = blk.mlp.fc1.weight.shape[1], blk.mlp.fc1.weight.shape[0]
+                nbytes = lib().kvq_block_tail_pack_bytes(Cb, hid) if self.fused_tail else 0
+                if nbytes:      # fused proj+norm2+Mlp launch for this width (csrc/tail.hip)
+                    tp = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                    check(lib().kvq_block_tail_pack(b.proj_w, b.proj_b, b.norm2_w, b.norm2_b, b.fc1_w, b.fc1_b, b.fc2_w,
+                                                    b.fc2_b, Cb, hid, ptr(tp), current_stream()), "kvq_block_tail_pack")
+                    keep.append(tp)
+                    b.tail_pack = ptr(tp)
             if layer.downsample is not None:
                 m = w.merges[i]
                 m.norm_w, m.norm_b = f32(layer.downsample.norm.weight), f32(layer.downsample.norm.bias)
@@ -323,6 +333,9 @@ class SwinTransformer3D(nn.Module):
                 sym = f"window_attention_kernel<{ename}, {str(bool(r.variant & 2)).lower()}, {str(bool(r.variant & 1)).lower()}>"
             elif kind == "layernorm":
                 sym = "layernorm_rows_kernel"
+            elif kind == "tail":
+                cm = r.variant // 10
+                sym = f"block_tail_kernel<{ename}, {cm}, {2 if cm == 3 else 1}, {str(bool(r.variant % 10)).lower()}>"
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))

@@ -309,3 +309,77 @@ def test_fragment_gather_reference_assert():
     z = torch.zeros(7, 7, 1, dtype=torch.int32, device=DEV)
     with pytest.raises(AssertionError, match="Please provide match vclip and align index"):
         kernels.fragment_gather(v, z, z, 7, 7, 32, 32, 8)
+
+
+# ------------------------------------------------------------------ fused proj + norm2 + Mlp (tail.hip)
+def _tail_reference(A, x, wts, half, lay, B, dims):
+    """fp32 composition with the 16-bit operand roundings the launch applies (norm2 output, GELU output)."""
+    Wp, bp, g2, b2n, W1, b1, W2, b2 = wts
+    y = A @ Wp.t() + bp
+    if lay is not None:
+        D, H, W = dims
+        L, C = D * H * W, x.shape[1]
+        y = O.scatter_windows(y.reshape(B, -1, C), lay, B, D, H, W).reshape(B * L, C)
+    x1 = x + y
+    h = rnd(torch.nn.functional.layer_norm(x1, (x.shape[1],), g2, b2n), half)
+    hid = rnd(torch.nn.functional.gelu(h @ W1.t() + b1), half)
+    return x1 + hid @ W2.t() + b2
+
+
+@pytest.mark.parametrize("C,dims,shift,nxt_shift", [(96, (8, 14, 14), (0, 0, 0), (4, 3, 3)),
+                                                   (96, (4, 10, 9), (4, 3, 3), None),      # padded: no emission
+                                                   (128, (8, 7, 14), (4, 3, 3), (0, 0, 0)),
+                                                   (192, (8, 14, 7), (0, 0, 0), (4, 3, 3)),
+                                                   (192, (3, 5, 7), (0, 0, 0), None)])     # clamped window, ragged tile
+def test_block_tail(C, dims, shift, nxt_shift, half):
+    g = rng(C + sum(dims))
+    D, H, W = dims
+    B, hidden = 2, 4 * C
+    lay = O.window_layout(D, H, W, (8, 7, 7), shift)
+    Lp, L = lay["nW"] * lay["N"], D * H * W
+    t = lambda *s, sc=1.0: torch.from_numpy((g.standard_normal(s) * sc).astype(np.float32))
+    A = rnd(t(B * Lp, C), half)
+    x = t(B * L, C, sc=2.0)
+    Wp, W1, W2 = rnd(t(C, C, sc=0.15), half), rnd(t(hidden, C, sc=0.15), half), rnd(t(C, hidden, sc=0.08), half)
+    bp, b1, b2 = t(C, sc=0.3), t(hidden, sc=0.3), t(C, sc=0.3)
+    g2, b2n = 1 + 0.2 * t(C), 0.2 * t(C)
+    wts = (Wp, bp, g2, b2n, W1, b1, W2, b2)
+    pack = kernels.block_tail_pack(dev(Wp, half), dev(bp), dev(g2), dev(b2n), dev(W1, half), dev(b1), dev(W2, half), dev(b2))
+    ref = _tail_reference(A, x, wts, half, lay, B, dims)
+    xd = dev(x.clone())
+    kw = {}
+    if nxt_shift is not None:
+        lay2 = O.window_layout(D, H, W, (8, 7, 7), nxt_shift)
+        assert (lay2["src"] >= 0).all()
+        dst = np.empty(L, np.int32)
+        dst[lay2["src"]] = np.arange(L, dtype=np.int32)
+        gn, bn = 1 + 0.2 * t(C), 0.2 * t(C)
+        kw = dict(next_norm=(dev(gn), dev(bn)), next_dst=dev(torch.from_numpy(dst)), next_rows=L)
+    out_ln = kernels.block_tail(dev(A, half), xd, pack, hidden, scatter_map=dev(torch.from_numpy(lay["src"].astype(np.int32))),
+                                map_rows=Lp, out_rows=L, **kw)
+    got = xd.cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 6 * EPS[half] * scale + 1e-4, ((got - ref).abs().max().item(), scale)
+    if nxt_shift is not None:
+        ln = torch.nn.functional.layer_norm(got, (C,), gn, bn).reshape(B, D, H, W, C)
+        ref_ln = O.gather_windows(ln, lay2).reshape(-1, C)
+        d = (out_ln.float().cpu() - ref_ln).abs().max().item()
+        assert d <= 2 * EPS[half] * ref_ln.abs().max().item() + 1e-5, d
+
+
+def test_block_tail_identity_map_and_unsupported(half):
+    g = rng(77)
+    C, hidden, M = 96, 384, 333
+    t = lambda *s, sc=1.0: torch.from_numpy((g.standard_normal(s) * sc).astype(np.float32))
+    A, x = rnd(t(M, C), half), t(M, C)
+    Wp, W1, W2 = rnd(t(C, C, sc=0.15), half), rnd(t(hidden, C, sc=0.15), half), rnd(t(C, hidden, sc=0.08), half)
+    bp, b1, b2, g2, b2n = t(C), t(hidden), t(C), 1 + 0.1 * t(C), 0.1 * t(C)
+    pack = kernels.block_tail_pack(dev(Wp, half), dev(bp), dev(g2), dev(b2n), dev(W1, half), dev(b1), dev(W2, half), dev(b2))
+    xd = dev(x.clone())
+    kernels.block_tail(dev(A, half), xd, pack, hidden)
+    ref = _tail_reference(A, x, (Wp, bp, g2, b2n, W1, b1, W2, b2), half, None, 1, None)
+    assert (xd.cpu() - ref).abs().max().item() <= 6 * EPS[half] * ref.abs().max().item() + 1e-4
+    assert _abi.lib().kvq_block_tail_pack_bytes(384, 1536) == 0
+    with pytest.raises(_abi.KvqError, match="unsupported"):
+        kernels.block_tail_pack(*(dev(torch.zeros(s), half if len(s) == 2 else None) for s in
+                                  [(384, 384), (384,), (384,), (384,), (1536, 384), (1536,), (384, 1536), (384,)]))
