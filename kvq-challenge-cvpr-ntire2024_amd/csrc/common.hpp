@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -103,19 +104,44 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// GELU for the GEMM epilogue: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. fp32-roundoff
-// class and ~4 orders below the 16-bit rounding applied to the result) — 1 rcp + 1 exp + 7 fma instead
-// of the ~35-instruction libm erff.  The fp32 score head keeps the libm erff (gelu_erf).
+// GELU for the fused epilogues, two values at a time.  erfc by Abramowitz-Stegun 7.1.28,
+//   erfc(z) = (1 + a1 z + ... + a6 z^6)^-16,  |err| <= 3e-7  (fp32-roundoff class, ~3 orders below the 16-bit
+// rounding applied to the result), and gelu(x) = max(x,0) - |x|/2 * erfc(|x|/sqrt2).  Written on float2 so that
+// the polynomial, the four squarings and the tail compile to packed v_pk_fma_f32 / v_pk_mul_f32 (2 lanes-worth
+// per issue slot); the only quarter-rate instruction left is ONE v_rcp_f32 per value (A&S 7.1.26, used before,
+// needs rcp + exp and ~2x the issue cycles — the fused MLP launch is bound by exactly this).  Overflow of the
+// 16th power for huge |x| gives rcp(inf) = 0, i.e. the exact limit.  The fp32 score head keeps libm erff.
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  f32x2 p = z * 0.0000430638f + 0.0002765672f;
+  p = p * z + 0.0001520143f;
+  p = p * z + 0.0092705272f;
+  p = p * z + 0.0422820123f;
+  p = p * z + 0.0705230784f;
+  p = p * z + 1.0f;
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  const f32x2 rc = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+  const f32x2 hz = z * 0.70710678118654752440f;        // |x| / 2
+  const f32x2 r = x * 0.5f + hz;                       // max(x, 0)
+  return r - hz * rc;
+}
 __device__ __forceinline__ float gelu_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-  const float erf_abs = fmaf(-poly * t, e, 1.0f);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+  float p = fmaf(z, 0.0000430638f, 0.0002765672f);
+  p = fmaf(p, z, 0.0001520143f);
+  p = fmaf(p, z, 0.0092705272f);
+  p = fmaf(p, z, 0.0422820123f);
+  p = fmaf(p, z, 0.0705230784f);
+  p = fmaf(p, z, 1.0f);
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  const float hz = z * 0.70710678118654752440f;
+  return fmaf(-hz, __builtin_amdgcn_rcpf(p), fmaf(x, 0.5f, hz));
 }
 
 // diagnostic stamp buffer (kvq_debug_gemm_trace): 8 uint64 per workgroup, NULL = off

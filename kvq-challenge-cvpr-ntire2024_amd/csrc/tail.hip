@@ -15,10 +15,17 @@
 // token), the proj output and norm2's output never exist in memory: per token the launch reads attn_out (2C B)
 // and x (4C B) and writes x (4C B) [+ 2C B for the next norm1] instead of 48C B over five launches.
 //
-// Weights stream through a 3-slot LDS ring by LDS-DMA as "panels" (32 x C 16-bit: 32 output channels of proj,
-// the W1 rows of 32 hidden units, or the W2 columns of the same 32 hidden units) already laid out fragment-major
-// (one 1 KB wave-load = one k-step of A fragments, lane-linear => conflict-free ds_read_b128); a ring item is
-// 1 or 2 panels (>= 12 KB).  One counted vmcnt wait + one raw barrier per item, as in gemm.hip.
+// Weights stream through an LDS ring by LDS-DMA as "panels" (32 x C 16-bit: 32 output channels of proj, the W1
+// rows of 32 hidden units, or the W2 columns of 32 hidden units) already laid out fragment-major (one 1 KB
+// wave-load = one k-step of A fragments, lane-linear => conflict-free ds_read_b128); a ring item is 2 panels.
+// One counted vmcnt wait + one raw barrier per item, as in gemm.hip.
+//
+// The MLP is bound by the GELU's VALU work, not by MFMA, so its loop is software-pipelined over 32-unit chunks:
+// iteration j issues the MFMAs of fc2(chunk j) and fc1(chunk j+2) and, between them, evaluates GELU(chunk j+1)
+// — the matrix pipe runs under the VALU stream of the SAME wave (two fc1 accumulators and two packed GELU
+// outputs rotate).  Ring item j is therefore {W2 panel j, W1 panel j+2}.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace kvq {
@@ -35,6 +42,8 @@ struct TailParams {
   uint16_t* next_ln;         // [n_batch*next_rows][C]
   int next_rows;
   float eps;
+  unsigned long long* trace;   // diagnostic stamps (kvq_debug_gemm_trace; -DKVQ_TAIL_TRACE builds only)
+  int trace_blocks;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -45,47 +54,60 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int TAIL_NST = 3;
-
-__host__ __device__ constexpr int tail_ppi(int C) { return 64 * C >= 12288 ? 1 : 2; }     // panels per ring item
-__host__ __device__ constexpr int tail_slot_bytes(int C) { return tail_ppi(C) * 64 * C; }
-__host__ __device__ constexpr int tail_proj_items(int C) { return (C / 32 + tail_ppi(C) - 1) / tail_ppi(C); }
-static size_t tail_items(int C, int hidden) { return tail_proj_items(C) + (size_t)(hidden / 32) * 2 / tail_ppi(C); }
+__host__ __device__ constexpr int tail_slot_bytes(int C) { return 128 * C; }            // 2 panels of 32 x C 16-bit
+__host__ __device__ constexpr int tail_proj_items(int C) { return (C / 32 + 1) / 2; }
+// workgroups per CU for NW waves of 32 tokens each: C=96 fits 3 waves per SIMD (<= 168 VGPRs), wider rows 2
+__host__ __device__ constexpr int tail_bpc(int C, int NW) { return (C == 96 ? 12 : 8) / NW; }
+__host__ __device__ constexpr int tail_ring(int C, int NW) {                            // ring slots: what LDS allows, <= 4
+  return (163840 / tail_bpc(C, NW) - 8192) / tail_slot_bytes(C) >= 4 ? 4 : 3;
+}
+static size_t tail_items(int C, int hidden) { return (size_t)tail_proj_items(C) + 1 + hidden / 32; }
 static size_t tail_param_bytes(int C, int hidden) { return (((size_t)(4 * C + hidden) * 4) + 4095) & ~(size_t)4095; }
 
 // ---- weight image ---------------------------------------------------------------------------------------------
 // panel = 64*C bytes = C/16 "fragment rows" of 64 lanes x 16 B.  Fragment row f of a panel holds, for lane
-// (m = lane&31, h = lane>>5), the 8 k-values an MFMA A operand needs at that lane.  Panel sequence:
+// (m = lane&31, h = lane>>5), the 8 k-values an MFMA A operand needs at that lane.
 //   proj panel i (i < C/32):  f = s (k-step):                Wp[32i+m][16s + 8h + e]            (e = 0..7)
-//   zero panels up to a whole number of ring items (tail_ppi(C) panels each), then per 32 hidden units j:
-//   W1 panel j:               f = s:                         W1[32j+m][chan(s,h,e)]
+//   W1 panel j (j < hid/32):  f = s:                         W1[32j+m][chan(s,h,e)]
 //   W2 panel j:               f = 2i + t (t = 0,1):          W2[32i+m][32j + 8(2t + (e>>2)) + 4h + (e&3)]
 //   chan(s,h,e) = 32(s>>1) + 8(2(s&1) + (e>>2)) + 4h + (e&3)   — the channel an accumulator register r = 8(s&1)+e
 //   of tile s>>1 holds in lane half h (C/D layout of v_mfma_f32_32x32x16).
-// After the panels: fp32 [proj_b C][norm2_w C][norm2_b C][fc2_b C][fc1_b hidden], padded to 4 KB.
+// Items (2 panels each): proj panels in order (zero-padded to a whole item); {W1_0, W1_1}; then for every j
+// {W2_j, W1_{j+2}} (zero where j+2 is past the end).  After the items: fp32 [proj_b C][norm2_w C][norm2_b C]
+// [fc2_b C][fc1_b hidden], padded to 4 KB.
 __global__ void tail_pack_kernel(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b,
                                  const float* n2w, const float* n2b, const float* b1, const float* b2, int C, int hidden,
                                  unsigned char* out, long n_chunks, long n_par) {
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int CM = C / 32, KS = C / 16, first_mlp = tail_proj_items(C) * tail_ppi(C);
+  const int CM = C / 32, KS = C / 16, NJ = hidden / 32, first_mlp = tail_proj_items(C) * 2;
   if (g < n_chunks) {
     const int panel = (int)(g / (KS * 64)), rem = (int)(g % (KS * 64));
     const int f = rem >> 6, lane = rem & 63, m = lane & 31, h = lane >> 5;
+    int kind = 0, idx = 0;             // 0 zero, 1 proj, 2 W1, 3 W2
+    if (panel < CM) {
+      kind = 1; idx = panel;
+    } else if (panel >= first_mlp) {
+      const int q = panel - first_mlp;
+      if (q < 2) {
+        kind = 2; idx = q;
+      } else if (((q - 2) & 1) == 0) {
+        kind = 3; idx = (q - 2) >> 1;
+      } else if (((q - 2) >> 1) + 2 < NJ) {
+        kind = 2; idx = ((q - 2) >> 1) + 2;
+      }
+    }
     uint16_t v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       uint16_t val = 0;
-      if (panel < CM) {
-        val = wp[(size_t)(32 * panel + m) * C + 16 * f + 8 * h + e];
-      } else if (panel >= first_mlp) {
-        const int j = (panel - first_mlp) >> 1;
-        if (((panel - first_mlp) & 1) == 0) {
-          const int ch = 32 * (f >> 1) + 8 * (2 * (f & 1) + (e >> 2)) + 4 * h + (e & 3);
-          val = w1[(size_t)(32 * j + m) * C + ch];
-        } else {
-          const int i = f >> 1, t = f & 1;
-          val = w2[(size_t)(32 * i + m) * hidden + 32 * j + 8 * (2 * t + (e >> 2)) + 4 * h + (e & 3)];
-        }
+      if (kind == 1) {
+        val = wp[(size_t)(32 * idx + m) * C + 16 * f + 8 * h + e];
+      } else if (kind == 2) {
+        const int ch = 32 * (f >> 1) + 8 * (2 * (f & 1) + (e >> 2)) + 4 * h + (e & 3);
+        val = w1[(size_t)(32 * idx + m) * C + ch];
+      } else if (kind == 3) {
+        const int i = f >> 1, t = f & 1;
+        val = w2[(size_t)(32 * i + m) * hidden + 32 * idx + 8 * (2 * t + (e >> 2)) + 4 * h + (e & 3)];
       }
       v[e] = val;
     }
@@ -105,11 +127,16 @@ __global__ void tail_pack_kernel(const uint16_t* wp, const uint16_t* w1, const u
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------
-template <typename E, int CM, int TN, bool EMIT>
-__global__ __launch_bounds__(256, 2) void block_tail_kernel(TailParams p) {
-  constexpr int C = 32 * CM, KS = 2 * CM, PPI = tail_ppi(C), PANEL = 64 * C, SLOT = PPI * PANEL, LPW = SLOT / 4096;
-  constexpr int NST = TAIL_NST, NPI = tail_proj_items(C);
-  static_assert(SLOT % 4096 == 0, "an item is a whole number of 1 KB loads per wave");
+// NW waves of 32 tokens share one weight ring.  Measured (B = 4 clips, stage 0 / stage 1, us per launch): NW = 4
+// 82 / 76, NW = 6 136 / -, NW = 8 - / 76, NW = 12 124 / -: the L2 -> LDS weight stream (1.7 KB per token at NW = 4) is
+// NOT the bound — the wider barrier domain costs more than the halved stream saves — so workgroups stay at 4 waves,
+// 3 (C = 96, <= 168 VGPRs) or 2 of them per CU.
+template <typename E, int CM, int NW, bool EMIT>
+__global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_kernel(TailParams p) {
+  constexpr int C = 32 * CM, KS = 2 * CM, PANEL = 64 * C, SLOT = 2 * PANEL, LPW = SLOT / 1024 / NW;
+  constexpr int NST = tail_ring(C, NW), NPI = tail_proj_items(C);
+  static_assert(SLOT % (1024 * NW) == 0, "an item is a whole number of 1 KB loads per wave");
+  static_assert(NST == 3 || NST == 4, "wait ladder below");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
   float* prm = reinterpret_cast<float*>(lds + NST * SLOT);
@@ -121,71 +148,97 @@ __global__ __launch_bounds__(256, 2) void block_tail_kernel(TailParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NJ = p.hidden >> 5, NI = NPI + NJ * 2 / PPI;
-  const int PL = (int)(((4 * C + p.hidden) * 4 + 4095) >> 12);      // 1 KB param loads per wave
+  const int NJ = p.hidden >> 5, NI = NPI + 1 + NJ;
+  const int NQ = ((4 * C + p.hidden) * 4 + 1023) >> 10;              // 1 KB wave-loads that carry the parameters
+  float* s_nn = reinterpret_cast<float*>(lds + NST * SLOT + NQ * 1024);   // [norm1_next_w C][norm1_next_b C] (EMIT)
+#ifdef KVQ_TAIL_TRACE   // diagnostic build only: the stamps cost registers and scheduling freedom
+  const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
+#define KVQ_STAMP(i) if (tr) p.trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define KVQ_STAMP(i)
+#endif
+  KVQ_STAMP(0);
 
-  // oldest in the queue: the fp32 parameters, straight into LDS
+  // oldest in the queue: the next block's norm1 vectors (registers -> LDS below) and the fp32 parameters (DMA)
+  f32x4 nn_reg = {0.f, 0.f, 0.f, 0.f};
+  if (EMIT && tid < C / 2) nn_reg = *reinterpret_cast<const f32x4*>((tid < C / 4 ? p.nn_w : p.nn_b - C) + 4 * tid);
   {
     const unsigned char* src = p.pack + (size_t)NI * SLOT;
-    for (int l = 0; l < PL; ++l) {
-      const int q = l * 4 + wave;
+    for (int q = wave; q < NQ; q += NW)      // uneven per wave is fine: these are OLDER than every counted item
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + q * 1024 + lane * 16),
                                        (lds_ptr_t)(lds + NST * SLOT + q * 1024), 16, 0, 0);
-    }
   }
-  // this lane's tokens
-  long orig[TN];
-  bool live[TN];
-  int tloc[TN], tb[TN];
-  V8 bx[TN][KS];
-  f32x16 acc[TN][CM];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const long row = (long)blockIdx.x * (128 * TN) + wave * (32 * TN) + t * 32 + (lane & 31);
-    const long rc = row < p.M ? row : p.M - 1;
-    int b = 0, s = (int)rc;
-    if (p.map) {
-      b = (int)(rc / p.map_rows);
-      s = p.map[rc - (long)b * p.map_rows];
-    } else {
-      b = (int)(rc / p.out_rows);
-      s = (int)(rc - (long)b * p.out_rows);
-    }
-    live[t] = row < p.M && s >= 0;
-    tb[t] = b;
-    tloc[t] = s < 0 ? 0 : s;
-    orig[t] = (long)b * p.out_rows + tloc[t];
+  // this lane's token
+  const long row = (long)blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+  const long rc = row < p.M ? row : p.M - 1;
+  int tb, tloc;
+  if (p.map) {
+    tb = (int)(rc / p.map_rows);
+    tloc = p.map[rc - (long)tb * p.map_rows];
+  } else {
+    tb = (int)(rc / p.out_rows);
+    tloc = (int)(rc - (long)tb * p.out_rows);
+  }
+  const bool live = row < p.M && tloc >= 0;
+  tloc = tloc < 0 ? 0 : tloc;
+  const long orig = (long)tb * p.out_rows + tloc;
+  V8 bx[KS];
+  f32x16 acc[CM];
+  {
     const uint16_t* ar = p.attn + (size_t)rc * C + 8 * h;
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) bx[t][s2] = *reinterpret_cast<const V8*>(ar + 16 * s2);
-    const float* xr = p.x + (size_t)orig[t] * C + 4 * h;
+    for (int s = 0; s < KS; ++s) bx[s] = *reinterpret_cast<const V8*>(ar + 16 * s);
+    // acc = x + proj bias (from the global image: LDS is not populated yet).  From here to the end of the MLP the
+    // accumulator tiles are only READ element-wise (norm2) or written by MFMA: element-wise updates in between
+    // would make the register allocator shuffle / spill the 16-register tuples.
+    const float* xr = p.x + (size_t)orig * C + 4 * h;
+    const float* pbg = reinterpret_cast<const float*>(p.pack + (size_t)NI * SLOT) + 4 * h;
 #pragma unroll
     for (int i = 0; i < CM; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 32 * i + 8 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pbg + 32 * i + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t][i][4 * q + e] = v[e];
+        for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = v[e] + b[e];
       }
   }
 
-  auto issue = [&](int it) {
-    unsigned char* dst = lds + (it % NST) * SLOT;
-    const unsigned char* src = p.pack + (size_t)it * SLOT;   // it % NST: items are issued in order, slot = ring position
+  auto issue = [&](int item, int slot) {
+    unsigned char* dst = lds + slot * SLOT;
+    const unsigned char* src = p.pack + (size_t)item * SLOT;
 #pragma unroll
     for (int l = 0; l < LPW; ++l) {
-      const int q = l * 4 + wave;
+      const int q = l * NW + wave;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + q * 1024 + lane * 16), (lds_ptr_t)(dst + q * 1024), 16, 0, 0);
     }
   };
-  issue(0);
-  issue(1);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue(i, i);
+  if (EMIT && tid < C / 2) *reinterpret_cast<f32x4*>(s_nn + 4 * tid) = nn_reg;
   int it = 0, slot = 0;
   // item `it` visible to every wave; everybody has left item it-1, whose slot takes item it+NST-1
+#ifdef KVQ_TAIL_TRACE
+  unsigned long long wait_dma = 0, wait_bar = 0;
+#endif
   auto next_item = [&]() -> const unsigned char* {
-    if (it < NI - 1) wait_vmcnt<LPW>(); else wait_vmcnt<0>();
+    const int younger = NI - 1 - it;
+#ifdef KVQ_TAIL_TRACE
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+    if (NST == 4 && younger >= 2) wait_vmcnt<2 * LPW>();
+    else if (younger >= 1) wait_vmcnt<LPW>();
+    else wait_vmcnt<0>();
+#ifdef KVQ_TAIL_TRACE
+    const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
     __builtin_amdgcn_s_barrier();
-    if (it + NST - 1 < NI) issue(it + NST - 1);
+#ifdef KVQ_TAIL_TRACE
+    wait_dma += t1 - t0;
+    wait_bar += __builtin_readcyclecounter() - t1;
+#endif
+    const int fill = slot == 0 ? NST - 1 : slot - 1;
+    if (it + NST - 1 < NI) issue(it + NST - 1, fill);
     const unsigned char* st = lds + slot * SLOT + lane * 16;
     ++it;
     slot = slot + 1 == NST ? 0 : slot + 1;
@@ -196,173 +249,210 @@ __global__ __launch_bounds__(256, 2) void block_tail_kernel(TailParams p) {
   const unsigned char* st = nullptr;
 #pragma unroll
   for (int i = 0; i < CM; ++i) {
-    if (i % PPI == 0) st = next_item();
+    if (i % 2 == 0) st = next_item();
+    if (i == 0) { KVQ_STAMP(1); }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const V8 a = *reinterpret_cast<const V8*>(st + (i % PPI) * PANEL + s * 1024);
-#pragma unroll
-      for (int t = 0; t < TN; ++t) acc[t][i] = E::mfma32(a, bx[t][s], acc[t][i]);
+      const V8 a = *reinterpret_cast<const V8*>(st + (i % 2) * PANEL + s * 1024);
+      acc[i] = E::mfma32(a, bx[s], acc[i]);
+      if (s % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // keeps the fragment loads from piling up in registers
     }
   }
-  // + proj bias (the parameters landed before item 0 and are visible since its barrier)
-#pragma unroll
-  for (int i = 0; i < CM; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(s_pb + 32 * i + 8 * q + 4 * h);
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t][i][4 * q + e] += b[e];
-    }
-
+  __builtin_amdgcn_sched_barrier(0);
   // ---- norm2 in registers: two-pass statistics, biased variance, eps inside the rsqrt (as ln.hip) -----------
-  float mean[TN], rstd[TN];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
+  {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; r += 4) s += (acc[t][i][r] + acc[t][i][r + 1]) + (acc[t][i][r + 2] + acc[t][i][r + 3]);
+      for (int r = 0; r < 16; r += 4) s += (acc[i][r] + acc[i][r + 1]) + (acc[i][r + 2] + acc[i][r + 3]);
     s += __shfl_xor(s, 32);
-    mean[t] = s / (float)C;
+    const float mean = s / (float)C;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < CM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float d = acc[t][i][r] - mean[t];
+        const float d = acc[i][r] - mean;
         sq += d * d;
       }
     sq += __shfl_xor(sq, 32);
-    rstd[t] = rsqrtf(sq / (float)C + p.eps);
-  }
-  // normalised rows -> B operands of fc1 (k order = accumulator order, see tail_pack_kernel); x1 + fc2 bias stays in acc
+    const float rstd = rsqrtf(sq / (float)C + p.eps);
+    float mean_n = mean;
+    asm volatile("" : "+v"(mean_n));   // an opaque copy: CSE with the variance pass would keep C/2 differences live (spills)
+    // normalised row -> B operands of fc1 (k order = accumulator order, see tail_pack_kernel); x1 stays in acc
 #pragma unroll
-  for (int i = 0; i < CM; ++i)
+    for (int i = 0; i < CM; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(s_g2 + 32 * i + 8 * q + 4 * h);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(s_b2n + 32 * i + 8 * q + 4 * h);
-      const f32x4 fb = *reinterpret_cast<const f32x4*>(s_fb2 + 32 * i + 8 * q + 4 * h);
-#pragma unroll
-      for (int t = 0; t < TN; ++t) {
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(s_g2 + 32 * i + 8 * q + 4 * h);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(s_b2n + 32 * i + 8 * q + 4 * h);
         float y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          y[e] = (acc[t][i][4 * q + e] - mean[t]) * rstd[t] * g[e] + be[e];
-          acc[t][i][4 * q + e] += fb[e];
-        }
-        u32x4 w = __builtin_bit_cast(u32x4, bx[t][2 * i + (q >> 1)]);
+        for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mean_n) * rstd * g[e] + be[e];
+        u32x4 w = __builtin_bit_cast(u32x4, bx[2 * i + (q >> 1)]);
         w[2 * (q & 1)] = E::pack2(y[0], y[1]);
         w[2 * (q & 1) + 1] = E::pack2(y[2], y[3]);
-        bx[t][2 * i + (q >> 1)] = __builtin_bit_cast(V8, w);
+        bx[2 * i + (q >> 1)] = __builtin_bit_cast(V8, w);
+        if (q & 1) __builtin_amdgcn_sched_barrier(0);
       }
-    }
+  }
+  __builtin_amdgcn_sched_barrier(0);     // nothing of the MLP prologue (bias / fragment loads) is hoisted into norm2
+  KVQ_STAMP(2);
 
-  // ---- MLP: 32 hidden units per item; they live and die in registers -----------------------------------------
-  for (int j = 0; j < NJ; ++j) {
-    st = next_item();
-    f32x16 hacc[TN];
+  // ---- MLP, software-pipelined over chunks of 32 hidden units ------------------------------------------------
+  // fc1 accumulator of a chunk, initialised with its bias
+  auto h_init = [&](f32x16& ha, int j) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(s_fb1 + 32 * j + 8 * q + 4 * h);
 #pragma unroll
-      for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hacc[t][4 * q + e] = b[e];
+      for (int e = 0; e < 4; ++e) ha[4 * q + e] = b[e];
     }
+  };
+  // GELU of accumulator registers 2g, 2g+1 -> dword g of the packed B operand pair
+  auto gelu_pair = [&](const f32x16& ha, u32x4 (&hb)[2], int g) {
+#ifdef KVQ_TAIL_NOGELU      // experiment: the MFMA / LDS / barrier floor of the loop without the VALU stream
+    uint32_t w = E::pack2_raw(fmaxf(ha[2 * g], 0.f), fmaxf(ha[2 * g + 1], 0.f));
+#else
+    uint32_t w = E::pack2(gelu_fast(ha[2 * g]), gelu_fast(ha[2 * g + 1]));
+#endif
+    asm volatile("" : "+v"(w));      // pins the evaluation HERE (between two MFMAs): IR-level sinking would otherwise
+    hb[g >> 2][g & 3] = w;           // move the whole GELU next to its first use, after the MFMA stream
+  };
+  f32x16 haA, haB;
+  u32x4 hbA[2], hbB[2];
+  // prologue item {W1_0, W1_1}: fc1 of chunks 0 and 1; GELU(chunk 0) runs under chunk 1's MFMAs
+  st = next_item();
+  h_init(haA, 0);
+  h_init(haB, 1);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const V8 a = *reinterpret_cast<const V8*>(st + s * 1024);
-#pragma unroll
-      for (int t = 0; t < TN; ++t) hacc[t] = E::mfma32(a, bx[t][s], hacc[t]);
-    }
-    V8 hb[TN][2];
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        u32x4 w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          w[e] = E::pack2(gelu_fast(hacc[t][8 * tt + 2 * e]), gelu_fast(hacc[t][8 * tt + 2 * e + 1]));
-        hb[t][tt] = __builtin_bit_cast(V8, w);
-      }
-    const unsigned char* st2 = PPI == 1 ? next_item() : st + PANEL;
-#pragma unroll
-    for (int i = 0; i < CM; ++i)
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const V8 a = *reinterpret_cast<const V8*>(st2 + (2 * i + tt) * 1024);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) acc[t][i] = E::mfma32(a, hb[t][tt], acc[t][i]);
-      }
+  for (int s = 0; s < KS; ++s) {
+    haA = E::mfma32(*reinterpret_cast<const V8*>(st + s * 1024), bx[s], haA);
+    if (s % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
-
-  // ---- write the residual stream back; optionally the next block's norm1 in ITS window order -----------------
 #pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    if (!live[t]) continue;
-    float* xr = p.x + (size_t)orig[t] * C + 4 * h;
+  for (int s = 0; s < KS; ++s) {
+    haB = E::mfma32(*reinterpret_cast<const V8*>(st + PANEL + s * 1024), bx[s], haB);
+    if (s % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) gelu_pair(haA, hbA, g);
+
+  // one pipeline step: Y += W2_j . hb_cur ; ha_cur <- fc1(chunk j+2) ; hb_nxt <- GELU(ha_nxt)   (ha_nxt = chunk j+1)
+  auto step = [&](int j, f32x16& ha_cur, u32x4 (&hb_cur)[2], f32x16& ha_nxt, u32x4 (&hb_nxt)[2], bool do_h,
+                  bool do_g) __attribute__((always_inline)) {
+    const unsigned char* sp = next_item();
+    const V8 b0 = __builtin_bit_cast(V8, hb_cur[0]), b1 = __builtin_bit_cast(V8, hb_cur[1]);
+    if (do_h) h_init(ha_cur, j + 2);
+    // 2*KS MFMAs (the item is their 2*KS A fragments in order) and 8 GELU pairs, interleaved in program order: MFMA k,
+    // then the k-th share of the VALU work; fragment k+1 is fetched before MFMA k is issued
+    const int nk = do_h ? 2 * KS : KS;
+    V8 a_nxt = *reinterpret_cast<const V8*>(sp);
+#pragma unroll
+    for (int k = 0; k < 2 * KS; ++k) {
+      const V8 a = a_nxt;
+      if (k + 1 < nk) a_nxt = *reinterpret_cast<const V8*>(sp + (k + 1) * 1024);
+      if (k < KS) {                                   // fc2: tile k>>1, k-step k&1 of this chunk
+        acc[k >> 1] = E::mfma32(a, (k & 1) ? b1 : b0, acc[k >> 1]);
+      } else if (do_h) {                              // fc1 of chunk j+2
+        ha_cur = E::mfma32(a, bx[k - KS], ha_cur);
+      }
+      if (do_g) {
+#pragma unroll
+        for (int g = (8 * k) / (2 * KS); g < (8 * (k + 1)) / (2 * KS); ++g) gelu_pair(ha_nxt, hb_nxt, g);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int j = 0;
+  for (; j + 2 < NJ; j += 2) {
+    step(j, haA, hbA, haB, hbB, true, true);
+    step(j + 1, haB, hbB, haA, hbA, true, true);
+  }
+  step(j, haA, hbA, haB, hbB, false, true);          // chunk NJ-2: nothing left to start
+  step(j + 1, haB, hbB, haA, hbA, false, false);     // chunk NJ-1
+  KVQ_STAMP(3);
+
+  // ---- + fc2 bias; write the residual stream back; optionally the next block's norm1 in ITS window order ------
+#pragma unroll
+  for (int i = 0; i < CM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(s_fb2 + 32 * i + 8 * q + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][4 * q + e] += fb[e];
+      if (q & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  if (live) {
+    float* xr = p.x + (size_t)orig * C + 4 * h;
 #pragma unroll
     for (int i = 0; i < CM; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(xr + 32 * i + 8 * q) =
-            (f32x4){acc[t][i][4 * q], acc[t][i][4 * q + 1], acc[t][i][4 * q + 2], acc[t][i][4 * q + 3]};
+            (f32x4){acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
   }
   if (EMIT) {
+    float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      float s = 0.f;
+    for (int i = 0; i < CM; ++i)
 #pragma unroll
-      for (int i = 0; i < CM; ++i)
+      for (int r = 0; r < 16; r += 4) s += (acc[i][r] + acc[i][r + 1]) + (acc[i][r + 2] + acc[i][r + 3]);
+    s += __shfl_xor(s, 32);
+    const float mu = s / (float)C;
+    float sq = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r += 4) s += (acc[t][i][r] + acc[t][i][r + 1]) + (acc[t][i][r + 2] + acc[t][i][r + 3]);
-      s += __shfl_xor(s, 32);
-      const float mu = s / (float)C;
-      float sq = 0.f;
+    for (int i = 0; i < CM; ++i)
 #pragma unroll
-      for (int i = 0; i < CM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = acc[t][i][r] - mu;
-          sq += d * d;
-        }
-      sq += __shfl_xor(sq, 32);
-      const float rs = rsqrtf(sq / (float)C + p.eps);
-      if (!live[t]) continue;
-      const long drow = (long)tb[t] * p.next_rows + p.next_dst[tloc[t]];
+      for (int r = 0; r < 16; ++r) {
+        const float d = acc[i][r] - mu;
+        sq += d * d;
+      }
+    sq += __shfl_xor(sq, 32);
+    const float rs = rsqrtf(sq / (float)C + p.eps);
+    float mu_n = mu;
+    asm volatile("" : "+v"(mu_n));
+    if (live) {
+      const long drow = (long)tb * p.next_rows + p.next_dst[tloc];
       uint16_t* o = p.next_ln + (size_t)drow * C + 4 * h;
 #pragma unroll
       for (int i = 0; i < CM; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(p.nn_w + 32 * i + 8 * q + 4 * h);
-          const f32x4 be = *reinterpret_cast<const f32x4*>(p.nn_b + 32 * i + 8 * q + 4 * h);
+          const f32x4 g = *reinterpret_cast<const f32x4*>(s_nn + 32 * i + 8 * q + 4 * h);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(s_nn + C + 32 * i + 8 * q + 4 * h);
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (acc[t][i][4 * q + e] - mu) * rs * g[e] + be[e];
+          for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mu_n) * rs * g[e] + be[e];
           *reinterpret_cast<u32x2*>(o + 32 * i + 8 * q) = (u32x2){E::pack2(y[0], y[1]), E::pack2(y[2], y[3])};
+          if (q & 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
   }
+#ifdef KVQ_TAIL_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tr) {
+    p.trace[blockIdx.x * 8 + 5] = wait_dma;
+    p.trace[blockIdx.x * 8 + 6] = wait_bar;
+  }
+#endif
+  KVQ_STAMP(4);
 }
 
-template <typename E, int CM, int TN>
+template <typename E, int CM, int NW>
 static int launch_tail(const TailParams& p, hipStream_t st) {
   constexpr int C = 32 * CM;
-  const size_t lds = (size_t)TAIL_NST * tail_slot_bytes(C) + tail_param_bytes(C, p.hidden);
-  KVQ_REQUIRE(lds <= 80 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
-  dim3 grid((unsigned)ceil_div(p.M, 128 * TN)), block(256);
+  const size_t lds = (size_t)tail_ring(C, NW) * tail_slot_bytes(C) +
+                     ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
+  KVQ_REQUIRE(lds <= (size_t)163840 / tail_bpc(C, NW), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
+  dim3 grid((unsigned)ceil_div(p.M, 32 * NW)), block(64 * NW);
   if (p.next_ln) {
-    auto k = block_tail_kernel<E, CM, TN, true>;
+    auto k = block_tail_kernel<E, CM, NW, true>;
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, block, lds, st, p);
   } else {
-    auto k = block_tail_kernel<E, CM, TN, false>;
+    auto k = block_tail_kernel<E, CM, NW, false>;
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, block, lds, st, p);
   }
@@ -372,10 +462,17 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
 
 template <typename E>
 static int launch_tail_e(const TailParams& p, int C, hipStream_t st) {
+  static const int nw_env = getenv("KVQ_TAIL_NW") ? atoi(getenv("KVQ_TAIL_NW")) : 4;   // experiments: waves per workgroup
   switch (C) {
-    case 96: return launch_tail<E, 3, 2>(p, st);
-    case 128: return launch_tail<E, 4, 1>(p, st);
-    case 192: return launch_tail<E, 6, 1>(p, st);
+    case 96:
+      if (nw_env == 12) return launch_tail<E, 3, 12>(p, st);
+      return launch_tail<E, 3, 4>(p, st);
+    case 128:
+      if (nw_env == 8) return launch_tail<E, 4, 8>(p, st);
+      return launch_tail<E, 4, 4>(p, st);
+    case 192:
+      if (nw_env == 8) return launch_tail<E, 6, 8>(p, st);
+      return launch_tail<E, 6, 4>(p, st);
     default: break;
   }
   KVQ_REQUIRE(false, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d not in {96,128,192}", C);
@@ -384,7 +481,8 @@ static int launch_tail_e(const TailParams& p, int C, hipStream_t st) {
 }  // namespace kvq
 
 extern "C" int kvq_block_tail_supported(int C, int hidden) {
-  return (C == 96 || C == 128 || C == 192) && hidden % 32 == 0 && hidden > 0 ? 1 : 0;
+  // hidden/32 even and >= 4: the MLP pipeline rotates two accumulators
+  return (C == 96 || C == 128 || C == 192) && hidden % 64 == 0 && hidden >= 128 ? 1 : 0;
 }
 
 extern "C" size_t kvq_block_tail_pack_bytes(int C, int hidden) {
@@ -422,7 +520,7 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   p.attn = (const uint16_t*)a->attn; p.x = a->x; p.map = a->scatter_map; p.map_rows = a->map_rows; p.out_rows = a->out_rows;
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
-  p.next_rows = a->next_rows; p.eps = a->eps;
+  p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;
   return a->dtype == KVQ_DT_FP16 ? launch_tail_e<Fp16>(p, a->C, (hipStream_t)stream)
                                  : launch_tail_e<Bf16>(p, a->C, (hipStream_t)stream);
 }

@@ -12,6 +12,7 @@ state_dict keys are the reference's, including the
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -111,7 +112,6 @@ class SwinTransformer3D(nn.Module):
         super().__init__()
         # 16-bit MFMA operand type (extension over the reference signature): "fp16" (default; holds the
         # 1e-3 MOS parity gate) or "bf16".  Env KVQ_OPERAND_DTYPE overrides the default.
-        import os
         self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
         # proj+norm2+Mlp as one launch where the width allows it (C <= 192); KVQ_FUSED_TAIL=0 keeps the GEMM chain
         self.fused_tail = os.environ.get("KVQ_FUSED_TAIL", "1") != "0"
@@ -335,7 +335,8 @@ class SwinTransformer3D(nn.Module):
                 sym = "layernorm_rows_kernel"
             elif kind == "tail":
                 cm = r.variant // 10
-                sym = f"block_tail_kernel<{ename}, {cm}, {2 if cm == 3 else 1}, {str(bool(r.variant % 10)).lower()}>"
+                nw = os.environ.get("KVQ_TAIL_NW") or 4
+                sym = f"block_tail_kernel<{ename}, {cm}, {nw}, {str(bool(r.variant % 10)).lower()}>"
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
