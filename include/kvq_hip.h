@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 3
+#define KVQ_ABI_VERSION 4
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -90,6 +90,10 @@ typedef struct {
   const void* tail_pack;   /* optional, derived: kvq_block_tail_pack image of (proj, norm2, fc1, fc2).  Non-NULL (and
                               C in {96,128,192}) -> proj+residual+norm2+Mlp+residual run as ONE launch
                               (kvq_block_tail); NULL -> GEMM/LayerNorm launches */
+  const void* bias_dense;  /* optional, derived, valid ONLY with the plan it was built for
+                              (kvq_swin3d_bias_dense_build): the block's attention bias per (window, head), gate,
+                              shift mask and padding included.  Non-NULL -> kvq_window_attention_dense; NULL -> the
+                              bias is rebuilt per score from the tables (kvq_window_attention) */
 } KvqSwinBlockW;
 
 typedef struct {            /* PatchMerging (swin_backbone.py:527-531) */
@@ -129,6 +133,12 @@ int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
  * When score != NULL the VQAHead (models/head.py:60-68) is applied too (see kvq_vqa_head). */
 int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, float* feat,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Dense attention bias of weights->blocks[block] for this plan's geometry (see kvq_attn_bias_dense_build): size
+ * and builder.  Independent of the batch size; rebuild when the block's tables change. */
+size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* plan, int block);
+int kvq_swin3d_bias_dense_build(const KvqSwinPlan* plan, int block, const float* rpb_table, const float* fpb_table,
+                                void* out, void* stream);
 
 /* Per-kernel-class GPU time of the most recent profiled forward.  Profiling brackets every
  * launch with hipEvents on the launch stream; enable with kvq_swin3d_profile(plan, 1). */
@@ -244,6 +254,18 @@ int kvq_block_tail(const KvqBlockTailArgs* host_args, void* stream);
 int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* rpb, const float* fpb,
                          const float* bias_pack, int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
                          int dtype, uint16_t* out, void* stream);
+
+/* The same attention with the bias PRE-BUILT per (window, head): bias[w][h][i][j] = what kvq_window_attention
+ * rebuilds per score (table gather, fragment gate, -100 shift mask), fp32, stored in the kernel's MFMA accumulator
+ * layout [nW][nH][ceil(N/16)][26][64 lanes][4]; keys >= N hold -60000.  A q-tile loads its bias tiles straight into
+ * the score accumulators: no per-score VALU or LDS work is left besides max / exp / pack.  4 B per score of HBM/L2
+ * traffic, shared by all clips of a step.
+ *   tok, rpb, fpb, table_len, center, use_mask: as kvq_window_attention (fpb NULL = no gate). */
+size_t kvq_attn_bias_dense_bytes(int nW, int N, int num_heads);
+int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center, int nW,
+                              int N, int num_heads, int use_mask, void* out, void* stream);
+int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int BW, int nW, int N, int num_heads,
+                               int dtype, uint16_t* out, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

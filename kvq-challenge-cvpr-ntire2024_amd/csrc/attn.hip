@@ -21,6 +21,8 @@
 //     rounded probabilities that multiply V, and lands in the O layout (no shuffles to normalise).
 // The kernel is VALU-bound (bias/mask/exp per score), so the per-score instruction count is what
 // matters: gate = one v_sad_u8, bias = one fma on a (fpb, rpb-fpb) table, table address = one v_sub.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace kvq {
@@ -308,4 +310,261 @@ extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, con
   if (gated) return launch_attn<Bf16, true, false>(p, lds, st);
   if (mask) return launch_attn<Bf16, false, true>(p, lds, st);
   return launch_attn<Bf16, false, false>(p, lds, st);
+}
+
+// ================================================================================================================
+// Dense-bias variant.  The gather path above spends ~half of its VALU issue slots and most of its LDS traffic on
+// REBUILDING the bias per score (descriptor reads, table gather, gate, mask select).  The bias of a (window, head)
+// depends only on the block's tables and the window's position in the clip, not on the clip: it is built once per
+// weight set by bias_dense_kernel and streamed from HBM/L2 (4 B per score) while the kernel is compute-bound.
+//   * layout [window][head][q-tile][key-tile][lane][4 x fp32] = the C operand of the score MFMA: a q-tile starts
+//     by loading its 26 bias tiles STRAIGHT INTO the score accumulators (26 independent 16-B loads in flight per
+//     lane, no staging registers, no LDS), the MFMAs then add K Q^T on top as the tiles arrive;
+//   * the -100 shift mask and the "key >= N" exclusion (-60000: exp2 underflows to exactly 0) are baked in, so
+//     there is one instantiation per operand type instead of gated x masked x full.
+namespace kvq {
+
+constexpr float ATT_DENSE_OFF = -60000.0f;
+constexpr int ATT_D_OFF_CTR = ATT_OFF_VT + ATT_VT_BYTES;
+constexpr int ATT_D_LDS = ATT_D_OFF_CTR + 16;
+
+struct DenseBuildParams {
+  const int32_t* tok;
+  const float* rpb;
+  const float* fpb;
+  int table_len, center, nW, N, nH, use_mask;
+  float* out;
+};
+
+__global__ __launch_bounds__(64) void bias_dense_kernel(DenseBuildParams p) {
+  const int nqt = (p.N + 15) >> 4;
+  const int qt = blockIdx.x / ATT_NT, t = blockIdx.x % ATT_NT, h = blockIdx.y, w = blockIdx.z;
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  const int q = 16 * qt + j;
+  f32x4 v;
+  int2 tq = make_int2(0, 0);
+  if (q < p.N) tq = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + q) * 2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = 32 * (t >> 1) + 4 * (t & 1) + 8 * g + r;     // this lane's keys of score tile t (header)
+    float b = 0.f;
+    if (key >= p.N) {
+      b = ATT_DENSE_OFF;
+    } else if (q < p.N) {
+      const int2 tk = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + key) * 2);
+      const int idx = tq.x - tk.x + p.center;
+      const float rr = p.rpb[(size_t)idx * p.nH + h];
+      b = rr;
+      if (p.fpb) {                      // exactly the gather path's arithmetic: f + g * (r - f), one fma
+        const float f = p.fpb[(size_t)idx * p.nH + h];
+        const float gate = (float)__builtin_amdgcn_sad_u8((unsigned)(tq.y & 0xffff), (unsigned)(tk.y & 0xffff), 0u);
+        b = fmaf(gate, rr - f, f);
+      }
+      if (p.use_mask && ((tq.y >> 16) & 0xff) != ((tk.y >> 16) & 0xff)) b = -100.0f;
+    }
+    v[r] = b;
+  }
+  *reinterpret_cast<f32x4*>(p.out + ((((size_t)w * p.nH + h) * nqt + qt) * ATT_NT + t) * 256 + lane * 4) = v;
+}
+
+struct AttnDenseParams {
+  const uint16_t* qkv;
+  const f32x4* dense;
+  int BW, nW, N, nH;
+  int qsplit;                  // workgroups per (window, head, clip): each takes a contiguous share of the q-tiles
+  uint16_t* out;
+  unsigned long long* trace;   // -DKVQ_ATT_TRACE builds only
+  int trace_blocks;
+};
+
+template <typename E>
+__global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kernel(AttnDenseParams p) {   // 3 x 52 KB LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* Ks = reinterpret_cast<u32x4*>(smem);
+  uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + ATT_OFF_VT);
+  int* ticket = reinterpret_cast<int*>(smem + ATT_D_OFF_CTR);
+  using V8 = typename E::v8;
+
+  // Block order: the nclip workgroups that share one (window, head) bias run on the SAME XCD (workgroup b -> XCD
+  // b % 8, each XCD has its own L2) back to back, so the bias is fetched from HBM once per step, not once per clip.
+  // Small grids (late stages: few windows) split a unit's q-tiles over qsplit workgroups, each staging K/V again.
+  const int nclip = p.BW / p.nW, npair = p.nW * p.nH, per_pair = nclip * p.qsplit;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pair = (slot / per_pair) * 8 + xcd, sub = slot % per_pair, clip = sub % nclip, part = sub / nclip;
+  if (pair >= npair) return;
+  const int w = pair / p.nH, h = pair - w * p.nH, bw = clip * p.nW + w;
+  const int tid = threadIdx.x, N = p.N;
+#ifdef KVQ_ATT_TRACE
+  const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
+  unsigned long long t_s = 0, t_x = 0, t_pv = 0, t_mark = 0;
+  if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
+#define ATT_MARK(acc) { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - t_mark; t_mark = n_; }
+#else
+#define ATT_MARK(acc)
+#endif
+  const size_t Mtot = (size_t)p.BW * N;
+  const int C = p.nH * 32;
+  const uint16_t* Qg = p.qkv + ((size_t)(0 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
+  const uint16_t* Kg = p.qkv + ((size_t)(1 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
+  const uint16_t* Vg = p.qkv + ((size_t)(2 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
+
+  for (int c = tid; c < ATT_KROWS * 4; c += ATT_WAVES * 64) {
+    const int row = c >> 2, g = c & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < N) v = *reinterpret_cast<const u32x4*>(Kg + (size_t)row * 32 + g * 8);
+    Ks[k_slot(row, g)] = v;
+  }
+  for (int c = tid; c < ATT_VPITCH * 4; c += ATT_WAVES * 64) {
+    const int key = c >> 2, g = c & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (key < N) v = *reinterpret_cast<const u32x4*>(Vg + (size_t)key * 32 + g * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Vt[(g * 8 + 2 * i) * ATT_VPITCH + key] = (uint16_t)(v[i] & 0xffffu);
+      Vt[(g * 8 + 2 * i + 1) * ATT_VPITCH + key] = (uint16_t)(v[i] >> 16);
+    }
+  }
+  if (tid < 32) Vt[32 * ATT_VPITCH + tid] = 0;
+  const int nqt = (N + 15) >> 4;
+  const int q_lo = part * nqt / p.qsplit, q_hi = (part + 1) * nqt / p.qsplit;
+  if (tid == 0) *ticket = q_lo;
+  __syncthreads();
+#ifdef KVQ_ATT_TRACE
+  t_mark = __builtin_readcyclecounter();
+  if (tr) p.trace[blockIdx.x * 8 + 1] = t_mark;
+#endif
+
+  const int lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const float kLog2e = 1.4426950408889634f;
+  const uint32_t one2 = (uint32_t)E::cvt(1.0f) * 0x10001u;
+  const V8 ones = __builtin_bit_cast(V8, (u32x4){one2, one2, one2, one2});
+  const f32x4* dense = p.dense + (size_t)pair * nqt * ATT_NT * 64 + lane;
+
+  while (true) {
+    int qt = 0;
+    if (lane == 0) qt = atomicAdd(ticket, 1);
+    qt = __builtin_amdgcn_readfirstlane(qt);
+    if (qt >= q_hi) break;
+    const int q0 = qt * 16;
+    const int qrow = min(q0 + j, N - 1);
+    const V8 qf = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + g * 8);
+    const f32x4* bd = dense + (size_t)qt * ATT_NT * 64;
+    f32x4 S[ATT_NT];
+#pragma unroll
+    for (int t = 0; t < ATT_NT; ++t) S[t] = bd[t * 64];      // the bias tiles, straight into the accumulators
+#define ATT_KEY0(t) (32 * ((t) >> 1) + 4 * ((t) & 1))
+    const int krow0 = 8 * (j >> 2) + (j & 3);
+    V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(0) + krow0, g)]), kfN = kfC;
+#pragma unroll
+    for (int t = 0; t < ATT_NT; ++t) {
+      if (t + 1 < ATT_NT) kfN = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(t + 1 < ATT_NT ? t + 1 : 0) + krow0, g)]);
+      S[t] = E::mfma16(kfC, qf, S[t]);
+      kfC = kfN;
+    }
+#undef ATT_KEY0
+    ATT_MARK(t_s);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < ATT_NT; ++t) mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mb = mx * kLog2e;
+    uint32_t P[ATT_NT][2];
+#pragma unroll
+    for (int t = 0; t < ATT_NT; ++t) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(S[t][r], kLog2e, -mb));
+      P[t][0] = E::pack2_raw(e[0], e[1]);
+      P[t][1] = E::pack2_raw(e[2], e[3]);
+    }
+    ATT_MARK(t_x);
+    f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f}, Ls = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < ATT_NT / 2; ++s) {
+      const u32x4 pa = {P[2 * s][0], P[2 * s][1], P[2 * s + 1][0], P[2 * s + 1][1]};
+      const V8 pf = __builtin_bit_cast(V8, pa);
+      const V8 v0 = *reinterpret_cast<const V8*>(Vt + j * ATT_VPITCH + 32 * s + 8 * g);
+      const V8 v1 = *reinterpret_cast<const V8*>(Vt + (j + 16) * ATT_VPITCH + 32 * s + 8 * g);
+      O0 = E::mfma16(pf, v0, O0);
+      O1 = E::mfma16(pf, v1, O1);
+      Ls = E::mfma16(pf, ones, Ls);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = 4 * g + r;
+      const float inv = 1.0f / Ls[r];
+      if (q0 + qq < N) {
+        uint16_t* o = p.out + ((size_t)bw * N + q0 + qq) * C + h * 32 + j;
+        o[0] = E::cvt(O0[r] * inv);
+        o[16] = E::cvt(O1[r] * inv);
+      }
+    }
+    ATT_MARK(t_pv);
+  }
+#ifdef KVQ_ATT_TRACE
+  if (tr) {
+    __builtin_amdgcn_s_waitcnt(0);
+    p.trace[blockIdx.x * 8 + 2] = __builtin_readcyclecounter();
+    p.trace[blockIdx.x * 8 + 3] = t_s;
+    p.trace[blockIdx.x * 8 + 4] = t_x;
+    p.trace[blockIdx.x * 8 + 5] = t_pv;
+  }
+#endif
+}
+
+template <typename E>
+static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
+  auto kern = window_attention_dense_kernel<E>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      ATT_D_LDS));
+    attr_set = true;
+  }
+  const int nclip = p.BW / p.nW, npair = p.nW * p.nH;
+  dim3 grid((unsigned)(8 * ceil_div(npair, 8) * nclip * p.qsplit)), block(ATT_WAVES * 64);
+  hipLaunchKernelGGL(kern, grid, block, ATT_D_LDS, st, p);
+  KVQ_CHECK_LAUNCH("window_attention_dense_kernel");
+  return KVQ_OK;
+}
+
+}  // namespace kvq
+
+extern "C" size_t kvq_attn_bias_dense_bytes(int nW, int N, int num_heads) {
+  if (nW <= 0 || N < 1 || N > 400 || num_heads <= 0) return 0;
+  return (size_t)nW * num_heads * ((N + 15) / 16) * kvq::ATT_NT * 1024;
+}
+
+extern "C" int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
+                                         int nW, int N, int num_heads, int use_mask, void* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(tok && rpb && out, KVQ_ERR_NULL, "kvq_attn_bias_dense_build: NULL pointer");
+  KVQ_REQUIRE(kvq_attn_bias_dense_bytes(nW, N, num_heads) > 0 && table_len > 0, KVQ_ERR_SHAPE,
+              "kvq_attn_bias_dense_build: bad shape nW=%d N=%d nH=%d", nW, N, num_heads);
+  DenseBuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (float*)out};
+  dim3 grid((unsigned)(((N + 15) / 16) * ATT_NT), (unsigned)num_heads, (unsigned)nW), block(64);
+  hipLaunchKernelGGL(bias_dense_kernel, grid, block, 0, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("bias_dense_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int BW, int nW, int N, int num_heads,
+                                          int dtype, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(qkv && bias_dense && out, KVQ_ERR_NULL, "kvq_window_attention_dense: NULL pointer");
+  KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0, KVQ_ERR_SHAPE,
+              "kvq_window_attention_dense: bad shape BW=%d nW=%d nH=%d", BW, nW, num_heads);
+  KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: window of %d tokens unsupported (1..400)", N);
+  KVQ_REQUIRE(((size_t)bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_dense: bias_dense must be 16-byte aligned");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: dtype %d", dtype);
+  // 768 = 256 CUs x 3 resident workgroups: fill them when there are fewer (window, head, clip) units than that
+  const int units = BW * num_heads, nqt = (N + 15) / 16;
+  int qsplit = units >= 768 ? 1 : 768 / units;
+  qsplit = qsplit > 4 ? 4 : qsplit;
+  qsplit = qsplit > nqt ? nqt : qsplit;
+  if (getenv("KVQ_ATT_QSPLIT")) qsplit = atoi(getenv("KVQ_ATT_QSPLIT"));
+  AttnDenseParams p{qkv, (const f32x4*)bias_dense, BW, nW, N, num_heads, qsplit, out, g_trace, g_trace_blocks};
+  return dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16>(p, (hipStream_t)stream) : launch_attn_dense<Bf16>(p, (hipStream_t)stream);
 }

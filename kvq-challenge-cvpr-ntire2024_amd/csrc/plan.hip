@@ -227,6 +227,41 @@ extern "C" int kvq_swin3d_out_dims(const KvqSwinPlan* pl, int32_t out4[4]) {
   return KVQ_OK;
 }
 
+namespace kvq {
+// stage / parity of weights->blocks[block]
+static bool locate_block(const KvqSwinPlan* pl, int block, int* stage, int* par) {
+  int k = 0;
+  for (int i = 0; i < pl->cfg.num_stages; ++i) {
+    const StageGeom& g = pl->st[i];
+    if (block < k + g.depth) {
+      *stage = i;
+      *par = ((block - k) & 1) && g.shifted_any ? 1 : 0;
+      return block >= k;
+    }
+    k += g.depth;
+  }
+  return false;
+}
+}  // namespace kvq
+
+extern "C" size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* pl, int block) {
+  int i = 0, par = 0;
+  if (!pl || !kvq::locate_block(pl, block, &i, &par)) return 0;
+  const kvq::StageGeom& g = pl->st[i];
+  return kvq_attn_bias_dense_bytes(g.nW, g.N, g.nH);
+}
+
+extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, const float* rpb, const float* fpb, void* out,
+                                           void* stream) {
+  using namespace kvq;
+  int i = 0, par = 0;
+  KVQ_REQUIRE(pl && rpb && out, KVQ_ERR_NULL, "kvq_swin3d_bias_dense_build: NULL pointer");
+  KVQ_REQUIRE(locate_block(pl, block, &i, &par), KVQ_ERR_SHAPE, "kvq_swin3d_bias_dense_build: no block %d", block);
+  const StageGeom& g = pl->st[i];
+  return kvq_attn_bias_dense_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
+                                   g.nW, g.N, g.nH, par, out, stream);
+}
+
 extern "C" int kvq_swin3d_profile(KvqSwinPlan* pl, int enable) {
   using namespace kvq;
   KVQ_REQUIRE(pl, KVQ_ERR_NULL, "kvq_swin3d_profile: NULL");
@@ -357,7 +392,12 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
       ln1_ready = false;
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                    0.17677669529663687f /* 32^-0.5 */));
-      {
+      if (bw.bias_dense) {
+        // + the dense bias once per step: 4 B per score of every (window, head)
+        Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C,
+                   2.0 * 4.0 * M * C + (double)kvq_attn_bias_dense_bytes(g.nW, g.N, g.nH));
+        KVQ_TRY(kvq_window_attention_dense(bbig, bw.bias_dense, B * g.nW, g.nW, g.N, g.nH, pl->dtype, bo, st));
+      } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);
         KVQ_TRY(kvq_window_attention(bbig, g.d_tok[par], bw.rpb_table, cfg.frag_bias[i] ? bw.fpb_table : nullptr,

@@ -115,6 +115,11 @@ class SwinTransformer3D(nn.Module):
         self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
         # proj+norm2+Mlp as one launch where the width allows it (C <= 192); KVQ_FUSED_TAIL=0 keeps the GEMM chain
         self.fused_tail = os.environ.get("KVQ_FUSED_TAIL", "1") != "0"
+        # attention bias pre-built per (window, head) for each plan geometry (csrc/attn.hip, dense variant): ~1.2 GB of
+        # HBM for Swin-T at 32x224x224; KVQ_DENSE_BIAS=0 (or a geometry above the cap) keeps the per-score gather path
+        self.dense_bias = os.environ.get("KVQ_DENSE_BIAS", "1") != "0"
+        self.dense_bias_max_bytes = int(float(os.environ.get("KVQ_DENSE_BIAS_MAX_GB", "8")) * 2 ** 30)
+        self._dense = {}
         if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
             raise NotImplementedError("per-stage window sizes are not used by any reference config")
         if qk_scale is not None or any(jump_attention) or not qkv_bias:
@@ -265,8 +270,36 @@ class SwinTransformer3D(nn.Module):
         w.blocks = C.cast(blocks, C.POINTER(KvqSwinBlockW))
         w.norm_w, w.norm_b = f32(self.norm.weight), f32(self.norm.bias)
         keep.append(blocks)
-        self._wcache = (sig, w, keep)
+        self._wcache = (sig, w, keep, blocks)
+        self._dense = {}                     # built from the old tables
+        torch.cuda.synchronize(device)       # the packs were built on THIS stream; other streams may run the forward
         return w
+
+    def _set_dense_bias(self, handle, geom, device):
+        """Point every block at the dense attention bias of this plan geometry (built on first use)."""
+        blocks = self._wcache[3]
+        nblk = sum(self.depths)
+        if not self.dense_bias:
+            for k in range(nblk):
+                blocks[k].bias_dense = None
+            return
+        key = geom + (str(device), self.operand_dtype)
+        bufs = self._dense.get(key)
+        if bufs is None:
+            sizes = [lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk)]
+            if sum(sizes) > self.dense_bias_max_bytes or not all(sizes):
+                bufs = [None] * nblk
+            else:
+                bufs = []
+                for k in range(nblk):
+                    t = torch.empty(sizes[k], dtype=torch.uint8, device=device)
+                    check(lib().kvq_swin3d_bias_dense_build(handle, k, blocks[k].rpb_table, blocks[k].fpb_table, ptr(t),
+                                                            current_stream()), "kvq_swin3d_bias_dense_build")
+                    bufs.append(t)
+                torch.cuda.synchronize(device)
+            self._dense[key] = bufs
+        for k in range(nblk):
+            blocks[k].bias_dense = ptr(bufs[k])
 
     def _plan(self, B, T, H, W, device):
         # one plan + workspace per (shape, stream): forwards issued on different streams may overlap
@@ -305,6 +338,7 @@ class SwinTransformer3D(nn.Module):
         B, _, T, H, W = x.shape
         handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device)
         w = self._weights(x.device)
+        self._set_dense_bias(handle, (T, H, W), x.device)
         feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
         check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), current_stream()),
               "kvq_swin3d_forward")
@@ -329,6 +363,8 @@ class SwinTransformer3D(nn.Module):
                 tile, epi = divmod(r.variant, 10)
                 mi, bk = divmod(tile, 100)
                 sym = f"gemm_kernel<{ename}, {mi}, {mi}, {bk}, {epi}>"
+            elif kind == "attn" and r.variant >= 4:
+                sym = f"window_attention_dense_kernel<{ename}>"
             elif kind == "attn":
                 sym = f"window_attention_kernel<{ename}, {str(bool(r.variant & 2)).lower()}, {str(bool(r.variant & 1)).lower()}>"
             elif kind == "layernorm":

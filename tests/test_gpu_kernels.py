@@ -239,6 +239,59 @@ def test_window_attention_softmax_extremes(half):
     assert (out - ref).abs().max().item() <= 6.4 * EPS[half]
 
 
+@pytest.mark.parametrize("dims,window,shifted,gated,nH", [
+    ((8, 14, 14), (8, 7, 7), False, True, 3),
+    ((8, 14, 14), (8, 7, 7), True, True, 3),
+    ((16, 7, 7), (8, 7, 7), True, False, 2),
+    ((4, 10, 9), (8, 7, 7), True, True, 1),
+    ((8, 8, 8), (4, 4, 4), True, False, 2),
+])
+def test_window_attention_dense_matches_gather_path(dims, window, shifted, gated, nH, half):
+    """Pre-built fp32 bias loaded into the score accumulators, against the oracle AND against the per-score gather
+    kernel (same arithmetic per score: only the rounding of the 16-bit output may differ)."""
+    g = rng(sum(dims) + nH + 100)
+    shift = tuple(w // 2 for w in window) if shifted else (0, 0, 0)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, B = lay["N"], lay["nW"], 3
+    BW = B * nW
+    tl = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+    q = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)) * 0.6, half)
+    k = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)), half)
+    v = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)), half)
+    rpb = torch.from_numpy(g.standard_normal((tl, nH)).astype(np.float32))
+    fpb = torch.from_numpy(g.standard_normal((tl, nH)).astype(np.float32)) if gated else None
+    ref = O.attention_core(q, k, v, rpb, fpb, window, lay).reshape(BW * N, nH * 32)
+    tok, center = _tok_table(lay, window)
+    qkv = dev(torch.stack([q, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, BW * N, 32).contiguous(), half)
+    use_mask = any(s > 0 for s in lay["ss"])
+    tokd, rpbd, fpbd = dev(torch.from_numpy(tok)), dev(rpb), None if fpb is None else dev(fpb)
+    dense = kernels.attn_bias_dense(tokd, rpbd, fpbd, center, nW, N, use_mask)
+    out = kernels.window_attention_dense(qkv, dense, nW, N).float().cpu()
+    assert (out - ref).abs().max().item() <= 6.4 * EPS[half]
+    assert (out - ref).abs().mean().item() <= 0.5 * EPS[half]
+    gather = kernels.window_attention(qkv, tokd, rpbd, fpbd, center, nW, N, use_mask).float().cpu()
+    assert (out - gather).abs().max().item() <= 4.1 * EPS[half]      # at most a flipped last bit of the 16-bit output
+
+
+def test_window_attention_dense_softmax_extremes(half):
+    g = rng(4)
+    lay = O.window_layout(8, 14, 14, (8, 7, 7), (4, 3, 3))
+    N, nW, nH = lay["N"], lay["nW"], 1
+    q = torch.zeros(nW, nH, N, 32)
+    k = torch.zeros(nW, nH, N, 32)
+    q[:, :, :, 0] = 16.0
+    k[:, :, 17, 0] = 6.0
+    v = rnd(torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32)), half)
+    rpb = torch.zeros(2535, 1)
+    ref = O.attention_core(q, k, v, rpb, None, (8, 7, 7), lay).reshape(nW * N, 32)
+    tok, center = _tok_table(lay, (8, 7, 7))
+    qkv = torch.stack([q, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, nW * N, 32).contiguous()
+    dense = kernels.attn_bias_dense(dev(torch.from_numpy(tok)), dev(rpb), None, center, nW, N, True)
+    out = kernels.window_attention_dense(dev(qkv, half), dense, nW, N).float().cpu()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 6.4 * EPS[half]
+
+
 def test_window_attention_rejects_large_window():
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.window_attention(torch.zeros(3, 1, 512, 32, dtype=torch.float16, device=DEV),
