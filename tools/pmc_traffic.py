@@ -14,7 +14,8 @@ def sym(name):
     name = re.sub(r"^void\s+", "", name)
     name = re.sub(r"\(.*$", "", name)
     return name.replace("kvq::window_attention", "window_attention").replace("kvq::gemm_kernel", "gemm_kernel") \
-               .replace("kvq::layernorm_rows_kernel", "layernorm_rows_kernel").replace("kvq::patch_im2col_kernel", "patch_im2col_kernel")
+               .replace("kvq::layernorm_rows_kernel", "layernorm_rows_kernel").replace("kvq::patch_im2col_kernel", "patch_im2col_kernel") \
+               .replace("kvq::block_tail_kernel", "block_tail_kernel")
 
 
 def agg(path, counter):
@@ -28,7 +29,7 @@ def agg(path, counter):
 f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in f:
-    if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "patch_im2col")):
+    if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "patch_im2col", "block_tail")):
         continue
     fb = 2.0 * 1024.0 * sum(f[k]) / len(f[k])
     wb = 1024.0 * sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
@@ -42,5 +43,5 @@ for k in f:
     e["write_bytes"] = (e["write_bytes"] * e["launches"] + wb * n) / (e["launches"] + n)
     e["launches"] += n
 json.dump({"note": "avg HBM bytes per launch over one B=4 fp16 step mix; FETCH_SIZE x2 (gfx950 correction), "
-                   "separate --pmc passes (r01d build)", "kernels": out}, open("profiles/pmc_traffic.json", "w"), indent=1)
+                   "separate --pmc passes (r01g build)", "kernels": out}, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])
