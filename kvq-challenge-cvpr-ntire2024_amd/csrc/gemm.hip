@@ -40,7 +40,10 @@ struct GemmParams {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
-#define KVQ_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void gemm_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // K loop: an NST-deep LDS ring of BK=32 slices filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane,
 // no VGPR round trip, no ds_write), NST-1 slices in flight while one is multiplied.  The waits are COUNTED
@@ -132,11 +135,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     // slice kt must have landed; up to two younger slices stay in flight
     const int younger = nk - 1 - kt;
     if (NST > 3 && younger >= 2) {
-      if (NL == 4) KVQ_WAIT_VMCNT(8); else KVQ_WAIT_VMCNT(4);
+      gemm_wait_vmcnt<2 * NL>();
     } else if (younger >= 1) {
-      if (NL == 4) KVQ_WAIT_VMCNT(4); else KVQ_WAIT_VMCNT(2);
+      gemm_wait_vmcnt<NL>();
     } else {
-      KVQ_WAIT_VMCNT(0);
+      gemm_wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     if (tr && kt == 0) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
@@ -302,17 +305,30 @@ static int launch_one(const GemmParams& p, hipStream_t st) {
   return KVQ_OK;
 }
 
+// tile (MI, NI) for a shape, encoded (10*MI + NI)*100 + BK
 int gemm_variant(int M, int N, int K) {
+  static const int forced = getenv("KVQ_GEMM_TILE") ? atoi(getenv("KVQ_GEMM_TILE")) : 0;   // experiments: 22 | 21 | 12 | 11
+  if (forced) return forced * 100 + 32;
+  // Measured per shape of the trunk (B = 4 clips, us: 128x128 / 128x64 / 64x64): fc2 stage 2 (K = 1536) 36.7 / 41.4 /
+  // 44.3 although 128x128 makes only 294 workgroups; qkv stage 3 25.6 / 31.0 / 35.1 (450 workgroups); proj stage 2
+  // (K = 384, epilogue-dominated) 25.0 / 21.3 / 20.2; merge stage 0 (N = 192 = 1.5 tiles of 128) 28.0 / 24.7 / 28.1.
+  // => the big tile whenever the K loop is long or it still fills the chip; 64-wide columns when the last
+  // 128-column tile would be at most half used.
   const long blocks128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-  const bool big = blocks128 >= 512;     // >= 2 tiles per CU: use the 128x128 tile
-  return (big ? 2 : 1) * 100 + 32;
+  const bool big = blocks128 >= 400 || K >= 1024 || (blocks128 >= 256 && K >= 768);
+  if (!big) return 11 * 100 + 32;
+  const int rem = N % 128;
+  return ((rem != 0 && rem <= 64) ? 21 : 22) * 100 + 32;
 }
 
 template <typename E, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t st) {
-  const int var = gemm_variant(p.M, p.N, p.K);
-  const bool big = var / 100 == 2;
-  return big ? launch_one<E, 2, 2, 32, EPI>(p, st) : launch_one<E, 1, 1, 32, EPI>(p, st);
+  switch (gemm_variant(p.M, p.N, p.K) / 100) {
+    case 22: return launch_one<E, 2, 2, 32, EPI>(p, st);
+    case 21: return launch_one<E, 2, 1, 32, EPI>(p, st);
+    case 12: return launch_one<E, 1, 2, 32, EPI>(p, st);
+    default: return launch_one<E, 1, 1, 32, EPI>(p, st);
+  }
 }
 
 template <int EPI>

@@ -361,8 +361,8 @@ class SwinTransformer3D(nn.Module):
             kind = _abi.K_NAMES[r.kind]
             if kind.startswith("gemm"):
                 tile, epi = divmod(r.variant, 10)
-                mi, bk = divmod(tile, 100)
-                sym = f"gemm_kernel<{ename}, {mi}, {mi}, {bk}, {epi}>"
+                mn, bk = divmod(tile, 100)
+                sym = f"gemm_kernel<{ename}, {mn // 10}, {mn % 10}, {bk}, {epi}>"
             elif kind == "attn" and r.variant >= 4:
                 sym = f"window_attention_dense_kernel<{ename}>"
             elif kind == "attn":
