@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 4
+#define KVQ_ABI_VERSION 5
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -107,6 +107,8 @@ typedef struct {
   const float* embed_b;     /* [E] */
   const float* embed_ln_w;  /* patch_embed.norm */
   const float* embed_ln_b;
+  const void* embed_pack;   /* optional, derived: kvq_patch_embed_pack image; non-NULL (and a fused shape, see
+                               kvq_patch_embed_supported) -> im2col + GEMM + LayerNorm run as ONE launch */
   const KvqSwinBlockW* blocks; /* host array, sum(depths) entries, stage-major */
   KvqSwinMergeW merges[KVQ_MAX_STAGES - 1];
   const float* norm_w;      /* final LayerNorm [C_out] */
@@ -144,7 +146,7 @@ int kvq_swin3d_bias_dense_build(const KvqSwinPlan* plan, int block, const float*
  * launch with hipEvents on the launch stream; enable with kvq_swin3d_profile(plan, 1). */
 enum {
   KVQ_K_IM2COL = 0, KVQ_K_LAYERNORM, KVQ_K_GEMM_QKV, KVQ_K_ATTN, KVQ_K_GEMM_PROJ, KVQ_K_GEMM_FC1,
-  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_TAIL, KVQ_K_COUNT
+  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_TAIL, KVQ_K_EMBED, KVQ_K_COUNT
 };
 typedef struct {
   int32_t kind;     /* KVQ_K_*                                                                    */
@@ -211,6 +213,32 @@ int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
  * dev_buf[8*b + {0:start, 1:first slice landed, 2:K loop done, 3:epilogue done}] (shader clock) and
  * [4] = XCC id << 32 | HW_ID.  Pass NULL to switch it off. */
 int kvq_debug_gemm_trace(void* dev_buf, int max_blocks);
+
+/* PatchEmbed3D (swin_backbone.py:715-733) as one launch, token-per-lane MFMA (csrc/embed.hip): the strided
+ * Conv3d reads its patches straight from the clip (no im2col buffer), + bias + LayerNorm(E), optionally + the
+ * first block's norm1 in its window order.  Fused shape: patch (pd,4,4), in_chans*pd == 6, E in {96,128}, clip
+ * dimensions multiples of the patch (anything else takes the im2col + GEMM + LayerNorm launches). */
+typedef struct {
+  const float* x;              /* fp32 (B, in_chans, T, H, W)                                           */
+  int32_t B, in_chans, T, H, W;
+  int32_t pd, ph, pw, embed_dim;
+  const void* pack;            /* kvq_patch_embed_pack image                                            */
+  int32_t has_norm;            /* patch_embed.norm present (the image carries identity vectors if not)  */
+  float* out;                  /* fp32 [B*D0*H0*W0][E]                                                  */
+  const float* next_norm_w;    /* the following four: only with next_ln != NULL                         */
+  const float* next_norm_b;
+  const int32_t* next_dst;     /* token -> row of the first block's window order (no padding)           */
+  void* next_ln;               /* 16-bit [B*next_rows][E]                                               */
+  int32_t next_rows;
+  float eps;
+  int32_t dtype;
+} KvqPatchEmbedArgs;
+int kvq_patch_embed_supported(int in_chans, int pd, int ph, int pw, int embed_dim, int T, int H, int W);
+size_t kvq_patch_embed_pack_bytes(int embed_dim, int K);
+/* w: 16-bit [E][K = in_chans*pd*ph*pw] (Conv3d weight order); ln_w / ln_b may be NULL (no norm). */
+int kvq_patch_embed_pack(const void* w, const float* bias, const float* ln_w, const float* ln_b, int embed_dim, int K,
+                         void* pack, void* stream);
+int kvq_patch_embed(const KvqPatchEmbedArgs* host_args, void* stream);
 
 /* Fused post-attention half of SwinTransformerBlock3D, one launch, token-per-lane MFMA (csrc/tail.hip):
  *   x <- x + window_reverse(roll(proj(attn)))        (swin_backbone.py:323, :472-488, :509)

@@ -14,12 +14,12 @@ from . import _build
 
 MAX_STAGES = 4
 K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "gemm_fc2", "gemm_merge",
-           "gemm_embed", "tail"]
+           "gemm_embed", "tail", "embed"]
 K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16 = range(6)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def dtype_code(dt) -> int:
@@ -58,7 +58,7 @@ class KvqSwinMergeW(C.Structure):
 
 class KvqSwinWeights(C.Structure):
     _fields_ = [("embed_w", p_void), ("embed_b", p_void), ("embed_ln_w", p_void), ("embed_ln_b", p_void),
-                ("blocks", C.POINTER(KvqSwinBlockW)), ("merges", KvqSwinMergeW * (MAX_STAGES - 1)),
+                ("embed_pack", p_void), ("blocks", C.POINTER(KvqSwinBlockW)), ("merges", KvqSwinMergeW * (MAX_STAGES - 1)),
                 ("norm_w", p_void), ("norm_b", p_void)]
 
 
@@ -74,6 +74,14 @@ class KvqBlockTailArgs(C.Structure):
                 ("out_rows", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("pack", p_void),
                 ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void),
                 ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
+
+
+class KvqPatchEmbedArgs(C.Structure):
+    _fields_ = [("x", p_void), ("B", C.c_int32), ("in_chans", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32), ("embed_dim", C.c_int32),
+                ("pack", p_void), ("has_norm", C.c_int32), ("out", p_void), ("next_norm_w", p_void),
+                ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void), ("next_rows", C.c_int32),
+                ("eps", C.c_float), ("dtype", C.c_int32)]
 
 
 class KvqProfRecord(C.Structure):
@@ -98,6 +106,10 @@ SYMBOLS = {
                                  p_void]),
     "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
     "kvq_debug_gemm_trace": (i32, [p_void, i32]),
+    "kvq_patch_embed_supported": (i32, [i32] * 8),
+    "kvq_patch_embed_pack_bytes": (sz, [i32, i32]),
+    "kvq_patch_embed_pack": (i32, [p_void, p_void, p_void, p_void, i32, i32, p_void, p_void]),
+    "kvq_patch_embed": (i32, [C.POINTER(KvqPatchEmbedArgs), p_void]),
     "kvq_block_tail_supported": (i32, [i32, i32]),
     "kvq_block_tail_pack_bytes": (sz, [i32, i32]),
     "kvq_block_tail_pack": (i32, [p_void, p_void, p_void, p_void, p_void, p_void, p_void, p_void, i32, i32, p_void,

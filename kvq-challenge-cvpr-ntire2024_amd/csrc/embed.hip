@@ -1,0 +1,227 @@
+// PatchEmbed3D as ONE launch (gfx950): strided Conv3d k = s = (pd,4,4) + bias + LayerNorm(E)
+// (swin_backbone.py:715-733) [+ norm1 + pad/roll/window_partition of the first block, :416-449].
+//
+// Token-per-lane, like csrc/tail.hip: Out^T[E][32 tokens] = W[E][K] * patch^T[K][32 tokens] with the weights as the
+// MFMA A operand (fragment-major in LDS) and the tokens as the 32 columns of v_mfma_f32_32x32x16.  The B operand is
+// read STRAIGHT from the clip: k = (c, kd, kh, kw) with ph*pw = 16, so k-step s is the (c, kd) plane and lane half
+// h takes patch rows 2h, 2h+1 — two 16-B loads (4 fp32 pixels each) that are contiguous across the 32 lanes of a
+// token row.  No im2col buffer, no separate LayerNorm launch: the clip is read once (4 B/pixel) and the residual
+// stream written once, instead of im2col (write 2 B/px) + GEMM (read 2, write 4·E/K) + LayerNorm (read/write 4·E/K).
+#include "common.hpp"
+
+namespace kvq {
+
+struct EmbedParams {
+  const float* x;            // (B, Cin, T, H, W)
+  int B, Cin, T, H, W, pd, D0, H0, W0;
+  const unsigned char* pack; // kvq_patch_embed_pack image
+  int has_ln;                // patch_embed.norm present
+  float* out;                // [B*L0][E] fp32
+  const float* nn_w;         // first block's norm1 (EMIT)
+  const float* nn_b;
+  const int32_t* next_dst;   // token -> window row
+  uint16_t* next_ln;         // [B*next_rows][E]
+  int next_rows;
+  float eps;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+// image: CM panels [KS frag rows][64 lanes][8 x 16-bit] with W[32i+m][16s + 8h + e] (k in Conv3d weight order
+// c, kd, kh, kw), then fp32 [bias E][ln_w E][ln_b E]
+__global__ void embed_pack_kernel(const uint16_t* w, const float* bias, const float* lnw, const float* lnb, int E, int K,
+                                  unsigned char* out, long n_chunks) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int KS = K / 16;
+  if (g < n_chunks) {
+    const int panel = (int)(g / (KS * 64)), rem = (int)(g % (KS * 64));
+    const int s = rem >> 6, lane = rem & 63, m = lane & 31, h = lane >> 5;
+    uint16_t* o = reinterpret_cast<uint16_t*>(out + g * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = w[(size_t)(32 * panel + m) * K + 16 * s + 8 * h + e];
+  } else if (g < n_chunks + 3 * E) {
+    const int q = (int)(g - n_chunks);
+    const float v = q < E ? bias[q] : (q < 2 * E ? (lnw ? lnw[q - E] : 1.f) : (lnb ? lnb[q - 2 * E] : 0.f));
+    reinterpret_cast<float*>(out + n_chunks * 16)[q] = v;
+  }
+}
+
+template <typename E_, int CM, int KS, bool EMIT>
+__global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
+  constexpr int E = 32 * CM, WBYTES = CM * KS * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using V8 = typename E_::v8;
+  float* prm = reinterpret_cast<float*>(lds + WBYTES);       // [bias][ln_w][ln_b][nn_w][nn_b]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  f32x4 nn_reg = {0.f, 0.f, 0.f, 0.f};
+  if (EMIT && tid < E / 2) nn_reg = *reinterpret_cast<const f32x4*>((tid < E / 4 ? p.nn_w : p.nn_b - E) + 4 * tid);
+  constexpr int NQ = (WBYTES + 3 * E * 4 + 1023) / 1024;     // weights + parameters, 1 KB wave-loads
+  for (int q = wave; q < NQ; q += 4)
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.pack + q * 1024 + lane * 16), (lds_ptr_t)(lds + q * 1024), 16, 0, 0);
+
+  // this lane's token and its patch rows
+  const long L0 = (long)p.D0 * p.H0 * p.W0, total = (long)p.B * L0;
+  const long row = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const long rc = row < total ? row : total - 1;
+  const int b = (int)(rc / L0);
+  const int tl = (int)(rc - (long)b * L0);
+  const int d = tl / (p.H0 * p.W0), hw = tl - d * (p.H0 * p.W0), hh = hw / p.W0, ww = hw - hh * p.W0;
+  const bool live = row < total;
+  V8 bx[KS];
+  {
+    const size_t plane = (size_t)p.H * p.W;
+    const float* base = p.x + (size_t)b * p.Cin * p.T * plane + (size_t)(d * p.pd) * plane + (size_t)(hh * 4 + 2 * h) * p.W + ww * 4;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = s / p.pd, kd = s - c * p.pd;       // pd is small; KS = Cin*pd is a compile-time count
+      const float* src = base + ((size_t)c * p.T + kd) * plane;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(src);
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(src + p.W);
+      const u32x4 w = {E_::pack2(r0[0], r0[1]), E_::pack2(r0[2], r0[3]), E_::pack2(r1[0], r1[1]), E_::pack2(r1[2], r1[3])};
+      bx[s] = __builtin_bit_cast(V8, w);
+    }
+  }
+  float* s_nn = reinterpret_cast<float*>(lds + NQ * 1024);    // past the DMA image (its last KB is padding)
+  if (EMIT && tid < E / 2) *reinterpret_cast<f32x4*>(s_nn + 4 * tid) = nn_reg;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 acc[CM];
+#pragma unroll
+  for (int i = 0; i < CM; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(prm + 32 * i + 8 * q + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = bq[e];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const V8 a = *reinterpret_cast<const V8*>(lds + (i * KS + s) * 1024 + lane * 16);
+      acc[i] = E_::mfma32(a, bx[s], acc[i]);
+    }
+  }
+
+  // LayerNorm over the E channels of a token: in-lane sums + one exchange with lane^32 (two-pass, as ln.hip)
+  auto stats = [&](float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) s += (acc[i][r] + acc[i][r + 1]) + (acc[i][r + 2] + acc[i][r + 3]);
+    s += __shfl_xor(s, 32);
+    mean = s / (float)E;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dd = acc[i][r] - mean;
+        sq += dd * dd;
+      }
+    sq += __shfl_xor(sq, 32);
+    rstd = rsqrtf(sq / (float)E + p.eps);
+    asm volatile("" : "+v"(mean));     // opaque: no CSE of (acc - mean) between the variance and the normalise pass
+  };
+  if (p.has_ln) {
+    float mean, rstd;
+    stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(prm + E + 32 * i + 8 * q + 4 * h);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(prm + 2 * E + 32 * i + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = (acc[i][4 * q + e] - mean) * rstd * g[e] + be[e];
+      }
+  }
+  if (live) {
+    float* o = p.out + (size_t)rc * E + 4 * h;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(o + 32 * i + 8 * q) =
+            (f32x4){acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+  }
+  if (EMIT) {
+    float mean, rstd;
+    stats(mean, rstd);
+    if (live) {
+      const long drow = (long)b * p.next_rows + p.next_dst[tl];
+      uint16_t* o = p.next_ln + (size_t)drow * E + 4 * h;
+#pragma unroll
+      for (int i = 0; i < CM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(s_nn + 32 * i + 8 * q + 4 * h);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(s_nn + E + 32 * i + 8 * q + 4 * h);
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mean) * rstd * g[e] + be[e];
+          *reinterpret_cast<u32x2*>(o + 32 * i + 8 * q) = (u32x2){E_::pack2(y[0], y[1]), E_::pack2(y[2], y[3])};
+        }
+    }
+  }
+}
+
+template <typename E_, int CM, int KS>
+static int launch_embed(const EmbedParams& p, hipStream_t st) {
+  const size_t lds = (size_t)CM * KS * 1024 + (size_t)5 * 32 * CM * 4 + 1024;
+  const long total = (long)p.B * p.D0 * p.H0 * p.W0;
+  dim3 grid((unsigned)((total + 127) / 128)), block(256);
+  if (p.next_ln) hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, true>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, false>), grid, block, lds, st, p);
+  KVQ_CHECK_LAUNCH("patch_embed_kernel");
+  return KVQ_OK;
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_patch_embed_supported(int in_chans, int pd, int ph, int pw, int embed_dim, int T, int H, int W) {
+  // one (c, kd) plane per MFMA k-step; no padded edge (the im2col path pads)
+  return ph == 4 && pw == 4 && in_chans * pd == 6 && (embed_dim == 96 || embed_dim == 128) && T % pd == 0 && H % 4 == 0 &&
+                 W % 4 == 0 ? 1 : 0;
+}
+
+extern "C" size_t kvq_patch_embed_pack_bytes(int embed_dim, int K) {
+  if (embed_dim % 32 || K % 16) return 0;
+  return (((size_t)embed_dim * K * 2 + (size_t)3 * embed_dim * 4) + 1023) & ~(size_t)1023;
+}
+
+extern "C" int kvq_patch_embed_pack(const void* w, const float* bias, const float* ln_w, const float* ln_b, int embed_dim, int K,
+                                    void* pack, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(w && bias && pack, KVQ_ERR_NULL, "kvq_patch_embed_pack: NULL pointer");
+  KVQ_REQUIRE(kvq_patch_embed_pack_bytes(embed_dim, K) > 0, KVQ_ERR_UNSUPPORTED, "kvq_patch_embed_pack: E=%d K=%d", embed_dim, K);
+  const long n_chunks = (long)embed_dim * K * 2 / 16, total = n_chunks + 3 * embed_dim;
+  hipLaunchKernelGGL(embed_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)w, bias, ln_w, ln_b, embed_dim, K, (unsigned char*)pack, n_chunks);
+  KVQ_CHECK_LAUNCH("embed_pack_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_patch_embed(const KvqPatchEmbedArgs* a, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(a && a->x && a->pack && a->out, KVQ_ERR_NULL, "kvq_patch_embed: NULL pointer");
+  KVQ_REQUIRE(kvq_patch_embed_supported(a->in_chans, a->pd, a->ph, a->pw, a->embed_dim, a->T, a->H, a->W), KVQ_ERR_UNSUPPORTED,
+              "kvq_patch_embed: patch (%d,%d,%d) x %d channels -> %d on %dx%dx%d is not the fused shape", a->pd, a->ph, a->pw,
+              a->in_chans, a->embed_dim, a->T, a->H, a->W);
+  KVQ_REQUIRE(a->B > 0, KVQ_ERR_SHAPE, "kvq_patch_embed: B=%d", a->B);
+  KVQ_REQUIRE(!a->next_ln || (a->next_norm_w && a->next_norm_b && a->next_dst && a->next_rows > 0), KVQ_ERR_NULL,
+              "kvq_patch_embed: next_ln without its norm / map");
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_patch_embed: dtype %d", a->dtype);
+  EmbedParams p{};
+  p.x = a->x; p.B = a->B; p.Cin = a->in_chans; p.T = a->T; p.H = a->H; p.W = a->W; p.pd = a->pd;
+  p.D0 = a->T / a->pd; p.H0 = a->H / 4; p.W0 = a->W / 4;
+  p.pack = (const unsigned char*)a->pack; p.has_ln = a->has_norm; p.out = a->out; p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b;
+  p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln; p.next_rows = a->next_rows; p.eps = a->eps;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->embed_dim == 96)
+    return a->dtype == KVQ_DT_FP16 ? launch_embed<Fp16, 3, 6>(p, st) : launch_embed<Bf16, 3, 6>(p, st);
+  return a->dtype == KVQ_DT_FP16 ? launch_embed<Fp16, 4, 6>(p, st) : launch_embed<Bf16, 4, 6>(p, st);
+}

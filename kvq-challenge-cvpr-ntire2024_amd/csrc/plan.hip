@@ -359,29 +359,47 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
   uint16_t* bo = (uint16_t*)(ws + pl->off_o);
   pl->ev_used = pl->profile ? pl->ev_used : 0;
 
-  // ---- PatchEmbed3D: im2col -> GEMM(+bias) -> LayerNorm  (swin_backbone.py:715-733) ----
+  // ---- PatchEmbed3D (swin_backbone.py:715-733): one fused launch, or im2col -> GEMM(+bias) -> LayerNorm ----
   const int L0 = pl->D0 * pl->H0 * pl->W0, E = cfg.embed_dim;
-  {
-    const double px = (double)B * pl->D0 * pl->H0 * pl->W0 * pl->K0;
-    Bracket br(pl, st, KVQ_K_IM2COL, 0, 0.0, px * 6.0);
-    KVQ_TRY(kvq_patch_im2col(x, B, cfg.in_chans, pl->T, pl->H, pl->W, cfg.patch[0], cfg.patch[1], cfg.patch[2], pl->dtype,
-                             bbig, st));
-  }
-  KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_EMBED, bbig, w->embed_w, w->embed_b, B * L0, E, pl->K0, KVQ_EPI_STORE_F32, nullptr,
-               xb));
   float* cur = xa;
   float* oth = xb;
-  if (w->embed_ln_w) {
-    KVQ_TRY(ln(pl, st, xb, nullptr, 1, L0, L0, E, w->embed_ln_w, w->embed_ln_b, nullptr, xa));
+  bool first_ln1_ready = false;
+  if (w->embed_pack && kvq_patch_embed_supported(cfg.in_chans, cfg.patch[0], cfg.patch[1], cfg.patch[2], E, pl->T, pl->H, pl->W)) {
+    KvqPatchEmbedArgs ea{};
+    ea.x = x; ea.B = B; ea.in_chans = cfg.in_chans; ea.T = pl->T; ea.H = pl->H; ea.W = pl->W;
+    ea.pd = cfg.patch[0]; ea.ph = cfg.patch[1]; ea.pw = cfg.patch[2]; ea.embed_dim = E; ea.pack = w->embed_pack;
+    ea.has_norm = w->embed_ln_w ? 1 : 0; ea.out = xa; ea.eps = 1e-5f; ea.dtype = pl->dtype;
+    const StageGeom& g0 = pl->st[0];
+    if (g0.d_dst[0] && w->blocks[0].norm1_w && w->blocks[0].norm1_b) {     // + norm1 / partition of the first block
+      ea.next_norm_w = w->blocks[0].norm1_w; ea.next_norm_b = w->blocks[0].norm1_b; ea.next_dst = g0.d_dst[0];
+      ea.next_ln = bln; ea.next_rows = g0.Lp;
+      first_ln1_ready = true;
+    }
+    const double px = (double)B * L0 * pl->K0;
+    Bracket br(pl, st, KVQ_K_EMBED, first_ln1_ready ? 1 : 0, 2.0 * B * L0 * (double)E * pl->K0,
+               px * 4.0 + (double)B * L0 * E * (4.0 + (first_ln1_ready ? 2.0 : 0.0)));
+    KVQ_TRY(kvq_patch_embed(&ea, st));
   } else {
-    cur = xb; oth = xa;
+    {
+      const double px = (double)B * pl->D0 * pl->H0 * pl->W0 * pl->K0;
+      Bracket br(pl, st, KVQ_K_IM2COL, 0, 0.0, px * 6.0);
+      KVQ_TRY(kvq_patch_im2col(x, B, cfg.in_chans, pl->T, pl->H, pl->W, cfg.patch[0], cfg.patch[1], cfg.patch[2], pl->dtype,
+                               bbig, st));
+    }
+    KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_EMBED, bbig, w->embed_w, w->embed_b, B * L0, E, pl->K0, KVQ_EPI_STORE_F32, nullptr,
+                 xb));
+    if (w->embed_ln_w) {
+      KVQ_TRY(ln(pl, st, xb, nullptr, 1, L0, L0, E, w->embed_ln_w, w->embed_ln_b, nullptr, xa));
+    } else {
+      cur = xb; oth = xa;
+    }
   }
 
   int blk = 0;
   for (int i = 0; i < cfg.num_stages; ++i) {
     const StageGeom& g = pl->st[i];
     const int C = g.C, M = B * g.Lp, ML = B * g.L;
-    bool ln1_ready = false;   // the previous block's tail already wrote this block's norm1 rows
+    bool ln1_ready = i == 0 && first_ln1_ready;   // the producer (embed / previous tail) already wrote this block's norm1 rows
     for (int b = 0; b < g.depth; ++b, ++blk) {
       const KvqSwinBlockW& bw = w->blocks[blk];
       KVQ_REQUIRE(bw.norm1_w && bw.rpb_table && bw.qkv_w && bw.proj_w && bw.fc1_w && bw.fc2_w, KVQ_ERR_NULL,

@@ -293,3 +293,31 @@ def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: 
                                                                             ptr(next_dst), ptr(nxt), next_rows)
     check(lib().kvq_block_tail(C.byref(a), current_stream()), "kvq_block_tail")
     return nxt
+
+
+def patch_embed(x: torch.Tensor, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, next_dst=None, next_rows=0,
+                eps=1e-5):
+    """PatchEmbed3D as one launch: x fp32 (B,Cin,T,H,W), w 16-bit [E][Cin*pd*ph*pw] -> fp32 [B*D0*H0*W0, E]
+    (+ the first block's norm1 rows when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
+    _need_gpu(x, w, bias, ln_w, ln_b, next_dst)
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype in HALF_TYPES and w.is_contiguous()
+    B, Cin, T, H, W = x.shape
+    pd, ph, pw = patch
+    Ed, K = w.shape
+    if not lib().kvq_patch_embed_supported(Cin, pd, ph, pw, Ed, T, H, W):
+        raise _abi.KvqError("kvq_patch_embed: unsupported shape (use patch_im2col + gemm + layernorm_rows)")
+    pack = torch.empty(lib().kvq_patch_embed_pack_bytes(Ed, K), dtype=torch.uint8, device=x.device)
+    check(lib().kvq_patch_embed_pack(ptr(w), ptr(bias), ptr(ln_w), ptr(ln_b), Ed, K, ptr(pack), current_stream()),
+          "kvq_patch_embed_pack")
+    L0 = (T // pd) * (H // ph) * (W // pw)
+    out = torch.empty(B * L0, Ed, dtype=torch.float32, device=x.device)
+    a = _abi.KvqPatchEmbedArgs()
+    a.x, a.B, a.in_chans, a.T, a.H, a.W, a.pd, a.ph, a.pw, a.embed_dim = ptr(x), B, Cin, T, H, W, pd, ph, pw, Ed
+    a.pack, a.has_norm, a.out, a.eps, a.dtype = ptr(pack), int(ln_w is not None), ptr(out), eps, dtype_code(w.dtype)
+    nxt = None
+    if next_norm is not None:
+        nxt = torch.empty(B * next_rows, Ed, dtype=w.dtype, device=x.device)
+        a.next_norm_w, a.next_norm_b, a.next_dst, a.next_ln, a.next_rows = (ptr(next_norm[0]), ptr(next_norm[1]),
+                                                                            ptr(next_dst), ptr(nxt), next_rows)
+    check(lib().kvq_patch_embed(C.byref(a), current_stream()), "kvq_patch_embed")
+    return out, nxt

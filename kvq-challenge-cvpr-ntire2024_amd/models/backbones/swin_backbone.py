@@ -228,6 +228,14 @@ class SwinTransformer3D(nn.Module):
         w.embed_b = f32(pe.proj.bias)
         if pe.norm is not None:
             w.embed_ln_w, w.embed_ln_b = f32(pe.norm.weight), f32(pe.norm.bias)
+        K0 = pe.proj.weight[0].numel()
+        nbytes = lib().kvq_patch_embed_pack_bytes(self.embed_dim, K0) if self.fused_tail else 0
+        if nbytes:          # im2col + GEMM + LayerNorm (+ the first norm1) as one launch (csrc/embed.hip)
+            ep = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(lib().kvq_patch_embed_pack(w.embed_w, w.embed_b, w.embed_ln_w, w.embed_ln_b, self.embed_dim, K0, ptr(ep),
+                                             current_stream()), "kvq_patch_embed_pack")
+            keep.append(ep)
+            w.embed_pack = ptr(ep)
         nblk = sum(self.depths)
         blocks = (KvqSwinBlockW * nblk)()
         k = 0
@@ -369,6 +377,8 @@ class SwinTransformer3D(nn.Module):
                 sym = f"window_attention_kernel<{ename}, {str(bool(r.variant & 2)).lower()}, {str(bool(r.variant & 1)).lower()}>"
             elif kind == "layernorm":
                 sym = "layernorm_rows_kernel"
+            elif kind == "embed":
+                sym = f"patch_embed_kernel<{ename}, {self.embed_dim // 32}, 6, {str(bool(r.variant)).lower()}>"
             elif kind == "tail":
                 cm = r.variant // 10
                 nw = os.environ.get("KVQ_TAIL_NW") or 4

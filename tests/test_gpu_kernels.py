@@ -436,3 +436,47 @@ def test_block_tail_identity_map_and_unsupported(half):
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.block_tail_pack(*(dev(torch.zeros(s), half if len(s) == 2 else None) for s in
                                   [(384, 384), (384,), (384,), (384,), (1536, 384), (1536,), (384, 1536), (384,)]))
+
+
+# ------------------------------------------------------------------ fused PatchEmbed3D (embed.hip)
+@pytest.mark.parametrize("shape,E,with_ln,emit", [((2, 3, 8, 56, 56), 96, True, True), ((1, 3, 6, 28, 44), 96, True, False),
+                                                 ((2, 3, 4, 28, 56), 128, False, True)])
+def test_patch_embed_fused(shape, E, with_ln, emit, half):
+    """conv3d(k=s=(2,4,4)) + bias + LayerNorm [+ norm1 of the first block in window order] against torch fp32 with the
+    operand roundings of the launch (pixels and weights to 16 bits)."""
+    g = rng(sum(shape) + E)
+    B, Cin, T, H, W = shape
+    x = torch.from_numpy((g.standard_normal(shape) * 1.5).astype(np.float32))
+    w = rnd(torch.from_numpy((g.standard_normal((E, Cin, 2, 4, 4)) * 0.1).astype(np.float32)), half)
+    b = torch.from_numpy((g.standard_normal(E) * 0.2).astype(np.float32))
+    lw = torch.from_numpy((1 + 0.2 * g.standard_normal(E)).astype(np.float32)) if with_ln else None
+    lb = torch.from_numpy((0.2 * g.standard_normal(E)).astype(np.float32)) if with_ln else None
+    y = torch.nn.functional.conv3d(rnd(x, half), w, b, stride=(2, 4, 4)).permute(0, 2, 3, 4, 1)     # (B,D,H0,W0,E)
+    if with_ln:
+        y = torch.nn.functional.layer_norm(y, (E,), lw, lb)
+    D, H0, W0 = y.shape[1:4]
+    kw = {}
+    if emit:
+        lay = O.window_layout(D, H0, W0, (8, 7, 7), (0, 0, 0))
+        if (lay["src"] < 0).any():
+            pytest.skip("padded layout: the plan keeps the separate norm1 launch")
+        L = D * H0 * W0
+        dst = np.empty(L, np.int32)
+        dst[lay["src"]] = np.arange(L, dtype=np.int32)
+        gn = torch.from_numpy((1 + 0.2 * g.standard_normal(E)).astype(np.float32))
+        bn = torch.from_numpy((0.2 * g.standard_normal(E)).astype(np.float32))
+        kw = dict(next_norm=(dev(gn), dev(bn)), next_dst=dev(torch.from_numpy(dst)), next_rows=L)
+    out, nxt = kernels.patch_embed(dev(x), dev(w.reshape(E, -1), half), dev(b), None if lw is None else dev(lw),
+                                   None if lb is None else dev(lb), (2, 4, 4), **kw)
+    ref = y.reshape(-1, E)
+    assert (out.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    if emit:
+        ln = torch.nn.functional.layer_norm(out.cpu(), (E,), gn, bn).reshape(B, D, H0, W0, E)
+        ref_ln = O.gather_windows(ln, lay).reshape(-1, E)
+        assert (nxt.float().cpu() - ref_ln).abs().max().item() <= 2 * EPS[half] * ref_ln.abs().max().item() + 1e-5
+
+
+def test_patch_embed_fused_rejects_padded_clip():
+    with pytest.raises(_abi.KvqError, match="unsupported"):
+        kernels.patch_embed(torch.zeros(1, 3, 7, 30, 27, device=DEV), torch.zeros(96, 96, dtype=torch.float16, device=DEV),
+                            torch.zeros(96, device=DEV), None, None, (2, 4, 4))
