@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
 
 template <typename E, int G, int NV>
 static int launch_ln_e(const LnParams& p, hipStream_t st) {
-  constexpr int R = NV <= 1 ? 4 : (NV <= 2 ? 2 : 1);       // ~4 float4 loads in flight per lane; more only adds VGPRs
+  constexpr int R = NV <= 1 ? 4 : (NV <= 3 ? 2 : 1);       // 4-6 float4 loads in flight per lane; more only adds VGPRs
   const long total = (long)p.n_batch * p.rows_out;
   const int rows_per_block = (256 / G) * R;
   dim3 grid((unsigned)((total + rows_per_block - 1) / rows_per_block)), block(256);
@@ -135,6 +135,11 @@ extern "C" int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts
   LnParams p{x, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_h, out_f32};
   hipStream_t st = (hipStream_t)stream;
   const int nvec = C / 4;
+  // widths of the form 3 * 2^k (C = 96, 192, 384, 768, 1536) split exactly into G lanes x 3 (x 6) float4: no idle lanes
+  if (nvec == 24) return launch_ln<8, 3>(p, dtype, st);
+  if (nvec == 48) return launch_ln<16, 3>(p, dtype, st);
+  if (nvec == 96) return launch_ln<32, 3>(p, dtype, st);
+  if (nvec == 384) return launch_ln<64, 6>(p, dtype, st);
   if (nvec <= 16) return launch_ln<16, 1>(p, dtype, st);
   if (nvec <= 32) return launch_ln<32, 1>(p, dtype, st);
   if (nvec <= 64) return launch_ln<64, 1>(p, dtype, st);

@@ -45,18 +45,20 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
 // 256-B row per channel; the token's feature value is a wave-uniform (broadcast) load.  A wave carries
 // HEAD_TOK tokens to amortise the W1 stream (L2-resident, 196 KB); one shuffle reduction per token.
 // ------------------------------------------------------------------------------------------------
-constexpr int HEAD_TOK = 2;
+constexpr int HEAD_TOK = 4;
 
+// One workgroup = HEAD_TOK tokens; its 4 waves split the CHANNELS (the reduction dimension) in four, so the
+// dependent chain of W1-row loads per wave is C/4/16 steps instead of C/8 (the kernel is L2-latency bound: 96
+// serial steps cost 52 us for 0.3 GFLOP), and the partial sums meet in LDS.
 __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __restrict__ feat, int B, int L, int C,
                                                              long sb, long sl, long sc, const float* __restrict__ w1t,
                                                              const float* __restrict__ b1, int hidden,
                                                              const float* __restrict__ w2,
                                                              float* __restrict__ tok_score) {
-  const int lane = threadIdx.x & 63;
-  const long wave_id = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long tok0 = wave_id * HEAD_TOK;
+  __shared__ float part[4][HEAD_TOK][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tok0 = (long)blockIdx.x * HEAD_TOK;
   const long total = (long)B * L;
-  if (tok0 >= total) return;
   const float* row[HEAD_TOK];
 #pragma unroll
   for (int t = 0; t < HEAD_TOK; ++t) {
@@ -64,6 +66,8 @@ __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __rest
     const long b = tk / L, l = tk - b * L;
     row[t] = feat + b * sb + l * sl;
   }
+  const int cq = ((C + 3) / 4 + 7) & ~7;                    // channels per wave, a multiple of 8
+  const int c_lo = min(wave * cq, C), c_hi = min(c_lo + cq, C);
   float acc[HEAD_TOK];
 #pragma unroll
   for (int t = 0; t < HEAD_TOK; ++t) acc[t] = 0.f;
@@ -74,35 +78,70 @@ __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __rest
     float d[HEAD_TOK];
 #pragma unroll
     for (int t = 0; t < HEAD_TOK; ++t) d[t] = 0.f;
-    if (sc == 1 && (C & 7) == 0) {
-      // channels-last features: 8 channels per step, the 8 W1 rows and the tokens' float4 pairs are all
-      // independent loads (16 in flight per wave) — this loop is L2-latency bound, not bandwidth bound
-      for (int c0 = 0; c0 < C; c0 += 8) {
-        float wv[8];
+    if (sc == 1 && (C & 7) == 0 && (hidden & 3) == 0) {
+      // channels-last features.  4-B loads are instruction-bound (256 B per wave-load), so the wave is re-shaped for
+      // this loop: lane = (hidden quad hq = lane & 15, channel quad cg = lane >> 4); a step covers 16 channels with
+      // 16-B loads of W1^T rows and of the tokens, 64 fma per lane; the four channel quads meet by two shuffles.
+      const int hq = lane & 15, cg = lane >> 4;
+      const int jq = min(j0 + 4 * hq, hidden - 4);
+      float dq[HEAD_TOK][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wv[k] = w1t[(size_t)(c0 + k) * hidden + jc];
+      for (int t = 0; t < HEAD_TOK; ++t)
 #pragma unroll
-        for (int t = 0; t < HEAD_TOK; ++t) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(row[t] + c0);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(row[t] + c0 + 4);
+        for (int k = 0; k < 4; ++k) dq[t][k] = 0.f;
+      for (int c0 = c_lo + 4 * cg; c0 < c_hi; c0 += 16) {      // c_lo, c_hi are multiples of 8: a quad is all in or out
+        f32x4 wq[4], xv[HEAD_TOK];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) d[t] = fmaf(a[k], wv[k], d[t]);
+        for (int k = 0; k < 4; ++k) wq[k] = *reinterpret_cast<const f32x4*>(w1t + (size_t)(c0 + k) * hidden + jq);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) d[t] = fmaf(b[k], wv[4 + k], d[t]);
+        for (int t = 0; t < HEAD_TOK; ++t) xv[t] = *reinterpret_cast<const f32x4*>(row[t] + c0);
+#pragma unroll
+        for (int t = 0; t < HEAD_TOK; ++t)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dq[t][e] = fmaf(xv[t][k], wq[k][e], dq[t][e]);
+      }
+      // lane j of the common layout needs hidden unit j0 + lane: sum the channel quads, then pick element lane & 3 of
+      // hidden quad lane >> 2
+#pragma unroll
+      for (int t = 0; t < HEAD_TOK; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = dq[t][e];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          dq[t][e] = v;
         }
+        const int srcl = lane >> 2;                            // the lane (hq = lane>>2, cg = 0) holds the quad
+        const float q0 = __shfl(dq[t][0], srcl), q1 = __shfl(dq[t][1], srcl), q2 = __shfl(dq[t][2], srcl),
+                    q3 = __shfl(dq[t][3], srcl);
+        const int e = lane & 3;
+        const float mine = e == 0 ? q0 : (e == 1 ? q1 : (e == 2 ? q2 : q3));
+        d[t] = mine;        // live lanes (j < hidden, hidden % 4 == 0) never see a clamped quad
       }
     } else {
 #pragma unroll 4
-      for (int c = 0; c < C; ++c) {
+      for (int c = c_lo; c < c_hi; ++c) {
         const float wv = w1t[(size_t)c * hidden + jc];
 #pragma unroll
         for (int t = 0; t < HEAD_TOK; ++t) d[t] = fmaf(row[t][c * sc], wv, d[t]);
       }
     }
-    const float bj = b1[jc], wj = live ? w2[jc] : 0.f;
+    __syncthreads();                                         // previous j0 round consumed
 #pragma unroll
-    for (int t = 0; t < HEAD_TOK; ++t) acc[t] = fmaf(wj, gelu_erf(d[t] + bj), acc[t]);
+    for (int t = 0; t < HEAD_TOK; ++t) part[wave][t][lane] = d[t];
+    __syncthreads();
+    if (wave == 0) {
+      const float bj = b1[jc], wj = live ? w2[jc] : 0.f;
+#pragma unroll
+      for (int t = 0; t < HEAD_TOK; ++t) {
+        const float full = (part[0][t][lane] + part[1][t][lane]) + (part[2][t][lane] + part[3][t][lane]);
+        acc[t] = fmaf(wj, gelu_erf(full + bj), acc[t]);
+      }
+    }
   }
+  if (wave != 0) return;
 #pragma unroll
   for (int t = 0; t < HEAD_TOK; ++t) {
 #pragma unroll
@@ -294,8 +333,7 @@ extern "C" int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stri
   using namespace kvq;
   KVQ_REQUIRE(feat && w1t && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head: NULL pointer");
   KVQ_REQUIRE(B > 0 && L > 0 && C > 0 && hidden > 0, KVQ_ERR_SHAPE, "kvq_vqa_head: bad shape");
-  const long waves = ((long)B * L + HEAD_TOK - 1) / HEAD_TOK;
-  const int grid = (int)((waves + 3) / 4);
+  const int grid = (int)(((long)B * L + HEAD_TOK - 1) / HEAD_TOK);
   hipLaunchKernelGGL(vqa_head_token_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, B, L, C,
                      (long)stride_b, (long)stride_l, (long)stride_c, w1t, b1, hidden, w2, scratch);
   KVQ_CHECK_LAUNCH("vqa_head_token_kernel");
