@@ -118,7 +118,8 @@ class SwinTransformer3D(nn.Module):
         # attention bias pre-built per (window, head) for each plan geometry (csrc/attn.hip, dense variant): ~1.2 GB of
         # HBM for Swin-T at 32x224x224; KVQ_DENSE_BIAS=0 (or a geometry above the cap) keeps the per-score gather path
         self.dense_bias = os.environ.get("KVQ_DENSE_BIAS", "1") != "0"
-        self.dense_bias_max_bytes = int(float(os.environ.get("KVQ_DENSE_BIAS_MAX_GB", "8")) * 2 ** 30)
+        self.dense_bias_max_bytes = int(float(os.environ.get("KVQ_DENSE_BIAS_MAX_GB", "24")) * 2 ** 30)
+        self.dense_bias_bytes_per_clip = int(float(os.environ.get("KVQ_DENSE_BIAS_GB_PER_CLIP", "0.5")) * 2 ** 30)
         self._dense = {}
         if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
             raise NotImplementedError("per-stage window sizes are not used by any reference config")
@@ -283,11 +284,14 @@ class SwinTransformer3D(nn.Module):
         torch.cuda.synchronize(device)       # the packs were built on THIS stream; other streams may run the forward
         return w
 
-    def _set_dense_bias(self, handle, geom, device):
-        """Point every block at the dense attention bias of this plan geometry (built on first use)."""
+    def _set_dense_bias(self, handle, geom, device, batch):
+        """Point every block at the dense attention bias of this plan geometry (built on first use).  The bias is read
+        from HBM once per step whatever the batch, so it only pays when enough clips share it: Swin-T at 32x224x224 streams
+        1.2 GB per step (0.3 GB per clip at B = 4: 890 -> 613 us of attention), Swin-B at 64x256x256 10 GB (no gain at B = 2)."""
         blocks = self._wcache[3]
         nblk = sum(self.depths)
-        if not self.dense_bias:
+        total = sum(lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk))
+        if not self.dense_bias or total > batch * self.dense_bias_bytes_per_clip:
             for k in range(nblk):
                 blocks[k].bias_dense = None
             return
@@ -295,16 +299,17 @@ class SwinTransformer3D(nn.Module):
         bufs = self._dense.get(key)
         if bufs is None:
             sizes = [lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk)]
-            if sum(sizes) > self.dense_bias_max_bytes or not all(sizes):
-                bufs = [None] * nblk
-            else:
-                bufs = []
-                for k in range(nblk):
-                    t = torch.empty(sizes[k], dtype=torch.uint8, device=device)
-                    check(lib().kvq_swin3d_bias_dense_build(handle, k, blocks[k].rpb_table, blocks[k].fpb_table, ptr(t),
-                                                            current_stream()), "kvq_swin3d_bias_dense_build")
-                    bufs.append(t)
-                torch.cuda.synchronize(device)
+            bufs, used = [], 0
+            for k in range(nblk):           # blocks that do not fit under the cap keep the per-score gather path
+                if not sizes[k] or used + sizes[k] > self.dense_bias_max_bytes:
+                    bufs.append(None)
+                    continue
+                t = torch.empty(sizes[k], dtype=torch.uint8, device=device)
+                check(lib().kvq_swin3d_bias_dense_build(handle, k, blocks[k].rpb_table, blocks[k].fpb_table, ptr(t),
+                                                        current_stream()), "kvq_swin3d_bias_dense_build")
+                bufs.append(t)
+                used += sizes[k]
+            torch.cuda.synchronize(device)
             self._dense[key] = bufs
         for k in range(nblk):
             blocks[k].bias_dense = ptr(bufs[k])
@@ -346,7 +351,7 @@ class SwinTransformer3D(nn.Module):
         B, _, T, H, W = x.shape
         handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device)
         w = self._weights(x.device)
-        self._set_dense_bias(handle, (T, H, W), x.device)
+        self._set_dense_bias(handle, (T, H, W), x.device, B)
         feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
         check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), current_stream()),
               "kvq_swin3d_forward")
