@@ -90,6 +90,28 @@ def test_bf16_path_matches_bf16_emulation(golden, case):
     assert (score - emu).abs().max().item() <= 2.5e-3, (score.ravel(), emu.ravel())
 
 
+@pytest.mark.parametrize("case", ["t_grpb_stress_16x64", "t_grpb_stress_32x224"])
+def test_unfused_launch_chain_and_gather_attention_vs_reference_golden(golden, case):
+    """The same fixtures through the un-fused chain (im2col/GEMM/LayerNorm launches, per-score bias gather), and
+    through the fused path with the pre-built attention bias forced on: both within the 1e-3 gate and within 3e-4 of
+    each other."""
+    g = golden("trunk.npz")
+    wseed, cseed, B, T, H, W = (int(v) for v in g[f"{case}/meta"])
+    scores = []
+    for fused in (False, True):
+        net, key = build_network(str(g[f"{case}/cfg"]), wseed, str(g[f"{case}/scheme"]))
+        bb = getattr(net, key + "_backbone")
+        bb.fused_tail = fused
+        bb.dense_bias = fused
+        bb.dense_bias_bytes_per_clip = 1 << 40          # small batches too
+        x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B)).to(DEV)
+        with torch.no_grad():
+            s = net(inputs={"technical": x}, reduce_scores=True).cpu().numpy()
+        assert np.abs(s - g[f"{case}/score"]).max() <= SCORE_TOL
+        scores.append(s)
+    assert np.abs(scores[0] - scores[1]).max() <= 3e-4
+
+
 def test_full_size_vs_oracle_on_box():
     """Fresh seeds (not in the fixtures): oracle runs on this box's CPU, full 32x224x224, B=2."""
     cfg = synth.SWIN_T_GRPB
