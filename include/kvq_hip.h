@@ -343,6 +343,12 @@ int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int T, int H, i
 int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_t strides5[5], const int32_t dims5[5],
                   const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int Kpad,
                   uint16_t* out, void* stream);
+/* Direct Conv3d for the few-output-channel stems (SlowFast fast pathway: 3 -> 8, k 5x7x7, SlowFast_features.py:140):
+ * x fp32 (B,C,D,H,W) contiguous, w fp32 [K][cout] with K ordered (kd,kh,kw,c), bias fp32 [cout] (BatchNorm folded),
+ * cout in {8,16}; out 16-bit channels-last (B,Do,Ho,Wo,cout).  fp32 arithmetic; no patch matrix is materialised. */
+int kvq_conv_stem_direct(const float* x, const int32_t dims5[5], const float* w, const float* bias, int cout,
+                         const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu, int dtype,
+                         uint16_t* out, void* stream);
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
                 const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream);

@@ -131,6 +131,8 @@ SYMBOLS = {
                                   C.POINTER(f32), p_void, p_void]),
     "kvq_im2col_nd": (i32, [p_void, i32, i32, C.POINTER(i64 * 5), C.POINTER(i32 * 5), C.POINTER(i32 * 3),
                             C.POINTER(i32 * 3), C.POINTER(i32 * 3), i32, p_void, p_void]),
+    "kvq_conv_stem_direct": (i32, [p_void, C.POINTER(i32 * 5), p_void, p_void, i32, C.POINTER(i32 * 3), C.POINTER(i32 * 3),
+                                   C.POINTER(i32 * 3), i32, i32, p_void, p_void]),
     "kvq_pool_nd": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
                           i32, p_void, p_void]),
     "kvq_mean_std_pool": (i32, [p_void, i32, i32, i32, i32, p_void, i64, i32, i32, p_void]),

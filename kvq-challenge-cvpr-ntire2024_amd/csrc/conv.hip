@@ -139,6 +139,74 @@ __global__ __launch_bounds__(256) void mean_std_pool_kernel(const uint16_t* __re
   }
 }
 
+
+// ---- direct stem convolution ---------------------------------------------------------------------------------------
+// The SlowFast fast-pathway stem is Conv3d(3 -> 8, k = 5x7x7, stride 1x2x2): K = 735 per output but only 8 output
+// channels, so as im2col + GEMM it WRITES a 4.7 GB patch matrix (3.2 M positions x 736 x 2 B: 7.6 ms of the 15 ms
+// forward) to feed an MFMA tile that is 3/4 padding.  Here a thread owns one output position and all Cout <= 16
+// channels: fp32 FMAs against weights broadcast from LDS ([K][Cout] fp32), the fp32 clip read through L1/L2 (adjacent
+// threads share 5/7 of their taps), folded-BN bias + ReLU, one 16-B channels-last store.  fp32 end to end.
+struct StemParams {
+  const float* x;          // (B, C, D, H, W) contiguous fp32
+  const float* w;          // [K][Cout] fp32, K ordered (kd, kh, kw, c) like kvq_im2col_nd
+  const float* bias;       // [Cout]
+  int B, C, D, H, W, kd, kh, kw, sd, sh, sw, pd, ph, pw, Do, Ho, Wo, relu;
+  uint16_t* out;           // (B, Do, Ho, Wo, Cout) 16-bit
+};
+
+template <typename E, int COUT>
+__global__ __launch_bounds__(256) void conv_stem_direct_kernel(StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);
+  const int K = p.kd * p.kh * p.kw * p.C;
+  for (int i = threadIdx.x; i < K * COUT; i += 256) wl[i] = p.w[i];
+  __syncthreads();
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo;
+  const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= total) return;
+  const int wo = (int)(pos % p.Wo), ho = (int)((pos / p.Wo) % p.Ho), dq = (int)((pos / ((long)p.Wo * p.Ho)) % p.Do);
+  const int b = (int)(pos / ((long)p.Wo * p.Ho * p.Do));
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = p.bias[o];
+  const size_t plane = (size_t)p.H * p.W, vol = plane * p.D;
+  const float* xb = p.x + (size_t)b * p.C * vol;
+  const int x0 = wo * p.sw - p.pw, y0 = ho * p.sh - p.ph, t0 = dq * p.sd - p.pd;
+  for (int a = 0; a < p.kd; ++a) {
+    const int t = t0 + a;
+    if (t < 0 || t >= p.D) continue;
+    for (int r = 0; r < p.kh; ++r) {
+      const int y = y0 + r;
+      if (y < 0 || y >= p.H) continue;
+      const float* row = xb + (size_t)t * plane + (size_t)y * p.W;
+      const float* wrow = wl + (size_t)((a * p.kh + r) * p.kw) * p.C * COUT;
+      for (int c2 = 0; c2 < p.kw; ++c2) {
+        const int xx = x0 + c2;
+        if (xx < 0 || xx >= p.W) continue;
+        for (int c = 0; c < p.C; ++c) {
+          const float v = row[(size_t)c * vol + xx];
+          const float* wv = wrow + (c2 * p.C + c) * COUT;
+#pragma unroll
+          for (int o = 0; o < COUT; o += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o + e] = fmaf(v, w4[e], acc[o + e]);
+          }
+        }
+      }
+    }
+  }
+  uint16_t* o16 = p.out + (size_t)pos * COUT;
+#pragma unroll
+  for (int o = 0; o < COUT; o += 8) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p.relu ? fmaxf(acc[o + e], 0.f) : acc[o + e];
+    *reinterpret_cast<u32x4*>(o16 + o) =
+        (u32x4){E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4], v[5]), E::pack2(v[6], v[7])};
+  }
+}
+
 }  // namespace kvq
 
 extern "C" int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_t strides5[5], const int32_t dims5[5],
@@ -212,5 +280,35 @@ extern "C" int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW,
     hipLaunchKernelGGL(mean_std_pool_kernel<Bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, out,
                        (long)out_stride, mean_off, std_off);
   KVQ_CHECK_LAUNCH("mean_std_pool_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_conv_stem_direct(const float* x, const int32_t dims5[5], const float* w, const float* bias, int cout,
+                                    const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu,
+                                    int dtype, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && dims5 && w && bias && kernel3 && stride3 && pad3 && out, KVQ_ERR_NULL, "kvq_conv_stem_direct: NULL pointer");
+  KVQ_REQUIRE(cout == 8 || cout == 16, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_direct: Cout=%d (8 or 16: wider convs are GEMMs)", cout);
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_direct: dtype %d", dtype);
+  StemParams p{};
+  p.x = x; p.w = w; p.bias = bias; p.B = dims5[0]; p.C = dims5[1]; p.D = dims5[2]; p.H = dims5[3]; p.W = dims5[4];
+  p.kd = kernel3[0]; p.kh = kernel3[1]; p.kw = kernel3[2]; p.sd = stride3[0]; p.sh = stride3[1]; p.sw = stride3[2];
+  p.pd = pad3[0]; p.ph = pad3[1]; p.pw = pad3[2]; p.relu = relu; p.out = out;
+  KVQ_REQUIRE(p.B > 0 && p.C > 0 && p.sd > 0 && p.sh > 0 && p.sw > 0, KVQ_ERR_SHAPE, "kvq_conv_stem_direct: bad shape");
+  p.Do = (p.D + 2 * p.pd - p.kd) / p.sd + 1; p.Ho = (p.H + 2 * p.ph - p.kh) / p.sh + 1; p.Wo = (p.W + 2 * p.pw - p.kw) / p.sw + 1;
+  KVQ_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0, KVQ_ERR_SHAPE, "kvq_conv_stem_direct: empty output");
+  const size_t lds = (size_t)p.kd * p.kh * p.kw * p.C * cout * 4;
+  KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_direct: %zu B of weights exceed LDS", lds);
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == KVQ_DT_FP16) {
+    if (cout == 8) hipLaunchKernelGGL((conv_stem_direct_kernel<Fp16, 8>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((conv_stem_direct_kernel<Fp16, 16>), grid, block, lds, st, p);
+  } else {
+    if (cout == 8) hipLaunchKernelGGL((conv_stem_direct_kernel<Bf16, 8>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((conv_stem_direct_kernel<Bf16, 16>), grid, block, lds, st, p);
+  }
+  KVQ_CHECK_LAUNCH("conv_stem_direct_kernel");
   return KVQ_OK;
 }

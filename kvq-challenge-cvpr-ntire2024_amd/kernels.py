@@ -321,3 +321,18 @@ def patch_embed(x: torch.Tensor, w: torch.Tensor, bias, ln_w, ln_b, patch, *, ne
                                                                             ptr(next_dst), ptr(nxt), next_rows)
     check(lib().kvq_patch_embed(C.byref(a), current_stream()), "kvq_patch_embed")
     return out, nxt
+
+
+def conv_stem_direct(x: torch.Tensor, w_kc: torch.Tensor, bias: torch.Tensor, kernel, stride, pad, relu: bool, out_dtype):
+    """Direct Conv3d for few output channels: x fp32 (B,C,D,H,W), w_kc fp32 [K][Cout] (K ordered kd,kh,kw,c), -> 16-bit
+    channels-last (B,Do,Ho,Wo,Cout)."""
+    _need_gpu(x, w_kc, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and w_kc.dtype == torch.float32 and w_kc.is_contiguous()
+    B, Cin, D, H, W = x.shape
+    cout = w_kc.shape[1]
+    do, ho, wo = conv_out_dims((D, H, W), kernel, stride, pad)
+    out = torch.empty(B, do, ho, wo, cout, dtype=out_dtype, device=x.device)
+    check(lib().kvq_conv_stem_direct(ptr(x), C.byref((C.c_int32 * 5)(B, Cin, D, H, W)), ptr(w_kc), ptr(bias), cout,
+                                     C.byref(_i32x(kernel)), C.byref(_i32x(stride)), C.byref(_i32x(pad)), int(relu),
+                                     dtype_code(out_dtype), ptr(out), current_stream()), "kvq_conv_stem_direct")
+    return out

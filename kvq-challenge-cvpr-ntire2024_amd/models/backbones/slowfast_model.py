@@ -103,6 +103,8 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             mu, var = sd[f"{base}.{nname}.running_mean"].to(device, torch.float32), sd[f"{base}.{nname}.running_var"].to(device, torch.float32)
             scale = g / torch.sqrt(var + 1e-5)
             w = (w * scale.view(-1, 1, 1, 1, 1)).permute(0, 2, 3, 4, 1).reshape(wshape[0], -1)
+            if wshape[0] in (8, 16) and w.shape[1] > 256:        # few outputs, long patch: direct fp32 stem conv (conv.hip)
+                out[key + "/direct"] = w.t().contiguous()
             kpad = -(-w.shape[1] // 32) * 32
             if kpad != w.shape[1]:
                 w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
@@ -141,12 +143,15 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         shape = (x16.shape[0], d, h, w, spec[0].shape[0])
         return y16.reshape(shape), y32.reshape(shape)
 
-    def _stem(self, x, spec, half):
+    def _stem(self, x, spec, half, direct=None):
         B, C, T, H, W = x.shape
         wt, bias, k, stride, pad = spec
-        a, (d, h, w) = kernels.im2col_nd(x, (B, C, T, H, W), (C * T * H * W, T * H * W, H * W, W, 1), k, stride, pad, half,
-                                         wt.shape[1])
-        y = kernels.conv_gemm(a, wt, bias, True).reshape(B, d, h, w, wt.shape[0])
+        if direct is not None:      # fast pathway: 3 -> 8 channels, k 5x7x7: the patch matrix would be 4.7 GB for 8 clips
+            y = kernels.conv_stem_direct(x, direct, bias, k, stride, pad, True, half)
+        else:
+            a, (d, h, w) = kernels.im2col_nd(x, (B, C, T, H, W), (C * T * H * W, T * H * W, H * W, W, 1), k, stride, pad,
+                                             half, wt.shape[1])
+            y = kernels.conv_gemm(a, wt, bias, True).reshape(B, d, h, w, wt.shape[0])
         return kernels.pool_nd(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), True)
 
     def forward(self, x):
@@ -159,7 +164,8 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         half = _abi.torch_dtype(self.operand_dtype)
         fe = "feature_extraction."
         slow = self._stem(slow_in.float().contiguous(), W[fe + "0.multipathway_blocks.0"], half)
-        fast = self._stem(fast_in.float().contiguous(), W[fe + "0.multipathway_blocks.1"], half)
+        fast = self._stem(fast_in.float().contiguous(), W[fe + "0.multipathway_blocks.1"], half,
+                          W.get(fe + "0.multipathway_blocks.1/direct"))
         slow = torch.cat([slow, self._conv_relu(fast, W[fe + "0.multipathway_fusion"])], dim=-1)
         s32 = f32 = None
         for si in range(4):
