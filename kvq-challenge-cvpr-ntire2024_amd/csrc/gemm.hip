@@ -53,12 +53,18 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // refilled with slice t+NST-1).  LDS rows are 64 B (no padding: the DMA image is lane-linear); the 16-B chunk
 // c of row r lives at chunk c ^ ((r>>2)&3) — applied on the SOURCE address of the DMA and on the
 // fragment read — which makes the 16-lane service groups of ds_read_b128 hit 16 distinct 16-B slots.
+// BK = 32: LDS rows of 64 B, 16-B chunk c of row r at chunk c ^ ((r>>2)&3).  BK = 64 (the "one big tile per CU"
+// variants for long-K shapes): rows of 128 B, chunk c at c ^ ((r>>1)&7) — in both, the 16 lanes of a ds_read_b128
+// service group land on 16 distinct 16-B slots.
 template <typename E, int MI, int NI, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  static_assert(BK == 32, "ring slices are 32 deep");
+  static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
   constexpr int BM = 64 * MI, BN = 64 * NI, NST = KVQ_GEMM_NST;
-  constexpr int A_BYTES = BM * 64, ST_BYTES = (BM + BN) * 64;
-  constexpr int A_PER = BM * 4 / 256, B_PER = BN * 4 / 256, NL = A_PER + B_PER;   // DMAs per thread per slice
+  constexpr int RB = BK * 2, CH = RB / 16, KK = BK / 16;             // row bytes, 16-B chunks per row, MFMA k-steps per slice
+  constexpr int A_BYTES = BM * RB, ST_BYTES = (BM + BN) * RB;
+  constexpr int A_PER = BM * CH / 256, B_PER = BN * CH / 256, NL = A_PER + B_PER;   // DMAs per thread per slice
+  static_assert((BM * CH) % 256 == 0 && (BN * CH) % 256 == 0, "whole DMA rounds");
+  auto swz = [](int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
 
@@ -80,12 +86,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const uint16_t* b_src[B_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
-    const int q = i * 256 + tid, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
     a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
   }
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
-    const int q = i * 256 + tid, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
     b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
   auto issue = [&](int kt) {
@@ -118,18 +124,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   if (NST > 3 && nk > 2) issue(2);
   const int frow = lane & 31, fkg = lane >> 5;
   // per-lane fragment byte offsets inside a slice (swizzled), one per kk
-  int a_off[MI][2], b_off[NI][2];
+  int a_off[MI][KK], b_off[NI][KK];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int row = wm * 32 * MI + i * 32 + frow;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = row * 64 + (((kk * 2 + fkg) ^ ((row >> 2) & 3)) << 4);
+    for (int kk = 0; kk < KK; ++kk) a_off[i][kk] = row * RB + (((kk * 2 + fkg) ^ swz(row)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int row = wn * 32 * NI + j * 32 + frow;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = A_BYTES + row * 64 + (((kk * 2 + fkg) ^ ((row >> 2) & 3)) << 4);
+    for (int kk = 0; kk < KK; ++kk) b_off[j][kk] = A_BYTES + row * RB + (((kk * 2 + fkg) ^ swz(row)) << 4);
   }
   for (int kt = 0; kt < nk; ++kt) {
     // slice kt must have landed; up to two younger slices stay in flight
@@ -145,18 +151,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (tr && kt == 0) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
     if (kt + NST - 1 < nk) issue(kt + NST - 1);
     const unsigned char* st = lds + (kt % NST) * ST_BYTES;
+    // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued (double-buffered registers): with
+    // one or two waves per SIMD (the big-tile variants) nothing else hides the LDS round trip
+    V8 af[2][MI], bfr[2][NI];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      V8 af[MI], bfr[NI];
+    for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const V8*>(st + a_off[i][0]);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(st + a_off[i][kk]);
+    for (int j = 0; j < NI; ++j) bfr[0][j] = *reinterpret_cast<const V8*>(st + b_off[j][0]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const V8*>(st + b_off[j][kk]);
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk + 1 < KK) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[(kk + 1) & 1][i] = *reinterpret_cast<const V8*>(st + a_off[i][kk + 1]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[(kk + 1) & 1][j] = *reinterpret_cast<const V8*>(st + b_off[j][kk + 1]);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = E::mfma32(af[i], bfr[j], acc[i][j]);   // columns >= N multiply clamped rows: discarded below
+          acc[i][j] = E::mfma32(af[kk & 1][i], bfr[kk & 1][j], acc[i][j]);   // columns >= N multiply clamped rows: discarded below
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();   // everybody is done with the ring before the epilogue slabs overwrite it
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 template <typename E, int MI, int NI, int BK, int EPI>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr size_t main_bytes = KVQ_GEMM_NST * (BM + BN) * 64;         // ring of 64-B rows
+  constexpr size_t main_bytes = KVQ_GEMM_NST * (BM + BN) * BK * 2;     // ring of 2*BK-byte rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   auto kern = gemm_kernel<E, MI, NI, BK, EPI>;
@@ -314,6 +329,16 @@ int gemm_variant(int M, int N, int K) {
   // (K = 384, epilogue-dominated) 25.0 / 21.3 / 20.2; merge stage 0 (N = 192 = 1.5 tiles of 128) 28.0 / 24.7 / 28.1.
   // => the big tile whenever the K loop is long or it still fills the chip; 64-wide columns when the last
   // 128-column tile would be at most half used.
+  // Long K with few tiles: ONE big tile per CU, 64-deep slices (what the vendor library picks for these shapes:
+  // 128x160x64 ... 128x256x64 tiles, 225-294 of them).  First candidate that fits the chip in a single round.
+  static const int no_deep = getenv("KVQ_GEMM_NO_DEEP") ? 1 : 0;
+  if (!no_deep && K % 64 == 0 && K >= 1024) {      // measured: fc2 stage 3 45 -> 40 us, merges -2 us; K = 768 shapes lose
+    static const int cand[3][2] = {{2, 2}, {3, 2}, {2, 4}};
+    for (auto& c : cand) {
+      const long tiles = (long)ceil_div(M, 64 * c[0]) * ceil_div(N, 64 * c[1]);
+      if (tiles <= 256) return (c[0] * 10 + c[1]) * 100 + 64;
+    }
+  }
   const long blocks128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
   const bool big = blocks128 >= 400 || K >= 1024 || (blocks128 >= 256 && K >= 768);
   if (!big) return 11 * 100 + 32;
@@ -323,7 +348,15 @@ int gemm_variant(int M, int N, int K) {
 
 template <typename E, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t st) {
-  switch (gemm_variant(p.M, p.N, p.K) / 100) {
+  const int var = gemm_variant(p.M, p.N, p.K);
+  if (var % 100 == 64) {
+    switch (var / 100) {
+      case 22: return launch_one<E, 2, 2, 64, EPI>(p, st);
+      case 32: return launch_one<E, 3, 2, 64, EPI>(p, st);
+      default: return launch_one<E, 2, 4, 64, EPI>(p, st);
+    }
+  }
+  switch (var / 100) {
     case 22: return launch_one<E, 2, 2, 32, EPI>(p, st);
     case 21: return launch_one<E, 2, 1, 32, EPI>(p, st);
     case 12: return launch_one<E, 1, 2, 32, EPI>(p, st);
