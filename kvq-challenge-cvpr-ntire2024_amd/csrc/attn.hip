@@ -62,6 +62,7 @@ __device__ __forceinline__ int k_slot(int row, int g) { return row * 4 + (g ^ ((
 // the generic instantiation checks every tile.
 template <typename E, bool GATED, bool MASK, bool FULL>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(AttnParams p) {
+  fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Ks = reinterpret_cast<u32x4*>(smem);                               // [416*4] 16-B slots
   uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + ATT_OFF_VT);            // [32][400] (+tail)
@@ -379,6 +380,7 @@ struct AttnDenseParams {
 
 template <typename E>
 __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kernel(AttnDenseParams p) {   // 3 x 52 KB LDS
+  fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Ks = reinterpret_cast<u32x4*>(smem);
   uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + ATT_OFF_VT);

@@ -74,9 +74,17 @@ struct Bf16 {
   }
 };
 
+// fp32 -> fp16 conversions must SATURATE (a value past 65504 would become inf and poison the row): instead of a
+// v_med3_f32 per element, every kernel that narrows sets MODE.FP16_OVFL (bit 23) once at its start — the converter
+// itself then clamps overflowed results to +/-65504 (true infinities are preserved).  ~1 VALU slot per element saved
+// in every 16-bit epilogue; bf16 shares fp32's exponent range and needs nothing.
+__device__ __forceinline__ void fp16_saturate_mode() {
+  __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1 /* hwreg(HW_REG_MODE, 23, 1) */, 1);
+}
+
 struct Fp16 {
   using v8 = f16x8;
-  static __device__ __forceinline__ float sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+  static __device__ __forceinline__ float sat(float f) { return f; }      // see fp16_saturate_mode()
   static __device__ __forceinline__ uint16_t cvt(float f) {
     _Float16 h = (_Float16)sat(f);
     return __builtin_bit_cast(uint16_t, h);

@@ -20,6 +20,7 @@ struct Im2colParams {
 
 template <typename E>
 __global__ __launch_bounds__(256) void im2col_nd_kernel(Im2colParams p) {
+  fp16_saturate_mode();
   const int chunks = p.Kpad / 8;
   const long total = (long)p.B * p.Do * p.Ho * p.Wo * chunks;
   const bool vec = !p.src_f32 && (p.C % 8 == 0) && p.sc == 1;
@@ -156,6 +157,7 @@ struct StemParams {
 
 template <typename E, int COUT>
 __global__ __launch_bounds__(256) void conv_stem_direct_kernel(StemParams p) {
+  fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);
   const int K = p.kd * p.kh * p.kw * p.C;

@@ -49,6 +49,7 @@ __global__ void embed_pack_kernel(const uint16_t* w, const float* bias, const fl
 
 template <typename E_, int CM, int KS, bool EMIT>
 __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
+  fp16_saturate_mode();
   constexpr int E = 32 * CM, WBYTES = CM * KS * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E_::v8;

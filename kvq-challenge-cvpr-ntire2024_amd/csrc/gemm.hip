@@ -58,6 +58,7 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // service group land on 16 distinct 16-B slots.
 template <typename E, int MI, int NI, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  fp16_saturate_mode();
   static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
   constexpr int BM = 64 * MI, BN = 64 * NI, NST = KVQ_GEMM_NST;
   constexpr int RB = BK * 2, CH = RB / 16, KK = BK / 16;             // row bytes, 16-B chunks per row, MFMA k-steps per slice

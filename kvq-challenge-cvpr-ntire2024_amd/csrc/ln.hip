@@ -27,6 +27,7 @@ struct LnParams {
 
 template <typename E, int G, int NV, int R>  // G lanes per row, NV float4 per lane (NV*G*4 >= C), R rows per group
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
+  fp16_saturate_mode();
   const int C = p.nparts * p.Cin;
   const int lane_in = threadIdx.x % G;
   const long row0 = ((long)blockIdx.x * (256 / G) + threadIdx.x / G) * R;

@@ -14,6 +14,7 @@ template <typename E>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, int B, int Cin, int T, int H,
                                                            int W, int pd, int ph, int pw, int D, int Hh, int Ww,
                                                            uint16_t* __restrict__ out) {
+  fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) uint16_t tile[];   // [Ww][K] in the output order
   const int K = Cin * pd * ph * pw;
   const int runs = Cin * pd * ph;                 // source rows feeding this token row

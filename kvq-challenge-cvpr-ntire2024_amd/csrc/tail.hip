@@ -133,6 +133,7 @@ __global__ void tail_pack_kernel(const uint16_t* wp, const uint16_t* w1, const u
 // 3 (C = 96, <= 168 VGPRs) or 2 of them per CU.
 template <typename E, int CM, int NW, bool EMIT>
 __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_kernel(TailParams p) {
+  fp16_saturate_mode();
   constexpr int C = 32 * CM, KS = 2 * CM, PANEL = 64 * C, SLOT = 2 * PANEL, LPW = SLOT / 1024 / NW;
   constexpr int NST = tail_ring(C, NW), NPI = tail_proj_items(C);
   static_assert(SLOT % (1024 * NW) == 0, "an item is a whole number of 1 KB loads per wave");

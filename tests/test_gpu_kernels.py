@@ -480,3 +480,17 @@ def test_patch_embed_fused_rejects_padded_clip():
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.patch_embed(torch.zeros(1, 3, 7, 30, 27, device=DEV), torch.zeros(96, 96, dtype=torch.float16, device=DEV),
                             torch.zeros(96, device=DEV), None, None, (2, 4, 4))
+
+
+def test_fp16_narrowing_saturates_instead_of_overflowing():
+    """Values past the fp16 range clamp to +/-65504 in every 16-bit epilogue (MODE.FP16_OVFL), never inf."""
+    A = torch.full((64, 32), 200.0, dtype=torch.float16, device=DEV)
+    W = torch.full((32, 32), 200.0, dtype=torch.float16, device=DEV)
+    W[1] = -200.0
+    out = kernels.gemm(A, W, None, _abi.EPI_BIAS_BF16)                 # 32 * 200 * 200 = 1.28e6 > 65504
+    assert torch.isfinite(out).all()
+    assert (out[:, 0] == 65504).all() and (out[:, 1] == -65504).all()
+    x = torch.zeros(8, 96, device=DEV)
+    x[:, 0] = 1e6
+    y = kernels.layernorm_rows(x, torch.full((96,), 1e5, device=DEV), torch.zeros(96, device=DEV), out_dtype=torch.float16)
+    assert torch.isfinite(y).all() and (y[:, 0] == 65504).all()
