@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 5
+#define KVQ_ABI_VERSION 6
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -140,7 +140,8 @@ int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const f
  * and builder.  Independent of the batch size; rebuild when the block's tables change. */
 size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* plan, int block);
 int kvq_swin3d_bias_dense_build(const KvqSwinPlan* plan, int block, const float* rpb_table, const float* fpb_table,
-                                void* out, void* stream);
+                                void* out, float* max_abs /* device, may be NULL: see kvq_attn_bias_dense_build */,
+                                void* stream);
 
 /* Per-kernel-class GPU time of the most recent profiled forward.  Profiling brackets every
  * launch with hipEvents on the launch stream; enable with kvq_swin3d_profile(plan, 1). */
@@ -284,16 +285,21 @@ int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* r
                          int dtype, uint16_t* out, void* stream);
 
 /* The same attention with the bias PRE-BUILT per (window, head): bias[w][h][i][j] = what kvq_window_attention
- * rebuilds per score (table gather, fragment gate, -100 shift mask), fp32, stored in the kernel's MFMA accumulator
- * layout [nW][nH][ceil(N/16)][26][64 lanes][4]; keys >= N hold -60000.  A q-tile loads its bias tiles straight into
- * the score accumulators: no per-score VALU or LDS work is left besides max / exp / pack.  4 B per score of HBM/L2
- * traffic, shared by all clips of a step.
+ * rebuilds per score (table gather, fragment gate, -100 shift mask), stored as fp16 in the kernel's MFMA accumulator
+ * layout [n_types][nH][ceil(N/16)][26][64 lanes][4]; keys >= N hold -60000.  A q-tile loads its bias tiles and widens
+ * them into the score accumulators: no per-score LDS work is left, and of the VALU work only widen / max / exp / pack.
+ * 2 B per score of HBM/L2 traffic, shared by all clips of a step and by the windows of one TYPE: n_types <= nW
+ * divides nW and window w uses bias w % n_types (un-shifted windows that differ only in depth index share one; pass
+ * the descriptors of the first n_types windows to the builder).  Stored is bias - max_key bias of the query's row
+ * (softmax is invariant to a per-row shift): the entries that carry the probability mass sit next to 0, where fp16
+ * resolves them to <= 2^-11.  The builder also reports max |bias| (un-masked entries) through max_abs (device
+ * float, zero it first; NULL = skip); the host mirror keeps the exact per-score path above a (generous) cap.
  *   tok, rpb, fpb, table_len, center, use_mask: as kvq_window_attention (fpb NULL = no gate). */
-size_t kvq_attn_bias_dense_bytes(int nW, int N, int num_heads);
-int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center, int nW,
-                              int N, int num_heads, int use_mask, void* out, void* stream);
-int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int BW, int nW, int N, int num_heads,
-                               int dtype, uint16_t* out, void* stream);
+size_t kvq_attn_bias_dense_bytes(int n_types, int N, int num_heads);
+int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
+                              int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
+int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
+                               int num_heads, int dtype, uint16_t* out, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

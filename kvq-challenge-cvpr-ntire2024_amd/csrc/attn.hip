@@ -318,9 +318,14 @@ extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, con
 // REBUILDING the bias per score (descriptor reads, table gather, gate, mask select).  The bias of a (window, head)
 // depends only on the block's tables and the window's position in the clip, not on the clip: it is built once per
 // weight set by bias_dense_kernel and streamed from HBM/L2 (4 B per score) while the kernel is compute-bound.
-//   * layout [window][head][q-tile][key-tile][lane][4 x fp32] = the C operand of the score MFMA: a q-tile starts
-//     by loading its 26 bias tiles STRAIGHT INTO the score accumulators (26 independent 16-B loads in flight per
-//     lane, no staging registers, no LDS), the MFMAs then add K Q^T on top as the tiles arrive;
+//   * layout [window type][head][q-tile][key-tile][lane][4 x fp16] = the C operand of the score MFMA, narrowed: a
+//     q-tile starts by loading its 26 bias tiles (26 independent 8-B loads in flight per lane, no LDS), widens them
+//     into the score accumulators, and the MFMAs add K Q^T on top.  The launch is HBM-heavy on exactly this stream
+//     (fp32 tiles: 1.2 GB per step, 410 MB of a stage-0 launch's 116 us), hence 2 B per score and one copy per
+//     window TYPE (un-shifted windows that differ only in their depth index share a bias).  What is stored is
+//     bias - max_key bias of the query's row: softmax is invariant to a per-row shift, and the shift puts the
+//     entries that carry the probability mass next to 0, where fp16 resolves them to <= 2^-11 (the size of the
+//     rounding of the probabilities themselves) whatever the magnitude of the tables;
 //   * the -100 shift mask and the "key >= N" exclusion (-60000: exp2 underflows to exactly 0) are baked in, so
 //     there is one instantiation per operand type instead of gated x masked x full.
 namespace kvq {
@@ -334,15 +339,46 @@ struct DenseBuildParams {
   const float* rpb;
   const float* fpb;
   int table_len, center, nW, N, nH, use_mask;
-  float* out;
+  uint16_t* out;
+  unsigned* max_abs;         // optional: bit pattern of max |bias| over the real (un-masked, in-range) entries
+  float* rowmax;             // [n_types][nH][N]: max over the un-masked keys of a query's bias row
 };
+
+// bias(q, key) of window type w, head h — exactly the gather path's arithmetic; masked = true -> the shift mask hits
+__device__ __forceinline__ float dense_bias_value(const DenseBuildParams& p, int w, int h, int2 tq, int key, bool* masked) {
+  const int2 tk = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + key) * 2);
+  const int idx = tq.x - tk.x + p.center;
+  const float rr = p.rpb[(size_t)idx * p.nH + h];
+  float b = rr;
+  if (p.fpb) {                          // f + g * (r - f), one fma
+    const float f = p.fpb[(size_t)idx * p.nH + h];
+    const float gate = (float)__builtin_amdgcn_sad_u8((unsigned)(tq.y & 0xffff), (unsigned)(tk.y & 0xffff), 0u);
+    b = fmaf(gate, rr - f, f);
+  }
+  *masked = p.use_mask && ((tq.y >> 16) & 0xff) != ((tk.y >> 16) & 0xff);
+  return b;
+}
+
+__global__ __launch_bounds__(64) void bias_rowmax_kernel(DenseBuildParams p) {
+  const int q = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, w = blockIdx.z;
+  if (q >= p.N) return;
+  const int2 tq = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + q) * 2);
+  float mx = -INFINITY;
+  for (int key = 0; key < p.N; ++key) {
+    bool masked;
+    const float b = dense_bias_value(p, w, h, tq, key, &masked);
+    if (!masked) mx = fmaxf(mx, b);
+  }
+  p.rowmax[((size_t)w * p.nH + h) * p.N + q] = mx;      // the query itself is never masked: finite
+}
 
 __global__ __launch_bounds__(64) void bias_dense_kernel(DenseBuildParams p) {
   const int nqt = (p.N + 15) >> 4;
   const int qt = blockIdx.x / ATT_NT, t = blockIdx.x % ATT_NT, h = blockIdx.y, w = blockIdx.z;
   const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
   const int q = 16 * qt + j;
-  f32x4 v;
+  float v[4];
+  float big = 0.f;
   int2 tq = make_int2(0, 0);
   if (q < p.N) tq = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + q) * 2);
 #pragma unroll
@@ -352,26 +388,30 @@ __global__ __launch_bounds__(64) void bias_dense_kernel(DenseBuildParams p) {
     if (key >= p.N) {
       b = ATT_DENSE_OFF;
     } else if (q < p.N) {
-      const int2 tk = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + key) * 2);
-      const int idx = tq.x - tk.x + p.center;
-      const float rr = p.rpb[(size_t)idx * p.nH + h];
-      b = rr;
-      if (p.fpb) {                      // exactly the gather path's arithmetic: f + g * (r - f), one fma
-        const float f = p.fpb[(size_t)idx * p.nH + h];
-        const float gate = (float)__builtin_amdgcn_sad_u8((unsigned)(tq.y & 0xffff), (unsigned)(tk.y & 0xffff), 0u);
-        b = fmaf(gate, rr - f, f);
-      }
-      if (p.use_mask && ((tq.y >> 16) & 0xff) != ((tk.y >> 16) & 0xff)) b = -100.0f;
+      bool masked;
+      const float shift = p.rowmax[((size_t)w * p.nH + h) * p.N + q];
+      b = dense_bias_value(p, w, h, tq, key, &masked);
+      if (masked) b = -100.0f;          // REPLACES the bias, as in the gather path
+      else big = fmaxf(big, fabsf(b));
+      b -= shift;
     }
     v[r] = b;
   }
-  *reinterpret_cast<f32x4*>(p.out + ((((size_t)w * p.nH + h) * nqt + qt) * ATT_NT + t) * 256 + lane * 4) = v;
+  if (p.max_abs) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = fmaxf(big, __shfl_xor(big, o));
+    if (lane == 0) atomicMax(p.max_abs, __float_as_uint(big));      // non-negative floats order like their bit patterns
+  }
+  // fp16 whatever the operand type; un-masked entries are <= 0 after the row shift, the largest exactly 0
+  *reinterpret_cast<u32x2*>(p.out + ((((size_t)w * p.nH + h) * nqt + qt) * ATT_NT + t) * 256 + lane * 4) =
+      (u32x2){Fp16::pack2_raw(v[0], v[1]), Fp16::pack2_raw(v[2], v[3])};
 }
 
 struct AttnDenseParams {
   const uint16_t* qkv;
-  const f32x4* dense;
+  const u32x2* dense;
   int BW, nW, N, nH;
+  int n_types;                 // distinct biases: window w uses type w % n_types
   int qsplit;                  // workgroups per (window, head, clip): each takes a contiguous share of the q-tiles
   uint16_t* out;
   unsigned long long* trace;   // -DKVQ_ATT_TRACE builds only
@@ -390,11 +430,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   // Block order: the nclip workgroups that share one (window, head) bias run on the SAME XCD (workgroup b -> XCD
   // b % 8, each XCD has its own L2) back to back, so the bias is fetched from HBM once per step, not once per clip.
   // Small grids (late stages: few windows) split a unit's q-tiles over qsplit workgroups, each staging K/V again.
-  const int nclip = p.BW / p.nW, npair = p.nW * p.nH, per_pair = nclip * p.qsplit;
+  const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH, per_pair = nclip * nrep * p.qsplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pair = (slot / per_pair) * 8 + xcd, sub = slot % per_pair, clip = sub % nclip, part = sub / nclip;
+  const int pair = (slot / per_pair) * 8 + xcd, sub = slot % per_pair;     // pair = (window type, head): one bias
+  const int clip = sub % nclip, rep = (sub / nclip) % nrep, part = sub / (nclip * nrep);
   if (pair >= npair) return;
-  const int w = pair / p.nH, h = pair - w * p.nH, bw = clip * p.nW + w;
+  const int wt = pair / p.nH, h = pair - wt * p.nH, w = rep * p.n_types + wt, bw = clip * p.nW + w;
   const int tid = threadIdx.x, N = p.N;
 #ifdef KVQ_ATT_TRACE
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
@@ -441,7 +482,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   const float kLog2e = 1.4426950408889634f;
   const uint32_t one2 = (uint32_t)E::cvt(1.0f) * 0x10001u;
   const V8 ones = __builtin_bit_cast(V8, (u32x4){one2, one2, one2, one2});
-  const f32x4* dense = p.dense + (size_t)pair * nqt * ATT_NT * 64 + lane;
+  const u32x2* dense = p.dense + (size_t)pair * nqt * ATT_NT * 64 + lane;
 
   while (true) {
     int qt = 0;
@@ -451,10 +492,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     const int q0 = qt * 16;
     const int qrow = min(q0 + j, N - 1);
     const V8 qf = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + g * 8);
-    const f32x4* bd = dense + (size_t)qt * ATT_NT * 64;
+    const u32x2* bd = dense + (size_t)qt * ATT_NT * 64;
+    u32x2 braw[ATT_NT];
+#pragma unroll
+    for (int t = 0; t < ATT_NT; ++t) braw[t] = bd[t * 64];   // all 26 bias tiles requested before anything waits
     f32x4 S[ATT_NT];
 #pragma unroll
-    for (int t = 0; t < ATT_NT; ++t) S[t] = bd[t * 64];      // the bias tiles, straight into the accumulators
+    for (int t = 0; t < ATT_NT; ++t)
+      S[t] = (f32x4){Fp16::to_f32((uint16_t)(braw[t][0] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][0] >> 16)),
+                     Fp16::to_f32((uint16_t)(braw[t][1] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][1] >> 16))};
 #define ATT_KEY0(t) (32 * ((t) >> 1) + 4 * ((t) & 1))
     const int krow0 = 8 * (j >> 2) + (j & 3);
     V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(0) + krow0, g)]), kfN = kfC;
@@ -525,8 +571,8 @@ static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
                                       ATT_D_LDS));
     attr_set = true;
   }
-  const int nclip = p.BW / p.nW, npair = p.nW * p.nH;
-  dim3 grid((unsigned)(8 * ceil_div(npair, 8) * nclip * p.qsplit)), block(ATT_WAVES * 64);
+  const int nclip = p.BW / p.nW, npair = p.n_types * p.nH;
+  dim3 grid((unsigned)(8 * ceil_div(npair, 8) * nclip * (p.nW / p.n_types) * p.qsplit)), block(ATT_WAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, ATT_D_LDS, st, p);
   KVQ_CHECK_LAUNCH("window_attention_dense_kernel");
   return KVQ_OK;
@@ -534,32 +580,41 @@ static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
 
 }  // namespace kvq
 
-extern "C" size_t kvq_attn_bias_dense_bytes(int nW, int N, int num_heads) {
-  if (nW <= 0 || N < 1 || N > 400 || num_heads <= 0) return 0;
-  return (size_t)nW * num_heads * ((N + 15) / 16) * kvq::ATT_NT * 1024;
+static size_t dense_image_bytes(int n_types, int N, int num_heads) {
+  return (size_t)n_types * num_heads * ((N + 15) / 16) * kvq::ATT_NT * 512;
+}
+
+extern "C" size_t kvq_attn_bias_dense_bytes(int n_types, int N, int num_heads) {
+  if (n_types <= 0 || N < 1 || N > 400 || num_heads <= 0) return 0;
+  // the image, then the builder's row maxima (fp32 [n_types][nH][N])
+  return dense_image_bytes(n_types, N, num_heads) + (((size_t)n_types * num_heads * N * 4 + 255) & ~(size_t)255);
 }
 
 extern "C" int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
-                                         int nW, int N, int num_heads, int use_mask, void* out, void* stream) {
+                                         int nW, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(tok && rpb && out, KVQ_ERR_NULL, "kvq_attn_bias_dense_build: NULL pointer");
   KVQ_REQUIRE(kvq_attn_bias_dense_bytes(nW, N, num_heads) > 0 && table_len > 0, KVQ_ERR_SHAPE,
               "kvq_attn_bias_dense_build: bad shape nW=%d N=%d nH=%d", nW, N, num_heads);
-  DenseBuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (float*)out};
+  DenseBuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (uint16_t*)out, (unsigned*)max_abs,
+                     (float*)((unsigned char*)out + dense_image_bytes(nW, N, num_heads))};
+  hipLaunchKernelGGL(bias_rowmax_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)num_heads, (unsigned)nW), dim3(64), 0,
+                     (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("bias_rowmax_kernel");
   dim3 grid((unsigned)(((N + 15) / 16) * ATT_NT), (unsigned)num_heads, (unsigned)nW), block(64);
   hipLaunchKernelGGL(bias_dense_kernel, grid, block, 0, (hipStream_t)stream, p);
   KVQ_CHECK_LAUNCH("bias_dense_kernel");
   return KVQ_OK;
 }
 
-extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int BW, int nW, int N, int num_heads,
-                                          int dtype, uint16_t* out, void* stream) {
+extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
+                                          int num_heads, int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(qkv && bias_dense && out, KVQ_ERR_NULL, "kvq_window_attention_dense: NULL pointer");
-  KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0, KVQ_ERR_SHAPE,
-              "kvq_window_attention_dense: bad shape BW=%d nW=%d nH=%d", BW, nW, num_heads);
+  KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
+              "kvq_window_attention_dense: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
   KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: window of %d tokens unsupported (1..400)", N);
-  KVQ_REQUIRE(((size_t)bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_dense: bias_dense must be 16-byte aligned");
+  KVQ_REQUIRE(((size_t)bias_dense & 7) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_dense: bias_dense must be 8-byte aligned");
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: dtype %d", dtype);
   // 768 = 256 CUs x 3 resident workgroups: fill them when there are fewer (window, head, clip) units than that
   const int units = BW * num_heads, nqt = (N + 15) / 16;
@@ -567,6 +622,6 @@ extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_
   qsplit = qsplit > 4 ? 4 : qsplit;
   qsplit = qsplit > nqt ? nqt : qsplit;
   if (getenv("KVQ_ATT_QSPLIT")) qsplit = atoi(getenv("KVQ_ATT_QSPLIT"));
-  AttnDenseParams p{qkv, (const f32x4*)bias_dense, BW, nW, N, num_heads, qsplit, out, g_trace, g_trace_blocks};
+  AttnDenseParams p{qkv, (const u32x2*)bias_dense, BW, nW, N, num_heads, n_types, qsplit, out, g_trace, g_trace_blocks};
   return dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16>(p, (hipStream_t)stream) : launch_attn_dense<Bf16>(p, (hipStream_t)stream);
 }

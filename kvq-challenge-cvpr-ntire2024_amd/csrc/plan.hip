@@ -244,22 +244,29 @@ static bool locate_block(const KvqSwinPlan* pl, int block, int* stage, int* par)
 }
 }  // namespace kvq
 
+namespace kvq {
+// distinct attention biases of a block: un-shifted windows that differ only in their depth index share one (the
+// position codes, fragment ids and — absent — mask regions of their tokens are identical); windows are ordered
+// depth-major, so window w has type w % n_types
+static int bias_types(const StageGeom& g, int par) { return par == 0 ? g.nW / (g.Dp / g.ws[0]) : g.nW; }
+}  // namespace kvq
+
 extern "C" size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* pl, int block) {
   int i = 0, par = 0;
   if (!pl || !kvq::locate_block(pl, block, &i, &par)) return 0;
   const kvq::StageGeom& g = pl->st[i];
-  return kvq_attn_bias_dense_bytes(g.nW, g.N, g.nH);
+  return kvq_attn_bias_dense_bytes(kvq::bias_types(g, par), g.N, g.nH);
 }
 
 extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, const float* rpb, const float* fpb, void* out,
-                                           void* stream) {
+                                           float* max_abs, void* stream) {
   using namespace kvq;
   int i = 0, par = 0;
   KVQ_REQUIRE(pl && rpb && out, KVQ_ERR_NULL, "kvq_swin3d_bias_dense_build: NULL pointer");
   KVQ_REQUIRE(locate_block(pl, block, &i, &par), KVQ_ERR_SHAPE, "kvq_swin3d_bias_dense_build: no block %d", block);
   const StageGeom& g = pl->st[i];
   return kvq_attn_bias_dense_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
-                                   g.nW, g.N, g.nH, par, out, stream);
+                                   bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
 }
 
 extern "C" int kvq_swin3d_profile(KvqSwinPlan* pl, int enable) {
@@ -413,8 +420,9 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
         Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C,
-                   2.0 * 4.0 * M * C + (double)kvq_attn_bias_dense_bytes(g.nW, g.N, g.nH));
-        KVQ_TRY(kvq_window_attention_dense(bbig, bw.bias_dense, B * g.nW, g.nW, g.N, g.nH, pl->dtype, bo, st));
+                   2.0 * 4.0 * M * C + (double)kvq_attn_bias_dense_bytes(bias_types(g, par), g.N, g.nH));
+        KVQ_TRY(kvq_window_attention_dense(bbig, bw.bias_dense, bias_types(g, par), B * g.nW, g.nW, g.N, g.nH, pl->dtype, bo,
+                                           st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);

@@ -93,24 +93,28 @@ def window_attention(qkv: torch.Tensor, tok: torch.Tensor, rpb: torch.Tensor, fp
 
 def attn_bias_dense(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor], center: int, nW: int, N: int,
                     use_mask: bool):
-    """Dense attention bias of one block for ``window_attention_dense`` (include/kvq_hip.h)."""
+    """Dense attention bias of one block for ``window_attention_dense`` (include/kvq_hip.h); ``nW`` = the number of
+    window TYPES to build (the first nW windows' descriptors of ``tok``)."""
     _need_gpu(tok, rpb, fpb)
     nH = rpb.shape[1]
     out = torch.empty(lib().kvq_attn_bias_dense_bytes(nW, N, nH), dtype=torch.uint8, device=rpb.device)
+    big = torch.zeros(1, dtype=torch.float32, device=rpb.device)
     check(lib().kvq_attn_bias_dense_build(ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, nW, N, nH, int(use_mask),
-                                          ptr(out), current_stream()), "kvq_attn_bias_dense_build")
+                                          ptr(out), ptr(big), current_stream()), "kvq_attn_bias_dense_build")
+    out.max_abs_bias = big          # device scalar: largest un-masked |bias| (fp16 storage rounds by 2^-11 of it)
     return out
 
 
-def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int):
-    """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled) + pre-built bias; returns [BW*N, nH*32]."""
+def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None):
+    """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled) + pre-built bias; returns [BW*N, nH*32].  ``n_types`` (default nW):
+    window w uses bias w % n_types."""
     _need_gpu(qkv, bias_dense)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
     out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
-    check(lib().kvq_window_attention_dense(ptr(qkv), ptr(bias_dense), BW, nW, N, nH, dtype_code(qkv.dtype), ptr(out),
-                                           current_stream()), "kvq_window_attention_dense")
+    check(lib().kvq_window_attention_dense(ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH,
+                                           dtype_code(qkv.dtype), ptr(out), current_stream()), "kvq_window_attention_dense")
     return out
 
 

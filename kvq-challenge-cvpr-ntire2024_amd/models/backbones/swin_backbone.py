@@ -119,7 +119,9 @@ class SwinTransformer3D(nn.Module):
         # HBM for Swin-T at 32x224x224; KVQ_DENSE_BIAS=0 (or a geometry above the cap) keeps the per-score gather path
         self.dense_bias = os.environ.get("KVQ_DENSE_BIAS", "1") != "0"
         self.dense_bias_max_bytes = int(float(os.environ.get("KVQ_DENSE_BIAS_MAX_GB", "24")) * 2 ** 30)
+        self.dense_bias_max_abs = float(os.environ.get("KVQ_DENSE_BIAS_MAX_ABS", "16"))
         self.dense_bias_bytes_per_clip = int(float(os.environ.get("KVQ_DENSE_BIAS_GB_PER_CLIP", "0.5")) * 2 ** 30)
+        self.dense_bias_max_abs = float(os.environ.get("KVQ_DENSE_BIAS_MAX_ABS", "16"))
         self._dense = {}
         if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
             raise NotImplementedError("per-stage window sizes are not used by any reference config")
@@ -300,16 +302,20 @@ class SwinTransformer3D(nn.Module):
         if bufs is None:
             sizes = [lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk)]
             bufs, used = [], 0
+            big = torch.zeros(nblk, dtype=torch.float32, device=device)
             for k in range(nblk):           # blocks that do not fit under the cap keep the per-score gather path
                 if not sizes[k] or used + sizes[k] > self.dense_bias_max_bytes:
                     bufs.append(None)
                     continue
                 t = torch.empty(sizes[k], dtype=torch.uint8, device=device)
                 check(lib().kvq_swin3d_bias_dense_build(handle, k, blocks[k].rpb_table, blocks[k].fpb_table, ptr(t),
-                                                        current_stream()), "kvq_swin3d_bias_dense_build")
+                                                        big[k:].data_ptr(), current_stream()), "kvq_swin3d_bias_dense_build")
                 bufs.append(t)
                 used += sizes[k]
-            torch.cuda.synchronize(device)
+            # the image is fp16, row-max shifted (error <= 2^-11 x distance below the row's largest bias): blocks whose
+            # biases reach past +-16 keep the exact per-score gather path
+            too_big = (big > self.dense_bias_max_abs).cpu().tolist()     # (also the synchronisation with the builders)
+            bufs = [None if tb else b for b, tb in zip(bufs, too_big)]
             self._dense[key] = bufs
         for k in range(nblk):
             blocks[k].bias_dense = ptr(bufs[k])
