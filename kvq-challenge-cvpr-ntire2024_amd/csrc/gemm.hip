@@ -40,6 +40,11 @@ struct GemmParams {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
+template <typename V>
+__device__ __forceinline__ void lds_read_b128(V& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void gemm_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   if (nk > 1) issue(1);
   if (NST > 3 && nk > 2) issue(2);
   const int frow = lane & 31, fkg = lane >> 5;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;          // LDS byte address of the ring
   // per-lane fragment byte offsets inside a slice (swizzled), one per kk
   int a_off[MI][KK], b_off[NI][KK];
 #pragma unroll
@@ -152,21 +158,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (tr && kt == 0) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
     if (kt + NST - 1 < nk) issue(kt + NST - 1);
     const unsigned char* st = lds + (kt % NST) * ST_BYTES;
-    // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued (double-buffered registers): with
-    // one or two waves per SIMD (the big-tile variants) nothing else hides the LDS round trip
+    // Fragments of k-step kk+1 are requested before the MFMAs of k-step kk (double-buffered registers).  The reads are
+    // issued from inline asm with COUNTED waits: LDS returns in order, so "at most MI+NI outstanding" = k-step kk has
+    // landed while k-step kk+1 is still in flight.  (Left to the compiler, every k-step waits lgkmcnt(0): with one or two
+    // waves per SIMD — the big-tile variants — nothing else hides that round trip.)
+    const unsigned sbase = lds_base + (kt % NST) * ST_BYTES;
     V8 af[2][MI], bfr[2][NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const V8*>(st + a_off[i][0]);
+    for (int i = 0; i < MI; ++i) lds_read_b128(af[0][i], sbase + a_off[i][0]);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) bfr[0][j] = *reinterpret_cast<const V8*>(st + b_off[j][0]);
+    for (int j = 0; j < NI; ++j) lds_read_b128(bfr[0][j], sbase + b_off[j][0]);
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       if (kk + 1 < KK) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[(kk + 1) & 1][i] = *reinterpret_cast<const V8*>(st + a_off[i][kk + 1]);
+        for (int i = 0; i < MI; ++i) lds_read_b128(af[(kk + 1) & 1][i], sbase + a_off[i][kk + 1]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[(kk + 1) & 1][j] = *reinterpret_cast<const V8*>(st + b_off[j][kk + 1]);
+        for (int j = 0; j < NI; ++j) lds_read_b128(bfr[(kk + 1) & 1][j], sbase + b_off[j][kk + 1]);
       }
+      // the wait is tied to the registers it releases, so no use can be scheduled above it
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (kk + 1 < KK) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[kk & 1][i]) : "n"(MI + NI) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[kk & 1][i])::"memory");
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bfr[kk & 1][j]));
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
