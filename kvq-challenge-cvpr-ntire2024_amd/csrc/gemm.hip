@@ -61,11 +61,12 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // BK = 32: LDS rows of 64 B, 16-B chunk c of row r at chunk c ^ ((r>>2)&3).  BK = 64 (the "one big tile per CU"
 // variants for long-K shapes): rows of 128 B, chunk c at c ^ ((r>>1)&7) — in both, the 16 lanes of a ds_read_b128
 // service group land on 16 distinct 16-B slots.
-template <typename E, int MI, int NI, int BK, int EPI>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   fp16_saturate_mode();
   static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
-  constexpr int BM = 64 * MI, BN = 64 * NI, NST = KVQ_GEMM_NST;
+  static_assert(NST == 2 || NST == 3, "ring of 2 or 3 slices");
+  constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr int RB = BK * 2, CH = RB / 16, KK = BK / 16;             // row bytes, 16-B chunks per row, MFMA k-steps per slice
   constexpr int A_BYTES = BM * RB, ST_BYTES = (BM + BN) * RB;
   constexpr int A_PER = BM * CH / 256, B_PER = BN * CH / 256, NL = A_PER + B_PER;   // DMAs per thread per slice
@@ -126,8 +127,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
   const int nk = p.K / BK;
   issue(0);
-  if (nk > 1) issue(1);
-  if (NST > 3 && nk > 2) issue(2);
+  if (NST > 2 && nk > 1) issue(1);
   const int frow = lane & 31, fkg = lane >> 5;
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;          // LDS byte address of the ring
   // per-lane fragment byte offsets inside a slice (swizzled), one per kk
@@ -147,9 +147,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     // slice kt must have landed; up to two younger slices stay in flight
     const int younger = nk - 1 - kt;
-    if (NST > 3 && younger >= 2) {
-      gemm_wait_vmcnt<2 * NL>();
-    } else if (younger >= 1) {
+    if (NST > 2 && younger >= 1) {
       gemm_wait_vmcnt<NL>();
     } else {
       gemm_wait_vmcnt<0>();
@@ -319,13 +317,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <typename E, int MI, int NI, int BK, int EPI>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr size_t main_bytes = KVQ_GEMM_NST * (BM + BN) * BK * 2;     // ring of 2*BK-byte rows
+  constexpr size_t main_bytes = NST * (BM + BN) * BK * 2;               // ring of 2*BK-byte rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  auto kern = gemm_kernel<E, MI, NI, BK, EPI>;
+  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -367,6 +365,9 @@ int gemm_variant(int M, int N, int K) {
 template <typename E, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t st) {
   const int var = gemm_variant(p.M, p.N, p.K);
+  // 128x128 with 64-deep slices and a 2-slice ring (64 KB, 2 workgroups per CU; whole 128-B lines per DMA row):
+  // measured per epilogue on the trunk's shapes — qkv stage 2: 28 -> 26 us, stage 3: 25 -> 22; fc1 equal; fc2 +2 us
+  if (EPI == KVQ_EPI_QKV_BF16 && var == 2232 && p.K % 64 == 0) return launch_one<E, 2, 2, 64, EPI, 2>(p, st);
   if (var % 100 == 64) {
     switch (var / 100) {
       case 22: return launch_one<E, 2, 2, 64, EPI>(p, st);
