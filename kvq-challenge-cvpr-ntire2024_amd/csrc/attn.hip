@@ -90,14 +90,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
     if (row < N) v = *reinterpret_cast<const u32x4*>(Kg + (size_t)row * 32 + g * 8);
     Ks[k_slot(row, g)] = v;
   }
-  for (int c = tid; c < ATT_VPITCH * 4; c += ATT_WAVES * 64) {
-    const int key = c >> 2, g = c & 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (key < N) v = *reinterpret_cast<const u32x4*>(Vg + (size_t)key * 32 + g * 8);
+  // V^T: a thread transposes the 8-feature chunks of TWO adjacent keys and writes (key, key+1) pairs: 8 4-byte LDS
+  // stores per 32 bytes instead of 16 2-byte ones
+  for (int c = tid; c < ATT_VPITCH * 2; c += ATT_WAVES * 64) {
+    const int key = (c >> 2) * 2, g = c & 3;
+    u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+    if (key < N) v0 = *reinterpret_cast<const u32x4*>(Vg + (size_t)key * 32 + g * 8);
+    if (key + 1 < N) v1 = *reinterpret_cast<const u32x4*>(Vg + (size_t)(key + 1) * 32 + g * 8);
+    uint32_t* vt32 = reinterpret_cast<uint32_t*>(Vt);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      Vt[(g * 8 + 2 * i) * ATT_VPITCH + key] = (uint16_t)(v[i] & 0xffffu);
-      Vt[(g * 8 + 2 * i + 1) * ATT_VPITCH + key] = (uint16_t)(v[i] >> 16);
+      vt32[((g * 8 + 2 * i) * ATT_VPITCH + key) >> 1] = (v0[i] & 0xffffu) | (v1[i] << 16);
+      vt32[((g * 8 + 2 * i + 1) * ATT_VPITCH + key) >> 1] = (v0[i] >> 16) | (v1[i] & 0xffff0000u);
     }
   }
   if (tid < 32) Vt[32 * ATT_VPITCH + tid] = 0;   // tail read by the last K-step of row 31
@@ -457,14 +461,18 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     if (row < N) v = *reinterpret_cast<const u32x4*>(Kg + (size_t)row * 32 + g * 8);
     Ks[k_slot(row, g)] = v;
   }
-  for (int c = tid; c < ATT_VPITCH * 4; c += ATT_WAVES * 64) {
-    const int key = c >> 2, g = c & 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (key < N) v = *reinterpret_cast<const u32x4*>(Vg + (size_t)key * 32 + g * 8);
+  // V^T: a thread transposes the 8-feature chunks of TWO adjacent keys and writes (key, key+1) pairs: 8 4-byte LDS
+  // stores per 32 bytes instead of 16 2-byte ones
+  for (int c = tid; c < ATT_VPITCH * 2; c += ATT_WAVES * 64) {
+    const int key = (c >> 2) * 2, g = c & 3;
+    u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+    if (key < N) v0 = *reinterpret_cast<const u32x4*>(Vg + (size_t)key * 32 + g * 8);
+    if (key + 1 < N) v1 = *reinterpret_cast<const u32x4*>(Vg + (size_t)(key + 1) * 32 + g * 8);
+    uint32_t* vt32 = reinterpret_cast<uint32_t*>(Vt);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      Vt[(g * 8 + 2 * i) * ATT_VPITCH + key] = (uint16_t)(v[i] & 0xffffu);
-      Vt[(g * 8 + 2 * i + 1) * ATT_VPITCH + key] = (uint16_t)(v[i] >> 16);
+      vt32[((g * 8 + 2 * i) * ATT_VPITCH + key) >> 1] = (v0[i] & 0xffffu) | (v1[i] << 16);
+      vt32[((g * 8 + 2 * i + 1) * ATT_VPITCH + key) >> 1] = (v0[i] >> 16) | (v1[i] & 0xffff0000u);
     }
   }
   if (tid < 32) Vt[32 * ATT_VPITCH + tid] = 0;
