@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("KVQ_OPERAND_DTYPE", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="split each step's batch over this many HIP streams (independent clips: the VALU-bound "
                          "attention of one half can overlap the MFMA-bound GEMMs of the other)")
     ap.add_argument("--profile-steps", type=int, default=3)
