@@ -27,24 +27,10 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "tail.hpp"
 
 namespace kvq {
 
-struct TailParams {
-  const uint16_t* attn;      // [M][C] 16-bit, window order
-  float* x;                  // [n_batch*out_rows][C] fp32, in place
-  const int32_t* map;        // window row -> token of the batch element (or <0 = padding); NULL = identity
-  int map_rows, out_rows, M, hidden;
-  const unsigned char* pack; // kvq_block_tail_pack image
-  const float* nn_w;         // next block's norm1 (EMIT)
-  const float* nn_b;
-  const int32_t* next_dst;   // token -> window row of the next block's partition
-  uint16_t* next_ln;         // [n_batch*next_rows][C]
-  int next_rows;
-  float eps;
-  unsigned long long* trace;   // diagnostic stamps (kvq_debug_gemm_trace; -DKVQ_TAIL_TRACE builds only)
-  int trace_blocks;
-};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
@@ -483,11 +469,14 @@ static int launch_tail_e(const TailParams& p, int C, hipStream_t st) {
 
 extern "C" int kvq_block_tail_supported(int C, int hidden) {
   // hidden/32 even and >= 4: the MLP pipeline rotates two accumulators
+  static const bool wide = !(getenv("KVQ_TAIL16") && atoi(getenv("KVQ_TAIL16")) == 0);   // C = 384: csrc/tail16.hip
+  if (wide && kvq::tail16_supported(C, hidden)) return 1;
   return (C == 96 || C == 128 || C == 192) && hidden % 64 == 0 && hidden >= 128 ? 1 : 0;
 }
 
 extern "C" size_t kvq_block_tail_pack_bytes(int C, int hidden) {
   if (!kvq_block_tail_supported(C, hidden)) return 0;
+  if (kvq::tail16_supported(C, hidden)) return kvq::tail16_pack_bytes(C, hidden);
   return kvq::tail_items(C, hidden) * kvq::tail_slot_bytes(C) + kvq::tail_param_bytes(C, hidden);
 }
 
@@ -498,6 +487,9 @@ extern "C" int kvq_block_tail_pack(const void* proj_w, const float* proj_b, cons
   KVQ_REQUIRE(proj_w && proj_b && norm2_w && norm2_b && fc1_w && fc1_b && fc2_w && fc2_b && pack, KVQ_ERR_NULL,
               "kvq_block_tail_pack: NULL pointer");
   KVQ_REQUIRE(kvq_block_tail_supported(C, hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail_pack: C=%d hidden=%d", C, hidden);
+  if (tail16_supported(C, hidden))
+    return tail16_pack((const uint16_t*)proj_w, (const uint16_t*)fc1_w, (const uint16_t*)fc2_w, proj_b, norm2_w, norm2_b, fc1_b,
+                       fc2_b, C, hidden, (unsigned char*)pack, (hipStream_t)stream);
   const long n_chunks = (long)tail_items(C, hidden) * tail_slot_bytes(C) / 16;
   const long n_par = (long)tail_param_bytes(C, hidden) / 4;
   const long total = n_chunks + n_par;
@@ -522,6 +514,7 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
   p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;
+  if (tail16_supported(a->C, a->hidden)) return tail16_launch(p, a->C, a->dtype, (hipStream_t)stream);
   return a->dtype == KVQ_DT_FP16 ? launch_tail_e<Fp16>(p, a->C, (hipStream_t)stream)
                                  : launch_tail_e<Bf16>(p, a->C, (hipStream_t)stream);
 }

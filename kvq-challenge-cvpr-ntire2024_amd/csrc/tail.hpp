@@ -1,0 +1,31 @@
+// Shared between tail.hip (32x32 MFMA, C <= 192) and tail16.hip (16x16 MFMA, C = 384): launch parameters of the fused
+// post-attention launch and the entry points of the wide variant.
+#pragma once
+#include "common.hpp"
+
+namespace kvq {
+
+struct TailParams {
+  const uint16_t* attn;      // [M][C] 16-bit, window order
+  float* x;                  // [n_batch*out_rows][C] fp32, in place
+  const int32_t* map;        // window row -> token of the batch element (or <0 = padding); NULL = identity
+  int map_rows, out_rows, M, hidden;
+  const unsigned char* pack; // kvq_block_tail_pack image
+  const float* nn_w;         // next block's norm1 (EMIT)
+  const float* nn_b;
+  const int32_t* next_dst;   // token -> window row of the next block's partition
+  uint16_t* next_ln;         // [n_batch*next_rows][C]
+  int next_rows;
+  float eps;
+  unsigned long long* trace;   // diagnostic stamps (kvq_debug_gemm_trace; -DKVQ_TAIL_TRACE builds only)
+  int trace_blocks;
+};
+
+// csrc/tail16.hip
+bool tail16_supported(int C, int hidden);
+size_t tail16_pack_bytes(int C, int hidden);
+int tail16_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
+                const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st);
+int tail16_launch(const TailParams& p, int C, int dtype, hipStream_t st);
+
+}  // namespace kvq

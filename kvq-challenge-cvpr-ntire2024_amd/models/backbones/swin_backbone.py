@@ -394,6 +394,8 @@ class SwinTransformer3D(nn.Module):
                 cm = r.variant // 10
                 nw = os.environ.get("KVQ_TAIL_NW") or 4
                 sym = f"block_tail_kernel<{ename}, {cm}, {nw}, {str(bool(r.variant % 10)).lower()}>"
+                if cm == 12:     # C = 384: the 16x16-MFMA variant (csrc/tail16.hip), CT = C / 16 channel tiles
+                    sym = f"block_tail16_kernel<{ename}, 24, {str(bool(r.variant % 10)).lower()}>"
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))

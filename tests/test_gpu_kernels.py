@@ -389,7 +389,10 @@ def _tail_reference(A, x, wts, half, lay, B, dims):
                                                    (96, (4, 10, 9), (4, 3, 3), None),      # padded: no emission
                                                    (128, (8, 7, 14), (4, 3, 3), (0, 0, 0)),
                                                    (192, (8, 14, 7), (0, 0, 0), (4, 3, 3)),
-                                                   (192, (3, 5, 7), (0, 0, 0), None)])     # clamped window, ragged tile
+                                                   (192, (3, 5, 7), (0, 0, 0), None),      # clamped window, ragged tile
+                                                   (384, (8, 14, 14), (0, 0, 0), (4, 3, 3)),   # wide rows: csrc/tail16.hip
+                                                   (384, (8, 7, 7), (0, 0, 0), (0, 0, 0)),
+                                                   (384, (4, 10, 9), (4, 3, 3), None)])
 def test_block_tail(C, dims, shift, nxt_shift, half):
     g = rng(C + sum(dims))
     D, H, W = dims
@@ -438,10 +441,10 @@ def test_block_tail_identity_map_and_unsupported(half):
     kernels.block_tail(dev(A, half), xd, pack, hidden)
     ref = _tail_reference(A, x, (Wp, bp, g2, b2n, W1, b1, W2, b2), half, None, 1, None)
     assert (xd.cpu() - ref).abs().max().item() <= 6 * EPS[half] * ref.abs().max().item() + 1e-4
-    assert _abi.lib().kvq_block_tail_pack_bytes(384, 1536) == 0
+    assert _abi.lib().kvq_block_tail_pack_bytes(768, 3072) == 0
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.block_tail_pack(*(dev(torch.zeros(s), half if len(s) == 2 else None) for s in
-                                  [(384, 384), (384,), (384,), (384,), (1536, 384), (1536,), (384, 1536), (384,)]))
+                                  [(768, 768), (768,), (768,), (768,), (3072, 768), (3072,), (768, 3072), (768,)]))
 
 
 # ------------------------------------------------------------------ fused PatchEmbed3D (embed.hip)

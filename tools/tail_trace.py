@@ -38,4 +38,7 @@ def run(M, C, emit=False):
     print(f"   {'lifetime':26} mean {d.mean():9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f} ticks")
 
 if __name__ == "__main__":
-    run(200704, 96); run(200704, 96, True); run(50176, 192); run(50176, 192, True)
+    if len(sys.argv) > 2:
+        run(int(sys.argv[1]), int(sys.argv[2]), True)
+    else:
+        run(200704, 96); run(200704, 96, True); run(50176, 192); run(50176, 192, True)
