@@ -33,9 +33,12 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("KVQ_OPERAND_DTYPE", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="split each step's batch over this many HIP streams (independent clips: the VALU-bound "
-                         "attention of one half can overlap the MFMA-bound GEMMs of the other)")
+    ap.add_argument("--overlap", choices=["batch", "steps"], default="steps",
+                    help="with --streams > 1: 'batch' splits each step's clips over the streams, 'steps' sends whole "
+                         "consecutive steps to alternating streams")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps are issued on (independent batches: the VALU-bound attention of one "
+                         "can overlap the MFMA-bound GEMMs of another, launch gaps and tails are filled)")
     ap.add_argument("--profile-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -108,6 +111,7 @@ def main():
     nstream = max(1, args.streams)
     side = [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
     parts = [{"technical": t.contiguous()} for t in x.chunk(nstream)]
+    by_step = args.overlap == "steps" and nstream > 1
 
     def forward():
         """one step = the whole batch once; with --streams > 1 the clips are split over HIP streams"""
@@ -125,15 +129,30 @@ def main():
             main.wait_stream(st)
         return torch.cat(outs)
 
+    def run_steps(n, out):
+        if not by_step:
+            for s in range(n):
+                out[s] = forward()
+            return
+        # consecutive steps (whole batches, independent of each other) go to alternating HIP streams: every launch keeps the
+        # full batch's grid, the streams fill each other's launch gaps and tails; all n steps end before the caller's sync
+        main = torch.cuda.current_stream()
+        lanes = [main] + side
+        for st in side:
+            st.wait_stream(main)
+        for s in range(n):
+            with torch.cuda.stream(lanes[s % nstream]):
+                out[s] = net(inputs=inputs, reduce_scores=True).reshape(-1)
+        for st in side:
+            main.wait_stream(st)
+
     with torch.no_grad():
-        for _ in range(args.warmup):
-            forward()
+        run_steps(args.warmup, torch.zeros(max(args.warmup, 1), B, device=device))
         torch.cuda.synchronize()
         kd.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for s in range(args.steps):
-            scores[s] = forward()
+        run_steps(args.steps, scores)
         # the path's one exchange step: all-gather of the per-rank score vectors (trainer_ddp.py:259-267)
         local = scores.reshape(-1)
         allscores = kd.gather_scores(local, local.numel() * world, rank, world) if world > 1 else local
@@ -194,7 +213,7 @@ def main():
             "config": {"workload": "C2: KSVQE Swin3D-T(GRPB) trunk + VQAHead, 3x32x224x224 clips, video = 8 clips",
                        "clips_per_gpu_per_step": B, "operand_dtype": args.dtype, "accumulate": "fp32",
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
-                       "streams": nstream},
+                       "streams": nstream, "overlap": args.overlap if nstream > 1 else "none"},
             "clips_per_s": clips / dt,
             "model_tflops": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3,
             "score_checksum": float(allscores.double().sum().item()),

@@ -170,11 +170,41 @@ class SwinTransformer3D(nn.Module):
                     p.zero_()
         if isinstance(self.pretrained, str):
             if self.pretrained2d:
-                raise NotImplementedError("2D->3D inflation (swin_backbone.py:858-931) is a checkpoint-format "
-                                          "row (SURVEY.md §8 f3), not built yet")
-            self.load_swin(self.pretrained)
+                self.inflate_weights()
+            else:
+                self.load_swin(self.pretrained)
         elif self.pretrained is not None:
             raise TypeError("pretrained must be a str or None")
+
+    def inflate_weights(self):
+        """Reference ``inflate_weights`` (swin_backbone.py:858-931): load a 2D Swin checkpoint (``{"model": ...}``)
+        into the 3D trunk.  ``relative_position_index`` / ``attn_mask`` entries are dropped (always re-derived);
+        the patch-embed conv is repeated along the new temporal axis and divided by its depth (so a clip of
+        identical frames embeds like the image did); every (L1, nH) bias table is bicubically resized to the
+        (2·ws_h−1)·(2·ws_w−1) in-plane offsets when the 2D window differs, then tiled over the 2·ws_d−1 temporal
+        offsets.  Tables whose head count differs are reported and still tiled as they are — load_state_dict then
+        rejects them, as in the reference.  Host-side, once per load: plain torch CPU ops."""
+        state = dict(torch.load(self.pretrained, map_location="cpu")["model"])
+        for k in [k for k in state if "relative_position_index" in k or "attn_mask" in k]:
+            del state[k]
+        pt = self.patch_size[0]
+        state["patch_embed.proj.weight"] = state["patch_embed.proj.weight"].unsqueeze(2).repeat(1, 1, pt, 1, 1) / pt
+        own = self.state_dict()
+        wd, sh, sw = self.window_size[0], 2 * self.window_size[1] - 1, 2 * self.window_size[2] - 1
+        for k in [k for k in state if "relative_position_bias_table" in k]:
+            tab = state[k]
+            (l1, nh1), nh2 = tab.shape, own[k].shape[1]
+            if nh1 != nh2:
+                print(f"Error in loading {k}, passing")
+            elif l1 != sh * sw:
+                s1 = int(l1 ** 0.5)
+                tab = torch.nn.functional.interpolate(tab.permute(1, 0).reshape(1, nh1, s1, s1), size=(sh, sw),
+                                                      mode="bicubic").reshape(nh2, sh * sw).permute(1, 0)
+            state[k] = tab.repeat(2 * wd - 1, 1)
+        msg = self.load_state_dict(state, strict=False)
+        print(msg)
+        print(f"=> loaded successfully '{self.pretrained}'")
+        return msg
 
     def load_swin(self, load_path, strict=False):
         """Reference ``load_swin`` (swin_backbone.py:933-1006): strip the 9-char ``backbone.`` prefix,

@@ -35,11 +35,16 @@ class Trainer:
         self.model = VQA_Network(self.config).to(self.device).eval()
         path = self.config.get("load_path")
         if path:
-            state = torch.load(path, map_location="cpu")
-            state = state.get("state_dict", state)
-            # DataParallel / DDP checkpoints carry a 'module.' prefix (trainer.py:62-74, trainer_ddp.py:74-79)
-            state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
-            print("load:", self.model.load_state_dict(state, strict=False))
+            print("load:", self.load_checkpoint(self.model, path))
+
+    @staticmethod
+    def load_checkpoint(model, path):
+        """DataParallel / DDP checkpoints carry a 'module.' prefix (trainer.py:62-74, trainer_ddp.py:74-79);
+        either the bare state dict or ``{"state_dict": ...}``; non-strict like the reference."""
+        state = torch.load(path, map_location="cpu")
+        state = state.get("state_dict", state)
+        state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
+        return model.load_state_dict(state, strict=False)
 
     def build_datasets(self):
         cfg = self.config["data"]["val"]

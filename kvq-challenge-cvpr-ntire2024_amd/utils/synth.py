@@ -192,6 +192,45 @@ def synth_swin_weights(cfg: SwinCfg = SWIN_T_GRPB, seed: int = 0, scheme: str = 
     return synth_params(swin_param_shapes(cfg), seed, scheme)
 
 
+def synth_swin2d_checkpoint(cfg: SwinCfg = SWIN_T_GRPB, seed: int = 0, window2d: int = 7):
+    """A synthetic 2D-Swin checkpoint body (the ``{"model": ...}`` dict ``inflate_weights`` reads, reference
+    swin_backbone.py:858-931): the 3D trunk's own keys with the patch-embed conv collapsed to (E, 3, ph, pw), every
+    relative-position table in its 2D size ((2·window2d−1)², nH), no fragment tables, plus the
+    ``relative_position_index`` / ``attn_mask`` buffers a 2D checkpoint carries (the loader must drop them)."""
+    w3 = synth_swin_weights(cfg, seed, "stress")
+    out = OrderedDict()
+    for k, v in w3.items():
+        if "fragment_position_bias_table" in k:
+            continue
+        if k == "patch_embed.proj.weight":
+            out[k] = np.ascontiguousarray(v[:, :, 0])
+        elif "relative_position_bias_table" in k:
+            out[k] = _gen(seed, "2d/" + k).standard_normal(((2 * window2d - 1) ** 2, v.shape[1])).astype(np.float32)
+            n = window2d * window2d
+            out[k.replace("relative_position_bias_table", "relative_position_index")] = \
+                _gen(seed, "2di/" + k).integers(0, (2 * window2d - 1) ** 2, (n, n)).astype(np.int64)
+        else:
+            out[k] = v
+    out["layers.0.blocks.1.attn_mask"] = np.zeros((64, window2d * window2d, window2d * window2d), np.float32)
+    return out
+
+
+def synth_swin3d_checkpoint(cfg: SwinCfg = SWIN_T_GRPB, seed: int = 0):
+    """A synthetic Video-Swin (mmaction-style) checkpoint body (the ``{"state_dict": ...}`` dict ``load_swin`` reads,
+    reference swin_backbone.py:933-1006): trunk keys under ``backbone.`` WITHOUT fragment tables (the loader forks
+    them from the relative tables), a classifier head that must be ignored and one key of the wrong shape that
+    must be dropped."""
+    w3 = synth_swin_weights(cfg, seed, "stress")
+    out = OrderedDict()
+    for k, v in w3.items():
+        if "fragment_position_bias_table" not in k:
+            out["backbone." + k] = v
+    out["backbone.norm.weight"] = np.ones((cfg.num_features + 1,), np.float32)      # shape mismatch: dropped
+    out["cls_head.fc_cls.weight"] = _gen(seed, "cls").standard_normal((400, cfg.num_features)).astype(np.float32)
+    out["cls_head.fc_cls.bias"] = np.zeros((400,), np.float32)
+    return out
+
+
 def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
     return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
 

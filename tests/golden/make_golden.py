@@ -270,7 +270,54 @@ def sec_resnet(ref):
     save("resnet.npz", d)
 
 
-SECTIONS = {"resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+def sec_ckpt(ref):
+    """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
+    dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
+    import contextlib
+    import io
+    import tempfile
+    from kvq_amd.models.backbones.swin_backbone import SwinTransformer3D as Mine
+    d = {}
+    cfg = synth.SWIN_T_GRPB
+    tmp = tempfile.mkdtemp(prefix="kvq_ckpt_")
+    cases = [("inflate_w7", "2d", 7), ("inflate_w12", "2d", 12), ("load_swin", "3d", 0)]
+    for name, kind, w2d in cases:
+        path = os.path.join(tmp, name + ".pth")
+        if kind == "2d":
+            body = {"model": {k: torch.from_numpy(v) for k, v in synth.synth_swin2d_checkpoint(cfg, 5, w2d).items()}}
+        else:
+            body = {"state_dict": {k: torch.from_numpy(v) for k, v in synth.synth_swin3d_checkpoint(cfg, 6).items()}}
+        torch.save(body, path)
+        m = _ref_trunk(ref, cfg)
+        mine = Mine()
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            if kind == "2d":
+                m.pretrained = path
+                m.inflate_weights()
+                mine.pretrained = path
+                mine.inflate_weights()
+            else:
+                m.load_swin(path)
+                mine.load_swin(path)
+        sr, sm = m.state_dict(), mine.state_dict()
+        keys = [k for k in sr if "relative_position_index" not in k and (
+            "position_bias_table" in k or k.startswith("patch_embed") or k.startswith("norm") or "blocks.1.attn.qkv" in k)]
+        worst = 0.0
+        for k in keys:
+            worst = max(worst, float((sr[k] - sm[k]).abs().max()))
+            if kind == "3d" and "fragment_position_bias_table" not in k and k != "norm.weight" and not k.startswith("patch_embed.norm"):
+                assert (sr[k] - sm[k]).abs().max() == 0
+        print(f"{name}: {len(keys)} tensors, |mine - ref| max {worst:.2e}")
+        assert worst <= 1e-6
+        for k in keys:
+            put(d, f"{name}/{k}", samples(sr[k].numpy(), 256))
+        d[f"{name}/keys"] = np.asarray(keys)
+    d["cases"] = np.asarray([c[0] for c in cases])
+    save("ckpt.npz", d)
+
+
+SECTIONS = {"ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():
