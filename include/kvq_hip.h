@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 6
+#define KVQ_ABI_VERSION 7
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -135,6 +135,20 @@ int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
  * When score != NULL the VQAHead (models/head.py:60-68) is applied too (see kvq_vqa_head). */
 int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, float* feat,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Feature taps of SwinTransformer3D.forward (swin_backbone.py:1060-1078: ``feats = [embed, stage 0, ..., stage n-1]``,
+ * read by ``multi=True`` and ``layer > -1``).  taps[i] (i = 0..num_stages) is NULL or a caller-owned fp32 channels-LAST
+ * buffer (B, D, H_i, W_i, C_i) that every following kvq_swin3d_forward on this plan fills with feats[i] (the residual
+ * stream after the patch embedding / after stage i-1 including its PatchMerging); taps == NULL clears them.
+ * kvq_swin3d_tap_dims: C_i, D, H_i, W_i. */
+int kvq_swin3d_set_taps(KvqSwinPlan* plan, float* const* taps);
+int kvq_swin3d_tap_dims(const KvqSwinPlan* plan, int index, int32_t out4[4]);
+
+/* F.interpolate(mode="trilinear", align_corners=False) on a channels-last fp32 volume, written into channels
+ * [c_off, c_off + C) of a channels-last destination with c_total channels (the torch.cat of multi=True,
+ * swin_backbone.py:1070-1075).  src (B, D, H, W, C) -> dst (B, Do, Ho, Wo, c_total). */
+int kvq_resize_trilinear_cl(const float* src, int B, int D, int H, int W, int C, float* dst, int Do, int Ho, int Wo,
+                            int c_total, int c_off, void* stream);
 
 /* Dense attention bias of weights->blocks[block] for this plan's geometry (see kvq_attn_bias_dense_build): size
  * and builder.  Independent of the batch size; rebuild when the block's tables change. */

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16 = range(6)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def dtype_code(dt) -> int:
@@ -99,6 +99,9 @@ SYMBOLS = {
     "kvq_swin3d_plan_destroy": (None, [p_void]),
     "kvq_swin3d_workspace_bytes": (sz, [p_void]),
     "kvq_swin3d_out_dims": (i32, [p_void, C.POINTER(i32 * 4)]),
+    "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
+    "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),
+    "kvq_resize_trilinear_cl": (i32, [p_void, i32, i32, i32, i32, i32, p_void, i32, i32, i32, i32, i32, p_void]),
     "kvq_swin3d_forward": (i32, [p_void, C.POINTER(KvqSwinWeights), p_void, p_void, p_void, sz, p_void]),
     "kvq_swin3d_profile": (i32, [p_void, i32]),
     "kvq_swin3d_profile_read": (i32, [p_void, C.POINTER(KvqProfRecord), i32, C.POINTER(i32)]),

@@ -385,3 +385,56 @@ extern "C" int kvq_fragment_gather(const void* video, int src_is_u8, int C, int 
   KVQ_CHECK_LAUNCH("fragment_gather_kernel");
   return KVQ_OK;
 }
+
+// ---- trilinear resize, channels-last (the torch.cat of multi=True feature taps, swin_backbone.py:1070-1075) --------
+namespace kvq {
+// ATen area_pixel_compute_source_index, align_corners = False, linear modes: max(0, scale * (dst + 0.5) - 0.5)
+__device__ __forceinline__ void lin_src(int dst, int in, int out, int& i0, int& i1, float& lam) {
+  if (in == out) { i0 = i1 = dst; lam = 0.f; return; }
+  const float scale = (float)in / (float)out;
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i0 = i0 < in - 1 ? i0 : in - 1;
+  i1 = i0 < in - 1 ? i0 + 1 : i0;
+  lam = s - (float)i0;
+}
+
+__global__ void resize_trilinear_cl_kernel(const float* __restrict__ src, int D, int H, int W, int C, float* __restrict__ dst,
+                                           int Do, int Ho, int Wo, int c_total, int c_off, long total) {
+  const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total) return;
+  const int c = (int)(gi % C);
+  long r = gi / C;
+  const int wo = (int)(r % Wo); r /= Wo;
+  const int ho = (int)(r % Ho); r /= Ho;
+  const int dd = (int)(r % Do);
+  const long b = r / Do;
+  int d0, d1, h0, h1, w0, w1;
+  float ld, lh, lw;
+  lin_src(dd, D, Do, d0, d1, ld);
+  lin_src(ho, H, Ho, h0, h1, lh);
+  lin_src(wo, W, Wo, w0, w1, lw);
+  auto at = [&](int d, int h, int w) { return src[(((b * D + d) * H + h) * (long)W + w) * C + c]; };
+  // ATen upsample_trilinear3d order: w, then h, then d
+  const float v00 = (1.f - lw) * at(d0, h0, w0) + lw * at(d0, h0, w1);
+  const float v01 = (1.f - lw) * at(d0, h1, w0) + lw * at(d0, h1, w1);
+  const float v10 = (1.f - lw) * at(d1, h0, w0) + lw * at(d1, h0, w1);
+  const float v11 = (1.f - lw) * at(d1, h1, w0) + lw * at(d1, h1, w1);
+  const float v0 = (1.f - lh) * v00 + lh * v01, v1 = (1.f - lh) * v10 + lh * v11;
+  dst[(((b * Do + dd) * Ho + ho) * (long)Wo + wo) * c_total + c_off + c] = (1.f - ld) * v0 + ld * v1;
+}
+}  // namespace kvq
+
+extern "C" int kvq_resize_trilinear_cl(const float* src, int B, int D, int H, int W, int C, float* dst, int Do, int Ho, int Wo,
+                                       int c_total, int c_off, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(src && dst, KVQ_ERR_NULL, "kvq_resize_trilinear_cl: NULL pointer");
+  KVQ_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Do > 0 && Ho > 0 && Wo > 0 && c_off >= 0 && c_off + C <= c_total,
+              KVQ_ERR_SHAPE, "kvq_resize_trilinear_cl: bad geometry");
+  const long total = (long)B * Do * Ho * Wo * C;
+  hipLaunchKernelGGL(resize_trilinear_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     D, H, W, C, dst, Do, Ho, Wo, c_total, c_off, total);
+  KVQ_CHECK_LAUNCH("resize_trilinear_cl_kernel");
+  return KVQ_OK;
+}

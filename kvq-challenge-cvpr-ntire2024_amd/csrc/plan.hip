@@ -48,6 +48,7 @@ struct KvqSwinPlan {
   size_t ws_bytes;
   size_t off_x0, off_x1, off_ln, off_big, off_o;
   int table_len, center;
+  std::vector<float*> taps;      // feats[i] destinations (kvq_swin3d_set_taps), empty = none
   // profiling
   bool profile;
   std::vector<kvq::ProfEvent> events;
@@ -346,6 +347,26 @@ static int ln(KvqSwinPlan* pl, hipStream_t st, const float* x, const int32_t* ma
     if (_rc) return _rc;   \
   } while (0)
 
+extern "C" int kvq_swin3d_set_taps(KvqSwinPlan* pl, float* const* taps) {
+  KVQ_REQUIRE(pl, KVQ_ERR_NULL, "kvq_swin3d_set_taps: NULL plan");
+  pl->taps.clear();
+  if (taps) pl->taps.assign(taps, taps + pl->cfg.num_stages + 1);
+  return KVQ_OK;
+}
+
+extern "C" int kvq_swin3d_tap_dims(const KvqSwinPlan* pl, int index, int32_t out4[4]) {
+  KVQ_REQUIRE(pl && out4, KVQ_ERR_NULL, "kvq_swin3d_tap_dims: NULL");
+  KVQ_REQUIRE(index >= 0 && index <= pl->cfg.num_stages, KVQ_ERR_SHAPE, "kvq_swin3d_tap_dims: index %d", index);
+  if (index == 0) {
+    out4[0] = pl->cfg.embed_dim; out4[1] = pl->D0; out4[2] = pl->H0; out4[3] = pl->W0;
+    return KVQ_OK;
+  }
+  const kvq::StageGeom& g = pl->st[index - 1];
+  const bool merged = index - 1 < pl->cfg.num_stages - 1;
+  out4[0] = merged ? 2 * g.C : g.C; out4[1] = merged ? g.Dn : g.D; out4[2] = merged ? g.Hn : g.H; out4[3] = merged ? g.Wn : g.W;
+  return KVQ_OK;
+}
+
 extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float* x, float* feat,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   using namespace kvq;
@@ -401,6 +422,12 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
       cur = xb; oth = xa;
     }
   }
+  auto tap = [&](int idx, size_t elems) -> int {          // feats[idx] of the reference's forward (multi / layer)
+    if (pl->taps.empty() || !pl->taps[idx]) return KVQ_OK;
+    KVQ_CHECK_HIP(hipMemcpyAsync(pl->taps[idx], cur, elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return KVQ_OK;
+  };
+  KVQ_TRY(tap(0, (size_t)B * L0 * E));
 
   int blk = 0;
   for (int i = 0; i < cfg.num_stages; ++i) {
@@ -468,6 +495,9 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
                    oth));
       float* t = cur; cur = oth; oth = t;
+      KVQ_TRY(tap(i + 1, (size_t)B * Ln * 2 * C));
+    } else {
+      KVQ_TRY(tap(i + 1, (size_t)ML * C));
     }
   }
   const StageGeom& gl = pl->st.back();

@@ -378,8 +378,8 @@ class SwinTransformer3D(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, batch, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
         """``batch['technical']``: fp32 (B,3,T,H,W) on a HIP device -> (B, C_out, T/2, H/32, W/32)."""
-        if multi or layer > -1 or adaptive_window_size:
-            raise NotImplementedError("multi / layer taps / adaptive windows: SURVEY.md §8 row f4 (no caller sets them)")
+        if adaptive_window_size:
+            raise NotImplementedError("adaptive windows (swin_backbone.py:1051-1054): no caller sets them")
         x = batch["technical"]
         if not x.is_cuda:
             raise _abi.KvqError("SwinTransformer3D.forward needs the clip on a HIP device; there is no CPU path")
@@ -389,8 +389,40 @@ class SwinTransformer3D(nn.Module):
         w = self._weights(x.device)
         self._set_dense_bias(handle, (T, H, W), x.device, B)
         feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
-        check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), current_stream()),
-              "kvq_swin3d_forward")
+        taps = None
+        if multi or layer > -1:
+            # feats = [embed, stage 0, ..., stage n-1] (swin_backbone.py:1060-1064): filled by the same forward
+            n = self.num_layers + 1
+            if layer >= n:
+                raise IndexError("list index out of range")          # feats[layer] in the reference
+            want = range(n - 1) if multi else [layer]
+            taps, arr = [None] * n, (C.c_void_p * n)()
+            for i in want:
+                d4 = (C.c_int32 * 4)()
+                check(lib().kvq_swin3d_tap_dims(handle, i, C.byref(d4)), "kvq_swin3d_tap_dims")
+                taps[i] = torch.empty(B, d4[1], d4[2], d4[3], d4[0], dtype=torch.float32, device=x.device)
+                arr[i] = ptr(taps[i])
+            check(lib().kvq_swin3d_set_taps(handle, arr), "kvq_swin3d_set_taps")
+        try:
+            check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), current_stream()),
+                  "kvq_swin3d_forward")
+        finally:
+            if taps is not None:
+                check(lib().kvq_swin3d_set_taps(handle, None), "kvq_swin3d_set_taps")
+        if multi:
+            # torch.cat([F.interpolate(f, size=final (D,H,W), mode="trilinear") for f in feats[:-1]], 1) (:1070-1075)
+            ctot = sum(t.shape[-1] for t in taps if t is not None)
+            out = torch.empty(B, D, Hh, Ww, ctot, dtype=torch.float32, device=x.device)
+            off = 0
+            for t in taps:
+                if t is None:
+                    continue
+                check(lib().kvq_resize_trilinear_cl(ptr(t), B, t.shape[1], t.shape[2], t.shape[3], t.shape[4], ptr(out), D, Hh,
+                                                    Ww, ctot, off, current_stream()), "kvq_resize_trilinear_cl")
+                off += t.shape[4]
+            return out.permute(0, 4, 1, 2, 3)
+        if layer > -1:
+            return taps[layer].permute(0, 4, 1, 2, 3)
         return feat.permute(0, 4, 1, 2, 3)      # channels-last storage, reference's (B,C,D,H,W) view
 
     # profiling hooks used by bench.py ------------------------------------------------------

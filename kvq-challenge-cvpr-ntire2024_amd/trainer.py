@@ -11,6 +11,8 @@ Training (optimizer, losses, EMA, checkpoints) is out of scope: this is an infer
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -74,9 +76,19 @@ class Trainer:
         n = len(self.val_dataset)
         mine = kd.shard_indices(n, self.rank, self.world)
         local = torch.empty(len(mine), dtype=torch.float32, device=self.device)
+        # videos are independent (batch_size 1, trainer.py:256-283): consecutive videos go to alternating HIP streams so
+        # that one video's latency-bound launches fill the gaps of another's; nothing synchronises with the host per video
+        nstream = max(1, int(self.config.get("streams", os.environ.get("KVQ_STREAMS", 3))))
+        main = torch.cuda.current_stream(self.device)
+        lanes = [main] + [torch.cuda.Stream(device=self.device) for _ in range(nstream - 1)]
+        for st in lanes[1:]:
+            st.wait_stream(main)
         for j, i in enumerate(mine):
-            pred = self._forward_video(self.val_dataset[i])
-            local[j] = pred.float().mean()                    # pred.mean(0) over clips (trainer.py:282)
+            with torch.cuda.stream(lanes[j % nstream]):
+                pred = self._forward_video(self.val_dataset[i])
+                local[j] = pred.float().mean()                # pred.mean(0) over clips (trainer.py:282)
+        for st in lanes[1:]:
+            main.wait_stream(st)
         return kd.gather_scores(local, n, self.rank, self.world).cpu().numpy()
 
     def inferece_test(self):

@@ -270,6 +270,35 @@ def sec_resnet(ref):
     save("resnet.npz", d)
 
 
+def sec_taps(ref):
+    """multi=True / layer>-1 feature taps of SwinTransformer3D.forward (swin_backbone.py:1060-1078)."""
+    import contextlib
+    import io
+    import torch.nn.functional as F
+    d = {}
+    name, cfgn, scheme, wseed, cseed, B, T, H, W = TRUNK_CASES[0]
+    cfg = getattr(synth, cfgn)
+    wts = synth.synth_swin_weights(cfg, wseed, scheme)
+    m = _ref_trunk(ref, cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=False)
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B))
+    with contextlib.redirect_stdout(io.StringIO()):
+        multi_ref = m({"technical": x}, multi=True)
+        layers_ref = [m({"technical": x}, layer=i) for i in range(5)]
+    feat, stages = O.swin3d_trunk(x, wts, cfg, return_stages=True)
+    st_cf = [s.permute(0, 4, 1, 2, 3) for s in stages]
+    multi = torch.cat([F.interpolate(s, size=feat.shape[2:], mode="trilinear") for s in st_cf[:-1]], 1)
+    e1 = float((multi - multi_ref).abs().max())
+    e2 = max(float((a - b).abs().max()) for a, b in zip(st_cf, layers_ref))
+    print(f"taps {name}: multi {tuple(multi_ref.shape)} |oracle-ref| {e1:.2e}; layers {e2:.2e}")
+    assert e1 <= 2e-5 and e2 <= 2e-5
+    put(d, "multi", samples(multi_ref.numpy(), 4096))
+    for i, t in enumerate(layers_ref):
+        put(d, f"layer{i}", samples(t.contiguous().numpy(), 2048))
+    d["case"] = np.asarray(name)
+    save("taps.npz", d)
+
+
 def sec_ckpt(ref):
     """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
     dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
@@ -317,7 +346,7 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

@@ -212,3 +212,47 @@ def test_config3_trunk_and_slowfast_on_the_same_clips():
         slow, fast = sf(pack_pathway_output(x))
     assert s.shape == (2, 1) and slow.shape == (2, 2048, 1, 1, 1) and fast.shape == (2, 256, 1, 1, 1)
     assert torch.isfinite(s).all() and torch.isfinite(slow).all() and torch.isfinite(fast).all()
+
+
+def test_feature_taps_multi_and_layer_vs_reference_golden(golden):
+    """``multi=True`` (trilinear-resized concat of feats[:-1]) and ``layer=i`` (feats[i]) of the trunk's forward
+    (swin_backbone.py:1060-1078) against the reference's outputs; the taps come out of the same HIP forward."""
+    g, t = golden("taps.npz"), golden("trunk.npz")
+    case = str(g["case"])
+    wseed, cseed, B, T, H, W = (int(v) for v in t[f"{case}/meta"])
+    net, key = build_network(str(t[f"{case}/cfg"]), wseed, str(t[f"{case}/scheme"]), "fp16")
+    bb = getattr(net, key + "_backbone")
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B)).to(DEV)
+    with torch.no_grad():
+        outs = {"multi": bb({"technical": x}, multi=True)}
+        for i in range(5):
+            outs[f"layer{i}"] = bb({"technical": x}, layer=i)
+        plain = bb({"technical": x})                      # the taps are cleared again: the plain forward is unchanged
+    for name, o in outs.items():
+        a = np.ascontiguousarray(o.cpu().numpy())
+        assert tuple(g[f"{name}/shape"]) == a.shape, name
+        got, ref = a.reshape(-1)[g[f"{name}/idx"]], g[f"{name}/val"]
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel <= FEAT_REL_L2["fp16"], (name, rel)
+    ref = t[f"{case}/feat/val"]
+    got = np.ascontiguousarray(plain.cpu().numpy()).reshape(-1)[t[f"{case}/feat/idx"]]
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= FEAT_REL_L2["fp16"]
+    with pytest.raises(IndexError):
+        bb({"technical": x}, layer=5)
+
+
+def test_resize_trilinear_cl_matches_interpolate():
+    """kvq_resize_trilinear_cl == F.interpolate(mode='trilinear', align_corners=False) (fp32, 1e-6)."""
+    import ctypes as C
+    from kvq_amd._abi import check, lib, ptr
+    from kvq_amd.kernels import current_stream
+    gen = torch.Generator().manual_seed(3)
+    for (B, D, H, W, Cc), (Do, Ho, Wo) in [((2, 4, 20, 20, 96), (4, 3, 3)), ((1, 5, 7, 9, 32), (8, 14, 5)), ((1, 2, 3, 3, 8), (2, 3, 3))]:
+        src = torch.randn(B, D, H, W, Cc, generator=gen)
+        ref = torch.nn.functional.interpolate(src.permute(0, 4, 1, 2, 3), size=(Do, Ho, Wo), mode="trilinear").permute(0, 2, 3, 4, 1)
+        s = src.to(DEV)
+        out = torch.zeros(B, Do, Ho, Wo, Cc + 5, device=DEV)
+        check(lib().kvq_resize_trilinear_cl(ptr(s), B, D, H, W, Cc, ptr(out), Do, Ho, Wo, Cc + 5, 3, current_stream()), "resize")
+        got = out.cpu()
+        assert (got[..., 3:3 + Cc] - ref).abs().max().item() <= 1e-5
+        assert got[..., :3].abs().max().item() == 0 and got[..., 3 + Cc:].abs().max().item() == 0
