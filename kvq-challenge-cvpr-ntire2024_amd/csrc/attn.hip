@@ -331,12 +331,17 @@ extern "C" int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, con
 //     entries that carry the probability mass next to 0, where fp16 resolves them to <= 2^-11 (the size of the
 //     rounding of the probabilities themselves) whatever the magnitude of the tables;
 //   * the -100 shift mask and the "key >= N" exclusion (-60000: exp2 underflows to exactly 0) are baked in, so
-//     there is one instantiation per operand type instead of gated x masked x full.
+//     there is one instantiation per operand type instead of gated x masked x full;
+//   * K and V are staged by LDS-DMA (no registers, no VALU; the gather kernel above transposes V through 2-byte LDS
+//     stores: 18k of a 76k-tick stage-0 unit).  V stays row-major: score tiles cover the keys in natural order, so a lane
+//     holds keys 16t+4g..+3 of tile t, and the PV step takes its V fragments through ds_read_b64_tr_b16 from
+//     [32 keys][16 features] subtiles — the hardware transpose delivers exactly that k order.
 namespace kvq {
 
 constexpr float ATT_DENSE_OFF = -60000.0f;
-constexpr int ATT_D_OFF_CTR = ATT_OFF_VT + ATT_VT_BYTES;
-constexpr int ATT_D_LDS = ATT_D_OFF_CTR + 16;
+constexpr int ATT_D_OFF_V = ATT_KROWS * 64;                       // K: 416 rows x 64 B
+constexpr int ATT_D_OFF_CTR = ATT_D_OFF_V + ATT_NT * 1024;        // V: 13 key blocks x 2 feature halves x 1 KB
+constexpr int ATT_D_LDS = ATT_D_OFF_CTR + 16;                     // 53 264 B: 3 workgroups per CU
 
 struct DenseBuildParams {
   const int32_t* tok;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64) void bias_dense_kernel(DenseBuildParams p) {
   if (q < p.N) tq = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + q) * 2);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int key = 32 * (t >> 1) + 4 * (t & 1) + 8 * g + r;     // this lane's keys of score tile t (header)
+    const int key = 16 * t + 4 * g + r;     // this lane's keys of score tile t: tiles cover keys in natural order
     float b = 0.f;
     if (key >= p.N) {
       b = ATT_DENSE_OFF;
@@ -411,6 +416,11 @@ __global__ __launch_bounds__(64) void bias_dense_kernel(DenseBuildParams p) {
       (u32x2){Fp16::pack2_raw(v[0], v[1]), Fp16::pack2_raw(v[2], v[3])};
 }
 
+typedef __attribute__((ext_vector_type(4))) short att_s4;
+typedef __attribute__((address_space(3))) att_s4* att_tr_t;      // 8-B units: pointer arithmetic below is in fragments of 4
+typedef __attribute__((address_space(3))) void* att_lds_t;
+typedef __attribute__((address_space(1))) const void* att_gbl_t;
+
 struct AttnDenseParams {
   const uint16_t* qkv;
   const u32x2* dense;
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Ks = reinterpret_cast<u32x4*>(smem);
-  uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + ATT_OFF_VT);
+  unsigned char* Vs = smem + ATT_D_OFF_V;     // row-major V as 13 x 2 subtiles of [32 keys][16 features] (1 KB each)
   int* ticket = reinterpret_cast<int*>(smem + ATT_D_OFF_CTR);
   using V8 = typename E::v8;
 
@@ -455,30 +465,33 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   const uint16_t* Kg = p.qkv + ((size_t)(1 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
   const uint16_t* Vg = p.qkv + ((size_t)(2 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
 
-  for (int c = tid; c < ATT_KROWS * 4; c += ATT_WAVES * 64) {
-    const int row = c >> 2, g = c & 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < N) v = *reinterpret_cast<const u32x4*>(Kg + (size_t)row * 32 + g * 8);
-    Ks[k_slot(row, g)] = v;
-  }
-  // V^T: a thread transposes the 8-feature chunks of TWO adjacent keys and writes (key, key+1) pairs: 8 4-byte LDS
-  // stores per 32 bytes instead of 16 2-byte ones
-  for (int c = tid; c < ATT_VPITCH * 2; c += ATT_WAVES * 64) {
-    const int key = (c >> 2) * 2, g = c & 3;
-    u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-    if (key < N) v0 = *reinterpret_cast<const u32x4*>(Vg + (size_t)key * 32 + g * 8);
-    if (key + 1 < N) v1 = *reinterpret_cast<const u32x4*>(Vg + (size_t)(key + 1) * 32 + g * 8);
-    uint32_t* vt32 = reinterpret_cast<uint32_t*>(Vt);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vt32[((g * 8 + 2 * i) * ATT_VPITCH + key) >> 1] = (v0[i] & 0xffffu) | (v1[i] << 16);
-      vt32[((g * 8 + 2 * i + 1) * ATT_VPITCH + key) >> 1] = (v0[i] >> 16) | (v1[i] & 0xffff0000u);
+  // K and V go global -> LDS by LDS-DMA: no registers, no VALU.  The DMA writes lane-linear (16 B per lane behind a
+  // wave-uniform base), so every lane picks the SOURCE chunk that belongs at its LDS position: K row-major with the
+  // XOR swizzle of k_slot(); V row-major too — the PV step reads it through the hardware transpose (ds_read_b64_tr_b16),
+  // which wants [32 keys][16 features] subtiles (32-B rows: the four lane groups of a read land on disjoint banks).
+  {
+    const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int it = wave_; it < ATT_KROWS * 4 / 64; it += ATT_WAVES) {
+      const int c = it * 64 + lane_, row = c >> 2, gs = c & 3, g = gs ^ ((-(row >> 3)) & 3);
+      if (row < N)
+        __builtin_amdgcn_global_load_lds((att_gbl_t)(Kg + (size_t)row * 32 + g * 8), (att_lds_t)(smem + it * 1024), 16, 0, 0);
+    }
+    for (int it = wave_; it < ATT_KROWS * 4 / 64; it += ATT_WAVES) {
+      const int key = 32 * (it >> 1) + (lane_ >> 1), feat = (it & 1) * 16 + (lane_ & 1) * 8;
+      if (key < N)
+        __builtin_amdgcn_global_load_lds((att_gbl_t)(Vg + (size_t)key * 32 + feat), (att_lds_t)(Vs + it * 1024), 16, 0, 0);
+    }
+    // keys N..415 exist only as padding (their bias is the -60000 of the image): finite zeros, never stale LDS
+    for (int i = tid; i < (ATT_KROWS - N) * 8; i += ATT_WAVES * 64) {
+      const int key = N + (i >> 3), q = i & 7;
+      if (q < 4) Ks[key * 4 + q] = (u32x4){0u, 0u, 0u, 0u};
+      else *reinterpret_cast<u32x4*>(Vs + (2 * (key >> 5) + ((q >> 1) & 1)) * 1024 + (key & 31) * 32 + (q & 1) * 16) = (u32x4){0u, 0u, 0u, 0u};
     }
   }
-  if (tid < 32) Vt[32 * ATT_VPITCH + tid] = 0;
   const int nqt = (N + 15) >> 4;
   const int q_lo = part * nqt / p.qsplit, q_hi = (part + 1) * nqt / p.qsplit;
   if (tid == 0) *ticket = q_lo;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the DMA has landed
   __syncthreads();
 #ifdef KVQ_ATT_TRACE
   t_mark = __builtin_readcyclecounter();
@@ -487,19 +500,28 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
 
   const int lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
+  // transpose-read source of this lane inside a V subtile: row 4g + j/4, features 4(j%4)..+3 (the hardware hands lane
+  // (feature j, group g) rows 4g..4g+3 of column j: the B fragment of a 16-key half k-step)
+  const att_tr_t vtr = (att_tr_t)(Vs + (4 * g + (j >> 2)) * 32 + (j & 3) * 8);
   const float kLog2e = 1.4426950408889634f;
   const uint32_t one2 = (uint32_t)E::cvt(1.0f) * 0x10001u;
   const V8 ones = __builtin_bit_cast(V8, (u32x4){one2, one2, one2, one2});
   const u32x2* dense = p.dense + (size_t)pair * nqt * ATT_NT * 64 + lane;
 
-  while (true) {
-    int qt = 0;
-    if (lane == 0) qt = atomicAdd(ticket, 1);
-    qt = __builtin_amdgcn_readfirstlane(qt);
-    if (qt >= q_hi) break;
+  // the ticket and the q fragment of the NEXT tile are fetched while this one is computed (both sit on the critical
+  // path of a tile's first MFMA otherwise); B operand of S^T = K Q^T: lane (j, g) holds Q[q0+j][8g..8g+7]
+  auto take = [&]() -> int {
+    int t_ = 0;
+    if (lane == 0) t_ = atomicAdd(ticket, 1);
+    return __builtin_amdgcn_readfirstlane(t_);
+  };
+  auto q_frag = [&](int t_) -> V8 { return *reinterpret_cast<const V8*>(Qg + (size_t)min(t_ * 16 + j, N - 1) * 32 + g * 8); };
+  int qt = take();
+  V8 qf = q_frag(qt);
+  while (qt < q_hi) {
     const int q0 = qt * 16;
-    const int qrow = min(q0 + j, N - 1);
-    const V8 qf = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + g * 8);
+    const int qt_next = take();
+    const V8 qf_next = q_frag(qt_next);
     const u32x2* bd = dense + (size_t)qt * ATT_NT * 64;
     u32x2 braw[ATT_NT];
 #pragma unroll
@@ -509,16 +531,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     for (int t = 0; t < ATT_NT; ++t)
       S[t] = (f32x4){Fp16::to_f32((uint16_t)(braw[t][0] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][0] >> 16)),
                      Fp16::to_f32((uint16_t)(braw[t][1] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][1] >> 16))};
-#define ATT_KEY0(t) (32 * ((t) >> 1) + 4 * ((t) & 1))
-    const int krow0 = 8 * (j >> 2) + (j & 3);
-    V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(0) + krow0, g)]), kfN = kfC;
+    // score tile t = keys 16t..16t+15 in natural order: lane (query j, group g) then holds keys 16t+4g..+3, which is the
+    // k order the transpose-read gives the V fragments
+    V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(j, g)]), kfN = kfC;
 #pragma unroll
     for (int t = 0; t < ATT_NT; ++t) {
-      if (t + 1 < ATT_NT) kfN = __builtin_bit_cast(V8, Ks[k_slot(ATT_KEY0(t + 1 < ATT_NT ? t + 1 : 0) + krow0, g)]);
+      if (t + 1 < ATT_NT) kfN = __builtin_bit_cast(V8, Ks[k_slot(16 * (t + 1 < ATT_NT ? t + 1 : 0) + j, g)]);
       S[t] = E::mfma16(kfC, qf, S[t]);
       kfC = kfN;
     }
-#undef ATT_KEY0
     ATT_MARK(t_s);
     float mx = -INFINITY;
 #pragma unroll
@@ -541,8 +562,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     for (int s = 0; s < ATT_NT / 2; ++s) {
       const u32x4 pa = {P[2 * s][0], P[2 * s][1], P[2 * s + 1][0], P[2 * s + 1][1]};
       const V8 pf = __builtin_bit_cast(V8, pa);
-      const V8 v0 = *reinterpret_cast<const V8*>(Vt + j * ATT_VPITCH + 32 * s + 8 * g);
-      const V8 v1 = *reinterpret_cast<const V8*>(Vt + (j + 16) * ATT_VPITCH + 32 * s + 8 * g);
+      // k-step s = keys 32s..32s+31: elements 0-3 = keys 32s+4g+e (rows 0-15 of the subtile), 4-7 = keys 32s+16+4g+e
+      const att_s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + (2 * s) * 128), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + (2 * s) * 128 + 64);
+      const att_s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + (2 * s + 1) * 128), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + (2 * s + 1) * 128 + 64);
+      const V8 v0 = __builtin_bit_cast(V8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      const V8 v1 = __builtin_bit_cast(V8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
       O0 = E::mfma16(pf, v0, O0);
       O1 = E::mfma16(pf, v1, O1);
       Ls = E::mfma16(pf, ones, Ls);
@@ -558,6 +582,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
       }
     }
     ATT_MARK(t_pv);
+    qt = qt_next;
+    qf = qf_next;
   }
 #ifdef KVQ_ATT_TRACE
   if (tr) {
