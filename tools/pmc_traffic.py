@@ -15,7 +15,8 @@ def sym(name):
     name = re.sub(r"\(.*$", "", name)
     return name.replace("kvq::window_attention", "window_attention").replace("kvq::gemm_kernel", "gemm_kernel") \
                .replace("kvq::layernorm_rows_kernel", "layernorm_rows_kernel").replace("kvq::patch_im2col_kernel", "patch_im2col_kernel") \
-               .replace("kvq::block_tail_kernel", "block_tail_kernel")
+               .replace("kvq::block_tail_kernel", "block_tail_kernel").replace("kvq::block_tail16_kernel", "block_tail16_kernel") \
+               .replace("kvq::patch_embed_kernel", "patch_embed_kernel")
 
 
 def agg(path, counter):
@@ -29,7 +30,7 @@ def agg(path, counter):
 f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in f:
-    if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "patch_im2col", "block_tail")):
+    if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "patch_im2col", "block_tail", "patch_embed")):
         continue
     fb = 2.0 * 1024.0 * sum(f[k]) / len(f[k])
     wb = 1024.0 * sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
@@ -43,5 +44,5 @@ for k in f:
     e["write_bytes"] = (e["write_bytes"] * e["launches"] + wb * n) / (e["launches"] + n)
     e["launches"] += n
 json.dump({"note": "avg HBM bytes per launch over one B=4 fp16 step mix; FETCH_SIZE x2 (gfx950 correction), "
-                   "separate --pmc passes (r01g build)", "kernels": out}, open("profiles/pmc_traffic.json", "w"), indent=1)
+                   "separate --pmc passes (" + (sys.argv[3] if len(sys.argv) > 3 else "r01") + " build, bench.py --streams 1)", "kernels": out}, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])
