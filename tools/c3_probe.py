@@ -25,3 +25,17 @@ with torch.no_grad():
     t_sf = timed(lambda: sf(pack_pathway_output(x)))
 print(f"C3, one video = 8 clips of 3x32x224x224: Swin3D-T+head {t_swin:.2f} ms, SlowFast-R50 {t_sf:.2f} ms -> "
       f"{1e3 / (t_swin + t_sf):.1f} videos/s with both branches on one GPU")
+
+# both branches of consecutive videos on their own HIP streams (independent work: the launches fill each other's gaps)
+s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+def both(n):
+    main = torch.cuda.current_stream()
+    s1.wait_stream(main); s2.wait_stream(main)
+    for _ in range(n):
+        with torch.cuda.stream(s1): net(inputs={"technical": x}, reduce_scores=True)
+        with torch.cuda.stream(s2): sf(pack_pathway_output(x))
+    main.wait_stream(s1); main.wait_stream(s2)
+with torch.no_grad():
+    both(2); torch.cuda.synchronize(); t = time.time(); both(10); torch.cuda.synchronize()
+    dt = (time.time() - t) / 10 * 1e3
+print(f"    the two branches on two streams: {dt:.2f} ms per video -> {1e3 / dt:.1f} videos/s")
