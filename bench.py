@@ -146,6 +146,11 @@ def main():
         for st in side:
             main.wait_stream(st)
 
+    if by_step:      # per-stream set-up (plans + workspaces: allocations), not steps: done before the warm-up
+        for st in [torch.cuda.current_stream()] + side:
+            with torch.cuda.stream(st):
+                net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
+        torch.cuda.synchronize()
     with torch.no_grad():
         run_steps(args.warmup, torch.zeros(max(args.warmup, 1), B, device=device))
         torch.cuda.synchronize()

@@ -375,6 +375,14 @@ class SwinTransformer3D(nn.Module):
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
+    def prepare(self, B, T, H, W, device):
+        """Set-up for forwards of this geometry on the CURRENT stream, without running one: the plan (index maps: device
+        allocations, i.e. implicit synchronisations), its workspace, the packed weights and the attention bias image.
+        A serving loop calls it once per stream before the first request."""
+        handle, _, _ = self._plan(B, T, H, W, device)
+        self._weights(device)
+        self._set_dense_bias(handle, (T, H, W), device, B)
+
     # ------------------------------------------------------------------ forward
     def forward(self, batch, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
         """``batch['technical']``: fp32 (B,3,T,H,W) on a HIP device -> (B, C_out, T/2, H/32, W/32)."""
