@@ -600,14 +600,17 @@ template <typename E>
 static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
   auto kern = window_attention_dense_kernel<E>;
   static bool attr_set = false;
+  // experiment knob: a larger LDS request lowers the workgroups per CU (3 at 53 KB, 2 above 54 KB), leaving room for
+  // another stream's workgroups on the same CU
+  static const int lds_req = getenv("KVQ_ATT_LDS") ? max(atoi(getenv("KVQ_ATT_LDS")), ATT_D_LDS) : ATT_D_LDS;
   if (!attr_set) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      ATT_D_LDS));
+                                      lds_req));
     attr_set = true;
   }
   const int nclip = p.BW / p.nW, npair = p.n_types * p.nH;
   dim3 grid((unsigned)(8 * ceil_div(npair, 8) * nclip * (p.nW / p.n_types) * p.qsplit)), block(ATT_WAVES * 64);
-  hipLaunchKernelGGL(kern, grid, block, ATT_D_LDS, st, p);
+  hipLaunchKernelGGL(kern, grid, block, lds_req, st, p);
   KVQ_CHECK_LAUNCH("window_attention_dense_kernel");
   return KVQ_OK;
 }

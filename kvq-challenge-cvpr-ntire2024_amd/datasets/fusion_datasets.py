@@ -2,7 +2,9 @@
 
   get_spatial_fragments   (:22-121)   grid-mini-patch sampler -> ``kvq_fragment_gather`` (HIP)
   UnifiedFrameSampler     (:612-660)  temporal index sampler (host integers, numpy)
-  ViewDecompositionDataset_KVQ (:930-1051)  dict assembly for the ``technical`` view
+  ViewDecompositionDataset_KVQ (:930-1051), ViewDecompositionDataset_add_forSimpleVQA (:786-927)
+                          the reference's dataset classes under their own names (annotation parsing, samplers, dict
+                          keys), fed by a frame reader (decord if present, uint8 .npy stacks otherwise)
   SyntheticKVQDataset     build-only: seeded post-decode frame stacks (no dataset/decoder is reachable
                           offline — SURVEY.md §8d); same dict keys.
 
@@ -212,3 +214,192 @@ class SyntheticKVQDataset(torch.utils.data.Dataset):
                                      aligned=s.get("aligned", 8), mean=KVQ_MEAN, std=KVQ_STD)
         return {"technical": tech, "num_clips": {"technical": s.get("num_clips", 1)}, "frame_inds": inds,
                 "label": float(self.labels[i]), "name": f"synthetic_{i:05d}", "video_name": f"synthetic_{i:05d}.mp4"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's dataset classes, under their own names, for its config/*.yml files (``data.val.type``).  Decode is
+# outside the built scope: frames come from a reader object — decord when it is installed, a uint8
+# ``[T, H, W, 3]`` ``.npy`` stack otherwise — and go to the device as uint8; sampling + normalisation run there.
+class NpyFrameReader:
+    """``len(reader)`` frames, ``reader[i]`` -> uint8 (H, W, 3): the slice of decord.VideoReader the datasets use."""
+
+    def __init__(self, path):
+        self.frames = np.load(path, mmap_mode="r")
+        if self.frames.ndim != 4 or self.frames.shape[-1] != 3 or self.frames.dtype != np.uint8:
+            raise ValueError(f"{path}: expected a uint8 [T, H, W, 3] frame stack, got {self.frames.dtype} {self.frames.shape}")
+
+    def __len__(self):
+        return self.frames.shape[0]
+
+    def __getitem__(self, i):
+        return np.asarray(self.frames[int(i)])
+
+
+def open_video(path):
+    """Frame reader for ``path``: ``<path>`` itself or ``<path>.npy`` as a frame stack, else decord.VideoReader
+    (fusion_datasets.py:381-383).  The cv2 fallback of the reference (:398-431) is not reproduced."""
+    import os
+    if path.endswith(".npy"):
+        return NpyFrameReader(path)
+    if os.path.exists(path + ".npy"):
+        return NpyFrameReader(path + ".npy")
+    try:
+        from decord import VideoReader
+    except ImportError as e:
+        raise ImportError(f"cannot read {path}: video decode needs decord (not built here: SURVEY.md §8 f2) — or "
+                          f"provide the decoded frames as a uint8 [T,H,W,3] array in {path}.npy") from e
+    return VideoReader(path)
+
+
+def _sampled_clips(path, samplers, is_train, device):
+    """Reference ``spatial_temporal_view_decomposition`` (:376-397), decode half: one reader, every frame fetched once,
+    per view a uint8 (3, T, H, W) tensor on the device + the sampled indices."""
+    vr = open_video(path)
+    frame_inds = {k: s(len(vr), is_train) for k, s in samplers.items()}
+    uniq = np.unique(np.concatenate(list(frame_inds.values()), 0))
+    cache = {}
+    for idx in uniq:
+        f = vr[int(idx)]
+        cache[int(idx)] = torch.from_numpy(f.asnumpy() if hasattr(f, "asnumpy") else np.array(f))
+    video = {k: torch.stack([cache[int(i)] for i in inds], 0).permute(3, 0, 1, 2).contiguous().to(device)
+             for k, inds in frame_inds.items()}
+    return video, frame_inds
+
+
+def _build_samplers(sample_types, phase):
+    samplers = {}
+    for stype, sopt in sample_types.items():
+        if "t_frag" not in sopt:      # (clip_len, num_clips, frame_interval) positionally, as the reference (:962-964)
+            samplers[stype] = UnifiedFrameSampler(sopt["clip_len"], sopt["num_clips"], sopt["frame_interval"])
+        else:
+            samplers[stype] = UnifiedFrameSampler(sopt["clip_len"] // sopt["t_frag"], sopt["t_frag"], sopt["frame_interval"],
+                                                  sopt["num_clips"])
+        print(stype + " branch sampled frames:", samplers[stype](40, phase == "train"))       # draws from the RNG, as there
+    return samplers
+
+
+def _default_device(device):
+    return torch.device(device if device is not None else "cuda:0")
+
+
+class ViewDecompositionDataset_add_forSimpleVQA(torch.utils.data.Dataset):  # noqa: N801  (reference spelling)
+    """Reference class of the same name (fusion_datasets.py:786-927): csv ``filename,label`` with a header row, per
+    video the ``simpleVQA`` view (resize 520 -> centre crop 448, normalised with the ImageNet constants on 0-255
+    pixels — reproduced as-is) and ``feat`` = 8 rows of SlowFast features from
+    ``data_prefix_3D/<video_name>/feature_{i}_{slow,fast}_feature.npy``.  Same dict keys."""
+
+    def __init__(self, opt, namelist=None, device=None):
+        import csv
+        import os.path as osp
+        super().__init__()
+        self.opt, self.namelist, self.device = opt, namelist, _default_device(device)
+        self.ann_file, self.data_prefix, self.data_prefix_3D = opt["anno_file"], opt["data_prefix"], opt["data_prefix_3D"]
+        self.sample_types, self.feature_type, self.phase = opt["sample_types"], opt["feature_type"], opt["phase"]
+        self.augment = opt.get("augment", False)
+        if self.phase == "train" or self.augment:
+            raise NotImplementedError("training-phase sampling / augmentation: this is an inference engine")
+        self.samplers = _build_samplers(self.sample_types, self.phase)
+        if isinstance(self.ann_file, list):
+            self.video_infos = self.ann_file
+        else:
+            self.video_infos = []
+            with open(self.ann_file, newline="") as f:
+                rows = csv.reader(f)
+                next(rows)
+                for row in rows:
+                    self.video_infos.append(dict(filename=osp.join(self.data_prefix, row[0]), label=float(row[1]), video_name=row[0]))
+            scores = [v["label"] for v in self.video_infos]
+            self.max, self.min = max(scores), min(scores)
+        self.labels = [v["label"] for v in self.video_infos]
+        self.video_names = [v["video_name"] for v in self.video_infos]
+
+    def __len__(self):
+        return len(self.video_infos)
+
+    def _features(self, video_name):
+        import os
+        folder = os.path.join(self.data_prefix_3D, video_name)
+        parts = {"Slow": ("slow",), "Fast": ("fast",), "SlowFast": ("slow", "fast")}[self.feature_type]
+        rows = []
+        for i in range(8):
+            rows.append(torch.cat([torch.from_numpy(np.load(os.path.join(folder, f"feature_{i}_{p}_feature.npy"))).squeeze().float().reshape(-1)
+                                   for p in parts]))
+        return torch.stack(rows)
+
+    def __getitem__(self, index):
+        info = self.video_infos[index]
+        feat = self._features(info["video_name"])
+        video, frame_inds = _sampled_clips(info["filename"], self.samplers, False, self.device)
+        data = {}
+        for stype, sopt in self.sample_types.items():
+            kw = dict(sopt, phase="test")
+            data[stype] = get_single_view(video[stype], stype, mean=SIMPLEVQA_MEAN, std=SIMPLEVQA_STD, **kw)
+        data["num_clips"] = {k: s["num_clips"] for k, s in self.sample_types.items()}
+        data["clip_len"] = {k: s["clip_len"] for k, s in self.sample_types.items()}
+        data["frame_inds"], data["label"], data["video_name"] = frame_inds, info["label"], info["video_name"]
+        if "simpleVQA" in data:
+            data["feat"] = feat
+        data["name"] = info["filename"]
+        return data
+
+
+class ViewDecompositionDataset_KVQ(torch.utils.data.Dataset):  # noqa: N801  (reference spelling)
+    """Reference class of the same name (fusion_datasets.py:930-1051): lines ``filename,cls_label,dis_label,label``;
+    per video the view(s) of ``sample_types`` normalised with the KVQ constants, plus the KSVQE inputs:
+    ``resize_video`` (``get_resized_video``, /255 then the CLIP constants), ``fragment`` (= the normalised view),
+    ``ori_fragment`` (a second, un-normalised fragment draw, as the reference makes), ``dis_label``,
+    ``original_shape``.  Same dict keys."""
+
+    CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+    CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+    def __init__(self, opt, namelist=None, device=None):
+        import os.path as osp
+        super().__init__()
+        self.opt, self.namelist, self.device = opt, namelist, _default_device(device)
+        self.ann_file, self.data_prefix = opt["anno_file"], opt["data_prefix"]
+        self.sample_types, self.phase = opt["sample_types"], opt["phase"]
+        self.augment = opt.get("augment", False)
+        if self.phase == "train" or self.augment:
+            raise NotImplementedError("training-phase sampling / augmentation: this is an inference engine")
+        self.samplers = _build_samplers(self.sample_types, self.phase)
+        if isinstance(self.ann_file, list):
+            self.video_infos = self.ann_file
+        else:
+            self.video_infos = []
+            with open(self.ann_file, "r") as f:
+                for line in f:
+                    filename, cls_label, dis_label, label = line.strip().split(",")
+                    self.video_infos.append(dict(filename=osp.join(self.data_prefix, filename), label=float(label),
+                                                 cls_label=int(float(cls_label)), dis_label=int(float(dis_label)),
+                                                 video_name=filename))
+            scores = [v["label"] for v in self.video_infos]
+            self.max, self.min = max(scores), min(scores)
+        self.labels = [v["label"] for v in self.video_infos]
+        self.video_names = [v["video_name"] for v in self.video_infos]
+
+    def __len__(self):
+        return len(self.video_infos)
+
+    def __getitem__(self, index):
+        info = self.video_infos[index]
+        video, frame_inds = _sampled_clips(info["filename"], self.samplers, False, self.device)
+        data, k = {}, None
+        resize = ori = None
+        for stype, sopt in self.sample_types.items():       # order of the reference's three calls per view (:455-459)
+            kw = dict(sopt, phase="test")
+            data[stype] = get_single_view(video[stype], stype, mean=KVQ_MEAN, std=KVQ_STD, **kw)
+            resize = get_resized_video(video[stype], mean=tuple(255.0 * m for m in self.CLIP_MEAN),
+                                       std=tuple(255.0 * s for s in self.CLIP_STD),
+                                       **{a: b for a, b in kw.items() if a in ("size_h", "size_w", "random_crop", "arp")})
+            ori = get_spatial_fragments(video[stype], **{a: b for a, b in kw.items() if a in (
+                "fragments_h", "fragments_w", "fsize_h", "fsize_w", "aligned", "nfrags")})
+            k = stype
+        data["resize_video"], data["fragment"], data["ori_fragment"] = resize, data[k], ori
+        data["num_clips"] = {s: o["num_clips"] for s, o in self.sample_types.items()}
+        data["clip_len"] = {s: o["clip_len"] for s, o in self.sample_types.items()}
+        data["frame_inds"], data["dis_label"] = frame_inds, info["dis_label"]
+        data["name"], data["video_name"] = info["filename"], info["video_name"]
+        data["original_shape"] = tuple(video[k].shape[1:])
+        data["label"] = info["label"]
+        return data

@@ -123,3 +123,100 @@ def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and d["value"] > 0
     assert abs(d["clips_per_s"] - 2 * 3 * 2 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["clips_per_s"]
+
+
+def _fake_kvq_tree(tmp_path, n=2, T=96, H=120, W=160):
+    g = np.random.Generator(np.random.PCG64(91))
+    vids = []
+    for i in range(n):
+        v = g.integers(0, 256, size=(T, H, W, 3), dtype=np.uint8)
+        np.save(str(tmp_path / f"clip{i}.mp4.npy"), v)
+        os.makedirs(str(tmp_path / "feat" / f"clip{i}.mp4"), exist_ok=True)
+        for k in range(8):
+            np.save(str(tmp_path / "feat" / f"clip{i}.mp4" / f"feature_{k}_slow_feature.npy"), g.standard_normal((1, 2048, 1, 1, 1)).astype(np.float32))
+            np.save(str(tmp_path / "feat" / f"clip{i}.mp4" / f"feature_{k}_fast_feature.npy"), g.standard_normal((1, 256, 1, 1, 1)).astype(np.float32))
+        vids.append(v)
+    return vids
+
+
+def test_reference_named_datasets_items_match_oracle(tmp_path):
+    """``__getitem__`` of the reference's dataset classes on decoded-frame stacks: same dict keys, views == the oracle's
+    sampler / resize restatements on the frames the seeded samplers pick (fusion_datasets.py:854-924, :998-1048)."""
+    import random
+    from kvq_amd.datasets import (KVQ_MEAN, KVQ_STD, SIMPLEVQA_MEAN, SIMPLEVQA_STD, ViewDecompositionDataset_add_forSimpleVQA,
+                                  ViewDecompositionDataset_KVQ)
+    vids = _fake_kvq_tree(tmp_path)
+    (tmp_path / "kvq.txt").write_text("clip0.mp4,1,3,2.5\nclip1.mp4,0,4,4.0\n")
+    (tmp_path / "simple.csv").write_text("filename,score\nclip0.mp4,2.5\nclip1.mp4,4.0\n")
+    topt = dict(fragments_h=3, fragments_w=4, fsize_h=32, fsize_w=32, aligned=8, clip_len=16, frame_interval=2, num_clips=2,
+                size_h=48, size_w=64)
+    kv = ViewDecompositionDataset_KVQ(dict(anno_file=str(tmp_path / "kvq.txt"), data_prefix=str(tmp_path), phase="test",
+                                           sample_types={"technical": topt}))
+    np.random.seed(5); random.seed(5); torch.manual_seed(5)
+    item = kv[1]
+    assert set(item) == {"technical", "resize_video", "fragment", "ori_fragment", "num_clips", "clip_len", "frame_inds", "dis_label",
+                         "name", "video_name", "original_shape", "label"}
+    # replay: same RNG streams -> same frame indices and fragment offsets
+    np.random.seed(5); random.seed(5); torch.manual_seed(5)
+    inds = kv.samplers["technical"](96, False)
+    assert np.array_equal(inds, item["frame_inds"]["technical"]) and len(inds) == 32
+    frames = vids[1][inds].transpose(3, 0, 1, 2).astype(np.float32)             # (3, T, H, W)
+    rh, rw = SO.draw_fragment_offsets(32, 120, 160, 3, 4, 32, 32, 8)
+    ref = SO.normalize(SO.spatial_fragments(frames, rh, rw, 3, 4, 32, 32, 8), KVQ_MEAN, KVQ_STD)
+    assert item["technical"].shape == (3, 32, 96, 128) and item["fragment"] is item["technical"]
+    assert np.abs(item["technical"].cpu().numpy() - ref).max() <= 1e-5
+    rs = SO.resize_bilinear(frames, 48, 64, round_u8=True) if False else SO.resize_bilinear(vids[1][inds].transpose(3, 0, 1, 2), 48, 64, round_u8=True)
+    clip_ref = (rs / 255.0 - np.asarray(kv.CLIP_MEAN, np.float32).reshape(3, 1, 1, 1)) / np.asarray(kv.CLIP_STD, np.float32).reshape(3, 1, 1, 1)
+    assert (np.abs(item["resize_video"].cpu().numpy() - clip_ref) > 0.5 / 255 / 0.26 + 1e-4).mean() <= 1e-3
+    rh2, rw2 = SO.draw_fragment_offsets(32, 120, 160, 3, 4, 32, 32, 8)            # the second, un-normalised draw
+    assert np.array_equal(item["ori_fragment"].cpu().numpy(), SO.spatial_fragments(frames, rh2, rw2, 3, 4, 32, 32, 8))
+    assert item["dis_label"] == 4 and item["label"] == 4.0 and item["original_shape"] == (32, 120, 160) and item["num_clips"] == {"technical": 2}
+
+    sv = ViewDecompositionDataset_add_forSimpleVQA(dict(
+        anno_file=str(tmp_path / "simple.csv"), data_prefix=str(tmp_path), data_prefix_3D=str(tmp_path / "feat"), feature_type="SlowFast",
+        phase="test", sample_types={"simpleVQA": dict(resize=130, crop=112, clip_len=8, frame_interval=10, t_frag=8, num_clips=1)}))
+    np.random.seed(6); random.seed(6)
+    item = sv[0]
+    assert set(item) == {"simpleVQA", "num_clips", "clip_len", "frame_inds", "label", "video_name", "feat", "name"}
+    np.random.seed(6); random.seed(6)
+    inds = sv.samplers["simpleVQA"](96, False)
+    assert np.array_equal(inds, item["frame_inds"]["simpleVQA"]) and len(inds) == 8
+    ref = SO.normalize(SO.resizecrop(vids[0][inds].transpose(3, 0, 1, 2), 130, 112), SIMPLEVQA_MEAN, SIMPLEVQA_STD)
+    got = item["simpleVQA"].cpu().numpy()
+    assert got.shape == (3, 8, 112, 112) and (np.abs(got - ref) > 0.5 / 0.224 + 1e-3).mean() <= 1e-3
+    feat = np.stack([np.concatenate([np.load(str(tmp_path / "feat" / "clip0.mp4" / f"feature_{k}_{p}_feature.npy")).reshape(-1) for p in ("slow", "fast")])
+                     for k in range(8)])
+    assert item["feat"].shape == (8, 2304) and np.array_equal(item["feat"].numpy(), feat)
+
+
+def test_cli_with_reference_style_simplevqa_config(tmp_path):
+    """``python test.py -o config/kwai_simpleVQA_test.yml`` (the reference's schema + dataset class) on a fake data
+    tree: output.txt has one ``video_name,score`` line per annotated video, and a video's score equals the in-process
+    forward of the same model (seeded weights saved to the config's ``load_path``) on the same dataset item."""
+    from kvq_amd.datasets import ViewDecompositionDataset_add_forSimpleVQA
+    from kvq_amd.models import VQA_Network
+    _fake_kvq_tree(tmp_path, n=2, T=80, H=135, W=240)
+    (tmp_path / "anno.csv").write_text("filename,score\nclip0.mp4,2.5\nclip1.mp4,4.0\n")
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "kwai_simpleVQA_test.yml")))
+    a = cfg["data"]["val"]["args"]
+    a.update(anno_file=str(tmp_path / "anno.csv"), data_prefix=str(tmp_path), data_prefix_3D=str(tmp_path / "feat"))
+    a["sample_types"]["simpleVQA"].update(resize=260, crop=224)
+    torch.manual_seed(3)
+    net = VQA_Network(cfg)
+    ck = tmp_path / "w.pth"
+    torch.save({"module." + k: v for k, v in net.state_dict().items()}, str(ck))          # DataParallel-style checkpoint
+    cfg["load_path"] = cfg["test_load_path"] = str(ck)
+    yml = tmp_path / "s.yml"
+    yml.write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "test.py"), "-o", str(yml), "--gpu_id", "0"], cwd=tmp_path,
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = (tmp_path / "output.txt").read_text().strip().splitlines()
+    assert [l.split(",")[0] for l in lines] == ["clip0.mp4", "clip1.mp4"]
+    got = np.asarray([float(l.split(",")[1]) for l in lines])
+    ds = ViewDecompositionDataset_add_forSimpleVQA(a)
+    item = ds[1]          # the temporal sampler draws nothing here (80 frames / 8 grids = 10 <= 1 * 10): deterministic
+    net = net.cuda().eval()
+    with torch.no_grad():
+        s = net(inputs={"simpleVQA": item["simpleVQA"].unsqueeze(0), "feat": item["feat"].unsqueeze(0)}, reduce_scores=True)
+    assert abs(float(s.float().mean()) - got[1]) <= 1e-4 * max(1.0, abs(got[1])), (float(s.mean()), got)

@@ -90,3 +90,42 @@ def test_trainer_strips_dataparallel_prefix(tmp_path, capsys):
     assert not msg.unexpected_keys and not msg.missing_keys
     for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+# ------------------------------------------------------------------ the reference's dataset classes (host half)
+def _write_videos(tmp_path, n=3, T=64, H=60, W=80):
+    g = np.random.Generator(np.random.PCG64(77))
+    for i in range(n):
+        np.save(str(tmp_path / f"v{i}.mp4.npy"), g.integers(0, 256, size=(T, H, W, 3), dtype=np.uint8))
+    return [f"v{i}.mp4" for i in range(n)]
+
+
+def test_reference_named_datasets_parse_like_the_reference(tmp_path, capsys):
+    """ViewDecompositionDataset_KVQ / _add_forSimpleVQA (fusion_datasets.py:786-1051): annotation formats, sampler
+    construction (positional quirk included), the frame reader; no GPU work (``__getitem__`` is a gpu test)."""
+    from kvq_amd.datasets import (NpyFrameReader, ViewDecompositionDataset_add_forSimpleVQA, ViewDecompositionDataset_KVQ,
+                                  open_video)
+    names = _write_videos(tmp_path)
+    (tmp_path / "kvq.txt").write_text("".join(f"{n},{i},{2 * i},{3.5 - 0.5 * i}\n" for i, n in enumerate(names)))
+    (tmp_path / "simple.csv").write_text("filename,score\n" + "".join(f"{n},{1.0 + i}\n" for i, n in enumerate(names)))
+    kv = ViewDecompositionDataset_KVQ(dict(anno_file=str(tmp_path / "kvq.txt"), data_prefix=str(tmp_path), phase="test",
+                                           sample_types={"technical": dict(fragments_h=7, fragments_w=7, fsize_h=8, fsize_w=8,
+                                                                           aligned=8, clip_len=32, frame_interval=2, num_clips=3)}))
+    assert len(kv) == 3 and kv.video_infos[1] == dict(filename=str(tmp_path / "v1.mp4"), label=3.0, cls_label=1, dis_label=2,
+                                                        video_name="v1.mp4")
+    assert (kv.max, kv.min) == (3.5, 2.5)
+    s = kv.samplers["technical"]            # (clip_len, num_clips, frame_interval) land in (fsize_t, fragments_t, interval)
+    assert (s.fsize_t, s.fragments_t, s.frame_interval, s.num_clips) == (32, 3, 2, 1)
+    sv = ViewDecompositionDataset_add_forSimpleVQA(dict(
+        anno_file=str(tmp_path / "simple.csv"), data_prefix=str(tmp_path), data_prefix_3D=str(tmp_path / "feat"), feature_type="SlowFast",
+        phase="test", sample_types={"simpleVQA": dict(resize=520, crop=448, clip_len=8, frame_interval=10, t_frag=8, num_clips=1)}))
+    assert len(sv) == 3 and sv.labels == [1.0, 2.0, 3.0] and sv.video_names == names
+    s = sv.samplers["simpleVQA"]
+    assert (s.fsize_t, s.fragments_t, s.frame_interval, s.num_clips) == (1, 8, 10, 1)
+    assert "branch sampled frames" in capsys.readouterr().out
+    r = open_video(str(tmp_path / "v0.mp4"))
+    assert isinstance(r, NpyFrameReader) and len(r) == 64 and r[5].shape == (60, 80, 3) and r[5].dtype == np.uint8
+    with pytest.raises(ImportError, match="decord"):
+        open_video(str(tmp_path / "missing.mp4"))
+    with pytest.raises(NotImplementedError):
+        ViewDecompositionDataset_KVQ(dict(anno_file=[], data_prefix="", phase="train", sample_types={}))
