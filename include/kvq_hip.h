@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 7
+#define KVQ_ABI_VERSION 8
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -356,6 +356,29 @@ int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int T, int H, i
  * SlowFast_features.py:137-165).  Activations are channels-last 16-bit (B,D,H,W,C); conv = im2col -> GEMM
  * (BatchNorm folded on the host, ReLU / identity add = KVQ_EPI_RELU_BF16); 1x1x1 stride-1 convs need no im2col.
  * ------------------------------------------------------------------------------------------- */
+
+/* Implicit-GEMM convolution (nn.Conv2d / nn.Conv3d + folded BatchNorm [+ identity] [+ ReLU], the Bottleneck convs of
+ * simpleVQA_model.py:85-126 and the SlowFast res blocks): the GEMM's A tiles are fetched straight from the channels-LAST
+ * 16-bit activation x (B, D, H, W, C), C % 8 == 0 — no patch matrix.  W [N][Kpad], columns ordered (kd,kh,kw,c) like
+ * kvq_im2col_nd and zero padded to Kpad (a multiple of 32).  taps: device int32 [Kpad/8][4], one row per 8-channel
+ * chunk of K: {kd, kh, kw, ((kd*H + kh)*W + kw)*C + c0}, last entry -1 for chunks of the K padding (depends on H, W, C).
+ * Output rows = output pixels (b, do, ho, wo), i.e. channels-last again.  epilogue: KVQ_EPI_RELU_BF16 | KVQ_EPI_BIAS_BF16 |
+ * KVQ_EPI_STORE_F32 (out_f32 [M][N] = acc + bias: the projection shortcuts, kept in fp32). */
+typedef struct {
+  const uint16_t* x;
+  const uint16_t* W;
+  const float* bias;
+  const int32_t* taps;
+  int32_t dims5[5];       /* B, C, D, H, W */
+  int32_t kernel3[3], stride3[3], pad3[3];
+  int32_t Kpad, N;
+  int32_t epilogue, dtype;
+  uint16_t* out_bf16;     /* [B*Do*Ho*Wo][N] */
+  float* out_f32;         /* optional fp32 copy (RELU epilogue) */
+  const uint16_t* resid_bf16;
+  const float* resid_f32;
+} KvqConvArgs;
+int kvq_conv_implicit(const KvqConvArgs* host_args, void* stream);
 
 /* Gather conv patches: x with explicit ELEMENT strides5 = {b,c,d,h,w} over dims5 = {B,C,D,H,W} (fp32 when
  * src_f32, else the 16-bit dtype) -> out [B*Do*Ho*Wo][Kpad], columns ordered (kd,kh,kw,c) and zero padded

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16 = range(6)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def dtype_code(dt) -> int:
@@ -69,6 +69,13 @@ class KvqGemmArgs(C.Structure):
                 ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void)]
 
 
+class KvqConvArgs(C.Structure):
+    _fields_ = [("x", p_void), ("W", p_void), ("bias", p_void), ("taps", p_void), ("dims5", C.c_int32 * 5),
+                ("kernel3", C.c_int32 * 3), ("stride3", C.c_int32 * 3), ("pad3", C.c_int32 * 3), ("Kpad", C.c_int32),
+                ("N", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
+                ("resid_bf16", p_void), ("resid_f32", p_void)]
+
+
 class KvqBlockTailArgs(C.Structure):
     _fields_ = [("attn", p_void), ("x", p_void), ("scatter_map", p_void), ("map_rows", C.c_int32),
                 ("out_rows", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("pack", p_void),
@@ -99,6 +106,7 @@ SYMBOLS = {
     "kvq_swin3d_plan_destroy": (None, [p_void]),
     "kvq_swin3d_workspace_bytes": (sz, [p_void]),
     "kvq_swin3d_out_dims": (i32, [p_void, C.POINTER(i32 * 4)]),
+    "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),
     "kvq_resize_trilinear_cl": (i32, [p_void, i32, i32, i32, i32, i32, p_void, i32, i32, i32, i32, i32, p_void]),

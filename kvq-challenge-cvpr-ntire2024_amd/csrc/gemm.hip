@@ -31,7 +31,15 @@ struct GemmParams {
   const float* resid_f32;      // KVQ_EPI_RELU_BF16: optional fp32 [M][N] identity branch (residual stream kept in fp32)
   unsigned long long* trace;   // diagnostic: per-block s_memtime stamps (kvq_debug_gemm_trace), else NULL
   int trace_blocks;
+  // IMPL (implicit-GEMM convolution): A is the channels-last 16-bit activation (B, D, H, W, Cin) itself; GEMM row m is the
+  // output pixel (b, do, ho, wo), K index ((kd*KH + kh)*KW + kw)*Cin + c, zero-padded to K.  taps[K/8]: per 8-channel chunk
+  // of K {kd, kh, kw, element offset ((kd*H + kh)*W + kw)*Cin + c0}, offset < 0 = a chunk of the K padding.
+  const int4* taps;
+  int cD, cH, cW, cC, cDo, cHo, cWo, csd, csh, csw, cpd, cph, cpw;
 };
+
+// what out-of-image / K-padding chunks of an implicit-GEMM A tile are fetched from
+__device__ __attribute__((aligned(16))) const uint32_t kvq_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
 #ifndef KVQ_GEMM_NST
 #define KVQ_GEMM_NST 3      // slices in the LDS ring: 48 KB per 128x128 block -> 3 blocks/CU (measured: 4 -> 3.66 ms,
@@ -61,7 +69,7 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // BK = 32: LDS rows of 64 B, 16-B chunk c of row r at chunk c ^ ((r>>2)&3).  BK = 64 (the "one big tile per CU"
 // variants for long-K shapes): rows of 128 B, chunk c at c ^ ((r>>1)&7) — in both, the 16 lanes of a ds_read_b128
 // service group land on 16 distinct 16-B slots.
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   fp16_saturate_mode();
   static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
@@ -91,10 +99,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // DMA assignment: 16-B chunk q = i*256 + tid of the slice image: row q>>2, physical chunk q&3
   const uint16_t* a_src[A_PER];
   const uint16_t* b_src[B_PER];
+  int a_t0[IMPL ? A_PER : 1], a_y0[IMPL ? A_PER : 1], a_x0[IMPL ? A_PER : 1], a_c[IMPL ? A_PER : 1];   // IMPL: pixel origin, chunk column
+  int4 a_tap[IMPL ? A_PER : 1];                                                                          // IMPL: tap of the next slice to issue
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
-    a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
+    if (IMPL) {
+      int m = min(m0 + row, p.M - 1);
+      const int wo = m % p.cWo; m /= p.cWo;
+      const int ho = m % p.cHo; m /= p.cHo;
+      const int dq = m % p.cDo, b = m / p.cDo;
+      a_t0[i] = dq * p.csd - p.cpd; a_y0[i] = ho * p.csh - p.cph; a_x0[i] = wo * p.csw - p.cpw; a_c[i] = c;
+      // element offset of (b, t0, y0, x0, 0): may point before the image; only ever dereferenced with an in-bounds tap added
+      a_src[i] = p.A + ((((long)b * p.cD + a_t0[i]) * p.cH + a_y0[i]) * p.cW + a_x0[i]) * (long)p.cC;
+      a_tap[i] = p.taps[c];
+    } else {
+      a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
+    }
   }
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
@@ -103,10 +124,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
   auto issue = [&](int kt) {
     unsigned char* st = lds + (kt % NST) * ST_BYTES;
+    if (IMPL) {
+      // issue() is called for consecutive slices: the tap of THIS slice was fetched during the previous call (its L2
+      // latency would otherwise sit in front of every DMA), the next slice's is requested now
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16,
-                                       0, 0);
+      for (int i = 0; i < A_PER; ++i) {
+        const int4 t = a_tap[i];
+        const bool ok = t.w >= 0 && (unsigned)(a_t0[i] + t.x) < (unsigned)p.cD && (unsigned)(a_y0[i] + t.y) < (unsigned)p.cH &&
+                        (unsigned)(a_x0[i] + t.z) < (unsigned)p.cW;
+        const uint16_t* src = ok ? a_src[i] + t.w : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        a_tap[i] = p.taps[min(kt + 1, p.K / BK - 1) * CH + a_c[i]];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16,
+                                         0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + kt * BK),
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     // slice kt must have landed; up to two younger slices stay in flight
     const int younger = nk - 1 - kt;
     if (NST > 2 && younger >= 1) {
-      gemm_wait_vmcnt<NL>();
+      gemm_wait_vmcnt<NL + (IMPL ? A_PER : 0)>();     // IMPL: every issue also carries A_PER tap loads
     } else {
       gemm_wait_vmcnt<0>();
     }
@@ -317,13 +352,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false>
 static int launch_one(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr size_t main_bytes = NST * (BM + BN) * BK * 2;               // ring of 2*BK-byte rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST>;
+  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -380,6 +415,19 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
     case 21: return launch_one<E, 2, 1, 32, EPI>(p, st);
     case 12: return launch_one<E, 1, 2, 32, EPI>(p, st);
     default: return launch_one<E, 1, 1, 32, EPI>(p, st);
+  }
+}
+
+// implicit-GEMM convolution: the 32-deep variants only (a slice = 4 chunks = at most 4 taps)
+template <typename E, int EPI>
+static int launch_conv(const GemmParams& p, hipStream_t st) {
+  int var = gemm_variant(p.M, p.N, p.K) / 100;
+  if (var != 22 && var != 21 && var != 12 && var != 11) var = 22;
+  switch (var) {
+    case 22: return launch_one<E, 2, 2, 32, EPI, KVQ_GEMM_NST, true>(p, st);
+    case 21: return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, true>(p, st);
+    case 12: return launch_one<E, 1, 2, 32, EPI, KVQ_GEMM_NST, true>(p, st);
+    default: return launch_one<E, 1, 1, 32, EPI, KVQ_GEMM_NST, true>(p, st);
   }
 }
 
@@ -440,4 +488,40 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
       set_error("kvq_gemm_bf16: unknown epilogue %d", a->epilogue);
       return KVQ_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(a && a->x && a->W && a->taps && (a->epilogue == KVQ_EPI_STORE_F32 ? (const void*)a->out_f32 : (const void*)a->out_bf16),
+              KVQ_ERR_NULL, "kvq_conv_implicit: NULL pointer");
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_conv_implicit: dtype %d", a->dtype);
+  const int B = a->dims5[0], Cin = a->dims5[1], D = a->dims5[2], H = a->dims5[3], W = a->dims5[4];
+  KVQ_REQUIRE(B > 0 && Cin > 0 && Cin % 8 == 0 && D > 0 && H > 0 && W > 0, KVQ_ERR_SHAPE,
+              "kvq_conv_implicit: channels-last input needs C %% 8 == 0 (got B=%d C=%d D=%d H=%d W=%d)", B, Cin, D, H, W);
+  for (int i = 0; i < 3; ++i)
+    KVQ_REQUIRE(a->kernel3[i] > 0 && a->stride3[i] > 0 && a->pad3[i] >= 0, KVQ_ERR_SHAPE, "kvq_conv_implicit: bad kernel/stride/pad");
+  const int Do = (D + 2 * a->pad3[0] - a->kernel3[0]) / a->stride3[0] + 1;
+  const int Ho = (H + 2 * a->pad3[1] - a->kernel3[1]) / a->stride3[1] + 1;
+  const int Wo = (W + 2 * a->pad3[2] - a->kernel3[2]) / a->stride3[2] + 1;
+  const long K = (long)a->kernel3[0] * a->kernel3[1] * a->kernel3[2] * Cin;
+  KVQ_REQUIRE(Do > 0 && Ho > 0 && Wo > 0 && a->Kpad >= K && a->Kpad % 32 == 0 && a->N > 0 && a->N % 8 == 0, KVQ_ERR_SHAPE,
+              "kvq_conv_implicit: Kpad=%d (K=%ld) must be a multiple of 32, N=%d a multiple of 8", a->Kpad, K, a->N);
+  KVQ_REQUIRE((long)B * D * H * W * Cin < (1L << 31) && (long)B * Do * Ho * Wo < (1L << 31), KVQ_ERR_SHAPE,
+              "kvq_conv_implicit: tensor too large for 32-bit tap offsets");
+  KVQ_REQUIRE(a->epilogue == KVQ_EPI_RELU_BF16 || a->epilogue == KVQ_EPI_BIAS_BF16 || a->epilogue == KVQ_EPI_STORE_F32,
+              KVQ_ERR_UNSUPPORTED, "kvq_conv_implicit: epilogue %d", a->epilogue);
+  GemmParams p{};
+  p.A = a->x; p.W = a->W; p.bias = a->bias; p.M = B * Do * Ho * Wo; p.N = a->N; p.K = a->Kpad;
+  p.out_h = a->out_bf16; p.out_f32 = a->out_f32; p.resid_h = a->resid_bf16; p.resid_f32 = a->resid_f32;
+  p.trace = g_trace; p.trace_blocks = g_trace_blocks;
+  p.taps = reinterpret_cast<const int4*>(a->taps);
+  p.cD = D; p.cH = H; p.cW = W; p.cC = Cin; p.cDo = Do; p.cHo = Ho; p.cWo = Wo;
+  p.csd = a->stride3[0]; p.csh = a->stride3[1]; p.csw = a->stride3[2];
+  p.cpd = a->pad3[0]; p.cph = a->pad3[1]; p.cpw = a->pad3[2];
+  hipStream_t st = (hipStream_t)stream;
+  if (a->epilogue == KVQ_EPI_STORE_F32)      // projection shortcuts: conv + BN, no ReLU, kept in fp32
+    return a->dtype == KVQ_DT_FP16 ? launch_conv<Fp16, KVQ_EPI_STORE_F32>(p, st) : launch_conv<Bf16, KVQ_EPI_STORE_F32>(p, st);
+  if (a->epilogue == KVQ_EPI_RELU_BF16)
+    return a->dtype == KVQ_DT_FP16 ? launch_conv<Fp16, KVQ_EPI_RELU_BF16>(p, st) : launch_conv<Bf16, KVQ_EPI_RELU_BF16>(p, st);
+  return a->dtype == KVQ_DT_FP16 ? launch_conv<Fp16, KVQ_EPI_BIAS_BF16>(p, st) : launch_conv<Bf16, KVQ_EPI_BIAS_BF16>(p, st);
 }

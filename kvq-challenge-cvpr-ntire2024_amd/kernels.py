@@ -248,6 +248,61 @@ def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None, re
     return (out, out32) if want_f32 else out
 
 
+_TAPS = {}
+
+
+def conv_taps(kernel, Cc: int, H: int, W: int, k_pad: int, device):
+    """Tap table of ``kvq_conv_implicit``: int32 [k_pad/8][4], one row per 8-channel chunk of the (kd,kh,kw,c)-ordered
+    K axis: {kd, kh, kw, ((kd*H + kh)*W + kw)*C + c0}; -1 in the last column marks the zero padding of K."""
+    key = (tuple(kernel), Cc, H, W, k_pad, str(device))
+    t = _TAPS.get(key)
+    if t is None:
+        import numpy as np
+        kd, kh, kw = kernel
+        rows = np.full((k_pad // 8, 4), -1, np.int32)
+        q = 0
+        for a in range(kd):
+            for b in range(kh):
+                for c in range(kw):
+                    for c0 in range(0, Cc, 8):
+                        rows[q] = (a, b, c, ((a * H + b) * W + c) * Cc + c0)
+                        q += 1
+        rows[q:, :3] = 0
+        t = _TAPS[key] = torch.from_numpy(rows).to(device)
+    return t
+
+
+def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, relu: bool, resid=None, resid_f32=None,
+                  want_f32=False, store_f32=False):
+    """Conv (+ folded BN, + identity, + ReLU) on a channels-last 16-bit activation x (B, D, H, W, C), C % 8 == 0, without a
+    patch matrix: W [N][Kpad] with the (kd,kh,kw,c) column order of ``im2col_nd``.  Returns the (B, Do, Ho, Wo, N) 16-bit
+    output, or (output, fp32 copy [M][N]) when ``want_f32``; ``store_f32``: only the fp32 [M][N] result (no ReLU)."""
+    _need_gpu(x, W, bias, resid, resid_f32)
+    assert x.dtype in HALF_TYPES and x.is_contiguous() and x.dim() == 5 and W.dtype == x.dtype and W.is_contiguous()
+    B, D, H, Wd, Cc = x.shape
+    if Cc % 8:
+        raise _abi.KvqError(f"kvq_conv_implicit: channels-last input needs C % 8 == 0 (got C={Cc})")
+    Do, Ho, Wo = conv_out_dims((D, H, Wd), kernel, stride, pad)
+    N, k_pad = W.shape
+    M = B * Do * Ho * Wo
+    out = None if store_f32 else torch.empty(M, N, dtype=x.dtype, device=x.device)
+    out32 = torch.empty(M, N, dtype=torch.float32, device=x.device) if (want_f32 or store_f32) else None
+    assert relu or (resid is None and resid_f32 is None and not want_f32), "identity add / fp32 copy: ReLU epilogue only"
+    a = _abi.KvqConvArgs()
+    a.x, a.W, a.bias, a.taps = ptr(x), ptr(W), ptr(bias), ptr(conv_taps(kernel, Cc, H, Wd, k_pad, x.device))
+    a.dims5[:] = (B, Cc, D, H, Wd)
+    a.kernel3[:], a.stride3[:], a.pad3[:] = tuple(kernel), tuple(stride), tuple(pad)
+    a.Kpad, a.N = k_pad, N
+    a.epilogue = _abi.EPI_STORE_F32 if store_f32 else (_abi.EPI_RELU_BF16 if relu else _abi.EPI_BIAS_BF16)
+    a.dtype = dtype_code(x.dtype)
+    a.out_bf16, a.out_f32, a.resid_bf16, a.resid_f32 = ptr(out), ptr(out32), ptr(resid), ptr(resid_f32)
+    check(lib().kvq_conv_implicit(C.byref(a), current_stream()), "kvq_conv_implicit")
+    if store_f32:
+        return out32
+    out = out.reshape(B, Do, Ho, Wo, N)
+    return (out, out32) if want_f32 else out
+
+
 def resize_bilinear(video: torch.Tensor, rh: int, rw: int, crop=None, mean=None, std=None, round_u8=None):
     """video u8|fp32 (C,T,H,W) -> bilinear resize to (rh,rw) [-> crop (cy,cx,oh,ow)] [-> (v-mean)/std], fp32."""
     _need_gpu(video)

@@ -15,6 +15,9 @@ from ... import _abi, kernels
 from .swin_backbone import _Affine
 
 
+IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
+
+
 class _BN(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -113,6 +116,11 @@ class ResNet(nn.Module):
         return a, (ho, wo)
 
     def _conv_relu(self, x, wb, k, stride, pad):
+        n, h, w_, c = x.shape
+        if IMPLICIT_CONV and not (k == 1 and stride == 1) and c % 8 == 0 and x.is_contiguous():
+            # implicit GEMM: the A tiles are fetched from the activation itself (no patch matrix)
+            y = kernels.conv_implicit(x.reshape(n, 1, h, w_, c), wb[0], wb[1], (1, k, k), (1, stride, stride), (0, pad, pad), True)
+            return y.reshape(n, y.shape[2], y.shape[3], wb[0].shape[0])
         a, (ho, wo) = self._cols(x, k, stride, pad, wb[0].shape[1])
         return kernels.conv_gemm(a, wb[0], wb[1], True).reshape(x.shape[0], ho, wo, wb[0].shape[0])
 
@@ -126,8 +134,13 @@ class ResNet(nn.Module):
             identity = x32.reshape(-1, x32.shape[-1])
         else:                                                   # 1x1/stride conv + BN, no ReLU, kept in fp32
             wd, bd = w[key + "d"]
-            a, _ = self._cols(x16, 1, blk.stride, 0, wd.shape[1])
-            identity = kernels.gemm(a, wd, bd, _abi.EPI_STORE_F32)
+            nb, hb, wb_, cb = x16.shape
+            if IMPLICIT_CONV and blk.stride != 1 and cb % 8 == 0 and x16.is_contiguous():
+                identity = kernels.conv_implicit(x16.reshape(nb, 1, hb, wb_, cb), wd, bd, (1, 1, 1), (1, blk.stride, blk.stride),
+                                                 (0, 0, 0), False, store_f32=True)
+            else:
+                a, _ = self._cols(x16, 1, blk.stride, 0, wd.shape[1])
+                identity = kernels.gemm(a, wd, bd, _abi.EPI_STORE_F32)
         ho, wo = out.shape[1], out.shape[2]
         w3, b3 = w[key + "3"]
         y16, y32 = kernels.conv_gemm(out.reshape(n * ho * wo, -1), w3, b3, True, resid_f32=identity, want_f32=True)

@@ -70,6 +70,9 @@ def pack_pathway_output(frames, device=None):
     return [slow if device is None else slow.to(device), frames if device is None else frames.to(device)]
 
 
+IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
+
+
 class slowfast(nn.Module):  # noqa: N801  (reference spelling)
     def __init__(self, operand_dtype=None):
         super().__init__()
@@ -125,6 +128,10 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
                                  wt.shape[1])
 
     def _conv_relu(self, x, spec):
+        wt, bias, k, stride, pad = spec
+        pointwise = k == (1, 1, 1) and stride == (1, 1, 1) and x.shape[-1] % 32 == 0
+        if IMPLICIT_CONV and not pointwise and x.shape[-1] % 8 == 0 and x.is_contiguous():
+            return kernels.conv_implicit(x, wt, bias, k, stride, pad, True)     # no patch matrix
         a, (d, h, w) = self._cols(x, spec)
         return kernels.conv_gemm(a, spec[0], spec[1], True).reshape(x.shape[0], d, h, w, spec[0].shape[0])
 
@@ -133,8 +140,12 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         out = self._conv_relu(out, W[pre + ".branch2#b"])
         if first:                                             # projection shortcut: conv + BN, no ReLU, fp32
             spec = W[pre + "#1"]
-            a, _ = self._cols(x16, spec)
-            identity = kernels.gemm(a, spec[0], spec[1], _abi.EPI_STORE_F32)
+            pointwise = spec[2] == (1, 1, 1) and spec[3] == (1, 1, 1) and x16.shape[-1] % 32 == 0
+            if IMPLICIT_CONV and not pointwise and x16.shape[-1] % 8 == 0 and x16.is_contiguous():
+                identity = kernels.conv_implicit(x16, spec[0], spec[1], spec[2], spec[3], spec[4], False, store_f32=True)
+            else:
+                a, _ = self._cols(x16, spec)
+                identity = kernels.gemm(a, spec[0], spec[1], _abi.EPI_STORE_F32)
         else:
             identity = x32.reshape(-1, x32.shape[-1])
         spec = W[pre + ".branch2#c"]

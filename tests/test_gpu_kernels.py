@@ -503,3 +503,53 @@ def test_fp16_narrowing_saturates_instead_of_overflowing():
     x[:, 0] = 1e6
     y = kernels.layernorm_rows(x, torch.full((96,), 1e5, device=DEV), torch.zeros(96, device=DEV), out_dtype=torch.float16)
     assert torch.isfinite(y).all() and (y[:, 0] == 65504).all()
+
+
+# ------------------------------------------------------------------ implicit-GEMM convolution (gemm.hip, IMPL)
+@pytest.mark.parametrize("shape,Cout,k,stride,pad", [
+    ((2, 1, 28, 28, 64), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # ResNet 3x3
+    ((2, 1, 29, 31, 128), 136, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # strided, odd sizes, ragged M / N tiles
+    ((1, 8, 14, 14, 32), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0)),       # SlowFast temporal conv
+    ((1, 6, 9, 9, 8), 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),          # K = 216 -> padded to 224; C = 8 (fast pathway)
+    ((1, 4, 7, 7, 8), 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),           # pointwise with C % 32 != 0: K = 8 -> 32
+    ((1, 16, 8, 8, 16), 64, (5, 1, 1), (4, 1, 1), (2, 0, 0)),        # lateral time-strided conv
+])
+@pytest.mark.parametrize("relu,with_resid", [(True, True), (False, False)])
+def test_conv_implicit_equals_im2col_gemm(shape, Cout, k, stride, pad, relu, with_resid, half):
+    """kvq_conv_implicit fetches the same operand values in the same K order as kvq_im2col_nd + kvq_gemm_bf16:
+    the outputs are bit-identical, and both match an fp32 F.conv3d of the rounded operands."""
+    g = rng(sum(shape) + Cout)
+    B, D, H, W, Cc = shape
+    x = rnd(torch.from_numpy(g.standard_normal(shape).astype(np.float32)), half)
+    K = k[0] * k[1] * k[2] * Cc
+    kpad = -(-K // 32) * 32
+    w5 = rnd(torch.from_numpy((g.standard_normal((Cout, Cc) + k) / np.sqrt(K)).astype(np.float32)), half)   # (N, C, kd, kh, kw)
+    wk = torch.zeros(Cout, kpad)
+    wk[:, :K] = w5.permute(0, 2, 3, 4, 1).reshape(Cout, K)                                                 # (kd, kh, kw, c) columns
+    bias = torch.from_numpy(g.standard_normal(Cout).astype(np.float32))
+    xd, wd, bd = dev(x, half), dev(wk, half), dev(bias)
+    cols, (Do, Ho, Wo) = kernels.im2col_nd(xd, (B, Cc, D, H, W), (D * H * W * Cc, 1, H * W * Cc, W * Cc, Cc), k, stride, pad,
+                                           xd.dtype, kpad)
+    M = B * Do * Ho * Wo
+    resid = torch.from_numpy(g.standard_normal((M, Cout)).astype(np.float32))
+    kw = dict(resid_f32=dev(resid), want_f32=True) if with_resid else {}
+    ref = kernels.conv_gemm(cols, wd, bd, relu, **kw)
+    got = kernels.conv_implicit(xd, wd, bd, k, stride, pad, relu, **kw)
+    if with_resid:
+        assert torch.equal(got[1], ref[1])
+        got, ref = got[0], ref[0]
+    assert got.shape == (B, Do, Ho, Wo, Cout) and torch.equal(got.reshape(M, Cout), ref)
+    if not relu:        # the fp32 projection-shortcut form
+        assert torch.equal(kernels.conv_implicit(xd, wd, bd, k, stride, pad, False, store_f32=True),
+                           kernels.gemm(cols, wd, bd, _abi.EPI_STORE_F32))
+    f = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3), w5, bias, stride, pad).permute(0, 2, 3, 4, 1).reshape(M, Cout)
+    if with_resid:
+        f = f + resid
+    f = torch.relu(f) if relu else f
+    assert (got.reshape(M, Cout).float().cpu() - f).abs().max().item() <= 4 * EPS[half] * max(1.0, f.abs().max().item())
+
+
+def test_conv_implicit_rejects_bad_shapes(half):
+    x = dev(torch.zeros(1, 1, 4, 4, 12), half)           # C % 8 != 0
+    with pytest.raises(_abi.KvqError, match="C % 8"):
+        kernels.conv_implicit(x, dev(torch.zeros(8, 128), half), dev(torch.zeros(8)), (1, 3, 3), (1, 1, 1), (0, 1, 1), True)
