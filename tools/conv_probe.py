@@ -19,7 +19,7 @@ def wrap(name):
         acc.setdefault(name, []).append((e0, e1))
         return r
     setattr(kernels, name, g)
-for n in ("im2col_nd", "conv_gemm", "pool_nd", "mean_std_pool", "conv_stem_direct"):
+for n in ("im2col_nd", "conv_gemm", "conv_implicit", "gemm", "pool_nd", "mean_std_pool", "conv_stem_direct"):
     wrap(n)
 
 def run(label, fn, flops):
