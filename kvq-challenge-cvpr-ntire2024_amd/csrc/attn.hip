@@ -498,6 +498,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   if (tr) p.trace[blockIdx.x * 8 + 1] = t_mark;
 #endif
 
+  constexpr int NTD = ATT_NT - 1;      // score tiles that can hold a key < N (N <= 400): the 26th tile of the image is never live
   const int lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
   // transpose-read source of this lane inside a V subtile: row 4g + j/4, features 4(j%4)..+3 (the hardware hands lane
@@ -525,31 +526,32 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     const u32x2* bd = dense + (size_t)qt * ATT_NT * 64;
     u32x2 braw[ATT_NT];
 #pragma unroll
-    for (int t = 0; t < ATT_NT; ++t) braw[t] = bd[t * 64];   // all 26 bias tiles requested before anything waits
+    for (int t = 0; t < NTD; ++t) braw[t] = bd[t * 64];   // all bias tiles requested before anything waits
     f32x4 S[ATT_NT];
 #pragma unroll
-    for (int t = 0; t < ATT_NT; ++t)
+    for (int t = 0; t < NTD; ++t)
       S[t] = (f32x4){Fp16::to_f32((uint16_t)(braw[t][0] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][0] >> 16)),
                      Fp16::to_f32((uint16_t)(braw[t][1] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][1] >> 16))};
     // score tile t = keys 16t..16t+15 in natural order: lane (query j, group g) then holds keys 16t+4g..+3, which is the
     // k order the transpose-read gives the V fragments
     V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(j, g)]), kfN = kfC;
 #pragma unroll
-    for (int t = 0; t < ATT_NT; ++t) {
-      if (t + 1 < ATT_NT) kfN = __builtin_bit_cast(V8, Ks[k_slot(16 * (t + 1 < ATT_NT ? t + 1 : 0) + j, g)]);
+    for (int t = 0; t < NTD; ++t) {
+      if (t + 1 < NTD) kfN = __builtin_bit_cast(V8, Ks[k_slot(16 * (t + 1 < NTD ? t + 1 : 0) + j, g)]);
       S[t] = E::mfma16(kfC, qf, S[t]);
       kfC = kfN;
     }
     ATT_MARK(t_s);
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < ATT_NT; ++t) mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
+    for (int t = 0; t < NTD; ++t) mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mb = mx * kLog2e;
     uint32_t P[ATT_NT][2];
+    P[ATT_NT - 1][0] = P[ATT_NT - 1][1] = 0u;       // keys 400..415: padding for every supported N (<= 400)
 #pragma unroll
-    for (int t = 0; t < ATT_NT; ++t) {
+    for (int t = 0; t < NTD; ++t) {
       float e[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(S[t][r], kLog2e, -mb));
