@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 8
+#define KVQ_ABI_VERSION 9
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -199,7 +199,8 @@ typedef enum {
   KVQ_EPI_QKV_BF16 = 2,    /* head-major split: out[(which*nH+h)*M + m][e], q scaled (:253-260)      */
   KVQ_EPI_RESID_F32 = 3,   /* out_f32[row(m)][n] += acc + bias, row(m) via scatter map (:472-488,509,514) */
   KVQ_EPI_STORE_F32 = 4,   /* out_f32[m][n] = acc (+ bias if non-NULL)         (reduction :553, embed) */
-  KVQ_EPI_RELU_BF16 = 5    /* out_bf16[m][n] = relu(acc + bias [+ resid_bf16[m][n]])   conv+BN(+identity)+ReLU */
+  KVQ_EPI_RELU_BF16 = 5,   /* out_bf16[m][n] = relu(acc + bias [+ resid_bf16[m][n]])   conv+BN(+identity)+ReLU */
+  KVQ_EPI_QGELU_BF16 = 6   /* out_bf16[m][n] = y * sigmoid(1.702 y), y = acc + bias     CLIP QuickGELU (clip/model.py:179-181) */
 } KvqEpilogue;
 
 typedef struct {
@@ -356,6 +357,26 @@ int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int T, int H, i
  * SlowFast_features.py:137-165).  Activations are channels-last 16-bit (B,D,H,W,C); conv = im2col -> GEMM
  * (BatchNorm folded on the host, ReLU / identity add = KVQ_EPI_RELU_BF16); 1x1x1 stride-1 convs need no im2col.
  * ------------------------------------------------------------------------------------------- */
+
+/* ---------------------------------------------------------------------------------------------
+ * KSVQE "CLIP_tool": CLIP_extractor_addadapter_cls.forward (models/backbones/CLIP_backbone.py:156-201) over the vendored
+ * CLIP vision transformer (models/backbones/clip/model.py:184-294).  Its Linear layers, LayerNorms and the 16x16 patch
+ * embedding run on kvq_gemm_bf16 / kvq_layernorm_rows / kvq_patch_im2col; these are the remaining pieces.
+ * ------------------------------------------------------------------------------------------- */
+/* Token assembly + ln_pre (:163-171): out[b][0] = LN(cls + pos[0]), out[b][1+i] = LN(tok[b*G+i] + pos[1+i]); fp32;
+ * pos is the positional embedding already resized to the G-token grid (resize_pos_embed2d :35-70 is host-side). */
+int kvq_vit_embed_ln(const float* tok, const float* cls, const float* pos, const float* ln_w, const float* ln_b, int B, int G,
+                     int D, float eps, float* out, void* stream);
+/* nn.MultiheadAttention(x, x, x) core (clip/model.py:199-201), no mask: qkv 16-bit [B*L][3*D] = the in_proj output
+ * (rows [q | k | v], head h = columns h*64.. of each third), q scaled by head_dim^-0.5 here; out 16-bit [B*L][D]
+ * (heads concatenated) = the out_proj input.  L <= 320, head_dim == 64. */
+int kvq_mha_small(const uint16_t* qkv, int B, int L, int heads, int head_dim, int dtype, uint16_t* out, void* stream);
+/* CLS adapter plumbing (CLIP_backbone.py:183-191): x (B, L, D) fp32; gather x[:, 0] as the 16-bit GEMM operand [B][D];
+ * x[:, 0] = ratio * a + (1 - ratio) * x[:, 0] with a = the adapter's 16-bit output [B][D]. */
+int kvq_cls_gather(const float* x, int B, int L, int D, int dtype, uint16_t* out, void* stream);
+int kvq_cls_mix(float* x, const uint16_t* a, int B, int L, int D, float ratio, int dtype, void* stream);
+/* torch.cosine_similarity(x[:, :1], x[:, 1:], dim=-1) (:199): out fp32 [B][L-1]. */
+int kvq_cosine_cls(const float* x, int B, int L, int D, float* out, void* stream);
 
 /* Implicit-GEMM convolution (nn.Conv2d / nn.Conv3d + folded BatchNorm [+ identity] [+ ReLU], the Bottleneck convs of
  * simpleVQA_model.py:85-126 and the SlowFast res blocks): the GEMM's A tiles are fetched straight from the channels-LAST

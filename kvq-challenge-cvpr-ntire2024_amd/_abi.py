@@ -17,9 +17,9 @@ K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "
            "gemm_embed", "tail", "embed"]
 K_COUNT = len(K_NAMES)
 
-EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16 = range(6)
+EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def dtype_code(dt) -> int:
@@ -106,6 +106,11 @@ SYMBOLS = {
     "kvq_swin3d_plan_destroy": (None, [p_void]),
     "kvq_swin3d_workspace_bytes": (sz, [p_void]),
     "kvq_swin3d_out_dims": (i32, [p_void, C.POINTER(i32 * 4)]),
+    "kvq_vit_embed_ln": (i32, [p_void, p_void, p_void, p_void, p_void, i32, i32, i32, f32, p_void, p_void]),
+    "kvq_mha_small": (i32, [p_void, i32, i32, i32, i32, i32, p_void, p_void]),
+    "kvq_cls_gather": (i32, [p_void, i32, i32, i32, i32, p_void, p_void]),
+    "kvq_cls_mix": (i32, [p_void, p_void, i32, i32, i32, f32, i32, p_void]),
+    "kvq_cosine_cls": (i32, [p_void, i32, i32, i32, p_void, p_void]),
     "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),

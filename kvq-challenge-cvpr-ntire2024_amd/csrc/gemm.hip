@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // >= 128 B contiguous per row).  Narrower stores are issue-bound: 16 dwordx2 per lane cost ~9k cycles of a
   // 128x128 tile's life, twice the 8 dwordx4 that carry the same bytes.
   constexpr bool OUT16 = EPI == KVQ_EPI_BIAS_BF16 || EPI == KVQ_EPI_GELU_BF16 || EPI == KVQ_EPI_RELU_BF16 ||
-                         EPI == KVQ_EPI_QKV_BF16;
+                         EPI == KVQ_EPI_QKV_BF16 || EPI == KVQ_EPI_QGELU_BF16;
   constexpr int CW = OUT16 ? 8 : 4;                              // columns per lane (N % 8 == 0)
   constexpr int SW = 32 * NI;                                   // slab width (floats)
   float* slab = reinterpret_cast<float*>(lds) + wave * 32 * SW;
@@ -290,6 +290,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         if (EPI == KVQ_EPI_GELU_BF16) {
 #pragma unroll
           for (int k = 0; k < CW; ++k) v[k] = gelu_fast(v[k]);
+        } else if (EPI == KVQ_EPI_QGELU_BF16) {  // CLIP's QuickGELU: x * sigmoid(1.702 x) (clip/model.py:179-181)
+#pragma unroll
+          for (int k = 0; k < CW; ++k) v[k] = v[k] / (1.f + __expf(-1.702f * v[k]));
         } else if (EPI == KVQ_EPI_RELU_BF16) {   // conv + folded BN (+ identity) + ReLU (simpleVQA_model.py:104-124)
           if (p.resid_h) {
             const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid_h + (size_t)m * p.N + n);
@@ -468,6 +471,9 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
     case KVQ_EPI_GELU_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
       return launch_dt<KVQ_EPI_GELU_BF16>(a->dtype, p, st);
+    case KVQ_EPI_QGELU_BF16:
+      KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
+      return launch_dt<KVQ_EPI_QGELU_BF16>(a->dtype, p, st);
     case KVQ_EPI_RELU_BF16:
       KVQ_REQUIRE(a->out_bf16, KVQ_ERR_NULL, "kvq_gemm_bf16: out_bf16 NULL");
       return launch_dt<KVQ_EPI_RELU_BF16>(a->dtype, p, st);

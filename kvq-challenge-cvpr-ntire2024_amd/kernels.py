@@ -57,7 +57,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     if out is None:
         if epilogue == _abi.EPI_QKV_BF16:
             out = torch.empty(3, num_heads, M, 32, dtype=A.dtype, device=A.device)
-        elif epilogue in (_abi.EPI_BIAS_BF16, _abi.EPI_GELU_BF16):
+        elif epilogue in (_abi.EPI_BIAS_BF16, _abi.EPI_GELU_BF16, _abi.EPI_QGELU_BF16):
             out = torch.empty(M, N, dtype=A.dtype, device=A.device)
         elif epilogue == _abi.EPI_STORE_F32:
             out = torch.empty(M, N, dtype=torch.float32, device=A.device)
@@ -246,6 +246,56 @@ def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None, re
     a.dtype = dtype_code(A.dtype)
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
     return (out, out32) if want_f32 else out
+
+
+def vit_embed_ln(tok: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, ln_w, ln_b, B: int, eps=1e-5):
+    """tok fp32 [B*G, D] (patch embeddings), cls [D], pos [1+G, D] -> LN(concat(cls, tok) + pos): fp32 (B, 1+G, D)."""
+    _need_gpu(tok, cls, pos, ln_w, ln_b)
+    G, D = tok.shape[0] // B, tok.shape[1]
+    assert tok.dtype == torch.float32 and tok.is_contiguous() and pos.shape == (G + 1, D) and pos.is_contiguous()
+    out = torch.empty(B, G + 1, D, dtype=torch.float32, device=tok.device)
+    check(lib().kvq_vit_embed_ln(ptr(tok), ptr(cls), ptr(pos), ptr(ln_w), ptr(ln_b), B, G, D, eps, ptr(out), current_stream()),
+          "kvq_vit_embed_ln")
+    return out
+
+
+def mha_small(qkv: torch.Tensor, B: int, L: int, heads: int):
+    """qkv 16-bit [B*L, 3*D] (in_proj output, rows [q|k|v]) -> softmax(q k^T / sqrt(hd)) v, heads concatenated: [B*L, D]."""
+    _need_gpu(qkv)
+    assert qkv.dtype in HALF_TYPES and qkv.is_contiguous() and qkv.shape[0] == B * L and qkv.shape[1] % (3 * heads) == 0
+    D = qkv.shape[1] // 3
+    out = torch.empty(B * L, D, dtype=qkv.dtype, device=qkv.device)
+    check(lib().kvq_mha_small(ptr(qkv), B, L, heads, D // heads, dtype_code(qkv.dtype), ptr(out), current_stream()), "kvq_mha_small")
+    return out
+
+
+def cls_gather(x: torch.Tensor, out_dtype):
+    """x fp32 (B, L, D) -> x[:, 0] as 16-bit [B, D]."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    B, L, D = x.shape
+    out = torch.empty(B, D, dtype=out_dtype, device=x.device)
+    check(lib().kvq_cls_gather(ptr(x), B, L, D, dtype_code(out_dtype), ptr(out), current_stream()), "kvq_cls_gather")
+    return out
+
+
+def cls_mix(x: torch.Tensor, a: torch.Tensor, ratio: float = 0.5):
+    """In place: x[:, 0] = ratio * a + (1 - ratio) * x[:, 0]; x fp32 (B, L, D), a 16-bit [B, D]."""
+    _need_gpu(x, a)
+    assert x.dtype == torch.float32 and x.is_contiguous() and a.dtype in HALF_TYPES and a.is_contiguous()
+    B, L, D = x.shape
+    check(lib().kvq_cls_mix(ptr(x), ptr(a), B, L, D, ratio, dtype_code(a.dtype), current_stream()), "kvq_cls_mix")
+    return x
+
+
+def cosine_cls(x: torch.Tensor):
+    """cosine similarity of x[:, 0] with x[:, 1:] along D: fp32 (B, L-1)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    B, L, D = x.shape
+    out = torch.empty(B, L - 1, dtype=torch.float32, device=x.device)
+    check(lib().kvq_cosine_cls(ptr(x), B, L, D, ptr(out), current_stream()), "kvq_cosine_cls")
+    return out
 
 
 _TAPS = {}

@@ -231,6 +231,59 @@ def synth_swin3d_checkpoint(cfg: SwinCfg = SWIN_T_GRPB, seed: int = 0):
     return out
 
 
+def clip_visual_param_shapes(width=768, layers=12, patch=16, grid=14, out_dim=512, clip_location=8, cls_use=True):
+    """state_dict of the reference's ``CLIP_extractor_addadapter_cls`` (CLIP_backbone.py:115-201) around the vendored
+    ViT (clip/model.py:252-267): ``visual.*`` + ``adapter_layer.{j}.{0,2}.*`` for the layers from ``clip_location`` on."""
+    sh = OrderedDict()
+    sh["visual.class_embedding"] = (width,)
+    sh["visual.positional_embedding"] = (grid * grid + 1, width)
+    sh["visual.proj"] = (width, out_dim)
+    sh["visual.conv1.weight"] = (width, 3, patch, patch)
+    sh["visual.ln_pre.weight"] = (width,)
+    sh["visual.ln_pre.bias"] = (width,)
+    for i in range(layers):
+        pre = f"visual.transformer.resblocks.{i}."
+        sh[pre + "attn.in_proj_weight"] = (3 * width, width)
+        sh[pre + "attn.in_proj_bias"] = (3 * width,)
+        sh[pre + "attn.out_proj.weight"] = (width, width)
+        sh[pre + "attn.out_proj.bias"] = (width,)
+        sh[pre + "ln_1.weight"] = (width,)
+        sh[pre + "ln_1.bias"] = (width,)
+        sh[pre + "mlp.c_fc.weight"] = (4 * width, width)
+        sh[pre + "mlp.c_fc.bias"] = (4 * width,)
+        sh[pre + "mlp.c_proj.weight"] = (width, 4 * width)
+        sh[pre + "mlp.c_proj.bias"] = (width,)
+        sh[pre + "ln_2.weight"] = (width,)
+        sh[pre + "ln_2.bias"] = (width,)
+    sh["visual.ln_post.weight"] = (width,)
+    sh["visual.ln_post.bias"] = (width,)
+    if cls_use:
+        for j in range(layers - clip_location):
+            sh[f"adapter_layer.{j}.0.weight"] = (width // 4, width)
+            sh[f"adapter_layer.{j}.0.bias"] = (width // 4,)
+            sh[f"adapter_layer.{j}.2.weight"] = (width, width // 4)
+            sh[f"adapter_layer.{j}.2.bias"] = (width,)
+    return sh
+
+
+def synth_clip_visual_weights(seed: int = 0, **kw):
+    """Fan-in scaled Linear / conv weights, LayerNorm weights around 1 ('stress' rules: the ``ln_`` names count as norms),
+    embeddings at the ViT's width^-0.5 scale."""
+    out = OrderedDict()
+    for name, shape in clip_visual_param_shapes(**kw).items():
+        g = _gen(seed, "clip/" + name)
+        leaf = name.rsplit(".", 1)[-1]
+        if ".ln_" in name:
+            out[name] = ((1.0 + 0.1 * g.standard_normal(shape)) if leaf == "weight" else 0.1 * g.standard_normal(shape)).astype(np.float32)
+        elif "embedding" in name or name == "visual.proj":
+            out[name] = (g.standard_normal(shape) * shape[-1] ** -0.5).astype(np.float32)
+        elif leaf in ("bias", "in_proj_bias"):
+            out[name] = (0.1 * g.standard_normal(shape)).astype(np.float32)
+        else:
+            out[name] = (g.standard_normal(shape) / np.sqrt(int(np.prod(shape[1:])))).astype(np.float32)
+    return out
+
+
 def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
     return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
 

@@ -299,6 +299,41 @@ def sec_taps(ref):
     save("taps.npz", d)
 
 
+CLIP_CASES = [("clip_112", 3, 112, 112, 21), ("clip_224", 2, 224, 224, 22), ("clip_96x128", 2, 96, 128, 23)]
+
+
+def sec_clip(ref):
+    """KSVQE's CLIP_tool: the reference extractor over the vendored CLIP ViT-B/16 with synthetic weights."""
+    import contextlib
+    import importlib
+    import io
+    from oracle import clip_oracle as CO
+    with contextlib.redirect_stdout(io.StringIO()):
+        CB = importlib.import_module("models.backbones.CLIP_backbone")
+        CM = importlib.import_module("models.backbones.clip.model")
+    wts = synth.synth_clip_visual_weights(7)
+    vis = CM.VisionTransformer(input_resolution=224, patch_size=16, width=768, layers=12, heads=12, output_dim=512)
+    ext = CB.CLIP_extractor_addadapter_cls(visual=vis, CLIP_location=8, cls_use=True).eval()
+    missing = ext.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=True)
+    # the reference's blocks run under torch.utils.checkpoint by default (model.py:206): same numbers in eval / no_grad
+    d = {}
+    for name, B, H, W, seed in CLIP_CASES:
+        g = np.random.Generator(np.random.PCG64(seed))
+        x = torch.from_numpy(g.standard_normal((B, 3, H, W)).astype(np.float32))
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            ra, rc, rp = ext(x)
+            oa, oc, op = CO.clip_visual_extractor(x, wts)
+        e = [float((a - b).abs().max()) for a, b in ((ra, oa), (rc, oc), (rp, op))]
+        print(f"{name}: cls_attn {tuple(ra.shape)} cls {tuple(rc.shape)} pat {tuple(rp.shape)}  |oracle-ref| {e[0]:.2e} {e[1]:.2e} {e[2]:.2e}")
+        assert e[0] <= 2e-5 and e[1] <= 2e-4 and e[2] <= 2e-4
+        put(d, f"{name}/cls_attn", samples(ra.numpy()))
+        put(d, f"{name}/cls_token", samples(rc.numpy()))
+        put(d, f"{name}/pat_token", samples(rp.numpy(), 4096))
+        d[f"{name}/meta"] = np.asarray([B, H, W, seed])
+    d["cases"] = np.asarray([c[0] for c in CLIP_CASES])
+    save("clip.npz", d)
+
+
 def sec_ckpt(ref):
     """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
     dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
@@ -346,7 +381,7 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

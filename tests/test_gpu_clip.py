@@ -1,0 +1,99 @@
+"""GPU: KSVQE's CLIP_tool on the HIP kernels (models/backbones/clip_visual.py) against the oracle and the reference's
+stored outputs; the small ViT kernels one by one against torch."""
+import numpy as np
+import pytest
+import torch
+
+import kvq_amd  # noqa: F401
+from kvq_amd import _abi, kernels
+from kvq_amd.models.backbones.clip_visual import CLIP_extractor_addadapter_cls
+from kvq_amd.utils import synth
+from oracle import clip_oracle as CO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HALF = {"fp16": torch.float16, "bf16": torch.bfloat16}
+EPS = {"fp16": 2.0 ** -11, "bf16": 2.0 ** -8}
+
+
+def _model(dtype):
+    m = CLIP_extractor_addadapter_cls(CLIP_location=8, cls_use=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_clip_visual_weights(7).items()}, strict=True)
+    m.operand_dtype = _abi.dtype_code(dtype)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", ["clip_112", "clip_224", "clip_96x128"])
+def test_clip_tool_vs_reference_golden(golden, case, dtype):
+    g = golden("clip.npz")
+    B, H, W, seed = (int(v) for v in g[f"{case}/meta"])
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal((B, 3, H, W)).astype(np.float32))
+    with torch.no_grad():
+        outs = _model(dtype)(x.to(DEV))
+    tol = {"fp16": 6e-3, "bf16": 4e-2}[dtype]                     # relative L2: 12 blocks of 16-bit-operand GEMMs
+    for name, o in zip(("cls_attn", "cls_token", "pat_token"), outs):
+        a = np.ascontiguousarray(o.float().cpu().numpy())
+        assert tuple(g[f"{case}/{name}/shape"]) == a.shape, name
+        got, ref = a.reshape(-1)[g[f"{case}/{name}/idx"]], g[f"{case}/{name}/val"]
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel <= tol, (name, rel)
+    # the cosine map is what the region selection ranks: absolute error
+    a = outs[0].float().cpu().numpy().reshape(-1)[g[f"{case}/cls_attn/idx"]]
+    assert np.abs(a - g[f"{case}/cls_attn/val"]).max() <= {"fp16": 4e-3, "bf16": 3e-2}[dtype]
+
+
+def test_clip_tool_vs_oracle_no_adapter_and_errors():
+    m = CLIP_extractor_addadapter_cls(CLIP_location=10, cls_use=False, layers=2, heads=12)
+    wts = synth.synth_clip_visual_weights(9, layers=2, cls_use=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).standard_normal((2, 3, 64, 80)).astype(np.float32))
+    with torch.no_grad():
+        got = m(x.to(DEV))
+        ref = CO.clip_visual_extractor(x, wts, cls_use=False)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        assert (a.float().cpu() - b).norm() / b.norm() <= 3e-3
+    with pytest.raises(_abi.KvqError, match="multiple"):
+        m(torch.zeros(1, 3, 70, 64, device=DEV))
+    with pytest.raises(_abi.KvqError, match="HIP device"):
+        m(torch.zeros(1, 3, 64, 64))
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,L,heads", [(3, 50, 12), (2, 197, 12), (1, 7, 2), (2, 300, 1)])
+def test_mha_small(B, L, heads, dtype):
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    D = heads * 64
+    qkv = (torch.randn(B * L, 3 * D, generator=g) * 0.7).to(HALF[dtype])
+    out = kernels.mha_small(qkv.to(DEV), B, L, heads).float().cpu()
+    q, k, v = qkv.float().reshape(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * L, D)
+    assert (out - ref).abs().max().item() <= 2.1 * EPS[dtype] * max(1.0, ref.abs().max().item())
+
+
+def test_vit_embed_ln_cls_mix_cosine_and_quickgelu():
+    g = torch.Generator().manual_seed(5)
+    B, G, D = 3, 49, 768
+    tok, cls, pos = torch.randn(B * G, D, generator=g), torch.randn(D, generator=g), torch.randn(G + 1, D, generator=g)
+    lw, lb = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    x = kernels.vit_embed_ln(tok.to(DEV), cls.to(DEV), pos.to(DEV), lw.to(DEV), lb.to(DEV), B)
+    ref = torch.nn.functional.layer_norm(torch.cat([cls.expand(B, 1, D), tok.reshape(B, G, D)], 1) + pos, (D,), lw, lb)
+    assert x.shape == (B, G + 1, D) and (x.cpu() - ref).abs().max().item() <= 2e-5
+    cos = kernels.cosine_cls(x).cpu()
+    assert (cos - torch.cosine_similarity(ref[:, :1], ref[:, 1:], dim=-1)).abs().max().item() <= 2e-6
+    c16 = kernels.cls_gather(x, torch.float16)
+    assert torch.equal(c16.cpu(), ref[:, 0].to(torch.float16)) or (c16.float().cpu() - ref[:, 0]).abs().max().item() <= 2.0 ** -10
+    a = torch.randn(B, D, generator=g).to(torch.float16)
+    before = x.clone()
+    kernels.cls_mix(x, a.to(DEV), 0.5)
+    assert (x[:, 0].cpu() - (0.5 * a.float() + 0.5 * before[:, 0].cpu())).abs().max().item() <= 1e-6
+    assert torch.equal(x[:, 1:], before[:, 1:])
+    # QuickGELU epilogue of the GEMM
+    A = (torch.randn(70, 64, generator=g)).to(torch.float16)
+    Wt = (torch.randn(40, 64, generator=g) / 8).to(torch.float16)
+    bias = torch.randn(40, generator=g)
+    y = kernels.gemm(A.to(DEV), Wt.to(DEV), bias.to(DEV), _abi.EPI_QGELU_BF16).float().cpu()
+    z = A.float() @ Wt.float().t() + bias
+    assert (y - z * torch.sigmoid(1.702 * z)).abs().max().item() <= 2.1 * 2.0 ** -11 * max(1.0, z.abs().max().item())

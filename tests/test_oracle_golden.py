@@ -127,3 +127,19 @@ def test_flops_model():
     # 175.53 GFLOP per 32x224x224 Swin-T clip; Swin-B 64x256x256 = 1892.3 GFLOP
     assert abs(O.swin_flops(synth.SWIN_T_GRPB, 32, 224, 224) / 1e9 - 175.53) < 0.01
     assert abs(O.swin_flops(synth.SWIN_B_GRPB, 64, 256, 256) / 1e9 - 1892.3) < 0.1
+
+
+# ------------------------------------------------------------------ KSVQE CLIP_tool
+@pytest.mark.parametrize("case", ["clip_112", "clip_96x128"])
+def test_clip_visual_extractor(golden, case):
+    """oracle/clip_oracle.py == the reference's CLIP_extractor_addadapter_cls over the vendored ViT-B/16 (stored outputs)."""
+    from oracle import clip_oracle as CO
+    g = golden("clip.npz")
+    B, H, W, seed = (int(v) for v in g[f"{case}/meta"])
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal((B, 3, H, W)).astype(np.float32))
+    with torch.no_grad():
+        outs = CO.clip_visual_extractor(x, synth.synth_clip_visual_weights(7))
+    for name, o, tol in zip(("cls_attn", "cls_token", "pat_token"), outs, (2e-5, 2e-4, 2e-4)):
+        a = np.ascontiguousarray(o.numpy())
+        assert tuple(g[f"{case}/{name}/shape"]) == a.shape, name
+        assert np.abs(a.reshape(-1)[g[f"{case}/{name}/idx"]] - g[f"{case}/{name}/val"]).max() <= tol, name
