@@ -371,12 +371,28 @@ int kvq_vit_embed_ln(const float* tok, const float* cls, const float* pos, const
  * (rows [q | k | v], head h = columns h*64.. of each third), q scaled by head_dim^-0.5 here; out 16-bit [B*L][D]
  * (heads concatenated) = the out_proj input.  L <= 320, head_dim == 64. */
 int kvq_mha_small(const uint16_t* qkv, int B, int L, int heads, int head_dim, int dtype, uint16_t* out, void* stream);
+/* The general form: q [B*Lq] / k, v [B*Lk] rows with their own element strides (multiples of 8; k, v 16-byte aligned) and an
+ * explicit logit scale — KSVQE's crossattention1 (KSVQE_model.py:1553-1586: trunk tokens attend CLIP / distortion tokens,
+ * scale dim^-0.5, no output projection) and its temporal Attention (:1508-1551: 16 frames per position, scale head_dim^-0.5). */
+int kvq_mha_cross(const uint16_t* q, long ldq, const uint16_t* k, long ldk, const uint16_t* v, long ldv, int B, int Lq, int Lk,
+                  int heads, int head_dim, float scale, int dtype, uint16_t* out, void* stream);
 /* CLS adapter plumbing (CLIP_backbone.py:183-191): x (B, L, D) fp32; gather x[:, 0] as the 16-bit GEMM operand [B][D];
  * x[:, 0] = ratio * a + (1 - ratio) * x[:, 0] with a = the adapter's 16-bit output [B][D]. */
 int kvq_cls_gather(const float* x, int B, int L, int D, int dtype, uint16_t* out, void* stream);
 int kvq_cls_mix(float* x, const uint16_t* a, int B, int L, int D, float ratio, int dtype, void* stream);
 /* torch.cosine_similarity(x[:, :1], x[:, 1:], dim=-1) (:199): out fp32 [B][L-1]. */
 int kvq_cosine_cls(const float* x, int B, int L, int D, float* out, void* stream);
+
+/* fp32 <-> 16-bit element conversion of an activation (n elements; to_half: src fp32 16-B aligned). */
+int kvq_convert(const void* src, void* dst, long n, int to_half, int dtype, void* stream);
+/* Semantic_Transformation2.forward (KSVQE_model.py:829-835) on channels-last token rows: per row m
+ * gama = sigmoid(<w_gama, x_m> + b_gama), beta = <w_beta, x_m> + b_beta (the two 1x1 convs C -> 1), out_m = gama*input_m + beta. */
+int kvq_sem_modulate(const float* x, const float* input, const float* w_gama, float b_gama, const float* w_beta, float b_beta, int M,
+                     int C, float* out, void* stream);
+/* Dist_Transformation3.forward (:952-960), last step: out[b][r][c] = sigmoid(gamma_logit[b][c]) * input[b][r][c] + beta[b][c];
+ * gamma_logit / beta = get_gamma(std) / get_beta(mean), 16-bit [B][C] (GEMM outputs). */
+int kvq_dist_modulate(const float* input, const uint16_t* gamma_logit, const uint16_t* beta, int B, int rows, int C, int dtype,
+                      float* out, void* stream);
 
 /* Implicit-GEMM convolution (nn.Conv2d / nn.Conv3d + folded BatchNorm [+ identity] [+ ReLU], the Bottleneck convs of
  * simpleVQA_model.py:85-126 and the SlowFast res blocks): the GEMM's A tiles are fetched straight from the channels-LAST

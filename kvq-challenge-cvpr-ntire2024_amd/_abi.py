@@ -108,9 +108,13 @@ SYMBOLS = {
     "kvq_swin3d_out_dims": (i32, [p_void, C.POINTER(i32 * 4)]),
     "kvq_vit_embed_ln": (i32, [p_void, p_void, p_void, p_void, p_void, i32, i32, i32, f32, p_void, p_void]),
     "kvq_mha_small": (i32, [p_void, i32, i32, i32, i32, i32, p_void, p_void]),
+    "kvq_mha_cross": (i32, [p_void, i64, p_void, i64, p_void, i64, i32, i32, i32, i32, i32, f32, i32, p_void, p_void]),
     "kvq_cls_gather": (i32, [p_void, i32, i32, i32, i32, p_void, p_void]),
     "kvq_cls_mix": (i32, [p_void, p_void, i32, i32, i32, f32, i32, p_void]),
     "kvq_cosine_cls": (i32, [p_void, i32, i32, i32, p_void, p_void]),
+    "kvq_convert": (i32, [p_void, p_void, i64, i32, i32, p_void]),
+    "kvq_sem_modulate": (i32, [p_void, p_void, p_void, f32, p_void, f32, i32, i32, p_void, p_void]),
+    "kvq_dist_modulate": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, p_void, p_void]),
     "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),

@@ -37,32 +37,43 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restri
   for (int c = tid; c < D; c += 256) o[c] = (src[c] + pr[c] - mean) * rstd * lw[c] + lb[c];
 }
 
-// nn.MultiheadAttention core on the in_proj output: qkv [B*L][3*D] 16-bit, token-major rows [q | k | v], head h = columns
-// h*HD .. of each third.  One workgroup per (batch element, head): K and V of the head in LDS (16-bit), a thread owns a
-// query and runs the online softmax over the keys in fp32 (K / V rows are LDS broadcasts).
+// Short-sequence multi-head attention, head_dim HD: out[b][i][h*HD..] = softmax_j(scale * q_i . k_j) v_j over the Lk keys of
+// batch element b.  q / k / v are 16-bit row-major with their own row strides (the packed in_proj output of
+// nn.MultiheadAttention is q = qkv, k = qkv + D, v = qkv + 2D with stride 3D; a cross-attention passes separate tensors).
+// One workgroup per (batch element, head): K and V of the head in LDS (16-bit), a thread owns a query and runs the online
+// softmax over the keys in fp32 (K / V rows are LDS broadcasts).
+struct MhaParams {
+  const uint16_t *q, *k, *v;
+  long ldq, ldk, ldv;          // row strides in elements
+  int Lq, Lk, heads;
+  float scale;
+  uint16_t* out;               // [B*Lq][heads*HD]
+};
+
 template <typename E, int HD>
-__global__ __launch_bounds__(64) void mha_small_kernel(const uint16_t* __restrict__ qkv, int L, int heads, uint16_t* __restrict__ out) {
+__global__ __launch_bounds__(64) void mha_small_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
-  uint16_t* Vs = Ks + (size_t)L * HD;
-  const int h = blockIdx.x % heads, b = blockIdx.x / heads, tid = threadIdx.x, D = heads * HD;
-  const uint16_t* base = qkv + (size_t)b * L * 3 * D + h * HD;
-  for (int i = tid; i < L * (HD / 8); i += 64) {
+  uint16_t* Vs = Ks + (size_t)p.Lk * HD;
+  const int h = blockIdx.x % p.heads, b = blockIdx.x / p.heads, tid = threadIdx.x, D = p.heads * HD;
+  const uint16_t* kb = p.k + (size_t)b * p.Lk * p.ldk + h * HD;
+  const uint16_t* vb = p.v + (size_t)b * p.Lk * p.ldv + h * HD;
+  for (int i = tid; i < p.Lk * (HD / 8); i += 64) {
     const int r = i / (HD / 8), c = i % (HD / 8);
-    *reinterpret_cast<u32x4*>(Ks + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(base + (size_t)r * 3 * D + D + c * 8);
-    *reinterpret_cast<u32x4*>(Vs + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(base + (size_t)r * 3 * D + 2 * D + c * 8);
+    *reinterpret_cast<u32x4*>(Ks + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(kb + (size_t)r * p.ldk + c * 8);
+    *reinterpret_cast<u32x4*>(Vs + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(vb + (size_t)r * p.ldv + c * 8);
   }
   __syncthreads();
-  const float scale = rsqrtf((float)HD);
-  for (int l = tid; l < L; l += 64) {
+  const uint16_t* qb = p.q + (size_t)b * p.Lq * p.ldq + h * HD;
+  for (int l = tid; l < p.Lq; l += 64) {
     float q[HD], o[HD];
 #pragma unroll
     for (int c = 0; c < HD; ++c) {
-      q[c] = E::to_f32(base[(size_t)l * 3 * D + c]) * scale;
+      q[c] = E::to_f32(qb[(size_t)l * p.ldq + c]) * p.scale;
       o[c] = 0.f;
     }
     float mx = -INFINITY, sum = 0.f;
-    for (int j = 0; j < L; ++j) {
+    for (int j = 0; j < p.Lk; ++j) {
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) s = fmaf(q[c], E::to_f32(Ks[j * HD + c]), s);
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(64) void mha_small_kernel(const uint16_t* __restric
       mx = nm;
     }
     const float inv = 1.f / sum;
-    uint16_t* dst = out + ((size_t)b * L + l) * D + h * HD;
+    uint16_t* dst = p.out + ((size_t)b * p.Lq + l) * D + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 2) *reinterpret_cast<uint32_t*>(dst + c) = E::pack2(o[c] * inv, o[c + 1] * inv);
   }
@@ -133,25 +144,38 @@ extern "C" int kvq_vit_embed_ln(const float* tok, const float* cls, const float*
   return KVQ_OK;
 }
 
-extern "C" int kvq_mha_small(const uint16_t* qkv, int B, int L, int heads, int head_dim, int dtype, uint16_t* out, void* stream) {
+extern "C" int kvq_mha_cross(const uint16_t* q, long ldq, const uint16_t* k, long ldk, const uint16_t* v, long ldv, int B, int Lq,
+                             int Lk, int heads, int head_dim, float scale, int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(qkv && out, KVQ_ERR_NULL, "kvq_mha_small: NULL pointer");
-  KVQ_REQUIRE(B > 0 && L > 0 && L <= 320 && heads > 0, KVQ_ERR_SHAPE, "kvq_mha_small: bad shape B=%d L=%d heads=%d (L <= 320)", B, L, heads);
-  KVQ_REQUIRE(head_dim == 64, KVQ_ERR_UNSUPPORTED, "kvq_mha_small: head_dim %d (64 = CLIP ViT-B)", head_dim);
-  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mha_small: dtype %d", dtype);
-  const size_t lds = (size_t)2 * L * 64 * sizeof(uint16_t);
+  KVQ_REQUIRE(q && k && v && out, KVQ_ERR_NULL, "kvq_mha_cross: NULL pointer");
+  KVQ_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && Lk <= 320 && heads > 0 && ldq >= (long)heads * head_dim && ldk >= (long)heads * head_dim &&
+                  ldv >= (long)heads * head_dim && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0,
+              KVQ_ERR_SHAPE, "kvq_mha_cross: bad shape B=%d Lq=%d Lk=%d heads=%d (Lk <= 320, strides multiples of 8)", B, Lq, Lk, heads);
+  KVQ_REQUIRE(head_dim == 64, KVQ_ERR_UNSUPPORTED, "kvq_mha_cross: head_dim %d (64 only)", head_dim);
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mha_cross: dtype %d", dtype);
+  KVQ_REQUIRE((((size_t)k | (size_t)v) & 15) == 0, KVQ_ERR_SHAPE, "kvq_mha_cross: k / v must be 16-byte aligned");
+  MhaParams p{q, k, v, ldq, ldk, ldv, Lq, Lk, heads, scale, out};
+  const size_t lds = (size_t)2 * Lk * 64 * sizeof(uint16_t);
   dim3 grid((unsigned)(B * heads)), block(64);
   if (dtype == KVQ_DT_FP16) {
-    auto k = mha_small_kernel<Fp16, 64>;
-    if (lds > 64 * 1024) KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, (hipStream_t)stream, qkv, L, heads, out);
+    auto kern = mha_small_kernel<Fp16, 64>;
+    if (lds > 64 * 1024) KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, p);
   } else {
-    auto k = mha_small_kernel<Bf16, 64>;
-    if (lds > 64 * 1024) KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, (hipStream_t)stream, qkv, L, heads, out);
+    auto kern = mha_small_kernel<Bf16, 64>;
+    if (lds > 64 * 1024) KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, p);
   }
   KVQ_CHECK_LAUNCH("mha_small_kernel");
   return KVQ_OK;
+}
+
+extern "C" int kvq_mha_small(const uint16_t* qkv, int B, int L, int heads, int head_dim, int dtype, uint16_t* out, void* stream) {
+  KVQ_REQUIRE(qkv, KVQ_ERR_NULL, "kvq_mha_small: NULL pointer");
+  KVQ_REQUIRE(heads > 0 && head_dim > 0, KVQ_ERR_SHAPE, "kvq_mha_small: bad shape");
+  const long D = (long)heads * head_dim;
+  return kvq_mha_cross(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, B, L, L, heads, head_dim, 1.0f / sqrtf((float)head_dim), dtype, out,
+                       stream);
 }
 
 extern "C" int kvq_cls_gather(const float* x, int B, int L, int D, int dtype, uint16_t* out, void* stream) {
@@ -186,5 +210,107 @@ extern "C" int kvq_cosine_cls(const float* x, int B, int L, int D, float* out, v
   KVQ_REQUIRE(B > 0 && L > 1 && D > 0, KVQ_ERR_SHAPE, "kvq_cosine_cls: bad shape B=%d L=%d D=%d", B, L, D);
   hipLaunchKernelGGL(cosine_cls_kernel, dim3((unsigned)(B * (L - 1))), dim3(64), 0, (hipStream_t)stream, x, L, D, out);
   KVQ_CHECK_LAUNCH("cosine_cls_kernel");
+  return KVQ_OK;
+}
+
+// ---- KSVQE content-distortion modulation (CDM) pieces, KSVQE_model.py:817-835, :934-960 -----------------------------
+namespace kvq {
+
+template <typename E>
+__global__ void to_half_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    *reinterpret_cast<u32x2*>(out + i) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+  } else {
+    for (long j = i; j < n; ++j) out[j] = E::cvt(x[j]);
+  }
+}
+
+template <typename E>
+__global__ void to_float_kernel(const uint16_t* __restrict__ x, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = E::to_f32(x[i]);
+}
+
+// Semantic_Transformation2: per token row m: gama = sigmoid(<wg, x_m> + bg), beta = <wb, x_m> + bb; out_m = gama * in_m + beta
+__global__ __launch_bounds__(64) void sem_modulate_kernel(const float* __restrict__ x, const float* __restrict__ inp,
+                                                          const float* __restrict__ wg, float bg, const float* __restrict__ wb,
+                                                          float bb, int C, float* __restrict__ out) {
+  const size_t m = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* xr = x + m * C;
+  float sg = 0.f, sb = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    sg = fmaf(wg[c], xr[c], sg);
+    sb = fmaf(wb[c], xr[c], sb);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sg += __shfl_xor(sg, o);
+    sb += __shfl_xor(sb, o);
+  }
+  const float gama = 1.f / (1.f + __expf(-(sg + bg))), beta = sb + bb;
+  for (int c = lane; c < C; c += 64) out[m * C + c] = fmaf(gama, inp[m * C + c], beta);
+}
+
+// Dist_Transformation3: out[b][t][c] = sigmoid(g[b][c]) * in[b][t][c] + beta[b][c]   (g, beta: the two Linear outputs)
+template <typename E>
+__global__ void dist_modulate_kernel(const float* __restrict__ inp, const uint16_t* __restrict__ g, const uint16_t* __restrict__ beta,
+                                     int rows, int C, float* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long b = i / ((long)rows * C);
+  const float gm = 1.f / (1.f + __expf(-E::to_f32(g[b * C + c])));
+  out[i] = fmaf(gm, inp[i], E::to_f32(beta[b * C + c]));
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_convert(const void* src, void* dst, long n, int to_half, int dtype, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(src && dst, KVQ_ERR_NULL, "kvq_convert: NULL pointer");
+  KVQ_REQUIRE(n > 0, KVQ_ERR_SHAPE, "kvq_convert: n=%ld", n);
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_convert: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (to_half) {
+    KVQ_REQUIRE((((size_t)src & 15) | ((size_t)dst & 7)) == 0, KVQ_ERR_SHAPE, "kvq_convert: unaligned");
+    dim3 grid((unsigned)((n / 4 + 256) / 256)), block(256);
+    if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(to_half_kernel<Fp16>, grid, block, 0, st, (const float*)src, (uint16_t*)dst, n);
+    else hipLaunchKernelGGL(to_half_kernel<Bf16>, grid, block, 0, st, (const float*)src, (uint16_t*)dst, n);
+  } else {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(to_float_kernel<Fp16>, grid, block, 0, st, (const uint16_t*)src, (float*)dst, n);
+    else hipLaunchKernelGGL(to_float_kernel<Bf16>, grid, block, 0, st, (const uint16_t*)src, (float*)dst, n);
+  }
+  KVQ_CHECK_LAUNCH("convert kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_sem_modulate(const float* x, const float* input, const float* w_gama, float b_gama, const float* w_beta,
+                                float b_beta, int M, int C, float* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && input && w_gama && w_beta && out, KVQ_ERR_NULL, "kvq_sem_modulate: NULL pointer");
+  KVQ_REQUIRE(M > 0 && C > 0, KVQ_ERR_SHAPE, "kvq_sem_modulate: bad shape M=%d C=%d", M, C);
+  hipLaunchKernelGGL(sem_modulate_kernel, dim3((unsigned)M), dim3(64), 0, (hipStream_t)stream, x, input, w_gama, b_gama, w_beta,
+                     b_beta, C, out);
+  KVQ_CHECK_LAUNCH("sem_modulate_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_dist_modulate(const float* input, const uint16_t* gamma_logit, const uint16_t* beta, int B, int rows, int C,
+                                 int dtype, float* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(input && gamma_logit && beta && out, KVQ_ERR_NULL, "kvq_dist_modulate: NULL pointer");
+  KVQ_REQUIRE(B > 0 && rows > 0 && C > 0, KVQ_ERR_SHAPE, "kvq_dist_modulate: bad shape");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_dist_modulate: dtype %d", dtype);
+  const long total = (long)B * rows * C;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == KVQ_DT_FP16)
+    hipLaunchKernelGGL(dist_modulate_kernel<Fp16>, grid, block, 0, (hipStream_t)stream, input, gamma_logit, beta, rows, C, out, total);
+  else
+    hipLaunchKernelGGL(dist_modulate_kernel<Bf16>, grid, block, 0, (hipStream_t)stream, input, gamma_logit, beta, rows, C, out, total);
+  KVQ_CHECK_LAUNCH("dist_modulate_kernel");
   return KVQ_OK;
 }

@@ -269,6 +269,58 @@ def mha_small(qkv: torch.Tensor, B: int, L: int, heads: int):
     return out
 
 
+def mha_cross(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, heads: int, scale: float):
+    """q 16-bit [B*Lq, >= heads*64] / k, v [B*Lk, ...] (row-strided 2-D views allowed, last dim contiguous) ->
+    softmax(scale q k^T) v per head: [B*Lq, heads*64]."""
+    _need_gpu(q, k, v)
+    for t in (q, k, v):
+        assert t.dtype in HALF_TYPES and t.dim() == 2 and t.stride(1) == 1
+    Lq, Lk, D = q.shape[0] // B, k.shape[0] // B, heads * 64
+    out = torch.empty(B * Lq, D, dtype=q.dtype, device=q.device)
+    check(lib().kvq_mha_cross(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), B, Lq, Lk, heads, 64,
+                              scale, dtype_code(q.dtype), ptr(out), current_stream()), "kvq_mha_cross")
+    return out
+
+
+def to_half(x: torch.Tensor, out_dtype):
+    """fp32 activation -> 16-bit MFMA operand (same shape)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib().kvq_convert(ptr(x), ptr(out), x.numel(), 1, dtype_code(out_dtype), current_stream()), "kvq_convert")
+    return out
+
+
+def to_float(x: torch.Tensor):
+    """16-bit activation -> fp32 (same shape)."""
+    _need_gpu(x)
+    assert x.dtype in HALF_TYPES and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().kvq_convert(ptr(x), ptr(out), x.numel(), 0, dtype_code(x.dtype), current_stream()), "kvq_convert")
+    return out
+
+
+def sem_modulate(x: torch.Tensor, inp: torch.Tensor, w_gama, b_gama: float, w_beta, b_beta: float):
+    """x, inp fp32 [M, C] token rows -> sigmoid(<w_gama, x_m> + b_gama) * inp_m + (<w_beta, x_m> + b_beta)."""
+    _need_gpu(x, inp, w_gama, w_beta)
+    assert x.dtype == torch.float32 and inp.dtype == torch.float32 and x.is_contiguous() and inp.is_contiguous() and x.shape == inp.shape
+    out = torch.empty_like(inp)
+    check(lib().kvq_sem_modulate(ptr(x), ptr(inp), ptr(w_gama), float(b_gama), ptr(w_beta), float(b_beta), x.shape[0], x.shape[1],
+                                 ptr(out), current_stream()), "kvq_sem_modulate")
+    return out
+
+
+def dist_modulate(inp: torch.Tensor, gamma_logit: torch.Tensor, beta: torch.Tensor):
+    """inp fp32 (B, rows, C); gamma_logit / beta 16-bit [B, C] -> sigmoid(gamma_logit)[:, None] * inp + beta[:, None]."""
+    _need_gpu(inp, gamma_logit, beta)
+    assert inp.dtype == torch.float32 and inp.is_contiguous() and gamma_logit.dtype in HALF_TYPES and beta.dtype == gamma_logit.dtype
+    B, rows, Cc = inp.shape
+    out = torch.empty_like(inp)
+    check(lib().kvq_dist_modulate(ptr(inp), ptr(gamma_logit), ptr(beta), B, rows, Cc, dtype_code(beta.dtype), ptr(out),
+                                  current_stream()), "kvq_dist_modulate")
+    return out
+
+
 def cls_gather(x: torch.Tensor, out_dtype):
     """x fp32 (B, L, D) -> x[:, 0] as 16-bit [B, D]."""
     _need_gpu(x)

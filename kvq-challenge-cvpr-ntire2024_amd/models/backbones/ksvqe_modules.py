@@ -1,0 +1,132 @@
+"""Host-side mirrors of KSVQE's content-distortion modulation (CDM) modules, ``models/backbones/KSVQE_model.py``:
+``crossattention1`` (:1553-1586), ``Attention`` (:1508-1551), ``Semantic_Transformation2`` (:817-835) and
+``Dist_Transformation3`` (:934-960) — the four the trainer's KSVQE instantiates per tuned stage (:1160-1186) — with the
+reference's constructor arguments, ``state_dict`` keys, argument layouts and outputs.  The torch modules only hold
+parameters; the arithmetic runs on ``libkvq_hip.so`` (GEMMs, ``kvq_mha_cross``, ``kvq_mean_std_pool``, the modulation
+kernels).  Part of SURVEY.md §8 f1; KSVQE's forward itself (key frames, QRS, CONTRIQUE, the stage hooks) is not built yet."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from ... import _abi, kernels
+
+
+class _HipModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.operand_dtype = _abi.dtype_code(os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
+        self._wc = None
+
+    def _half(self):
+        return _abi.torch_dtype(self.operand_dtype)
+
+    def _cached(self, device, build):
+        sig = (self.operand_dtype, str(device)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._wc is None or self._wc[0] != sig:
+            self._wc = (sig, build())
+        return self._wc[1]
+
+    def _w16(self, t, device):
+        t = t.detach().to(device, torch.float32)
+        if self._half() == torch.float16:
+            t = t.clamp(-65504.0, 65504.0)
+        return t.to(self._half()).contiguous()
+
+    @staticmethod
+    def _need(*ts):
+        for t in ts:
+            if not t.is_cuda:
+                raise _abi.KvqError("this module needs its inputs on a HIP device; there is no CPU path")
+
+
+class crossattention1(_HipModule):  # noqa: N801  (reference spelling)
+    """Q (B, Nq, C) attends K (B, Nk, C): heads of C / num_heads = 64 channels, logits scaled by C^-0.5 (the full width, as
+    the reference does), no output projection.  Returns ``(O, None)``: the reference's second output (the head-averaged
+    attention map) is discarded by every caller (KSVQE_model.py:1451, :1471) and is not produced here."""
+
+    def __init__(self, dim, num_heads, ln=False):
+        super().__init__()
+        self.dim_V, self.num_heads = dim, num_heads
+        self.fc_q, self.fc_k, self.fc_v = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
+
+    def forward(self, Q, K):
+        self._need(Q, K)
+        dev, h = Q.device, self._half()
+        w = self._cached(dev, lambda: [(self._w16(m.weight, dev), m.bias.detach().to(dev, torch.float32).contiguous())
+                                       for m in (self.fc_q, self.fc_k, self.fc_v)])
+        B, Nq, C = Q.shape
+        q16 = kernels.to_half(Q.to(torch.float32).contiguous().reshape(-1, C), h)
+        k16 = kernels.to_half(K.to(torch.float32).contiguous().reshape(-1, C), h)
+        q = kernels.gemm(q16, *w[0], _abi.EPI_BIAS_BF16)
+        k = kernels.gemm(k16, *w[1], _abi.EPI_BIAS_BF16)
+        v = kernels.gemm(k16, *w[2], _abi.EPI_BIAS_BF16)
+        o = kernels.mha_cross(q, k, v, B, self.num_heads, float(self.dim_V) ** -0.5)
+        return kernels.to_float(o).reshape(B, Nq, C), None
+
+
+class Attention(_HipModule):
+    """Self-attention over x (B, n, C) with a bias-free qkv projection, head_dim^-0.5 scaling and an output Linear."""
+
+    def __init__(self, dim, heads=8, dropout=0.0):
+        super().__init__()
+        self.heads, self.scale = heads, (dim // heads) ** -0.5
+        self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Dropout(dropout))
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("key mask: no caller passes one (KSVQE_model.py:1473)")
+        self._need(x)
+        dev, h = x.device, self._half()
+        w = self._cached(dev, lambda: (self._w16(self.to_qkv.weight, dev), self._w16(self.to_out[0].weight, dev),
+                                       self.to_out[0].bias.detach().to(dev, torch.float32).contiguous()))
+        B, n, C = x.shape
+        qkv = kernels.gemm(kernels.to_half(x.to(torch.float32).contiguous().reshape(-1, C), h), w[0], None, _abi.EPI_BIAS_BF16)
+        o = kernels.mha_small(qkv, B, n, self.heads)
+        return kernels.to_float(kernels.gemm(o, w[1], w[2], _abi.EPI_BIAS_BF16)).reshape(B, n, C)
+
+
+class Semantic_Transformation2(_HipModule):  # noqa: N801
+    """x, input (N, C, h, w): gama = sigmoid(conv1x1_{C->1}(x)), beta = conv1x1_{C->1}(x); returns gama * input + beta."""
+
+    def __init__(self, inChannels):  # noqa: N803
+        super().__init__()
+        self.conv_gama = nn.Conv2d(inChannels, 1, 1, padding=0, stride=1)
+        self.conv_beta = nn.Conv2d(inChannels, 1, 1, padding=0, stride=1)
+
+    def forward(self, x, input):  # noqa: A002  (reference argument name)
+        self._need(x, input)
+        dev = x.device
+        w = self._cached(dev, lambda: (self.conv_gama.weight.detach().to(dev, torch.float32).reshape(-1).contiguous(),
+                                       float(self.conv_gama.bias.detach()), self.conv_beta.weight.detach().to(dev, torch.float32)
+                                       .reshape(-1).contiguous(), float(self.conv_beta.bias.detach())))
+        N, C, hh, ww = x.shape
+        rows = lambda t: t.to(torch.float32).permute(0, 2, 3, 1).reshape(N * hh * ww, C).contiguous()   # noqa: E731  (layout only)
+        out = kernels.sem_modulate(rows(x), rows(input), *w)
+        return out.reshape(N, hh, ww, C).permute(0, 3, 1, 2)
+
+
+class Dist_Transformation3(_HipModule):  # noqa: N801
+    """x (B, C, T, H, W), input (B, T·H·W, C): gamma = sigmoid(Linear(std_{THW} x)) (unbiased std), beta = Linear(mean_{THW} x);
+    returns gamma[:, None] * input + beta[:, None]."""
+
+    def __init__(self, inChannels):  # noqa: N803
+        super().__init__()
+        self.get_gamma, self.get_beta = nn.Linear(inChannels, inChannels), nn.Linear(inChannels, inChannels)
+
+    def forward(self, x, input):  # noqa: A002
+        self._need(x, input)
+        dev, h = x.device, self._half()
+        w = self._cached(dev, lambda: (self._w16(self.get_gamma.weight, dev), self.get_gamma.bias.detach().to(dev, torch.float32).contiguous(),
+                                       self._w16(self.get_beta.weight, dev), self.get_beta.bias.detach().to(dev, torch.float32).contiguous()))
+        B, C = x.shape[:2]
+        x16 = kernels.to_half(x.to(torch.float32).reshape(B, C, -1).permute(0, 2, 1).contiguous(), h)      # (B, THW, C) channels-last
+        stats = torch.empty(B, 2 * C, dtype=torch.float32, device=dev)
+        kernels.mean_std_pool(x16, stats, 0, C)
+        s16 = kernels.to_half(stats, h)
+        g = kernels.gemm(s16[:, C:].contiguous(), w[0], w[1], _abi.EPI_BIAS_BF16)
+        b = kernels.gemm(s16[:, :C].contiguous(), w[2], w[3], _abi.EPI_BIAS_BF16)
+        return kernels.dist_modulate(input.to(torch.float32).contiguous(), g, b)

@@ -284,6 +284,27 @@ def synth_clip_visual_weights(seed: int = 0, **kw):
     return out
 
 
+def synth_cdm_weights(seed: int = 0, dim: int = 768):
+    """Synthetic state_dicts of the four CDM modules of one tuned KSVQE stage (KSVQE_model.py:1160-1186), keyed by module."""
+    shapes = {
+        "cross": {"fc_q.weight": (dim, dim), "fc_q.bias": (dim,), "fc_k.weight": (dim, dim), "fc_k.bias": (dim,),
+                  "fc_v.weight": (dim, dim), "fc_v.bias": (dim,)},
+        "self": {"to_qkv.weight": (3 * dim, dim), "to_out.0.weight": (dim, dim), "to_out.0.bias": (dim,)},
+        "sem": {"conv_gama.weight": (1, dim, 1, 1), "conv_gama.bias": (1,), "conv_beta.weight": (1, dim, 1, 1), "conv_beta.bias": (1,)},
+        "dist": {"get_gamma.weight": (dim, dim), "get_gamma.bias": (dim,), "get_beta.weight": (dim, dim), "get_beta.bias": (dim,)},
+    }
+    out = {}
+    for mod, sh in shapes.items():
+        out[mod] = OrderedDict()
+        for name, shape in sh.items():
+            g = _gen(seed, f"cdm/{mod}/{name}")
+            if name.endswith("bias"):
+                out[mod][name] = (0.1 * g.standard_normal(shape)).astype(np.float32)
+            else:
+                out[mod][name] = (g.standard_normal(shape) / np.sqrt(int(np.prod(shape[1:])))).astype(np.float32)
+    return out
+
+
 def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
     return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
 

@@ -1,0 +1,54 @@
+"""ORACLE (test infrastructure, never shipped in the product path).
+
+CPU fp32 restatements of KSVQE's content-distortion modulation modules (``models/backbones/KSVQE_model.py``):
+``crossattention1`` :1553-1586, ``Attention`` :1508-1551, ``Semantic_Transformation2`` :817-835,
+``Dist_Transformation3`` :934-960, as plain functions over their state_dicts.
+
+Pinned: ``tests/golden/make_golden.py cdm`` runs the imported reference modules with the same synthetic weights,
+checks these functions against them and stores the reference's outputs in ``tests/golden/cdm.npz``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def cross_attention(Q, K, p, num_heads):
+    """(B, Nq, C), (B, Nk, C) -> (O (B, Nq, C), A (B, Nq, Nk) = head-mean of the softmax); logits / sqrt(C)."""
+    q = F.linear(Q, p["fc_q.weight"], p["fc_q.bias"])
+    k = F.linear(K, p["fc_k.weight"], p["fc_k.bias"])
+    v = F.linear(K, p["fc_v.weight"], p["fc_v.bias"])
+    B, Nq, C = q.shape
+    hd = C // num_heads
+    qh, kh, vh = (t.reshape(B, -1, num_heads, hd).transpose(1, 2) for t in (q, k, v))
+    a = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(C), dim=-1)
+    # second output: the reference stacks the heads HEAD-major ([h*B + b], torch.cat of the channel splits along dim 0) and
+    # then views that as (B, heads, ...) before averaging (:1585) — so its "head mean" mixes batch elements.  Reproduced
+    # as-is; every caller discards it (:1451, :1471).
+    a_cat = a.transpose(0, 1).reshape(num_heads * B, Nq, -1)
+    return (a @ vh).transpose(1, 2).reshape(B, Nq, C), a_cat.reshape(B, num_heads, Nq, -1).mean(dim=1)
+
+
+def self_attention(x, p, heads):
+    B, n, C = x.shape
+    hd = C // heads
+    q, k, v = (t.reshape(B, n, heads, hd).transpose(1, 2) for t in F.linear(x, p["to_qkv.weight"]).chunk(3, dim=-1))
+    a = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    return F.linear((a @ v).transpose(1, 2).reshape(B, n, C), p["to_out.0.weight"], p["to_out.0.bias"])
+
+
+def semantic_transformation2(x, inp, p):
+    gama = torch.sigmoid(F.conv2d(x, p["conv_gama.weight"], p["conv_gama.bias"]))
+    return gama * inp + F.conv2d(x, p["conv_beta.weight"], p["conv_beta.bias"])
+
+
+def dist_transformation3(x, inp, p):
+    B, C = x.shape[:2]
+    flat = x.reshape(B, C, -1)
+    gama = torch.sigmoid(F.linear(flat.std(dim=2), p["get_gamma.weight"], p["get_gamma.bias"]))
+    beta = F.linear(flat.mean(dim=2), p["get_beta.weight"], p["get_beta.bias"])
+    return gama.unsqueeze(1) * inp + beta.unsqueeze(1)

@@ -334,6 +334,44 @@ def sec_clip(ref):
     save("clip.npz", d)
 
 
+def cdm_inputs(seed=31, n=2, t=16, hw=49, nk=49, dim=768):
+    g = np.random.Generator(np.random.PCG64(seed))
+    r = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32))     # noqa: E731
+    return dict(Q=r(n * t, hw, dim), K=r(n * t, nk, dim), xs=r(n * hw, t, dim), sem_x=r(n * t, dim, 7, 7), sem_in=r(n * t, dim, 7, 7),
+                dist_x=r(n, dim, t, 7, 7) * 1.5 + 0.3, dist_in=r(n, t * hw, dim))
+
+
+def sec_cdm(ref):
+    """KSVQE's CDM modules: the reference classes with synthetic weights on seeded inputs."""
+    import contextlib
+    import importlib
+    import io
+    from oracle import ksvqe_oracle as KO
+    with contextlib.redirect_stdout(io.StringIO()):
+        K = importlib.import_module("models.backbones.KSVQE_model")
+    w = {m: {k: torch.from_numpy(v) for k, v in sd.items()} for m, sd in synth.synth_cdm_weights(11).items()}
+    x = cdm_inputs()
+    mods = dict(cross=K.crossattention1(768, 12), self=K.Attention(768, 12), sem=K.Semantic_Transformation2(768),
+                dist=K.Dist_Transformation3(768))
+    for k, m in mods.items():
+        m.load_state_dict(w[k], strict=True)
+        m.eval()
+    with torch.no_grad():
+        ref_out = dict(cross=mods["cross"](x["Q"], x["K"])[0], cross_A=mods["cross"](x["Q"], x["K"])[1], self=mods["self"](x["xs"]),
+                       sem=mods["sem"](x["sem_x"], x["sem_in"]), dist=mods["dist"](x["dist_x"], x["dist_in"]))
+        o, a = KO.cross_attention(x["Q"], x["K"], w["cross"], 12)
+        mine = dict(cross=o, cross_A=a, self=KO.self_attention(x["xs"], w["self"], 12),
+                    sem=KO.semantic_transformation2(x["sem_x"], x["sem_in"], w["sem"]),
+                    dist=KO.dist_transformation3(x["dist_x"], x["dist_in"], w["dist"]))
+    d = {}
+    for k in ref_out:
+        e = float((ref_out[k] - mine[k]).abs().max())
+        print(f"cdm {k}: {tuple(ref_out[k].shape)} |oracle-ref| {e:.2e}")
+        assert e <= 2e-5
+        put(d, k, samples(ref_out[k].contiguous().numpy(), 4096))
+    save("cdm.npz", d)
+
+
 def sec_ckpt(ref):
     """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
     dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
@@ -381,7 +419,7 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

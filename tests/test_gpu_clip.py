@@ -97,3 +97,49 @@ def test_vit_embed_ln_cls_mix_cosine_and_quickgelu():
     y = kernels.gemm(A.to(DEV), Wt.to(DEV), bias.to(DEV), _abi.EPI_QGELU_BF16).float().cpu()
     z = A.float() @ Wt.float().t() + bias
     assert (y - z * torch.sigmoid(1.702 * z)).abs().max().item() <= 2.1 * 2.0 ** -11 * max(1.0, z.abs().max().item())
+
+
+# ------------------------------------------------------------------ KSVQE CDM modules (models/backbones/ksvqe_modules.py)
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_cdm_modules_vs_reference_golden(golden, dtype):
+    from kvq_amd.models.backbones import ksvqe_modules as KM
+    from test_oracle_golden import _cdm_inputs
+    g = golden("cdm.npz")
+    w = {m: {k: torch.from_numpy(v) for k, v in sd.items()} for m, sd in synth.synth_cdm_weights(11).items()}
+    x = {k: v.to(DEV) for k, v in _cdm_inputs().items()}
+    mods = dict(cross=KM.crossattention1(768, 12), self=KM.Attention(768, 12), sem=KM.Semantic_Transformation2(768),
+                dist=KM.Dist_Transformation3(768))
+    for k, m in mods.items():
+        m.load_state_dict(w[k], strict=True)
+        m.operand_dtype = _abi.dtype_code(dtype)
+        m.to(DEV).eval()
+    with torch.no_grad():
+        o, a = mods["cross"](x["Q"], x["K"])
+        outs = dict(cross=o, self=mods["self"](x["xs"]), sem=mods["sem"](x["sem_x"], x["sem_in"]), dist=mods["dist"](x["dist_x"], x["dist_in"]))
+    assert a is None
+    tol = dict(cross=2.5, self=2.5, sem=0.02, dist=2.5)            # x the 16-bit epsilon, relative L2 (sem is fp32 end to end)
+    for k, o in outs.items():
+        arr = np.ascontiguousarray(o.float().cpu().numpy())
+        assert tuple(g[f"{k}/shape"]) == arr.shape, k
+        got, ref = arr.reshape(-1)[g[f"{k}/idx"]], g[f"{k}/val"]
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel <= tol[k] * EPS[dtype], (k, rel)
+    with pytest.raises(NotImplementedError):
+        mods["self"](x["xs"], mask=torch.ones(98, 16, dtype=torch.bool, device=DEV))
+    with pytest.raises(_abi.KvqError, match="HIP device"):
+        mods["sem"](torch.zeros(1, 768, 7, 7), torch.zeros(1, 768, 7, 7))
+
+
+@pytest.mark.parametrize("B,Lq,Lk,heads", [(4, 49, 49, 12), (3, 16, 16, 12), (2, 100, 7, 3)])
+def test_mha_cross_strided(B, Lq, Lk, heads):
+    g = torch.Generator().manual_seed(Lq * 100 + Lk)
+    D = heads * 64
+    q = torch.randn(B * Lq, D, generator=g).to(torch.float16)
+    kv = torch.randn(B * Lk, 2 * D + 8, generator=g).to(torch.float16)       # k and v interleaved in one buffer: strided rows
+    kvd = kv.to(DEV)
+    out = kernels.mha_cross(q.to(DEV), kvd[:, :D], kvd[:, D:2 * D], B, heads, 0.05).float().cpu()
+    qh = q.float().reshape(B, Lq, heads, 64).transpose(1, 2)
+    kh = kv[:, :D].float().reshape(B, Lk, heads, 64).transpose(1, 2)
+    vh = kv[:, D:2 * D].float().reshape(B, Lk, heads, 64).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.05, -1) @ vh).transpose(1, 2).reshape(B * Lq, D)
+    assert (out - ref).abs().max().item() <= 2.1 * 2.0 ** -11 * max(1.0, ref.abs().max().item())

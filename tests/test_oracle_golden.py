@@ -143,3 +143,29 @@ def test_clip_visual_extractor(golden, case):
         a = np.ascontiguousarray(o.numpy())
         assert tuple(g[f"{case}/{name}/shape"]) == a.shape, name
         assert np.abs(a.reshape(-1)[g[f"{case}/{name}/idx"]] - g[f"{case}/{name}/val"]).max() <= tol, name
+
+
+def _cdm_inputs(seed=31, n=2, t=16, hw=49, nk=49, dim=768):
+    """the seeded inputs of tests/golden/make_golden.py::cdm_inputs"""
+    g = np.random.Generator(np.random.PCG64(seed))
+    r = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32))     # noqa: E731
+    return dict(Q=r(n * t, hw, dim), K=r(n * t, nk, dim), xs=r(n * hw, t, dim), sem_x=r(n * t, dim, 7, 7), sem_in=r(n * t, dim, 7, 7),
+                dist_x=r(n, dim, t, 7, 7) * 1.5 + 0.3, dist_in=r(n, t * hw, dim))
+
+
+def test_ksvqe_cdm_modules(golden):
+    """oracle/ksvqe_oracle.py == the reference's crossattention1 / Attention / Semantic_Transformation2 /
+    Dist_Transformation3 (stored outputs), including the reference's batch-mixing head mean of the attention map."""
+    from oracle import ksvqe_oracle as KO
+    g = golden("cdm.npz")
+    w = {m: {k: torch.from_numpy(v) for k, v in sd.items()} for m, sd in synth.synth_cdm_weights(11).items()}
+    x = _cdm_inputs()
+    with torch.no_grad():
+        o, a = KO.cross_attention(x["Q"], x["K"], w["cross"], 12)
+        outs = dict(cross=o, cross_A=a, self=KO.self_attention(x["xs"], w["self"], 12),
+                    sem=KO.semantic_transformation2(x["sem_x"], x["sem_in"], w["sem"]),
+                    dist=KO.dist_transformation3(x["dist_x"], x["dist_in"], w["dist"]))
+    for k, o in outs.items():
+        a = np.ascontiguousarray(o.numpy())
+        assert tuple(g[f"{k}/shape"]) == a.shape, k
+        assert np.abs(a.reshape(-1)[g[f"{k}/idx"]] - g[f"{k}/val"]).max() <= 2e-5, k
