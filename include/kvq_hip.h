@@ -394,6 +394,15 @@ int kvq_sem_modulate(const float* x, const float* input, const float* w_gama, fl
 int kvq_dist_modulate(const float* input, const uint16_t* gamma_logit, const uint16_t* beta, int B, int rows, int C, int dtype,
                       float* out, void* stream);
 
+/* KSVQE quality-aware region selection, eval path of RegionNet_CLIP.forward (models/backbones/patchnet.py:461-550): the CLIP
+ * CLS-to-patch map of a key frame (BK maps of gs x gs, fp32) is nearest-upsampled to the anchor grid gh x gw, averaged over
+ * every kh x kw window (F.unfold, stride 1) and the best window's index (row-major over (gh-kh+1) x (gw-kw+1), first
+ * maximum) is returned; kvq_crop_regions then cuts that window (kh*anchor x kw*anchor pixels at (ry*anchor, rx*anchor))
+ * out of every frame: x (B, C, T, H, W) fp32, region int32 [B*T] -> out (B, C, T, kh*anchor, kw*anchor). */
+int kvq_qrs_top_region(const float* score, int BK, int gs, int gh, int gw, int kh, int kw, int32_t* idx, void* stream);
+int kvq_crop_regions(const float* x, const int32_t* region, int B, int C, int T, int H, int W, int anchor, int kh, int kw,
+                     float* out, void* stream);
+
 /* Implicit-GEMM convolution (nn.Conv2d / nn.Conv3d + folded BatchNorm [+ identity] [+ ReLU], the Bottleneck convs of
  * simpleVQA_model.py:85-126 and the SlowFast res blocks): the GEMM's A tiles are fetched straight from the channels-LAST
  * 16-bit activation x (B, D, H, W, C), C % 8 == 0 — no patch matrix.  W [N][Kpad], columns ordered (kd,kh,kw,c) like

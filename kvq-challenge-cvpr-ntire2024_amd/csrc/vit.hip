@@ -314,3 +314,76 @@ extern "C" int kvq_dist_modulate(const float* input, const uint16_t* gamma_logit
   KVQ_CHECK_LAUNCH("dist_modulate_kernel");
   return KVQ_OK;
 }
+
+// ---- KSVQE quality-aware region selection (QRS), eval path of RegionNet_CLIP.forward (patchnet.py:461-550) ---------
+namespace kvq {
+
+// score (BK, gs, gs) -> nearest upsample to (gh, gw) (legacy nearest: src = floor(dst * gs / g)) -> mean over every kh x kw
+// window (F.unfold, stride 1) -> first argmax over the (gh-kh+1) x (gw-kw+1) candidates (min-max normalisation is monotonic).
+__global__ __launch_bounds__(64) void qrs_top_region_kernel(const float* __restrict__ score, int gs, int gh, int gw, int kh, int kw,
+                                                           int32_t* __restrict__ idx) {
+  const int bk = blockIdx.x, lane = threadIdx.x, ny = gh - kh + 1, nx = gw - kw + 1, nreg = ny * nx;
+  const float* s = score + (size_t)bk * gs * gs;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int r = lane; r < nreg; r += 64) {
+    const int ry = r / nx, rx = r % nx;
+    float acc = 0.f;
+    for (int y = 0; y < kh; ++y)
+      for (int x = 0; x < kw; ++x) {
+        const int sy = min((int)floorf((float)(ry + y) * ((float)gs / (float)gh)), gs - 1);
+        const int sx = min((int)floorf((float)(rx + x) * ((float)gs / (float)gw)), gs - 1);
+        acc += s[sy * gs + sx];
+      }
+    acc /= (float)(kh * kw);
+    if (acc > best) { best = acc; besti = r; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(besti, o);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane == 0) idx[bk] = besti;
+}
+
+// out[b][c][t][y][x] = x[b][c][t][ry*anchor + y][rx*anchor + x], (ry, rx) = region[b*T + t] decoded over nx candidates per row
+__global__ void crop_regions_kernel(const float* __restrict__ x, const int32_t* __restrict__ region, int C, int T, int H, int W,
+                                    int anchor, int nx, int oh, int ow, float* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int xx = (int)(i % ow);
+  long r = i / ow;
+  const int yy = (int)(r % oh); r /= oh;
+  const int t = (int)(r % T); r /= T;
+  const int c = (int)(r % C);
+  const long b = r / C;
+  const int reg = region[b * T + t], ry = reg / nx, rx = reg % nx;
+  out[i] = x[(((b * C + c) * T + t) * (long)H + ry * anchor + yy) * W + rx * anchor + xx];
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_qrs_top_region(const float* score, int BK, int gs, int gh, int gw, int kh, int kw, int32_t* idx, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(score && idx, KVQ_ERR_NULL, "kvq_qrs_top_region: NULL pointer");
+  KVQ_REQUIRE(BK > 0 && gs > 0 && gh >= kh && gw >= kw && kh > 0 && kw > 0, KVQ_ERR_SHAPE,
+              "kvq_qrs_top_region: bad shape gs=%d grid %dx%d window %dx%d", gs, gh, gw, kh, kw);
+  hipLaunchKernelGGL(qrs_top_region_kernel, dim3((unsigned)BK), dim3(64), 0, (hipStream_t)stream, score, gs, gh, gw, kh, kw, idx);
+  KVQ_CHECK_LAUNCH("qrs_top_region_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_crop_regions(const float* x, const int32_t* region, int B, int C, int T, int H, int W, int anchor, int kh, int kw,
+                                float* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && region && out, KVQ_ERR_NULL, "kvq_crop_regions: NULL pointer");
+  KVQ_REQUIRE(B > 0 && C > 0 && T > 0 && anchor > 0 && H / anchor >= kh && W / anchor >= kw && kh > 0 && kw > 0, KVQ_ERR_SHAPE,
+              "kvq_crop_regions: bad shape %dx%d anchor %d window %dx%d", H, W, anchor, kh, kw);
+  const int oh = kh * anchor, ow = kw * anchor, nx = W / anchor - kw + 1;
+  const long total = (long)B * C * T * oh * ow;
+  hipLaunchKernelGGL(crop_regions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, region, C, T,
+                     H, W, anchor, nx, oh, ow, out, total);
+  KVQ_CHECK_LAUNCH("crop_regions_kernel");
+  return KVQ_OK;
+}

@@ -321,6 +321,26 @@ def dist_modulate(inp: torch.Tensor, gamma_logit: torch.Tensor, beta: torch.Tens
     return out
 
 
+def qrs_top_region(score: torch.Tensor, gh: int, gw: int, kh: int, kw: int):
+    """score fp32 (BK, gs, gs) -> int32 [BK]: index of the kh x kw window of the (gh, gw)-upsampled map with the largest mean."""
+    _need_gpu(score)
+    assert score.dtype == torch.float32 and score.is_contiguous() and score.dim() == 3 and score.shape[1] == score.shape[2]
+    idx = torch.empty(score.shape[0], dtype=torch.int32, device=score.device)
+    check(lib().kvq_qrs_top_region(ptr(score), score.shape[0], score.shape[1], gh, gw, kh, kw, ptr(idx), current_stream()),
+          "kvq_qrs_top_region")
+    return idx
+
+
+def crop_regions(x: torch.Tensor, region: torch.Tensor, anchor: int, kh: int, kw: int):
+    """x fp32 (B, C, T, H, W), region int32 [B*T] -> (B, C, T, kh*anchor, kw*anchor): every frame's selected window."""
+    _need_gpu(x, region)
+    assert x.dtype == torch.float32 and x.is_contiguous() and region.dtype == torch.int32 and region.is_contiguous()
+    B, Cc, T, H, W = x.shape
+    out = torch.empty(B, Cc, T, kh * anchor, kw * anchor, dtype=torch.float32, device=x.device)
+    check(lib().kvq_crop_regions(ptr(x), ptr(region), B, Cc, T, H, W, anchor, kh, kw, ptr(out), current_stream()), "kvq_crop_regions")
+    return out
+
+
 def cls_gather(x: torch.Tensor, out_dtype):
     """x fp32 (B, L, D) -> x[:, 0] as 16-bit [B, D]."""
     _need_gpu(x)

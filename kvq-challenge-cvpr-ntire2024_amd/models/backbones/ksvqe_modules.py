@@ -130,3 +130,48 @@ class Dist_Transformation3(_HipModule):  # noqa: N801
         g = kernels.gemm(s16[:, C:].contiguous(), w[0], w[1], _abi.EPI_BIAS_BF16)
         b = kernels.gemm(s16[:, :C].contiguous(), w[2], w[3], _abi.EPI_BIAS_BF16)
         return kernels.dist_modulate(input.to(torch.float32).contiguous(), g, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def obtain_keyframes(x):
+    """``KSVQE.obtain_keyframes`` (KSVQE_model.py:1352-1376): x (b, c, t, h, w) -> (group_idx (b, t), key_frame (b, 4, c, h, w)):
+    the frames 0, t/4-1, t/2-1, 3t/4-1; a frame's group id counts how many of the last three positions are <= its index."""
+    b, c, t, h, w = x.shape
+    pos = [0, t // 4 - 1, t // 2 - 1, t * 3 // 4 - 1]
+    key = x.permute(0, 2, 1, 3, 4)[:, pos]
+    j = torch.arange(t, device=x.device)
+    gid = sum((j >= p).to(x.dtype) for p in dict.fromkeys(pos[1:]))      # equal positions (tiny t) bump once, as the elif chain does
+    return gid.unsqueeze(0).expand(b, t).contiguous(), key
+
+
+def extend_by_group(per_key, group_id):
+    """``extend_fullcls_attn`` / ``extend_fullcls_indices`` (KSVQE_model.py:1378-1387, patchnet.py:450-460): per_key (B, N_key, ...)
+    -> (B, T, ...) with row t = per_key[b, group_id[b, t]] — an index_select instead of the reference's ``.item()`` double loop."""
+    idx = group_id.long()
+    return torch.gather(per_key, 1, idx.reshape(idx.shape + (1,) * (per_key.dim() - 2)).expand(idx.shape + per_key.shape[2:]))
+
+
+class RegionNet_CLIP(nn.Module):  # noqa: N801
+    """Eval path of the reference's quality-aware region selection (patchnet.py:390-550, ``sample_type`` other than
+    'random'): the CLIP CLS-to-patch map of every key frame picks ONE window of sqrt(k) x sqrt(k) anchors (top-1 of the
+    window means), frames take the window of their key frame, the window is cut out: x (b, c, t, h, w) -> (b, c, t,
+    sqrt(k)·anchor, sqrt(k)·anchor).  Training-time samplers (perturbed top-k, Gumbel, multinomial, random) are not built."""
+
+    def __init__(self, k, anchor_size, stride, num_samples=500, sample_type="topkpertubation"):
+        super().__init__()
+        self.k, self.stride, self.anchor_size, self.num_samples, self.sample_type = k, stride, anchor_size, num_samples, sample_type
+        if stride != 1:
+            raise NotImplementedError("window stride other than 1")
+
+    def forward(self, x, score, sigma, group_id, extra_score=None):
+        if self.training or self.sample_type == "random" or extra_score is not None:
+            raise NotImplementedError("training-time / random region sampling and extra_score: this is an inference engine")
+        if not x.is_cuda:
+            raise _abi.KvqError("RegionNet_CLIP.forward needs its inputs on a HIP device; there is no CPU path")
+        b, c, t, h, w = x.shape
+        _, n_key, L = score.shape
+        gs, kk = int(round(L ** 0.5)), int(round(self.k ** 0.5))
+        idx = kernels.qrs_top_region(score.to(torch.float32).reshape(b * n_key, gs, gs).contiguous(), h // self.anchor_size,
+                                     w // self.anchor_size, kk, kk)
+        full = extend_by_group(idx.reshape(b, n_key), group_id).reshape(b * t).contiguous()
+        return kernels.crop_regions(x.to(torch.float32).contiguous(), full, self.anchor_size, kk, kk)

@@ -52,3 +52,46 @@ def dist_transformation3(x, inp, p):
     gama = torch.sigmoid(F.linear(flat.std(dim=2), p["get_gamma.weight"], p["get_gamma.bias"]))
     beta = F.linear(flat.mean(dim=2), p["get_beta.weight"], p["get_beta.bias"])
     return gama.unsqueeze(1) * inp + beta.unsqueeze(1)
+
+
+def obtain_keyframes(x):
+    """KSVQE.obtain_keyframes (:1352-1376), loops as written there."""
+    b, c, t, h, w = x.shape
+    xt = x.permute(0, 2, 1, 3, 4)
+    key = torch.stack([xt[:, 0], xt[:, t // 4 - 1], xt[:, t // 2 - 1], xt[:, t * 3 // 4 - 1]], 1)
+    gid = x.new_zeros((b, t))
+    for i in range(b):
+        g = 0
+        for j in range(t):
+            if j == t // 4 - 1:
+                g += 1
+            elif j == t // 2 - 1:
+                g += 1
+            elif j == t * 3 // 4 - 1:
+                g += 1
+            gid[i, j] = g
+    return gid, key
+
+
+def qrs_select(x, score, group_id, k=49, anchor=32):
+    """Eval path of RegionNet_CLIP.forward (patchnet.py:461-550): returns (patches (b, c, t, 7*anchor, 7*anchor), region index
+    per key frame (b, n_key))."""
+    b, c, t, h, w = x.shape
+    _, n_key, L = score.shape
+    gs, kk = int(round(L ** 0.5)), int(round(k ** 0.5))
+    gh, gw = h // anchor, w // anchor
+    s = score.reshape(b * n_key, 1, gs, gs)
+    if (gs, gs) != (gh, gw):
+        s = F.interpolate(s, scale_factor=(gh / gs, gw / gs), mode="nearest")
+    m = F.unfold(s, kernel_size=kk, stride=1).mean(dim=1)                       # (b*n_key, regions)
+    mn, mx = m.min(-1, keepdim=True).values, m.max(-1, keepdim=True).values
+    m = (m - mn) / (mx - mn + 1e-5)
+    idx = m.argmax(dim=-1).reshape(b, n_key)
+    nx = gw - kk + 1
+    out = x.new_zeros((b, c, t, kk * anchor, kk * anchor))
+    for i in range(b):
+        for j in range(t):
+            r = int(idx[i, int(group_id[i, j])])
+            ry, rx = r // nx, r % nx
+            out[i, :, j] = x[i, :, j, ry * anchor: ry * anchor + kk * anchor, rx * anchor: rx * anchor + kk * anchor]
+    return out, idx

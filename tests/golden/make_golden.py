@@ -372,6 +372,40 @@ def sec_cdm(ref):
     save("cdm.npz", d)
 
 
+def qrs_inputs(seed=41, b=2, t=16, n_key=4, hw=288):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return (torch.from_numpy(g.standard_normal((b, 3, t, hw, hw)).astype(np.float32)),
+            torch.from_numpy(g.uniform(-1, 1, (b, n_key, 49)).astype(np.float32)))
+
+
+def sec_qrs(ref):
+    """KSVQE's key-frame selection and QRS eval path: the reference's own functions on seeded inputs."""
+    import contextlib
+    import importlib
+    import io
+    import types
+    from oracle import ksvqe_oracle as KO
+    with contextlib.redirect_stdout(io.StringIO()):
+        K = importlib.import_module("models.backbones.KSVQE_model")
+        P = importlib.import_module("models.backbones.patchnet")
+    x, score = qrs_inputs()
+    fake = types.SimpleNamespace()
+    with torch.no_grad():
+        gid_ref, key_ref = K.KSVQE.obtain_keyframes(fake, x[:, :, :, :16, :16].contiguous())
+        gid, key = KO.obtain_keyframes(x[:, :, :, :16, :16].contiguous())
+        assert torch.equal(gid, gid_ref) and torch.equal(key, key_ref)
+        net = P.RegionNet_CLIP(k=49, anchor_size=32, stride=1, num_samples=1, sample_type="topkpertubation").eval()
+        out_ref = net(x, score, 0.5, gid_ref)
+        out, idx = KO.qrs_select(x, score, gid_ref)
+    e = float((out - out_ref).abs().max())
+    print(f"qrs: patches {tuple(out_ref.shape)} |oracle-ref| {e:.2e}; regions {idx.tolist()}; group ids {gid_ref[0].int().tolist()}")
+    assert e == 0.0
+    d = {"gid": gid_ref.numpy(), "idx": idx.numpy().astype(np.int32)}
+    put(d, "patches", samples(out_ref.numpy(), 8192))
+    put(d, "key", samples(key_ref.numpy(), 1024))
+    save("qrs.npz", d)
+
+
 def sec_ckpt(ref):
     """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
     dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
@@ -419,7 +453,7 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

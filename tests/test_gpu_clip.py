@@ -143,3 +143,33 @@ def test_mha_cross_strided(B, Lq, Lk, heads):
     vh = kv[:, D:2 * D].float().reshape(B, Lk, heads, 64).transpose(1, 2)
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.05, -1) @ vh).transpose(1, 2).reshape(B * Lq, D)
     assert (out - ref).abs().max().item() <= 2.1 * 2.0 ** -11 * max(1.0, ref.abs().max().item())
+
+
+def test_keyframes_and_qrs_vs_reference_golden(golden):
+    """Key-frame grouping (host index logic) and the QRS eval path (kvq_qrs_top_region + kvq_crop_regions): bit-exact
+    against the reference's outputs — integer / copy work."""
+    from kvq_amd.models.backbones import ksvqe_modules as KM
+    from test_oracle_golden import _qrs_inputs
+    g = golden("qrs.npz")
+    x, score = _qrs_inputs()
+    xd, sd = x.to(DEV), score.to(DEV)
+    gid, key = KM.obtain_keyframes(xd[:, :, :, :16, :16].contiguous())
+    assert np.array_equal(gid.cpu().numpy(), g["gid"])
+    assert np.array_equal(key.contiguous().cpu().numpy().reshape(-1)[g["key/idx"]], g["key/val"])
+    net = KM.RegionNet_CLIP(k=49, anchor_size=32, stride=1, num_samples=1).eval()
+    out = net(xd, sd, 0.5, gid)
+    assert out.shape == (2, 3, 16, 224, 224)
+    assert np.array_equal(out.cpu().numpy().reshape(-1)[g["patches/idx"]], g["patches/val"])
+    idx = kernels.qrs_top_region(sd.reshape(8, 7, 7).contiguous(), 9, 9, 7, 7).cpu().numpy().reshape(2, 4)
+    assert np.array_equal(idx, g["idx"])
+    # extend_by_group == the reference's .item() double loop
+    per_key = torch.arange(2 * 4 * 5, dtype=torch.float32, device=DEV).reshape(2, 4, 5)
+    full = KM.extend_by_group(per_key, gid).cpu()
+    for i in range(2):
+        for j in range(16):
+            assert torch.equal(full[i, j], per_key[i, int(g["gid"][i, j])].cpu())
+    # same grid as the map: no upsample; a tie keeps the first window
+    flat = torch.zeros(3, 9, 9, device=DEV)
+    assert kernels.qrs_top_region(flat, 9, 9, 7, 7).cpu().tolist() == [0, 0, 0]
+    with pytest.raises(NotImplementedError):
+        KM.RegionNet_CLIP(k=49, anchor_size=32, stride=1, sample_type="random").eval()(xd, sd, 0.5, gid)

@@ -169,3 +169,22 @@ def test_ksvqe_cdm_modules(golden):
         a = np.ascontiguousarray(o.numpy())
         assert tuple(g[f"{k}/shape"]) == a.shape, k
         assert np.abs(a.reshape(-1)[g[f"{k}/idx"]] - g[f"{k}/val"]).max() <= 2e-5, k
+
+
+def _qrs_inputs(seed=41, b=2, t=16, n_key=4, hw=288):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return (torch.from_numpy(g.standard_normal((b, 3, t, hw, hw)).astype(np.float32)),
+            torch.from_numpy(g.uniform(-1, 1, (b, n_key, 49)).astype(np.float32)))
+
+
+def test_ksvqe_keyframes_and_qrs(golden):
+    """oracle == the reference's obtain_keyframes and RegionNet_CLIP eval path (stored outputs / indices)."""
+    from oracle import ksvqe_oracle as KO
+    g = golden("qrs.npz")
+    x, score = _qrs_inputs()
+    gid, key = KO.obtain_keyframes(x[:, :, :, :16, :16].contiguous())
+    assert np.array_equal(gid.numpy(), g["gid"])
+    assert np.array_equal(key.numpy().reshape(-1)[g["key/idx"]], g["key/val"])
+    out, idx = KO.qrs_select(x, score, gid)
+    assert np.array_equal(idx.numpy().astype(np.int32), g["idx"])
+    assert np.array_equal(out.numpy().reshape(-1)[g["patches/idx"]], g["patches/val"])
