@@ -117,6 +117,7 @@ SYMBOLS = {
     "kvq_dist_modulate": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, p_void, p_void]),
     "kvq_qrs_top_region": (i32, [p_void, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_crop_regions": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
+    "kvq_l2_normalize_rows": (i32, [p_void, i32, i32, i32, p_void, p_void]),
     "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),

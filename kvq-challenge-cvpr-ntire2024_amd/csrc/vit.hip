@@ -387,3 +387,31 @@ extern "C" int kvq_crop_regions(const float* x, const int32_t* region, int B, in
   KVQ_CHECK_LAUNCH("crop_regions_kernel");
   return KVQ_OK;
 }
+
+// F.normalize(x, dim=1) (x / max(||x||_2, 1e-12)) on fp32 rows -> 16-bit (the projector's GEMM operand; CONTRIQUE_model.forward,
+// KSVQE_model.py:1654-1656)
+namespace kvq {
+template <typename E>
+__global__ __launch_bounds__(64) void l2_normalize_rows_kernel(const float* __restrict__ x, int D, uint16_t* __restrict__ out) {
+  const size_t m = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* xr = x + m * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s = fmaf(xr[c], xr[c], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int c = lane; c < D; c += 64) out[m * D + c] = E::cvt(xr[c] * inv);
+}
+}  // namespace kvq
+
+extern "C" int kvq_l2_normalize_rows(const float* x, int M, int D, int dtype, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && out, KVQ_ERR_NULL, "kvq_l2_normalize_rows: NULL pointer");
+  KVQ_REQUIRE(M > 0 && D > 0, KVQ_ERR_SHAPE, "kvq_l2_normalize_rows: bad shape");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_l2_normalize_rows: dtype %d", dtype);
+  if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(l2_normalize_rows_kernel<Fp16>, dim3((unsigned)M), dim3(64), 0, (hipStream_t)stream, x, D, out);
+  else hipLaunchKernelGGL(l2_normalize_rows_kernel<Bf16>, dim3((unsigned)M), dim3(64), 0, (hipStream_t)stream, x, D, out);
+  KVQ_CHECK_LAUNCH("l2_normalize_rows_kernel");
+  return KVQ_OK;
+}

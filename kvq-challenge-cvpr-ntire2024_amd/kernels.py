@@ -341,6 +341,16 @@ def crop_regions(x: torch.Tensor, region: torch.Tensor, anchor: int, kh: int, kw
     return out
 
 
+def l2_normalize_rows(x: torch.Tensor, out_dtype):
+    """F.normalize(x, dim=1) of fp32 [M, D] -> 16-bit [M, D]."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib().kvq_l2_normalize_rows(ptr(x), x.shape[0], x.shape[1], dtype_code(out_dtype), ptr(out), current_stream()),
+          "kvq_l2_normalize_rows")
+    return out
+
+
 def cls_gather(x: torch.Tensor, out_dtype):
     """x fp32 (B, L, D) -> x[:, 0] as 16-bit [B, D]."""
     _need_gpu(x)

@@ -175,3 +175,57 @@ class RegionNet_CLIP(nn.Module):  # noqa: N801
                                      w // self.anchor_size, kk, kk)
         full = extend_by_group(idx.reshape(b, n_key), group_id).reshape(b * t).contiguous()
         return kernels.crop_regions(x.to(torch.float32).contiguous(), full, self.anchor_size, kk, kk)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def get_network(name, pretrained=False):
+    """``get_network`` (KSVQE_model.py:1608-1620): only the ResNet-50 KSVQE asks for; randomly initialised (no downloads)."""
+    if name != "resnet50":
+        raise KeyError(f"{name}: only 'resnet50' is built")
+    from .simpleVQA_model import TorchvisionResNet50
+    return TorchvisionResNet50()
+
+
+class CONTRIQUE_model(_HipModule):  # noqa: N801
+    """The reference's distortion branch (KSVQE_model.py:1622-1664): every anchor x anchor patch of x (b, c, t, h, w) goes
+    through the ResNet-50 trunk (``encoder`` = the network's children without avgpool / fc, same state_dict keys), the
+    2048-vector is L2-normalised and projected (Linear -> BatchNorm1d -> ReLU -> Linear -> BatchNorm1d, eval statistics
+    folded into the two GEMMs) to ``projection_dim``: returns (b, t, patches per frame, projection_dim) fp32."""
+
+    def __init__(self, encoder, n_features, anchor_size=32, patch_dim=(2, 2), normalize=True, projection_dim=128):
+        super().__init__()
+        self.anchor_size, self.normalize, self.n_features, self.patch_dim = anchor_size, normalize, n_features, patch_dim
+        if not hasattr(encoder, "features"):
+            raise TypeError("encoder must be the network get_network('resnet50') returns")
+        self.encoder = nn.Sequential(*list(encoder.children())[:-2])
+        object.__setattr__(self, "_net", encoder)              # the same modules, kept for their HIP forward (not re-registered)
+        self.projector = nn.Sequential(nn.Linear(n_features, n_features, bias=False), nn.BatchNorm1d(n_features), nn.ReLU(),
+                                       nn.Linear(n_features, projection_dim, bias=False), nn.BatchNorm1d(projection_dim))
+
+    def _fold(self, lin, bn, device):
+        scale = bn.weight.detach().to(device, torch.float32) / torch.sqrt(bn.running_var.to(device, torch.float32) + bn.eps)
+        bias = bn.bias.detach().to(device, torch.float32) - bn.running_mean.to(device, torch.float32) * scale
+        return self._w16(lin.weight.detach().to(device, torch.float32) * scale[:, None], device), bias.contiguous()
+
+    def forward(self, x):
+        self._need(x)
+        dev, h = x.device, self._half()
+        self._net.operand_dtype = self.operand_dtype
+        sig_extra = tuple((t.data_ptr(), t._version) for t in self.projector.buffers())
+        w = self._cached(dev, lambda: (sig_extra, self._fold(self.projector[0], self.projector[1], dev),
+                                       self._fold(self.projector[3], self.projector[4], dev)))
+        if w[0] != sig_extra:                                    # running statistics changed: refold
+            self._wc = None
+            return self.forward(x)
+        b, c, t, hh, ww = x.shape
+        a = self.anchor_size
+        gh, gw = hh // a, ww // a
+        # (b t) c (gh a) (gw a) -> (b t gh gw) c a a: layout only
+        p = (x.to(torch.float32).permute(0, 2, 1, 3, 4).reshape(b * t, c, gh, a, gw, a).permute(0, 2, 4, 1, 3, 5)
+             .reshape(b * t * gh * gw, c, a, a).contiguous())
+        _, f32 = self._net.features(p)
+        f = f32.reshape(-1, self.n_features)
+        f16 = kernels.l2_normalize_rows(f.contiguous(), h) if self.normalize else kernels.to_half(f.contiguous(), h)
+        z = kernels.conv_gemm(f16, *w[1], True)
+        z = kernels.gemm(z, *w[2], _abi.EPI_BIAS_BF16)
+        return kernels.to_float(z).reshape(b, t, gh * gw, -1)

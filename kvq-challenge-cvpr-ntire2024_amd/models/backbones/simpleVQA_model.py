@@ -174,6 +174,26 @@ class ResNet(nn.Module):
         out[:, off:] = feat3d                                                # x_3D_features (:256)
         return out.reshape(b, T, -1)
 
+    def features(self, x):
+        """The convolutional trunk alone: x (N, 3, H, W) fp32 on a HIP device -> the layer4 output, channels-last, as
+        (16-bit (N, H/32, W/32, 2048), its un-rounded fp32 copy)."""
+        if not x.is_cuda:
+            raise _abi.KvqError("ResNet.features needs the frames on a HIP device; there is no CPU path")
+        x = x.to(torch.float32).contiguous()
+        n, c, h, w_ = x.shape
+        w = self._weights(x.device)
+        half = _abi.torch_dtype(self.operand_dtype)
+        wt, bias = w["stem"]
+        a, (_, ho, wo) = kernels.im2col_nd(x, (n, c, 1, h, w_), (c * h * w_, h * w_, 0, w_, 1), (1, 7, 7), (1, 2, 2), (0, 3, 3),
+                                           half, wt.shape[1])
+        y = kernels.conv_gemm(a, wt, bias, True).reshape(n, ho, wo, 64)
+        y = kernels.pool_nd(y.unsqueeze(1), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).squeeze(1)        # maxpool 3x3/2
+        y32 = None
+        for li, layer_mod in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
+            for bi, blk in enumerate(layer_mod):
+                y, y32 = self._bottleneck(y, y32, w, f"l{li}.{bi}.", blk)
+        return y, y32
+
     @staticmethod
     def _stem_im2col(x, half, kpad):
         b, c, T, h, w_ = x.shape
@@ -184,6 +204,28 @@ class ResNet(nn.Module):
         parts = [kernels.im2col_nd(x[i], (T, c, 1, h, w_), (h * w_, T * h * w_, 0, w_, 1), (1, 7, 7), (1, 2, 2),
                                    (0, 3, 3), half, kpad) for i in range(b)]
         return torch.cat([p[0] for p in parts]), parts[0][1]
+
+
+class TorchvisionResNet50(ResNet):
+    """``torchvision.models.resnet50()`` as a parameter container: children in torchvision's order (conv1, bn1, relu, maxpool,
+    layer1..4, avgpool, fc), so that ``nn.Sequential(*list(net.children())[:-2])`` — what the reference's ``CONTRIQUE_model``
+    keeps (KSVQE_model.py:1630) — has the reference's ``state_dict`` keys.  Same blocks and HIP execution as ``ResNet``."""
+
+    def __init__(self, operand_dtype=None):
+        nn.Module.__init__(self)
+        self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
+        self.inplanes = 64
+        self.conv1, self.bn1 = _Conv(3, 64, 7, 2, 3), _BN(64)
+        self.relu, self.maxpool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(64, 3, 1)
+        self.layer2 = self._make_layer(128, 4, 2)
+        self.layer3 = self._make_layer(256, 6, 2)
+        self.layer4 = self._make_layer(512, 3, 2)
+        self.avgpool, self.fc = nn.AdaptiveAvgPool2d((1, 1)), nn.Linear(2048, 1000)
+        self._wcache = None
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("only the convolutional trunk is used (CONTRIQUE_model); call features()")
 
 
 def resnet50(pretrained=False, progress=True, **kwargs):

@@ -305,6 +305,29 @@ def synth_cdm_weights(seed: int = 0, dim: int = 768):
     return out
 
 
+def synth_contrique_weights(seed: int = 0, n_features=2048, projection_dim=128):
+    """state_dict of the reference's ``CONTRIQUE_model`` (KSVQE_model.py:1622-1641): ``encoder.{0,1,4..7}`` = conv1, bn1,
+    layer1..4 of a ResNet-50 (the 'stress' weights of ``synth_resnet50_weights``) + the two-layer projector with its
+    BatchNorm1d statistics."""
+    out = OrderedDict()
+    for k, v in synth_resnet50_weights(seed).items():
+        if k.startswith("quality"):
+            continue
+        head, rest = k.split(".", 1)
+        idx = {"conv1": "0", "bn1": "1"}.get(head) or str(int(head[5:]) + 3)
+        out[f"encoder.{idx}.{rest}"] = v
+    for name, shape in (("projector.0.weight", (n_features, n_features)), ("projector.3.weight", (projection_dim, n_features))):
+        out[name] = (_gen(seed, "contrique/" + name).standard_normal(shape) * 4.0 / np.sqrt(shape[1])).astype(np.float32)
+    for pre, c in (("projector.1", n_features), ("projector.4", projection_dim)):
+        g = _gen(seed, "contrique/" + pre)
+        out[pre + ".weight"] = (1.0 + 0.1 * g.standard_normal(c)).astype(np.float32)
+        out[pre + ".bias"] = (0.1 * g.standard_normal(c)).astype(np.float32)
+        out[pre + ".running_mean"] = (0.02 * g.standard_normal(c)).astype(np.float32)
+        out[pre + ".running_var"] = g.uniform(0.005, 0.02, c).astype(np.float32)
+        out[pre + ".num_batches_tracked"] = np.zeros((), np.int64)
+    return out
+
+
 def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
     return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
 

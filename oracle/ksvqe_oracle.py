@@ -95,3 +95,34 @@ def qrs_select(x, score, group_id, k=49, anchor=32):
             ry, rx = r // nx, r % nx
             out[i, :, j] = x[i, :, j, ry * anchor: ry * anchor + kk * anchor, rx * anchor: rx * anchor + kk * anchor]
     return out, idx
+
+
+def contrique(x, params, anchor=32, normalize=True):
+    """CONTRIQUE_model.forward (:1643-1664) over its state_dict (``encoder.{0,1,4..7}`` = conv1, bn1, layer1..4 of a ResNet-50;
+    ``projector.{0,1,3,4}``): x (b, c, t, h, w) -> (b, t, patches per frame, projection_dim)."""
+    from . import resnet_oracle as R
+    p = {k: (v if torch.is_tensor(v) else torch.from_numpy(v)) for k, v in params.items()}
+    b, c, t, h, w = x.shape
+    gh, gw = h // anchor, w // anchor
+    z = (x.permute(0, 2, 1, 3, 4).reshape(b * t, c, gh, anchor, gw, anchor).permute(0, 2, 4, 1, 3, 5)
+         .reshape(b * t * gh * gw, c, anchor, anchor))
+    q = {}
+    for k, v in p.items():                       # encoder.N.* -> the oracle's conv1 / bn1 / layerL names
+        if k.startswith("encoder."):
+            n, rest = k[len("encoder."):].split(".", 1)
+            q[{"0": "conv1", "1": "bn1"}.get(n, f"layer{int(n) - 3}") + "." + rest] = v.float() if v.is_floating_point() else v
+    z = F.relu(R._bn(F.conv2d(z, q["conv1.weight"], stride=2, padding=3), q, "bn1"))
+    z = F.max_pool2d(z, 3, 2, 1)
+    for li, (planes, blocks, stride) in enumerate(R.LAYERS, 1):
+        for bi in range(blocks):
+            z = R._bottleneck(z, q, f"layer{li}.{bi}", stride if bi == 0 else 1, bi == 0)
+    f = z.reshape(-1, z.shape[1])
+    if normalize:
+        f = F.normalize(f, dim=1)
+
+    def bn1d(v, pre):
+        return F.batch_norm(v, p[pre + ".running_mean"], p[pre + ".running_var"], p[pre + ".weight"], p[pre + ".bias"], False, 0.0, 1e-5)
+
+    f = F.relu(bn1d(F.linear(f, p["projector.0.weight"]), "projector.1"))
+    f = bn1d(F.linear(f, p["projector.3.weight"]), "projector.4")
+    return f.reshape(b, t, gh * gw, -1)

@@ -406,6 +406,37 @@ def sec_qrs(ref):
     save("qrs.npz", d)
 
 
+def sec_contrique(ref):
+    """KSVQE's CONTRIQUE branch (SURVEY §8 f1).  torchvision is absent here, so the reference's ``CONTRIQUE_model`` is built
+    around a torchvision-ORDERED shell of the reference's OWN ResNet-50 blocks (simpleVQA_model.py Bottleneck: the same
+    v1.5 structure as torchvision.models.resnet50) — the patching, normalisation and projector are the reference's code,
+    the encoder's block arithmetic is the reference's SimpleVQA restatement of it."""
+    import contextlib
+    import importlib
+    import io
+    from oracle import ksvqe_oracle as KO
+    with contextlib.redirect_stdout(io.StringIO()):
+        K = importlib.import_module("models.backbones.KSVQE_model")
+        r = ref.simple.resnet50(pretrained=False)
+    shell = torch.nn.Module()
+    for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool"):
+        shell.add_module(name, getattr(r, name))
+    shell.add_module("fc", torch.nn.Linear(2048, 10))
+    m = K.CONTRIQUE_model(shell, 2048).eval()
+    wts = synth.synth_contrique_weights(13)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=True)
+    g = np.random.Generator(np.random.PCG64(51))
+    x = torch.from_numpy(g.standard_normal((1, 3, 3, 64, 96)).astype(np.float32))
+    with torch.no_grad():
+        z_ref = m(x)
+        z = KO.contrique(x, wts)
+    e = float((z - z_ref).abs().max())
+    print(f"contrique: {tuple(z_ref.shape)} |oracle-ref| {e:.2e}  |z| max {float(z_ref.abs().max()):.3f}")
+    assert e <= 2e-4
+    d = {"z": z_ref.numpy()}
+    save("contrique.npz", d)
+
+
 def sec_ckpt(ref):
     """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
     dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
@@ -453,7 +484,7 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

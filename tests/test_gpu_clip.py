@@ -173,3 +173,23 @@ def test_keyframes_and_qrs_vs_reference_golden(golden):
     assert kernels.qrs_top_region(flat, 9, 9, 7, 7).cpu().tolist() == [0, 0, 0]
     with pytest.raises(NotImplementedError):
         KM.RegionNet_CLIP(k=49, anchor_size=32, stride=1, sample_type="random").eval()(xd, sd, 0.5, gid)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_contrique_vs_reference_golden(golden, dtype):
+    """KSVQE's distortion branch on the HIP conv stack (implicit-GEMM ResNet-50 trunk on 32x32 patches, kvq_l2_normalize_rows,
+    the BatchNorm-folded projector GEMMs) against the reference's stored output."""
+    from kvq_amd.models.backbones import ksvqe_modules as KM
+    z_ref = golden("contrique.npz")["z"]
+    m = KM.CONTRIQUE_model(KM.get_network("resnet50"), 2048)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_contrique_weights(13).items()}, strict=True)
+    m.operand_dtype = _abi.dtype_code(dtype)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(51)).standard_normal((1, 3, 3, 64, 96)).astype(np.float32))
+    with torch.no_grad():
+        z = m(x.to(DEV)).cpu().numpy()
+    assert z.shape == z_ref.shape
+    rel = np.linalg.norm(z - z_ref) / np.linalg.norm(z_ref)
+    assert rel <= {"fp16": 1.5e-2, "bf16": 1e-1}[dtype], rel
+    with pytest.raises(KeyError):
+        KM.get_network("VGG16")

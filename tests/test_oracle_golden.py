@@ -188,3 +188,13 @@ def test_ksvqe_keyframes_and_qrs(golden):
     out, idx = KO.qrs_select(x, score, gid)
     assert np.array_equal(idx.numpy().astype(np.int32), g["idx"])
     assert np.array_equal(out.numpy().reshape(-1)[g["patches/idx"]], g["patches/val"])
+
+
+def test_ksvqe_contrique(golden):
+    """oracle == the reference's CONTRIQUE_model.forward (patching, ResNet-50 trunk, normalise, projector; stored output)."""
+    from oracle import ksvqe_oracle as KO
+    z_ref = golden("contrique.npz")["z"]
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(51)).standard_normal((1, 3, 3, 64, 96)).astype(np.float32))
+    with torch.no_grad():
+        z = KO.contrique(x, synth.synth_contrique_weights(13)).numpy()
+    assert z.shape == z_ref.shape == (1, 3, 6, 128) and np.abs(z - z_ref).max() <= 2e-4
