@@ -150,6 +150,14 @@ int kvq_swin3d_tap_dims(const KvqSwinPlan* plan, int index, int32_t out4[4]);
 int kvq_resize_trilinear_cl(const float* src, int B, int D, int H, int W, int C, float* dst, int Do, int Ho, int Wo,
                             int c_total, int c_off, void* stream);
 
+/* Stages stage_lo .. stage_hi only (0-based, inclusive) — what KSVQE.forward needs to modulate the stream between stages
+ * (KSVQE_model.py:1433-1486).  stage_lo == 0 starts from the clip x; otherwise from io, the residual stream in front of
+ * stage_lo: fp32 channels-last (B, D, H, W, C) of that stage (kvq_swin3d_tap_dims(plan, stage_lo)).  On return io (may be
+ * NULL when feat is taken) holds the stream behind stage_hi (its PatchMerging included: kvq_swin3d_tap_dims(plan,
+ * stage_hi + 1)); feat (may be NULL) additionally receives the final LayerNorm when stage_hi is the last stage. */
+int kvq_swin3d_forward_stages(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, int stage_lo, int stage_hi,
+                              float* io, float* feat, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Dense attention bias of weights->blocks[block] for this plan's geometry (see kvq_attn_bias_dense_build): size
  * and builder.  Independent of the batch size; rebuild when the block's tables change. */
 size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* plan, int block);

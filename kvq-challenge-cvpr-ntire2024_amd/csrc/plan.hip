@@ -367,13 +367,21 @@ extern "C" int kvq_swin3d_tap_dims(const KvqSwinPlan* pl, int index, int32_t out
   return KVQ_OK;
 }
 
-extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float* x, float* feat,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+// stages stage_lo .. stage_hi of the trunk.  stage_lo == 0: starts from the clip x (patch embedding first); otherwise from
+// the residual stream `io` (fp32 channels-last (B, D, H_lo, W_lo, C_lo), copied into the workspace).  Afterwards `io`, when
+// given, receives the residual stream behind stage_hi (incl. its PatchMerging), and — stage_hi being the last stage — `feat`,
+// when given, the final LayerNorm of it.
+static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float* x, int stage_lo, int stage_hi, float* io,
+                    float* feat, void* workspace, size_t workspace_bytes, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(cpl && w && x && feat && workspace, KVQ_ERR_NULL, "kvq_swin3d_forward: NULL pointer");
+  KVQ_REQUIRE(cpl && w && workspace, KVQ_ERR_NULL, "kvq_swin3d_forward: NULL pointer");
   KVQ_REQUIRE(w->blocks && w->embed_w && w->embed_b && w->norm_w && w->norm_b, KVQ_ERR_NULL,
               "kvq_swin3d_forward: incomplete weights");
   KvqSwinPlan* pl = const_cast<KvqSwinPlan*>(cpl);   // profiling state only
+  KVQ_REQUIRE(stage_lo >= 0 && stage_lo <= stage_hi && stage_hi < pl->cfg.num_stages, KVQ_ERR_SHAPE,
+              "kvq_swin3d_forward: stages %d..%d of %d", stage_lo, stage_hi, pl->cfg.num_stages);
+  KVQ_REQUIRE(stage_lo == 0 ? x != nullptr : io != nullptr, KVQ_ERR_NULL, "kvq_swin3d_forward: no input for stage %d", stage_lo);
+  KVQ_REQUIRE(io || (feat && stage_hi == pl->cfg.num_stages - 1), KVQ_ERR_NULL, "kvq_swin3d_forward: no output buffer");
   KVQ_REQUIRE(workspace_bytes >= pl->ws_bytes, KVQ_ERR_WORKSPACE, "kvq_swin3d_forward: workspace %zu < %zu bytes",
               workspace_bytes, pl->ws_bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -392,7 +400,10 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
   float* cur = xa;
   float* oth = xb;
   bool first_ln1_ready = false;
-  if (w->embed_pack && kvq_patch_embed_supported(cfg.in_chans, cfg.patch[0], cfg.patch[1], cfg.patch[2], E, pl->T, pl->H, pl->W)) {
+  if (stage_lo > 0) {
+    const StageGeom& g0 = pl->st[stage_lo];
+    KVQ_CHECK_HIP(hipMemcpyAsync(xa, io, (size_t)B * g0.L * g0.C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else if (w->embed_pack && kvq_patch_embed_supported(cfg.in_chans, cfg.patch[0], cfg.patch[1], cfg.patch[2], E, pl->T, pl->H, pl->W)) {
     KvqPatchEmbedArgs ea{};
     ea.x = x; ea.B = B; ea.in_chans = cfg.in_chans; ea.T = pl->T; ea.H = pl->H; ea.W = pl->W;
     ea.pd = cfg.patch[0]; ea.ph = cfg.patch[1]; ea.pw = cfg.patch[2]; ea.embed_dim = E; ea.pack = w->embed_pack;
@@ -427,13 +438,16 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
     KVQ_CHECK_HIP(hipMemcpyAsync(pl->taps[idx], cur, elems * sizeof(float), hipMemcpyDeviceToDevice, st));
     return KVQ_OK;
   };
-  KVQ_TRY(tap(0, (size_t)B * L0 * E));
+  if (stage_lo == 0) KVQ_TRY(tap(0, (size_t)B * L0 * E));
 
   int blk = 0;
-  for (int i = 0; i < cfg.num_stages; ++i) {
+  for (int i = 0; i < stage_lo; ++i) blk += pl->st[i].depth;
+  size_t out_elems = 0;           // size of the residual stream behind the last stage run
+  for (int i = stage_lo; i <= stage_hi; ++i) {
     const StageGeom& g = pl->st[i];
     const int C = g.C, M = B * g.Lp, ML = B * g.L;
     bool ln1_ready = i == 0 && first_ln1_ready;   // the producer (embed / previous tail) already wrote this block's norm1 rows
+    if (i == stage_lo && i > 0) cur = xa, oth = xb;
     for (int b = 0; b < g.depth; ++b, ++blk) {
       const KvqSwinBlockW& bw = w->blocks[blk];
       KVQ_REQUIRE(bw.norm1_w && bw.rpb_table && bw.qkv_w && bw.proj_w && bw.fc1_w && bw.fc2_w, KVQ_ERR_NULL,
@@ -495,12 +509,28 @@ extern "C" int kvq_swin3d_forward(const KvqSwinPlan* cpl, const KvqSwinWeights* 
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
                    oth));
       float* t = cur; cur = oth; oth = t;
-      KVQ_TRY(tap(i + 1, (size_t)B * Ln * 2 * C));
+      out_elems = (size_t)B * Ln * 2 * C;
     } else {
-      KVQ_TRY(tap(i + 1, (size_t)ML * C));
+      out_elems = (size_t)ML * C;
     }
+    KVQ_TRY(tap(i + 1, out_elems));
   }
-  const StageGeom& gl = pl->st.back();
-  KVQ_TRY(ln(pl, st, cur, nullptr, 1, gl.L, gl.L, gl.C, w->norm_w, w->norm_b, nullptr, feat));
+  if (io) KVQ_CHECK_HIP(hipMemcpyAsync(io, cur, out_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (feat && stage_hi == cfg.num_stages - 1) {
+    const StageGeom& gl = pl->st.back();
+    KVQ_TRY(ln(pl, st, cur, nullptr, 1, gl.L, gl.L, gl.C, w->norm_w, w->norm_b, nullptr, feat));
+  }
   return KVQ_OK;
+}
+
+extern "C" int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, float* feat, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  KVQ_REQUIRE(plan && x && feat, KVQ_ERR_NULL, "kvq_swin3d_forward: NULL pointer");
+  return swin_run(plan, w, x, 0, plan->cfg.num_stages - 1, nullptr, feat, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kvq_swin3d_forward_stages(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, int stage_lo,
+                                         int stage_hi, float* io, float* feat, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  return swin_run(plan, w, x, stage_lo, stage_hi, io, feat, workspace, workspace_bytes, stream);
 }

@@ -433,6 +433,42 @@ class SwinTransformer3D(nn.Module):
             return taps[layer].permute(0, 4, 1, 2, 3)
         return feat.permute(0, 4, 1, 2, 3)      # channels-last storage, reference's (B,C,D,H,W) view
 
+    def forward_stages(self, x, stage_lo, stage_hi, geometry=None, want_feat=False):
+        """Stages ``stage_lo..stage_hi`` only (what KSVQE.forward interleaves its modulation with, KSVQE_model.py:1433-1486).
+        ``stage_lo == 0``: x is the clip (B,3,T,H,W); otherwise x is the residual stream in front of ``stage_lo`` in the
+        reference's layout (B, C, D, H', W') and ``geometry`` = the clip's (T, H, W).  Returns the stream behind
+        ``stage_hi`` as (B, C, D, H', W') — the permuted view of the channels-last result — and, with ``want_feat`` on the
+        last stage, the final-norm feature map as ``forward`` returns it."""
+        if not x.is_cuda:
+            raise _abi.KvqError("SwinTransformer3D.forward_stages needs its input on a HIP device; there is no CPU path")
+        if stage_lo == 0:
+            x = x.to(torch.float32).contiguous()
+            B, _, T, H, W = x.shape
+        else:
+            B = x.shape[0]
+            T, H, W = geometry
+        handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device)
+        w = self._weights(x.device)
+        self._set_dense_bias(handle, (T, H, W), x.device, B)
+        d4 = (C.c_int32 * 4)()
+        check(lib().kvq_swin3d_tap_dims(handle, stage_hi + 1, C.byref(d4)), "kvq_swin3d_tap_dims")
+        io = torch.empty(B, d4[1], d4[2], d4[3], d4[0], dtype=torch.float32, device=x.device)
+        if stage_lo > 0:
+            check(lib().kvq_swin3d_tap_dims(handle, stage_lo, C.byref(d4)), "kvq_swin3d_tap_dims")
+            if tuple(x.shape) != (B, d4[0], d4[1], d4[2], d4[3]):
+                raise _abi.KvqError(f"stage {stage_lo} expects a (B, {d4[0]}, {d4[1]}, {d4[2]}, {d4[3]}) stream, got {tuple(x.shape)}")
+            src = x.to(torch.float32).permute(0, 2, 3, 4, 1).contiguous()           # channels-last (layout only)
+            if src.numel() > io.numel():
+                io = torch.empty(src.numel(), dtype=torch.float32, device=x.device)
+            io.reshape(-1)[: src.numel()].copy_(src.reshape(-1))
+        feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device) if want_feat else None
+        check(lib().kvq_swin3d_forward_stages(handle, C.byref(w), ptr(x) if stage_lo == 0 else None, stage_lo, stage_hi, ptr(io),
+                                              ptr(feat), ptr(ws), ws.numel(), current_stream()), "kvq_swin3d_forward_stages")
+        check(lib().kvq_swin3d_tap_dims(handle, stage_hi + 1, C.byref(d4)), "kvq_swin3d_tap_dims")
+        n = B * d4[0] * d4[1] * d4[2] * d4[3]
+        out = io.reshape(-1)[:n].reshape(B, d4[1], d4[2], d4[3], d4[0]).permute(0, 4, 1, 2, 3)
+        return (out, feat.permute(0, 4, 1, 2, 3)) if want_feat else out
+
     # profiling hooks used by bench.py ------------------------------------------------------
     def profile(self, B, T, H, W, device, enable: bool):
         handle, _, _ = self._plan(B, T, H, W, device)

@@ -256,3 +256,25 @@ def test_resize_trilinear_cl_matches_interpolate():
         got = out.cpu()
         assert (got[..., 3:3 + Cc] - ref).abs().max().item() <= 1e-5
         assert got[..., :3].abs().max().item() == 0 and got[..., 3 + Cc:].abs().max().item() == 0
+
+
+def test_forward_stages_equals_whole_forward(golden):
+    """The trunk run stage by stage through ``forward_stages`` (the stream leaves and re-enters the library between the
+    calls, as KSVQE's modulation needs) gives the whole forward's feature map bit for bit, and the taps' streams."""
+    t = golden("trunk.npz")
+    case = "t_grpb_stress_8x80"
+    wseed, cseed, B, T, H, W = (int(v) for v in t[f"{case}/meta"])
+    net, key = build_network(str(t[f"{case}/cfg"]), wseed, str(t[f"{case}/scheme"]), "fp16")
+    bb = getattr(net, key + "_backbone")
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B)).to(DEV)
+    with torch.no_grad():
+        whole = bb({"technical": x})
+        tap2 = bb({"technical": x}, layer=2)
+        s = bb.forward_stages(x, 0, 1)
+        assert torch.equal(s, tap2)
+        s = bb.forward_stages(s, 2, 2, geometry=(T, H, W))
+        s, feat = bb.forward_stages(s, 3, 3, geometry=(T, H, W), want_feat=True)
+        allin, feat2 = bb.forward_stages(x, 0, 3, want_feat=True)
+    assert torch.equal(feat, whole) and torch.equal(feat2, whole) and torch.equal(s, allin)
+    with pytest.raises(_abi.KvqError, match="expects"):
+        bb.forward_stages(torch.zeros(B, 5, 1, 1, 1, device=DEV), 2, 2, geometry=(T, H, W))
