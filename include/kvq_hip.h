@@ -414,6 +414,9 @@ int kvq_crop_regions(const float* x, const int32_t* region, int B, int C, int T,
 /* F.normalize(x, dim=1) of fp32 rows [M][D] -> 16-bit [M][D] (CONTRIQUE_model.forward, KSVQE_model.py:1654-1656). */
 int kvq_l2_normalize_rows(const float* x, int M, int D, int dtype, uint16_t* out, void* stream);
 
+/* out = a * x + b * y over n fp32 elements (out may alias x or y): the fixed blends of KSVQE.forward (KSVQE_model.py:1426, :1482). */
+int kvq_axpby(const float* x, const float* y, float a, float b, float* out, long n, void* stream);
+
 /* Implicit-GEMM convolution (nn.Conv2d / nn.Conv3d + folded BatchNorm [+ identity] [+ ReLU], the Bottleneck convs of
  * simpleVQA_model.py:85-126 and the SlowFast res blocks): the GEMM's A tiles are fetched straight from the channels-LAST
  * 16-bit activation x (B, D, H, W, C), C % 8 == 0 — no patch matrix.  W [N][Kpad], columns ordered (kd,kh,kw,c) like

@@ -118,6 +118,7 @@ SYMBOLS = {
     "kvq_qrs_top_region": (i32, [p_void, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_crop_regions": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_l2_normalize_rows": (i32, [p_void, i32, i32, i32, p_void, p_void]),
+    "kvq_axpby": (i32, [p_void, p_void, f32, f32, p_void, i64, p_void]),
     "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
     "kvq_swin3d_forward_stages": (i32, [p_void, p_void, p_void, i32, i32, p_void, p_void, p_void, sz, p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),

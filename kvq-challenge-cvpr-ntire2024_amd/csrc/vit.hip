@@ -415,3 +415,20 @@ extern "C" int kvq_l2_normalize_rows(const float* x, int M, int D, int dtype, ui
   KVQ_CHECK_LAUNCH("l2_normalize_rows_kernel");
   return KVQ_OK;
 }
+
+// out = a * x + b * y (fp32, n elements): the fixed mixes of KSVQE.forward (0.2 / 0.8 adapter blend :1426, (a1 x_d + a2 x_s) / 2 :1482)
+namespace kvq {
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fmaf(a, x[i], b * y[i]);
+}
+}  // namespace kvq
+
+extern "C" int kvq_axpby(const float* x, const float* y, float a, float b, float* out, long n, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && y && out, KVQ_ERR_NULL, "kvq_axpby: NULL pointer");
+  KVQ_REQUIRE(n > 0, KVQ_ERR_SHAPE, "kvq_axpby: n=%ld", n);
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, b, out, n);
+  KVQ_CHECK_LAUNCH("axpby_kernel");
+  return KVQ_OK;
+}

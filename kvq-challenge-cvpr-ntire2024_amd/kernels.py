@@ -351,6 +351,15 @@ def l2_normalize_rows(x: torch.Tensor, out_dtype):
     return out
 
 
+def axpby(x: torch.Tensor, y: torch.Tensor, a: float, b: float):
+    """a * x + b * y, fp32, same shape."""
+    _need_gpu(x, y)
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    out = torch.empty_like(x)
+    check(lib().kvq_axpby(ptr(x), ptr(y), float(a), float(b), ptr(out), x.numel(), current_stream()), "kvq_axpby")
+    return out
+
+
 def cls_gather(x: torch.Tensor, out_dtype):
     """x fp32 (B, L, D) -> x[:, 0] as 16-bit [B, D]."""
     _need_gpu(x)

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's ``KSVQE`` (``models/backbones/KSVQE_model.py:1024-1500``): the Swin-3D(GRPB) trunk with
+the quality-aware region selection in front of it and the content / distortion modulation behind its last two stages.
+
+Same constructor arguments, module tree and ``state_dict`` keys (trunk keys at the top level as in the reference; ``CLIP_tool.*``,
+``distortion_tool.*``, ``dist_adapter.*``, ``semantic_adapter.k.*``, ``distortion_adapter.k.*``, ``semantic_mod.k.*``,
+``distortion_mod.k.*``, ``semantic_cross.k.*``, ``distortion_cross.k.*``, ``distortion_self.k.*``, ``a1``, ``a2``), same forward:
+``x`` = the dataset dict (``resize_video`` (b,3,t,112,112), ``fragment`` (b,3,t,288,288), ``dis_label``) ->
+``(feature map (b, 768, t/2, 7, 7), distortion contrastive loss)``.
+
+Everything on the score path runs on ``libkvq_hip.so``: CLIP_tool (clip_visual.py), QRS, the CONTRIQUE branch and the CDM
+modules (ksvqe_modules.py), the trunk stage by stage (``SwinTransformer3D.forward_stages``).  The reference's constructor
+downloads / loads CLIP and CONTRIQUE checkpoints from absolute paths (:1068-1074); here the sub-networks are created
+randomly initialised and the checkpoints arrive through ``load_state_dict`` / ``Trainer.load_checkpoint``.  The contrastive
+loss (:1666-1691, returned next to the features, unused by inference) is a few torch ops on a (b·t/2·49, 128) matrix."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import _abi, kernels
+from . import ksvqe_modules as KM
+from .clip_visual import build_CLIPmodel_basedadapter_cls
+from .swin_backbone import SwinTransformer3D
+
+
+def _adapter(cin, hidden, cout):
+    return nn.Sequential(nn.Linear(cin, hidden), nn.ReLU(inplace=True), nn.Linear(hidden, cout), nn.ReLU(inplace=True))
+
+
+def distortion_contrastive_supervised(distortion_feature, dis_label):
+    """Reference loss (:1666-1691): supervised contrastive over all (clip, frame, patch) tokens, positives = same distortion
+    label (self excluded), temperature 0.1.  Auxiliary output; plain torch on the device."""
+    b, t, g, _ = distortion_feature.shape
+    f = distortion_feature.reshape(b * t * g, -1)
+    same = (dis_label.unsqueeze(1).repeat(1, b) == dis_label).to(torch.float32).to(f.device)
+    labels = same.repeat(1, t * g).view(b * t * g, -1)
+    z = nn.functional.normalize(f, p=2, dim=1)
+    sim = z @ z.t() / 0.1
+    n = b * t * g
+    off = 1.0 - torch.eye(n, device=f.device)
+    pos = (labels @ labels.t()) * off
+    return torch.mean(torch.log(torch.sum(torch.exp(sim) * off, dim=1)) - torch.sum(sim * pos, dim=1) / torch.sum(pos, dim=1))
+
+
+class KSVQE(SwinTransformer3D):
+    def __init__(self, pretrained=None, pretrained2d=False, num_samples=500, sample_type="topkpertubation", CLIP_location=10,
+                 cls_use=True, tuning_stage=2, a1=1, a2=0, checkpoint=None, qls_swin=None, frozen3D=None, **trunk):
+        trunk.setdefault("frag_biases", (True, True, True, False))
+        super().__init__(pretrained=pretrained, pretrained2d=pretrained2d, **trunk)
+        depths, heads, E = self.depths, self.heads, self.embed_dim
+        self.N_key = 5                                   # reference attribute; four frames are actually used (:1357-1361)
+        self.CLIP_tool = build_CLIPmodel_basedadapter_cls(CLIP_location=CLIP_location, cls_use=cls_use)
+        self.distortion_tool = KM.CONTRIQUE_model(KM.get_network("resnet50"), 2048)
+        self.dist_adapter = _adapter(128, 32, 128)
+        self.spa_patchnet = KM.RegionNet_CLIP(k=7 * 7, anchor_size=32, stride=1, num_samples=num_samples, sample_type=sample_type)
+        self.sigma_max = self.sigma = 0.5
+        self.tuning_stage = tuning_stage
+        self.semantic_adapter, self.distortion_adapter = nn.ModuleList(), nn.ModuleList()
+        self.semantic_mod, self.distortion_mod = nn.ModuleList(), nn.ModuleList()
+        self.semantic_cross, self.distortion_cross, self.distortion_self = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        n_tuned = len(depths) - tuning_stage
+        self.a1 = nn.Parameter(torch.zeros(n_tuned, 1) + a1)
+        self.a2 = nn.Parameter(torch.zeros(n_tuned, 1) + a2)
+        for i in range(tuning_stage, len(depths)):
+            if i + 1 > len(depths) - 1:
+                i = len(depths) - 2
+            c = int(E * 2 ** (i + 1))
+            self.semantic_adapter.append(_adapter(768, 768 // 4, c))
+            self.distortion_adapter.append(_adapter(128, 128 // 4, c))
+            self.semantic_mod.append(KM.Semantic_Transformation2(c))
+            self.distortion_mod.append(KM.Dist_Transformation3(c))
+            self.semantic_cross.append(KM.crossattention1(c, heads[i]))
+            self.distortion_cross.append(KM.crossattention1(c, heads[i]))
+            self.distortion_self.append(KM.Attention(c, heads[i]))
+        self._acache = None
+
+    # ------------------------------------------------------------------ adapters: Linear -> ReLU -> Linear -> ReLU = two GEMMs
+    def _adapters(self, device):
+        half = _abi.torch_dtype(self.operand_dtype)
+        mods = [self.dist_adapter] + list(self.semantic_adapter) + list(self.distortion_adapter)
+        sig = (self.operand_dtype,) + tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+        if self._acache is None or self._acache[0] != sig:
+            def f(m):
+                w = m.weight.detach().to(device, torch.float32)
+                if half == torch.float16:
+                    w = w.clamp(-65504.0, 65504.0)
+                return w.to(half).contiguous(), m.bias.detach().to(device, torch.float32).contiguous()
+            self._acache = (sig, {id(m): (f(m[0]), f(m[2])) for m in mods})
+        return self._acache[1]
+
+    def _run_adapter(self, mod, rows16):
+        (w0, b0), (w2, b2) = self._adapters(rows16.device)[id(mod)]
+        return kernels.conv_gemm(kernels.conv_gemm(rows16, w0, b0, True), w2, b2, True)
+
+    def _sync_dtype(self):
+        mods = [self.CLIP_tool, self.distortion_tool] + list(self.semantic_mod) + list(self.distortion_mod)
+        for m in mods + list(self.semantic_cross) + list(self.distortion_cross) + list(self.distortion_self):
+            m.operand_dtype = self.operand_dtype
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
+        if multi or layer > -1 or adaptive_window_size:
+            raise NotImplementedError("feature taps / adaptive windows of KSVQE: no caller sets them")
+        revideo, fragment, dis_label = x["resize_video"], x["fragment"], x["dis_label"]
+        if not fragment.is_cuda:
+            raise _abi.KvqError("KSVQE.forward needs its inputs on a HIP device; there is no CPU path")
+        self._sync_dtype()
+        half = _abi.torch_dtype(self.operand_dtype)
+        dev = fragment.device
+        revideo, fragment = revideo.to(dev, torch.float32), fragment.to(torch.float32).contiguous()
+        if not torch.is_tensor(dis_label):
+            dis_label = torch.as_tensor(dis_label)
+        dis_label = dis_label.reshape(-1).to(dev)
+        b, _, t = fragment.shape[:3]
+        # key frames -> CLIP: the CLS-to-patch map ranks the regions, the patch tokens feed the semantic modulation
+        group_id, key = KM.obtain_keyframes(revideo)
+        n_key = key.shape[1]
+        cls_attn, _, pat = self.CLIP_tool(key.reshape((b * n_key,) + tuple(key.shape[2:])).contiguous())
+        grid = pat.shape[2]
+        patch_tokens = KM.extend_by_group(pat.reshape(b, n_key, grid * pat.shape[3]), group_id).reshape(b, t, grid, -1)
+        # QRS: one 224x224 window of the 288x288 fragment canvas per key frame
+        x_sel_ori = self.spa_patchnet(fragment, cls_attn.reshape(b, n_key, -1), self.sigma, group_id)
+        # distortion tokens of every other frame
+        dist = self.distortion_tool(x_sel_ori[:, :, ::2].contiguous())                       # (b, t/2, 49, 128) fp32
+        d16 = kernels.to_half(dist.reshape(-1, dist.shape[-1]).contiguous(), half)
+        dist = kernels.axpby(kernels.to_float(self._run_adapter(self.dist_adapter, d16)).reshape(dist.shape), dist, 0.2, 0.8)
+        loss = distortion_contrastive_supervised(dist, dis_label)
+        geom = tuple(x_sel_ori.shape[2:])
+        n_st = self.num_layers
+        x_sel = self.forward_stages(x_sel_ori, 0, min(self.tuning_stage, n_st) - 1) if self.tuning_stage > 0 else x_sel_ori
+        for l in range(self.tuning_stage, n_st):
+            x_sel = self.forward_stages(x_sel if l > 0 else x_sel_ori, l, l, geometry=geom)
+            x_sel = self._modulate(l - self.tuning_stage, x_sel, patch_tokens, dist, half)
+        n, c, d, hh, ww = x_sel.shape
+        rows = x_sel.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+        feat = kernels.layernorm_rows(rows, self.norm.weight.detach().to(dev, torch.float32), self.norm.bias.detach().to(dev, torch.float32),
+                                      out_dtype=torch.float32)
+        return feat.reshape(n, d, hh, ww, c).permute(0, 4, 1, 2, 3), loss
+
+    def _modulate(self, k, x_sel, patch_tokens, dist, half):
+        """CDM behind a tuned stage (:1436-1482): x_sel (n, c, t', h, w) -> (a1 * distortion-modulated + a2 * semantic-modulated) / 2."""
+        n, c, tt, hh, ww = x_sel.shape
+        hw = hh * ww
+        rows = x_sel.permute(0, 2, 3, 4, 1).reshape(n * tt * hw, c).contiguous()            # token rows, frame-major (layout only)
+        frames = rows.reshape(n * tt, hw, c)
+        # --- semantic: CLIP patch tokens of every other frame, adapted to c channels, cross-attended by the frame's tokens
+        pt = patch_tokens[:, ::2].reshape(-1, patch_tokens.shape[-1]).contiguous()
+        pt = kernels.to_float(self._run_adapter(self.semantic_adapter[k], kernels.to_half(pt, half))).reshape(n * tt, -1, c)
+        enhanced, _ = self.semantic_cross[k](frames, pt)
+        sm = self.semantic_mod[k]
+        wsm = sm._cached(rows.device, lambda: (sm.conv_gama.weight.detach().to(rows.device, torch.float32).reshape(-1).contiguous(),
+                                               float(sm.conv_gama.bias.detach()),
+                                               sm.conv_beta.weight.detach().to(rows.device, torch.float32).reshape(-1).contiguous(),
+                                               float(sm.conv_beta.bias.detach())))
+        x_s = kernels.sem_modulate(enhanced.reshape(-1, c).contiguous(), rows, *wsm)         # (n t' hw, c)
+        # --- distortion: CONTRIQUE tokens adapted to c channels, cross-attended per frame, then self-attention over the
+        # frames of every spatial position, then (mean, std)-driven channel modulation
+        dt = kernels.to_float(self._run_adapter(self.distortion_adapter[k], kernels.to_half(dist.reshape(-1, dist.shape[-1]).contiguous(), half)))
+        d_enh, _ = self.distortion_cross[k](frames, dt.reshape(n * tt, -1, c))
+        d_enh = d_enh.reshape(n, tt, hw, c).permute(0, 2, 1, 3).reshape(n * hw, tt, c).contiguous()
+        d_enh = self.distortion_self[k](d_enh)
+        d_enh = d_enh.reshape(n, hw, tt, c).permute(0, 3, 2, 1).reshape(n, c, tt, hh, ww)
+        x_d = self.distortion_mod[k](d_enh, rows.reshape(n, tt * hw, c))                      # (n, t' hw, c)
+        a1, a2 = float(self.a1[k]), float(self.a2[k])
+        out = kernels.axpby(x_d.reshape(-1, c).contiguous(), x_s, a1 / 2.0, a2 / 2.0)
+        return out.reshape(n, tt, hh, ww, c).permute(0, 4, 1, 2, 3)

@@ -38,11 +38,16 @@ class VQA_Network(nn.Module):  # noqa: N801  (reference spelling)
                 from .backbones.simpleVQA_model import resnet50 as simpleVQA_Backbone
                 backbone = simpleVQA_Backbone(pretrained=False)
                 head = simpleVQAHead(**(hypers.get("head") or {}))
-            elif key in ("KSVQE", "conv_tiny"):
-                raise NotImplementedError(
-                    f"model key {key!r}: the CLIP / CONTRIQUE / QRS / CDM modules (KSVQE) and ConvNeXt (conv_tiny) are "
-                    "outside the built hot path (SURVEY.md §8 rows f1 / out-of-scope); the KSVQE trunk is available "
-                    "as key 'swin_tiny_grpb'")
+            elif key == "KSVQE":                                # the reference reads these keys one by one (model.py:59-68)
+                from .backbones.KSVQE_model import KSVQE as KSVQE_Backbone
+                bk = hypers["backbone"]
+                backbone = KSVQE_Backbone(num_samples=bk["num_samples"], sample_type=bk["sample_type"],
+                                          CLIP_location=bk["CLIP_location"], cls_use=bk["cls_use"],
+                                          tuning_stage=bk["tuning_stage"], a1=bk.get("a1", 1), a2=bk.get("a2", 0),
+                                          frozen_stages=bk.get("frozen_stages", -1))
+                head = VQAHead(**(hypers.get("head") or {}))
+            elif key == "conv_tiny":
+                raise NotImplementedError("model key 'conv_tiny' (ConvNeXt-3D) is outside the built scope (SURVEY.md §8)")
             else:
                 raise NotImplementedError
             self.key_names.append(key)
@@ -51,14 +56,18 @@ class VQA_Network(nn.Module):  # noqa: N801  (reference spelling)
 
     def forward(self, inputs, targets=None, inference=True, return_pooled_feats=False, reduce_scores=False,
                 pooled=False, clip_return=False, **kwargs):
-        scores, feats = [], {}
+        scores, feats, dis_contra_loss = [], {}, None
         for key in self.key_names:
             feat = getattr(self, key + "_backbone")(inputs, multi=self.multi, layer=self.layer, **kwargs)
+            if key == "KSVQE":                                   # (features, distortion contrastive loss) (model.py:93-96)
+                feat, dis_contra_loss = feat
             scores += [getattr(self, key + "_head")(feat)]
             if return_pooled_feats:
                 feats[key] = feat
         if reduce_scores:
             scores = reduce(lambda a, b: a + b, scores) if len(scores) > 1 else scores[0]
         if return_pooled_feats:
-            return scores, feats
+            return (scores, feats, dis_contra_loss) if dis_contra_loss is not None else (scores, feats)
+        if dis_contra_loss is not None:
+            return scores, dis_contra_loss
         return scores

@@ -328,6 +328,45 @@ def synth_contrique_weights(seed: int = 0, n_features=2048, projection_dim=128):
     return out
 
 
+def synth_ksvqe_weights(seed: int = 0, clip_location: int = 8):
+    """A complete synthetic state_dict of the reference's KSVQE (KSVQE_model.py:1024-1198): trunk ('stress'), CLIP_tool,
+    distortion_tool, the Linear-ReLU adapters, the CDM modules of the two tuned stages, and a1 / a2 away from their (1, 0)
+    defaults so that both modulation branches reach the output."""
+    out = OrderedDict(synth_swin_weights(SWIN_T_GRPB, seed, "stress"))
+    for k, v in synth_clip_visual_weights(seed + 1, clip_location=clip_location).items():
+        out["CLIP_tool." + k] = v
+    for k, v in synth_contrique_weights(seed + 2).items():
+        out["distortion_tool." + k] = v
+
+    def adapter(pre, cin, hid, cout):
+        for idx, (o, i) in (("0", (hid, cin)), ("2", (cout, hid))):
+            g = _gen(seed, "ksvqe/" + pre + idx)
+            out[f"{pre}{idx}.weight"] = (g.standard_normal((o, i)) * (2.0 / i) ** 0.5).astype(np.float32)
+            out[f"{pre}{idx}.bias"] = (0.1 * g.standard_normal(o)).astype(np.float32)
+
+    adapter("dist_adapter.", 128, 32, 128)
+    for k in range(2):
+        adapter(f"semantic_adapter.{k}.", 768, 192, 768)
+        adapter(f"distortion_adapter.{k}.", 128, 32, 768)
+        cdm = synth_cdm_weights(seed + 10 + k)
+        for mod, pre in (("cross", "semantic_cross"), ("sem", "semantic_mod"), ("dist", "distortion_mod"), ("self", "distortion_self")):
+            for name, v in cdm[mod].items():
+                out[f"{pre}.{k}.{name}"] = v
+        for name, v in synth_cdm_weights(seed + 20 + k)["cross"].items():
+            out[f"distortion_cross.{k}.{name}"] = v
+    out["a1"] = np.asarray([[0.9], [1.1]], np.float32)
+    out["a2"] = np.asarray([[0.4], [0.3]], np.float32)
+    return out
+
+
+def synth_ksvqe_inputs(seed: int = 0, b: int = 2, t: int = 32):
+    """resize_video (b,3,t,112,112) ~ N(0,1) (CLIP-normalised scale), fragment (b,3,t,288,288) ~ N(0,1) (KVQ-normalised), labels."""
+    g = _gen(seed, "ksvqe/inputs")
+    return {"resize_video": g.standard_normal((b, 3, t, 112, 112)).astype(np.float32),
+            "fragment": g.standard_normal((b, 3, t, 288, 288)).astype(np.float32),
+            "dis_label": np.arange(b, dtype=np.int64) % 2}
+
+
 def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
     return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
 

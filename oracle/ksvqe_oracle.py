@@ -126,3 +126,69 @@ def contrique(x, params, anchor=32, normalize=True):
     f = F.relu(bn1d(F.linear(f, p["projector.0.weight"]), "projector.1"))
     f = bn1d(F.linear(f, p["projector.3.weight"]), "projector.4")
     return f.reshape(b, t, gh * gw, -1)
+
+
+def _adapter(v, p, pre):
+    v = F.relu(F.linear(v, p[pre + "0.weight"], p[pre + "0.bias"]))
+    return F.relu(F.linear(v, p[pre + "2.weight"], p[pre + "2.bias"]))
+
+
+def contrastive_supervised(feat, dis_label):
+    """distortion_contrastive_supervised (:1666-1691)."""
+    b, t, g, _ = feat.shape
+    f = feat.reshape(b * t * g, -1)
+    same = (dis_label.unsqueeze(1).repeat(1, b) == dis_label).float()
+    labels = same.repeat(1, t * g).view(b * t * g, -1)
+    z = F.normalize(f, p=2, dim=1)
+    sim = z @ z.t() / 0.1
+    n = b * t * g
+    off = 1.0 - torch.eye(n)
+    pos = (labels @ labels.t()) * off
+    return torch.mean(torch.log(torch.sum(torch.exp(sim) * off, dim=1)) - torch.sum(sim * pos, dim=1) / torch.sum(pos, dim=1))
+
+
+def ksvqe_forward(inputs, params, cfg, clip_location=8, tuning_stage=2):
+    """KSVQE.forward (:1389-1500), eval: inputs = {resize_video (b,3,t,112,112), fragment (b,3,t,288,288), dis_label (b,)};
+    params = the model's state_dict (numpy / tensors); cfg = the trunk's SwinCfg.  Returns (features (b, 768, t/2, 7, 7), loss)."""
+    from . import clip_oracle as CO
+    from . import swin3d_oracle as O
+    p = {k: ((v if torch.is_tensor(v) else torch.from_numpy(v))) for k, v in params.items()}
+    p = {k: (v.float() if v.is_floating_point() else v) for k, v in p.items()}
+    sub = lambda pre: {k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}       # noqa: E731
+    rv, frag, dis_label = inputs["resize_video"].float(), inputs["fragment"].float(), inputs["dis_label"]
+    b, _, t = frag.shape[:3]
+    gid, key = obtain_keyframes(rv)
+    n_key = key.shape[1]
+    cls_attn, _, pat = CO.clip_visual_extractor(key.reshape((b * n_key,) + tuple(key.shape[2:])), sub("CLIP_tool."),
+                                                clip_location=clip_location)
+    pat = pat.reshape(b, n_key, pat.shape[2], pat.shape[3])
+    patch_tokens = torch.stack([torch.stack([pat[i, int(gid[i, j])] for j in range(t)]) for i in range(b)])      # (b, t, 49, 768)
+    x_ori, _ = qrs_select(frag, cls_attn.reshape(b, n_key, -1), gid)
+    dist = contrique(x_ori[:, :, ::2], sub("distortion_tool."))
+    dist = 0.2 * _adapter(dist, p, "dist_adapter.") + 0.8 * dist
+    loss = contrastive_supervised(dist, dis_label)
+    shift = tuple(w // 2 for w in cfg.window)
+    y = O.patch_embed(x_ori, p, cfg.patch)
+    for i in range(len(cfg.depths)):
+        for blk in range(cfg.depths[i]):
+            y = O.swin_block(y, p, f"layers.{i}.blocks.{blk}.", cfg.num_heads[i], cfg.window, (0, 0, 0) if blk % 2 == 0 else shift)
+        if i < len(cfg.depths) - 1:
+            y = O.patch_merge(y, p, f"layers.{i}.downsample.")
+        if i >= tuning_stage:                                      # CDM on the stage output (:1436-1482); y channels-last (n, t', h, w, c)
+            k = i - tuning_stage
+            n, tt, hh, ww, c = y.shape
+            frames = y.reshape(n * tt, hh * ww, c)
+            pt = _adapter(patch_tokens[:, ::2].reshape(n * tt, -1, patch_tokens.shape[-1]), p, f"semantic_adapter.{k}.")
+            heads = cfg.num_heads[min(i, len(cfg.depths) - 2)]
+            enh, _ = cross_attention(frames, pt, sub(f"semantic_cross.{k}."), heads)
+            cf = lambda v: v.reshape(n * tt, hh, ww, c).permute(0, 3, 1, 2)               # noqa: E731
+            x_s = semantic_transformation2(cf(enh), cf(frames), sub(f"semantic_mod.{k}.")).permute(0, 2, 3, 1).reshape(n, tt, hh, ww, c)
+            dt = _adapter(dist.reshape(n * tt, -1, dist.shape[-1]), p, f"distortion_adapter.{k}.")
+            de, _ = cross_attention(frames, dt, sub(f"distortion_cross.{k}."), heads)
+            de = de.reshape(n, tt, hh * ww, c).permute(0, 2, 1, 3).reshape(n * hh * ww, tt, c)
+            de = self_attention(de, sub(f"distortion_self.{k}."), heads)
+            de = de.reshape(n, hh * ww, tt, c).permute(0, 3, 2, 1).reshape(n, c, tt, hh, ww)
+            x_d = dist_transformation3(de, y.reshape(n, tt * hh * ww, c), sub(f"distortion_mod.{k}.")).reshape(n, tt, hh, ww, c)
+            y = (p["a1"][k] * x_d + p["a2"][k] * x_s) / 2
+    y = F.layer_norm(y, (y.shape[-1],), p["norm.weight"], p["norm.bias"])
+    return y.permute(0, 4, 1, 2, 3).contiguous(), loss

@@ -437,6 +437,57 @@ def sec_contrique(ref):
     save("contrique.npz", d)
 
 
+def sec_ksvqe(ref):
+    """The whole KSVQE.forward of the REFERENCE with synthetic weights.  Its constructor fetches CLIP and a
+    CONTRIQUE checkpoint from absolute paths and needs torchvision (KSVQE_model.py:1068-1074, :1608): those three hooks are
+    replaced here by the reference's own classes (vendored ViT, CONTRIQUE_model over the torchvision-ordered shell of the
+    reference's ResNet-50 blocks) — the forward itself is untouched reference code."""
+    import contextlib
+    import importlib
+    import io
+    from oracle import ksvqe_oracle as KO
+    with contextlib.redirect_stdout(io.StringIO()):
+        K = importlib.import_module("models.backbones.KSVQE_model")
+        CB = importlib.import_module("models.backbones.CLIP_backbone")
+        CM = importlib.import_module("models.backbones.clip.model")
+
+    def shell(*a, **k):
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = ref.simple.resnet50(pretrained=False)
+        sh = torch.nn.Module()
+        for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool"):
+            sh.add_module(name, getattr(r, name))
+        sh.add_module("fc", torch.nn.Linear(2048, 10))
+        return sh
+
+    K.get_network = shell
+    K.build_CLIPmodel_basedadapter_cls = lambda CLIP_location=None, cls_use=None, **k: CB.CLIP_extractor_addadapter_cls(
+        visual=CM.VisionTransformer(224, 16, 768, 12, 12, 512), CLIP_location=CLIP_location, cls_use=cls_use)
+    wts = synth.synth_ksvqe_weights(3)
+    real_load = torch.load
+    torch.load = lambda path, *a, **k: ({kk[len("distortion_tool."):]: torch.from_numpy(v) for kk, v in wts.items()
+                                         if kk.startswith("distortion_tool.")} if "CONTRIQUE" in str(path) else real_load(path, *a, **k))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = K.KSVQE(pretrained=None, num_samples=1, sample_type="topkpertubation", CLIP_location=8, cls_use=True, tuning_stage=2,
+                        use_checkpoint=False)
+    finally:
+        torch.load = real_load
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=False)
+    assert not missing.unexpected_keys and all("relative_position_index" in k for k in missing.missing_keys), missing
+    m.eval()
+    inp = {k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_inputs(4, b=2).items()}
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        f_ref, l_ref = m(inp)
+        f, l = KO.ksvqe_forward(inp, wts, synth.SWIN_T_GRPB)
+    e = float((f - f_ref).abs().max())
+    print(f"ksvqe: feat {tuple(f_ref.shape)} |oracle-ref| {e:.2e} (max |f| {float(f_ref.abs().max()):.2f}); loss {float(l_ref):.6f} vs {float(l):.6f}")
+    assert e <= 5e-4 and abs(float(l) - float(l_ref)) <= 1e-4
+    d = {"loss": np.float64(l_ref)}
+    put(d, "feat", samples(f_ref.numpy(), 8192))
+    save("ksvqe.npz", d)
+
+
 def sec_ckpt(ref):
     """Checkpoint formats: what the REFERENCE's inflate_weights / load_swin leave in the trunk's state
     dict for synthetic 2D / Video-Swin checkpoints (kvq_amd.utils.synth), and the build's loaders on the same files."""
@@ -484,7 +535,7 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"ksvqe": sec_ksvqe, "contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

@@ -73,8 +73,8 @@ def test_model_keys_and_errors():
     assert m.swin_tiny_grpb_m_backbone.window_size == (4, 4, 4)
     with pytest.raises(NotImplementedError):
         VQA_Network({"model": {"args": {"unknown_key": {}}}})
-    with pytest.raises(NotImplementedError, match="KSVQE"):
-        VQA_Network({"model": {"args": {"KSVQE": {}}}})
+    with pytest.raises(NotImplementedError, match="conv_tiny"):
+        VQA_Network({"model": {"args": {"conv_tiny": {}}}})
     with pytest.raises(_abi.KvqError, match="no CPU path"):
         tiny(inputs={"technical": torch.zeros(1, 3, 8, 64, 64)})
 

@@ -193,3 +193,37 @@ def test_contrique_vs_reference_golden(golden, dtype):
     assert rel <= {"fp16": 1.5e-2, "bf16": 1e-1}[dtype], rel
     with pytest.raises(KeyError):
         KM.get_network("VGG16")
+
+
+@pytest.mark.parametrize("dtype", ["fp16"])
+def test_ksvqe_end_to_end_vs_reference_golden(golden, dtype):
+    """The whole KSVQE forward on the HIP kernels (key frames -> CLIP_tool -> QRS -> CONTRIQUE / adapters -> trunk stage by
+    stage with the CDM behind stages 2 and 3 -> norm) through VQA_Network, against the reference's stored features/loss."""
+    from kvq_amd.models import VQA_Network
+    g = golden("ksvqe.npz")
+    net = VQA_Network({"model": {"args": {"KSVQE": {"backbone": dict(num_samples=1, sample_type="topkpertubation", CLIP_location=8,
+                                                                       cls_use=True, tuning_stage=2, a1=1, a2=0, frozen_stages=-1),
+                                                      "head": {"in_channels": 768, "hidden_channels": 64}}}}})
+    bb = net.KSVQE_backbone
+    missing = bb.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_weights(3).items()}, strict=False)
+    assert not missing.unexpected_keys and all("relative_position_index" in k for k in missing.missing_keys)
+    bb.operand_dtype = _abi.dtype_code(dtype)
+    net = net.to(DEV).eval()
+    inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_ksvqe_inputs(4, b=2).items()}
+    with torch.no_grad():
+        (scores, feats, loss) = net(inputs=dict(inp), reduce_scores=True, return_pooled_feats=True)
+        scores2, loss2 = net(inputs=dict(inp), reduce_scores=True)
+    f = np.ascontiguousarray(feats["KSVQE"].float().cpu().numpy())
+    assert f.shape == tuple(g["feat/shape"]) and scores.shape == (2, 1) and torch.equal(scores, scores2)
+    got, ref = f.reshape(-1)[g["feat/idx"]], g["feat/val"]
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-2, rel
+    assert abs(float(loss) - float(g["loss"])) <= 2e-2 and abs(float(loss2) - float(loss)) <= 1e-6
+    # the head on the oracle's features vs on the HIP features: the score gate of the trunk tests
+    from oracle import ksvqe_oracle as KO
+    from oracle import swin3d_oracle as O
+    hw = {k[len("KSVQE_head."):]: v.detach().cpu().numpy() for k, v in net.state_dict().items() if k.startswith("KSVQE_head.")}
+    with torch.no_grad():
+        f_or, _ = KO.ksvqe_forward({k: v.cpu() for k, v in inp.items()}, synth.synth_ksvqe_weights(3), synth.SWIN_T_GRPB)
+        s_or = O.vqa_head(f_or, hw)
+    assert (scores.float().cpu() - s_or).abs().max().item() <= 1e-3

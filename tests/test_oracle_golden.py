@@ -198,3 +198,29 @@ def test_ksvqe_contrique(golden):
     with torch.no_grad():
         z = KO.contrique(x, synth.synth_contrique_weights(13)).numpy()
     assert z.shape == z_ref.shape == (1, 3, 6, 128) and np.abs(z - z_ref).max() <= 2e-4
+
+
+def test_ksvqe_forward_end_to_end(golden):
+    """oracle/ksvqe_oracle.py::ksvqe_forward == the reference's KSVQE.forward (features sampled + the contrastive loss)."""
+    from oracle import ksvqe_oracle as KO
+    g = golden("ksvqe.npz")
+    inp = {k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_inputs(4, b=2).items()}
+    with torch.no_grad():
+        f, l = KO.ksvqe_forward(inp, synth.synth_ksvqe_weights(3), synth.SWIN_T_GRPB)
+    a = np.ascontiguousarray(f.numpy())
+    assert tuple(g["feat/shape"]) == a.shape == (2, 768, 16, 7, 7)
+    assert np.abs(a.reshape(-1)[g["feat/idx"]] - g["feat/val"]).max() <= 5e-4
+    assert abs(float(l) - float(g["loss"])) <= 1e-4
+
+
+def test_ksvqe_state_dict_surface():
+    """VQA_Network(key KSVQE): the reference's state_dict keys and shapes (synthetic weights load strictly, buffers aside)."""
+    from kvq_amd.models import VQA_Network
+    net = VQA_Network({"model": {"args": {"KSVQE": {"backbone": dict(num_samples=1, sample_type="topkpertubation", CLIP_location=8,
+                                                                       cls_use=True, tuning_stage=2, frozen_stages=-1),
+                                                      "head": {"in_channels": 768, "hidden_channels": 64}}}}})
+    sd = net.KSVQE_backbone.state_dict()
+    w = synth.synth_ksvqe_weights(3)
+    assert set(w) <= set(sd) and all("relative_position_index" in k for k in set(sd) - set(w)), sorted(set(sd) ^ set(w))[:8]
+    for k, v in w.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
