@@ -69,6 +69,16 @@ class Trainer:
                 nc = int(data.get("num_clips", {}).get(key, 1)) if isinstance(data.get("num_clips"), dict) else 1
                 data[key] = (x.reshape(b, c, nc, t // nc, h, w).permute(0, 2, 1, 3, 4, 5)
                              .reshape(b * nc, c, t // nc, h, w).contiguous())
+        if self.config["model"]["type"] == "KSVQE":
+            # the DataLoader of the reference adds the batch dimension (batch_size 1) and the whole T-frame sample goes to
+            # KSVQE as ONE clip (trainer.py:306-326): resize_video / fragment (1, 3, T, h, w), dis_label (1,)
+            for k in ("resize_video", "fragment"):
+                v = data[k].to(self.device)
+                data[k] = v.unsqueeze(0) if v.dim() == 4 else v
+            data["dis_label"] = torch.as_tensor(data["dis_label"]).reshape(-1).to(self.device)
+            with torch.no_grad():
+                pred, _ = self.model(inputs=data, reduce_scores=True)       # (scores, distortion contrastive loss)
+            return pred
         with torch.no_grad():
             return self.model(inputs=data, reduce_scores=True)
 
