@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 9
+#define KVQ_ABI_VERSION 10
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -422,6 +422,8 @@ int kvq_axpby(const float* x, const float* y, float a, float b, float* out, long
  * 16-bit activation x (B, D, H, W, C), C % 8 == 0 — no patch matrix.  W [N][Kpad], columns ordered (kd,kh,kw,c) like
  * kvq_im2col_nd and zero padded to Kpad (a multiple of 32).  taps: device int32 [Kpad/8][4], one row per 8-channel
  * chunk of K: {kd, kh, kw, ((kd*H + kh)*W + kw)*C + c0}, last entry -1 for chunks of the K padding (depends on H, W, C).
+ * The table defines K: taps that only ever read the zero border (3x3 / pad 1 on a 1x1 map: eight of nine) may be left out
+ * of it together with their columns of W — Kpad is 8 x the table's rows, not necessarily >= kd*kh*kw*C.
  * Output rows = output pixels (b, do, ho, wo), i.e. channels-last again.  epilogue: KVQ_EPI_RELU_BF16 | KVQ_EPI_BIAS_BF16 |
  * KVQ_EPI_STORE_F32 (out_f32 [M][N] = acc + bias: the projection shortcuts, kept in fp32). */
 typedef struct {
@@ -446,6 +448,11 @@ int kvq_conv_implicit(const KvqConvArgs* host_args, void* stream);
 int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_t strides5[5], const int32_t dims5[5],
                   const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int Kpad,
                   uint16_t* out, void* stream);
+/* The 3-channel network input as an implicit-GEMM operand (stem conv 7x7/2 of ResNet-50, simpleVQA_model.py:220-223 /
+ * torchvision resnet50 inside CONTRIQUE_model, KSVQE_model.py:1630): fp32 frames addressed through ELEMENT strides5 =
+ * {b,t,c,h,w} over dims5 = {B,T,C,H,W} (C <= 8) -> 16-bit channels-last (B*T, H, W, 8), channels >= C zero. */
+int kvq_pack_channels_last8(const float* x, const int32_t dims5[5], const int64_t strides5[5], int dtype, uint16_t* out,
+                            void* stream);
 /* Direct Conv3d for the few-output-channel stems (SlowFast fast pathway: 3 -> 8, k 5x7x7, SlowFast_features.py:140):
  * x fp32 (B,C,D,H,W) contiguous, w fp32 [K][cout] with K ordered (kd,kh,kw,c), bias fp32 [cout] (BatchNorm folded),
  * cout in {8,16}; out 16-bit channels-last (B,Do,Ho,Wo,cout).  fp32 arithmetic; no patch matrix is materialised. */

@@ -106,6 +106,62 @@ __global__ __launch_bounds__(256) void pool_nd_kernel(PoolParams p) {
   }
 }
 
+// fp32 frames addressed through element strides (b, t, c, h, w) -> 16-bit channels-last (B*T, H, W, 8), channels >= C zero:
+// the operand layout the implicit-GEMM conv wants for the 3-channel network input (one 16-byte chunk per pixel).
+template <typename E>
+__global__ __launch_bounds__(256) void pack_cl8_kernel(const float* __restrict__ x, int T, int Cc, int H, int W, long sb, long st,
+                                                       long sc, long sh, long sw, uint16_t* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int w = (int)(i % W);
+  long r = i / W;
+  const int h = (int)(r % H);
+  const long n = r / H;
+  const float* src = x + (n / T) * sb + (n % T) * st + (long)h * sh + (long)w * sw;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = c < Cc ? src[c * sc] : 0.f;
+  *reinterpret_cast<u32x4*>(out + i * 8) = (u32x4){E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4], v[5]), E::pack2(v[6], v[7])};
+}
+
+// C % 8 == 0: a thread owns 8 channels of an output position (16-byte loads / stores; same fp32 arithmetic and order)
+template <typename E>
+__global__ __launch_bounds__(256) void pool_nd_vec8_kernel(PoolParams p) {
+  const int C8 = p.C / 8;
+  const long total = (long)p.B * p.Do * p.Ho * p.Wo * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8) * 8;
+    long r = i / C8;
+    const int wo = (int)(r % p.Wo); r /= p.Wo;
+    const int ho = (int)(r % p.Ho); r /= p.Ho;
+    const int dO = (int)(r % p.Do);
+    const int b = (int)(r / p.Do);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = p.is_max ? -INFINITY : 0.f;
+    for (int kd = 0; kd < p.kd; ++kd)
+      for (int kh = 0; kh < p.kh; ++kh)
+        for (int kw = 0; kw < p.kw; ++kw) {
+          const int d = dO * p.sdd - p.pd + kd, h = ho * p.shh - p.ph + kh, w = wo * p.sww - p.pw + kw;
+          if (d < 0 || d >= p.D || h < 0 || h >= p.H || w < 0 || w >= p.W) continue;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + ((((size_t)b * p.D + d) * p.H + h) * p.W + w) * p.C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = E::to_f32((uint16_t)(v[e] & 0xffffu)), hi = E::to_f32((uint16_t)(v[e] >> 16));
+            acc[2 * e] = p.is_max ? fmaxf(acc[2 * e], lo) : acc[2 * e] + lo;
+            acc[2 * e + 1] = p.is_max ? fmaxf(acc[2 * e + 1], hi) : acc[2 * e + 1] + hi;
+          }
+        }
+    const float cnt = (float)(p.kd * p.kh * p.kw);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = p.is_max ? E::pack2(acc[2 * e], acc[2 * e + 1])
+                      : E::pack2(acc[2 * e] / cnt, acc[2 * e + 1] / cnt);
+    *reinterpret_cast<u32x4*>(p.out + i * 8) = o;
+  }
+}
+
 // SimpleVQA pooling (simpleVQA_model.py:8-11, 242-252): per (frame, channel) mean and UNBIASED std over
 // the H*W positions of a channels-last map; two passes in fp32.  grid (rows, ceil(C/64)), block 256 =
 // 64 channels x 4 position groups.
@@ -260,11 +316,40 @@ extern "C" int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5],
   p.Ho = (p.H + 2 * p.ph - p.kh) / p.shh + 1;
   p.Wo = (p.W + 2 * p.pw - p.kw) / p.sww + 1;
   KVQ_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0, KVQ_ERR_SHAPE, "kvq_pool_nd: empty output");
+  if (p.C % 8 == 0 && (((size_t)p.x | (size_t)p.out) & 15) == 0) {
+    const long tot8 = (long)p.B * p.Do * p.Ho * p.Wo * (p.C / 8);
+    const int g8 = (int)((tot8 + 255) / 256 < 131072 ? (tot8 + 255) / 256 : 131072);
+    if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(pool_nd_vec8_kernel<Fp16>, dim3(g8), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(pool_nd_vec8_kernel<Bf16>, dim3(g8), dim3(256), 0, (hipStream_t)stream, p);
+    KVQ_CHECK_LAUNCH("pool_nd_vec8_kernel");
+    return KVQ_OK;
+  }
   const long total = (long)p.B * p.Do * p.Ho * p.Wo * p.C;
   const int grid = (int)((total + 255) / 256 < 131072 ? (total + 255) / 256 : 131072);
   if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(pool_nd_kernel<Fp16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(pool_nd_kernel<Bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   KVQ_CHECK_LAUNCH("pool_nd_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_pack_channels_last8(const float* x, const int32_t dims5[5], const int64_t strides5[5], int dtype, uint16_t* out,
+                                       void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && dims5 && strides5 && out, KVQ_ERR_NULL, "kvq_pack_channels_last8: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_pack_channels_last8: dtype %d", dtype);
+  const int B = dims5[0], T = dims5[1], Cc = dims5[2], H = dims5[3], W = dims5[4];
+  KVQ_REQUIRE(B > 0 && T > 0 && Cc > 0 && Cc <= 8 && H > 0 && W > 0, KVQ_ERR_SHAPE,
+              "kvq_pack_channels_last8: bad shape B=%d T=%d C=%d (1..8) H=%d W=%d", B, T, Cc, H, W);
+  KVQ_REQUIRE(((size_t)out & 15) == 0, KVQ_ERR_SHAPE, "kvq_pack_channels_last8: out must be 16-byte aligned");
+  const long total = (long)B * T * H * W;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == KVQ_DT_FP16)
+    hipLaunchKernelGGL(pack_cl8_kernel<Fp16>, grid, block, 0, (hipStream_t)stream, x, T, Cc, H, W, (long)strides5[0], (long)strides5[1],
+                       (long)strides5[2], (long)strides5[3], (long)strides5[4], out, total);
+  else
+    hipLaunchKernelGGL(pack_cl8_kernel<Bf16>, grid, block, 0, (hipStream_t)stream, x, T, Cc, H, W, (long)strides5[0], (long)strides5[1],
+                       (long)strides5[2], (long)strides5[3], (long)strides5[4], out, total);
+  KVQ_CHECK_LAUNCH("pack_cl8_kernel");
   return KVQ_OK;
 }
 

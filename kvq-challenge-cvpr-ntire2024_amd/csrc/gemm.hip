@@ -509,9 +509,10 @@ extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
   const int Do = (D + 2 * a->pad3[0] - a->kernel3[0]) / a->stride3[0] + 1;
   const int Ho = (H + 2 * a->pad3[1] - a->kernel3[1]) / a->stride3[1] + 1;
   const int Wo = (W + 2 * a->pad3[2] - a->kernel3[2]) / a->stride3[2] + 1;
-  const long K = (long)a->kernel3[0] * a->kernel3[1] * a->kernel3[2] * Cin;
-  KVQ_REQUIRE(Do > 0 && Ho > 0 && Wo > 0 && a->Kpad >= K && a->Kpad % 32 == 0 && a->N > 0 && a->N % 8 == 0, KVQ_ERR_SHAPE,
-              "kvq_conv_implicit: Kpad=%d (K=%ld) must be a multiple of 32, N=%d a multiple of 8", a->Kpad, K, a->N);
+  // Kpad = 8 x the rows of the tap table.  Normally >= kd*kh*kw*C; a caller may leave out taps that fall into the padding for
+  // EVERY output position (3x3 / pad 1 on a 1x1 map: the centre tap only) together with the matching columns of W.
+  KVQ_REQUIRE(Do > 0 && Ho > 0 && Wo > 0 && a->Kpad >= 32 && a->Kpad % 32 == 0 && a->N > 0 && a->N % 8 == 0, KVQ_ERR_SHAPE,
+              "kvq_conv_implicit: Kpad=%d must be a positive multiple of 32, N=%d a multiple of 8", a->Kpad, a->N);
   KVQ_REQUIRE((long)B * D * H * W * Cin < (1L << 31) && (long)B * Do * Ho * Wo < (1L << 31), KVQ_ERR_SHAPE,
               "kvq_conv_implicit: tensor too large for 32-bit tap offsets");
   KVQ_REQUIRE(a->epilogue == KVQ_EPI_RELU_BF16 || a->epilogue == KVQ_EPI_BIAS_BF16 || a->epilogue == KVQ_EPI_STORE_F32,

@@ -3,6 +3,7 @@
 // the GEMMs (patch embedding, in_proj, out_proj, c_fc + QuickGELU, c_proj, the CLS adapters) and the LayerNorms are the
 // trunk's kernels (gemm.hip, ln.hip); what is left is token assembly, a short-sequence multi-head attention, the CLS
 // adapter mix and the cosine map.  All HBM-trivial: written for clarity, fp32 arithmetic throughout.
+#include <algorithm>
 #include "common.hpp"
 
 namespace kvq {
@@ -40,8 +41,9 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restri
 // Short-sequence multi-head attention, head_dim HD: out[b][i][h*HD..] = softmax_j(scale * q_i . k_j) v_j over the Lk keys of
 // batch element b.  q / k / v are 16-bit row-major with their own row strides (the packed in_proj output of
 // nn.MultiheadAttention is q = qkv, k = qkv + D, v = qkv + 2D with stride 3D; a cross-attention passes separate tensors).
-// One workgroup per (batch element, head): K and V of the head in LDS (16-bit), a thread owns a query and runs the online
-// softmax over the keys in fp32 (K / V rows are LDS broadcasts).
+// One workgroup per (batch element, head) of 64 * ceil(min(Lq, 256) / 64) threads: K and V of the head in LDS (16-bit), a
+// thread owns a query and runs the online softmax over the keys in fp32 (K / V rows are LDS broadcasts).  The launches are
+// latency-bound (197 queries x 197 keys per head): four waves cover the queries of a CLIP frame in one pass.
 struct MhaParams {
   const uint16_t *q, *k, *v;
   long ldq, ldk, ldv;          // row strides in elements
@@ -50,37 +52,90 @@ struct MhaParams {
   uint16_t* out;               // [B*Lq][heads*HD]
 };
 
+// a.lo * b.lo + a.hi * b.hi + c on packed 16-bit pairs, fp32 accumulate
+template <typename E>
+__device__ __forceinline__ float mha_dot2(uint32_t a, uint32_t b, float c);
+template <>
+__device__ __forceinline__ float mha_dot2<Fp16>(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+}
+template <>
+__device__ __forceinline__ float mha_dot2<Bf16>(uint32_t a, uint32_t b, float c) {
+  return fmaf(__uint_as_float(a << 16), __uint_as_float(b << 16), fmaf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u), c));
+}
+
 template <typename E, int HD>
-__global__ __launch_bounds__(64) void mha_small_kernel(MhaParams p) {
+__global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
   uint16_t* Vs = Ks + (size_t)p.Lk * HD;
   const int h = blockIdx.x % p.heads, b = blockIdx.x / p.heads, tid = threadIdx.x, D = p.heads * HD;
   const uint16_t* kb = p.k + (size_t)b * p.Lk * p.ldk + h * HD;
   const uint16_t* vb = p.v + (size_t)b * p.Lk * p.ldv + h * HD;
-  for (int i = tid; i < p.Lk * (HD / 8); i += 64) {
+  const int nthr = blockDim.x;
+  for (int i = tid; i < p.Lk * (HD / 8); i += nthr) {
     const int r = i / (HD / 8), c = i % (HD / 8);
     *reinterpret_cast<u32x4*>(Ks + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(kb + (size_t)r * p.ldk + c * 8);
     *reinterpret_cast<u32x4*>(Vs + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(vb + (size_t)r * p.ldv + c * 8);
   }
   __syncthreads();
   const uint16_t* qb = p.q + (size_t)b * p.Lq * p.ldq + h * HD;
-  for (int l = tid; l < p.Lq; l += 64) {
-    float q[HD], o[HD];
+  // The loop is issue-bound (LDS instructions first, VALU second), so: 16-byte LDS reads of the K / V rows (a broadcast each),
+  // q kept as packed 16-bit pairs and multiplied by v_dot2 (fp16) without conversions, the logit scale applied to the fp32
+  // dot, and the online-softmax rescale of the 64 accumulators done once per 8 keys instead of once per key.
+  for (int l = tid; l < p.Lq; l += nthr) {
+    uint32_t qp[HD / 2];
+    float o[HD];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-      q[c] = E::to_f32(qb[(size_t)l * p.ldq + c]) * p.scale;
-      o[c] = 0.f;
+    for (int c8 = 0; c8 < HD / 8; ++c8) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(qb + (size_t)l * p.ldq + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qp[c8 * 4 + e] = t[e];
     }
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = 0.f;
     float mx = -INFINITY, sum = 0.f;
-    for (int j = 0; j < p.Lk; ++j) {
-      float s = 0.f;
+    for (int j0 = 0; j0 < p.Lk; j0 += 8) {
+      float sc[8];
 #pragma unroll
-      for (int c = 0; c < HD; ++c) s = fmaf(q[c], E::to_f32(Ks[j * HD + c]), s);
-      const float nm = fmaxf(mx, s), corr = __expf(mx - nm), pj = __expf(s - nm);
-      sum = sum * corr + pj;
+      for (int jj = 0; jj < 8; ++jj) {
+        float acc = 0.f;
+        if (j0 + jj < p.Lk) {
+          const uint16_t* kr = Ks + (j0 + jj) * HD;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) o[c] = fmaf(pj, E::to_f32(Vs[j * HD + c]), o[c] * corr);
+          for (int c8 = 0; c8 < HD / 8; ++c8) {
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(kr + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mha_dot2<E>(qp[c8 * 4 + e], kv[e], acc);
+          }
+          sc[jj] = acc * p.scale;
+        } else {
+          sc[jj] = -INFINITY;
+        }
+      }
+      float nm = mx;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) nm = fmaxf(nm, sc[jj]);
+      const float corr = __expf(mx - nm);
+      sum *= corr;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] *= corr;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        if (j0 + jj >= p.Lk) break;
+        const float pj = __expf(sc[jj] - nm);
+        sum += pj;
+        const uint16_t* vr = Vs + (j0 + jj) * HD;
+#pragma unroll
+        for (int c8 = 0; c8 < HD / 8; ++c8) {
+          const u32x4 vv = *reinterpret_cast<const u32x4*>(vr + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[c8 * 8 + 2 * e] = fmaf(pj, E::to_f32((uint16_t)(vv[e] & 0xffffu)), o[c8 * 8 + 2 * e]);
+            o[c8 * 8 + 2 * e + 1] = fmaf(pj, E::to_f32((uint16_t)(vv[e] >> 16)), o[c8 * 8 + 2 * e + 1]);
+          }
+        }
+      }
       mx = nm;
     }
     const float inv = 1.f / sum;
@@ -156,7 +211,7 @@ extern "C" int kvq_mha_cross(const uint16_t* q, long ldq, const uint16_t* k, lon
   KVQ_REQUIRE((((size_t)k | (size_t)v) & 15) == 0, KVQ_ERR_SHAPE, "kvq_mha_cross: k / v must be 16-byte aligned");
   MhaParams p{q, k, v, ldq, ldk, ldv, Lq, Lk, heads, scale, out};
   const size_t lds = (size_t)2 * Lk * 64 * sizeof(uint16_t);
-  dim3 grid((unsigned)(B * heads)), block(64);
+  dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * std::min(4, (Lq + 63) / 64)));
   if (dtype == KVQ_DT_FP16) {
     auto kern = mha_small_kernel<Fp16, 64>;
     if (lds > 64 * 1024) KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -207,6 +207,19 @@ def im2col_nd(x: torch.Tensor, dims5, strides5, kernel, stride, pad, out_dtype, 
     return out, (Do, Ho, Wo)
 
 
+def pack_channels_last8(x: torch.Tensor, dims5, strides5, out_dtype):
+    """fp32 frames addressed through ELEMENT strides5 = (b,t,c,h,w) over dims5 = (B,T,C,H,W), C <= 8 -> 16-bit channels-last
+    (B*T, H, W, 8) with the channels >= C zero (the implicit-GEMM operand of a stem conv)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32
+    B, T, Cc, H, W = dims5
+    out = torch.empty(B * T, H, W, 8, dtype=out_dtype, device=x.device)
+    st = (C.c_int64 * 5)(*[int(s) for s in strides5])
+    check(lib().kvq_pack_channels_last8(ptr(x), C.byref(_i32x(dims5)), C.byref(st), dtype_code(out_dtype), ptr(out),
+                                        current_stream()), "kvq_pack_channels_last8")
+    return out
+
+
 def pool_nd(x: torch.Tensor, kernel, stride, pad, is_max: bool):
     """x (B,D,H,W,C) channels-last 16-bit, contiguous."""
     _need_gpu(x)
@@ -392,19 +405,44 @@ def cosine_cls(x: torch.Tensor):
 _TAPS = {}
 
 
-def conv_taps(kernel, Cc: int, H: int, W: int, k_pad: int, device):
+def live_taps(size, kernel, stride, pad):
+    """Per axis, the kernel offsets that touch the image for at least one output position (the others only ever read
+    padding): 3x3 / pad 1 on a 1x1 map keeps the centre tap, 3x3 / stride 2 / pad 1 on 2x2 keeps offsets {1, 2}."""
+    out = []
+    for n, k, s, p in zip(size, kernel, stride, pad):
+        no = (n + 2 * p - k) // s + 1
+        out.append([a for a in range(k) if any(0 <= o * s - p + a < n for o in range(no))])
+    return out
+
+
+def prune_conv_weight(W: torch.Tensor, kernel, Cc: int, live):
+    """Columns of a (kd,kh,kw,c)-ordered [N][Kpad] conv weight that belong to the ``live`` taps, zero-padded to a multiple of 32."""
+    kd, kh, kw = kernel
+    n = W.shape[0]
+    w = W[:, :kd * kh * kw * Cc].reshape(n, kd, kh, kw, Cc)
+    idx = [torch.as_tensor(l, device=W.device) for l in live]
+    w = w.index_select(1, idx[0]).index_select(2, idx[1]).index_select(3, idx[2]).reshape(n, -1)
+    k = w.shape[1]
+    out = torch.zeros(n, (k + 31) // 32 * 32, dtype=W.dtype, device=W.device)
+    out[:, :k] = w
+    return out
+
+
+def conv_taps(kernel, Cc: int, H: int, W: int, k_pad: int, device, live=None):
     """Tap table of ``kvq_conv_implicit``: int32 [k_pad/8][4], one row per 8-channel chunk of the (kd,kh,kw,c)-ordered
-    K axis: {kd, kh, kw, ((kd*H + kh)*W + kw)*C + c0}; -1 in the last column marks the zero padding of K."""
-    key = (tuple(kernel), Cc, H, W, k_pad, str(device))
+    K axis: {kd, kh, kw, ((kd*H + kh)*W + kw)*C + c0}; -1 in the last column marks the zero padding of K.  ``live``:
+    per-axis lists of the kernel offsets kept (``live_taps``), in which case K only spans those taps."""
+    key = (tuple(kernel), Cc, H, W, k_pad, str(device), None if live is None else tuple(map(tuple, live)))
     t = _TAPS.get(key)
     if t is None:
         import numpy as np
         kd, kh, kw = kernel
+        la, lb, lc = live if live is not None else (range(kd), range(kh), range(kw))
         rows = np.full((k_pad // 8, 4), -1, np.int32)
         q = 0
-        for a in range(kd):
-            for b in range(kh):
-                for c in range(kw):
+        for a in la:
+            for b in lb:
+                for c in lc:
                     for c0 in range(0, Cc, 8):
                         rows[q] = (a, b, c, ((a * H + b) * W + c) * Cc + c0)
                         q += 1
@@ -414,10 +452,11 @@ def conv_taps(kernel, Cc: int, H: int, W: int, k_pad: int, device):
 
 
 def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, relu: bool, resid=None, resid_f32=None,
-                  want_f32=False, store_f32=False):
+                  want_f32=False, store_f32=False, live=None):
     """Conv (+ folded BN, + identity, + ReLU) on a channels-last 16-bit activation x (B, D, H, W, C), C % 8 == 0, without a
     patch matrix: W [N][Kpad] with the (kd,kh,kw,c) column order of ``im2col_nd``.  Returns the (B, Do, Ho, Wo, N) 16-bit
-    output, or (output, fp32 copy [M][N]) when ``want_f32``; ``store_f32``: only the fp32 [M][N] result (no ReLU)."""
+    output, or (output, fp32 copy [M][N]) when ``want_f32``; ``store_f32``: only the fp32 [M][N] result (no ReLU).
+    ``live`` (``live_taps``): W holds the columns of those taps only (``prune_conv_weight``)."""
     _need_gpu(x, W, bias, resid, resid_f32)
     assert x.dtype in HALF_TYPES and x.is_contiguous() and x.dim() == 5 and W.dtype == x.dtype and W.is_contiguous()
     B, D, H, Wd, Cc = x.shape
@@ -430,7 +469,7 @@ def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, r
     out32 = torch.empty(M, N, dtype=torch.float32, device=x.device) if (want_f32 or store_f32) else None
     assert relu or (resid is None and resid_f32 is None and not want_f32), "identity add / fp32 copy: ReLU epilogue only"
     a = _abi.KvqConvArgs()
-    a.x, a.W, a.bias, a.taps = ptr(x), ptr(W), ptr(bias), ptr(conv_taps(kernel, Cc, H, Wd, k_pad, x.device))
+    a.x, a.W, a.bias, a.taps = ptr(x), ptr(W), ptr(bias), ptr(conv_taps(kernel, Cc, H, Wd, k_pad, x.device, live))
     a.dims5[:] = (B, Cc, D, H, Wd)
     a.kernel3[:], a.stride3[:], a.pad3[:] = tuple(kernel), tuple(stride), tuple(pad)
     a.Kpad, a.N = k_pad, N

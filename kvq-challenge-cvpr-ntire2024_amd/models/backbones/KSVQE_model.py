@@ -88,6 +88,16 @@ class KSVQE(SwinTransformer3D):
             self._acache = (sig, {id(m): (f(m[0]), f(m[2])) for m in mods})
         return self._acache[1]
 
+    def _mix_coeffs(self):
+        """(a1, a2) of every tuned stage as host floats, re-read only when the parameters change (no device sync per forward)."""
+        sig = ((self.a1.data_ptr(), self.a1._version), (self.a2.data_ptr(), self.a2._version))
+        c = self.__dict__.get("_mixc")
+        if c is None or c[0] != sig:
+            a1, a2 = self.a1.detach().cpu().reshape(-1).tolist(), self.a2.detach().cpu().reshape(-1).tolist()
+            c = (sig, list(zip(a1, a2)))
+            self.__dict__["_mixc"] = c
+        return c[1]
+
     def _run_adapter(self, mod, rows16):
         (w0, b0), (w2, b2) = self._adapters(rows16.device)[id(mod)]
         return kernels.conv_gemm(kernels.conv_gemm(rows16, w0, b0, True), w2, b2, True)
@@ -161,6 +171,6 @@ class KSVQE(SwinTransformer3D):
         d_enh = self.distortion_self[k](d_enh)
         d_enh = d_enh.reshape(n, hw, tt, c).permute(0, 3, 2, 1).reshape(n, c, tt, hh, ww)
         x_d = self.distortion_mod[k](d_enh, rows.reshape(n, tt * hw, c))                      # (n, t' hw, c)
-        a1, a2 = float(self.a1[k]), float(self.a2[k])
+        a1, a2 = self._mix_coeffs()[k]
         out = kernels.axpby(x_d.reshape(-1, c).contiguous(), x_s, a1 / 2.0, a2 / 2.0)
         return out.reshape(n, tt, hh, ww, c).permute(0, 4, 1, 2, 3)

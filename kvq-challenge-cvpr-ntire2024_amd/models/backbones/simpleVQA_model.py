@@ -94,6 +94,12 @@ class ResNet(nn.Module):
             return self._wcache[1]
         half = _abi.torch_dtype(self.operand_dtype)
         w = {"stem": _fold(self.conv1, self.bn1, half, device)}
+        # the same stem weight for the channel-padded implicit conv: (kh,kw,c<3) columns spread to (kh,kw,8), K 392 -> 416
+        ws = w["stem"][0][:, :147].reshape(64, 49, 3)
+        w8 = torch.zeros(64, 416, dtype=ws.dtype, device=device)
+        w8[:, :392].view(64, 49, 8)[:, :, :3] = ws
+        w["stem8"] = w8
+        self.__dict__["_pruned"] = {}
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
             for bi, blk in enumerate(layer):
                 k = f"l{li}.{bi}."
@@ -118,8 +124,21 @@ class ResNet(nn.Module):
     def _conv_relu(self, x, wb, k, stride, pad):
         n, h, w_, c = x.shape
         if IMPLICIT_CONV and not (k == 1 and stride == 1) and c % 8 == 0 and x.is_contiguous():
-            # implicit GEMM: the A tiles are fetched from the activation itself (no patch matrix)
-            y = kernels.conv_implicit(x.reshape(n, 1, h, w_, c), wb[0], wb[1], (1, k, k), (1, stride, stride), (0, pad, pad), True)
+            # implicit GEMM: the A tiles are fetched from the activation itself (no patch matrix).  On tiny maps (CONTRIQUE's
+            # 32x32 patches reach 2x2 and 1x1) most taps of a padded 3x3 only ever read zeros: drop them from K.
+            live, wk = None, wb[0]
+            if k > 1 and min(h, w_) < k and os.environ.get("KVQ_PRUNE_TAPS", "1") != "0":
+                live = kernels.live_taps((1, h, w_), (1, k, k), (1, stride, stride), (0, pad, pad))
+                if len(live[1]) * len(live[2]) < k * k:
+                    cache = self.__dict__.setdefault("_pruned", {})
+                    ck = (wb[0].data_ptr(), wb[0]._version, h, w_, stride)
+                    if ck not in cache:
+                        cache[ck] = kernels.prune_conv_weight(wb[0], (1, k, k), c, live)
+                    wk = cache[ck]
+                else:
+                    live = None
+            y = kernels.conv_implicit(x.reshape(n, 1, h, w_, c), wk, wb[1], (1, k, k), (1, stride, stride), (0, pad, pad), True,
+                                      live=live)
             return y.reshape(n, y.shape[2], y.shape[3], wb[0].shape[0])
         a, (ho, wo) = self._cols(x, k, stride, pad, wb[0].shape[1])
         return kernels.conv_gemm(a, wb[0], wb[1], True).reshape(x.shape[0], ho, wo, wb[0].shape[0])
@@ -157,9 +176,7 @@ class ResNet(nn.Module):
         half = _abi.torch_dtype(self.operand_dtype)
         n = b * T
         # stem 7x7/2 reads the fp32 (b,c,T,h,w) input directly: frame index = (b, t) through the strides
-        wt, bias = w["stem"]
-        a, (_, ho, wo) = self._stem_im2col(x, half, wt.shape[1])
-        y = kernels.conv_gemm(a, wt, bias, True).reshape(n, ho, wo, 64)
+        y = self._stem(x, (b, T, c, h1, w1), (c * T * h1 * w1, h1 * w1, T * h1 * w1, w1, 1), w, half)
         y = kernels.pool_nd(y.unsqueeze(1), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).squeeze(1)        # maxpool 3x3/2
         out = torch.empty(n, 7168 + feat3d.shape[1], dtype=torch.float32, device=x.device)
         off = 0
@@ -183,16 +200,30 @@ class ResNet(nn.Module):
         n, c, h, w_ = x.shape
         w = self._weights(x.device)
         half = _abi.torch_dtype(self.operand_dtype)
-        wt, bias = w["stem"]
-        a, (_, ho, wo) = kernels.im2col_nd(x, (n, c, 1, h, w_), (c * h * w_, h * w_, 0, w_, 1), (1, 7, 7), (1, 2, 2), (0, 3, 3),
-                                           half, wt.shape[1])
-        y = kernels.conv_gemm(a, wt, bias, True).reshape(n, ho, wo, 64)
+        y = self._stem(x, (n, 1, c, h, w_), (c * h * w_, 0, h * w_, w_, 1), w, half)
         y = kernels.pool_nd(y.unsqueeze(1), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).squeeze(1)        # maxpool 3x3/2
         y32 = None
         for li, layer_mod in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
             for bi, blk in enumerate(layer_mod):
                 y, y32 = self._bottleneck(y, y32, w, f"l{li}.{bi}.", blk)
         return y, y32
+
+    def _stem(self, x, dims5, strides5, w, half):
+        """conv1 7x7/2 + bn1 + ReLU on the fp32 input, frames addressed as (b, t) through element strides (b,t,c,h,w):
+        -> 16-bit channels-last (b*t, ho, wo, 64).  Implicit GEMM over the input packed to 8 channels (no patch matrix: the
+        147-column im2col of a 224x224 frame is 12x the frame), or the materialised im2col with KVQ_IMPLICIT_CONV=0."""
+        B, T, c, h, w_ = dims5
+        if IMPLICIT_CONV and c <= 8 and os.environ.get("KVQ_STEM_IMPLICIT", "1") != "0":
+            x8 = kernels.pack_channels_last8(x, dims5, strides5, half)
+            y = kernels.conv_implicit(x8.reshape(B * T, 1, h, w_, 8), w["stem8"], w["stem"][1], (1, 7, 7), (1, 2, 2), (0, 3, 3), True)
+            return y.reshape(B * T, y.shape[2], y.shape[3], 64)
+        wt, bias = w["stem"]
+        if T == 1:
+            a, (_, ho, wo) = kernels.im2col_nd(x, (B, c, 1, h, w_), (strides5[0], strides5[2], 0, strides5[3], strides5[4]), (1, 7, 7),
+                                               (1, 2, 2), (0, 3, 3), half, wt.shape[1])
+        else:
+            a, (_, ho, wo) = self._stem_im2col(x, half, wt.shape[1])
+        return kernels.conv_gemm(a, wt, bias, True).reshape(B * T, ho, wo, 64)
 
     @staticmethod
     def _stem_im2col(x, half, kpad):

@@ -120,3 +120,62 @@ def test_simplevqa_network_vs_reference_golden(golden, case):
     assert rel <= 5e-3, rel                                  # 53 conv layers on fp16 operands, fp32 accumulate
     assert np.array_equal(f[..., 7168:], f_ref[..., 7168:])  # the SlowFast features pass through untouched
     assert np.abs(score.cpu().numpy() - s_ref).max() <= 1e-3, (score, s_ref)
+
+
+@gpu
+@pytest.mark.parametrize("C", [40, 6])          # C % 8 == 0: the 8-channel-per-thread kernel; 6: the scalar one
+def test_pool_vector_and_scalar_paths_agree_with_torch(C):
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(40 + C))
+    x = torch.from_numpy(g.standard_normal((3, 2, 9, 11, C)).astype(np.float32)).half()
+    mp = kernels.pool_nd(x.cuda(), (1, 3, 3), (1, 2, 2), (0, 1, 1), True).float().cpu()
+    ref = torch.nn.functional.max_pool3d(x.float().permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1)).permute(0, 2, 3, 4, 1)
+    assert torch.equal(mp, ref)                                                      # max of fp16 values: exact
+    ap = kernels.pool_nd(x.cuda(), (2, 3, 3), (1, 2, 2), (0, 0, 0), False).float().cpu()
+    ref = torch.nn.functional.avg_pool3d(x.float().permute(0, 4, 1, 2, 3), (2, 3, 3), (1, 2, 2)).permute(0, 2, 3, 4, 1)
+    assert torch.equal(ap, ref.half().float()) or (ap - ref).abs().max().item() <= 1e-3
+
+
+@gpu
+def test_pack_channels_last8_strided_frames():
+    """(b, c, T, h, w) fp32 -> (b*T, h, w, 8) 16-bit, frame index = (b, t) through the strides, channels 3..7 zero: bit-exact."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(8))
+    b, c, T, h, w = 2, 3, 3, 10, 13
+    x = torch.from_numpy(g.standard_normal((b, c, T, h, w)).astype(np.float32))
+    out = kernels.pack_channels_last8(x.cuda(), (b, T, c, h, w), (c * T * h * w, h * w, T * h * w, w, 1), torch.float16).cpu()
+    ref = torch.zeros(b * T, h, w, 8, dtype=torch.float16)
+    ref[..., :3] = x.permute(0, 2, 3, 4, 1).reshape(b * T, h, w, 3).half()
+    assert torch.equal(out, ref)
+    with pytest.raises(Exception, match="C=9"):
+        kernels.pack_channels_last8(torch.zeros(1, 9, 1, 4, 4).cuda(), (1, 1, 9, 4, 4), (144, 0, 16, 4, 1), torch.float16)
+
+
+@gpu
+@pytest.mark.parametrize("hw,stride", [((1, 1), 1), ((2, 2), 2), ((2, 1), 1), ((3, 3), 1)])
+def test_conv_implicit_with_pruned_taps_equals_full_conv(hw, stride):
+    """Dropping the taps that only ever read the zero border (live_taps / prune_conv_weight) leaves the conv unchanged: same
+    products, in the same order, minus exact zeros -> bit-identical to the full tap table whenever K stays slice-aligned,
+    and equal to F.conv2d of the rounded operands within fp32 accumulation noise otherwise."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(sum(hw) + stride))
+    n, c, cout = 70, 64, 32
+    x = torch.from_numpy(g.standard_normal((n, 1) + hw + (c,)).astype(np.float32)).half()
+    w5 = torch.from_numpy((g.standard_normal((cout, c, 3, 3)) / 24).astype(np.float32)).half()
+    wk = w5.permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous()
+    bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+    live = kernels.live_taps((1,) + hw, (1, 3, 3), (1, stride, stride), (0, 1, 1))
+    if hw == (1, 1):
+        assert live == [[0], [1], [1]]
+    if hw == (2, 2) and stride == 2:
+        assert live == [[0], [1, 2], [1, 2]]
+    if hw == (3, 3):
+        assert live == [[0], [0, 1, 2], [0, 1, 2]]
+    wp = kernels.prune_conv_weight(wk.cuda(), (1, 3, 3), c, live)
+    assert wp.shape[1] == len(live[1]) * len(live[2]) * c
+    full = kernels.conv_implicit(x.cuda(), wk.cuda(), bias.cuda(), (1, 3, 3), (1, stride, stride), (0, 1, 1), True)
+    got = kernels.conv_implicit(x.cuda(), wp, bias.cuda(), (1, 3, 3), (1, stride, stride), (0, 1, 1), True, live=live)
+    ref = torch.relu(torch.nn.functional.conv2d(x.float()[:, 0].permute(0, 3, 1, 2), w5.float(), bias, stride, 1)).permute(0, 2, 3, 1)
+    assert got.shape == full.shape
+    assert (got.float().cpu()[:, 0] - ref).abs().max().item() <= 4e-3
+    assert (got.float() - full.float()).abs().max().item() <= 2e-3

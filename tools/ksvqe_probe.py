@@ -1,0 +1,55 @@
+"""KSVQE (f1) forward timing on one MI355X: ms per forward at B samples of 32 frames, with a per-section breakdown
+(CLIP_tool / QRS / CONTRIQUE / trunk stages / CDM) from HIP events.  `python tools/ksvqe_probe.py [B] [iters]`."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import kvq_amd  # noqa
+from kvq_amd.models import VQA_Network
+from kvq_amd.models.backbones import ksvqe_modules as KM
+from kvq_amd.utils import synth
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+IT = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+cfg = {"model": {"type": "KSVQE", "args": {"KSVQE": {"backbone": dict(checkpoint=True, pretrained=None, num_samples=1, sample_type="topkpertubation",
+       CLIP_location=8, cls_use=True, tuning_stage=2, qls_swin=True, frozen3D=False, frozen_stages=-1),
+       "head": {"in_channels": 768, "hidden_channels": 64}}}}}
+net = VQA_Network(cfg)
+sd = {"KSVQE_backbone." + k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_weights(3).items()}
+sd.update({"KSVQE_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_head_weights(768, 64, 3, "stress").items()})
+net.load_state_dict(sd, strict=False)
+net = net.cuda().eval()
+inp = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_ksvqe_inputs(1, B, 32).items()}
+
+def run():
+    with torch.no_grad():
+        return net(inputs=dict(inp), reduce_scores=True)
+
+for _ in range(3):
+    s, _ = run()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(IT):
+    s, _ = run()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / IT
+print(f"B={B} forward {dt*1e3:.2f} ms  -> {B/dt:.1f} samples/s (32-frame sample, 1 clip)", s.flatten().tolist()[:2])
+
+# section breakdown: wrap the submodules with event timers
+bb = net.KSVQE_backbone
+ev = []
+def timed(name, fn):
+    def w(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(*a, **k); e1.record(); ev.append((name, e0, e1)); return r
+    return w
+bb.CLIP_tool.forward = timed("clip", bb.CLIP_tool.forward)
+bb.spa_patchnet.forward = timed("qrs", bb.spa_patchnet.forward)
+bb.distortion_tool.forward = timed("contrique", bb.distortion_tool.forward)
+bb.forward_stages = timed("trunk", bb.forward_stages)
+bb._modulate = timed("cdm", bb._modulate)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+tot = {}
+for n, a, b in ev:
+    tot[n] = tot.get(n, 0) + a.elapsed_time(b)
+print("sections ms:", {k: round(v, 3) for k, v in tot.items()}, "total", round(e0.elapsed_time(e1), 3))
