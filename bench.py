@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on (independent batches: the VALU-bound attention of one "
                          "can overlap the MFMA-bound GEMMs of another, launch gaps and tails are filled)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("KVQ_BENCH_GRAPH", "0")),
+                    help="1: capture one step per stream in a hipGraph (static inputs, resident in HBM) and replay it")
     ap.add_argument("--profile-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -129,7 +131,39 @@ def main():
             main.wait_stream(st)
         return torch.cat(outs)
 
+    graphs = []
+
+    def capture():
+        """one hipGraph per lane: the lane's stream runs two eager steps (plans, workspaces, caches), then records a third"""
+        lanes = [torch.cuda.current_stream()] + side if by_step else [torch.cuda.current_stream()]
+        for st in lanes:
+            cap = torch.cuda.Stream(device=device) if st == torch.cuda.current_stream() else st   # capture needs a side stream
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                for _ in range(2):
+                    net(inputs=inputs, reduce_scores=True)
+            cap.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                o = net(inputs=inputs, reduce_scores=True).reshape(-1)
+            graphs.append((g, o, cap))
+        torch.cuda.synchronize()
+
+    def run_graphs(n, out):
+        main = torch.cuda.current_stream()
+        for _, _, st in graphs:
+            st.wait_stream(main)
+        for s in range(n):
+            g, o, st = graphs[s % len(graphs)]
+            with torch.cuda.stream(st):
+                g.replay()
+                out[s].copy_(o, non_blocking=True)
+        for _, _, st in graphs:
+            main.wait_stream(st)
+
     def run_steps(n, out):
+        if graphs:
+            return run_graphs(n, out)
         if not by_step:
             for s in range(n):
                 out[s] = forward()
@@ -152,6 +186,8 @@ def main():
                 net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
         torch.cuda.synchronize()
     with torch.no_grad():
+        if args.graph:
+            capture()
         run_steps(args.warmup, torch.zeros(max(args.warmup, 1), B, device=device))
         torch.cuda.synchronize()
         kd.barrier()
@@ -218,7 +254,8 @@ def main():
             "config": {"workload": "C2: KSVQE Swin3D-T(GRPB) trunk + VQAHead, 3x32x224x224 clips, video = 8 clips",
                        "clips_per_gpu_per_step": B, "operand_dtype": args.dtype, "accumulate": "fp32",
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
-                       "streams": nstream, "overlap": args.overlap if nstream > 1 else "none"},
+                       "streams": nstream, "overlap": args.overlap if nstream > 1 else "none",
+                       "hipgraph": bool(args.graph)},
             "clips_per_s": clips / dt,
             "model_tflops": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3,
             "score_checksum": float(allscores.double().sum().item()),

@@ -1,0 +1,64 @@
+"""hipGraph replay of a whole per-video forward.
+
+The per-video forwards of the harness are launch-bound when the batch is one video: KSVQE enqueues ~360 kernels for ~4 ms
+of GPU work and the Python / ctypes enqueue costs ~6 ms, so the GPU idles (tools/ksvqe_probe.py: 168 -> 296 samples/s at
+one sample per forward with replay).  ``LaneGraphs`` records one forward per (HIP stream "lane", input signature) into a
+hipGraph — static input buffers, the forward's temporaries in the graph's private pool — and replays it for every later
+video of that signature; lanes replay concurrently, like the eager streams of ``Trainer._score_all``.
+
+What makes a forward capturable here: no host synchronisation inside it (host-cached scalars, device-side index logic),
+per-stream plans / workspaces / weight images created by the two eager warm-up runs on the lane's stream, and every kernel
+of ``libkvq_hip.so`` launched on the caller's stream handle.  Nothing else changes: the same kernels run, in the same order,
+on the same data — the scores are bit-identical to the eager path (tests/test_gpu_harness.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Tuple
+
+import torch
+
+
+def _signature(inputs: Dict[str, torch.Tensor]) -> Tuple:
+    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(inputs.items()))
+
+
+class LaneGraphs:
+    def __init__(self, fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], lanes: List[torch.cuda.Stream], max_signatures: int = 4,
+                 warmup: int = 2):
+        """fn(inputs) -> device tensor, inputs a dict of device tensors; ``lanes``: side streams (capture cannot run on the
+        default stream).  At most ``max_signatures`` input signatures are recorded per lane; further ones run eagerly."""
+        self.fn, self.lanes, self.max_signatures, self.warmup = fn, lanes, max_signatures, warmup
+        self._graphs: List[Dict[Tuple, Tuple]] = [dict() for _ in lanes]
+        self.replays = self.eager_runs = 0
+
+    def _record(self, lane: int, sig: Tuple, inputs: Dict[str, torch.Tensor]):
+        st = self.lanes[lane]
+        with torch.cuda.stream(st):
+            static = {k: v.clone() for k, v in inputs.items()}
+            for _ in range(self.warmup):                       # plans, workspaces, weight images, tap tables: created eagerly
+                self.fn(dict(static))
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            out = self.fn(dict(static))
+        self._graphs[lane][sig] = (g, static, out)
+
+    def run(self, lane: int, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Enqueue fn(inputs) on lane's stream.  The returned tensor is the graph's static output: consume it on the same
+        stream before the lane's next ``run`` (stream order makes that safe without host synchronisation)."""
+        sig = _signature(inputs)
+        rec = self._graphs[lane].get(sig)
+        if rec is None:
+            if len(self._graphs[lane]) >= self.max_signatures:
+                self.eager_runs += 1
+                with torch.cuda.stream(self.lanes[lane]):
+                    return self.fn(inputs)
+            self._record(lane, sig, inputs)
+            rec = self._graphs[lane][sig]
+        g, static, out = rec
+        with torch.cuda.stream(self.lanes[lane]):
+            for k, v in inputs.items():
+                static[k].copy_(v, non_blocking=True)
+            g.replay()
+        self.replays += 1
+        return out

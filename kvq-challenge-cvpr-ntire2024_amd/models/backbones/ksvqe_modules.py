@@ -138,7 +138,8 @@ def obtain_keyframes(x):
     the frames 0, t/4-1, t/2-1, 3t/4-1; a frame's group id counts how many of the last three positions are <= its index."""
     b, c, t, h, w = x.shape
     pos = [0, t // 4 - 1, t // 2 - 1, t * 3 // 4 - 1]
-    key = x.permute(0, 2, 1, 3, 4)[:, pos]
+    xt = x.permute(0, 2, 1, 3, 4)
+    key = torch.stack([xt[:, p] for p in pos], 1)          # slices, not a host index list: no H2D copy (hipGraph-capturable)
     j = torch.arange(t, device=x.device)
     gid = sum((j >= p).to(x.dtype) for p in dict.fromkeys(pos[1:]))      # equal positions (tiny t) bump once, as the elif chain does
     return gid.unsqueeze(0).expand(b, t).contiguous(), key

@@ -55,8 +55,9 @@ class Trainer:
             else cls(cfg["args"], None)
 
     # ------------------------------------------------------------------------------------------
-    def _forward_video(self, data):
-        """clip reshape (trainer.py:306-319) + model forward (:320-327) -> device tensor of clip scores."""
+    def _model_inputs(self, data):
+        """clip reshape of the dataset item (trainer.py:306-319) -> dict of DEVICE tensors, the model's inputs."""
+        inputs = {}
         for key in list(data):
             if key in self.key_list or key == "technical":
                 x = data[key]
@@ -67,20 +68,29 @@ class Trainer:
                     x = x.unsqueeze(0)
                 b, c, t, h, w = x.shape
                 nc = int(data.get("num_clips", {}).get(key, 1)) if isinstance(data.get("num_clips"), dict) else 1
-                data[key] = (x.reshape(b, c, nc, t // nc, h, w).permute(0, 2, 1, 3, 4, 5)
-                             .reshape(b * nc, c, t // nc, h, w).contiguous())
+                inputs[key] = (x.reshape(b, c, nc, t // nc, h, w).permute(0, 2, 1, 3, 4, 5)
+                               .reshape(b * nc, c, t // nc, h, w).contiguous())
         if self.config["model"]["type"] == "KSVQE":
             # the DataLoader of the reference adds the batch dimension (batch_size 1) and the whole T-frame sample goes to
             # KSVQE as ONE clip (trainer.py:306-326): resize_video / fragment (1, 3, T, h, w), dis_label (1,)
             for k in ("resize_video", "fragment"):
                 v = data[k].to(self.device)
-                data[k] = v.unsqueeze(0) if v.dim() == 4 else v
-            data["dis_label"] = torch.as_tensor(data["dis_label"]).reshape(-1).to(self.device)
-            with torch.no_grad():
-                pred, _ = self.model(inputs=data, reduce_scores=True)       # (scores, distortion contrastive loss)
-            return pred
+                inputs[k] = v.unsqueeze(0) if v.dim() == 4 else v
+            inputs["dis_label"] = torch.as_tensor(data["dis_label"]).reshape(-1).to(self.device)
+        elif "feat" in data and torch.is_tensor(data["feat"]):
+            inputs["feat"] = data["feat"].to(self.device)
+        return inputs
+
+    def _run_model(self, inputs):
+        """model forward (trainer.py:320-327) -> device tensor of clip scores."""
         with torch.no_grad():
-            return self.model(inputs=data, reduce_scores=True)
+            if self.config["model"]["type"] == "KSVQE":
+                pred, _ = self.model(inputs=inputs, reduce_scores=True)       # (scores, distortion contrastive loss)
+                return pred
+            return self.model(inputs=inputs, reduce_scores=True)
+
+    def _forward_video(self, data):
+        return self._run_model(self._model_inputs(data))
 
     def _score_all(self):
         n = len(self.val_dataset)
@@ -90,6 +100,27 @@ class Trainer:
         # that one video's latency-bound launches fill the gaps of another's; nothing synchronises with the host per video
         nstream = max(1, int(self.config.get("streams", os.environ.get("KVQ_STREAMS", 3))))
         main = torch.cuda.current_stream(self.device)
+        # hipGraph replay of the per-video forward (kvq_amd/graph.py): default for KSVQE, whose ~360 launches per video
+        # are enqueue-bound; KVQ_GRAPH=1 / 0 forces it on / off for any model
+        want = str(self.config.get("hipgraph", os.environ.get("KVQ_GRAPH", "auto"))).lower()
+        use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] == "KSVQE")
+        if use_graph:
+            from .graph import LaneGraphs
+            lanes = [torch.cuda.Stream(device=self.device) for _ in range(nstream)]
+            graphs = LaneGraphs(self._run_model, lanes)
+            for st in lanes:
+                st.wait_stream(main)
+            for j, i in enumerate(mine):
+                inputs = self._model_inputs(self.val_dataset[i])
+                lane = j % nstream
+                lanes[lane].wait_stream(main)                      # the H2D copies of the inputs ran on the main stream
+                pred = graphs.run(lane, inputs)
+                with torch.cuda.stream(lanes[lane]):
+                    local[j] = pred.float().mean()
+            for st in lanes:
+                main.wait_stream(st)
+            self.graph_stats = (graphs.replays, graphs.eager_runs)
+            return kd.gather_scores(local, n, self.rank, self.world).cpu().numpy()
         lanes = [main] + [torch.cuda.Stream(device=self.device) for _ in range(nstream - 1)]
         for st in lanes[1:]:
             st.wait_stream(main)

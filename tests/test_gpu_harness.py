@@ -264,3 +264,41 @@ def test_cli_with_reference_style_ksvqe_config(tmp_path):
         s1, _ = net(inputs=dict(inp), reduce_scores=True)
         s2, _ = net(inputs=dict(inp), reduce_scores=True)
     assert s1.shape == (1, 1) and torch.equal(s1, s2) and torch.isfinite(s1).all()
+
+
+@pytest.mark.parametrize("kind", ["swin_tiny_grpb", "KSVQE"])
+def test_hipgraph_replay_is_bit_identical_to_eager(kind):
+    """kvq_amd/graph.py: the per-video forward recorded into a hipGraph per lane and replayed on new inputs gives the eager
+    path's scores bit for bit (same kernels, same order), on two lanes, with one recording per lane and signature."""
+    from kvq_amd.graph import LaneGraphs
+    from kvq_amd.models import VQA_Network
+    if kind == "KSVQE":
+        net = VQA_Network({"model": {"type": "KSVQE", "args": {"KSVQE": {"backbone": dict(CLIP_location=8, tuning_stage=2, num_samples=1, sample_type="topkpertubation", cls_use=True),
+                                                                          "head": {"in_channels": 768, "hidden_channels": 64}}}}})
+        sd = {"KSVQE_backbone." + k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_weights(3).items()}
+        sd.update({"KSVQE_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_head_weights(768, 64, 3, "stress").items()})
+        assert not net.load_state_dict(sd, strict=False).unexpected_keys
+        ins = [{k: torch.from_numpy(v).cuda() for k, v in synth.synth_ksvqe_inputs(s, 1, 32).items()} for s in (1, 2)]
+        fn = lambda d: net(inputs=dict(d), reduce_scores=True)[0]
+    else:
+        net = VQA_Network({"model": {"args": {kind: {"head": {"in_channels": 768, "hidden_channels": 64}}}}})
+        sd = {f"{kind}_backbone." + k: torch.from_numpy(v) for k, v in synth.synth_swin_weights(synth.SWIN_T_GRPB, 3, "stress").items()}
+        sd.update({f"{kind}_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_head_weights(768, 64, 3, "stress").items()})
+        net.load_state_dict(sd, strict=False)
+        ins = [{"technical": torch.from_numpy(synth.synth_clip(s, 32, 224, 224, batch=2)).cuda()} for s in (1, 2)]
+        fn = lambda d: net(inputs=dict(d), reduce_scores=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        eager = [fn(d).clone() for d in ins]
+        lanes = [torch.cuda.Stream() for _ in range(2)]
+        lg = LaneGraphs(lambda d: fn(d), lanes)
+        got = []
+        for lane, j in ((0, 0), (1, 1), (0, 1), (1, 0), (0, 0)):
+            out = lg.run(lane, ins[j])
+            with torch.cuda.stream(lanes[lane]):
+                got.append((j, out.clone()))
+        torch.cuda.synchronize()
+    assert not torch.equal(eager[0], eager[1])
+    for j, o in got:
+        assert torch.equal(o, eager[j]), (j, o, eager[j])
+    assert lg.replays == 5 and lg.eager_runs == 0 and all(len(g) == 1 for g in lg._graphs)

@@ -34,6 +34,54 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / IT
 print(f"B={B} forward {dt*1e3:.2f} ms  -> {B/dt:.1f} samples/s (32-frame sample, 1 clip)", s.flatten().tolist()[:2])
 
+# whole forwards of consecutive batches on alternating HIP streams (what Trainer._score_all does with KVQ_STREAMS=3)
+NS = int(os.environ.get("KVQ_STREAMS", "3"))
+if NS > 1:
+    lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NS - 1)]
+    def many(n):
+        main = lanes[0]
+        for st in lanes[1:]:
+            st.wait_stream(main)
+        outs = []
+        for i in range(n):
+            with torch.cuda.stream(lanes[i % NS]):
+                outs.append(run()[0])
+        for st in lanes[1:]:
+            main.wait_stream(st)
+        return outs
+    many(2 * NS); torch.cuda.synchronize()
+    t0 = time.perf_counter(); o = many(4 * IT); torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / (4 * IT)
+    print(f"B={B} x {NS} streams: {dt2*1e3:.2f} ms per forward -> {B/dt2:.1f} samples/s; same scores: {torch.equal(o[0], s) and torch.equal(o[-1], s)}")
+
+# hipGraph replay: capture one forward per lane (static inputs), replay lanes round-robin
+if os.environ.get("KSVQE_GRAPH", "1") != "0":
+    lanes = [torch.cuda.Stream() for _ in range(max(NS, 1))]
+    graphs = []
+    for st in lanes:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            static = {k: v.clone() for k, v in inp.items()}
+            for _ in range(2):
+                with torch.no_grad():
+                    net(inputs=dict(static), reduce_scores=True)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            with torch.no_grad():
+                out = net(inputs=dict(static), reduce_scores=True)[0]
+        graphs.append((g, static, out))
+    torch.cuda.synchronize()
+    def replay(n):
+        for i in range(n):
+            g, _, _ = graphs[i % len(lanes)]
+            with torch.cuda.stream(lanes[i % len(lanes)]):
+                g.replay()
+    replay(2 * len(lanes)); torch.cuda.synchronize()
+    t0 = time.perf_counter(); replay(4 * IT); torch.cuda.synchronize()
+    dt3 = (time.perf_counter() - t0) / (4 * IT)
+    print(f"B={B} hipGraph x {len(lanes)} lanes: {dt3*1e3:.2f} ms per forward -> {B/dt3:.1f} samples/s; same scores: {all(torch.equal(o, s) for _, _, o in graphs)}")
+
 # section breakdown: wrap the submodules with event timers
 bb = net.KSVQE_backbone
 ev = []
