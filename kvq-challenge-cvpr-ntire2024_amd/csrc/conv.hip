@@ -165,32 +165,48 @@ __global__ __launch_bounds__(256) void pool_nd_vec8_kernel(PoolParams p) {
 // SimpleVQA pooling (simpleVQA_model.py:8-11, 242-252): per (frame, channel) mean and UNBIASED std over
 // the H*W positions of a channels-last map; two passes in fp32.  grid (rows, ceil(C/64)), block 256 =
 // 64 channels x 4 position groups.
-template <typename E>
+template <typename E, int CH>
 __global__ __launch_bounds__(256) void mean_std_pool_kernel(const uint16_t* __restrict__ x, int HW, int C,
                                                             float* __restrict__ out, long out_stride, int mean_off,
                                                             int std_off) {
-  __shared__ float red[4][64];
-  const int row = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  // CH channels x GR = 256 / CH position groups per block: CH = 64 for many rows (one frame each), CH = 16 when a few rows
+  // pool over thousands of positions (KSVQE's Dist_Transformation3: 4 rows x 3136) and the grid would not fill the chip
+  constexpr int GR = 256 / CH;
+  __shared__ float red[GR][CH];
+  const int cl = threadIdx.x % CH, grp = threadIdx.x / CH;
+  const int row = blockIdx.x, c = blockIdx.y * CH + cl;
   const bool live = c < C;
   const uint16_t* xr = x + (size_t)row * HW * C;
   float s = 0.f;
   if (live)
-    for (int i = grp; i < HW; i += 4) s += E::to_f32(xr[(size_t)i * C + c]);
-  red[grp][threadIdx.x & 63] = s;
+    for (int i = grp; i < HW; i += GR) s += E::to_f32(xr[(size_t)i * C + c]);
+  red[grp][cl] = s;
   __syncthreads();
-  const float mean = ((red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63]) +
-                      (red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63])) / (float)HW;
+  float tot = 0.f;
+  if (GR == 4) {
+    tot = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  } else {
+#pragma unroll
+    for (int g = 0; g < GR; ++g) tot += red[g][cl];
+  }
+  const float mean = tot / (float)HW;
   __syncthreads();
   float q = 0.f;
   if (live)
-    for (int i = grp; i < HW; i += 4) {
+    for (int i = grp; i < HW; i += GR) {
       const float d = E::to_f32(xr[(size_t)i * C + c]) - mean;
       q += d * d;
     }
-  red[grp][threadIdx.x & 63] = q;
+  red[grp][cl] = q;
   __syncthreads();
   if (grp == 0 && live) {
-    const float ss = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float ss = 0.f;
+    if (GR == 4) {
+      ss = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < GR; ++g) ss += red[g][cl];
+    }
     out[(size_t)row * out_stride + mean_off + c] = mean;
     if (std_off >= 0) out[(size_t)row * out_stride + std_off + c] = sqrtf(ss / (float)(HW - 1));
   }
@@ -359,13 +375,16 @@ extern "C" int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW,
   KVQ_REQUIRE(x && out, KVQ_ERR_NULL, "kvq_mean_std_pool: NULL pointer");
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mean_std_pool: dtype %d", dtype);
   KVQ_REQUIRE(rows > 0 && HW > 0 && C > 0 && (std_off < 0 || HW > 1), KVQ_ERR_SHAPE, "kvq_mean_std_pool: bad shape");
-  dim3 grid(rows, ceil_div(C, 64));
-  if (dtype == KVQ_DT_FP16)
-    hipLaunchKernelGGL(mean_std_pool_kernel<Fp16>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, out,
-                       (long)out_stride, mean_off, std_off);
-  else
-    hipLaunchKernelGGL(mean_std_pool_kernel<Bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, HW, C, out,
-                       (long)out_stride, mean_off, std_off);
+  const bool narrow = (long)rows * ceil_div(C, 64) < 128 && HW >= 256;
+  dim3 grid(rows, ceil_div(C, narrow ? 16 : 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == KVQ_DT_FP16) {
+    if (narrow) hipLaunchKernelGGL((mean_std_pool_kernel<Fp16, 16>), grid, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
+    else hipLaunchKernelGGL((mean_std_pool_kernel<Fp16, 64>), grid, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
+  } else {
+    if (narrow) hipLaunchKernelGGL((mean_std_pool_kernel<Bf16, 16>), grid, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
+    else hipLaunchKernelGGL((mean_std_pool_kernel<Bf16, 64>), grid, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
+  }
   KVQ_CHECK_LAUNCH("mean_std_pool_kernel");
   return KVQ_OK;
 }

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
   uint16_t* Vs = Ks + (size_t)p.Lk * HD;
+  float* part = reinterpret_cast<float*>(Vs + (size_t)p.Lk * HD);       // key-split partials: [ks-1][qwv*64][HD+2]
   const int h = blockIdx.x % p.heads, b = blockIdx.x / p.heads, tid = threadIdx.x, D = p.heads * HD;
   const uint16_t* kb = p.k + (size_t)b * p.Lk * p.ldk + h * HD;
   const uint16_t* vb = p.v + (size_t)b * p.Lk * p.ldv + h * HD;
@@ -79,28 +80,39 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
     *reinterpret_cast<u32x4*>(Vs + r * HD + c * 8) = *reinterpret_cast<const u32x4*>(vb + (size_t)r * p.ldv + c * 8);
   }
   __syncthreads();
+  // Four waves per (batch element, head).  Up to 64 queries: one query per lane and the KEYS split over the four waves (a
+  // CLIP frame at 112x112 has 50 tokens: a single wave walking 50 keys is pure latency), partial (max, sum, o) merged through
+  // LDS; up to 128: two query waves x two key halves; more: the waves take 64 queries each and walk all keys.
+  const int nw = nthr >> 6, wave = tid >> 6, lane = tid & 63;
+  const int ks = p.Lq <= 64 ? nw : (p.Lq <= 128 && nw >= 2 ? nw / 2 : 1);      // key splits
+  const int qwv = nw / ks, qstride = qwv * 64;
+  const int kpart = wave / qwv, kper = (p.Lk + ks - 1) / ks;
+  const int k_lo = kpart * kper, k_hi = min(p.Lk, k_lo + kper);
   const uint16_t* qb = p.q + (size_t)b * p.Lq * p.ldq + h * HD;
   // The loop is issue-bound (LDS instructions first, VALU second), so: 16-byte LDS reads of the K / V rows (a broadcast each),
   // q kept as packed 16-bit pairs and multiplied by v_dot2 (fp16) without conversions, the logit scale applied to the fp32
   // dot, and the online-softmax rescale of the 64 accumulators done once per 8 keys instead of once per key.
-  for (int l = tid; l < p.Lq; l += nthr) {
+  for (int l0 = (wave % qwv) * 64; l0 < p.Lq; l0 += qstride) {
+    const int l = l0 + lane;
+    const bool live = l < p.Lq;
+    const int lq = live ? l : p.Lq - 1;
     uint32_t qp[HD / 2];
     float o[HD];
 #pragma unroll
     for (int c8 = 0; c8 < HD / 8; ++c8) {
-      const u32x4 t = *reinterpret_cast<const u32x4*>(qb + (size_t)l * p.ldq + c8 * 8);
+      const u32x4 t = *reinterpret_cast<const u32x4*>(qb + (size_t)lq * p.ldq + c8 * 8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) qp[c8 * 4 + e] = t[e];
     }
 #pragma unroll
     for (int c = 0; c < HD; ++c) o[c] = 0.f;
     float mx = -INFINITY, sum = 0.f;
-    for (int j0 = 0; j0 < p.Lk; j0 += 8) {
+    for (int j0 = k_lo; j0 < k_hi; j0 += 8) {
       float sc[8];
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         float acc = 0.f;
-        if (j0 + jj < p.Lk) {
+        if (j0 + jj < k_hi) {
           const uint16_t* kr = Ks + (j0 + jj) * HD;
 #pragma unroll
           for (int c8 = 0; c8 < HD / 8; ++c8) {
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
       for (int c = 0; c < HD; ++c) o[c] *= corr;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        if (j0 + jj >= p.Lk) break;
+        if (j0 + jj >= k_hi) break;
         const float pj = __expf(sc[jj] - nm);
         sum += pj;
         const uint16_t* vr = Vs + (j0 + jj) * HD;
@@ -138,6 +150,31 @@ __global__ __launch_bounds__(256) void mha_small_kernel(MhaParams p) {
       }
       mx = nm;
     }
+    if (ks > 1) {           // one pass of the query loop in this mode (qstride >= Lq): the barrier is uniform
+      float* mine = part + ((size_t)(kpart > 0 ? kpart - 1 : 0) * qstride + (wave % qwv) * 64 + lane) * (HD + 2);
+      if (kpart > 0) {
+        mine[0] = mx;
+        mine[1] = sum;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) mine[2 + c] = o[c];
+      }
+      __syncthreads();
+      if (kpart > 0) continue;
+      float M = mx;
+      for (int s = 0; s < ks - 1; ++s) M = fmaxf(M, part[((size_t)s * qstride + (wave % qwv) * 64 + lane) * (HD + 2)]);
+      const float c0 = __expf(mx - M);        // a part without keys carries (-inf, 0, 0): weight exp(-inf) = 0
+      sum *= c0;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] *= c0;
+      for (int s = 0; s < ks - 1; ++s) {
+        const float* pr = part + ((size_t)s * qstride + (wave % qwv) * 64 + lane) * (HD + 2);
+        const float cs = __expf(pr[0] - M);
+        sum = fmaf(pr[1], cs, sum);
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = fmaf(pr[2 + c], cs, o[c]);
+      }
+    }
+    if (!live) continue;
     const float inv = 1.f / sum;
     uint16_t* dst = p.out + ((size_t)b * p.Lq + l) * D + h * HD;
 #pragma unroll
@@ -210,8 +247,9 @@ extern "C" int kvq_mha_cross(const uint16_t* q, long ldq, const uint16_t* k, lon
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mha_cross: dtype %d", dtype);
   KVQ_REQUIRE((((size_t)k | (size_t)v) & 15) == 0, KVQ_ERR_SHAPE, "kvq_mha_cross: k / v must be 16-byte aligned");
   MhaParams p{q, k, v, ldq, ldk, ldv, Lq, Lk, heads, scale, out};
-  const size_t lds = (size_t)2 * Lk * 64 * sizeof(uint16_t);
-  dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * std::min(4, (Lq + 63) / 64)));
+  // K + V of the head (16-bit) + the key-split partials of Lq <= 128 (three parts x 64 queries, or one x 128)
+  const size_t lds = (size_t)2 * Lk * 64 * sizeof(uint16_t) + (Lq <= 64 ? 3 * 64 : (Lq <= 128 ? 128 : 0)) * (size_t)(64 + 2) * sizeof(float);
+  dim3 grid((unsigned)(B * heads)), block(256);
   if (dtype == KVQ_DT_FP16) {
     auto kern = mha_small_kernel<Fp16, 64>;
     if (lds > 64 * 1024) KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

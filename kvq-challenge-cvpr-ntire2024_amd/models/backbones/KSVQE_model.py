@@ -55,6 +55,7 @@ class KSVQE(SwinTransformer3D):
         self.spa_patchnet = KM.RegionNet_CLIP(k=7 * 7, anchor_size=32, stride=1, num_samples=num_samples, sample_type=sample_type)
         self.sigma_max = self.sigma = 0.5
         self.tuning_stage = tuning_stage
+        self.aux_loss = True
         self.semantic_adapter, self.distortion_adapter = nn.ModuleList(), nn.ModuleList()
         self.semantic_mod, self.distortion_mod = nn.ModuleList(), nn.ModuleList()
         self.semantic_cross, self.distortion_cross, self.distortion_self = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
@@ -134,7 +135,9 @@ class KSVQE(SwinTransformer3D):
         dist = self.distortion_tool(x_sel_ori[:, :, ::2].contiguous())                       # (b, t/2, 49, 128) fp32
         d16 = kernels.to_half(dist.reshape(-1, dist.shape[-1]).contiguous(), half)
         dist = kernels.axpby(kernels.to_float(self._run_adapter(self.dist_adapter, d16)).reshape(dist.shape), dist, 0.2, 0.8)
-        loss = distortion_contrastive_supervised(dist, dis_label)
+        # the auxiliary loss (second return value): the inference loop discards it (trainer.py:323-327), so the harness
+        # switches it off (``aux_loss = False`` -> None is returned in its place); on by default, like the reference
+        loss = distortion_contrastive_supervised(dist, dis_label) if self.aux_loss else None
         geom = tuple(x_sel_ori.shape[2:])
         n_st = self.num_layers
         x_sel = self.forward_stages(x_sel_ori, 0, min(self.tuning_stage, n_st) - 1) if self.tuning_stage > 0 else x_sel_ori

@@ -56,18 +56,19 @@ class VQA_Network(nn.Module):  # noqa: N801  (reference spelling)
 
     def forward(self, inputs, targets=None, inference=True, return_pooled_feats=False, reduce_scores=False,
                 pooled=False, clip_return=False, **kwargs):
-        scores, feats, dis_contra_loss = [], {}, None
+        scores, feats, dis_contra_loss, with_loss = [], {}, None, False
         for key in self.key_names:
             feat = getattr(self, key + "_backbone")(inputs, multi=self.multi, layer=self.layer, **kwargs)
             if key == "KSVQE":                                   # (features, distortion contrastive loss) (model.py:93-96)
-                feat, dis_contra_loss = feat
+                feat, dis_contra_loss = feat                     # loss is None when the backbone's aux_loss is off
+                with_loss = True
             scores += [getattr(self, key + "_head")(feat)]
             if return_pooled_feats:
                 feats[key] = feat
         if reduce_scores:
             scores = reduce(lambda a, b: a + b, scores) if len(scores) > 1 else scores[0]
         if return_pooled_feats:
-            return (scores, feats, dis_contra_loss) if dis_contra_loss is not None else (scores, feats)
-        if dis_contra_loss is not None:
+            return (scores, feats, dis_contra_loss) if with_loss else (scores, feats)
+        if with_loss:
             return scores, dis_contra_loss
         return scores

@@ -93,6 +93,9 @@ class Trainer:
         return self._run_model(self._model_inputs(data))
 
     def _score_all(self):
+        bb = getattr(self.model, "KSVQE_backbone", None)
+        if bb is not None:
+            bb.aux_loss = False                    # `pred, _ = model(...)`: the contrastive loss is never read at inference
         n = len(self.val_dataset)
         mine = kd.shard_indices(n, self.rank, self.world)
         local = torch.empty(len(mine), dtype=torch.float32, device=self.device)

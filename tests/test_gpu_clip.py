@@ -130,7 +130,7 @@ def test_cdm_modules_vs_reference_golden(golden, dtype):
         mods["sem"](torch.zeros(1, 768, 7, 7), torch.zeros(1, 768, 7, 7))
 
 
-@pytest.mark.parametrize("B,Lq,Lk,heads", [(4, 49, 49, 12), (3, 16, 16, 12), (2, 100, 7, 3)])
+@pytest.mark.parametrize("B,Lq,Lk,heads", [(4, 49, 49, 12), (3, 16, 16, 12), (2, 100, 7, 3), (1, 64, 2, 2), (2, 128, 130, 1), (1, 129, 320, 1)])
 def test_mha_cross_strided(B, Lq, Lk, heads):
     g = torch.Generator().manual_seed(Lq * 100 + Lk)
     D = heads * 64

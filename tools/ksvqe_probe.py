@@ -18,6 +18,7 @@ sd = {"KSVQE_backbone." + k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_w
 sd.update({"KSVQE_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_head_weights(768, 64, 3, "stress").items()})
 net.load_state_dict(sd, strict=False)
 net = net.cuda().eval()
+net.KSVQE_backbone.aux_loss = os.environ.get("KSVQE_AUX_LOSS", "0") == "1"      # the harness discards the loss (Trainer._score_all)
 inp = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_ksvqe_inputs(1, B, 32).items()}
 
 def run():
