@@ -20,6 +20,9 @@ from __future__ import annotations
 import random as _pyrandom
 from typing import Optional
 
+import os
+import threading
+
 import numpy as np
 import torch
 
@@ -234,6 +237,10 @@ class NpyFrameReader:
     def __getitem__(self, i):
         return np.asarray(self.frames[int(i)])
 
+    def read_into(self, indices, out):
+        """frames[indices] -> out (len(indices), H, W, 3) uint8, one copy straight from the mapped file"""
+        np.take(self.frames, np.asarray(indices, np.int64), axis=0, out=out)
+
 
 def open_video(path):
     """Frame reader for ``path``: ``<path>`` itself or ``<path>.npy`` as a frame stack, else decord.VideoReader
@@ -251,18 +258,73 @@ def open_video(path):
     return VideoReader(path)
 
 
+class _Staging:
+    """Reusable PINNED host buffers for the frames of one video (two per thread, alternating: the H2D copy of one video
+    overlaps the host-side gather of the next; a buffer is rewritten only after its copy's event has completed)."""
+    _local = threading.local()
+
+    @classmethod
+    def get(cls, nbytes):
+        st = cls._local.__dict__.setdefault("slots", {"i": 0, "buf": [None, None], "ev": [None, None]})
+        k = st["i"] = 1 - st["i"]
+        if st["buf"][k] is None or st["buf"][k].numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8)
+            st["buf"][k] = buf.pin_memory() if torch.cuda.is_available() else buf
+        elif st["ev"][k] is not None:
+            st["ev"][k].synchronize()
+        return st, k
+
+
+_COPY_POOL = None
+
+
+def _frames_to_device(vr, uniq, device):
+    """The sampled frames ``uniq`` of a reader -> ONE uint8 (n, H, W, 3) device tensor: gathered into pinned staging memory
+    by a few host threads (numpy copies release the GIL), then a single asynchronous H2D copy on the current stream."""
+    global _COPY_POOL
+    first = vr[int(uniq[0])]
+    first = first.asnumpy() if hasattr(first, "asnumpy") else np.asarray(first)
+    n, shape = len(uniq), tuple(first.shape)
+    nbytes = n * int(np.prod(shape))
+    st, k = _Staging.get(nbytes)
+    stage = st["buf"][k][:nbytes].view((n,) + shape)
+    host = stage.numpy()
+    if hasattr(vr, "read_into"):
+        if _COPY_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _COPY_POOL = ThreadPoolExecutor(max_workers=int(os.environ.get("KVQ_COPY_THREADS", 4)), thread_name_prefix="kvq-copy")
+        nt = max(1, min(_COPY_POOL._max_workers, n // 8))
+        bounds = np.linspace(0, n, nt + 1).astype(int)
+        jobs = [_COPY_POOL.submit(vr.read_into, uniq[a:b], host[a:b]) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+        for j in jobs:
+            j.result()
+    elif hasattr(vr, "get_batch"):                      # decord: one decode call for all frames
+        host[...] = vr.get_batch([int(i) for i in uniq]).asnumpy()
+    else:
+        host[0] = first
+        for j in range(1, n):
+            f = vr[int(uniq[j])]
+            host[j] = f.asnumpy() if hasattr(f, "asnumpy") else np.asarray(f)
+    dev = stage.to(device, non_blocking=True)
+    if dev.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev.device))
+        st["ev"][k] = ev
+    return dev
+
+
 def _sampled_clips(path, samplers, is_train, device):
-    """Reference ``spatial_temporal_view_decomposition`` (:376-397), decode half: one reader, every frame fetched once,
-    per view a uint8 (3, T, H, W) tensor on the device + the sampled indices."""
+    """Reference ``spatial_temporal_view_decomposition`` (:376-397), decode half: one reader, every frame fetched once and
+    sent to the device once, as uint8; per view a uint8 (3, T, H, W) device tensor (frame gather + layout change in HBM) +
+    the sampled indices."""
     vr = open_video(path)
     frame_inds = {k: s(len(vr), is_train) for k, s in samplers.items()}
     uniq = np.unique(np.concatenate(list(frame_inds.values()), 0))
-    cache = {}
-    for idx in uniq:
-        f = vr[int(idx)]
-        cache[int(idx)] = torch.from_numpy(f.asnumpy() if hasattr(f, "asnumpy") else np.array(f))
-    video = {k: torch.stack([cache[int(i)] for i in inds], 0).permute(3, 0, 1, 2).contiguous().to(device)
-             for k, inds in frame_inds.items()}
+    frames = _frames_to_device(vr, uniq, device)                               # (n, H, W, 3) uint8
+    video = {}
+    for k, inds in frame_inds.items():
+        pos = torch.from_numpy(np.searchsorted(uniq, inds).astype(np.int64)).to(frames.device)
+        video[k] = frames.index_select(0, pos).permute(3, 0, 1, 2).contiguous()
     return video, frame_inds
 
 

@@ -39,7 +39,8 @@ class LaneGraphs:
                 self.fn(dict(static))
         st.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
+        # thread_local: the prefetch thread (datasets/prefetch.py) keeps allocating and copying while this thread records
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
             out = self.fn(dict(static))
         self._graphs[lane][sig] = (g, static, out)
 

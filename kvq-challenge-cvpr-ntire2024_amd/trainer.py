@@ -107,32 +107,45 @@ class Trainer:
         # are enqueue-bound; KVQ_GRAPH=1 / 0 forces it on / off for any model
         want = str(self.config.get("hipgraph", os.environ.get("KVQ_GRAPH", "auto"))).lower()
         use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] == "KSVQE")
+        # items are built on the device `prefetch` videos ahead by a host thread on its own stream (datasets/prefetch.py);
+        # 0: in line, on the consuming stream
+        depth = int(self.config.get("prefetch", os.environ.get("KVQ_PREFETCH", 2)))
         if use_graph:
             from .graph import LaneGraphs
             lanes = [torch.cuda.Stream(device=self.device) for _ in range(nstream)]
             graphs = LaneGraphs(self._run_model, lanes)
-            for st in lanes:
+        else:
+            lanes = [main] + [torch.cuda.Stream(device=self.device) for _ in range(nstream - 1)]
+            graphs = None
+        for st in lanes:
+            if st != main:
                 st.wait_stream(main)
-            for j, i in enumerate(mine):
-                inputs = self._model_inputs(self.val_dataset[i])
+        if depth > 0:
+            from .datasets.prefetch import DevicePrefetcher
+            feed = DevicePrefetcher(self.val_dataset, mine, self.device, depth)
+            items = iter(feed)
+        else:
+            feed, items = None, ((i, None, None) for i in mine)
+        try:
+            for j, (i, item, ready) in enumerate(items):
                 lane = j % nstream
-                lanes[lane].wait_stream(main)                      # the H2D copies of the inputs ran on the main stream
-                pred = graphs.run(lane, inputs)
                 with torch.cuda.stream(lanes[lane]):
-                    local[j] = pred.float().mean()
-            for st in lanes:
+                    if ready is not None:
+                        lanes[lane].wait_event(ready)
+                        feed.hand_over(item, lanes[lane])
+                    else:
+                        item = self.val_dataset[i]
+                    inputs = self._model_inputs(item)
+                    pred = graphs.run(lane, inputs) if graphs is not None else self._run_model(inputs)
+                    local[j] = pred.float().mean()                # pred.mean(0) over clips (trainer.py:282)
+        finally:
+            if feed is not None:
+                feed.close()
+        for st in lanes:
+            if st != main:
                 main.wait_stream(st)
+        if graphs is not None:
             self.graph_stats = (graphs.replays, graphs.eager_runs)
-            return kd.gather_scores(local, n, self.rank, self.world).cpu().numpy()
-        lanes = [main] + [torch.cuda.Stream(device=self.device) for _ in range(nstream - 1)]
-        for st in lanes[1:]:
-            st.wait_stream(main)
-        for j, i in enumerate(mine):
-            with torch.cuda.stream(lanes[j % nstream]):
-                pred = self._forward_video(self.val_dataset[i])
-                local[j] = pred.float().mean()                # pred.mean(0) over clips (trainer.py:282)
-        for st in lanes[1:]:
-            main.wait_stream(st)
         return kd.gather_scores(local, n, self.rank, self.world).cpu().numpy()
 
     def inferece_test(self):
