@@ -385,6 +385,10 @@ int gemm_variant(int M, int N, int K) {
   // 128-column tile would be at most half used.
   // Long K with few tiles: ONE big tile per CU, 64-deep slices (what the vendor library picks for these shapes:
   // 128x160x64 ... 128x256x64 tiles, 225-294 of them).  First candidate that fits the chip in a single round.
+  // Few rows (KSVQE's CLIP tower: 200-800 token rows; one clip's stage 3: 784): 128x128 tiles leave most of the chip idle
+  // (12-48 workgroups walking a K of 3072) — 64x64 tiles quadruple the workgroups; operand re-reads are irrelevant at this size.
+  static const int no_small = getenv("KVQ_GEMM_NO_SMALL") ? 1 : 0;
+  if (!no_small && (long)ceil_div(M, 128) * ceil_div(N, 128) < 96) return 11 * 100 + 32;
   static const int no_deep = getenv("KVQ_GEMM_NO_DEEP") ? 1 : 0;
   if (!no_deep && K % 64 == 0 && K >= 1024) {      // measured: fc2 stage 3 45 -> 40 us, merges -2 us; K = 768 shapes lose
     static const int cand[3][2] = {{2, 2}, {3, 2}, {2, 4}};
