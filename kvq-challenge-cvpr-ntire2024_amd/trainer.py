@@ -101,19 +101,26 @@ class Trainer:
         local = torch.empty(len(mine), dtype=torch.float32, device=self.device)
         # videos are independent (batch_size 1, trainer.py:256-283): consecutive videos go to alternating HIP streams so
         # that one video's latency-bound launches fill the gaps of another's; nothing synchronises with the host per video
-        nstream = max(1, int(self.config.get("streams", os.environ.get("KVQ_STREAMS", 3))))
         main = torch.cuda.current_stream(self.device)
         # hipGraph replay of the per-video forward (kvq_amd/graph.py): default for KSVQE, whose ~360 launches per video
         # are enqueue-bound; KVQ_GRAPH=1 / 0 forces it on / off for any model
         want = str(self.config.get("hipgraph", os.environ.get("KVQ_GRAPH", "auto"))).lower()
         use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] == "KSVQE")
+        # lanes: 3 eager streams; 4 graph lanes = one per hardware queue (measured, tools/harness_probe.py: 2 / 3 / 4 / 5 lanes ->
+        # 238 / 270 / 284 / 240 videos/s on 96-frame KSVQE samples: a fifth lane shares a queue and its graph serialises)
+        nstream = max(1, int(self.config.get("streams", os.environ.get("KVQ_STREAMS", 4 if use_graph else 3))))
         # items are built on the device `prefetch` videos ahead by a host thread on its own stream (datasets/prefetch.py);
         # 0: in line, on the consuming stream
-        depth = int(self.config.get("prefetch", os.environ.get("KVQ_PREFETCH", 2)))
+        # default: 2 when the forwards are enqueued eagerly (their ~6 ms of host work per video would otherwise wait for the
+        # item), 0 under graph replay (a launch is 0.3 ms of host time, the replay already overlaps the next item's build;
+        # measured 101 vs 92 videos/s end to end)
+        depth = int(self.config.get("prefetch", os.environ.get("KVQ_PREFETCH", 0 if use_graph else 2)))
         if use_graph:
             from .graph import LaneGraphs
-            lanes = [torch.cuda.Stream(device=self.device) for _ in range(nstream)]
-            graphs = LaneGraphs(self._run_model, lanes)
+            cached = getattr(self, "_lane_graphs", None)           # recordings outlive one call (inferece_test + inferece_val)
+            if cached is None or len(cached.lanes) != nstream:
+                cached = self._lane_graphs = LaneGraphs(self._run_model, [torch.cuda.Stream(device=self.device) for _ in range(nstream)])
+            graphs, lanes = cached, cached.lanes
         else:
             lanes = [main] + [torch.cuda.Stream(device=self.device) for _ in range(nstream - 1)]
             graphs = None

@@ -37,7 +37,7 @@ print(f"B={B} forward {dt*1e3:.2f} ms  -> {B/dt:.1f} samples/s (32-frame sample,
 
 # whole forwards of consecutive batches on alternating HIP streams (what Trainer._score_all does with KVQ_STREAMS=3)
 NS = int(os.environ.get("KVQ_STREAMS", "3"))
-if NS > 1:
+if NS > 1 and os.environ.get("KSVQE_EAGER_STREAMS", "1") != "0":
     lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NS - 1)]
     def many(n):
         main = lanes[0]
@@ -79,6 +79,8 @@ if os.environ.get("KSVQE_GRAPH", "1") != "0":
             with torch.cuda.stream(lanes[i % len(lanes)]):
                 g.replay()
     replay(2 * len(lanes)); torch.cuda.synchronize()
+    t0 = time.perf_counter(); replay(len(lanes)); t_enq = (time.perf_counter() - t0) / len(lanes); torch.cuda.synchronize()
+    print(f"host time of one graph launch: {t_enq*1e3:.2f} ms")
     t0 = time.perf_counter(); replay(4 * IT); torch.cuda.synchronize()
     dt3 = (time.perf_counter() - t0) / (4 * IT)
     print(f"B={B} hipGraph x {len(lanes)} lanes: {dt3*1e3:.2f} ms per forward -> {B/dt3:.1f} samples/s; same scores: {all(torch.equal(o, s) for _, _, o in graphs)}")
