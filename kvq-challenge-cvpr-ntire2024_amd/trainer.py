@@ -102,10 +102,11 @@ class Trainer:
         # videos are independent (batch_size 1, trainer.py:256-283): consecutive videos go to alternating HIP streams so
         # that one video's latency-bound launches fill the gaps of another's; nothing synchronises with the host per video
         main = torch.cuda.current_stream(self.device)
-        # hipGraph replay of the per-video forward (kvq_amd/graph.py): default for KSVQE, whose ~360 launches per video
-        # are enqueue-bound; KVQ_GRAPH=1 / 0 forces it on / off for any model
+        # hipGraph replay of the per-video forward (kvq_amd/graph.py): default for KSVQE (~360 launches per video) and
+        # SimpleVQA (~70 launches for 8 frames), which are enqueue-bound (tools/harness_probe*.py: 101 vs 62 and 283 vs 213
+        # videos/s end to end); the Swin trunk alone is not (+1 %).  KVQ_GRAPH=1 / 0 forces it on / off for any model
         want = str(self.config.get("hipgraph", os.environ.get("KVQ_GRAPH", "auto"))).lower()
-        use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] == "KSVQE")
+        use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] in ("KSVQE", "simpleVQA"))
         # lanes: 3 eager streams; 4 graph lanes = one per hardware queue (measured, tools/harness_probe.py: 2 / 3 / 4 / 5 lanes ->
         # 238 / 270 / 284 / 240 videos/s on 96-frame KSVQE samples: a fifth lane shares a queue and its graph serialises)
         nstream = max(1, int(self.config.get("streams", os.environ.get("KVQ_STREAMS", 4 if use_graph else 3))))
