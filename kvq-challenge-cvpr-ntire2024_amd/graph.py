@@ -39,23 +39,32 @@ class LaneGraphs:
                 self.fn(dict(static))
         st.synchronize()
         g = torch.cuda.CUDAGraph()
-        # thread_local: the prefetch thread (datasets/prefetch.py) keeps allocating and copying while this thread records
-        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
-            out = self.fn(dict(static))
+        try:
+            # thread_local: the prefetch thread (datasets/prefetch.py) keeps allocating and copying while this thread records
+            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                out = self.fn(dict(static))
+        except Exception as e:  # noqa: BLE001
+            # a forward that cannot be recorded (a host synchronisation or an allocation of the library inside it) still runs:
+            # the same kernels, launched eagerly — say so once per signature instead of failing the job
+            import warnings
+            warnings.warn(f"hipGraph capture failed for {sig[0][0]}... ({type(e).__name__}: {str(e).splitlines()[0][:160]}); "
+                          f"this input signature runs with eager launches", RuntimeWarning)
+            torch.cuda.synchronize()
+            self._graphs[lane][sig] = None
+            return
         self._graphs[lane][sig] = (g, static, out)
 
     def run(self, lane: int, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Enqueue fn(inputs) on lane's stream.  The returned tensor is the graph's static output: consume it on the same
         stream before the lane's next ``run`` (stream order makes that safe without host synchronisation)."""
         sig = _signature(inputs)
-        rec = self._graphs[lane].get(sig)
-        if rec is None:
-            if len(self._graphs[lane]) >= self.max_signatures:
-                self.eager_runs += 1
-                with torch.cuda.stream(self.lanes[lane]):
-                    return self.fn(inputs)
+        if sig not in self._graphs[lane] and len(self._graphs[lane]) < self.max_signatures:
             self._record(lane, sig, inputs)
-            rec = self._graphs[lane][sig]
+        rec = self._graphs[lane].get(sig)
+        if rec is None:                                        # beyond max_signatures, or a signature whose capture failed
+            self.eager_runs += 1
+            with torch.cuda.stream(self.lanes[lane]):
+                return self.fn(inputs)
         g, static, out = rec
         with torch.cuda.stream(self.lanes[lane]):
             for k, v in inputs.items():

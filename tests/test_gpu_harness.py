@@ -302,3 +302,24 @@ def test_hipgraph_replay_is_bit_identical_to_eager(kind):
     for j, o in got:
         assert torch.equal(o, eager[j]), (j, o, eager[j])
     assert lg.replays == 5 and lg.eager_runs == 0 and all(len(g) == 1 for g in lg._graphs)
+
+
+def test_hipgraph_capture_failure_falls_back_to_eager_launches():
+    """A forward with a host synchronisation inside cannot be recorded: LaneGraphs warns once and runs that signature with
+    eager launches (same kernels), instead of failing the job."""
+    from kvq_amd.graph import LaneGraphs
+    def fn(d):
+        y = d["x"] * 2
+        if float(y.sum()) > 1e30:            # .item(): not capturable
+            y = y + 1
+        return y
+    lanes = [torch.cuda.Stream()]
+    lg = LaneGraphs(fn, lanes)
+    x = torch.arange(8, dtype=torch.float32, device="cuda")
+    with pytest.warns(RuntimeWarning, match="capture failed"):
+        out = lg.run(0, {"x": x})
+    torch.cuda.synchronize()
+    assert torch.equal(out, x * 2) and lg.eager_runs == 1 and lg.replays == 0
+    out = lg.run(0, {"x": x + 1})
+    torch.cuda.synchronize()
+    assert torch.equal(out, (x + 1) * 2) and lg.eager_runs == 2
