@@ -155,11 +155,11 @@ class KSVQE(SwinTransformer3D):
         n, c, tt, hh, ww = x_sel.shape
         hw = hh * ww
         rows = x_sel.permute(0, 2, 3, 4, 1).reshape(n * tt * hw, c).contiguous()            # token rows, frame-major (layout only)
-        frames = rows.reshape(n * tt, hw, c)
+        frames16 = kernels.to_half(rows, half).reshape(n * tt, hw, c)       # one 16-bit copy of the frame tokens for both cross attentions
         # --- semantic: CLIP patch tokens of every other frame, adapted to c channels, cross-attended by the frame's tokens
         pt = patch_tokens[:, ::2].reshape(-1, patch_tokens.shape[-1]).contiguous()
-        pt = kernels.to_float(self._run_adapter(self.semantic_adapter[k], kernels.to_half(pt, half))).reshape(n * tt, -1, c)
-        enhanced, _ = self.semantic_cross[k](frames, pt)
+        pt = self._run_adapter(self.semantic_adapter[k], kernels.to_half(pt, half)).reshape(n * tt, -1, c)
+        enhanced, _ = self.semantic_cross[k](frames16, pt)
         sm = self.semantic_mod[k]
         wsm = sm._cached(rows.device, lambda: (sm.conv_gama.weight.detach().to(rows.device, torch.float32).reshape(-1).contiguous(),
                                                float(sm.conv_gama.bias.detach()),
@@ -167,13 +167,13 @@ class KSVQE(SwinTransformer3D):
                                                float(sm.conv_beta.bias.detach())))
         x_s = kernels.sem_modulate(enhanced.reshape(-1, c).contiguous(), rows, *wsm)         # (n t' hw, c)
         # --- distortion: CONTRIQUE tokens adapted to c channels, cross-attended per frame, then self-attention over the
-        # frames of every spatial position, then (mean, std)-driven channel modulation
-        dt = kernels.to_float(self._run_adapter(self.distortion_adapter[k], kernels.to_half(dist.reshape(-1, dist.shape[-1]).contiguous(), half)))
-        d_enh, _ = self.distortion_cross[k](frames, dt.reshape(n * tt, -1, c))
+        # frames of every spatial position, then (mean, std)-driven channel modulation.  The chain stays in the 16-bit operand
+        # type between its GEMMs (the values each next GEMM would round to anyway)
+        dt = self._run_adapter(self.distortion_adapter[k], kernels.to_half(dist.reshape(-1, dist.shape[-1]).contiguous(), half))
+        d_enh, _ = self.distortion_cross[k](frames16, dt.reshape(n * tt, -1, c), keep16=True)
         d_enh = d_enh.reshape(n, tt, hw, c).permute(0, 2, 1, 3).reshape(n * hw, tt, c).contiguous()
-        d_enh = self.distortion_self[k](d_enh)
-        d_enh = d_enh.reshape(n, hw, tt, c).permute(0, 3, 2, 1).reshape(n, c, tt, hh, ww)
-        x_d = self.distortion_mod[k](d_enh, rows.reshape(n, tt * hw, c))                      # (n, t' hw, c)
+        d_enh = self.distortion_self[k](d_enh, keep16=True)                                   # (n hw, t', c) 16-bit
+        x_d = self.distortion_mod[k](d_enh.reshape(n, hw * tt, c), rows.reshape(n, tt * hw, c))   # (n, t' hw, c)
         a1, a2 = self._mix_coeffs()[k]
         out = kernels.axpby(x_d.reshape(-1, c).contiguous(), x_s, a1 / 2.0, a2 / 2.0)
         return out.reshape(n, tt, hh, ww, c).permute(0, 4, 1, 2, 3)

@@ -52,18 +52,23 @@ class crossattention1(_HipModule):  # noqa: N801  (reference spelling)
         self.dim_V, self.num_heads = dim, num_heads
         self.fc_q, self.fc_k, self.fc_v = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
 
-    def forward(self, Q, K):
+    def forward(self, Q, K, keep16=False):
+        """``keep16``: return the 16-bit attention output as it leaves the kernel (what the next GEMM would convert to)."""
         self._need(Q, K)
         dev, h = Q.device, self._half()
         w = self._cached(dev, lambda: [(self._w16(m.weight, dev), m.bias.detach().to(dev, torch.float32).contiguous())
                                        for m in (self.fc_q, self.fc_k, self.fc_v)])
         B, Nq, C = Q.shape
-        q16 = kernels.to_half(Q.to(torch.float32).contiguous().reshape(-1, C), h)
-        k16 = kernels.to_half(K.to(torch.float32).contiguous().reshape(-1, C), h)
+        # operands already in the 16-bit operand type (KSVQE.forward hands the adapters' GEMM outputs and one shared copy of
+        # the frame tokens over) are used as they are: same values the conversion would produce
+        q16 = Q.contiguous().reshape(-1, C) if Q.dtype == h else kernels.to_half(Q.to(torch.float32).contiguous().reshape(-1, C), h)
+        k16 = K.contiguous().reshape(-1, C) if K.dtype == h else kernels.to_half(K.to(torch.float32).contiguous().reshape(-1, C), h)
         q = kernels.gemm(q16, *w[0], _abi.EPI_BIAS_BF16)
         k = kernels.gemm(k16, *w[1], _abi.EPI_BIAS_BF16)
         v = kernels.gemm(k16, *w[2], _abi.EPI_BIAS_BF16)
         o = kernels.mha_cross(q, k, v, B, self.num_heads, float(self.dim_V) ** -0.5)
+        if keep16:
+            return o.reshape(B, Nq, C), None
         return kernels.to_float(o).reshape(B, Nq, C), None
 
 
@@ -76,7 +81,7 @@ class Attention(_HipModule):
         self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
         self.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Dropout(dropout))
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, keep16=False):
         if mask is not None:
             raise NotImplementedError("key mask: no caller passes one (KSVQE_model.py:1473)")
         self._need(x)
@@ -84,9 +89,11 @@ class Attention(_HipModule):
         w = self._cached(dev, lambda: (self._w16(self.to_qkv.weight, dev), self._w16(self.to_out[0].weight, dev),
                                        self.to_out[0].bias.detach().to(dev, torch.float32).contiguous()))
         B, n, C = x.shape
-        qkv = kernels.gemm(kernels.to_half(x.to(torch.float32).contiguous().reshape(-1, C), h), w[0], None, _abi.EPI_BIAS_BF16)
+        x16 = x.contiguous().reshape(-1, C) if x.dtype == h else kernels.to_half(x.to(torch.float32).contiguous().reshape(-1, C), h)
+        qkv = kernels.gemm(x16, w[0], None, _abi.EPI_BIAS_BF16)
         o = kernels.mha_small(qkv, B, n, self.heads)
-        return kernels.to_float(kernels.gemm(o, w[1], w[2], _abi.EPI_BIAS_BF16)).reshape(B, n, C)
+        y = kernels.gemm(o, w[1], w[2], _abi.EPI_BIAS_BF16)
+        return y.reshape(B, n, C) if keep16 else kernels.to_float(y).reshape(B, n, C)
 
 
 class Semantic_Transformation2(_HipModule):  # noqa: N801
@@ -122,8 +129,13 @@ class Dist_Transformation3(_HipModule):  # noqa: N801
         dev, h = x.device, self._half()
         w = self._cached(dev, lambda: (self._w16(self.get_gamma.weight, dev), self.get_gamma.bias.detach().to(dev, torch.float32).contiguous(),
                                        self._w16(self.get_beta.weight, dev), self.get_beta.bias.detach().to(dev, torch.float32).contiguous()))
-        B, C = x.shape[:2]
-        x16 = kernels.to_half(x.to(torch.float32).reshape(B, C, -1).permute(0, 2, 1).contiguous(), h)      # (B, THW, C) channels-last
+        if x.dtype == h and x.dim() == 3:
+            # (B, positions, C) 16-bit rows, any position order: the statistics are over all positions of a sample
+            B, C = x.shape[0], x.shape[2]
+            x16 = x.contiguous()
+        else:
+            B, C = x.shape[:2]
+            x16 = kernels.to_half(x.to(torch.float32).reshape(B, C, -1).permute(0, 2, 1).contiguous(), h)  # (B, THW, C) channels-last
         stats = torch.empty(B, 2 * C, dtype=torch.float32, device=dev)
         kernels.mean_std_pool(x16, stats, 0, C)
         s16 = kernels.to_half(stats, h)
