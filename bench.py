@@ -137,9 +137,8 @@ def main():
 
     def capture():
         """one hipGraph per lane: the lane's stream runs two eager steps (plans, workspaces, caches), then records a third"""
-        lanes = [torch.cuda.current_stream()] + side if by_step else [torch.cuda.current_stream()]
-        for st in lanes:
-            cap = torch.cuda.Stream(device=device) if st == torch.cuda.current_stream() else st   # capture needs a side stream
+        lanes = (side + [torch.cuda.Stream(device=device)]) if by_step else [torch.cuda.Stream(device=device)]
+        for cap in lanes:                                   # capture needs non-default streams
             cap.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cap):
                 for _ in range(2):
