@@ -3,7 +3,8 @@
 ``Dist_Transformation3`` (:934-960) — the four the trainer's KSVQE instantiates per tuned stage (:1160-1186) — with the
 reference's constructor arguments, ``state_dict`` keys, argument layouts and outputs.  The torch modules only hold
 parameters; the arithmetic runs on ``libkvq_hip.so`` (GEMMs, ``kvq_mha_cross``, ``kvq_mean_std_pool``, the modulation
-kernels).  Part of SURVEY.md §8 f1; KSVQE's forward itself (key frames, QRS, CONTRIQUE, the stage hooks) is not built yet."""
+kernels).  Also here: key-frame selection, the QRS region selection (``RegionNet_CLIP``, eval path) and the CONTRIQUE
+distortion branch.  Part of SURVEY.md §8 f1; ``KSVQE_model.py`` composes them into the reference's ``KSVQE.forward``."""
 from __future__ import annotations
 
 import os
