@@ -323,7 +323,10 @@ class SwinTransformer3D(nn.Module):
         blocks = self._wcache[3]
         nblk = sum(self.depths)
         total = sum(lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk))
-        if not self.dense_bias or total > batch * self.dense_bias_bytes_per_clip:
+        # "clips" in units of the 32 x 224 x 224 clip the cap was measured on: a 96-frame KSVQE sample has three times the
+        # windows per bias image (measured at T = 96, B = 1: 790 -> 480 us of attention per forward with the dense path)
+        clips = batch * max(1.0, geom[0] / 32.0) * max(1.0, geom[1] * geom[2] / (224.0 * 224.0))
+        if not self.dense_bias or total > clips * self.dense_bias_bytes_per_clip:
             for k in range(nblk):
                 blocks[k].bias_dense = None
             return

@@ -10,6 +10,7 @@ from kvq_amd.utils import synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 IT = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 cfg = {"model": {"type": "KSVQE", "args": {"KSVQE": {"backbone": dict(checkpoint=True, pretrained=None, num_samples=1, sample_type="topkpertubation",
        CLIP_location=8, cls_use=True, tuning_stage=2, qls_swin=True, frozen3D=False, frozen_stages=-1),
        "head": {"in_channels": 768, "hidden_channels": 64}}}}}
@@ -19,7 +20,7 @@ sd.update({"KSVQE_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_he
 net.load_state_dict(sd, strict=False)
 net = net.cuda().eval()
 net.KSVQE_backbone.aux_loss = os.environ.get("KSVQE_AUX_LOSS", "0") == "1"      # the harness discards the loss (Trainer._score_all)
-inp = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_ksvqe_inputs(1, B, 32).items()}
+inp = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_ksvqe_inputs(1, B, T).items()}
 
 def run():
     with torch.no_grad():
@@ -33,7 +34,7 @@ for _ in range(IT):
     s, _ = run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / IT
-print(f"B={B} forward {dt*1e3:.2f} ms  -> {B/dt:.1f} samples/s (32-frame sample, 1 clip)", s.flatten().tolist()[:2])
+print(f"B={B} forward {dt*1e3:.2f} ms  -> {B/dt:.1f} samples/s ({T}-frame sample, 1 clip)", s.flatten().tolist()[:2])
 
 # whole forwards of consecutive batches on alternating HIP streams (what Trainer._score_all does with KVQ_STREAMS=3)
 NS = int(os.environ.get("KVQ_STREAMS", "3"))
