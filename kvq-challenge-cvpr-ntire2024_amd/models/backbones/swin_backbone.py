@@ -120,7 +120,7 @@ class SwinTransformer3D(nn.Module):
         self.dense_bias = os.environ.get("KVQ_DENSE_BIAS", "1") != "0"
         self.dense_bias_max_bytes = int(float(os.environ.get("KVQ_DENSE_BIAS_MAX_GB", "24")) * 2 ** 30)
         self.dense_bias_max_abs = float(os.environ.get("KVQ_DENSE_BIAS_MAX_ABS", "16"))
-        self.dense_bias_bytes_per_clip = int(float(os.environ.get("KVQ_DENSE_BIAS_GB_PER_CLIP", "0.5")) * 2 ** 30)
+        self.dense_bias_bytes_per_clip = int(float(os.environ.get("KVQ_DENSE_BIAS_GB_PER_CLIP", "2")) * 2 ** 30)
         self.dense_bias_max_abs = float(os.environ.get("KVQ_DENSE_BIAS_MAX_ABS", "16"))
         self._dense = {}
         if isinstance(window_size, list) and window_size and isinstance(window_size[0], (list, tuple)):
@@ -318,8 +318,10 @@ class SwinTransformer3D(nn.Module):
 
     def _set_dense_bias(self, handle, geom, device, batch):
         """Point every block at the dense attention bias of this plan geometry (built on first use).  The bias is read
-        from HBM once per step whatever the batch, so it only pays when enough clips share it: Swin-T at 32x224x224 streams
-        1.2 GB per step (0.3 GB per clip at B = 4: 890 -> 613 us of attention), Swin-B at 64x256x256 10 GB (no gain at B = 2)."""
+        from HBM once per step whatever the batch, so it pays when enough windows share an image (one image per window TYPE and
+        head): Swin-T at 32x224x224 pays at any batch, Swin-B at 64x256x256 (3.2 GB of images) pays from one clip on with the
+        present kernel (5.76 -> 5.28 ms per clip at B = 1, 4.85 -> 4.29 at B = 2); the cap (2 GB per 32x224x224-equivalent of
+        tokens in the batch) only fends off geometries whose images would dwarf the activations."""
         blocks = self._wcache[3]
         nblk = sum(self.depths)
         total = sum(lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk))
