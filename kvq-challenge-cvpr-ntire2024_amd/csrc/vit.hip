@@ -455,6 +455,23 @@ __global__ void crop_regions_kernel(const float* __restrict__ x, const int32_t* 
   out[i] = x[(((b * C + c) * T + t) * (long)H + ry * anchor + yy) * W + rx * anchor + xx];
 }
 
+// the same with 16-byte accesses: anchor, W and the output width are multiples of 4 pixels (32-pixel anchors)
+__global__ void crop_regions_vec4_kernel(const float* __restrict__ x, const int32_t* __restrict__ region, int C, int T, int H, int W,
+                                         int anchor, int nx, int oh, int ow, float* __restrict__ out, long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int ow4 = ow / 4;
+  const int xx = (int)(i % ow4) * 4;
+  long r = i / ow4;
+  const int yy = (int)(r % oh); r /= oh;
+  const int t = (int)(r % T); r /= T;
+  const int c = (int)(r % C);
+  const long b = r / C;
+  const int reg = region[b * T + t], ry = reg / nx, rx = reg % nx;
+  *reinterpret_cast<f32x4*>(out + i * 4) =
+      *reinterpret_cast<const f32x4*>(x + (((b * C + c) * T + t) * (long)H + ry * anchor + yy) * W + rx * anchor + xx);
+}
+
 }  // namespace kvq
 
 extern "C" int kvq_qrs_top_region(const float* score, int BK, int gs, int gh, int gw, int kh, int kw, int32_t* idx, void* stream) {
@@ -475,6 +492,12 @@ extern "C" int kvq_crop_regions(const float* x, const int32_t* region, int B, in
               "kvq_crop_regions: bad shape %dx%d anchor %d window %dx%d", H, W, anchor, kh, kw);
   const int oh = kh * anchor, ow = kw * anchor, nx = W / anchor - kw + 1;
   const long total = (long)B * C * T * oh * ow;
+  if (anchor % 4 == 0 && W % 4 == 0 && (((size_t)x | (size_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(crop_regions_vec4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, region,
+                       C, T, H, W, anchor, nx, oh, ow, out, total / 4);
+    KVQ_CHECK_LAUNCH("crop_regions_vec4_kernel");
+    return KVQ_OK;
+  }
   hipLaunchKernelGGL(crop_regions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, region, C, T,
                      H, W, anchor, nx, oh, ow, out, total);
   KVQ_CHECK_LAUNCH("crop_regions_kernel");

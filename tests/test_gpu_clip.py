@@ -227,3 +227,19 @@ def test_ksvqe_end_to_end_vs_reference_golden(golden, dtype):
         f_or, _ = KO.ksvqe_forward({k: v.cpu() for k, v in inp.items()}, synth.synth_ksvqe_weights(3), synth.SWIN_T_GRPB)
         s_or = O.vqa_head(f_or, hw)
     assert (scores.float().cpu() - s_or).abs().max().item() <= 1e-3
+
+
+def test_crop_regions_scalar_and_vector_paths():
+    """kvq_crop_regions against the same gather written with slices: 6-pixel anchors (scalar kernel) and 32-pixel ones (16-byte
+    kernel) — copy work, bit-exact."""
+    gen = np.random.Generator(np.random.PCG64(3))
+    for anchor, grid, k in ((6, 5, 3), (32, 4, 2)):
+        xs = torch.from_numpy(gen.standard_normal((2, 3, 4, grid * anchor, grid * anchor)).astype(np.float32))
+        nx = grid - k + 1
+        reg = torch.from_numpy(gen.integers(0, nx * nx, size=8).astype(np.int32))
+        got = kernels.crop_regions(xs.to(DEV), reg.to(DEV), anchor, k, k).cpu()
+        assert got.shape == (2, 3, 4, k * anchor, k * anchor)
+        for b in range(2):
+            for t in range(4):
+                ry, rx = divmod(int(reg[b * 4 + t]), nx)
+                assert torch.equal(got[b, :, t], xs[b, :, t, ry * anchor:(ry + k) * anchor, rx * anchor:(rx + k) * anchor])
