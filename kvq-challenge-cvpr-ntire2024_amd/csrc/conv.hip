@@ -213,6 +213,66 @@ __global__ __launch_bounds__(256) void mean_std_pool_kernel(const uint16_t* __re
 }
 
 
+// Few rows, thousands of positions, C % 8 == 0: a block owns 8 channels, a thread strides over the positions with 16-byte loads
+// (KSVQE's Dist_Transformation3 at 96 frames: 1 row x 9408 positions x 384 channels -> 48 workgroups of 37 loads per thread)
+template <typename E>
+__global__ __launch_bounds__(256) void mean_std_pool_vec8_kernel(const uint16_t* __restrict__ x, int HW, int C,
+                                                                 float* __restrict__ out, long out_stride, int mean_off,
+                                                                 int std_off) {
+  __shared__ float red[4][8];
+  const int row = blockIdx.x, c0 = blockIdx.y * 8, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* xr = x + (size_t)row * HW * C + c0;
+  auto block_sum8 = [&](float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v[e] += __shfl_xor(v[e], o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  };
+  auto load8 = [&](int i, float (&f)[8]) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + (size_t)i * C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = E::to_f32((uint16_t)(v[e] & 0xffffu));
+      f[2 * e + 1] = E::to_f32((uint16_t)(v[e] >> 16));
+    }
+  };
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, f[8];
+  for (int i = tid; i < HW; i += 256) {
+    load8(i, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += f[e];
+  }
+  block_sum8(s);
+  float mean[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mean[e] = s[e] / (float)HW;
+    q[e] = 0.f;
+  }
+  for (int i = tid; i < HW; i += 256) {
+    load8(i, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = f[e] - mean[e];
+      q[e] = fmaf(d, d, q[e]);
+    }
+  }
+  block_sum8(q);
+  if (tid < 8) {
+    out[(size_t)row * out_stride + mean_off + c0 + tid] = mean[tid];
+    if (std_off >= 0) out[(size_t)row * out_stride + std_off + c0 + tid] = sqrtf(q[tid] / (float)(HW - 1));
+  }
+}
+
 // ---- direct stem convolution ---------------------------------------------------------------------------------------
 // The SlowFast fast-pathway stem is Conv3d(3 -> 8, k = 5x7x7, stride 1x2x2): K = 735 per output but only 8 output
 // channels, so as im2col + GEMM it WRITES a 4.7 GB patch matrix (3.2 M positions x 736 x 2 B: 7.6 ms of the 15 ms
@@ -376,8 +436,15 @@ extern "C" int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW,
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mean_std_pool: dtype %d", dtype);
   KVQ_REQUIRE(rows > 0 && HW > 0 && C > 0 && (std_off < 0 || HW > 1), KVQ_ERR_SHAPE, "kvq_mean_std_pool: bad shape");
   const bool narrow = (long)rows * ceil_div(C, 64) < 128 && HW >= 256;
-  dim3 grid(rows, ceil_div(C, narrow ? 16 : 64));
   hipStream_t st = (hipStream_t)stream;
+  if (narrow && HW >= 1024 && C % 8 == 0 && ((size_t)x & 15) == 0) {
+    dim3 g8(rows, C / 8);
+    if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(mean_std_pool_vec8_kernel<Fp16>, g8, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
+    else hipLaunchKernelGGL(mean_std_pool_vec8_kernel<Bf16>, g8, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
+    KVQ_CHECK_LAUNCH("mean_std_pool_vec8_kernel");
+    return KVQ_OK;
+  }
+  dim3 grid(rows, ceil_div(C, narrow ? 16 : 64));
   if (dtype == KVQ_DT_FP16) {
     if (narrow) hipLaunchKernelGGL((mean_std_pool_kernel<Fp16, 16>), grid, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
     else hipLaunchKernelGGL((mean_std_pool_kernel<Fp16, 64>), grid, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);

@@ -179,3 +179,17 @@ def test_conv_implicit_with_pruned_taps_equals_full_conv(hw, stride):
     assert got.shape == full.shape
     assert (got.float().cpu()[:, 0] - ref).abs().max().item() <= 4e-3
     assert (got.float() - full.float()).abs().max().item() <= 2e-3
+
+
+@gpu
+@pytest.mark.parametrize("rows,HW,C", [(1, 9408, 384), (2, 3136, 768), (3, 300, 40), (1, 1500, 20)])
+def test_mean_std_pool_variants(rows, HW, C):
+    """(mean, unbiased std) pooling on its three kernels (64-channel tile, 16-channel tile, 8-channel 16-byte tile) vs torch."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(rows + HW + C))
+    y = torch.from_numpy((g.standard_normal((rows, HW, C)) * 2 + 0.5).astype(np.float32)).half()
+    out = torch.zeros(rows, 2 * C + 3, device="cuda")
+    kernels.mean_std_pool(y.cuda(), out, 1, C + 2)
+    assert (out[:, 1:1 + C].cpu() - y.float().mean(1)).abs().max().item() <= 2e-5
+    assert (out[:, C + 2:2 * C + 2].cpu() - y.float().std(1)).abs().max().item() <= 2e-5
+    assert out[:, 0].abs().max().item() == 0 and out[:, C + 1].abs().max().item() == 0 and out[:, -1].abs().max().item() == 0
