@@ -51,3 +51,25 @@ def test_hip_slowfast_matches_oracle(shape):
     for got, ref in ((s, s_ref), (f, f_ref)):
         rel = ((got.cpu() - ref).norm() / ref.norm()).item()
         assert rel <= 5e-3, rel          # ~100 conv layers on fp16 operands, fp32 accumulate / residual stream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,kernel,stride,pad,cout", [
+    ((2, 3, 6, 30, 46), (5, 7, 7), (1, 2, 2), (2, 3, 3), 8),      # the fast-pathway stem geometry, Wo = 23
+    ((1, 3, 4, 16, 32), (1, 7, 7), (1, 2, 2), (0, 3, 3), 8),
+    ((1, 3, 4, 16, 20), (3, 5, 5), (1, 1, 1), (1, 2, 2), 8),      # other kernel width
+    ((1, 3, 3, 12, 18), (1, 7, 7), (1, 2, 2), (0, 3, 3), 16),
+])
+def test_conv_stem_direct_vs_torch_conv3d(shape, kernel, stride, pad, cout):
+    """kvq_conv_stem_direct (fp32 arithmetic, 16-bit channels-last output) against F.conv3d + bias + ReLU on the same fp32 data."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(sum(shape) + cout))
+    x = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+    K = kernel[0] * kernel[1] * kernel[2] * shape[1]
+    w5 = torch.from_numpy((g.standard_normal((cout, shape[1]) + kernel) / np.sqrt(K)).astype(np.float32))
+    bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+    w_kc = w5.permute(2, 3, 4, 1, 0).reshape(K, cout).contiguous()                      # [K][Cout], K ordered (kd, kh, kw, c)
+    out = kernels.conv_stem_direct(x.cuda(), w_kc.cuda(), bias.cuda(), kernel, stride, pad, True, torch.float16).float().cpu()
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), w5.double(), bias.double(), stride, pad)).permute(0, 2, 3, 4, 1).float()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 2.0 ** -10 * max(1.0, ref.abs().max().item())      # fp32 accumulate, one fp16 rounding
