@@ -149,6 +149,10 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         else:
             identity = x32.reshape(-1, x32.shape[-1])
         spec = W[pre + ".branch2#c"]
+        if IMPLICIT_CONV and out.shape[-1] % 32 and out.shape[-1] % 8 == 0 and out.is_contiguous():
+            # 1x1x1 from 8 / 16 channels (fast pathway): the K padding to 32 lives in the tap table, not in a patch matrix
+            y16, y32 = kernels.conv_implicit(out, spec[0], spec[1], spec[2], spec[3], spec[4], True, resid_f32=identity, want_f32=True)
+            return y16, y32.reshape(y16.shape)
         a, (d, h, w) = self._cols(out, spec)
         y16, y32 = kernels.conv_gemm(a, spec[0], spec[1], True, resid_f32=identity, want_f32=True)
         shape = (x16.shape[0], d, h, w, spec[0].shape[0])
@@ -159,6 +163,18 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         wt, bias, k, stride, pad = spec
         if direct is not None:      # fast pathway: 3 -> 8 channels, k 5x7x7: the patch matrix would be 4.7 GB for 8 clips
             y = kernels.conv_stem_direct(x, direct, bias, k, stride, pad, True, half)
+        elif IMPLICIT_CONV and C <= 8 and k[0] == 1 and os.environ.get("KVQ_STEM_IMPLICIT", "1") != "0":
+            # slow pathway: 3 -> 64 channels, k 1x7x7: implicit GEMM over the clip packed to 8 channels (no 147-column patch matrix)
+            x8 = kernels.pack_channels_last8(x, (B, T, C, H, W), (C * T * H * W, H * W, T * H * W, W, 1), half)
+            w8 = self.__dict__.setdefault("_stem8", {})
+            key = (wt.data_ptr(), wt._version)
+            if key not in w8:
+                taps = k[1] * k[2]
+                t8 = torch.zeros(wt.shape[0], -(-taps * 8 // 32) * 32, dtype=wt.dtype, device=wt.device)
+                t8[:, :taps * 8].view(wt.shape[0], taps, 8)[:, :, :C] = wt[:, :taps * C].reshape(wt.shape[0], taps, C)
+                w8.clear()
+                w8[key] = t8
+            y = kernels.conv_implicit(x8.reshape(B, T, H, W, 8), w8[key], bias, k, stride, pad, True)
         else:
             a, (d, h, w) = kernels.im2col_nd(x, (B, C, T, H, W), (C * T * H * W, T * H * W, H * W, W, 1), k, stride, pad,
                                              half, wt.shape[1])
