@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 10
+#define KVQ_ABI_VERSION 11
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -459,6 +459,16 @@ int kvq_pack_channels_last8(const float* x, const int32_t dims5[5], const int64_
 int kvq_conv_stem_direct(const float* x, const int32_t dims5[5], const float* w, const float* bias, int cout,
                          const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu, int dtype,
                          uint16_t* out, void* stream);
+/* The same stem on the matrix cores (SlowFast fast pathway, SlowFast_features.py:140: Conv3d(3, 8, (5,7,7), stride (1,2,2),
+ * padding (2,3,3)) + BatchNorm + ReLU).  kvq_pack_clip_cl4: x fp32 (B,C<=4,T,H,W) contiguous -> 16-bit channels-last with four
+ * channels and `border` zero pixels left and right, (B, T, H, W + 2*border, 4).  kvq_conv_stem_mfma: x4 packed with border 4,
+ * dims4 = {B, T, H, W}; wpack 16-bit [kd*kh][16][32], entry [a*kh + r][o][tap*4 + c] = w[o][c][a][r][tap] (BatchNorm folded;
+ * rows o >= 8, tap 7 and c >= C zero); bias8 fp32 [8]; kernel width 7 / stride 2 / pad 3 along W; out 16-bit (B,Do,Ho,Wo,8).
+ * 16-bit operands, fp32 accumulate; no patch matrix. */
+int kvq_pack_clip_cl4(const float* x, const int32_t dims5[5], int border, int dtype, uint16_t* out, void* stream);
+int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], const uint16_t* wpack, const float* bias8,
+                       const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu, int dtype,
+                       uint16_t* out, void* stream);
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
                 const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream);

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def dtype_code(dt) -> int:
@@ -159,6 +159,9 @@ SYMBOLS = {
     "kvq_pack_channels_last8": (i32, [p_void, C.POINTER(i32 * 5), C.POINTER(i64 * 5), i32, p_void, p_void]),
     "kvq_conv_stem_direct": (i32, [p_void, C.POINTER(i32 * 5), p_void, p_void, i32, C.POINTER(i32 * 3), C.POINTER(i32 * 3),
                                    C.POINTER(i32 * 3), i32, i32, p_void, p_void]),
+    "kvq_pack_clip_cl4": (i32, [p_void, C.POINTER(i32 * 5), i32, i32, p_void, p_void]),
+    "kvq_conv_stem_mfma": (i32, [p_void, C.POINTER(i32 * 4), p_void, p_void, C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
+                                 i32, i32, p_void, p_void]),
     "kvq_pool_nd": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
                           i32, p_void, p_void]),
     "kvq_mean_std_pool": (i32, [p_void, i32, i32, i32, i32, p_void, i64, i32, i32, p_void]),

@@ -341,7 +341,143 @@ __global__ __launch_bounds__(256) void conv_stem_direct_kernel(StemParams p) {
   }
 }
 
+// ---- MFMA stem convolution for few output channels ------------------------------------------------------------------
+// The fast-pathway stem again (3 -> 8 channels, 5x7x7, stride 1x2x2), on the matrix cores: the fp32 direct kernel above is
+// bound by its loads (24 TFLOP/s).  Here the clip is packed once to 16-bit channels-last with FOUR channels and a zero border
+// of 4 pixels left and right (B, T, H, W + 8, 4): the 8 taps (7 + a zero-weight one) x 4 channels of one kernel ROW are 32
+// consecutive k values = one v_mfma_f32_16x16x32 slice, and a lane's 8 k values (2 adjacent taps x 4 channels) are 16
+// contiguous bytes of the packed clip — the B fragment is loaded straight from global memory / L1 (no LDS, no patch matrix).
+// C[channel][position]: A = weights [16 rows (8 used)][32 k] per (kd, kh) from LDS, B = 16 adjacent output columns.  A wave
+// owns one output row (up to 7 tiles of 16 columns), so a weight fragment is read once per 7 MFMAs.
+template <typename E>
+__global__ __launch_bounds__(256) void pack_cl4_border_kernel(const float* __restrict__ x, int Cc, int T, int H, int W, int border,
+                                                              uint16_t* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Wp = W + 2 * border;
+  const int xp = (int)(i % Wp);
+  long r = i / Wp;
+  const int y = (int)(r % H); r /= H;
+  const int t = (int)(r % T);
+  const long b = r / T;
+  const int xx = xp - border;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (xx >= 0 && xx < W) {
+    const float* src = x + ((b * Cc * T + t) * (long)H + y) * W + xx;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < Cc) v[c] = src[(long)c * T * H * W];
+  }
+  *reinterpret_cast<u32x2*>(out + i * 4) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+}
+
+struct StemMfmaParams {
+  const uint16_t* x4;      // (B, T, H, W + 8, 4) 16-bit, zero border
+  const uint16_t* wp;      // [kd*kh][16][32] 16-bit: k = tap * 4 + c, rows >= Cout and tap 7 zero
+  const float* bias;       // [8]
+  int B, T, H, Wp, kd, kh, sd, sh, pd, ph, Do, Ho, Wo, relu;
+  uint16_t* out;           // (B, Do, Ho, Wo, 8)
+};
+
+template <typename E>
+__global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
+  fp16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+  const int nsl = p.kd * p.kh, tid = threadIdx.x;
+  for (int i = tid; i < nsl * 64; i += 256) *reinterpret_cast<u32x4*>(wl + i * 8) = *reinterpret_cast<const u32x4*>(p.wp + (size_t)i * 8);
+  __syncthreads();
+  const long rows = (long)p.B * p.Do * p.Ho, row = (long)blockIdx.x * 4 + (tid >> 6);
+  if (row >= rows) return;
+  const int lane = tid & 63, n = lane & 15, kg = lane >> 4;
+  const int ho = (int)(row % p.Ho), dq = (int)((row / p.Ho) % p.Do);
+  const long b = row / ((long)p.Ho * p.Do);
+  constexpr int NT = 7;
+  using v8 = typename E::v8;
+  for (int w0 = 0; w0 < p.Wo; w0 += 16 * NT) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < p.kd; ++a) {
+      const int t = dq * p.sd - p.pd + a;
+      if (t < 0 || t >= p.T) continue;
+      for (int r = 0; r < p.kh; ++r) {
+        const int y = ho * p.sh - p.ph + r;
+        if (y < 0 || y >= p.H) continue;
+        const v8 wa = *reinterpret_cast<const v8*>(wl + ((a * p.kh + r) * 16 + n) * 32 + kg * 8);
+        const uint16_t* rowp = p.x4 + (((b * p.T + t) * (long)p.H + y) * p.Wp) * 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int wo = w0 + j * 16 + n;
+          u32x4 raw = {0u, 0u, 0u, 0u};
+          if (wo < p.Wo) {                                   // pixel 2*wo - 3 + 2*kg of the image = + 4 in the bordered row
+            const uint16_t* src = rowp + (size_t)(2 * wo + 1 + 2 * kg) * 4;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 4);
+            raw = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+          acc[j] = E::mfma16(wa, __builtin_bit_cast(v8, raw), acc[j]);
+        }
+      }
+    }
+    if (kg < 2) {                                            // lanes 0..31 hold channels kg*4 .. +3 of position n
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + kg * 4);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int wo = w0 + j * 16 + n;
+        if (wo >= p.Wo) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[j][e] + bv[e];
+          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<u32x2*>(p.out + ((size_t)row * p.Wo + wo) * 8 + kg * 4) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+      }
+    }
+  }
+}
+
 }  // namespace kvq
+
+extern "C" int kvq_pack_clip_cl4(const float* x, const int32_t dims5[5], int border, int dtype, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && dims5 && out, KVQ_ERR_NULL, "kvq_pack_clip_cl4: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_pack_clip_cl4: dtype %d", dtype);
+  const int B = dims5[0], Cc = dims5[1], T = dims5[2], H = dims5[3], W = dims5[4];
+  KVQ_REQUIRE(B > 0 && Cc > 0 && Cc <= 4 && T > 0 && H > 0 && W > 0 && border >= 0, KVQ_ERR_SHAPE,
+              "kvq_pack_clip_cl4: bad shape B=%d C=%d (1..4) T=%d H=%d W=%d border=%d", B, Cc, T, H, W, border);
+  const long total = (long)B * T * H * (W + 2 * border);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(pack_cl4_border_kernel<Fp16>, grid, block, 0, (hipStream_t)stream, x, Cc, T, H, W, border, out, total);
+  else hipLaunchKernelGGL(pack_cl4_border_kernel<Bf16>, grid, block, 0, (hipStream_t)stream, x, Cc, T, H, W, border, out, total);
+  KVQ_CHECK_LAUNCH("pack_cl4_border_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], const uint16_t* wpack, const float* bias8,
+                                  const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu, int dtype,
+                                  uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x4 && dims4 && wpack && bias8 && kernel3 && stride3 && pad3 && out, KVQ_ERR_NULL, "kvq_conv_stem_mfma: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_mfma: dtype %d", dtype);
+  KVQ_REQUIRE(kernel3[2] == 7 && stride3[2] == 2 && pad3[2] == 3, KVQ_ERR_UNSUPPORTED,
+              "kvq_conv_stem_mfma: kernel width 7 / stride 2 / pad 3 along W only (got %d / %d / %d)", kernel3[2], stride3[2], pad3[2]);
+  StemMfmaParams p{};
+  p.x4 = x4; p.wp = wpack; p.bias = bias8; p.B = dims4[0]; p.T = dims4[1]; p.H = dims4[2]; p.Wp = dims4[3] + 8;
+  p.kd = kernel3[0]; p.kh = kernel3[1]; p.sd = stride3[0]; p.sh = stride3[1]; p.pd = pad3[0]; p.ph = pad3[1]; p.relu = relu; p.out = out;
+  KVQ_REQUIRE(p.B > 0 && p.T > 0 && p.H > 0 && dims4[3] > 0 && p.kd > 0 && p.kh > 0 && p.sd > 0 && p.sh > 0, KVQ_ERR_SHAPE,
+              "kvq_conv_stem_mfma: bad shape");
+  p.Do = (p.T + 2 * p.pd - p.kd) / p.sd + 1; p.Ho = (p.H + 2 * p.ph - p.kh) / p.sh + 1; p.Wo = (dims4[3] + 6 - 7) / 2 + 1;
+  KVQ_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0, KVQ_ERR_SHAPE, "kvq_conv_stem_mfma: empty output");
+  const size_t lds = (size_t)p.kd * p.kh * 16 * 32 * 2;
+  KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_mfma: %zu B of weights exceed LDS", lds);
+  const long rows = (long)p.B * p.Do * p.Ho;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(conv_stem_mfma_kernel<Fp16>, grid, block, lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(conv_stem_mfma_kernel<Bf16>, grid, block, lds, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("conv_stem_mfma_kernel");
+  return KVQ_OK;
+}
 
 extern "C" int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_t strides5[5], const int32_t dims5[5],
                              const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int Kpad,

@@ -562,6 +562,37 @@ def patch_embed(x: torch.Tensor, w: torch.Tensor, bias, ln_w, ln_b, patch, *, ne
     return out, nxt
 
 
+def stem_mfma_pack_weight(w_kc: torch.Tensor, kernel, cin: int, out_dtype):
+    """[K][Cout] fp32 stem weight (K ordered kd,kh,kw,c; Cout <= 8, kw = 7, cin <= 4) -> the 16-bit [kd*kh][16][32] image of
+    ``kvq_conv_stem_mfma``: k = tap * 4 + c, zero rows / taps / channels as padding."""
+    kd, kh, kw = kernel
+    cout = w_kc.shape[1]
+    assert kw == 7 and cin <= 4 and cout <= 8 and w_kc.shape[0] == kd * kh * kw * cin
+    w = w_kc.reshape(kd * kh, kw, cin, cout).permute(0, 3, 1, 2)                 # [slice][o][tap][c]
+    img = torch.zeros(kd * kh, 16, 8, 4, dtype=torch.float32, device=w_kc.device)
+    img[:, :cout, :kw, :cin] = w
+    if out_dtype == torch.float16:
+        img = img.clamp(-65504.0, 65504.0)
+    return img.reshape(kd * kh, 16, 32).to(out_dtype).contiguous()
+
+
+def conv_stem_mfma(x: torch.Tensor, wpack: torch.Tensor, bias8: torch.Tensor, kernel, stride, pad, relu: bool):
+    """Conv3d(C <= 4 -> 8, (kd, kh, 7), stride (sd, sh, 2), padding (pd, ph, 3)) + bias [+ ReLU] on the matrix cores: x fp32
+    (B,C,T,H,W) contiguous -> 16-bit channels-last (B,Do,Ho,Wo,8).  ``wpack`` from ``stem_mfma_pack_weight``."""
+    _need_gpu(x, wpack, bias8)
+    assert x.dtype == torch.float32 and x.is_contiguous() and wpack.dtype in HALF_TYPES and bias8.numel() == 8
+    B, Cin, T, H, W = x.shape
+    x4 = torch.empty(B, T, H, W + 8, 4, dtype=wpack.dtype, device=x.device)
+    check(lib().kvq_pack_clip_cl4(ptr(x), C.byref((C.c_int32 * 5)(B, Cin, T, H, W)), 4, dtype_code(wpack.dtype), ptr(x4),
+                                  current_stream()), "kvq_pack_clip_cl4")
+    do, ho, wo = conv_out_dims((T, H, W), kernel, stride, pad)
+    out = torch.empty(B, do, ho, wo, 8, dtype=wpack.dtype, device=x.device)
+    check(lib().kvq_conv_stem_mfma(ptr(x4), C.byref((C.c_int32 * 4)(B, T, H, W)), ptr(wpack), ptr(bias8), C.byref(_i32x(kernel)),
+                                   C.byref(_i32x(stride)), C.byref(_i32x(pad)), int(relu), dtype_code(wpack.dtype), ptr(out),
+                                   current_stream()), "kvq_conv_stem_mfma")
+    return out
+
+
 def conv_stem_direct(x: torch.Tensor, w_kc: torch.Tensor, bias: torch.Tensor, kernel, stride, pad, relu: bool, out_dtype):
     """Direct Conv3d for few output channels: x fp32 (B,C,D,H,W), w_kc fp32 [K][Cout] (K ordered kd,kh,kw,c), -> 16-bit
     channels-last (B,Do,Ho,Wo,Cout)."""

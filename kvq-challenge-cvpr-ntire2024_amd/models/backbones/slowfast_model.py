@@ -71,6 +71,7 @@ def pack_pathway_output(frames, device=None):
 
 
 IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
+STEM_MFMA = os.environ.get("KVQ_STEM_MFMA", "1") != "0"             # 0: fast-pathway stem on the fp32 direct kernel
 
 
 class slowfast(nn.Module):  # noqa: N801  (reference spelling)
@@ -108,6 +109,10 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             w = (w * scale.view(-1, 1, 1, 1, 1)).permute(0, 2, 3, 4, 1).reshape(wshape[0], -1)
             if wshape[0] in (8, 16) and w.shape[1] > 256:        # few outputs, long patch: direct fp32 stem conv (conv.hip)
                 out[key + "/direct"] = w.t().contiguous()
+                kk = tuple(wshape[2:])
+                if wshape[0] == 8 and wshape[1] <= 4 and kk[2] == 7 and stride[2] == 2 and pad[2] == 3:
+                    # the same stem on the matrix cores (kvq_conv_stem_mfma): 16-bit [kd*kh][16][32] weight image
+                    out[key + "/mfma"] = kernels.stem_mfma_pack_weight(out[key + "/direct"], kk, wshape[1], half)
             kpad = -(-w.shape[1] // 32) * 32
             if kpad != w.shape[1]:
                 w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
@@ -158,10 +163,14 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         shape = (x16.shape[0], d, h, w, spec[0].shape[0])
         return y16.reshape(shape), y32.reshape(shape)
 
-    def _stem(self, x, spec, half, direct=None):
+    def _stem(self, x, spec, half, direct=None, mfma=None):
         B, C, T, H, W = x.shape
         wt, bias, k, stride, pad = spec
-        if direct is not None:      # fast pathway: 3 -> 8 channels, k 5x7x7: the patch matrix would be 4.7 GB for 8 clips
+        if mfma is not None and STEM_MFMA:
+            # fast pathway: 3 -> 8 channels, k 5x7x7 (the patch matrix would be 4.7 GB for 8 clips): clip packed to 4-channel
+            # 16-bit rows, one MFMA k-slice per kernel row (1.51 -> 0.63 ms for 8 clips against the fp32 direct kernel)
+            y = kernels.conv_stem_mfma(x.contiguous(), mfma, bias, k, stride, pad, True)
+        elif direct is not None:
             y = kernels.conv_stem_direct(x, direct, bias, k, stride, pad, True, half)
         elif IMPLICIT_CONV and C <= 8 and k[0] == 1 and os.environ.get("KVQ_STEM_IMPLICIT", "1") != "0":
             # slow pathway: 3 -> 64 channels, k 1x7x7: implicit GEMM over the clip packed to 8 channels (no 147-column patch matrix)
@@ -192,7 +201,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         fe = "feature_extraction."
         slow = self._stem(slow_in.float().contiguous(), W[fe + "0.multipathway_blocks.0"], half)
         fast = self._stem(fast_in.float().contiguous(), W[fe + "0.multipathway_blocks.1"], half,
-                          W.get(fe + "0.multipathway_blocks.1/direct"))
+                          W.get(fe + "0.multipathway_blocks.1/direct"), W.get(fe + "0.multipathway_blocks.1/mfma"))
         slow = torch.cat([slow, self._conv_relu(fast, W[fe + "0.multipathway_fusion"])], dim=-1)
         s32 = f32 = None
         for si in range(4):

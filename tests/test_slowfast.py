@@ -73,3 +73,33 @@ def test_conv_stem_direct_vs_torch_conv3d(shape, kernel, stride, pad, cout):
     ref = torch.relu(torch.nn.functional.conv3d(x.double(), w5.double(), bias.double(), stride, pad)).permute(0, 2, 3, 4, 1).float()
     assert out.shape == ref.shape
     assert (out - ref).abs().max().item() <= 2.0 ** -10 * max(1.0, ref.abs().max().item())      # fp32 accumulate, one fp16 rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,kernel,stride,pad", [
+    ((2, 3, 6, 30, 46), (5, 7, 7), (1, 2, 2), (2, 3, 3)),      # fast-pathway stem geometry; Wo = 23: ragged last tile
+    ((1, 3, 4, 18, 250), (1, 7, 7), (1, 2, 2), (0, 3, 3)),     # Wo = 125 > 112: second pass of the 7-tile loop
+    ((1, 2, 3, 9, 16), (3, 3, 7), (2, 1, 2), (1, 1, 3)),       # two channels, other kd / kh / strides
+])
+def test_conv_stem_mfma_vs_torch_conv3d(shape, kernel, stride, pad, dtype):
+    """kvq_pack_clip_cl4 + kvq_conv_stem_mfma (16-bit operands, fp32 accumulate) against F.conv3d of the ROUNDED operands + bias +
+    ReLU; and against the fp32 direct kernel within the operand rounding."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(sum(shape)))
+    cin, cout = shape[1], 8
+    x = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+    K = kernel[0] * kernel[1] * kernel[2] * cin
+    w5 = torch.from_numpy((g.standard_normal((cout, cin) + kernel) / np.sqrt(K)).astype(np.float32))
+    bias = torch.from_numpy(g.standard_normal(cout).astype(np.float32))
+    w_kc = w5.permute(2, 3, 4, 1, 0).reshape(K, cout).contiguous()
+    wp = kernels.stem_mfma_pack_weight(w_kc.cuda(), kernel, cin, dtype)
+    out = kernels.conv_stem_mfma(x.cuda(), wp, bias.cuda(), kernel, stride, pad, True).float().cpu()
+    xr, wr = x.to(dtype).double(), w5.to(dtype).double()
+    ref = torch.relu(torch.nn.functional.conv3d(xr, wr, bias.double(), stride, pad)).permute(0, 2, 3, 4, 1).float()
+    assert out.shape == ref.shape
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert (out - ref).abs().max().item() <= ulp * max(1.0, ref.abs().max().item())
+    if cin == 3:
+        direct = kernels.conv_stem_direct(x.cuda(), w_kc.cuda(), bias.cuda(), kernel, stride, pad, True, dtype).float().cpu()
+        assert (out - direct).abs().max().item() <= (3e-2 if dtype == torch.float16 else 2e-1)

@@ -1,0 +1,18 @@
+"""SlowFast fast-pathway stem (Conv3d 3 -> 8, 5x7x7, stride 1x2x2) on 8 clips of 32 x 224 x 224: fp32 direct kernel vs MFMA kernel."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import kvq_amd  # noqa
+from kvq_amd import kernels
+x = torch.randn(8, 3, 32, 224, 224, device="cuda")
+k, s, p = (5, 7, 7), (1, 2, 2), (2, 3, 3)
+w = torch.randn(735, 8, device="cuda") / 27
+b = torch.randn(8, device="cuda")
+wp = kernels.stem_mfma_pack_weight(w, k, 3, torch.float16)
+def t(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) * 100
+print(f"direct fp32: {t(lambda: kernels.conv_stem_direct(x, w, b, k, s, p, True, torch.float16)):.3f} ms   "
+      f"mfma (pack + conv): {t(lambda: kernels.conv_stem_mfma(x, wp, b, k, s, p, True)):.3f} ms")
