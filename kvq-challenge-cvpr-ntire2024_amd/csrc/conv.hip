@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_stem_direct_kernel(StemParams p) {
 // bound by its loads (24 TFLOP/s).  Here the clip is packed once to 16-bit channels-last with FOUR channels and a zero border
 // of 4 pixels left and right (B, T, H, W + 8, 4): the 8 taps (7 + a zero-weight one) x 4 channels of one kernel ROW are 32
 // consecutive k values = one v_mfma_f32_16x16x32 slice, and a lane's 8 k values (2 adjacent taps x 4 channels) are 16
-// contiguous bytes of the packed clip — the B fragment is loaded straight from global memory / L1 (no LDS, no patch matrix).
+// contiguous bytes of the packed clip — no patch matrix; a wave stages the row segment it needs in LDS and reads the fragments there.
 // C[channel][position]: A = weights [16 rows (8 used)][32 k] per (kd, kh) from LDS, B = 16 adjacent output columns.  A wave
 // owns one output row (up to 7 tiles of 16 columns), so a weight fragment is read once per 7 MFMAs.
 template <typename E>
@@ -394,29 +394,42 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
   const long b = row / ((long)p.Ho * p.Do);
   constexpr int NT = 7;
   using v8 = typename E::v8;
+  // per-wave staging of the input row segment (256 pixels x 4 channels = 2 KB): the 16 x 8-tap patches of a tile overlap 3.4x,
+  // so fetching them per lane from global memory makes the texture-address path the bound (14 loads per kernel row and wave);
+  // here a wave fetches the segment once (2 coalesced 16-byte loads per lane) and the fragments come out of LDS
+  uint16_t* seg = wl + (size_t)nsl * 512 + (tid >> 6) * 1024;
+  // the taps inside the clip form a box [a_lo, a_hi) x [r_lo, r_hi)
+  const int t0 = dq * p.sd - p.pd, y0 = ho * p.sh - p.ph;
+  const int a_lo = max(0, -t0), a_hi = min(p.kd, p.T - t0), r_lo = max(0, -y0), r_hi = min(p.kh, p.H - y0);
+  const int nr = r_hi - r_lo, ns = (a_hi - a_lo) * nr;
   for (int w0 = 0; w0 < p.Wo; w0 += 16 * NT) {
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int a = 0; a < p.kd; ++a) {
-      const int t = dq * p.sd - p.pd + a;
-      if (t < 0 || t >= p.T) continue;
-      for (int r = 0; r < p.kh; ++r) {
-        const int y = ho * p.sh - p.ph + r;
-        if (y < 0 || y >= p.H) continue;
-        const v8 wa = *reinterpret_cast<const v8*>(wl + ((a * p.kh + r) * 16 + n) * 32 + kg * 8);
-        const uint16_t* rowp = p.x4 + (((b * p.T + t) * (long)p.H + y) * p.Wp) * 4;
+    const int px0 = 2 * w0 + 2 * lane, px1 = px0 + 128;              // this lane's two pixel pairs of the segment (bordered row)
+    auto gload = [&](int sidx, u32x4& v0, u32x4& v1) {
+      const int a = a_lo + sidx / nr, r = r_lo + sidx % nr;
+      const uint16_t* rowp = p.x4 + (((b * p.T + t0 + a) * (long)p.H + y0 + r) * p.Wp) * 4;
+      v0 = px0 + 1 < p.Wp ? *reinterpret_cast<const u32x4*>(rowp + (size_t)px0 * 4) : (u32x4){0u, 0u, 0u, 0u};
+      v1 = px1 + 1 < p.Wp ? *reinterpret_cast<const u32x4*>(rowp + (size_t)px1 * 4) : (u32x4){0u, 0u, 0u, 0u};
+    };
+    u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = {0u, 0u, 0u, 0u};
+    if (ns > 0) gload(0, g0, g1);
+    for (int sidx = 0; sidx < ns; ++sidx) {
+      __builtin_amdgcn_wave_barrier();                                 // the previous row's fragment reads are issued
+      *reinterpret_cast<u32x4*>(seg + lane * 8) = g0;
+      *reinterpret_cast<u32x4*>(seg + 512 + lane * 8) = g1;
+      __builtin_amdgcn_wave_barrier();
+      if (sidx + 1 < ns) gload(sidx + 1, g0, g1);                      // in flight under this row's MFMAs
+      const int a = a_lo + sidx / nr, r = r_lo + sidx % nr;
+      const v8 wa = *reinterpret_cast<const v8*>(wl + ((a * p.kh + r) * 16 + n) * 32 + kg * 8);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int wo = w0 + j * 16 + n;
-          u32x4 raw = {0u, 0u, 0u, 0u};
-          if (wo < p.Wo) {                                   // pixel 2*wo - 3 + 2*kg of the image = + 4 in the bordered row
-            const uint16_t* src = rowp + (size_t)(2 * wo + 1 + 2 * kg) * 4;
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 4);
-            raw = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-          }
-          acc[j] = E::mfma16(wa, __builtin_bit_cast(v8, raw), acc[j]);
-        }
+      for (int j = 0; j < NT; ++j) {
+        // pixel 2*wo - 3 + 2*kg of the image = 2*wo + 1 + 2*kg of the bordered row = + 2*(j*16 + n) + 1 + 2*kg of the segment
+        const uint16_t* src = seg + (size_t)(2 * (j * 16 + n) + 1 + 2 * kg) * 4;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 4);
+        const u32x4 raw = {lo[0], lo[1], hi[0], hi[1]};
+        acc[j] = E::mfma16(wa, __builtin_bit_cast(v8, raw), acc[j]);
       }
     }
     if (kg < 2) {                                            // lanes 0..31 hold channels kg*4 .. +3 of position n
@@ -469,8 +482,9 @@ extern "C" int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], co
               "kvq_conv_stem_mfma: bad shape");
   p.Do = (p.T + 2 * p.pd - p.kd) / p.sd + 1; p.Ho = (p.H + 2 * p.ph - p.kh) / p.sh + 1; p.Wo = (dims4[3] + 6 - 7) / 2 + 1;
   KVQ_REQUIRE(p.Do > 0 && p.Ho > 0 && p.Wo > 0, KVQ_ERR_SHAPE, "kvq_conv_stem_mfma: empty output");
-  const size_t lds = (size_t)p.kd * p.kh * 16 * 32 * 2;
+  const size_t lds = (size_t)p.kd * p.kh * 16 * 32 * 2 + 4 * 2048;       // weights + a 2 KB row segment per wave
   KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_mfma: %zu B of weights exceed LDS", lds);
+  KVQ_REQUIRE(p.Wp % 2 == 0 && (((size_t)x4) & 15) == 0, KVQ_ERR_SHAPE, "kvq_conv_stem_mfma: W must be even and x4 16-byte aligned");
   const long rows = (long)p.B * p.Do * p.Ho;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(conv_stem_mfma_kernel<Fp16>, grid, block, lds, (hipStream_t)stream, p);
