@@ -406,12 +406,20 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int px0 = 2 * w0 + 2 * lane, px1 = px0 + 128;              // this lane's two pixel pairs of the segment (bordered row)
+    // this lane's two pixel pairs of the segment.  The segment starts at the ODD pixel 2*w0 + 1 of the bordered row (the first
+    // tap of output column w0), so that every fragment below is a 16-byte ALIGNED LDS read; the global side then sits on 8-byte
+    // boundaries and is fetched as two 8-byte halves
+    const int px0 = 2 * w0 + 1 + 2 * lane, px1 = px0 + 128;
+    auto pair = [&](const uint16_t* rowp, int px) -> u32x4 {
+      if (px + 1 >= p.Wp) return (u32x4){0u, 0u, 0u, 0u};
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(rowp + (size_t)px * 4), hi = *reinterpret_cast<const u32x2*>(rowp + (size_t)px * 4 + 4);
+      return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    };
     auto gload = [&](int sidx, u32x4& v0, u32x4& v1) {
       const int a = a_lo + sidx / nr, r = r_lo + sidx % nr;
       const uint16_t* rowp = p.x4 + (((b * p.T + t0 + a) * (long)p.H + y0 + r) * p.Wp) * 4;
-      v0 = px0 + 1 < p.Wp ? *reinterpret_cast<const u32x4*>(rowp + (size_t)px0 * 4) : (u32x4){0u, 0u, 0u, 0u};
-      v1 = px1 + 1 < p.Wp ? *reinterpret_cast<const u32x4*>(rowp + (size_t)px1 * 4) : (u32x4){0u, 0u, 0u, 0u};
+      v0 = pair(rowp, px0);
+      v1 = pair(rowp, px1);
     };
     u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = {0u, 0u, 0u, 0u};
     if (ns > 0) gload(0, g0, g1);
@@ -425,10 +433,8 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
       const v8 wa = *reinterpret_cast<const v8*>(wl + ((a * p.kh + r) * 16 + n) * 32 + kg * 8);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        // pixel 2*wo - 3 + 2*kg of the image = 2*wo + 1 + 2*kg of the bordered row = + 2*(j*16 + n) + 1 + 2*kg of the segment
-        const uint16_t* src = seg + (size_t)(2 * (j * 16 + n) + 1 + 2 * kg) * 4;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 4);
-        const u32x4 raw = {lo[0], lo[1], hi[0], hi[1]};
+        // pixel 2*wo - 3 + 2*kg of the image = 2*wo + 1 + 2*kg of the bordered row = 2*(j*16 + n) + 2*kg of the segment
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(seg + (size_t)(2 * (j * 16 + n) + 2 * kg) * 4);
         acc[j] = E::mfma16(wa, __builtin_bit_cast(v8, raw), acc[j]);
       }
     }

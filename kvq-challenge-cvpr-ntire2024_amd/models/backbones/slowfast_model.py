@@ -168,7 +168,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         wt, bias, k, stride, pad = spec
         if mfma is not None and STEM_MFMA:
             # fast pathway: 3 -> 8 channels, k 5x7x7 (the patch matrix would be 4.7 GB for 8 clips): clip packed to 4-channel
-            # 16-bit rows, one MFMA k-slice per kernel row (1.51 -> 0.33 ms for 8 clips against the fp32 direct kernel)
+            # 16-bit rows, one MFMA k-slice per kernel row (1.51 -> 0.26 ms for 8 clips against the fp32 direct kernel)
             y = kernels.conv_stem_mfma(x.contiguous(), mfma, bias, k, stride, pad, True)
         elif direct is not None:
             y = kernels.conv_stem_direct(x, direct, bias, k, stride, pad, True, half)
