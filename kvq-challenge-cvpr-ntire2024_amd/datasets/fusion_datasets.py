@@ -276,6 +276,7 @@ class _Staging:
 
 
 _COPY_POOL = None
+_COPY_THREADS = max(1, int(os.environ.get("KVQ_COPY_THREADS", 4)))
 
 
 def _frames_to_device(vr, uniq, device):
@@ -292,8 +293,8 @@ def _frames_to_device(vr, uniq, device):
     if hasattr(vr, "read_into"):
         if _COPY_POOL is None:
             from concurrent.futures import ThreadPoolExecutor
-            _COPY_POOL = ThreadPoolExecutor(max_workers=int(os.environ.get("KVQ_COPY_THREADS", 4)), thread_name_prefix="kvq-copy")
-        nt = max(1, min(_COPY_POOL._max_workers, n // 8))
+            _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="kvq-copy")
+        nt = max(1, min(_COPY_THREADS, n // 8))
         bounds = np.linspace(0, n, nt + 1).astype(int)
         jobs = [_COPY_POOL.submit(vr.read_into, uniq[a:b], host[a:b]) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
         for j in jobs:
