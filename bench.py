@@ -1,13 +1,21 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path (BASELINE.json metric): videos/sec of the Swin3D-T(GRPB) trunk + VQAHead
-on synthetic 8-fragment x 32 x 224 x 224 clips ("video" = 8 clips), inputs resident in HBM.
+"""Benchmark of the hot path (BASELINE.json metric): videos/sec of the per-video forward on synthetic
+8-fragment x 32 x 224 x 224 clips ("video" = 8 clips).
 
     python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run)
 
-A "step" = one forward of the hot path over one batch of ``--batch`` clips per GPU (default 4 =
-BASELINE.json configs[1], "C2").  Prints ONE JSON line on rank 0 with the contract's keys plus
-``roofline`` (dominant kernel: algorithmic flops / hipEvent-measured launch time vs the dense
-MFMA peak) and ``cpu_baseline`` (the CPU oracle timed on this box's host cores, N=1 only).
+Headline leg = C2 (BASELINE.json configs[1]): a "step" = one pass of the hot path over one batch of ``--batch`` clips per
+GPU (default 4): K1 (``kvq_fragment_gather``: 7x7 grid of 32x32 mini-patches + normalisation) out of a
+uint8 frame stack resident in HBM -> Swin3D-T(GRPB) trunk -> VQAHead.  Every step reads DIFFERENT source clips.
+One JSON line on rank 0 with the contract's keys plus
+  roofline      dominant kernel of the C2 step: algorithmic flops / hipEvent-measured launch time vs the dense MFMA peak
+  cpu_baseline  the CPU oracle timed on this box's host cores (N = 1 only)
+  no_sampler    the same steps on pre-sampled fp32 clips (K1 outside the timed region; the round-1 definition)
+  bf16          the same steps with bf16 operands (BASELINE names bf16; fp16 is the default because it holds the 1e-3
+                parity gate) and the max |delta score| against the fp16 scores of the same clips
+  c3            BASELINE configs[2]: Swin3D-T + SlowFast-R50 on the same 8 clips (1 video per step)
+  c5            BASELINE configs[4]: Swin-B on 64x256x256 clips, fp16 (video = 16 clips)
+(the extra legs run at N = 1; ``--legs c2`` skips them).
 """
 import argparse
 import json
@@ -22,32 +30,33 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/fp16, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
 CLIPS_PER_VIDEO = 8
 SWIN_T_GFLOP_PER_CLIP = 175.53   # SURVEY.md §8d (2*MAC, GEMM-only, padding as the reference pads)
+SWIN_B_GFLOP_PER_CLIP = 1892.3   # Swin-B on 64x256x256
+SRC_H, SRC_W = 540, 960          # post-decode frame size of the synthetic source
+MEAN, STD = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)     # fusion_datasets.py:953-954
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the first ~20 steps (35 ms) after start-up run ~5 % slower (clocks / queues still ramping); 10 + 60 steps of
-    # 1.7 ms measure the steady state a 900-video job sees and still finish in a blink
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU per step (C2: 4)")
     ap.add_argument("--dtype", default=os.environ.get("KVQ_OPERAND_DTYPE", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--no-sampler", action="store_true",
+                    help="headline on pre-sampled fp32 clips (K1 outside the timed region); default: K1 inside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=6)
-    ap.add_argument("--overlap", choices=["batch", "steps"], default="steps",
-                    help="with --streams > 1: 'batch' splits each step's clips over the streams, 'steps' sends whole "
-                         "consecutive steps to alternating streams")
+    ap.add_argument("--cpu-clips", type=int, default=24, help="clips the CPU oracle is timed on (24 = 3 videos)")
     ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the steps are issued on (independent batches: the VALU-bound attention of one "
-                         "can overlap the MFMA-bound GEMMs of another, launch gaps and tails are filled)")
+                    help="HIP streams consecutive steps alternate over (independent batches fill each other's launch gaps)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("KVQ_BENCH_GRAPH", "0")),
-                    help="1: capture one step per stream in a hipGraph (static inputs, resident in HBM) and replay it")
+                    help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
+    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,c3,c5 ('all', 'c2' = none)")
+    ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")
     ap.add_argument("--profile-steps", type=int, default=3)
     return ap.parse_args()
 
 
-def build_net(dtype, device):
+def build_net(dtype, device, cfg_name="swin_tiny_grpb"):
     import torch
     import kvq_amd  # noqa: F401
     from kvq_amd import _abi
@@ -89,15 +98,216 @@ def cpu_baseline(cfg, wts, hw, n_clips):
     except OSError:
         pass
     return {"value": n_clips / CLIPS_PER_VIDEO / dt, "unit": "videos/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n_clips} clips of 3x32x224x224 (= {n_clips / CLIPS_PER_VIDEO:g} video), "
-            f"B=1 per forward, fp32 torch CPU oracle, {dt:.1f} s", "cpu": model}
+            "kind": "port", "sample": f"{n_clips} clips of 3x32x224x224 (= {n_clips / CLIPS_PER_VIDEO:g} videos), "
+            f"B=1 per forward, fp32 torch CPU oracle, trunk + head (the CPU sampler is not in it), {dt:.1f} s", "cpu": model}
+
+
+class Source:
+    """Synthetic post-decode frames in HBM: ``n`` uint8 clips (3, 32, 540, 960) — a video's (3, 256, 540, 960) stack is 8
+    consecutive clips — i.i.d. uniform bytes, plus each clip's 7 x 7 x 4 sampler origins (hoff, woff: grid origin
+    ``min(H//7*i, H-32)`` + U{0..H//7-32-1}, one draw per 8-frame block, fusion_datasets.py:64-98) drawn on the host from
+    ``torch.Generator().manual_seed(1234 + clip)``."""
+
+    def __init__(self, n, device, seed):
+        import torch
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.clips = [torch.randint(0, 256, (3, 32, SRC_H, SRC_W), dtype=torch.uint8, device=device, generator=g)
+                      for _ in range(n)]
+        gh = torch.tensor([min(SRC_H // 7 * i, SRC_H - 32) for i in range(7)]).view(7, 1, 1)
+        gw = torch.tensor([min(SRC_W // 7 * i, SRC_W - 32) for i in range(7)]).view(1, 7, 1)
+        self.hoff, self.woff = [], []
+        for i in range(n):
+            cg = torch.Generator().manual_seed(seed * 100003 + i)
+            rh = torch.randint(SRC_H // 7 - 32, (7, 7, 4), generator=cg)
+            rw = torch.randint(SRC_W // 7 - 32, (7, 7, 4), generator=cg)
+            self.hoff.append((rh + gh).int().to(device))
+            self.woff.append((rw + gw).int().to(device))
+        self.n = n
+
+    def sample_into(self, x, first):
+        """K1: clips first .. first+B-1 (mod pool) -> the (B, 3, 32, 224, 224) fp32 batch tensor ``x``, normalised."""
+        from kvq_amd import kernels
+        for b in range(x.shape[0]):
+            i = (first + b) % self.n
+            kernels.fragment_gather(self.clips[i], self.hoff[i], self.woff[i], 7, 7, 32, 32, 8, MEAN, STD, out=x[b])
+
+
+def run_lanes(lanes, n, fn):
+    """consecutive steps (whole batches, independent of each other) go to alternating HIP streams; all n steps are enqueued,
+    the caller synchronises.  fn(step, lane_index) enqueues one step on the CURRENT stream and returns its output."""
+    import torch
+    main = torch.cuda.current_stream()
+    for st in lanes[1:]:
+        st.wait_stream(main)
+    outs = []
+    for s in range(n):
+        with torch.cuda.stream(lanes[s % len(lanes)]):
+            outs.append(fn(s, s % len(lanes)))
+    for st in lanes[1:]:
+        main.wait_stream(st)
+    return outs
+
+
+def timed(kd, device, fn_steps, steps, warmup, finish=None):
+    """W untimed steps, barrier + sync, K timed steps (+ ``finish``: the path's exchange step), sync + barrier; max over ranks."""
+    import torch
+    fn_steps(warmup, 0)
+    torch.cuda.synchronize()
+    kd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = fn_steps(steps, warmup)
+    extra = finish(outs) if finish is not None else None
+    torch.cuda.synchronize()
+    kd.barrier()
+    torch.cuda.synchronize()
+    return kd.max_over_ranks(time.perf_counter() - t0, device), outs, extra
+
+
+def c2_roofline(net, inputs, B, profile_steps):
+    import torch
+    bb = net.swin_tiny_grpb_backbone
+    dev = inputs["technical"].device
+    bb.profile(B, 32, 224, 224, dev, True)
+    with torch.no_grad():
+        for _ in range(profile_steps):
+            net(inputs=inputs, reduce_scores=True)
+    recs = bb.profile_read(B, 32, 224, 224, dev)
+    bb.profile(B, 32, 224, 224, dev, False)
+    agg = {}
+    for r in recs:
+        a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+        a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["n"] += 1
+    total_ms = sum(a["ms"] for a in agg.values())
+    name, top = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    if top["flops"] > 0:
+        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                "traffic": None}
+    else:
+        ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    # HBM traffic of that kernel: PMC counters cannot be read from inside this process — they come from a SEPARATE
+    # `rocprofv3 --pmc` pass over this same command (tools/pmc_traffic.py -> profiles/pmc_traffic.json; FETCH_SIZE x2 as the
+    # gfx950 guide prescribes), per launch like `achieved`; null when that file has no row for the kernel
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        row = pmc["kernels"].get(name)
+        if row:
+            roof["traffic"] = row["fetch_bytes"] + row["write_bytes"]
+            roof["traffic_source"] = f"profiles/pmc_traffic.json ({pmc.get('build', 'separate rocprofv3 --pmc pass')})"
+    except (OSError, ValueError, KeyError):
+        pass
+    roof.update({"kernel": name, "launches_per_step": top["n"] / profile_steps, "avg_launch_us": 1e3 * top["ms"] / top["n"],
+                 "share_of_gpu_time": top["ms"] / total_ms, "alg_flops_per_launch": top["flops"] / top["n"],
+                 "alg_bytes_per_launch": top["bytes"] / top["n"], "step_gpu_ms": total_ms / profile_steps,
+                 "whole_step_tflops": SWIN_T_GFLOP_PER_CLIP * B / (total_ms / profile_steps),
+                 "whole_step_frac": SWIN_T_GFLOP_PER_CLIP * B / (total_ms / profile_steps) / MFMA_PEAK_TFLOPS,
+                 "by_kernel_ms_per_step": {k: round(v["ms"] / profile_steps, 4)
+                                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}})
+    return roof
+
+
+def leg_c3(args, device, net, src, kd):
+    """configs[2]: one video (8 clips) per step: K1 -> Swin3D-T + head on one stream, pathway packing + SlowFast-R50 (blocks
+    0-4 + pools) on a second stream, both from the same sampled batch; consecutive videos alternate over two lane pairs."""
+    import torch
+    from kvq_amd.models.backbones.slowfast_model import conv_flops, pack_pathway_output, slowfast
+    sf = slowfast(operand_dtype=args.dtype).to(device).eval()
+    B = 8
+    nl = 2
+    swin_st = [torch.cuda.Stream(device=device) for _ in range(nl)]
+    sf_st = [torch.cuda.Stream(device=device) for _ in range(nl)]
+    xs = [torch.empty(B, 3, 32, 224, 224, device=device) for _ in range(nl)]
+    with torch.no_grad():
+        for ln in range(nl):
+            with torch.cuda.stream(swin_st[ln]):
+                net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
+        torch.cuda.synchronize()
+
+    def steps(n, first):
+        main = torch.cuda.current_stream()
+        for st in swin_st + sf_st:
+            st.wait_stream(main)
+        outs = []
+        for s in range(n):
+            ln = s % nl
+            with torch.cuda.stream(swin_st[ln]):
+                swin_st[ln].wait_stream(sf_st[ln])               # the lane's previous SlowFast pass still reads xs[ln]
+                src.sample_into(xs[ln], (first + s) * B)
+                sampled = torch.cuda.Event()
+                sampled.record()
+                score = net(inputs={"technical": xs[ln]}, reduce_scores=True)
+            with torch.cuda.stream(sf_st[ln]):
+                sf_st[ln].wait_event(sampled)
+                slow_f, fast_f = sf(pack_pathway_output(xs[ln]))
+            outs.append((score, slow_f, fast_f))
+        for st in swin_st + sf_st:
+            main.wait_stream(st)
+        return outs
+
+    k = max(2, min(args.steps, 20))
+    with torch.no_grad():
+        dt, outs, _ = timed(kd, device, steps, k, max(2, min(args.warmup, 5)))
+    sf_flops, _ = conv_flops(32, 224, 224)
+    flops = B * (SWIN_T_GFLOP_PER_CLIP * 1e9 + sf_flops)
+    ach = flops * k / dt / 1e12
+    finite = all(bool(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() and torch.isfinite(o[2]).all()) for o in outs[-2:])
+    return {"workload": "C3: K1 + Swin3D-T(GRPB) trunk + VQAHead and SlowFast-R50 (blocks 0-4 + pools) on the same 8 clips, "
+            "1 video per step, two branches on two HIP streams", "value": k / dt, "unit": "videos/s", "steps": k,
+            "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": args.dtype, "finite": finite,
+            "alg_gflop_per_clip": {"swin3d_t": SWIN_T_GFLOP_PER_CLIP, "slowfast_r50": sf_flops / 1e9,
+                                   "slowfast_counted_from": "kvq_amd.models.backbones.slowfast_model.conv_flops (2*MAC of every Conv3d "
+                                   "of the restated pytorchvideo R50 8x8, the shapes oracle/slowfast_oracle.py runs)"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                         "scope": "whole step (both branches), wall time", "traffic": None,
+                         "per_kernel": "profiles/r02_c3_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/c3_probe.py)"}}
+
+
+def leg_c5(args, device, kd):
+    """configs[4]: Swin-B (E=128, depths 2/2/18/2, heads 4/8/16/32) on 64x256x256 clips, fp16 operands; video = 16 clips."""
+    import torch
+    from kvq_amd import _abi
+    from kvq_amd.models.backbones.swin_backbone import SwinTransformer3D
+    from kvq_amd.models.head import VQAHead
+    from kvq_amd.utils import synth
+    cfg = synth.SWIN_B_GRPB
+    bb = SwinTransformer3D(embed_dim=128, depths=list(cfg.depths), num_heads=list(cfg.num_heads)).to(device).eval()
+    bb.operand_dtype = _abi.dtype_code("fp16")
+    head = VQAHead(in_channels=1024, hidden_channels=64).to(device).eval()
+    B = 4
+    g = torch.Generator(device=device)
+    g.manual_seed(77)
+    pool = [torch.randn(B, 3, 64, 256, 256, device=device, generator=g) for _ in range(3)]     # 3 x 201 MB: distinct per step
+    lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device)]
+    with torch.no_grad():
+        for st in lanes:
+            with torch.cuda.stream(st):
+                bb.prepare(B, 64, 256, 256, device)
+        torch.cuda.synchronize()
+
+    def steps(n, first):
+        return run_lanes(lanes, n, lambda s, ln: head(bb({"technical": pool[(first + s) % len(pool)]})))
+
+    k = max(2, min(args.steps, 10))
+    with torch.no_grad():
+        dt, outs, _ = timed(kd, device, steps, k, 2)
+    ach = SWIN_B_GFLOP_PER_CLIP * B * k / dt / 1e3
+    return {"workload": "C5: Swin-B(GRPB) trunk + VQAHead, 3x64x256x256 clips, fp16 operands, video = 16 clips", "value": B * k / 16.0 / dt,
+            "unit": "videos/s", "steps": k, "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": "fp16",
+            "finite": bool(torch.isfinite(torch.cat([o.reshape(-1) for o in outs])).all()),
+            "alg_gflop_per_clip": SWIN_B_GFLOP_PER_CLIP,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                         "scope": "whole step, wall time", "traffic": None,
+                         "per_kernel": "profiles/r02_c5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/swinb_probe.py)"}}
 
 
 def main():
     args = parse()
     import torch
     import kvq_amd  # noqa: F401
-    from kvq_amd import dist as kd
+    from kvq_amd import _abi, dist as kd
     from kvq_amd.utils import synth
 
     rank, local_rank, world = kd.init()
@@ -107,165 +317,154 @@ def main():
     device = torch.device("cuda", 0 if os.environ.get("KVQ_BENCH_ONE_GPU") else local_rank)
     torch.cuda.set_device(device)
     net, cfg, wts, hw = build_net(args.dtype, device)
+    bb = net.swin_tiny_grpb_backbone
     B = args.batch
-    # synthetic clips of this rank's shard, resident in HBM before the timed region
-    x = torch.from_numpy(synth.synth_clip(1234 + rank, 32, 224, 224, batch=B)).to(device)
-    inputs = {"technical": x}
-    scores = torch.zeros(args.steps, B, device=device)
     nstream = max(1, args.streams)
-    side = [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
-    parts = [{"technical": t.contiguous()} for t in x.chunk(nstream)]
-    by_step = args.overlap == "steps" and nstream > 1
+    lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
+    legs = {"no_sampler", "bf16", "c3", "c5"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
+    if world > 1:
+        legs = set()
 
-    def forward():
-        """one step = the whole batch once; with --streams > 1 the clips are split over HIP streams"""
-        if nstream == 1:
-            return net(inputs=inputs, reduce_scores=True).reshape(-1)
-        main = torch.cuda.current_stream()
-        outs = [None] * nstream
-        for st in side:
-            st.wait_stream(main)
-        for i, st in enumerate(side):
+    # ---- synthetic source of this rank's shard, resident in HBM before the timed region --------------------------------
+    need = (args.warmup + args.steps) * B
+    src = Source(min(need, max(B, args.src_pool)), device, 1234 + rank)
+    xs = [torch.empty(B, 3, 32, 224, 224, device=device) for _ in range(nstream)]      # one batch tensor per lane
+    with torch.no_grad():
+        for st in lanes:      # per-stream set-up (plans + workspaces: allocations), not steps: done before the warm-up
             with torch.cuda.stream(st):
-                outs[i + 1] = net(inputs=parts[i + 1], reduce_scores=True).reshape(-1)
-        outs[0] = net(inputs=parts[0], reduce_scores=True).reshape(-1)
-        for st in side:
-            main.wait_stream(st)
-        return torch.cat(outs)
+                bb.prepare(B, 32, 224, 224, device)
+        torch.cuda.synchronize()
+
+    def step_sampled(s, ln):
+        src.sample_into(xs[ln], s * B)
+        return net(inputs={"technical": xs[ln]}, reduce_scores=True)
+
+    # pre-sampled clips for the --no-sampler definition: K1 run once, outside the timed region, distinct per step
+    pre = None
+    if args.no_sampler or "no_sampler" in legs or args.graph:
+        npre = min(need, src.n) // B
+        pre = [torch.empty(B, 3, 32, 224, 224, device=device) for _ in range(max(1, npre))]
+        for i, t in enumerate(pre):
+            src.sample_into(t, i * B)
+        torch.cuda.synchronize()
+
+    def step_presampled(s, ln):
+        return net(inputs={"technical": pre[s % len(pre)]}, reduce_scores=True)
 
     graphs = []
+    if args.graph:            # one hipGraph per lane over a STATIC pre-sampled batch (replay measures launch overhead only)
+        with torch.no_grad():
+            for cap in [torch.cuda.Stream(device=device) for _ in range(nstream)]:
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    for _ in range(2):
+                        net(inputs={"technical": pre[0]}, reduce_scores=True)
+                cap.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    o = net(inputs={"technical": pre[0]}, reduce_scores=True)
+                graphs.append((g, o, cap))
+            torch.cuda.synchronize()
 
-    def capture():
-        """one hipGraph per lane: the lane's stream runs two eager steps (plans, workspaces, caches), then records a third"""
-        lanes = (side + [torch.cuda.Stream(device=device)]) if by_step else [torch.cuda.Stream(device=device)]
-        for cap in lanes:                                   # capture needs non-default streams
-            cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap):
-                for _ in range(2):
-                    net(inputs=inputs, reduce_scores=True)
-            cap.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
-                o = net(inputs=inputs, reduce_scores=True).reshape(-1)
-            graphs.append((g, o, cap))
-        torch.cuda.synchronize()
+    def steps_of(step_fn):
+        def run(n, first):
+            if graphs:
+                glanes = [g[2] for g in graphs]
+                main = torch.cuda.current_stream()
+                for st in glanes:
+                    st.wait_stream(main)
+                outs = []
+                for s in range(n):
+                    g, o, st = graphs[s % len(graphs)]
+                    with torch.cuda.stream(st):
+                        g.replay()
+                        outs.append(o.clone())
+                for st in glanes:
+                    main.wait_stream(st)
+                return outs
+            return run_lanes(lanes, n, lambda s, ln: step_fn(first + s, ln))
+        return run
 
-    def run_graphs(n, out):
-        main = torch.cuda.current_stream()
-        for _, _, st in graphs:
-            st.wait_stream(main)
-        for s in range(n):
-            g, o, st = graphs[s % len(graphs)]
-            with torch.cuda.stream(st):
-                g.replay()
-                out[s].copy_(o, non_blocking=True)
-        for _, _, st in graphs:
-            main.wait_stream(st)
-
-    def run_steps(n, out):
-        if graphs:
-            return run_graphs(n, out)
-        if not by_step:
-            for s in range(n):
-                out[s] = forward()
-            return
-        # consecutive steps (whole batches, independent of each other) go to alternating HIP streams: every launch keeps the
-        # full batch's grid, the streams fill each other's launch gaps and tails; all n steps end before the caller's sync
-        main = torch.cuda.current_stream()
-        lanes = [main] + side
-        for st in side:
-            st.wait_stream(main)
-        for s in range(n):
-            with torch.cuda.stream(lanes[s % nstream]):
-                out[s] = net(inputs=inputs, reduce_scores=True).reshape(-1)
-        for st in side:
-            main.wait_stream(st)
-
-    if by_step:      # per-stream set-up (plans + workspaces: allocations), not steps: done before the warm-up
-        for st in [torch.cuda.current_stream()] + side:
-            with torch.cuda.stream(st):
-                net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
-        torch.cuda.synchronize()
-    with torch.no_grad():
-        if args.graph:
-            capture()
-        run_steps(args.warmup, torch.zeros(max(args.warmup, 1), B, device=device))
-        torch.cuda.synchronize()
-        kd.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(args.steps, scores)
+    def finish(outs):
         # the path's one exchange step: all-gather of the per-rank score vectors (trainer_ddp.py:259-267)
-        local = scores.reshape(-1)
-        allscores = kd.gather_scores(local, local.numel() * world, rank, world) if world > 1 else local
-        torch.cuda.synchronize()
-        kd.barrier()
-        torch.cuda.synchronize()
-        dt = kd.max_over_ranks(time.perf_counter() - t0, device)
+        local = torch.cat([o.reshape(-1) for o in outs])
+        return kd.gather_scores(local, local.numel() * world, rank, world) if world > 1 else local
+
+    sampler_on = not (args.no_sampler or args.graph)
+    with torch.no_grad():
+        dt, outs, allscores = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps, args.warmup,
+                                    finish)
     clips = args.steps * B * world
     value = clips / CLIPS_PER_VIDEO / dt
+    fp_scores = torch.cat([o.reshape(-1) for o in outs]).float().cpu()
 
-    # ---- roofline of the dominant kernel: hipEvents around every launch, on the launch stream ----
-    roof = None
-    if rank == 0 and args.profile_steps > 0:
-        bb = net.swin_tiny_grpb_backbone
-        bb.profile(B, 32, 224, 224, device, True)
-        with torch.no_grad():
-            for _ in range(args.profile_steps):
-                net(inputs=inputs, reduce_scores=True)
-        recs = bb.profile_read(B, 32, 224, 224, device)
-        bb.profile(B, 32, 224, 224, device, False)
-        agg = {}
-        for r in recs:
-            a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
-            a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["n"] += 1
-        total_ms = sum(a["ms"] for a in agg.values())
-        name, top = max(agg.items(), key=lambda kv: kv[1]["ms"])
-        is_mfma = top["flops"] > 0
-        if is_mfma:
-            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None}
-        else:
-            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None}
-        # HBM traffic of that kernel: PMC counters from a SEPARATE rocprofv3 --pmc pass (tools/pmc_traffic.py ->
-        # profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction), per launch like `achieved`
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name)
-            if pmc:
-                roof["traffic"] = pmc["fetch_bytes"] + pmc["write_bytes"]
-        except (OSError, ValueError, KeyError):
-            pass
-        roof.update({"kernel": name, "launches_per_step": top["n"] / args.profile_steps,
-                     "avg_launch_us": 1e3 * top["ms"] / top["n"],
-                     "share_of_gpu_time": top["ms"] / total_ms,
-                     "alg_flops_per_launch": top["flops"] / top["n"], "alg_bytes_per_launch": top["bytes"] / top["n"],
-                     "step_gpu_ms": total_ms / args.profile_steps,
-                     "whole_step_tflops": SWIN_T_GFLOP_PER_CLIP * B / (total_ms / args.profile_steps),
-                     "by_kernel_ms_per_step": {k: round(v["ms"] / args.profile_steps, 4)
-                                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}})
+    out = None
     if rank == 0:
+        roof = None
+        if args.profile_steps > 0:
+            src.sample_into(xs[0], 0)
+            roof = c2_roofline(net, {"technical": xs[0]}, B, args.profile_steps)
         out = {
             "metric": "videos/sec (8-frag x 32 x 224 x 224)", "value": value, "unit": "videos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic (PCG64 clips + procedurally generated 'stress' weights, resident in HBM)",
-            "config": {"workload": "C2: KSVQE Swin3D-T(GRPB) trunk + VQAHead, 3x32x224x224 clips, video = 8 clips",
+            "data": "synthetic (uint8 frames i.i.d. uniform, seeded sampler offsets, procedurally generated 'stress' weights; "
+                    "all resident in HBM before the timed region)",
+            "config": {"workload": "C2: KSVQE Swin3D-T(GRPB) trunk + VQAHead, 3x32x224x224 clips, video = 8 clips"
+                                   + (", fragment sampler K1 (uint8 3x32x540x960 per clip -> 7x7 grid of 32x32 patches, normalised) "
+                                      "inside the step" if sampler_on else ", pre-sampled fp32 clips (K1 outside the step)"),
                        "clips_per_gpu_per_step": B, "operand_dtype": args.dtype, "accumulate": "fp32",
+                       "sampler_in_step": sampler_on, "source_pool_clips": src.n, "distinct_clips_per_step": True,
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
-                       "streams": nstream, "overlap": args.overlap if nstream > 1 else "none",
-                       "hipgraph": bool(args.graph)},
+                       "streams": nstream, "overlap": "steps" if nstream > 1 else "none", "hipgraph": bool(args.graph)},
             "clips_per_s": clips / dt,
             "model_tflops": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3,
+            "whole_job_frac_of_mfma_peak": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3 / MFMA_PEAK_TFLOPS / world,
             "score_checksum": float(allscores.double().sum().item()),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, wts, hw, args.cpu_clips)
-        else:
-            out["cpu_baseline"] = None
+    # ---- extra legs (N = 1): the other definitions / configs, each timed the same way -----------------------------------
+    if rank == 0 and world == 1:
+        with torch.no_grad():
+            if "no_sampler" in legs and sampler_on:
+                dt2, _, _ = timed(kd, device, steps_of(step_presampled), args.steps, min(args.warmup, 5))
+                out["no_sampler"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt2, "unit": "videos/s",
+                                     "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
+                                     "note": "same steps on pre-sampled fp32 clips (K1 outside the timed region, distinct clips per "
+                                             "step): the round-1 definition of the step"}
+            if "bf16" in legs and args.dtype == "fp16":
+                bb.operand_dtype = _abi.dtype_code("bf16")
+                for st in lanes:
+                    with torch.cuda.stream(st):
+                        bb.prepare(B, 32, 224, 224, device)
+                torch.cuda.synchronize()
+                dt3, outs3, _ = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
+                                      min(args.warmup, 5))
+                bf = torch.cat([o.reshape(-1) for o in outs3]).float().cpu()
+                out["bf16"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt3, "unit": "videos/s", "ms_per_step": 1e3 * dt3 / args.steps,
+                               "steps": args.steps, "max_abs_dscore_vs_fp16": float((bf - fp_scores).abs().max()),
+                               "parity": "bf16 operands do NOT hold the 1e-3 gate against the fp32 oracle on these 'stress' weights "
+                                         "(tests/test_gpu_e2e.py: 1.4e-3..3.1e-3; the 8-bit mantissa is the limit, DESIGN.md §2); fp16 "
+                                         "operands do (<= 3.6e-4) and are the default"}
+                bb.operand_dtype = _abi.dtype_code(args.dtype)
+                for st in lanes:
+                    with torch.cuda.stream(st):
+                        bb.prepare(B, 32, 224, 224, device)
+                torch.cuda.synchronize()
+        for name, fn in (("c3", lambda: leg_c3(args, device, net, src, kd)), ("c5", lambda: leg_c5(args, device, kd))):
+            if name in legs:
+                try:
+                    out[name] = fn()
+                except Exception as e:  # noqa: BLE001  (an extra leg must not take the headline line down with it)
+                    out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                torch.cuda.empty_cache()
+        out["parity_pins"] = ("Swin3D trunk / heads / sampler / ResNet-50: oracle bit-pinned to the imported reference; UNPINNED by "
+                              "necessity (packages absent here): SlowFast-R50 (pytorchvideo), torchvision Resize, CONTRIQUE's "
+                              "torchvision resnet50 (stand-in = the reference's own Bottleneck)")
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(cfg, wts, hw, args.cpu_clips)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -170,6 +170,7 @@ SYMBOLS = {
 }
 
 _lib: Optional[C.CDLL] = None
+_lib_lock = __import__("threading").Lock()      # lib() is entered from the prefetch thread too
 
 
 class KvqError(RuntimeError):
@@ -178,6 +179,14 @@ class KvqError(RuntimeError):
 
 def lib() -> C.CDLL:
     """Load (building first if missing/stale) libkvq_hip.so.  Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        return _load()
+
+
+def _load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
@@ -219,4 +228,16 @@ def ptr(t) -> Optional[int]:
 
 def current_stream() -> int:
     import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def stream_of(t) -> int:
+    """The launch stream for work on tensor ``t``: the CURRENT stream of the CURRENT device, which must be the tensor's
+    device — a pointer of another GPU handed to this device's stream would be a cross-device launch with no ordering
+    against the copies that produced it (rank r of a multi-GPU job must keep its data on cuda:r)."""
+    import torch
+    cur = torch.cuda.current_device()
+    if not t.is_cuda or t.device.index != cur:
+        raise KvqError(f"tensor lives on {t.device} but the current HIP device is cuda:{cur}: "
+                       "torch.cuda.set_device() to the tensor's device (or move the tensor) before calling the kernels")
     return torch.cuda.current_stream().cuda_stream

@@ -42,11 +42,26 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile + link under an inter-process file lock: N ranks of one torch.distributed.run job (or a prefetch thread and
+    the main thread) that all find the library missing must not write the same objects at once — the first builds, the
+    others wait on the lock and then find the library fresh."""
     if not force and not is_stale():
         return LIB
-    cc = _hipcc()
+    import fcntl
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():      # another process built it while this one waited
+                return LIB
+            return _build_locked(force, verbose, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool, objdir: str) -> str:
+    cc = _hipcc()
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -54,22 +69,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj
+        tmp = f"{obj}.{os.getpid()}.tmp"          # never leave a half-written object under the final name
         cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), []) + os.environ.get("KVQ_EXTRA_HIPCC_FLAGS", "").split()
-               + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj])
+               + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", tmp])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
         if verbose and r.stderr.strip():
             print(r.stderr[-2000:])
+        os.replace(tmp, obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(sources()))) as ex:
         objs = list(ex.map(compile_one, sources()))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"],
+    tmp = f"{LIB}.{os.getpid()}.tmp"
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)                          # atomic: a concurrent dlopen sees the old or the new file, never half
     return LIB
 
 

@@ -112,8 +112,8 @@ class SyntheticSimpleVQADataset(torch.utils.data.Dataset):
     ``data_prefix_3D/<video_name>/feature_{i}_{slow,fast}_feature.npy`` (:878-890) or, when
     ``compute_feat`` is set, produced in-process by the HIP SlowFast branch (BASELINE config C3)."""
 
-    def __init__(self, opt, namelist=None, device="cuda:0"):
-        self.opt, self.device = opt, torch.device(device)
+    def __init__(self, opt, namelist=None, device=None):
+        self.opt, self.device = opt, _default_device(device)
         self.n = int(opt.get("num_videos", 4))
         self.frames, self.h, self.w = int(opt.get("frames", 256)), int(opt.get("height", 540)), int(opt.get("width", 960))
         self.sopt = dict(opt["sample_types"]["simpleVQA"])
@@ -192,8 +192,8 @@ class SyntheticKVQDataset(torch.utils.data.Dataset):
     ``num_videos, frames, height, width, labels (optional list), sample_types.technical.{fragments_h,
     fragments_w, fsize_h, fsize_w, aligned, clip_len, frame_interval, num_clips}``."""
 
-    def __init__(self, opt, namelist=None, device="cuda:0"):
-        self.opt, self.device = opt, torch.device(device)
+    def __init__(self, opt, namelist=None, device=None):
+        self.opt, self.device = opt, _default_device(device)
         self.n = int(opt.get("num_videos", 8))
         self.frames, self.h, self.w = int(opt.get("frames", 256)), int(opt.get("height", 540)), int(opt.get("width", 960))
         self.sopt = dict(opt["sample_types"]["technical"])
@@ -211,6 +211,12 @@ class SyntheticKVQDataset(torch.utils.data.Dataset):
         from ..utils import synth
         s = self.sopt
         frames = torch.from_numpy(synth.synth_video_u8(1234 + i, self.frames, self.h, self.w))
+        if self.opt.get("seed_per_item"):
+            # the samplers draw from the process-global RNGs like the reference's (a1 / a2): seeding them per item makes item i
+            # the same whatever rank builds it and whatever was built before (the 1-rank vs N-rank rehearsal of C4)
+            np.random.seed(1234 + i)
+            _pyrandom.seed(1234 + i)
+            torch.manual_seed(1234 + i)
         inds = self.sampler(self.frames)
         clip = frames[:, torch.from_numpy(inds.astype(np.int64))].to(self.device)
         tech = get_spatial_fragments(clip, s["fragments_h"], s["fragments_w"], s["fsize_h"], s["fsize_w"],
@@ -342,7 +348,11 @@ def _build_samplers(sample_types, phase):
 
 
 def _default_device(device):
-    return torch.device(device if device is not None else "cuda:0")
+    """``None`` -> the process's CURRENT HIP device (rank r of a torch.distributed.run job has set cuda:r): the K1
+    kernels are launched on the current device's stream, so the frames must live there."""
+    if device is not None:
+        return torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
 
 
 class ViewDecompositionDataset_add_forSimpleVQA(torch.utils.data.Dataset):  # noqa: N801  (reference spelling)

@@ -31,11 +31,23 @@ class DevicePrefetcher:
                     item = self.dataset[i]
                     ready = torch.cuda.Event()
                     ready.record(self.stream)
-                self.queue.put((i, item, ready))
+                if not self._put((i, item, ready)):
+                    return
         except BaseException as e:  # noqa: BLE001  (re-raised in the consumer)
-            self.queue.put(e)
+            self._put(e)
             return
-        self.queue.put(None)
+        self._put(None)
+
+    def _put(self, x) -> bool:
+        """queue.put that gives up once close() was called: a worker blocked on a full queue must not outlive its consumer
+        (it would keep the item's device tensors and the pinned staging buffers alive)."""
+        while not self._stop:
+            try:
+                self.queue.put(x, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def __iter__(self):
         """Yields (index, item, ready): make the consuming stream ``wait_event(ready)`` before it touches the item, and call
@@ -55,7 +67,16 @@ class DevicePrefetcher:
                 v.record_stream(stream)
 
     def close(self):
+        """Stop the worker and JOIN it: the queue is drained until the thread has exited (a worker blocked in put wakes up,
+        sees ``_stop`` and returns), so no item, event or staging buffer survives an early exit of the consumer."""
         self._stop = True
+        while self.thread.is_alive():
+            try:
+                while True:
+                    self.queue.get_nowait()
+            except queue.Empty:
+                pass
+            self.thread.join(timeout=0.05)
         try:
             while True:
                 self.queue.get_nowait()

@@ -19,11 +19,18 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init(backend: str = None) -> Tuple[int, int, int]:
+def default_master_port() -> int:
+    """Rendezvous port when the launcher exported none (torch.distributed.run always does): derived from the PARENT pid,
+    which all ranks of one job share and two jobs on one node do not — a fixed 29500 makes concurrent jobs collide."""
+    return 20000 + (os.getppid() * 7919) % 20000
+
+
+def init(backend: str = None, force: bool = False) -> Tuple[int, int, int]:
+    """Join the job's process group (world > 1, or ``force`` for a 1-rank group: lets the RCCL path run on a 1-GPU box)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("MASTER_PORT", str(default_master_port()))
         if backend is None:
             backend = os.environ.get("KVQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
@@ -44,10 +51,15 @@ def gather_scores(local: torch.Tensor, n_items: int, rank: int, world: int) -> t
     rank.  One all_gather_into_tensor of a <1 KB vector: latency-bound, ring vs direct irrelevant."""
     per = -(-n_items // world)
     assert local.numel() == per
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local[:n_items].clone()
     dev = local.device
-    if dist.get_backend() == "gloo" and local.is_cuda:       # CPU-only backend (tests): stage through the host
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        # gloo moves host memory only.  Device scores through it are a TEST arrangement (N ranks sharing one GPU): it has to
+        # be asked for by name, a production job on GPUs runs RCCL ("nccl") and never stages through the host.
+        if os.environ.get("KVQ_DIST_BACKEND") != "gloo":
+            raise RuntimeError("score all-gather: the process group is gloo but the scores live on a GPU; use the nccl "
+                               "backend (RCCL), or set KVQ_DIST_BACKEND=gloo to stage through the host on purpose")
         local = local.cpu()
     out = torch.empty(world * per, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _abi
-from ._abi import check, current_stream, dtype_code, lib, ptr
+from ._abi import check, current_stream, dtype_code, lib, ptr, stream_of
 
 HALF_TYPES = (torch.float16, torch.bfloat16)
 
@@ -164,19 +164,23 @@ def simple_vqa_head(feat: torch.Tensor, w1, b1, w2, b2):
 
 
 def fragment_gather(video: torch.Tensor, hoff: torch.Tensor, woff: torch.Tensor, fragments_h, fragments_w,
-                    fsize_h, fsize_w, aligned, mean=None, std=None):
-    """video uint8/fp32 (C,T,H,W) on device; hoff/woff int32 (Fh,Fw,T//aligned) ABSOLUTE patch origins."""
+                    fsize_h, fsize_w, aligned, mean=None, std=None, out=None):
+    """video uint8/fp32 (C,T,H,W) on device; hoff/woff int32 (Fh,Fw,T//aligned) ABSOLUTE patch origins.
+    ``out``: optional fp32 (C,T,Fh*fs,Fw*fs) destination (e.g. one clip of a batch tensor) — no allocation, no copy."""
     _need_gpu(video, hoff, woff)
     assert video.dtype in (torch.uint8, torch.float32) and video.is_contiguous()
     Cc, T, H, W = video.shape
-    out = torch.empty(Cc, T, fragments_h * fsize_h, fragments_w * fsize_w, dtype=torch.float32,
-                      device=video.device)
+    shape = (Cc, T, fragments_h * fsize_h, fragments_w * fsize_w)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=video.device)
+    else:
+        assert tuple(out.shape) == shape and out.dtype == torch.float32 and out.is_contiguous() and out.device == video.device
     m = (C.c_float * Cc)(*mean) if mean is not None else None
     s = (C.c_float * Cc)(*std) if std is not None else None
     hoff, woff = hoff.contiguous(), woff.contiguous()
     check(lib().kvq_fragment_gather(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W, ptr(hoff), ptr(woff),
                                     fragments_h, fragments_w, fsize_h, fsize_w, aligned, m, s, ptr(out),
-                                    current_stream()), "kvq_fragment_gather")
+                                    stream_of(video)), "kvq_fragment_gather")
     return out
 
 
@@ -494,7 +498,7 @@ def resize_bilinear(video: torch.Tensor, rh: int, rw: int, crop=None, mean=None,
     s = (C.c_float * Cc)(*std) if std is not None else None
     rnd = int(video.dtype == torch.uint8) if round_u8 is None else int(round_u8)
     check(lib().kvq_resize_bilinear(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W, rh, rw, cy, cx, oh, ow,
-                                    rnd, m, s, ptr(out), current_stream()), "kvq_resize_bilinear")
+                                    rnd, m, s, ptr(out), stream_of(video)), "kvq_resize_bilinear")
     return out
 
 

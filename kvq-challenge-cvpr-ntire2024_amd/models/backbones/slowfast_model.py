@@ -50,6 +50,39 @@ def conv_table():
     return t
 
 
+def conv_flops(T=32, H=224, W=224):
+    """ALGORITHMIC flops (2 x MAC, convolutions only, padding taps counted as the reference's F.conv3d computes them) of ONE
+    clip through blocks 0-4, counted from ``conv_table()`` by walking the forward's shapes: slow pathway T/4 frames, fast
+    pathway T frames; stem stride (1,2,2) + max-pool (1,2,2); res2..res5 at H/4 .. H/32.  Returns (total, per-conv dict)."""
+    def out_sz(n, k, s, p):
+        return (n + 2 * p - k) // s + 1
+    per = OrderedDict()
+    fe = "feature_extraction."
+    tab = conv_table()
+    dims = {0: [T // 4, H, W], 1: [T, H, W]}                   # pathway -> current (D, H, W)
+    def conv(key, d3):
+        (co, ci, kd, kh, kw), st, pd = tab[key][0], tab[key][1], tab[key][2]
+        o = [out_sz(d3[0], kd, st[0], pd[0]), out_sz(d3[1], kh, st[1], pd[1]), out_sz(d3[2], kw, st[2], pd[2])]
+        per[key] = 2.0 * o[0] * o[1] * o[2] * co * ci * kd * kh * kw
+        return o
+    for pi in (0, 1):
+        d = conv(fe + f"0.multipathway_blocks.{pi}", dims[pi])
+        dims[pi] = [d[0], out_sz(d[1], 3, 2, 1), out_sz(d[2], 3, 2, 1)]            # MaxPool3d (1,3,3) / (1,2,2) / (0,1,1)
+    conv(fe + "0.multipathway_fusion", dims[1])
+    for si in range(4):
+        for pi in (0, 1):
+            for bi in range(DEPTHS[si]):
+                pre = fe + f"{si + 1}.multipathway_blocks.{pi}.res_blocks.{bi}"
+                if bi == 0:
+                    conv(pre + "#1", dims[pi])
+                d = conv(pre + ".branch2#a", dims[pi])
+                d = conv(pre + ".branch2#b", d)
+                dims[pi] = conv(pre + ".branch2#c", d)
+        if si < 3:
+            conv(fe + f"{si + 1}.multipathway_fusion", dims[1])
+    return sum(per.values()), per
+
+
 def _set_nested(root: nn.Module, dotted: str, value, buffer=False):
     parts = dotted.split(".")
     m = root

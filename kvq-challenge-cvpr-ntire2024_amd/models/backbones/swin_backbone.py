@@ -417,7 +417,7 @@ class SwinTransformer3D(nn.Module):
                 arr[i] = ptr(taps[i])
             check(lib().kvq_swin3d_set_taps(handle, arr), "kvq_swin3d_set_taps")
         try:
-            check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), current_stream()),
+            check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), _abi.stream_of(x)),
                   "kvq_swin3d_forward")
         finally:
             if taps is not None:

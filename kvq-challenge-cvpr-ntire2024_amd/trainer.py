@@ -35,9 +35,15 @@ class Trainer:
 
     def build_models(self):
         self.model = VQA_Network(self.config).to(self.device).eval()
+        self._lane_graphs = None                 # recorded forwards bake the weight images in: never outlive a weight change
         path = self.config.get("load_path")
         if path:
-            print("load:", self.load_checkpoint(self.model, path))
+            print("load:", self.load_weights(path))
+
+    def load_weights(self, path):
+        """load a checkpoint into the built model; drops the recorded hipGraphs (they replay the OLD weight images)."""
+        self._lane_graphs = None
+        return self.load_checkpoint(self.model, path)
 
     @staticmethod
     def load_checkpoint(model, path):
@@ -51,14 +57,18 @@ class Trainer:
     def build_datasets(self):
         cfg = self.config["data"]["val"]
         cls = getattr(_datasets, cfg["type"])
-        self.val_dataset = cls(cfg["args"], None, device=self.device) if cfg["type"].startswith("Synthetic") \
-            else cls(cfg["args"], None)
+        # every dataset class stages and samples on THIS rank's device (rank r / --gpu_id N, not cuda:0): the K1 kernels run
+        # on the current device's stream and must see pointers of the same device
+        self.val_dataset = cls(cfg["args"], None, device=self.device)
 
     # ------------------------------------------------------------------------------------------
     def _model_inputs(self, data):
         """clip reshape of the dataset item (trainer.py:306-319) -> dict of DEVICE tensors, the model's inputs."""
         inputs = {}
-        for key in list(data):
+        ksvqe = self.config["model"]["type"] == "KSVQE"
+        # KSVQE reads resize_video / fragment / dis_label only (key_list = ['KSVQE'], trainer.py:56,259-260): the 'technical'
+        # view (the same pixels as 'fragment', ~95 MB fp32 per 96-frame sample) is neither reshaped nor copied
+        for key in ([] if ksvqe else list(data)):
             if key in self.key_list or key == "technical":
                 x = data[key]
                 if not torch.is_tensor(x) or x.dim() not in (4, 5):
@@ -70,7 +80,7 @@ class Trainer:
                 nc = int(data.get("num_clips", {}).get(key, 1)) if isinstance(data.get("num_clips"), dict) else 1
                 inputs[key] = (x.reshape(b, c, nc, t // nc, h, w).permute(0, 2, 1, 3, 4, 5)
                                .reshape(b * nc, c, t // nc, h, w).contiguous())
-        if self.config["model"]["type"] == "KSVQE":
+        if ksvqe:
             # the DataLoader of the reference adds the batch dimension (batch_size 1) and the whole T-frame sample goes to
             # KSVQE as ONE clip (trainer.py:306-326): resize_video / fragment (1, 3, T, h, w), dis_label (1,)
             for k in ("resize_video", "fragment"):
@@ -146,6 +156,10 @@ class Trainer:
                     inputs = self._model_inputs(item)
                     pred = graphs.run(lane, inputs) if graphs is not None else self._run_model(inputs)
                     local[j] = pred.float().mean()                # pred.mean(0) over clips (trainer.py:282)
+                if j == 0 and graphs is None and nstream > 1:
+                    # the first forward (re)builds the lazily cached weight images (16-bit copies, packed panels, folded
+                    # BatchNorms, bias images) on ITS stream; the other lanes read them — they must be complete first
+                    torch.cuda.synchronize(self.device)
         finally:
             if feed is not None:
                 feed.close()

@@ -55,7 +55,8 @@ class SwinCfg:
 
 SWIN_T_GRPB = SwinCfg()
 SWIN_T_PLAIN = SwinCfg(frag_biases=(False, False, False, False))
-SWIN_S_PLAIN = SwinCfg(depths=(2, 2, 18, 2), frag_biases=(False, False, False, False))
+SWIN_S_PLAIN = SwinCfg(depths=(2, 2, 18, 2), frag_biases=(False, False, False, False))        # model key swin_small
+SWIN_T_GRPB_M = SwinCfg(window=(4, 4, 4), frag_biases=(False, False, False, False))             # model key swin_tiny_grpb_m
 # BASELINE.json config 5: a parameterisation the build defines (SURVEY.md §0 trap 7)
 SWIN_B_GRPB = SwinCfg(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32))
 

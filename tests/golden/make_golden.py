@@ -115,6 +115,10 @@ TRUNK_CASES = [
     ("t_grpb_stress_10x50x70", "SWIN_T_GRPB", "stress", 2, 14, 1, 10, 50, 70),
     ("t_grpb_stress_32x224", "SWIN_T_GRPB", "stress", 0, 15, 1, 32, 224, 224),
     ("t_grpb_init_32x224", "SWIN_T_GRPB", "init", 3, 16, 1, 32, 224, 224),
+    # the other model.py keys (model.py:39-47): swin_small (depths 2/2/18/2) and swin_tiny_grpb_m (window 4,4,4)
+    ("s_plain_stress_16x96", "SWIN_S_PLAIN", "stress", 4, 17, 1, 16, 96, 96),
+    ("t_m444_stress_16x96", "SWIN_T_GRPB_M", "stress", 5, 18, 1, 16, 96, 96),
+    ("t_m444_stress_12x72x104", "SWIN_T_GRPB_M", "stress", 6, 19, 2, 12, 72, 104),
 ]
 
 
@@ -535,7 +539,82 @@ def sec_ckpt(ref):
     save("ckpt.npz", d)
 
 
-SECTIONS = {"ksvqe": sec_ksvqe, "contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SFCLIP_CASES = [  # (frames, fps reported by the container, frames the decoder delivers)
+    (300, 30.0, 300), (250, 29.97, 250), (100, 30.0, 100), (70, 30.0, 70), (61, 30.0, 61), (50, 30.0, 50), (45, 25.0, 45),
+    (20, 10.0, 20), (40, 0.0, 40), (96, 23.976, 96), (200, 60.0, 200), (300, 30.0, 270), (64, 30.0, 40), (10, 30.0, 10)]
+
+
+def sec_sfclips(ref):
+    """Clip assembly of the motion-feature extractor: the reference's OWN ``VideoDataset_NR_SlowFast_feature.__getitem__``
+    (SlowFast_features.py:52-107) run over a fake cv2.VideoCapture whose frame i carries i in its pixels; stored: the frame
+    index of every slot of every clip."""
+    import importlib
+    import types
+    from kvq_amd.datasets.slowfast_clips import clip_frame_indices
+    state = {}
+
+    class FakeCapture:
+        def __init__(self, *a):
+            self.pos = 0
+
+        def open(self, filename):
+            self.pos = 0
+
+        def get(self, prop):
+            return {7: float(state["length"]), 5: float(state["fps"])}[prop]
+
+        def read(self):
+            i = self.pos
+            self.pos += 1
+            if i >= state["readable"]:
+                return False, None
+            f = np.zeros((2, 2, 3), np.uint8)
+            f[..., 0], f[..., 1] = i % 251, i // 251          # "BGR"; cvtColor below reverses the channels
+            return True, f
+
+        def release(self):
+            pass
+
+    cv2 = sys.modules["cv2"]
+    cv2.VideoCapture, cv2.CAP_PROP_FRAME_COUNT, cv2.CAP_PROP_FPS, cv2.COLOR_BGR2RGB = FakeCapture, 7, 5, 4
+    cv2.cvtColor = lambda frame, code: frame[..., ::-1].copy()
+    hub = types.ModuleType("pytorchvideo.models.hub")
+    hub.slowfast_r50 = None
+    for n in ("pytorchvideo", "pytorchvideo.models"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["pytorchvideo.models.hub"] = hub
+    sf = importlib.import_module("SlowFast_features")
+    csv_path = os.path.join(os.getcwd(), "one.csv")
+    with open(csv_path, "w") as f:
+        f.write("filename,score\nfake.mp4,1\n")
+    d, names = {}, []
+    to_t = lambda img: torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float()      # noqa: E731  (RGB after cvtColor)
+    for length, fps, readable in SFCLIP_CASES:
+        state.update(length=length, fps=fps, readable=readable)
+        ds = sf.VideoDataset_NR_SlowFast_feature(types.SimpleNamespace(resize=2), to_t, os.getcwd(), csv_path)
+        name = f"L{length}_f{fps:g}_r{readable}"
+        try:
+            clips, vname = ds[0]
+            assert vname == "fake.mp4"
+            idx = np.stack([(c[:, 2, 0, 0] + 251 * c[:, 1, 0, 0]).numpy().astype(np.int64) for c in clips])     # RGB: R = B of the fake
+            mine = np.stack(clip_frame_indices(length, int(round(fps)), readable))
+            assert np.array_equal(idx, mine), (name, idx, mine)
+            d[f"{name}/idx"] = idx.astype(np.int32)
+        except IndexError as e:
+            try:
+                clip_frame_indices(length, int(round(fps)), readable)
+                raise AssertionError(f"{name}: the reference raised IndexError, the restatement did not")
+            except IndexError:
+                pass
+            d[f"{name}/error"] = np.asarray(f"IndexError: {e}")
+        d[f"{name}/meta"] = np.asarray([length, int(round(fps)), readable])
+        names.append(name)
+        print(name, "clips:", d.get(f"{name}/idx", np.zeros((0, 0))).shape[0], str(d.get(f"{name}/error", "")))
+    d["cases"] = np.asarray(names)
+    save("sfclips.npz", d)
+
+
+SECTIONS = {"sfclips": sec_sfclips, "ksvqe": sec_ksvqe, "contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
 
 
 def main():

@@ -27,7 +27,8 @@ SCORE_TOL = 1e-3          # MOS units, north_star
 BF16_STRESS_TOL = 5e-3    # format-limited (see module docstring)
 FEAT_REL_L2 = {"fp16": 4e-3, "bf16": 2e-2}
 
-KEY_FOR_CFG = {"SWIN_T_GRPB": "swin_tiny_grpb", "SWIN_T_PLAIN": "swin_tiny"}
+KEY_FOR_CFG = {"SWIN_T_GRPB": "swin_tiny_grpb", "SWIN_T_PLAIN": "swin_tiny", "SWIN_S_PLAIN": "swin_small",
+               "SWIN_T_GRPB_M": "swin_tiny_grpb_m"}
 
 
 def build_network(cfgn, wseed, scheme, dtype="fp16"):
@@ -45,7 +46,9 @@ def build_network(cfgn, wseed, scheme, dtype="fp16"):
 
 
 CASES = ["t_grpb_stress_8x80", "t_grpb_stress_16x64", "t_plain_stress_16x96", "t_grpb_stress_10x50x70",
-         "t_grpb_stress_32x224", "t_grpb_init_32x224"]
+         "t_grpb_stress_32x224", "t_grpb_init_32x224",
+         # the other model keys of model.py:39-47, end to end
+         "s_plain_stress_16x96", "t_m444_stress_16x96", "t_m444_stress_12x72x104"]
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
@@ -212,6 +215,41 @@ def test_config3_trunk_and_slowfast_on_the_same_clips():
         slow, fast = sf(pack_pathway_output(x))
     assert s.shape == (2, 1) and slow.shape == (2, 2048, 1, 1, 1) and fast.shape == (2, 256, 1, 1, 1)
     assert torch.isfinite(s).all() and torch.isfinite(slow).all() and torch.isfinite(fast).all()
+
+
+def test_config3_batch8_both_branches_scores_vs_oracle():
+    """BASELINE config 3 at its size: one video = 8 clips of 32x224x224 through the Swin trunk + head AND the SlowFast branch on
+    two HIP streams from the same batch tensor; every clip's score within the 1e-3 gate of the CPU Swin oracle, the SlowFast
+    features of clip 0 within 5e-3 relative L2 of its CPU restatement (batch-invariance: clip 0 alone == clip 0 of the batch)."""
+    from kvq_amd.models.backbones.slowfast_model import pack_pathway_output, slowfast
+    from oracle import slowfast_oracle as SF
+    cfg = synth.SWIN_T_GRPB
+    net, _ = build_network("SWIN_T_GRPB", 0, "stress")
+    wsf = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    sf = slowfast()
+    sf.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in wsf.items()})
+    sf = sf.to(DEV).eval()
+    xc = torch.from_numpy(synth.synth_clip(8, 32, 224, 224, batch=8))
+    x = xc.to(DEV)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.no_grad():
+        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s1):
+            score = net(inputs={"technical": x}, reduce_scores=True)
+        with torch.cuda.stream(s2):
+            slow, fast = sf(pack_pathway_output(x))
+            slow1, fast1 = sf(pack_pathway_output(x[:1].contiguous()))
+        torch.cuda.synchronize()
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        ref = torch.cat([O.vqa_head(O.swin3d_trunk(xc[i:i + 1], synth.synth_swin_weights(cfg, 0, "stress"), cfg),
+                                    synth.synth_vqa_head_weights(768, 64, 0, "stress")) for i in range(8)])
+        s_ref, f_ref = SF.slowfast_features(xc[:1], wsf)
+    assert score.shape == (8, 1) and slow.shape == (8, 2048, 1, 1, 1) and fast.shape == (8, 256, 1, 1, 1)
+    assert (score.cpu() - ref).abs().max().item() <= SCORE_TOL, (score.cpu().ravel(), ref.ravel())
+    for got, r in ((slow[:1], s_ref), (fast[:1], f_ref)):
+        assert ((got.cpu() - r).norm() / r.norm()).item() <= 5e-3
+    assert (slow[:1] - slow1).abs().max().item() <= 1e-3 * slow1.abs().max().item()
+    assert (fast[:1] - fast1).abs().max().item() <= 1e-3 * fast1.abs().max().item()
 
 
 def test_feature_taps_multi_and_layer_vs_reference_golden(golden):

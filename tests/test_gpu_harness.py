@@ -323,3 +323,90 @@ def test_hipgraph_capture_failure_falls_back_to_eager_launches():
     out = lg.run(0, {"x": x + 1})
     torch.cuda.synchronize()
     assert torch.equal(out, (x + 1) * 2) and lg.eager_runs == 2
+
+
+def _run_cli(tmp, yml, world, port=None):
+    """test.py as 1 process, or as ``world`` processes that share this box's single GPU over gloo (LOCAL_RANK 0 for all)."""
+    base = dict(os.environ, PYTHONPATH=ROOT)
+    if world == 1:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "test.py"), "-o", str(yml), "--gpu_id", "0"], cwd=tmp, env=base,
+                           capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r.stdout
+    env = dict(base, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), KVQ_DIST_BACKEND="gloo", LOCAL_RANK="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "test.py"), "-o", str(yml)], cwd=tmp, env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=1500) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "".join(o[1][-1500:] for o in outs)
+    return outs[0][0]
+
+
+def test_c4_rehearsal_900_videos_one_and_two_ranks(tmp_path):
+    """BASELINE config 4 at its workload, rehearsed on one GPU: 900 labelled synthetic videos (small clips) through ``test.py``
+    with 1 rank and with 2 ranks (``videos[rank::2]``, wrap-around padding, one all-gather, rank 0 rescales): identical
+    ``output.txt``, SRCC / PLCC identical to 4 d.p. (trainer.py:287-294, 356-361; trainer_ddp.py:259-267), and the scores of a
+    32-video subset within 1e-3 of the CPU oracle on the same dataset items."""
+    import re
+    import socket
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "kwai_swin_grpb_synthetic_test.yml")))
+    a = cfg["data"]["val"]["args"]
+    a.update(num_videos=900, frames=24, height=80, width=112, seed_per_item=True)
+    a["sample_types"]["technical"].update(fragments_h=2, fragments_w=3, clip_len=8, num_clips=2, aligned=8)
+    wts = synth.synth_swin_weights(synth.SWIN_T_GRPB, 0, "stress")
+    hw = synth.synth_vqa_head_weights(768, 64, 0, "stress")
+    sd = {"module.swin_tiny_grpb_backbone." + k: torch.from_numpy(v) for k, v in wts.items()}
+    sd.update({"module.swin_tiny_grpb_head." + k: torch.from_numpy(v) for k, v in hw.items()})
+    torch.save({"state_dict": sd}, str(tmp_path / "w.pth"))
+    cfg["load_path"] = str(tmp_path / "w.pth")
+    yml = tmp_path / "c4.yml"
+    yml.write_text(yaml.safe_dump(cfg))
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    out1 = _run_cli(one, yml, 1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out2 = _run_cli(two, yml, 2, port)
+    t1, t2 = (one / "output.txt").read_text(), (two / "output.txt").read_text()
+    assert len(t1.strip().splitlines()) == 900 and t1 == t2
+    m1, m2 = (re.search(r"SRCC(.+?)PLCC(.+?)KRCC(.+?)RMSE(.+)", o) for o in (out1, out2))
+    assert m1 and m2
+    for k in (1, 2):
+        assert round(float(m1.group(k)), 4) == round(float(m2.group(k)), 4)
+    got = np.asarray([float(l.split(",")[1]) for l in t1.strip().splitlines()])
+    assert np.isfinite(got).all() and got.std() > 0
+    ds = SyntheticKVQDataset(a, device="cuda:0")
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    for i in list(range(0, 900, 29))[:32]:
+        x = ds[i]["technical"].cpu()
+        c, t, h, w = x.shape
+        clips = x.reshape(c, 2, t // 2, h, w).permute(1, 0, 2, 3, 4).contiguous()
+        with torch.no_grad():
+            ref = O.vqa_head(O.swin3d_trunk(clips, wts, synth.SWIN_T_GRPB), hw).mean().item()
+        assert abs(ref - got[i]) <= 1e-3, (i, ref, got[i])
+    # the metric line is the reference's: rescale to the labels' mean / std, then SRCC / PLCC (trainer.py:287-294, 356-361)
+    from scipy.stats import pearsonr, spearmanr
+    labels = np.asarray(ds.labels, np.float64)
+    pr = (got - got.mean()) / got.std() * labels.std() + labels.mean()
+    assert round(spearmanr(labels, pr)[0], 4) == round(float(m1.group(1)), 4)
+    assert round(pearsonr(labels, pr)[0], 4) == round(float(m1.group(2)), 4)
+
+
+def test_rccl_backend_world_size_one():
+    """The RCCL ("nccl") branch of kvq_amd/dist.py on a 1-GPU box: a 1-rank process group, the score all-gather, the barrier and
+    the max-over-ranks all-reduce run through RCCL once (an 8-GPU node must not be the first place this code executes)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = ("import torch, kvq_amd\nfrom kvq_amd import dist as kd\n"
+            "r, lr, w = kd.init(backend='nccl', force=True)\n"
+            "import torch.distributed as dist\nassert dist.is_initialized() and dist.get_backend() == 'nccl' and w == 1\n"
+            "x = torch.arange(5, dtype=torch.float32, device='cuda:0') * 0.5\n"
+            "g = kd.gather_scores(x, 5, r, w)\nassert g.is_cuda and torch.equal(g, x)\n"
+            "kd.barrier()\nassert kd.max_over_ranks(1.25, torch.device('cuda:0')) == 1.25\n"
+            "dist.destroy_process_group()\nprint('RCCL_OK')\n")
+    env = dict(os.environ, PYTHONPATH=ROOT, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("KVQ_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-3000:]

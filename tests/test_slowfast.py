@@ -35,6 +35,107 @@ def test_architecture_invariants():
     assert s.shape == (1, 2048, 1, 1, 1) and f.shape == (1, 256, 1, 1, 1)
 
 
+def test_clip_assembly_vs_reference_golden(golden):
+    """``clip_frame_indices`` against the frame indices the reference's own ``VideoDataset_NR_SlowFast_feature.__getitem__``
+    (SlowFast_features.py:52-107) produced over a fake capture (tests/golden/make_golden.py::sec_sfclips): per-second 32-frame
+    clips, last-frame padding, minimum 8 clips, undelivered frames, fps 0, and the too-short-video IndexError."""
+    from kvq_amd.datasets.slowfast_clips import clip_frame_indices
+    g = golden("sfclips.npz")
+    assert len(g["cases"]) >= 14
+    for name in g["cases"]:
+        length, rate, readable = (int(v) for v in g[f"{name}/meta"])
+        if f"{name}/error" in g:
+            with pytest.raises(IndexError):
+                clip_frame_indices(length, rate, readable)
+            continue
+        got = np.stack(clip_frame_indices(length, rate, readable))
+        assert np.array_equal(got, g[f"{name}/idx"]), name
+        assert got.shape[0] >= 8 and got.shape[1] == 32
+
+
+def test_pil_transform_and_dataset_over_a_frame_stack(tmp_path):
+    """The reference's frame transform (PIL Resize([r, r]) -> ToTensor -> Normalize(.45, .225), SlowFast_features.py:172-173)
+    and the dataset over a ``.npy`` frame stack + ``.fps`` side file: clip count, padding, values."""
+    import types
+    from PIL import Image
+    from kvq_amd.datasets.slowfast_clips import VideoDataset_NR_SlowFast_feature, pil_transform
+    g = np.random.Generator(np.random.PCG64(5))
+    frames = g.integers(0, 256, size=(70, 36, 48, 3), dtype=np.uint8)
+    np.save(str(tmp_path / "a.mp4.npy"), frames)
+    (tmp_path / "a.mp4.fps").write_text("29.97")
+    (tmp_path / "v.csv").write_text("filename,score\na.mp4,3.5\n")
+    tr = pil_transform(16)
+    ref = (torch.from_numpy(np.array(Image.fromarray(frames[3]).resize((16, 16), Image.BILINEAR))).permute(2, 0, 1).float() / 255 - 0.45) / 0.225
+    assert torch.equal(tr(frames[3]), ref)
+    ds = VideoDataset_NR_SlowFast_feature(types.SimpleNamespace(resize=16, fps=None), None, str(tmp_path), str(tmp_path / "v.csv"))
+    clips, name = ds[0]
+    assert name == "a.mp4" and len(ds) == 1 and len(clips) == 8 and clips[0].shape == (32, 3, 16, 16)
+    assert torch.equal(clips[0][5], tr(frames[5])) and torch.equal(clips[1][0], tr(frames[30]))
+    assert torch.equal(clips[1][31], tr(frames[61])) and all(torch.equal(clips[k], clips[1]) for k in range(2, 8))
+
+
+@pytest.mark.gpu
+def test_hip_slowfast_full_clip_matches_oracle():
+    """One 32 x 224 x 224 clip — the size BASELINE config 3 runs — HIP vs the CPU restatement (parity UNPINNED vs pytorchvideo)."""
+    from kvq_amd.models.backbones.slowfast_model import pack_pathway_output, slowfast
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    x = torch.from_numpy(synth.synth_clip(31, 32, 224, 224, batch=1))
+    m = slowfast()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    m = m.cuda().eval()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        s_ref, f_ref = SF.slowfast_features(x, w)
+        s, f = m(pack_pathway_output(x.cuda()))
+    assert s.shape == s_ref.shape == (1, 2048, 1, 1, 1) and f.shape == f_ref.shape == (1, 256, 1, 1, 1)
+    for got, ref in ((s, s_ref), (f, f_ref)):
+        rel = ((got.cpu() - ref).norm() / ref.norm()).item()
+        assert rel <= 5e-3, rel
+
+
+@pytest.mark.gpu
+def test_cli_extracts_features_from_a_video_tree(tmp_path):
+    """``python SlowFast_features.py --video_root --video_csv --database --feature_save_folder`` (reference CLI, :200-217) over
+    two ``.npy`` frame stacks: the on-disk layout the SimpleVQA dataset reads, clip count incl. the 8-clip minimum, and the
+    saved features == the model called directly on the assembled clips."""
+    import os
+    import subprocess
+    import sys
+    import types
+    from kvq_amd.datasets.slowfast_clips import VideoDataset_NR_SlowFast_feature, extract_video
+    from kvq_amd.models.backbones.slowfast_model import slowfast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.random.Generator(np.random.PCG64(9))
+    for name, n in (("a.mp4", 100), ("b.mp4", 45)):
+        np.save(str(tmp_path / f"{name}.npy"), g.integers(0, 256, size=(n, 60, 80, 3), dtype=np.uint8))
+    (tmp_path / "b.mp4.fps").write_text("15")
+    (tmp_path / "v.csv").write_text("filename,score\na.mp4,1\nb.mp4,2\n")
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, str(tmp_path / "w.pth"))
+    r = subprocess.run([sys.executable, os.path.join(root, "SlowFast_features.py"), "--video_root", str(tmp_path), "--video_csv",
+                        str(tmp_path / "v.csv"), "--database", "kvq", "--feature_save_folder", str(tmp_path / "feat"), "--resize", "64",
+                        "--num_workers", "0", "--fps", "30", "--weights", str(tmp_path / "w.pth")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = slowfast()
+    m.load_state_dict(torch.load(str(tmp_path / "w.pth")))
+    m = m.cuda().eval()
+    ds = VideoDataset_NR_SlowFast_feature(types.SimpleNamespace(resize=64, fps=30.0), None, str(tmp_path), str(tmp_path / "v.csv"))
+    for vi, (name, nclip) in enumerate((("a.mp4", 8), ("b.mp4", 8))):
+        d = tmp_path / "feat" / "kvq" / name
+        files = sorted(os.listdir(d))
+        assert len(files) == 2 * nclip, files
+        clips, vname = ds[vi]
+        assert vname == name and len(clips) == nclip
+        direct = extract_video(m, clips, "cuda")
+        for i in range(nclip):
+            slow = np.load(str(d / f"feature_{i}_slow_feature.npy"))
+            fast = np.load(str(d / f"feature_{i}_fast_feature.npy"))
+            assert slow.shape == (1, 2048, 1, 1, 1) and fast.shape == (1, 256, 1, 1, 1)
+            assert np.allclose(slow, direct[i][0], rtol=0, atol=2e-3 * np.abs(direct[i][0]).max())
+            assert np.allclose(fast, direct[i][1], rtol=0, atol=2e-3 * np.abs(direct[i][1]).max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 3, 16, 64, 64), (2, 3, 8, 96, 64)])
 def test_hip_slowfast_matches_oracle(shape):
