@@ -467,15 +467,23 @@ static int launch_tail_e(const TailParams& p, int C, hipStream_t st) {
 
 }  // namespace kvq
 
+// C = 384: csrc/tailmm.hip (32x32x16 GEMM chain) unless KVQ_TAILMM=0 selects csrc/tail16.hip (token-per-lane 16x16x32); the
+// choice is per process: the packed weight images differ
+static bool use_tailmm(int C, int hidden) {
+  static const bool on = !(getenv("KVQ_TAILMM") && atoi(getenv("KVQ_TAILMM")) == 0);
+  return on && kvq::tailmm_supported(C, hidden);
+}
+
 extern "C" int kvq_block_tail_supported(int C, int hidden) {
   // hidden/32 even and >= 4: the MLP pipeline rotates two accumulators
-  static const bool wide = !(getenv("KVQ_TAIL16") && atoi(getenv("KVQ_TAIL16")) == 0);   // C = 384: csrc/tail16.hip
+  static const bool wide = !(getenv("KVQ_TAIL16") && atoi(getenv("KVQ_TAIL16")) == 0);   // C = 384: csrc/tail16.hip / tailmm.hip
   if (wide && kvq::tail16_supported(C, hidden)) return 1;
   return (C == 96 || C == 128 || C == 192) && hidden % 64 == 0 && hidden >= 128 ? 1 : 0;
 }
 
 extern "C" size_t kvq_block_tail_pack_bytes(int C, int hidden) {
   if (!kvq_block_tail_supported(C, hidden)) return 0;
+  if (use_tailmm(C, hidden)) return kvq::tailmm_pack_bytes(C, hidden);
   if (kvq::tail16_supported(C, hidden)) return kvq::tail16_pack_bytes(C, hidden);
   return kvq::tail_items(C, hidden) * kvq::tail_slot_bytes(C) + kvq::tail_param_bytes(C, hidden);
 }
@@ -487,6 +495,9 @@ extern "C" int kvq_block_tail_pack(const void* proj_w, const float* proj_b, cons
   KVQ_REQUIRE(proj_w && proj_b && norm2_w && norm2_b && fc1_w && fc1_b && fc2_w && fc2_b && pack, KVQ_ERR_NULL,
               "kvq_block_tail_pack: NULL pointer");
   KVQ_REQUIRE(kvq_block_tail_supported(C, hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail_pack: C=%d hidden=%d", C, hidden);
+  if (use_tailmm(C, hidden))
+    return tailmm_pack((const uint16_t*)proj_w, (const uint16_t*)fc1_w, (const uint16_t*)fc2_w, proj_b, norm2_w, norm2_b, fc1_b,
+                       fc2_b, C, hidden, (unsigned char*)pack, (hipStream_t)stream);
   if (tail16_supported(C, hidden))
     return tail16_pack((const uint16_t*)proj_w, (const uint16_t*)fc1_w, (const uint16_t*)fc2_w, proj_b, norm2_w, norm2_b, fc1_b,
                        fc2_b, C, hidden, (unsigned char*)pack, (hipStream_t)stream);
@@ -514,6 +525,7 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
   p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;
+  if (use_tailmm(a->C, a->hidden)) return tailmm_launch(p, a->C, a->dtype, (hipStream_t)stream);
   if (tail16_supported(a->C, a->hidden)) return tail16_launch(p, a->C, a->dtype, (hipStream_t)stream);
   return a->dtype == KVQ_DT_FP16 ? launch_tail_e<Fp16>(p, a->C, (hipStream_t)stream)
                                  : launch_tail_e<Bf16>(p, a->C, (hipStream_t)stream);

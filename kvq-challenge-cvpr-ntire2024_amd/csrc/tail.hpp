@@ -28,4 +28,11 @@ int tail16_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st);
 int tail16_launch(const TailParams& p, int C, int dtype, hipStream_t st);
 
+// csrc/tailmm.hip: the same launch for C = 384 as a register-blocked 32x32x16 GEMM chain (default; KVQ_TAILMM=0 -> tail16.hip)
+bool tailmm_supported(int C, int hidden);
+size_t tailmm_pack_bytes(int C, int hidden);
+int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
+                const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st);
+int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st);
+
 }  // namespace kvq

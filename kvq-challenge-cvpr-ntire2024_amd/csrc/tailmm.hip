@@ -1,0 +1,521 @@
+// The fused post-attention launch for WIDE rows (C = 384: stage 2 of Swin-T/S) as a register-blocked GEMM chain on
+// v_mfma_f32_32x32x16 — the replacement of tail16.hip's token-per-lane 16x16x32 design.
+//
+// Same computation (swin_backbone.py:479-516): x += proj(attn) (window-reverse / roll-back / crop through the row map);
+// x += fc2(GELU(fc1(norm2(x)))) [+ the next block's norm1 in ITS window order].
+//
+// Why a second design: tail16 feeds every 16-cycle MFMA with its own 1 KB weight fragment from LDS and has ONE wave per SIMD,
+// so its floor is the wave's instruction stream: 2592 MFMAs x 17 ticks + 2592 fragment reads + the GELU stream, additive on
+// gfx950 (tools/ubench/pipe_share.hip: VALU and LDS issue of a wave do not hide under that wave's own MFMAs beyond ~4 cycles
+// per 16x16x32 / ~11 per 32x32x16).  Here a workgroup is still 64 tokens x 4 waves, but a wave owns a FEATURE slice for all
+// 64 tokens instead of a token slice for all features:
+//   * D[feature][token] = W[feature][k] . X[token][k]: weights are the A operand, activations the B operand, 32x32x16 tiles;
+//     a wave's k-step is 3 weight fragments + 2 activation fragments for 6 MFMAs (fc1: 2 + 2 for 4) — 1296 MFMAs of 32
+//     cycles per wave instead of 2592 of 16, and 5 LDS reads per 192 MFMA cycles instead of 12;
+//   * a wave reads only ITS feature rows' weights, so each wave streams its own fragment list (648 x 1 KB, consumption
+//     order, packed by tailmm_pack_kernel) through a PRIVATE LDS ring by LDS-DMA with a counted vmcnt — no workgroup barrier
+//     per ring item, the stream runs 12 fragments ahead across all phases;
+//   * activations go through LDS as ready-made B fragments: the attention rows by LDS-DMA (row gather), norm2's output and
+//     the GELU output written by their producers straight from the accumulator layout (a lane holds one token and, per tile
+//     and register quad pair, 8 k values = one 16-byte fragment slot; the k order inside a 16-step is permuted accordingly in
+//     the packed weights): 3 + 2 x 6 workgroup barriers per launch;
+//   * D keeps a token per lane (column) — residual, LayerNorm statistics (in-lane + lane^32 + a 4-wave exchange through
+//     LDS), bias and GELU are register arithmetic as before.
+// LDS: 48 KB activation tile (attention rows, then norm2 rows) + 32 KB GELU chunk + 4 x 16 KB rings + 12 KB parameters.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.hpp"
+#include "tail.hpp"
+
+namespace kvq {
+
+typedef __attribute__((address_space(3))) void* mm_lds_t;
+typedef __attribute__((address_space(1))) const void* mm_gbl_t;
+
+constexpr int MM_C = 384, MM_H = 1536, MM_TOK = 64;
+constexpr int MM_HC = 256, MM_NCH = MM_H / MM_HC;            // hidden chunk, chunks
+constexpr int MM_KS_C = MM_C / 16, MM_KS_H = MM_HC / 16;     // 24 k-steps over C, 16 over a hidden chunk
+constexpr int MM_NF_PROJ = MM_KS_C * 3, MM_NF_FC1 = MM_KS_C * 2, MM_NF_FC2 = MM_KS_H * 3;
+constexpr int MM_NF = MM_NF_PROJ + MM_NCH * (MM_NF_FC1 + MM_NF_FC2);     // 648 fragments per wave
+constexpr int MM_RING = 16, MM_PF = 12;                      // ring slots (1 KB) per wave, fragments in flight
+constexpr int MM_OFF_X = 0;                                  // [24 k-steps][2 token tiles][64 lanes][16 B] = 48 KB
+constexpr int MM_OFF_G = MM_OFF_X + MM_KS_C * 2 * 1024;      // [16][2][64][16 B] = 32 KB
+constexpr int MM_OFF_RING = MM_OFF_G + MM_KS_H * 2 * 1024;   // 4 waves x 16 KB
+constexpr int MM_OFF_PRM = MM_OFF_RING + 4 * MM_RING * 1024; // b1[1536] g2[384] b2n[384] proj_b[384] b2[384] fp32 = 12 KB
+constexpr int MM_PRM_FLOATS = MM_H + 4 * MM_C;
+constexpr int MM_OFF_RED = MM_OFF_PRM + MM_PRM_FLOATS * 4;   // [4 waves][64 tokens] fp32
+constexpr int MM_LDS = MM_OFF_RED + 4 * MM_TOK * 4;
+// packed image: 4 waves x 648 KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
+constexpr size_t MM_PACK_FRAG_BYTES = (size_t)4 * MM_NF * 1024;
+constexpr int MM_PACK_PRM_FLOATS = MM_H + 4 * MM_C;
+
+bool tailmm_supported(int C, int hidden) { return C == MM_C && hidden == MM_H; }
+size_t tailmm_pack_bytes(int C, int hidden) {
+  return tailmm_supported(C, hidden) ? MM_PACK_FRAG_BYTES + (((size_t)MM_PACK_PRM_FLOATS * 4 + 255) & ~(size_t)255) : 0;
+}
+
+// k offset inside a 16-step of element e of fragment slot group g when the B operand is written from accumulators: a lane
+// (token, half) holds, per 32-row tile, rows 8q + 4 half + i; quads (q even, q odd) of one 16-row half are one slot
+__host__ __device__ inline int mm_kperm(int g, int e) { return e < 4 ? 4 * g + e : 8 + 4 * g + (e - 4); }
+
+__global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w,
+                                   const float* n2b, const float* b1, const float* b2, unsigned char* out) {
+  const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_slots = (long)4 * MM_NF * 64;
+  if (gi < n_slots) {
+    const int lane = (int)(gi & 63), i = lane & 31, g = lane >> 5;
+    const int f = (int)((gi >> 6) % MM_NF), w = (int)((gi >> 6) / MM_NF);
+    uint16_t* o = reinterpret_cast<uint16_t*>(out + gi * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint16_t v;
+      if (f < MM_NF_PROJ) {                                  // proj: natural k (B fragments come straight from the attention rows)
+        const int ks = f / 3, ft = f % 3;
+        v = wp[(size_t)(96 * w + 32 * ft + i) * MM_C + 16 * ks + 8 * g + e];
+      } else {
+        // consumption order behind proj: fc1(0); then fc1(c+1), fc2(c) for c = 0..4; then fc2(5)
+        const int r = f - MM_NF_PROJ;
+        int c, q;
+        if (r < MM_NF_FC1) { c = 0; q = r; }
+        else {
+          const int r2 = r - MM_NF_FC1, blk = r2 / (MM_NF_FC1 + MM_NF_FC2), o2 = r2 % (MM_NF_FC1 + MM_NF_FC2);
+          if (blk >= MM_NCH - 1) { c = MM_NCH - 1; q = MM_NF_FC1 + (r2 - (MM_NCH - 1) * (MM_NF_FC1 + MM_NF_FC2)); }
+          else if (o2 < MM_NF_FC1) { c = blk + 1; q = o2; }
+          else { c = blk; q = o2; }
+        }
+        if (q < MM_NF_FC1) {                                 // fc1 rows of chunk c, k = channel in accumulator order
+          const int ks = q / 2, ft = q % 2;
+          v = w1[(size_t)(MM_HC * c + 64 * w + 32 * ft + i) * MM_C + 16 * ks + mm_kperm(g, e)];
+        } else {                                             // fc2: all C outputs, k = hidden unit of chunk c in accumulator order
+          const int q2 = q - MM_NF_FC1, ks = q2 / 3, ft = q2 % 3;
+          v = w2[(size_t)(96 * w + 32 * ft + i) * MM_H + MM_HC * c + 16 * ks + mm_kperm(g, e)];
+        }
+      }
+      o[e] = v;
+    }
+  } else if (gi < n_slots + MM_PACK_PRM_FLOATS) {
+    const int q = (int)(gi - n_slots);
+    float v;
+    if (q < MM_H) v = b1[q];
+    else if (q < MM_H + MM_C) v = n2w[q - MM_H];
+    else if (q < MM_H + 2 * MM_C) v = n2b[q - MM_H - MM_C];
+    else if (q < MM_H + 3 * MM_C) v = proj_b[q - MM_H - 2 * MM_C];
+    else v = b2[q - MM_H - 3 * MM_C];
+    reinterpret_cast<float*>(out + MM_PACK_FRAG_BYTES)[q] = v;
+  }
+}
+
+int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
+                const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st) {
+  const long total = (long)4 * MM_NF * 64 + MM_PACK_PRM_FLOATS;
+  hipLaunchKernelGGL(tailmm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1,
+                     b2, out);
+  KVQ_CHECK_LAUNCH("tailmm_pack_kernel");
+  return KVQ_OK;
+}
+
+// DBG (diagnostic builds of the same kernel, tools/tail_time.py): 1 = no weight stream (no LDS-DMA, no vmcnt waits: stale ring
+// contents), 2 = no MFMAs, 3 = neither, 4 = no fragment reads
+template <typename E, bool EMIT, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
+  fp16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using V8 = typename E::v8;
+  constexpr int C = MM_C;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* ring = lds + MM_OFF_RING + wave * (MM_RING * 1024);
+  const unsigned char* wsrc = p.pack + (size_t)wave * MM_NF * 1024 + lane * 16;    // this wave's fragment list
+  float* prm = reinterpret_cast<float*>(lds + MM_OFF_PRM);
+  float* red = reinterpret_cast<float*>(lds + MM_OFF_RED);
+  const float* gprm = reinterpret_cast<const float*>(p.pack + MM_PACK_FRAG_BYTES);
+#ifdef KVQ_TAIL_TRACE   // diagnostic build only (tools/tail_trace.py): per-workgroup shader-clock stamps of wave 0
+  const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
+  unsigned long long wait_dma = 0, wait_bar = 0;
+#define MM_STAMP(i) if (tr) p.trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter()
+#define MM_BARRIER() { const unsigned long long t0_ = __builtin_readcyclecounter(); __syncthreads(); wait_bar += __builtin_readcyclecounter() - t0_; }
+#else
+#define MM_STAMP(i)
+#define MM_BARRIER() __syncthreads()
+#endif
+  MM_STAMP(0);
+
+  // ---- the weight stream: fragment i of the list lives in ring slot i % 16; `issued` fragments have been requested ----
+  // (past the end of the list the LAST fragment is requested again, into a slot nobody reads any more: the vmcnt arithmetic
+  // stays uniform and the loop bodies stay branch-free)
+  int issued = 0;
+  auto issue = [&](int n) __attribute__((always_inline)) {
+    if (DBG & 1) { issued += n; return; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < n) {
+        const int src = issued < MM_NF ? issued : MM_NF - 1;
+        __builtin_amdgcn_global_load_lds((mm_gbl_t)(wsrc + (size_t)src * 1024), (mm_lds_t)(ring + (issued & (MM_RING - 1)) * 1024), 16, 0, 0);
+        ++issued;
+      }
+  };
+
+  // ---- this workgroup's rows: token tt*32 + j of 64, window order -> token of the residual stream ----
+  long orig[2];
+  bool live[2];
+  int tloc_[2], tb_[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const long row = (long)blockIdx.x * MM_TOK + 32 * tt + j;
+    const long rc = row < p.M ? row : p.M - 1;
+    int tb, tloc;
+    if (p.map) {
+      tb = (int)(rc / p.map_rows);
+      tloc = p.map[rc - (long)tb * p.map_rows];
+    } else {
+      tb = (int)(rc / p.out_rows);
+      tloc = (int)(rc - (long)tb * p.out_rows);
+    }
+    live[tt] = row < p.M && tloc >= 0;
+    tloc = tloc < 0 ? 0 : tloc;
+    tloc_[tt] = tloc; tb_[tt] = tb;
+    orig[tt] = (long)tb * p.out_rows + tloc;
+  }
+  // ---- attention rows -> B fragments [k-step][token tile] by LDS-DMA (lane (j, half) fetches row j's k 16ks + 8 half ..+7) ----
+  {
+    const long row0 = (long)blockIdx.x * MM_TOK;
+    for (int fr = wave; fr < MM_KS_C * 2; fr += 4) {
+      const int ks = fr >> 1, tt = fr & 1;
+      long row = row0 + 32 * tt + j;
+      row = row < p.M ? row : p.M - 1;
+      __builtin_amdgcn_global_load_lds((mm_gbl_t)(p.attn + (size_t)row * C + 16 * ks + 8 * half), (mm_lds_t)(lds + MM_OFF_X + fr * 1024), 16, 0, 0);
+    }
+    for (int q = wave; q < (MM_PRM_FLOATS * 4) / 1024; q += 4)      // b1 | g2 | b2n | proj_b | b2: 12 KB
+      __builtin_amdgcn_global_load_lds((mm_gbl_t)((const unsigned char*)gprm + q * 1024 + lane * 16), (mm_lds_t)(lds + MM_OFF_PRM + q * 1024), 16, 0, 0);
+  }
+  issue(3); issue(3); issue(3); issue(3);            // 12 fragments of the weight list in flight from here on
+  // ---- accumulators = x + proj bias: tile (ft, tt), register r <-> feature 96 wave + 32 ft + (r&3) + 8 (r>>2) + 4 half ----
+  // all 24 row pieces of a lane are requested before anything waits (they queue behind the DMA requests above: one drain)
+  f32x16 acc[3][2];
+  {
+    f32x4 xv[3][4][2];
+#pragma unroll
+    for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          xv[ft][q][tt] = *reinterpret_cast<const f32x4*>(p.x + (size_t)orig[tt] * C + 96 * wave + 32 * ft + 8 * q + 4 * half);
+    __builtin_amdgcn_sched_barrier(0);
+    // everything requested so far has landed (the row loads were issued last: vmcnt(0) covers the DMA before them too)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    MM_STAMP(1);
+#pragma unroll
+    for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(prm + MM_H + 2 * MM_C + 96 * wave + 32 * ft + 8 * q + 4 * half);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ft][tt][4 * q + i] = xv[ft][q][tt][i] + pb[i];
+      }
+  }
+
+  // One GEMM phase: nk k-steps, NA weight tiles per wave; weight fragments are consumed from the ring at list position
+  // `cons` (advanced), activation fragments from `bbuf` ([k-step][2][1 KB]); mm(ft, tt, a, b) issues one MFMA.
+  // Fragments of k-step s+1 are read while the MFMAs of k-step s run; after the reads have returned, NA new fragments are
+  // requested — the stream stays MM_PF fragments ahead of the reads, counted by vmcnt(MM_PF - NA).
+  int cons = 0;
+  auto gemm_phase = [&](auto na_tag, auto nk_tag, const unsigned char* bbuf, auto&& mm, auto&& between) __attribute__((always_inline)) {
+    // NA weight tiles per wave; a loop body covers KU k-steps (fc1 has only 4 MFMAs per k-step: two are paired so that a fragment
+    // is still requested >= 5 MFMAs before its first use); NR fragments of the list per body
+    constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : 1, NR = NA * KU;
+    constexpr int NM = 2 * NA * KU, NRD = (NA + 2) * KU;          // MFMAs / fragment reads per body
+    static_assert(nk % KU == 0 && MM_PF - NR >= 0, "k-steps per body");
+    V8 a[2][KU][3], b[2][KU][2];        // fragments of two bodies: the one in use and the one being read
+    // read q of a body (base k-step ks, weight fragments from list position cons): per k-step the order a0 b0 b1 a1 [a2] against
+    // the MFMA order (a0 b0) (a0 b1) (a1 b0) (a1 b1) [(a2 b0) (a2 b1)]
+    auto rd1 = [&](int buf, int ks, int q) __attribute__((always_inline)) {
+      const int k = q / (NA + 2), r = q % (NA + 2);
+      const int what = r == 0 ? 2 : r <= 2 ? r - 1 : r;            // 0, 1 = activation tile; 2 + i = weight fragment i
+      if (DBG == 4) {
+        if (what < 2) asm volatile("" : "+v"(b[buf][k][what]));
+        else asm volatile("" : "+v"(a[buf][k][what - 2]));
+        return;
+      }
+      if (what < 2) b[buf][k][what] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * 2 + what) * 1024 + lane * 16);
+      else a[buf][k][what - 2] = *reinterpret_cast<const V8*>(ring + ((cons + k * NA + what - 2) & (MM_RING - 1)) * 1024 + lane * 16);
+    };
+    if (DBG == 4) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a[u][k][q] = V8{};
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) b[u][k][tt] = V8{};
+        }
+    }
+    // the next NR fragments of the list have landed: exactly MM_PF - NR younger requests may still be in flight
+    auto landed = [&]() __attribute__((always_inline)) {
+      if (DBG & 1) return;
+#ifdef KVQ_TAIL_TRACE
+      const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MM_PF - NR) : "memory");
+#ifdef KVQ_TAIL_TRACE
+      wait_dma += __builtin_readcyclecounter() - t0_;
+#endif
+    };
+    auto mfma1 = [&](int u, int m) __attribute__((always_inline)) {        // MFMA m of a body: k-step m / 2NA, weight tile, token tile
+      const int k = m / (2 * NA), t = (m % (2 * NA)) >> 1, tt = m & 1;
+      if (DBG & 2) { asm volatile("" :: "v"(a[u][k][t]), "v"(b[u][k][tt])); }
+      else mm(t, tt, a[u][k][t], b[u][k][tt]);
+    };
+    // A body: the fragments of the NEXT body are read and NR new ones requested BETWEEN the MFMAs of this one, one at a time: a
+    // wave's LDS / VMEM issue hides under its own MFMAs only ~10 cycles at a time (tools/ubench/pipe_share.hip) — a burst of 5
+    // reads in front of 6 MFMAs does not hide at all.  Request i (issued behind MFMA NM - NR + i) overwrites the ring slot of list
+    // position cons - 4 + i: a fragment of the previous body, or one of this body that MFMAs already ISSUED have consumed (NA = 3:
+    // cons-4 = previous body, cons-3 = a0, cons-2 = a1, used by MFMAs 0..3; NA = 2, two k-steps: cons-4+i is used by MFMAs 2i, 2i+1
+    // and overwritten behind MFMA 4+i) — no wait for LDS reads is needed.
+    auto body = [&](int s, bool more) __attribute__((always_inline)) {
+      const int u = (s / KU) & 1;
+      if (more) landed();
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        mfma1(u, m);
+        if (more && m < NRD) rd1(u ^ 1, s + KU, m);
+        if (more && m >= NM - NR) issue(1);
+        between(s * 2 * NA + m);                        // VALU work of the caller, placed between two MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) cons += NR;
+    };
+    landed();
+#pragma unroll
+    for (int q = 0; q < NRD; ++q) rd1(0, 0, q);
+    cons += NR;
+    issue(NR > 3 ? 3 : NR);
+    if (NR > 3) issue(NR - 3);
+#pragma unroll
+    for (int s = 0; s + KU < nk; s += KU) body(s, true);
+    body(nk - KU, false);
+  };
+  using KC = std::integral_constant<int, MM_KS_C>;
+  using KH = std::integral_constant<int, MM_KS_H>;
+  auto nothing = [](int) {};
+  using T2 = std::integral_constant<int, 2>;
+  using T3 = std::integral_constant<int, 3>;
+
+  // ---- proj: acc (= x + bias) += Wp . attn^T -------------------------------------------------------------------------
+  gemm_phase(T3{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+
+  // ---- LayerNorm statistics of a token over the 4 waves' slices: in-lane + lane^32 + LDS exchange; two passes -----------
+  auto token_sums = [&](auto&& term) __attribute__((always_inline)) {       // term(ft, tt, r) -> sum over all 384 features, per tt
+    float s[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      float v = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += term(ft, tt, r);
+      v += __shfl_xor(v, 32);
+      s[tt] = v;
+    }
+    __syncthreads();                               // the previous use of `red` has been read by everybody
+    if (half == 0) {
+      red[wave * MM_TOK + j] = s[0];
+      red[wave * MM_TOK + 32 + j] = s[1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+      s[tt] = (red[0 * MM_TOK + 32 * tt + j] + red[1 * MM_TOK + 32 * tt + j]) + (red[2 * MM_TOK + 32 * tt + j] + red[3 * MM_TOK + 32 * tt + j]);
+    return f32x2{s[0], s[1]};
+  };
+  // (acc - mean) * rstd * gamma + beta, 16-bit, written as B fragments: tile ft covers k-steps kbase + 2 ft + {0, 1}
+  auto write_norm = [&](const f32x2 mean, const f32x2 rstd, const float* gam, const float* bet, unsigned char* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {               // quad pair (2 hp, 2 hp + 1) = 16 features = one k-step
+        const int f0 = 96 * wave + 32 * ft + 16 * hp + 4 * half;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + f0), g1 = *reinterpret_cast<const f32x4*>(gam + f0 + 8);
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(bet + f0), e1 = *reinterpret_cast<const f32x4*>(bet + f0 + 8);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          float y[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            y[i] = (acc[ft][tt][8 * hp + i] - mean[tt]) * rstd[tt] * g0[i] + e0[i];
+            y[4 + i] = (acc[ft][tt][8 * hp + 4 + i] - mean[tt]) * rstd[tt] * g1[i] + e1[i];
+          }
+          const u32x4 w = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3]), E::pack2(y[4], y[5]), E::pack2(y[6], y[7])};
+          const int ks = 6 * wave + 2 * ft + hp;
+          *reinterpret_cast<u32x4*>(dst + (ks * 2 + tt) * 1024 + lane * 16) = w;
+        }
+      }
+  };
+  {
+    const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
+    const f32x2 mean = sum * (1.0f / (float)C);
+    const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
+    const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+    // every wave is past its last read of the attention tile (two barriers ago): norm2 rows take its place
+    write_norm(mean, rstd, prm + MM_H, prm + MM_H + MM_C, lds + MM_OFF_X);
+  }
+  // acc becomes the fc2 accumulator: x_mid + fc2 bias
+#pragma unroll
+  for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(prm + MM_H + 3 * MM_C + 96 * wave + 32 * ft + 8 * q + 4 * half);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ft][tt][4 * q + i] += b2[i];
+    }
+  MM_BARRIER();                                      // norm2 rows complete
+  MM_STAMP(2);
+
+  // ---- MLP over 6 chunks of 256 hidden units: fc1 (wave: 64 units x 64 tokens) -> GELU -> LDS -> fc2 partial.  Software
+  // pipeline: fc1 of chunk c+1 runs first, then the GELU of chunk c+1 is evaluated BETWEEN the MFMAs of fc2(chunk c) — one pair
+  // per three MFMAs — so that the VALU stream no longer stops the weight stream (the ring only buffers 12 KB per wave) ----------
+  f32x16 hacc[2][2];
+  u32x4 gp[2][2][2];                                  // GELU outputs of a chunk, packed: [weight tile][k-step half][token tile]
+  auto fc1 = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(prm + MM_HC * c + 64 * wave + 32 * ft + 8 * q + 4 * half);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) hacc[ft][tt][4 * q + i] = b1[i];
+      }
+    gemm_phase(T2{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) { hacc[ft][tt] = E::mfma32(a, b, hacc[ft][tt]); }, nothing);
+  };
+  auto gelu_pair = [&](int pi) __attribute__((always_inline)) {      // pi = ((ft * 2 + hp) * 2 + tt) * 4 + i, 0..31
+    const int i = pi & 3, tt = (pi >> 2) & 1, hp = (pi >> 3) & 1, ft = pi >> 4;
+    const int r = 8 * hp + 2 * (i & 1) + 4 * (i >> 1);              // pairs (r, r+1): i = 0,1 -> quad 2hp; i = 2,3 -> quad 2hp+1
+    const f32x2 gv = gelu_fast2(f32x2{hacc[ft][tt][r], hacc[ft][tt][r + 1]});
+    uint32_t w = E::pack2(gv[0], gv[1]);
+    asm volatile("" : "+v"(w));                        // pins the evaluation where it is placed
+    gp[ft][hp][tt][i] = w;
+  };
+  auto write_gelu = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          *reinterpret_cast<u32x4*>(lds + MM_OFF_G + ((4 * wave + 2 * ft + hp) * 2 + tt) * 1024 + lane * 16) = gp[ft][hp][tt];
+  };
+  fc1(0);
+#pragma unroll
+  for (int pi = 0; pi < 32; ++pi) gelu_pair(pi);
+  write_gelu();
+  MM_BARRIER();                                      // GELU rows of chunk 0 complete
+  for (int c = 0; c < MM_NCH; ++c) {
+    const bool more = c + 1 < MM_NCH;
+    if (more) {
+      fc1(c + 1);
+      gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); },
+                 [&](int m) { if (m % 3 == 0) gelu_pair(m / 3); });
+      MM_BARRIER();                                  // everybody has finished fc2 of chunk c: its GELU rows may go
+      write_gelu();
+      MM_BARRIER();                                  // GELU rows of chunk c + 1 complete
+    } else {
+      gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+    }
+  }
+
+  MM_STAMP(3);
+  // ---- write the residual stream back; optionally the next block's norm1 rows in ITS window order ----------------------
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+    if (live[tt]) {
+      float* xr = p.x + (size_t)orig[tt] * C + 96 * wave + 4 * half;
+#pragma unroll
+      for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(xr + 32 * ft + 8 * q) = (f32x4){acc[ft][tt][4 * q], acc[ft][tt][4 * q + 1], acc[ft][tt][4 * q + 2], acc[ft][tt][4 * q + 3]};
+    }
+  if (EMIT) {
+    const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
+    const f32x2 mean = sum * (1.0f / (float)C);
+    const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
+    const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+      if (live[tt]) {
+        const long drow = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
+        uint16_t* o = p.next_ln + (size_t)drow * C + 96 * wave + 4 * half;
+#pragma unroll
+        for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f0 = 96 * wave + 32 * ft + 8 * q + 4 * half;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.nn_w + f0), be = *reinterpret_cast<const f32x4*>(p.nn_b + f0);
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (acc[ft][tt][4 * q + i] - mean[tt]) * rstd[tt] * gm[i] + be[i];
+            *reinterpret_cast<u32x2*>(o + 32 * ft + 8 * q) = (u32x2){E::pack2(y[0], y[1]), E::pack2(y[2], y[3])};
+          }
+      }
+  }
+#ifdef KVQ_TAIL_TRACE
+  if (tr) {
+    __builtin_amdgcn_s_waitcnt(0);
+    p.trace[blockIdx.x * 8 + 5] = wait_dma;
+    p.trace[blockIdx.x * 8 + 6] = wait_bar;
+  }
+#endif
+  MM_STAMP(4);
+}
+
+template <typename E, int DBG>
+static int launch_mm_dbg(const TailParams& p, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(p.M, MM_TOK)), block(256);
+  auto k = block_tailmm_kernel<E, true, DBG>;
+  KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS));
+  hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
+  KVQ_CHECK_LAUNCH("block_tailmm_kernel(dbg)");
+  return KVQ_OK;
+}
+
+template <typename E>
+static int launch_mm(const TailParams& p, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(p.M, MM_TOK)), block(256);
+  static const int dbg = getenv("KVQ_MM_DEBUG") ? atoi(getenv("KVQ_MM_DEBUG")) : 0;
+  if (dbg && p.next_ln) {
+    if (dbg == 1) return launch_mm_dbg<E, 1>(p, st);
+    if (dbg == 2) return launch_mm_dbg<E, 2>(p, st);
+    if (dbg == 3) return launch_mm_dbg<E, 3>(p, st);
+    if (dbg == 4) return launch_mm_dbg<E, 4>(p, st);
+  }
+  if (p.next_ln) {
+    auto k = block_tailmm_kernel<E, true>;
+    static bool set = false;
+    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
+    hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
+  } else {
+    auto k = block_tailmm_kernel<E, false>;
+    static bool set = false;
+    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
+    hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
+  }
+  KVQ_CHECK_LAUNCH("block_tailmm_kernel");
+  return KVQ_OK;
+}
+
+int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
+  KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
+  return dtype == KVQ_DT_FP16 ? launch_mm<Fp16>(p, st) : launch_mm<Bf16>(p, st);
+}
+
+}  // namespace kvq

@@ -117,6 +117,7 @@ TRUNK_CASES = [
     ("t_grpb_init_32x224", "SWIN_T_GRPB", "init", 3, 16, 1, 32, 224, 224),
     # the other model.py keys (model.py:39-47): swin_small (depths 2/2/18/2) and swin_tiny_grpb_m (window 4,4,4)
     ("s_plain_stress_16x96", "SWIN_S_PLAIN", "stress", 4, 17, 1, 16, 96, 96),
+    ("s_plain_init_16x96", "SWIN_S_PLAIN", "init", 7, 20, 1, 16, 96, 96),
     ("t_m444_stress_16x96", "SWIN_T_GRPB_M", "stress", 5, 18, 1, 16, 96, 96),
     ("t_m444_stress_12x72x104", "SWIN_T_GRPB_M", "stress", 6, 19, 2, 12, 72, 104),
 ]
