@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 11
+#define KVQ_ABI_VERSION 12
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -230,7 +230,15 @@ typedef struct {
   const uint16_t* resid_bf16; /* KVQ_EPI_RELU_BF16: optional [M][N] identity branch, same dtype */
   const float* resid_f32;     /* KVQ_EPI_RELU_BF16: optional fp32 [M][N] identity branch; with this epilogue a
                                  non-NULL out_f32 additionally receives the fp32 (un-rounded) result */
+  /* Split-K (long K, few output tiles: the late convolutions of the conv nets, stage 3 of the trunk): NULL = never.  With a
+   * scratch buffer the launch MAY cut K into S ranges (kvq_gemm_splitk_factor), each workgroup writing its fp32 partial tile
+   * [S][M][N] there; a second launch sums the S partials IN ORDER (bit-reproducible) and applies the epilogue.  Not for QKV. */
+  void* splitk_ws;
+  size_t splitk_ws_bytes;     /* >= kvq_gemm_splitk_bytes(M, N, K) or the launch stays un-split */
 } KvqGemmArgs;
+/* S the launch would use (1 = no split) and the scratch bytes that S needs */
+int kvq_gemm_splitk_factor(int M, int N, int K);
+size_t kvq_gemm_splitk_bytes(int M, int N, int K);
 
 int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
 /* Diagnostic: while dev_buf != NULL every GEMM block b < max_blocks writes uint64 stamps
@@ -439,6 +447,8 @@ typedef struct {
   float* out_f32;         /* optional fp32 copy (RELU epilogue) */
   const uint16_t* resid_bf16;
   const float* resid_f32;
+  void* splitk_ws;        /* optional split-K scratch, as in KvqGemmArgs (M = B*Do*Ho*Wo, K = Kpad) */
+  size_t splitk_ws_bytes;
 } KvqConvArgs;
 int kvq_conv_implicit(const KvqConvArgs* host_args, void* stream);
 

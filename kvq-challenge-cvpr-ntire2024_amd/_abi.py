@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def dtype_code(dt) -> int:
@@ -66,14 +66,15 @@ class KvqGemmArgs(C.Structure):
     _fields_ = [("A", p_void), ("W", p_void), ("bias", p_void), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
-                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void)]
+                ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void),
+                ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t)]
 
 
 class KvqConvArgs(C.Structure):
     _fields_ = [("x", p_void), ("W", p_void), ("bias", p_void), ("taps", p_void), ("dims5", C.c_int32 * 5),
                 ("kernel3", C.c_int32 * 3), ("stride3", C.c_int32 * 3), ("pad3", C.c_int32 * 3), ("Kpad", C.c_int32),
                 ("N", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
-                ("resid_bf16", p_void), ("resid_f32", p_void)]
+                ("resid_bf16", p_void), ("resid_f32", p_void), ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t)]
 
 
 class KvqBlockTailArgs(C.Structure):
@@ -130,6 +131,8 @@ SYMBOLS = {
     "kvq_layernorm_rows": (i32, [p_void, p_void, i32, i32, i32, i32, i32, p_void, p_void, f32, p_void, i32, p_void,
                                  p_void]),
     "kvq_gemm_bf16": (i32, [C.POINTER(KvqGemmArgs), p_void]),
+    "kvq_gemm_splitk_factor": (i32, [i32, i32, i32]),
+    "kvq_gemm_splitk_bytes": (sz, [i32, i32, i32]),
     "kvq_debug_gemm_trace": (i32, [p_void, i32]),
     "kvq_patch_embed_supported": (i32, [i32] * 8),
     "kvq_patch_embed_pack_bytes": (sz, [i32, i32]),

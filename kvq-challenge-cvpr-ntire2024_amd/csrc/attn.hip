@@ -542,21 +542,26 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
       kfC = kfN;
     }
     ATT_MARK(t_s);
-    float mx = -INFINITY;
+    // row max: two chains of 3-input maxima (v_max3_f32: two new scores per instruction, 50 instead of 75 for the 100 scores)
+    float mx = S[0][0], mx1 = S[0][2];
 #pragma unroll
-    for (int t = 0; t < NTD; ++t) mx = fmaxf(mx, fmaxf(fmaxf(S[t][0], S[t][1]), fmaxf(S[t][2], S[t][3])));
+    for (int t = 0; t < NTD; ++t) {
+      mx = fmaxf(fmaxf(mx, S[t][0]), S[t][1]);
+      mx1 = fmaxf(fmaxf(mx1, S[t][2]), S[t][3]);
+    }
+    mx = fmaxf(mx, mx1);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mb = mx * kLog2e;
+    // exponent arguments two at a time (v_pk_fma_f32: the kernel is VALU-issue bound, tools/ubench/pipe_share.hip)
+    const f32x2 k2 = {kLog2e, kLog2e}, mb2 = {-mx * kLog2e, -mx * kLog2e};
     uint32_t P[ATT_NT][2];
     P[ATT_NT - 1][0] = P[ATT_NT - 1][1] = 0u;       // keys 400..415: padding for every supported N (<= 400)
 #pragma unroll
     for (int t = 0; t < NTD; ++t) {
-      float e[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(S[t][r], kLog2e, -mb));
-      P[t][0] = E::pack2_raw(e[0], e[1]);
-      P[t][1] = E::pack2_raw(e[2], e[3]);
+      const f32x2 x0 = __builtin_elementwise_fma((f32x2){S[t][0], S[t][1]}, k2, mb2);
+      const f32x2 x1 = __builtin_elementwise_fma((f32x2){S[t][2], S[t][3]}, k2, mb2);
+      P[t][0] = E::pack2_raw(__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1]));
+      P[t][1] = E::pack2_raw(__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1]));
     }
     ATT_MARK(t_x);
     f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f}, Ls = {0.f, 0.f, 0.f, 0.f};

@@ -12,6 +12,8 @@
 // by LDS-DMA with counted waits (see the kernel comment).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace kvq {
@@ -36,6 +38,11 @@ struct GemmParams {
   // of K {kd, kh, kw, element offset ((kd*H + kh)*W + kw)*Cin + c0}, offset < 0 = a chunk of the K padding.
   const int4* taps;
   int cD, cH, cW, cC, cDo, cHo, cWo, csd, csh, csw, cpd, cph, cpw;
+  // split-K: the grid holds ksplit copies of the tile grid; copy s multiplies k-slices [s nk / ksplit, (s + 1) nk / ksplit) and
+  // stores its fp32 partial tile at out_f32 + s M N (KVQ_EPI_STORE_F32 instantiation, no bias); splitk_reduce_kernel finishes
+  int ksplit;
+  float* sk_ws;                // host side only: split-K scratch of the caller (NULL = never split) and its size
+  size_t sk_bytes;
 };
 
 // what out-of-image / K-padding chunks of an implicit-GEMM A tile are fetched from
@@ -92,7 +99,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // row-panel share an L2 instead of fetching it once per XCD (bijective also when nwg % 8 != 0).
   const int nbn = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, qd = nwg >> 3, rm = nwg & 7;
-  const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+  const int lid0 = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+  const int ntile = nwg / p.ksplit, ksl = lid0 / ntile, lid = lid0 - ksl * ntile;     // K range index (slowest), tile
   const int bm = lid / nbn, bn = lid % nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       a_t0[i] = dq * p.csd - p.cpd; a_y0[i] = ho * p.csh - p.cph; a_x0[i] = wo * p.csw - p.cpw; a_c[i] = c;
       // element offset of (b, t0, y0, x0, 0): may point before the image; only ever dereferenced with an in-bounds tap added
       a_src[i] = p.A + ((((long)b * p.cD + a_t0[i]) * p.cH + a_y0[i]) * p.cW + a_x0[i]) * (long)p.cC;
-      a_tap[i] = p.taps[c];
+      a_tap[i] = p.taps[(ksl * (p.K / BK) / p.ksplit) * CH + c];
     } else {
       a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
     }
@@ -122,8 +130,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
     b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
-  auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt % NST) * ST_BYTES;
+  const int kt0 = ksl * (p.K / BK) / p.ksplit, nk = (ksl + 1) * (p.K / BK) / p.ksplit - kt0;      // this workgroup's k-slices
+  auto issue = [&](int kl) {                      // kl: slice index inside the range; ring slot kl % NST
+    const int kt = kt0 + kl;
+    unsigned char* st = lds + (kl % NST) * ST_BYTES;
     if (IMPL) {
       // issue() is called for consecutive slices: the tap of THIS slice was fetched during the previous call (its L2
       // latency would otherwise sit in front of every DMA), the next slice's is requested now
@@ -160,7 +170,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
   (void)bn;
   if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
-  const int nk = p.K / BK;
   issue(0);
   if (NST > 2 && nk > 1) issue(1);
   const int frow = lane & 31, fkg = lane >> 5;
@@ -339,8 +348,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[k] += v[k];
         *o = x;
-      } else {  // KVQ_EPI_STORE_F32
-        *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n) = (f32x4){v[0], v[1], v[2], v[3]};
+      } else {  // KVQ_EPI_STORE_F32 (split-K: partial tile of K range ksl)
+        *reinterpret_cast<f32x4*>(p.out_f32 + ((size_t)ksl * p.M + m) * p.N + n) = (f32x4){v[0], v[1], v[2], v[3]};
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -356,7 +365,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 }
 
 template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false>
-static int launch_one(const GemmParams& p, hipStream_t st) {
+static int launch_one(const GemmParams& p_in, hipStream_t st) {
+  GemmParams p = p_in;
+  p.ksplit = p.ksplit < 1 ? 1 : p.ksplit;
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr size_t main_bytes = NST * (BM + BN) * BK * 2;               // ring of 2*BK-byte rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
@@ -368,10 +379,90 @@ static int launch_one(const GemmParams& p, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN)), block(256);
+  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN) * p.ksplit), block(256);
   hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
   KVQ_CHECK_LAUNCH("gemm_kernel");
   return KVQ_OK;
+}
+
+// ---- split-K, second launch: out = epilogue(sum_s partial[s]) — the S partials are added in index order (bit-reproducible),
+// then bias / activation / identity / residual scatter exactly as the GEMM's own epilogue does.  A thread owns 8 columns of a row.
+template <typename E>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const float* partial, int S, int epi) {
+  fp16_saturate_mode();
+  const long chunks = (long)p.M * (p.N / 8);
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= chunks) return;
+  const int m = (int)(idx / (p.N / 8)), n = (int)(idx % (p.N / 8)) * 8;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.f;
+  for (int s2 = 0; s2 < S; ++s2) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial + ((size_t)s2 * p.M + m) * p.N + n);
+    const f32x4 a = src[0], b = src[1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+  }
+  if (p.bias) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.bias + n), b = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+  }
+  if (epi == KVQ_EPI_STORE_F32 || epi == KVQ_EPI_RESID_F32) {
+    long orow = m;
+    if (epi == KVQ_EPI_RESID_F32 && p.scatter_map) {
+      const int b = m / p.map_rows, s3 = p.scatter_map[m - b * p.map_rows];
+      if (s3 < 0) return;
+      orow = (long)b * p.out_rows + s3;
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(p.out_f32 + (size_t)orow * p.N + n);
+    f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+    if (epi == KVQ_EPI_RESID_F32) { x0 += o[0]; x1 += o[1]; }
+    o[0] = x0; o[1] = x1;
+    return;
+  }
+  if (epi == KVQ_EPI_GELU_BF16) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+  } else if (epi == KVQ_EPI_QGELU_BF16) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] / (1.f + __expf(-1.702f * v[k]));
+  } else if (epi == KVQ_EPI_RELU_BF16) {
+    if (p.resid_h) {
+      const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid_h + (size_t)m * p.N + n);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] += E::to_f32((uint16_t)(rr[k] & 0xffffu));
+        v[2 * k + 1] += E::to_f32((uint16_t)(rr[k] >> 16));
+      }
+    }
+    if (p.resid_f32) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.resid_f32 + (size_t)m * p.N + n);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.resid_f32 + (size_t)m * p.N + n + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    if (p.out_f32) {
+      f32x4* o = reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.N + n);
+      o[0] = (f32x4){v[0], v[1], v[2], v[3]};
+      o[1] = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+  }
+  *reinterpret_cast<u32x4*>(p.out_h + (size_t)m * p.N + n) =
+      (u32x4){E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4], v[5]), E::pack2(v[6], v[7])};
+}
+
+// S for a launch of `tiles` output tiles walking nk ring slices each: few tiles on 256 CUs with a long K loop are split until
+// about two workgroups per CU exist, keeping >= 12 slices per workgroup (below that the prologue / epilogue dominate again)
+static int splitk_factor(long tiles, int nk) {
+  static const int off = getenv("KVQ_GEMM_SPLITK") && atoi(getenv("KVQ_GEMM_SPLITK")) == 0;
+  if (off || tiles > 200 || nk < 24) return 1;
+  int S = (int)(512 / tiles);
+  S = S > 8 ? 8 : S;
+  while (S > 1 && nk / S < 12) --S;
+  return S < 1 ? 1 : S;
 }
 
 // tile (MI, NI) for a shape, encoded (10*MI + NI)*100 + BK
@@ -404,8 +495,29 @@ int gemm_variant(int M, int N, int K) {
   return ((rem != 0 && rem <= 64) ? 21 : 22) * 100 + 32;
 }
 
+// the tile grid and slice count of the variant launch_gemm / launch_conv would pick
+static void variant_tiles(int M, int N, int K, bool conv, long* tiles, int* nk) {
+  int var = gemm_variant(M, N, K);
+  int bk = var % 100, mi = var / 1000, ni = (var / 100) % 10;
+  if (conv) {
+    const int v = var / 100;
+    if (v != 22 && v != 21 && v != 12 && v != 11) { mi = 2; ni = 2; }
+    bk = 32;
+  }
+  *tiles = (long)ceil_div(M, 64 * mi) * ceil_div(N, 64 * ni);
+  *nk = K / bk;
+}
+
 template <typename E, int EPI>
-static int launch_gemm(const GemmParams& p, hipStream_t st) {
+static int finish_splitk(const GemmParams& p, const float* partial, int S, hipStream_t st) {
+  const long chunks = (long)p.M * (p.N / 8);
+  hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, p, partial, S, (int)EPI);
+  KVQ_CHECK_LAUNCH("splitk_reduce_kernel");
+  return KVQ_OK;
+}
+
+template <typename E, int EPI>
+static int launch_gemm_variant(const GemmParams& p, hipStream_t st) {
   const int var = gemm_variant(p.M, p.N, p.K);
   // 128x128 with 64-deep slices and a 2-slice ring (64 KB, 2 workgroups per CU; whole 128-B lines per DMA row):
   // measured per epilogue on the trunk's shapes — qkv stage 2: 28 -> 26 us, stage 3: 25 -> 22; fc1 equal; fc2 +2 us
@@ -425,9 +537,16 @@ static int launch_gemm(const GemmParams& p, hipStream_t st) {
   }
 }
 
+// split-K around a variant launcher: partial tiles (STORE_F32 instantiation of the same variant) + the reduce / epilogue launch
+template <typename E, int EPI, bool CONV>
+static int launch_maybe_split(const GemmParams& p, hipStream_t st);
+
+template <typename E, int EPI>
+static int launch_gemm(const GemmParams& p, hipStream_t st) { return launch_maybe_split<E, EPI, false>(p, st); }
+
 // implicit-GEMM convolution: the 32-deep variants only (a slice = 4 chunks = at most 4 taps)
 template <typename E, int EPI>
-static int launch_conv(const GemmParams& p, hipStream_t st) {
+static int launch_conv_variant(const GemmParams& p, hipStream_t st) {
   int var = gemm_variant(p.M, p.N, p.K) / 100;
   if (var != 22 && var != 21 && var != 12 && var != 11) var = 22;
   switch (var) {
@@ -436,6 +555,26 @@ static int launch_conv(const GemmParams& p, hipStream_t st) {
     case 12: return launch_one<E, 1, 2, 32, EPI, KVQ_GEMM_NST, true>(p, st);
     default: return launch_one<E, 1, 1, 32, EPI, KVQ_GEMM_NST, true>(p, st);
   }
+}
+
+template <typename E, int EPI>
+static int launch_conv(const GemmParams& p, hipStream_t st) { return launch_maybe_split<E, EPI, true>(p, st); }
+
+template <typename E, int EPI, bool CONV>
+static int launch_maybe_split(const GemmParams& p, hipStream_t st) {
+  long tiles;
+  int nk;
+  variant_tiles(p.M, p.N, p.K, CONV, &tiles, &nk);
+  const int S = (EPI != KVQ_EPI_QKV_BF16 && p.sk_ws) ? splitk_factor(tiles, nk) : 1;
+  if (S > 1 && (size_t)S * p.M * p.N * sizeof(float) <= p.sk_bytes) {
+    GemmParams q = p;
+    q.bias = nullptr; q.out_f32 = p.sk_ws; q.out_h = nullptr; q.scatter_map = nullptr; q.resid_h = nullptr; q.resid_f32 = nullptr;
+    q.ksplit = S;
+    const int rc = CONV ? launch_conv_variant<E, KVQ_EPI_STORE_F32>(q, st) : launch_gemm_variant<E, KVQ_EPI_STORE_F32>(q, st);
+    if (rc) return rc;
+    return finish_splitk<E, EPI>(p, p.sk_ws, S, st);
+  }
+  return CONV ? launch_conv_variant<E, EPI>(p, st) : launch_gemm_variant<E, EPI>(p, st);
 }
 
 template <int EPI>
@@ -458,6 +597,25 @@ extern "C" int kvq_debug_gemm_trace(void* dev_buf, int max_blocks) {
   return KVQ_OK;
 }
 
+extern "C" int kvq_gemm_splitk_factor(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 1;
+  long tiles;
+  int nk;
+  kvq::variant_tiles(M, N, K, false, &tiles, &nk);
+  return kvq::splitk_factor(tiles, nk);
+}
+
+extern "C" size_t kvq_gemm_splitk_bytes(int M, int N, int K) {
+  // the conv front end may pick a different tile for the same (M, N, K): size for the larger factor of the two
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
+  long t1, t2;
+  int n1, n2;
+  kvq::variant_tiles(M, N, K, false, &t1, &n1);
+  kvq::variant_tiles(M, N, K, true, &t2, &n2);
+  const int S = std::max(kvq::splitk_factor(t1, n1), kvq::splitk_factor(t2, n2));
+  return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
 extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(a && a->A && a->W, KVQ_ERR_NULL, "kvq_gemm_bf16: NULL A/W");
@@ -467,6 +625,9 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
               "kvq_gemm_bf16: unknown dtype %d", a->dtype);
   GemmParams p{a->A, a->W, a->bias, a->M, a->N, a->K, a->out_bf16, a->out_f32, a->num_heads, a->q_scale,
                a->scatter_map, a->map_rows, a->out_rows, a->resid_bf16, a->resid_f32, g_trace, g_trace_blocks};
+  p.ksplit = 1;
+  p.sk_ws = (float*)a->splitk_ws; p.sk_bytes = a->splitk_ws_bytes;
+  KVQ_REQUIRE(!p.sk_ws || ((size_t)p.sk_ws & 15) == 0, KVQ_ERR_SHAPE, "kvq_gemm_bf16: splitk_ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   switch (a->epilogue) {
     case KVQ_EPI_BIAS_BF16:
@@ -529,6 +690,9 @@ extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
   p.cD = D; p.cH = H; p.cW = W; p.cC = Cin; p.cDo = Do; p.cHo = Ho; p.cWo = Wo;
   p.csd = a->stride3[0]; p.csh = a->stride3[1]; p.csw = a->stride3[2];
   p.cpd = a->pad3[0]; p.cph = a->pad3[1]; p.cpw = a->pad3[2];
+  p.ksplit = 1;
+  p.sk_ws = (float*)a->splitk_ws; p.sk_bytes = a->splitk_ws_bytes;
+  KVQ_REQUIRE(!p.sk_ws || ((size_t)p.sk_ws & 15) == 0, KVQ_ERR_SHAPE, "kvq_conv_implicit: splitk_ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (a->epilogue == KVQ_EPI_STORE_F32)      // projection shortcuts: conv + BN, no ReLU, kept in fp32
     return a->dtype == KVQ_DT_FP16 ? launch_conv<Fp16, KVQ_EPI_STORE_F32>(p, st) : launch_conv<Bf16, KVQ_EPI_STORE_F32>(p, st);

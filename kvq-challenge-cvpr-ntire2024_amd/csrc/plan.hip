@@ -46,7 +46,8 @@ struct KvqSwinPlan {
   std::vector<kvq::StageGeom> st;
   std::vector<void*> owned;      // device allocations to free
   size_t ws_bytes;
-  size_t off_x0, off_x1, off_ln, off_big, off_o;
+  size_t off_x0, off_x1, off_ln, off_big, off_o, off_sk, sk_bytes;   // off_sk: split-K scratch of the un-fused GEMMs
+  unsigned char* run_ws;         // workspace of the forward in progress (for the GEMM helper)
   int table_len, center;
   std::vector<float*> taps;      // feats[i] destinations (kvq_swin3d_set_taps), empty = none
   // profiling
@@ -183,7 +184,7 @@ extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H
   pl->table_len = (2 * Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1);
   pl->center = (Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1) + (Wh - 1) * (2 * Ww - 1) + (Ww - 1);
   int D = pl->D0, Hh = pl->H0, Wv = pl->W0;
-  size_t max_x = 0, max_ln = 0, max_big = (size_t)B * D * Hh * Wv * pl->K0, max_o = 0;
+  size_t max_x = 0, max_ln = 0, max_big = (size_t)B * D * Hh * Wv * pl->K0, max_o = 0, max_sk = 0;
   for (int i = 0; i < cfg->num_stages; ++i) {
     StageGeom g{};
     g.D = D; g.H = Hh; g.W = Wv; g.C = cfg->embed_dim << i; g.nH = cfg->num_heads[i]; g.depth = cfg->depths[i];
@@ -197,6 +198,13 @@ extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H
     max_ln = std::max(max_ln, std::max(BLp * g.C, BL * g.C));
     max_big = std::max(max_big, std::max(BLp * 3 * g.C, BL * (size_t)cfg->mlp_ratio * g.C));
     max_o = std::max(max_o, BLp * g.C);
+    {   // GEMM shapes of this stage that may run split-K (long K, few tiles: stage 3 of the trunk)
+      const int Mw = (int)BLp, Mt = (int)BL, C = g.C, Hd = cfg->mlp_ratio * g.C;
+      max_sk = std::max(max_sk, std::max(kvq_gemm_splitk_bytes(Mw, C, C), std::max(kvq_gemm_splitk_bytes(Mt, Hd, C),
+                                                                                    kvq_gemm_splitk_bytes(Mt, C, Hd))));
+      if (i < cfg->num_stages - 1)
+        max_sk = std::max(max_sk, kvq_gemm_splitk_bytes(B * g.Dn * g.Hn * g.Wn, 2 * C, 4 * C));
+    }
     pl->st.push_back(g);
     if (i < cfg->num_stages - 1) { Hh = g.Hn; Wv = g.Wn; }
   }
@@ -206,6 +214,9 @@ extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H
   pl->off_ln = off; off += align_up(max_ln * 2);
   pl->off_big = off; off += align_up(max_big * 2);
   pl->off_o = off; off += align_up(max_o * 2);
+  pl->off_sk = off; off += align_up(max_sk);
+  pl->sk_bytes = max_sk;
+  pl->run_ws = nullptr;
   pl->ws_bytes = off;
   *out = pl;
   return KVQ_OK;
@@ -325,6 +336,10 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
   a.A = A; a.W = Wt; a.bias = bias; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_bf16 = obf; a.out_f32 = of32;
   a.num_heads = nH; a.q_scale = qs; a.scatter_map = map; a.map_rows = map_rows; a.out_rows = out_rows;
   a.dtype = pl->dtype;
+  if (pl->sk_bytes && pl->run_ws && epi != KVQ_EPI_QKV_BF16) {
+    a.splitk_ws = pl->run_ws + pl->off_sk;
+    a.splitk_ws_bytes = pl->sk_bytes;
+  }
   // algorithmic bytes: A + W once, output once (fp32 residual epilogues read-modify-write)
   const double out_b = (epi == KVQ_EPI_RESID_F32) ? 8.0 : (epi == KVQ_EPI_STORE_F32 ? 4.0 : 2.0);
   Bracket br(pl, st, kind, gemm_variant(M, N, K) * 10 + epi, 2.0 * M * N * K,
@@ -388,6 +403,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   const KvqSwinCfg& cfg = pl->cfg;
   const int B = pl->B;
   unsigned char* ws = (unsigned char*)workspace;
+  pl->run_ws = ws;
   float* xa = (float*)(ws + pl->off_x0);
   float* xb = (float*)(ws + pl->off_x1);
   uint16_t* bln = (uint16_t*)(ws + pl->off_ln);

@@ -47,6 +47,18 @@ def layernorm_rows(x: torch.Tensor, gamma, beta, *, index_map: Optional[torch.Te
     return out
 
 
+def _splitk_scratch(a, M: int, N: int, K: int, device):
+    """Split-K scratch for a GEMM / implicit-conv launch (long K, few output tiles): the library says how much it would use;
+    the buffer comes from torch's stream-ordered allocator (reused only by later work of this stream), so it may be dropped
+    as soon as the launch is enqueued.  Returned so that the caller keeps it alive across the call."""
+    nb = lib().kvq_gemm_splitk_bytes(M, N, K)
+    if not nb:
+        return None
+    ws = torch.empty(nb, dtype=torch.uint8, device=device)
+    a.splitk_ws, a.splitk_ws_bytes = ptr(ws), nb
+    return ws
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int, *, out=None,
          num_heads=0, q_scale=1.0, scatter_map=None, map_rows=0, out_rows=0):
     """A [M,K], W [N,K], both fp16 or both bf16.  Returns the output tensor (allocated unless given)."""
@@ -73,6 +85,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     a.num_heads, a.q_scale = num_heads, q_scale
     a.scatter_map, a.map_rows, a.out_rows = ptr(scatter_map), map_rows, out_rows
     a.dtype = dtype_code(A.dtype)
+    _ws = _splitk_scratch(a, a.M, a.N, a.K, A.device) if a.epilogue != _abi.EPI_QKV_BF16 else None   # noqa: F841
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
     return out
 
@@ -261,6 +274,7 @@ def conv_gemm(A: torch.Tensor, W: torch.Tensor, bias, relu: bool, resid=None, re
     assert relu or (resid is None and resid_f32 is None and not want_f32), "identity add / fp32 copy: ReLU epilogue only"
     a.out_bf16, a.out_f32, a.resid_bf16, a.resid_f32 = ptr(out), ptr(out32), ptr(resid), ptr(resid_f32)
     a.dtype = dtype_code(A.dtype)
+    _ws = _splitk_scratch(a, a.M, a.N, a.K, A.device) if a.epilogue != _abi.EPI_QKV_BF16 else None   # noqa: F841
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
     return (out, out32) if want_f32 else out
 
@@ -480,6 +494,7 @@ def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, r
     a.epilogue = _abi.EPI_STORE_F32 if store_f32 else (_abi.EPI_RELU_BF16 if relu else _abi.EPI_BIAS_BF16)
     a.dtype = dtype_code(x.dtype)
     a.out_bf16, a.out_f32, a.resid_bf16, a.resid_f32 = ptr(out), ptr(out32), ptr(resid), ptr(resid_f32)
+    _ws = _splitk_scratch(a, x.shape[0] * Do * Ho * Wo, N, k_pad, x.device)   # noqa: F841
     check(lib().kvq_conv_implicit(C.byref(a), current_stream()), "kvq_conv_implicit")
     if store_f32:
         return out32

@@ -104,6 +104,11 @@ def pack_pathway_output(frames, device=None):
 
 
 IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
+# Residual stream between bottlenecks: 16-bit (default) or fp32.  The conv_c launches that carry it are HBM-bound — per output
+# element an fp32 stream reads 4 B, writes 4 B + the 16-bit copy the next conv_a needs; a 16-bit stream reads 2 B and writes 2 B
+# (17 launches, 0.92 -> ~0.5 ms per video of 8 clips).  HIP vs the fp32 CPU restatement stays within the 5e-3 relative-L2 bar of
+# tests/test_slowfast.py either way (fp32 accumulation inside every conv; one extra 16-bit rounding per block).
+RESIDUAL16 = os.environ.get("KVQ_SF_RESID16", "1") != "0"
 STEM_MFMA = os.environ.get("KVQ_STEM_MFMA", "1") != "0"             # 0: fast-pathway stem on the fp32 direct kernel
 
 
@@ -176,25 +181,28 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
     def _res_block(self, x16, x32, W, pre, first):
         out = self._conv_relu(x16, W[pre + ".branch2#a"])
         out = self._conv_relu(out, W[pre + ".branch2#b"])
-        if first:                                             # projection shortcut: conv + BN, no ReLU, fp32
+        r16 = RESIDUAL16
+        if first:                                             # projection shortcut: conv + BN, no ReLU
             spec = W[pre + "#1"]
             pointwise = spec[2] == (1, 1, 1) and spec[3] == (1, 1, 1) and x16.shape[-1] % 32 == 0
             if IMPLICIT_CONV and not pointwise and x16.shape[-1] % 8 == 0 and x16.is_contiguous():
-                identity = kernels.conv_implicit(x16, spec[0], spec[1], spec[2], spec[3], spec[4], False, store_f32=True)
+                identity = kernels.conv_implicit(x16, spec[0], spec[1], spec[2], spec[3], spec[4], False, store_f32=not r16)
+                identity = identity.reshape(-1, identity.shape[-1])
             else:
                 a, _ = self._cols(x16, spec)
-                identity = kernels.gemm(a, spec[0], spec[1], _abi.EPI_STORE_F32)
+                identity = kernels.gemm(a, spec[0], spec[1], _abi.EPI_BIAS_BF16 if r16 else _abi.EPI_STORE_F32)
         else:
-            identity = x32.reshape(-1, x32.shape[-1])
+            identity = (x16 if r16 else x32).reshape(-1, x16.shape[-1])
+        rkw = dict(resid=identity) if r16 else dict(resid_f32=identity, want_f32=True)
         spec = W[pre + ".branch2#c"]
         if IMPLICIT_CONV and out.shape[-1] % 32 and out.shape[-1] % 8 == 0 and out.is_contiguous():
             # 1x1x1 from 8 / 16 channels (fast pathway): the K padding to 32 lives in the tap table, not in a patch matrix
-            y16, y32 = kernels.conv_implicit(out, spec[0], spec[1], spec[2], spec[3], spec[4], True, resid_f32=identity, want_f32=True)
-            return y16, y32.reshape(y16.shape)
+            y = kernels.conv_implicit(out, spec[0], spec[1], spec[2], spec[3], spec[4], True, **rkw)
+            return (y, None) if r16 else (y[0], y[1].reshape(y[0].shape))
         a, (d, h, w) = self._cols(out, spec)
-        y16, y32 = kernels.conv_gemm(a, spec[0], spec[1], True, resid_f32=identity, want_f32=True)
         shape = (x16.shape[0], d, h, w, spec[0].shape[0])
-        return y16.reshape(shape), y32.reshape(shape)
+        y = kernels.conv_gemm(a, spec[0], spec[1], True, **rkw)
+        return (y.reshape(shape), None) if r16 else (y[0].reshape(shape), y[1].reshape(shape))
 
     def _stem(self, x, spec, half, direct=None, mfma=None):
         B, C, T, H, W = x.shape

@@ -112,6 +112,53 @@ def test_gemm_residual_scatter(half):
     assert (x2.cpu() - (x[:300] + A2 @ W.t() + b)).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (3136, 512, 6144), (98, 768, 3072)])
+def test_gemm_split_k_every_epilogue(M, N, K, half):
+    """Long K, few output tiles (the late convolutions of the conv nets, stage 3 of the trunk): the launch cuts K into S ranges,
+    partial tiles go to the caller's scratch and a second launch adds them IN ORDER and applies the epilogue.  Every epilogue that
+    may split against the fp64 product; and twice the same call -> bit-identical (the order of the partial sums is fixed)."""
+    S = _abi.lib().kvq_gemm_splitk_factor(M, N, K)
+    assert S > 1 and _abi.lib().kvq_gemm_splitk_bytes(M, N, K) >= S * M * N * 4
+    g = rng(M + N + K)
+    A = rnd(torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)), half)
+    W = rnd(torch.from_numpy((g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)), half)
+    b = torch.from_numpy(g.standard_normal(N).astype(np.float32))
+    ref = A.double() @ W.double().t() + b.double()
+    out = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_STORE_F32)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5 * np.sqrt(K)
+    assert torch.equal(out, kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_STORE_F32))
+    out_h = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_BIAS_BF16)
+    assert (out_h.float().cpu().double() - ref).abs().max().item() <= EPS[half] * ref.abs().max().item() + 1e-4
+    out_g = kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_GELU_BF16)
+    ref_g = torch.nn.functional.gelu(ref.float())
+    assert (out_g.float().cpu() - ref_g).abs().max().item() <= EPS[half] * ref_g.abs().max().item() + 1e-4
+    # residual accumulate (identity map) and conv-style ReLU with an fp32 identity branch + fp32 copy
+    x = torch.from_numpy(g.standard_normal((M, N)).astype(np.float32))
+    xd = dev(x.clone())
+    kernels.gemm(dev(A, half), dev(W, half), dev(b), _abi.EPI_RESID_F32, out=xd)
+    assert (xd.cpu().double() - (x.double() + ref)).abs().max().item() <= 2e-5 * np.sqrt(K)
+    y16, y32 = kernels.conv_gemm(dev(A, half), dev(W, half), dev(b), True, resid_f32=dev(x), want_f32=True)
+    ref_r = torch.relu(ref + x.double())
+    assert (y32.cpu().double() - ref_r).abs().max().item() <= 2e-5 * np.sqrt(K)
+    assert (y16.float().cpu().double() - ref_r).abs().max().item() <= EPS[half] * ref_r.abs().max().item() + 1e-4
+
+
+def test_conv_implicit_split_k_matches_conv3d():
+    """A temporal 3x1x1 convolution over 512 channels on a small map (the res5 geometry of SlowFast's slow pathway): K = 1536 over
+    8 output tiles -> split-K; against F.conv3d of the rounded operands."""
+    g = rng(99)
+    B, D, H, W, Cc, N = 1, 4, 7, 7, 512, 256
+    x = torch.from_numpy(g.standard_normal((B, D, H, W, Cc)).astype(np.float32)).half()
+    w5 = torch.from_numpy((g.standard_normal((N, Cc, 3, 1, 1)) / np.sqrt(3 * Cc)).astype(np.float32)).half()
+    wk = w5.permute(0, 2, 3, 4, 1).reshape(N, 3 * Cc).contiguous()
+    bias = torch.from_numpy(g.standard_normal(N).astype(np.float32))
+    assert _abi.lib().kvq_gemm_splitk_bytes(B * D * H * W, N, 3 * Cc) > 0
+    got = kernels.conv_implicit(x.cuda(), wk.cuda(), bias.cuda(), (3, 1, 1), (1, 1, 1), (1, 0, 0), True)
+    ref = torch.relu(torch.nn.functional.conv3d(x.float().permute(0, 4, 1, 2, 3), w5.float(), bias, 1, (1, 0, 0))).permute(0, 2, 3, 4, 1)
+    assert got.shape == ref.shape
+    assert (got.float().cpu() - ref).abs().max().item() <= 2.0 ** -10 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_rejects_bad_shapes():
     A = torch.zeros(8, 40, dtype=torch.float16, device=DEV)
     W = torch.zeros(32, 40, dtype=torch.float16, device=DEV)
