@@ -149,15 +149,17 @@ def run_lanes(lanes, n, fn):
     return outs
 
 
-def timed(kd, device, fn_steps, steps, warmup, finish=None):
-    """W untimed steps, barrier + sync, K timed steps (+ ``finish``: the path's exchange step), sync + barrier; max over ranks."""
+def timed(kd, device, fn_steps, steps, warmup, finish=None, first=None):
+    """W untimed steps, barrier + sync, K timed steps (+ ``finish``: the path's exchange step), sync + barrier; max over ranks.
+    ``first``: index of the first TIMED step (default: behind the warm-up steps) — legs that compare scores time the same steps."""
     import torch
-    fn_steps(warmup, 0)
+    first = warmup if first is None else first
+    fn_steps(warmup, max(0, first - warmup))
     torch.cuda.synchronize()
     kd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = fn_steps(steps, warmup)
+    outs = fn_steps(steps, first)
     extra = finish(outs) if finish is not None else None
     torch.cuda.synchronize()
     kd.barrier()
@@ -439,7 +441,7 @@ def main():
                         bb.prepare(B, 32, 224, 224, device)
                 torch.cuda.synchronize()
                 dt3, outs3, _ = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
-                                      min(args.warmup, 5))
+                                      min(args.warmup, 5), first=args.warmup)       # the SAME clips as the fp16 line
                 bf = torch.cat([o.reshape(-1) for o in outs3]).float().cpu()
                 out["bf16"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt3, "unit": "videos/s", "ms_per_step": 1e3 * dt3 / args.steps,
                                "steps": args.steps, "max_abs_dscore_vs_fp16": float((bf - fp_scores).abs().max()),

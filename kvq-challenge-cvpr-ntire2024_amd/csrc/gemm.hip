@@ -454,14 +454,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const 
       (u32x4){E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4], v[5]), E::pack2(v[6], v[7])};
 }
 
-// S for a launch of `tiles` output tiles walking nk ring slices each: few tiles on 256 CUs with a long K loop are split until
-// about two workgroups per CU exist, keeping >= 12 slices per workgroup (below that the prologue / epilogue dominate again)
-static int splitk_factor(long tiles, int nk) {
+// S for a launch of `tiles` output tiles walking nk ring slices of bk each: few tiles on 256 CUs with a long K loop are split
+// until about two workgroups per CU exist, keeping >= 768 of K per workgroup (below that the partial-tile traffic and the second
+// launch cost more than the idle CUs: measured on the trunk's stage-2 merge, K = 1536 over 150 tiles, 25 -> 35 us split in two).
+// The 64-deep variants hold a CU's whole LDS (one workgroup per CU): more than 256 workgroups would only add a second, half-empty
+// round (fc2 of stage 3, K = 3072 over 150 tiles: 43.6 us un-split, 43.8 split in three) — they stay whole.
+static int splitk_factor(long tiles, int nk, int bk) {
   static const int off = getenv("KVQ_GEMM_SPLITK") && atoi(getenv("KVQ_GEMM_SPLITK")) == 0;
-  if (off || tiles > 200 || nk < 24) return 1;
+  if (off || bk != 32 || tiles > 200 || nk < 48) return 1;
   int S = (int)(512 / tiles);
   S = S > 8 ? 8 : S;
-  while (S > 1 && nk / S < 12) --S;
+  while (S > 1 && nk / S < 24) --S;
   return S < 1 ? 1 : S;
 }
 
@@ -496,7 +499,7 @@ int gemm_variant(int M, int N, int K) {
 }
 
 // the tile grid and slice count of the variant launch_gemm / launch_conv would pick
-static void variant_tiles(int M, int N, int K, bool conv, long* tiles, int* nk) {
+static void variant_tiles(int M, int N, int K, bool conv, long* tiles, int* nk, int* bk_out) {
   int var = gemm_variant(M, N, K);
   int bk = var % 100, mi = var / 1000, ni = (var / 100) % 10;
   if (conv) {
@@ -506,6 +509,7 @@ static void variant_tiles(int M, int N, int K, bool conv, long* tiles, int* nk) 
   }
   *tiles = (long)ceil_div(M, 64 * mi) * ceil_div(N, 64 * ni);
   *nk = K / bk;
+  *bk_out = bk;
 }
 
 template <typename E, int EPI>
@@ -563,9 +567,9 @@ static int launch_conv(const GemmParams& p, hipStream_t st) { return launch_mayb
 template <typename E, int EPI, bool CONV>
 static int launch_maybe_split(const GemmParams& p, hipStream_t st) {
   long tiles;
-  int nk;
-  variant_tiles(p.M, p.N, p.K, CONV, &tiles, &nk);
-  const int S = (EPI != KVQ_EPI_QKV_BF16 && p.sk_ws) ? splitk_factor(tiles, nk) : 1;
+  int nk, bk;
+  variant_tiles(p.M, p.N, p.K, CONV, &tiles, &nk, &bk);
+  const int S = (EPI != KVQ_EPI_QKV_BF16 && p.sk_ws) ? splitk_factor(tiles, nk, bk) : 1;
   if (S > 1 && (size_t)S * p.M * p.N * sizeof(float) <= p.sk_bytes) {
     GemmParams q = p;
     q.bias = nullptr; q.out_f32 = p.sk_ws; q.out_h = nullptr; q.scatter_map = nullptr; q.resid_h = nullptr; q.resid_f32 = nullptr;
@@ -600,19 +604,19 @@ extern "C" int kvq_debug_gemm_trace(void* dev_buf, int max_blocks) {
 extern "C" int kvq_gemm_splitk_factor(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 1;
   long tiles;
-  int nk;
-  kvq::variant_tiles(M, N, K, false, &tiles, &nk);
-  return kvq::splitk_factor(tiles, nk);
+  int nk, bk;
+  kvq::variant_tiles(M, N, K, false, &tiles, &nk, &bk);
+  return kvq::splitk_factor(tiles, nk, bk);
 }
 
 extern "C" size_t kvq_gemm_splitk_bytes(int M, int N, int K) {
   // the conv front end may pick a different tile for the same (M, N, K): size for the larger factor of the two
   if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
   long t1, t2;
-  int n1, n2;
-  kvq::variant_tiles(M, N, K, false, &t1, &n1);
-  kvq::variant_tiles(M, N, K, true, &t2, &n2);
-  const int S = std::max(kvq::splitk_factor(t1, n1), kvq::splitk_factor(t2, n2));
+  int n1, n2, b1, b2;
+  kvq::variant_tiles(M, N, K, false, &t1, &n1, &b1);
+  kvq::variant_tiles(M, N, K, true, &t2, &n2, &b2);
+  const int S = std::max(kvq::splitk_factor(t1, n1, b1), kvq::splitk_factor(t2, n2, b2));
   return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
 }
 

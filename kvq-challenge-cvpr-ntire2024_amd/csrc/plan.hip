@@ -9,6 +9,7 @@
 //   PatchMerging's strided slices + pad (:542-550)      -> one 4-neighbour map
 // A (nW,N,N,3) int64 tensor (472 MB at stage 0) becomes 8 bytes per token.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -336,7 +337,11 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
   a.A = A; a.W = Wt; a.bias = bias; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_bf16 = obf; a.out_f32 = of32;
   a.num_heads = nH; a.q_scale = qs; a.scatter_map = map; a.map_rows = map_rows; a.out_rows = out_rows;
   a.dtype = pl->dtype;
-  if (pl->sk_bytes && pl->run_ws && epi != KVQ_EPI_QKV_BF16) {
+  // Split-K stays OFF in the trunk: whether a GEMM splits depends on its row count, i.e. on the batch — a clip's score would
+  // differ in the last bits with what else is in the batch (tests/test_gpu_e2e.py::test_batch_invariance_and_determinism), and
+  // the trunk's only long-K / few-tile shape (fc2 of stage 3) gains nothing from it (43.6 vs 43.8 us).  KVQ_SWIN_SPLITK=1: on.
+  static const bool swin_splitk = getenv("KVQ_SWIN_SPLITK") && atoi(getenv("KVQ_SWIN_SPLITK")) != 0;
+  if (swin_splitk && pl->sk_bytes && pl->run_ws && epi != KVQ_EPI_QKV_BF16) {
     a.splitk_ws = pl->run_ws + pl->off_sk;
     a.splitk_ws_bytes = pl->sk_bytes;
   }

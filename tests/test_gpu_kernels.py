@@ -112,7 +112,7 @@ def test_gemm_residual_scatter(half):
     assert (x2.cpu() - (x[:300] + A2 @ W.t() + b)).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (3136, 512, 6144), (98, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (196, 256, 1536), (98, 768, 3072)])
 def test_gemm_split_k_every_epilogue(M, N, K, half):
     """Long K, few output tiles (the late convolutions of the conv nets, stage 3 of the trunk): the launch cuts K into S ranges,
     partial tiles go to the caller's scratch and a second launch adds them IN ORDER and applies the epilogue.  Every epilogue that
