@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 12
+#define KVQ_ABI_VERSION 13
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -235,6 +235,9 @@ typedef struct {
    * [S][M][N] there; a second launch sums the S partials IN ORDER (bit-reproducible) and applies the epilogue.  Not for QKV. */
   void* splitk_ws;
   size_t splitk_ws_bytes;     /* >= kvq_gemm_splitk_bytes(M, N, K) or the launch stays un-split */
+  /* 16-bit row-major epilogues (BIAS / GELU / QGELU / RELU): the N columns land at columns col_off .. col_off+N-1 of rows of
+   * ldc elements — a channel concatenation (torch.cat along C of channels-last tensors) for free.  ldc = 0: ldc = N, col_off 0. */
+  int32_t ldc, col_off;
 } KvqGemmArgs;
 /* S the launch would use (1 = no split) and the scratch bytes that S needs */
 int kvq_gemm_splitk_factor(int M, int N, int K);
@@ -449,6 +452,7 @@ typedef struct {
   const float* resid_f32;
   void* splitk_ws;        /* optional split-K scratch, as in KvqGemmArgs (M = B*Do*Ho*Wo, K = Kpad) */
   size_t splitk_ws_bytes;
+  int32_t ldc, col_off;   /* as in KvqGemmArgs: out_bf16 rows of ldc channels, this conv's N at channel col_off (0 = N / 0) */
 } KvqConvArgs;
 int kvq_conv_implicit(const KvqConvArgs* host_args, void* stream);
 
@@ -479,9 +483,60 @@ int kvq_pack_clip_cl4(const float* x, const int32_t dims5[5], int border, int dt
 int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], const uint16_t* wpack, const float* bias8,
                        const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu, int dtype,
                        uint16_t* out, void* stream);
+/* ---- Whole-network entry for the convolutional branches (csrc/convnet.hip) ------------------------------------------------
+ * The reference sequences these networks layer by layer from Python (SlowFast_features.py:137-165: blocks 0-4 of
+ * pytorchvideo's slowfast_r50 + the head pools; simpleVQA_model.py:220-264: ResNet-50 + avg / std pooling).  Here the layer
+ * table is handed over ONCE (kvq_convnet_create: shapes checked, tap tables and the workspace layout built) and a forward is one
+ * call that enqueues every launch on the caller's stream — what kvq_swin3d_forward is for the trunk.  Slots 0 .. n_inputs-1 of
+ * the tensor table are the caller's input pointers (fp32 planar clips), the others live in the caller's workspace. */
+typedef enum {
+  KVQ_NET_CONV = 0,       /* Conv3d/2d + folded BatchNorm [+ identity src2] [+ ReLU]; 1x1x1 stride 1 over C % 32 == 0 runs as a plain GEMM */
+  KVQ_NET_POOL = 1,       /* max / average pool */
+  KVQ_NET_STEM8 = 2,      /* <= 8-channel fp32 planar input -> packed 8-channel rows -> implicit GEMM with a 1 x kh x kw kernel */
+  KVQ_NET_STEM_MFMA = 3,  /* <= 4-channel fp32 planar input, kernel kd x kh x 7, W stride 2, pad 3, 8 outputs (SlowFast fast stem) */
+  KVQ_NET_MEAN_STD = 4,   /* mean (and unbiased std) over the positions of every row -> fp32 output `dst` of the caller */
+  KVQ_NET_SELECT_T = 5    /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
+} KvqNetOpKind;
+typedef enum { KVQ_NET_T_ACT16 = 0 /* 16-bit channels-last (B,D,H,W,C) */, KVQ_NET_T_F32_PLANAR = 1 /* fp32 (B,C,D,H,W) */ } KvqNetTensorKind;
+typedef struct {
+  int32_t B, D, H, W, C;
+  int32_t kind;           /* KvqNetTensorKind */
+} KvqNetTensor;
+typedef struct {
+  int32_t kind;           /* KvqNetOpKind */
+  int32_t src;            /* slot read */
+  int32_t src2;           /* CONV: slot of the 16-bit identity branch ([M][cout], ReLU only) or -1 */
+  int32_t dst;            /* slot written; MEAN_STD: index into the caller's output pointers */
+  int32_t kernel3[3], stride3[3], pad3[3];
+  int32_t cout;           /* CONV / STEM*: output channels */
+  int32_t kpad;           /* CONV / STEM8: columns of w, (kd,kh,kw,c)-ordered and zero padded to a multiple of 32 */
+  int32_t relu;
+  int32_t is_max;         /* POOL: max (1) or average (0) */
+  int32_t dst_coff;       /* CONV / POOL: first channel of this op inside a wider dst (torch.cat along C for free) */
+  int32_t per_frame;      /* MEAN_STD: rows = B*D frames pooled over H*W (1) or B clips pooled over D*H*W (0) */
+  int32_t mean_off, std_off;   /* MEAN_STD: float offsets inside an output row; std_off < 0: mean only */
+  int64_t out_stride;     /* MEAN_STD: floats per output row */
+  const void* w;          /* device: CONV / STEM8 16-bit [cout][kpad]; STEM_MFMA the kvq_conv_stem_mfma weight image */
+  const float* bias;      /* device fp32 [cout] (BatchNorm folded) */
+  const int32_t* t_index; /* SELECT_T: HOST frame indices (copied) */
+  int32_t n_index;
+} KvqNetOp;
+typedef struct KvqConvNet KvqConvNet;
+int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTensor* tensors, int n_tensors, int n_inputs, int n_outputs,
+                       int dtype, KvqConvNet** out);
+void kvq_convnet_destroy(KvqConvNet* net);
+size_t kvq_convnet_workspace_bytes(const KvqConvNet* net);
+/* inputs[n_inputs]: device pointers of the input slots; outputs[n_outputs]: fp32 device buffers of the MEAN_STD ops */
+int kvq_convnet_forward(const KvqConvNet* net, const void* const* inputs, float* const* outputs, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
                 const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream);
+/* the same, writing the C channels at channel col_off of output rows of ldc channels (ldc <= 0: dense) */
+int kvq_pool_nd_strided(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
+                        const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, int ldc, int col_off,
+                        void* stream);
 /* avgpool + global_std_pool2d (simpleVQA_model.py:8-11, 242-252): x 16-bit [rows][HW][C] -> fp32
  * out[row*out_stride + mean_off + c] = mean, out[row*out_stride + std_off + c] = UNBIASED std (std_off < 0: skip). */
 int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW, int C, float* out, int64_t out_stride,

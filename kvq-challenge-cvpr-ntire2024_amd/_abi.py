@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def dtype_code(dt) -> int:
@@ -67,14 +67,31 @@ class KvqGemmArgs(C.Structure):
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
                 ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void),
-                ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t)]
+                ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t), ("ldc", C.c_int32), ("col_off", C.c_int32)]
 
 
 class KvqConvArgs(C.Structure):
     _fields_ = [("x", p_void), ("W", p_void), ("bias", p_void), ("taps", p_void), ("dims5", C.c_int32 * 5),
                 ("kernel3", C.c_int32 * 3), ("stride3", C.c_int32 * 3), ("pad3", C.c_int32 * 3), ("Kpad", C.c_int32),
                 ("N", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
-                ("resid_bf16", p_void), ("resid_f32", p_void), ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t)]
+                ("resid_bf16", p_void), ("resid_f32", p_void), ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t),
+                ("ldc", C.c_int32), ("col_off", C.c_int32)]
+
+
+class KvqNetTensor(C.Structure):
+    _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("kind", C.c_int32)]
+
+
+class KvqNetOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("src2", C.c_int32), ("dst", C.c_int32), ("kernel3", C.c_int32 * 3),
+                ("stride3", C.c_int32 * 3), ("pad3", C.c_int32 * 3), ("cout", C.c_int32), ("kpad", C.c_int32), ("relu", C.c_int32),
+                ("is_max", C.c_int32), ("dst_coff", C.c_int32), ("per_frame", C.c_int32), ("mean_off", C.c_int32),
+                ("std_off", C.c_int32), ("out_stride", C.c_int64), ("w", p_void), ("bias", p_void), ("t_index", p_void),
+                ("n_index", C.c_int32)]
+
+
+NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T = range(6)
+NET_T_ACT16, NET_T_F32_PLANAR = 0, 1
 
 
 class KvqBlockTailArgs(C.Structure):
@@ -121,6 +138,10 @@ SYMBOLS = {
     "kvq_l2_normalize_rows": (i32, [p_void, i32, i32, i32, p_void, p_void]),
     "kvq_axpby": (i32, [p_void, p_void, f32, f32, p_void, i64, p_void]),
     "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
+    "kvq_convnet_create": (i32, [C.POINTER(KvqNetOp), i32, C.POINTER(KvqNetTensor), i32, i32, i32, i32, C.POINTER(p_void)]),
+    "kvq_convnet_destroy": (None, [p_void]),
+    "kvq_convnet_workspace_bytes": (sz, [p_void]),
+    "kvq_convnet_forward": (i32, [p_void, C.POINTER(p_void), C.POINTER(p_void), p_void, sz, p_void]),
     "kvq_swin3d_forward_stages": (i32, [p_void, p_void, p_void, i32, i32, p_void, p_void, p_void, sz, p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),
@@ -167,6 +188,8 @@ SYMBOLS = {
                                  i32, i32, p_void, p_void]),
     "kvq_pool_nd": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
                           i32, p_void, p_void]),
+    "kvq_pool_nd_strided": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
+                                  i32, p_void, i32, i32, p_void]),
     "kvq_mean_std_pool": (i32, [p_void, i32, i32, i32, i32, p_void, i64, i32, i32, p_void]),
     "kvq_fragment_gather": (i32, [p_void, i32, i32, i32, i32, i32, p_void, p_void, i32, i32, i32, i32, i32,
                                   C.POINTER(f32), C.POINTER(f32), p_void, p_void]),

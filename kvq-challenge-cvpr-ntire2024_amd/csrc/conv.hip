@@ -78,6 +78,7 @@ struct PoolParams {
   const uint16_t* x;     // (B,D,H,W,C) channels-last 16-bit
   uint16_t* out;         // (B,Do,Ho,Wo,C)
   int B, C, D, H, W, kd, kh, kw, sdd, shh, sww, pd, ph, pw, Do, Ho, Wo, is_max;
+  int ldc, coff;         // output rows of ldc channels, this pool's C at channel coff (kvq_pool_nd_strided; else C / 0)
 };
 
 // max: padding never wins (-inf); avg: divides by the full window (count_include_pad=True, the
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void pool_nd_kernel(PoolParams p) {
           acc = p.is_max ? fmaxf(acc, v) : acc + v;
         }
     if (!p.is_max) acc /= (float)(p.kd * p.kh * p.kw);
-    p.out[i] = E::cvt(acc);
+    p.out[(i / p.C) * p.ldc + p.coff + c] = E::cvt(acc);
   }
 }
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void pool_nd_vec8_kernel(PoolParams p) {
     for (int e = 0; e < 4; ++e)
       o[e] = p.is_max ? E::pack2(acc[2 * e], acc[2 * e + 1])
                       : E::pack2(acc[2 * e] / cnt, acc[2 * e + 1] / cnt);
-    *reinterpret_cast<u32x4*>(p.out + i * 8) = o;
+    *reinterpret_cast<u32x4*>(p.out + (i / C8) * p.ldc + p.coff + c) = o;
   }
 }
 
@@ -530,8 +531,9 @@ extern "C" int kvq_im2col_nd(const void* x, int src_f32, int dtype, const int64_
   return KVQ_OK;
 }
 
-extern "C" int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
-                           const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream) {
+extern "C" int kvq_pool_nd_strided(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
+                                   const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, int ldc, int col_off,
+                                   void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(x && out && dims5 && kernel3 && stride3 && pad3, KVQ_ERR_NULL, "kvq_pool_nd: NULL pointer");
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_pool_nd: dtype %d", dtype);
@@ -542,6 +544,9 @@ extern "C" int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5],
   p.sdd = stride3[0]; p.shh = stride3[1]; p.sww = stride3[2];
   p.pd = pad3[0]; p.ph = pad3[1]; p.pw = pad3[2];
   p.is_max = is_max;
+  p.ldc = ldc > 0 ? ldc : dims5[1]; p.coff = ldc > 0 ? col_off : 0;
+  KVQ_REQUIRE(p.ldc % 8 == 0 && p.coff % 8 == 0 && p.coff >= 0 && p.coff + dims5[1] <= p.ldc || ldc <= 0, KVQ_ERR_SHAPE,
+              "kvq_pool_nd: ldc / col_off must be multiples of 8 with col_off + C <= ldc");
   KVQ_REQUIRE(p.B > 0 && p.C > 0 && p.kd > 0 && p.kh > 0 && p.kw > 0 && p.sdd > 0 && p.shh > 0 && p.sww > 0,
               KVQ_ERR_SHAPE, "kvq_pool_nd: bad shape");
   p.Do = (p.D + 2 * p.pd - p.kd) / p.sdd + 1;
@@ -562,6 +567,11 @@ extern "C" int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5],
   else hipLaunchKernelGGL(pool_nd_kernel<Bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   KVQ_CHECK_LAUNCH("pool_nd_kernel");
   return KVQ_OK;
+}
+
+extern "C" int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],
+                           const int32_t stride3[3], const int32_t pad3[3], int is_max, uint16_t* out, void* stream) {
+  return kvq_pool_nd_strided(x, dtype, dims5, kernel3, stride3, pad3, is_max, out, 0, 0, stream);
 }
 
 extern "C" int kvq_pack_channels_last8(const float* x, const int32_t dims5[5], const int64_t strides5[5], int dtype, uint16_t* out,

@@ -41,6 +41,7 @@ struct GemmParams {
   // split-K: the grid holds ksplit copies of the tile grid; copy s multiplies k-slices [s nk / ksplit, (s + 1) nk / ksplit) and
   // stores its fp32 partial tile at out_f32 + s M N (KVQ_EPI_STORE_F32 instantiation, no bias); splitk_reduce_kernel finishes
   int ksplit;
+  int ldc, col_off;            // 16-bit outputs (not QKV): row pitch / first column inside a wider destination (0 = N / 0)
   float* sk_ws;                // host side only: split-K scratch of the caller (NULL = never split) and its size
   size_t sk_bytes;
 };
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       }
       if (m >= p.M || !col_live) continue;
       if (OUT16) {
-        uint16_t* dst = p.out_h + (size_t)m * p.N + n;
+        uint16_t* dst = p.out_h + (size_t)m * (p.ldc ? p.ldc : p.N) + p.col_off + n;
         if (EPI == KVQ_EPI_GELU_BF16) {
 #pragma unroll
           for (int k = 0; k < CW; ++k) v[k] = gelu_fast(v[k]);
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const 
       o[1] = (f32x4){v[4], v[5], v[6], v[7]};
     }
   }
-  *reinterpret_cast<u32x4*>(p.out_h + (size_t)m * p.N + n) =
+  *reinterpret_cast<u32x4*>(p.out_h + (size_t)m * (p.ldc ? p.ldc : p.N) + p.col_off + n) =
       (u32x4){E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4], v[5]), E::pack2(v[6], v[7])};
 }
 
@@ -632,6 +633,10 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   p.ksplit = 1;
   p.sk_ws = (float*)a->splitk_ws; p.sk_bytes = a->splitk_ws_bytes;
   KVQ_REQUIRE(!p.sk_ws || ((size_t)p.sk_ws & 15) == 0, KVQ_ERR_SHAPE, "kvq_gemm_bf16: splitk_ws must be 16-byte aligned");
+  p.ldc = a->ldc; p.col_off = a->col_off;
+  KVQ_REQUIRE(a->ldc == 0 || (a->epilogue != KVQ_EPI_QKV_BF16 && a->epilogue != KVQ_EPI_RESID_F32 && a->epilogue != KVQ_EPI_STORE_F32 &&
+                              a->ldc % 8 == 0 && a->col_off % 8 == 0 && a->col_off >= 0 && a->col_off + a->N <= a->ldc),
+              KVQ_ERR_SHAPE, "kvq_gemm_bf16: ldc / col_off need a 16-bit row-major epilogue, multiples of 8, col_off + N <= ldc");
   hipStream_t st = (hipStream_t)stream;
   switch (a->epilogue) {
     case KVQ_EPI_BIAS_BF16:
@@ -697,6 +702,10 @@ extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
   p.ksplit = 1;
   p.sk_ws = (float*)a->splitk_ws; p.sk_bytes = a->splitk_ws_bytes;
   KVQ_REQUIRE(!p.sk_ws || ((size_t)p.sk_ws & 15) == 0, KVQ_ERR_SHAPE, "kvq_conv_implicit: splitk_ws must be 16-byte aligned");
+  p.ldc = a->ldc; p.col_off = a->col_off;
+  KVQ_REQUIRE(a->ldc == 0 || (a->epilogue != KVQ_EPI_STORE_F32 && a->ldc % 8 == 0 && a->col_off % 8 == 0 && a->col_off >= 0 &&
+                              a->col_off + a->N <= a->ldc),
+              KVQ_ERR_SHAPE, "kvq_conv_implicit: ldc / col_off need a 16-bit epilogue, multiples of 8, col_off + N <= ldc");
   hipStream_t st = (hipStream_t)stream;
   if (a->epilogue == KVQ_EPI_STORE_F32)      // projection shortcuts: conv + BN, no ReLU, kept in fp32
     return a->dtype == KVQ_DT_FP16 ? launch_conv<Fp16, KVQ_EPI_STORE_F32>(p, st) : launch_conv<Bf16, KVQ_EPI_STORE_F32>(p, st);

@@ -109,6 +109,7 @@ IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materia
 # (17 launches, 0.92 -> ~0.5 ms per video of 8 clips).  HIP vs the fp32 CPU restatement stays within the 5e-3 relative-L2 bar of
 # tests/test_slowfast.py either way (fp32 accumulation inside every conv; one extra 16-bit rounding per block).
 RESIDUAL16 = os.environ.get("KVQ_SF_RESID16", "1") != "0"
+CONVNET = os.environ.get("KVQ_CONVNET", "1") != "0"                  # 0: the layer-by-layer Python sequencing below
 STEM_MFMA = os.environ.get("KVQ_STEM_MFMA", "1") != "0"             # 0: fast-pathway stem on the fp32 direct kernel
 
 
@@ -231,12 +232,136 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             y = kernels.conv_gemm(a, wt, bias, True).reshape(B, d, h, w, wt.shape[0])
         return kernels.pool_nd(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), True)
 
+    # ---- the whole network as ONE C call (csrc/convnet.hip): layer table built once per geometry -------------------------
+    def _net(self, B, T, H, W, device):
+        """kvq_convnet plan of blocks 0-4 + the head pools for (B, 3, T, H, W) clips: pathway packing = a frame-select launch,
+        the lateral connections' torch.cat = the producing launches write at a channel offset of the wider tensor, residual
+        stream 16-bit.  One plan + workspace per (geometry, stream): forwards on different streams may overlap."""
+        import ctypes as C
+        Wt = self._weights(device)
+        key = (B, T, H, W, str(device), self.operand_dtype, _abi.current_stream(), id(Wt))
+        hit = self.__dict__.setdefault("_nets", {}).get(key)
+        if hit is not None:
+            return hit
+        fe = "feature_extraction."
+        tens, ops, keep = [], [], []
+
+        def tensor(b, d, h, w, c, kind=_abi.NET_T_ACT16):
+            tens.append((b, d, h, w, c, kind))
+            return len(tens) - 1
+
+        def op(kind, src, dst, k=(1, 1, 1), st=(1, 1, 1), pd=(0, 0, 0), **kw):
+            o = _abi.KvqNetOp()
+            o.kind, o.src, o.dst, o.src2 = kind, src, dst, kw.get("src2", -1)
+            o.kernel3[:], o.stride3[:], o.pad3[:] = tuple(k), tuple(st), tuple(pd)
+            for f in ("cout", "kpad", "relu", "is_max", "dst_coff", "per_frame", "mean_off", "std_off", "out_stride", "n_index"):
+                if f in kw:
+                    setattr(o, f, kw[f])
+            for f in ("w", "bias"):
+                if kw.get(f) is not None:
+                    setattr(o, f, kw[f].data_ptr())
+            if "t_index" in kw:
+                arr = (C.c_int32 * len(kw["t_index"]))(*kw["t_index"])
+                keep.append(arr)
+                o.t_index, o.n_index = C.cast(arr, C.c_void_p), len(kw["t_index"])
+            ops.append(o)
+
+        def odim(n, k, st, pd):
+            return (n + 2 * pd - k) // st + 1
+
+        def conv(src, spec, dst=None, coff=0, relu=True, src2=-1):
+            wt, bias, k, st, pd = spec
+            b, d, h, w, _, _ = tens[src]
+            if dst is None:
+                dst = tensor(b, odim(d, k[0], st[0], pd[0]), odim(h, k[1], st[1], pd[1]), odim(w, k[2], st[2], pd[2]), wt.shape[0])
+            op(_abi.NET_CONV, src, dst, k, st, pd, cout=wt.shape[0], kpad=wt.shape[1], relu=int(relu), dst_coff=coff, src2=src2, w=wt, bias=bias)
+            return dst
+
+        fast_in = tensor(B, T, H, W, 3, _abi.NET_T_F32_PLANAR)                       # slot 0: the caller's clips
+        slow_in = tensor(B, T // 4, H, W, 3, _abi.NET_T_F32_PLANAR)
+        op(_abi.NET_SELECT_T, fast_in, slow_in, t_index=[int(v) for v in torch.linspace(0, T - 1, T // 4).long().tolist()])
+        Hs, Ws = odim(H, 7, 2, 3), odim(W, 7, 2, 3)
+        Hp, Wp = odim(Hs, 3, 2, 1), odim(Ws, 3, 2, 1)
+        # stems: slow 3 -> 64 (1x7x7 over the 8-channel packed frames), fast 3 -> 8 (5x7x7 on the matrix cores); max-pools
+        wt, bias, k, st, pd = Wt[fe + "0.multipathway_blocks.0"]
+        taps = k[1] * k[2]
+        w8 = torch.zeros(wt.shape[0], -(-taps * 8 // 32) * 32, dtype=wt.dtype, device=device)
+        w8[:, :taps * 8].view(wt.shape[0], taps, 8)[:, :, :3] = wt[:, :taps * 3].reshape(wt.shape[0], taps, 3)
+        keep.append(w8)
+        s_stem = tensor(B, T // 4, Hs, Ws, 64)
+        op(_abi.NET_STEM8, slow_in, s_stem, k, st, pd, cout=64, kpad=w8.shape[1], relu=1, w=w8, bias=bias)
+        slow = tensor(B, T // 4, Hp, Wp, 64 + 2 * FAST_C[0])
+        op(_abi.NET_POOL, s_stem, slow, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1, dst_coff=0)
+        _, fbias, fk, fst, fpd = Wt[fe + "0.multipathway_blocks.1"]
+        f_stem = tensor(B, T, Hs, Ws, 8)
+        op(_abi.NET_STEM_MFMA, fast_in, f_stem, fk, fst, fpd, cout=8, relu=1, w=Wt[fe + "0.multipathway_blocks.1/mfma"], bias=fbias)
+        fast = tensor(B, T, Hp, Wp, 8)
+        op(_abi.NET_POOL, f_stem, fast, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1)
+        conv(fast, Wt[fe + "0.multipathway_fusion"], dst=slow, coff=64)
+        slow_out = (SLOW["out"], FAST["out"])
+        for si in range(4):
+            for pi in (0, 1):
+                x = slow if pi == 0 else fast
+                for bi in range(DEPTHS[si]):
+                    pre = fe + f"{si + 1}.multipathway_blocks.{pi}.res_blocks.{bi}"
+                    a = conv(x, Wt[pre + ".branch2#a"])
+                    b = conv(a, Wt[pre + ".branch2#b"])
+                    ident = conv(x, Wt[pre + "#1"], relu=False) if bi == 0 else x
+                    last = bi == DEPTHS[si] - 1
+                    if pi == 0 and last and si < 3:          # the stage output IS the first Cs channels of the next stage's input
+                        bb, d, h, w, _, _ = tens[b]
+                        wide = tensor(bb, d, h, w, SLOW["out"][si] + 2 * FAST_C[si + 1])
+                        x = conv(b, Wt[pre + ".branch2#c"], dst=wide, coff=0, src2=ident)
+                    else:
+                        x = conv(b, Wt[pre + ".branch2#c"], src2=ident)
+                if pi == 0:
+                    slow = x
+                else:
+                    fast = x
+            if si < 3:
+                conv(fast, Wt[fe + f"{si + 1}.multipathway_fusion"], dst=slow, coff=SLOW["out"][si])
+        # head: AvgPool3d((8,7,7)) / ((32,7,7)) + AdaptiveAvgPool3d(1) = a global mean over the remaining grid
+        op(_abi.NET_MEAN_STD, slow, 0, per_frame=0, mean_off=0, std_off=-1, out_stride=tens[slow][4])
+        op(_abi.NET_MEAN_STD, fast, 1, per_frame=0, mean_off=0, std_off=-1, out_stride=tens[fast][4])
+        ta = (_abi.KvqNetTensor * len(tens))()
+        for i, (b, d, h, w, c, kind) in enumerate(tens):
+            ta[i].B, ta[i].D, ta[i].H, ta[i].W, ta[i].C, ta[i].kind = b, d, h, w, c, kind
+        oa = (_abi.KvqNetOp * len(ops))(*ops)
+        handle = C.c_void_p()
+        _abi.check(_abi.lib().kvq_convnet_create(oa, len(ops), ta, len(tens), 1, 2, self.operand_dtype, C.byref(handle)), "kvq_convnet_create")
+        ws = torch.empty(_abi.lib().kvq_convnet_workspace_bytes(handle), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)       # tap tables / packed weights were built on this stream; other streams may run the plan
+        entry = (handle, ws, (tens[slow][4], tens[fast][4]), keep, Wt)
+        self._nets[key] = entry
+        return entry
+
+    def __del__(self):
+        try:
+            for handle, *_ in self.__dict__.get("_nets", {}).values():
+                _abi.lib().kvq_convnet_destroy(handle)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def forward(self, x):
         """x = [slow (B,3,T/4,H,W), fast (B,3,T,H,W)] fp32 on a HIP device (``pack_pathway_output``)
         -> (slow_feature (B,2048,1,1,1), fast_feature (B,256,1,1,1))."""
         slow_in, fast_in = x
         if not fast_in.is_cuda:
             raise _abi.KvqError("slowfast.forward needs the clips on a HIP device; there is no CPU path")
+        if CONVNET and STEM_MFMA and RESIDUAL16 and fast_in.shape[2] == 4 * slow_in.shape[2] and fast_in.shape[1] == 3:
+            # one C call enqueues the whole network (the slow pathway's frames are re-selected from the fast clip on the device:
+            # pack_pathway_output's indices, SlowFast_features.py:112-135)
+            import ctypes as C
+            fast_in = fast_in.float().contiguous()
+            B, _, T, H, W = fast_in.shape
+            handle, ws, (cs, cf), _, _ = self._net(B, T, H, W, fast_in.device)
+            s_out = torch.empty(B, cs, dtype=torch.float32, device=fast_in.device)
+            f_out = torch.empty(B, cf, dtype=torch.float32, device=fast_in.device)
+            ins = (C.c_void_p * 1)(fast_in.data_ptr())
+            outs = (C.c_void_p * 2)(s_out.data_ptr(), f_out.data_ptr())
+            _abi.check(_abi.lib().kvq_convnet_forward(handle, ins, outs, ws.data_ptr(), ws.numel(), _abi.stream_of(fast_in)),
+                       "kvq_convnet_forward")
+            return s_out.reshape(B, cs, 1, 1, 1), f_out.reshape(B, cf, 1, 1, 1)
         W = self._weights(fast_in.device)
         half = _abi.torch_dtype(self.operand_dtype)
         fe = "feature_extraction."

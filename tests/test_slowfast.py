@@ -94,6 +94,42 @@ def test_hip_slowfast_full_clip_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_one_call_network_equals_layer_by_layer_sequencing():
+    """``kvq_convnet_forward`` (the layer table handed to C once, one call per forward: frame select on the device, lateral
+    concatenations written in place at a channel offset, slots recycled in the workspace) against the same kernels sequenced layer by
+    layer from Python with torch.cat / index_select in between: the same values, bit for bit; and the plan's error paths."""
+    import ctypes as C
+    import kvq_amd.models.backbones.slowfast_model as M
+    from kvq_amd import _abi
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    m = M.slowfast()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.synth_clip(77, 16, 96, 64, batch=3)).cuda()
+    with torch.no_grad():
+        s1, f1 = m(M.pack_pathway_output(x))
+        s1b, f1b = m(M.pack_pathway_output(x))
+        M.CONVNET = False
+        try:
+            s0, f0 = m(M.pack_pathway_output(x))
+        finally:
+            M.CONVNET = True
+    assert m.__dict__.get("_nets"), "the one-call path did not run"
+    assert torch.equal(s1, s1b) and torch.equal(f1, f1b)
+    assert torch.equal(s1, s0) and torch.equal(f1, f0)
+    # a layer table whose shapes do not chain is rejected at plan creation, with a message
+    t = (_abi.KvqNetTensor * 2)()
+    t[0].B, t[0].D, t[0].H, t[0].W, t[0].C, t[0].kind = 1, 4, 8, 8, 16, _abi.NET_T_ACT16
+    t[1].B, t[1].D, t[1].H, t[1].W, t[1].C, t[1].kind = 1, 4, 8, 8, 16, _abi.NET_T_ACT16
+    o = (_abi.KvqNetOp * 1)()
+    o[0].kind, o[0].src, o[0].dst, o[0].src2 = _abi.NET_POOL, 0, 1, -1
+    o[0].kernel3[:], o[0].stride3[:], o[0].pad3[:] = (1, 3, 3), (1, 2, 2), (0, 1, 1)          # -> 4 x 4 x 4, not 4 x 8 x 8
+    h = C.c_void_p()
+    rc = _abi.lib().kvq_convnet_create(o, 1, t, 2, 1, 0, _abi.DT_FP16, C.byref(h))
+    assert rc != 0 and b"pool" in _abi.lib().kvq_last_error()
+
+
+@pytest.mark.gpu
 def test_cli_extracts_features_from_a_video_tree(tmp_path):
     """``python SlowFast_features.py --video_root --video_csv --database --feature_save_folder`` (reference CLI, :200-217) over
     two ``.npy`` frame stacks: the on-disk layout the SimpleVQA dataset reads, clip count incl. the 8-clip minimum, and the
