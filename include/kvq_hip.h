@@ -497,7 +497,11 @@ typedef enum {
   KVQ_NET_MEAN_STD = 4,   /* mean (and unbiased std) over the positions of every row -> fp32 output `dst` of the caller */
   KVQ_NET_SELECT_T = 5    /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
 } KvqNetOpKind;
-typedef enum { KVQ_NET_T_ACT16 = 0 /* 16-bit channels-last (B,D,H,W,C) */, KVQ_NET_T_F32_PLANAR = 1 /* fp32 (B,C,D,H,W) */ } KvqNetTensorKind;
+typedef enum {
+  KVQ_NET_T_ACT16 = 0,       /* 16-bit channels-last (B,D,H,W,C) */
+  KVQ_NET_T_F32_PLANAR = 1,  /* fp32 (B,C,D,H,W): network inputs */
+  KVQ_NET_T_ACT32 = 2        /* fp32 channels-last: an un-rounded residual stream (identity branch / fp32 copy of a conv output) */
+} KvqNetTensorKind;
 typedef struct {
   int32_t B, D, H, W, C;
   int32_t kind;           /* KvqNetTensorKind */
@@ -505,8 +509,10 @@ typedef struct {
 typedef struct {
   int32_t kind;           /* KvqNetOpKind */
   int32_t src;            /* slot read */
-  int32_t src2;           /* CONV: slot of the 16-bit identity branch ([M][cout], ReLU only) or -1 */
-  int32_t dst;            /* slot written; MEAN_STD: index into the caller's output pointers */
+  int32_t src2;           /* CONV: slot of the identity branch ([M][cout], 16-bit or ACT32; ReLU only) or -1 */
+  int32_t dst;            /* slot written (an ACT32 dst: conv + bias stored in fp32, no ReLU — a projection shortcut kept
+                             un-rounded); MEAN_STD: index into the caller's output pointers */
+  int32_t dst32;          /* CONV with ReLU: ACT32 slot that additionally receives the un-rounded result, or -1 */
   int32_t kernel3[3], stride3[3], pad3[3];
   int32_t cout;           /* CONV / STEM*: output channels */
   int32_t kpad;           /* CONV / STEM8: columns of w, (kd,kh,kw,c)-ordered and zero padded to a multiple of 32 */

@@ -83,7 +83,8 @@ class KvqNetTensor(C.Structure):
 
 
 class KvqNetOp(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("src2", C.c_int32), ("dst", C.c_int32), ("kernel3", C.c_int32 * 3),
+    _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("src2", C.c_int32), ("dst", C.c_int32), ("dst32", C.c_int32),
+                ("kernel3", C.c_int32 * 3),
                 ("stride3", C.c_int32 * 3), ("pad3", C.c_int32 * 3), ("cout", C.c_int32), ("kpad", C.c_int32), ("relu", C.c_int32),
                 ("is_max", C.c_int32), ("dst_coff", C.c_int32), ("per_frame", C.c_int32), ("mean_off", C.c_int32),
                 ("std_off", C.c_int32), ("out_stride", C.c_int64), ("w", p_void), ("bias", p_void), ("t_index", p_void),
@@ -91,7 +92,7 @@ class KvqNetOp(C.Structure):
 
 
 NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T = range(6)
-NET_T_ACT16, NET_T_F32_PLANAR = 0, 1
+NET_T_ACT16, NET_T_F32_PLANAR, NET_T_ACT32 = 0, 1, 2
 
 
 class KvqBlockTailArgs(C.Structure):

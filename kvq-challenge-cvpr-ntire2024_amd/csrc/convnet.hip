@@ -60,7 +60,7 @@ namespace kvq {
 
 static size_t tensor_bytes(const KvqNetTensor& t) {
   const size_t n = (size_t)t.B * t.D * t.H * t.W * t.C;
-  return ((t.kind == KVQ_NET_T_F32_PLANAR ? n * 4 : n * 2) + 255) & ~(size_t)255;
+  return ((t.kind == KVQ_NET_T_ACT16 ? n * 2 : n * 4) + 255) & ~(size_t)255;
 }
 
 static int upload_i32(KvqConvNet* net, const std::vector<int32_t>& h, int32_t** out) {
@@ -136,7 +136,10 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
     auto odim = [&](int n, int a) { return (n + 2 * p.pad3[a] - p.kernel3[a]) / p.stride3[a] + 1; };
     switch (p.kind) {
       case KVQ_NET_CONV: {
-        NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && d.kind == KVQ_NET_T_ACT16 && s.C % 8 == 0, "kvq_convnet_create: op %d (conv) operand kinds", i);
+        NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && (d.kind == KVQ_NET_T_ACT16 || d.kind == KVQ_NET_T_ACT32) && s.C % 8 == 0,
+                    "kvq_convnet_create: op %d (conv) operand kinds", i);
+        NET_REQUIRE(d.kind == KVQ_NET_T_ACT16 || (!p.relu && p.src2 < 0 && p.dst32 < 0 && d.C == p.cout),
+                    "kvq_convnet_create: op %d: an fp32 destination takes conv + bias only, dense", i);
         o.Do = odim(s.D, 0); o.Ho = odim(s.H, 1); o.Wo = odim(s.W, 2);
         NET_REQUIRE(d.B == s.B && d.D == o.Do && d.H == o.Ho && d.W == o.Wo && p.cout % 8 == 0 && p.dst_coff % 8 == 0 && d.C % 8 == 0 &&
                     p.dst_coff + p.cout <= d.C, "kvq_convnet_create: op %d (conv) output shape (%d,%d,%d,%d,%d) vs (%d,%d,%d,%d,>=%d)", i,
@@ -149,9 +152,15 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
         if (p.src2 >= 0) {
           NET_REQUIRE(p.src2 < n_tensors && p.relu, "kvq_convnet_create: op %d identity slot %d", i, p.src2);
           const KvqNetTensor r = net->tensors[p.src2].t;
-          NET_REQUIRE(r.kind == KVQ_NET_T_ACT16 && r.C == p.cout && (size_t)r.B * r.D * r.H * r.W == (size_t)d.B * d.D * d.H * d.W,
-                      "kvq_convnet_create: op %d identity branch shape", i);
+          NET_REQUIRE((r.kind == KVQ_NET_T_ACT16 || r.kind == KVQ_NET_T_ACT32) && r.C == p.cout &&
+                      (size_t)r.B * r.D * r.H * r.W == (size_t)d.B * d.D * d.H * d.W, "kvq_convnet_create: op %d identity branch shape", i);
           net->tensors[p.src2].last_use = i;
+        }
+        if (p.dst32 >= 0) {
+          NET_REQUIRE(p.dst32 >= n_inputs && p.dst32 < n_tensors && p.relu && d.C == p.cout, "kvq_convnet_create: op %d fp32 copy slot %d", i, p.dst32);
+          const KvqNetTensor r = net->tensors[p.dst32].t;
+          NET_REQUIRE(r.kind == KVQ_NET_T_ACT32 && r.C == p.cout && r.B == d.B && r.D == d.D && r.H == d.H && r.W == d.W,
+                      "kvq_convnet_create: op %d fp32 copy shape", i);
         }
         if (!o.pointwise) {
           int rc = upload_i32(net, build_taps(p.kernel3, s.C, s.H, s.W, p.kpad), &o.d_taps);
@@ -230,6 +239,7 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
     const NetOpState& o = net->ops[i];
     if (o.tmp >= 0) place(o.tmp);
     if (o.op.kind != KVQ_NET_MEAN_STD) place(o.op.dst);
+    if (o.op.kind == KVQ_NET_CONV && o.op.dst32 >= 0) place(o.op.dst32);
     for (int slot = n_inputs; slot < (int)net->tensors.size(); ++slot) {
       NetTensorState& t = net->tensors[slot];
       if (t.placed && t.last_use == i && t.bytes) {
@@ -266,13 +276,19 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
       case KVQ_NET_CONV: {
         const KvqNetTensor& d = net->tensors[p.dst].t;
         const int M = s.B * o.Do * o.Ho * o.Wo;
-        const int epi = p.relu ? KVQ_EPI_RELU_BF16 : KVQ_EPI_BIAS_BF16;
+        const bool f32dst = d.kind == KVQ_NET_T_ACT32;
+        const int epi = f32dst ? KVQ_EPI_STORE_F32 : (p.relu ? KVQ_EPI_RELU_BF16 : KVQ_EPI_BIAS_BF16);
         const bool wide = d.C != p.cout;
+        const bool r32 = p.src2 >= 0 && net->tensors[p.src2].t.kind == KVQ_NET_T_ACT32;
         if (o.pointwise) {
           KvqGemmArgs a{};
           a.A = (const uint16_t*)ptr_of(p.src); a.W = (const uint16_t*)p.w; a.bias = p.bias; a.M = M; a.N = p.cout; a.K = p.kpad;
-          a.epilogue = epi; a.out_bf16 = (uint16_t*)ptr_of(p.dst); a.dtype = net->dtype;
-          a.resid_bf16 = p.src2 >= 0 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
+          a.epilogue = epi; a.dtype = net->dtype;
+          if (f32dst) a.out_f32 = (float*)ptr_of(p.dst);
+          else a.out_bf16 = (uint16_t*)ptr_of(p.dst);
+          if (p.dst32 >= 0) a.out_f32 = (float*)ptr_of(p.dst32);
+          a.resid_bf16 = p.src2 >= 0 && !r32 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
+          a.resid_f32 = r32 ? (const float*)ptr_of(p.src2) : nullptr;
           a.ldc = wide ? d.C : 0; a.col_off = wide ? p.dst_coff : 0;
           if (net->sk_bytes) { a.splitk_ws = ws + net->sk_off; a.splitk_ws_bytes = net->sk_bytes; }
           KVQ_TRY(kvq_gemm_bf16(&a, st));
@@ -281,8 +297,12 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
           a.x = (const uint16_t*)ptr_of(p.src); a.W = (const uint16_t*)p.w; a.bias = p.bias; a.taps = o.d_taps;
           a.dims5[0] = s.B; a.dims5[1] = s.C; a.dims5[2] = s.D; a.dims5[3] = s.H; a.dims5[4] = s.W;
           memcpy(a.kernel3, p.kernel3, sizeof(a.kernel3)); memcpy(a.stride3, p.stride3, sizeof(a.stride3)); memcpy(a.pad3, p.pad3, sizeof(a.pad3));
-          a.Kpad = p.kpad; a.N = p.cout; a.epilogue = epi; a.dtype = net->dtype; a.out_bf16 = (uint16_t*)ptr_of(p.dst);
-          a.resid_bf16 = p.src2 >= 0 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
+          a.Kpad = p.kpad; a.N = p.cout; a.epilogue = epi; a.dtype = net->dtype;
+          if (f32dst) a.out_f32 = (float*)ptr_of(p.dst);
+          else a.out_bf16 = (uint16_t*)ptr_of(p.dst);
+          if (p.dst32 >= 0) a.out_f32 = (float*)ptr_of(p.dst32);
+          a.resid_bf16 = p.src2 >= 0 && !r32 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
+          a.resid_f32 = r32 ? (const float*)ptr_of(p.src2) : nullptr;
           a.ldc = wide ? d.C : 0; a.col_off = wide ? p.dst_coff : 0;
           if (net->sk_bytes) { a.splitk_ws = ws + net->sk_off; a.splitk_ws_bytes = net->sk_bytes; }
           KVQ_TRY(kvq_conv_implicit(&a, st));

@@ -16,6 +16,7 @@ from .swin_backbone import _Affine
 
 
 IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
+CONVNET = os.environ.get("KVQ_CONVNET", "1") != "0"                  # 0: the layer-by-layer Python sequencing
 
 
 class _BN(nn.Module):
@@ -165,6 +166,87 @@ class ResNet(nn.Module):
         y16, y32 = kernels.conv_gemm(out.reshape(n * ho * wo, -1), w3, b3, True, resid_f32=identity, want_f32=True)
         return y16.reshape(n, ho, wo, -1), y32.reshape(n, ho, wo, -1)        # relu(bn3(conv3) + identity)
 
+    # ---- the whole network as ONE C call (csrc/convnet.hip) ---------------------------------------------------------------
+    def _net(self, b, T, h1, w1, feat_dim, device):
+        """kvq_convnet plan of forward(): stem over the 8-channel packed frames, max-pool, the 16 bottlenecks with their
+        un-rounded fp32 residual stream (identity branch / projection shortcut / fp32 copy of every block output), and the
+        avgpool + global_std_pool2d of layers 2-4 written straight into the (frames, 7168 + feat) feature rows."""
+        import ctypes as C
+        w = self._weights(device)
+        key = (b, T, h1, w1, feat_dim, str(device), self.operand_dtype, _abi.current_stream(), id(w))
+        hit = self.__dict__.setdefault("_nets", {}).get(key)
+        if hit is not None:
+            return hit
+        tens, ops = [], []
+
+        def tensor(d, h, ww, c, kind=_abi.NET_T_ACT16):
+            tens.append((b, d, h, ww, c, kind))
+            return len(tens) - 1
+
+        def op(kind, src, dst, k=(1, 1, 1), st=(1, 1, 1), pd=(0, 0, 0), **kw):
+            o = _abi.KvqNetOp()
+            o.kind, o.src, o.dst, o.src2, o.dst32 = kind, src, dst, kw.get("src2", -1), kw.get("dst32", -1)
+            o.kernel3[:], o.stride3[:], o.pad3[:] = tuple(k), tuple(st), tuple(pd)
+            for f in ("cout", "kpad", "relu", "is_max", "per_frame", "mean_off", "std_off", "out_stride"):
+                if f in kw:
+                    setattr(o, f, kw[f])
+            for f in ("w", "bias"):
+                if kw.get(f) is not None:
+                    setattr(o, f, kw[f].data_ptr())
+            ops.append(o)
+
+        od = lambda n, k, st, pd: (n + 2 * pd - k) // st + 1       # noqa: E731
+        x_in = tensor(T, h1, w1, 3, _abi.NET_T_F32_PLANAR)          # slot 0: (b, 3, T, h, w) frames
+        hs, ws_ = od(h1, 7, 2, 3), od(w1, 7, 2, 3)
+        stem = tensor(T, hs, ws_, 64)
+        op(_abi.NET_STEM8, x_in, stem, (1, 7, 7), (1, 2, 2), (0, 3, 3), cout=64, kpad=w["stem8"].shape[1], relu=1, w=w["stem8"], bias=w["stem"][1])
+        hp, wp = od(hs, 3, 2, 1), od(ws_, 3, 2, 1)
+        y = tensor(T, hp, wp, 64)
+        op(_abi.NET_POOL, stem, y, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1)
+        y32, off, width = -1, 0, 7168 + feat_dim
+        for li, layer_mod in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
+            for bi, blk in enumerate(layer_mod):
+                k = f"l{li}.{bi}."
+                _, d, hh, ww, cin, _ = tens[y]
+                planes = w[k + "1"][0].shape[0]
+                t1 = tensor(d, hh, ww, planes)
+                op(_abi.NET_CONV, y, t1, cout=planes, kpad=w[k + "1"][0].shape[1], relu=1, w=w[k + "1"][0], bias=w[k + "1"][1])
+                ho, wo = od(hh, 3, blk.stride, 1), od(ww, 3, blk.stride, 1)
+                t2 = tensor(d, ho, wo, planes)
+                op(_abi.NET_CONV, t1, t2, (1, 3, 3), (1, blk.stride, blk.stride), (0, 1, 1), cout=planes, kpad=w[k + "2"][0].shape[1],
+                   relu=1, w=w[k + "2"][0], bias=w[k + "2"][1])
+                cout = w[k + "3"][0].shape[0]
+                if blk.downsample is None:
+                    ident = y32
+                else:                                                # 1x1 / stride conv + BN, no ReLU, kept in fp32
+                    ident = tensor(d, ho, wo, cout, _abi.NET_T_ACT32)
+                    op(_abi.NET_CONV, y, ident, (1, 1, 1), (1, blk.stride, blk.stride), cout=cout, kpad=w[k + "d"][0].shape[1], relu=0,
+                       w=w[k + "d"][0], bias=w[k + "d"][1])
+                y, y32 = tensor(d, ho, wo, cout), tensor(d, ho, wo, cout, _abi.NET_T_ACT32)
+                op(_abi.NET_CONV, t2, y, cout=cout, kpad=w[k + "3"][0].shape[1], relu=1, src2=ident, dst32=y32, w=w[k + "3"][0], bias=w[k + "3"][1])
+            if li >= 2:                                              # avgpool + global_std_pool2d (:242-252), per frame
+                cc = tens[y][4]
+                op(_abi.NET_MEAN_STD, y, 0, per_frame=1, mean_off=off, std_off=off + cc, out_stride=width)
+                off += 2 * cc
+        ta = (_abi.KvqNetTensor * len(tens))()
+        for i, (bb, d, h, ww, c, kind) in enumerate(tens):
+            ta[i].B, ta[i].D, ta[i].H, ta[i].W, ta[i].C, ta[i].kind = bb, d, h, ww, c, kind
+        oa = (_abi.KvqNetOp * len(ops))(*ops)
+        handle = C.c_void_p()
+        _abi.check(_abi.lib().kvq_convnet_create(oa, len(ops), ta, len(tens), 1, 1, self.operand_dtype, C.byref(handle)), "kvq_convnet_create")
+        ws = torch.empty(_abi.lib().kvq_convnet_workspace_bytes(handle), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        entry = (handle, ws, off, w)
+        self._nets[key] = entry
+        return entry
+
+    def __del__(self):
+        try:
+            for handle, *_ in self.__dict__.get("_nets", {}).values():
+                _abi.lib().kvq_convnet_destroy(handle)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def forward(self, batch, multi=None, layer=None):
         x = batch["simpleVQA"]
         if not x.is_cuda:
@@ -172,6 +254,15 @@ class ResNet(nn.Module):
         x = x.to(torch.float32).contiguous()
         b, c, T, h1, w1 = x.shape
         feat3d = batch["feat"].to(x.device, torch.float32).reshape(b * T, -1)
+        if CONVNET and IMPLICIT_CONV and c == 3:
+            # one C call enqueues the whole network; the SlowFast features are appended to the pooled rows
+            import ctypes as C
+            handle, ws, off, _ = self._net(b, T, h1, w1, feat3d.shape[1], x.device)
+            out = torch.empty(b * T, off + feat3d.shape[1], dtype=torch.float32, device=x.device)
+            ins, outs = (C.c_void_p * 1)(x.data_ptr()), (C.c_void_p * 1)(out.data_ptr())
+            _abi.check(_abi.lib().kvq_convnet_forward(handle, ins, outs, ws.data_ptr(), ws.numel(), _abi.stream_of(x)), "kvq_convnet_forward")
+            out[:, off:] = feat3d                                            # x_3D_features (:256)
+            return out.reshape(b, T, -1)
         w = self._weights(x.device)
         half = _abi.torch_dtype(self.operand_dtype)
         n = b * T

@@ -252,7 +252,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
 
         def op(kind, src, dst, k=(1, 1, 1), st=(1, 1, 1), pd=(0, 0, 0), **kw):
             o = _abi.KvqNetOp()
-            o.kind, o.src, o.dst, o.src2 = kind, src, dst, kw.get("src2", -1)
+            o.kind, o.src, o.dst, o.src2, o.dst32 = kind, src, dst, kw.get("src2", -1), -1
             o.kernel3[:], o.stride3[:], o.pad3[:] = tuple(k), tuple(st), tuple(pd)
             for f in ("cout", "kpad", "relu", "is_max", "dst_coff", "per_frame", "mean_off", "std_off", "out_stride", "n_index"):
                 if f in kw:

@@ -122,7 +122,7 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     t[0].B, t[0].D, t[0].H, t[0].W, t[0].C, t[0].kind = 1, 4, 8, 8, 16, _abi.NET_T_ACT16
     t[1].B, t[1].D, t[1].H, t[1].W, t[1].C, t[1].kind = 1, 4, 8, 8, 16, _abi.NET_T_ACT16
     o = (_abi.KvqNetOp * 1)()
-    o[0].kind, o[0].src, o[0].dst, o[0].src2 = _abi.NET_POOL, 0, 1, -1
+    o[0].kind, o[0].src, o[0].dst, o[0].src2, o[0].dst32 = _abi.NET_POOL, 0, 1, -1, -1
     o[0].kernel3[:], o[0].stride3[:], o[0].pad3[:] = (1, 3, 3), (1, 2, 2), (0, 1, 1)          # -> 4 x 4 x 4, not 4 x 8 x 8
     h = C.c_void_p()
     rc = _abi.lib().kvq_convnet_create(o, 1, t, 2, 1, 0, _abi.DT_FP16, C.byref(h))
