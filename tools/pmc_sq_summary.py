@@ -19,7 +19,8 @@ cols = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_
 print(f"{'kernel':72} {'n':>4} " + " ".join(f"{c[3:][:12]:>12}" for c in cols) + "  wait/wave")
 rows = []
 for k, d in acc.items():
-    if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "block_tail", "patch_embed", "vqa_head")):
+    if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "block_tail", "patch_embed", "vqa_head", "conv_stem", "splitk",
+                         "pool_nd", "mean_std", "fragment_gather", "pack_")):
         continue
     avg = {c: (sum(d[c]) / len(d[c]) if d.get(c) else 0.0) for c in cols}
     n = len(d.get(cols[2], []))

@@ -16,6 +16,7 @@ def sym(name):
     return name.replace("kvq::window_attention", "window_attention").replace("kvq::gemm_kernel", "gemm_kernel") \
                .replace("kvq::layernorm_rows_kernel", "layernorm_rows_kernel").replace("kvq::patch_im2col_kernel", "patch_im2col_kernel") \
                .replace("kvq::block_tail_kernel", "block_tail_kernel").replace("kvq::block_tail16_kernel", "block_tail16_kernel") \
+               .replace("kvq::block_tailmm_kernel", "block_tailmm_kernel") \
                .replace("kvq::patch_embed_kernel", "patch_embed_kernel")
 
 
@@ -43,6 +44,6 @@ for k in f:
     e["fetch_bytes"] = (e["fetch_bytes"] * e["launches"] + fb * n) / (e["launches"] + n)
     e["write_bytes"] = (e["write_bytes"] * e["launches"] + wb * n) / (e["launches"] + n)
     e["launches"] += n
-json.dump({"note": "avg HBM bytes per launch over one B=4 fp16 step mix; FETCH_SIZE x2 (gfx950 correction), "
+json.dump({"build": (sys.argv[3] if len(sys.argv) > 3 else "r01"), "note": "avg HBM bytes per launch over one B=4 fp16 step mix; FETCH_SIZE x2 (gfx950 correction), "
                    "separate --pmc passes (" + (sys.argv[3] if len(sys.argv) > 3 else "r01") + " build, bench.py --streams 1)", "kernels": out}, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])
