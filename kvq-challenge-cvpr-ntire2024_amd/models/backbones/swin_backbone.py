@@ -505,8 +505,10 @@ class SwinTransformer3D(nn.Module):
                 cm = r.variant // 10
                 nw = os.environ.get("KVQ_TAIL_NW") or 4
                 sym = f"block_tail_kernel<{ename}, {cm}, {nw}, {str(bool(r.variant % 10)).lower()}>"
-                if cm == 12:     # C = 384: the 16x16-MFMA variant (csrc/tail16.hip), CT = C / 16 channel tiles
-                    sym = f"block_tail16_kernel<{ename}, 24, {str(bool(r.variant % 10)).lower()}>"
+                if cm == 12:     # C = 384: csrc/tailmm.hip (feature-sliced GEMM chain) unless KVQ_TAILMM=0 -> csrc/tail16.hip
+                    emit = str(bool(r.variant % 10)).lower()
+                    sym = (f"block_tail16_kernel<{ename}, 24, {emit}>" if os.environ.get("KVQ_TAILMM", "1") == "0"
+                           else f"block_tailmm_kernel<{ename}, {emit}, 0>")
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
