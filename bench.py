@@ -215,8 +215,8 @@ def leg_c3(args, device, net, src, kd):
     """configs[2]: one video (8 clips) per step: K1 -> Swin3D-T + head on one stream, pathway packing + SlowFast-R50 (blocks
     0-4 + pools) on a second stream, both from the same sampled batch; consecutive videos alternate over two lane pairs."""
     import torch
-    from kvq_amd.models.backbones.slowfast_model import conv_flops, pack_pathway_output, slowfast
-    sf = slowfast(operand_dtype=args.dtype).to(device).eval()
+    from kvq_amd.models.backbones.slowfast_model import conv_flops, slowfast
+    sf = slowfast(operand_dtype=args.dtype, two_lanes=False).to(device).eval()     # the trunk already fills the chip from its stream
     B = 8
     nl = 2
     swin_st = [torch.cuda.Stream(device=device) for _ in range(nl)]
@@ -243,7 +243,7 @@ def leg_c3(args, device, net, src, kd):
                 score = net(inputs={"technical": xs[ln]}, reduce_scores=True)
             with torch.cuda.stream(sf_st[ln]):
                 sf_st[ln].wait_event(sampled)
-                slow_f, fast_f = sf(pack_pathway_output(xs[ln]))
+                slow_f, fast_f = sf.forward_clips(xs[ln])
             outs.append((score, slow_f, fast_f))
         for st in swin_st + sf_st:
             main.wait_stream(st)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 13
+#define KVQ_ABI_VERSION 14
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -526,6 +526,10 @@ typedef struct {
   const float* bias;      /* device fp32 [cout] (BatchNorm folded) */
   const int32_t* t_index; /* SELECT_T: HOST frame indices (copied) */
   int32_t n_index;
+  int32_t lane;           /* 0: the caller's stream; 1: the plan's own second stream — two independent pathways (SlowFast's slow and
+                             fast) then run side by side; ops of different lanes that touch the same workspace bytes are ordered by
+                             events worked out in kvq_convnet_create, the second stream is forked off / joined back into the
+                             caller's stream inside every forward (hipGraph-capturable).  One forward of a plan at a time. */
 } KvqNetOp;
 typedef struct KvqConvNet KvqConvNet;
 int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTensor* tensors, int n_tensors, int n_inputs, int n_outputs,
@@ -535,6 +539,10 @@ size_t kvq_convnet_workspace_bytes(const KvqConvNet* net);
 /* inputs[n_inputs]: device pointers of the input slots; outputs[n_outputs]: fp32 device buffers of the MEAN_STD ops */
 int kvq_convnet_forward(const KvqConvNet* net, const void* const* inputs, float* const* outputs, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* measurement only: with enable != 0 the following forwards bracket every op with HIP events on the forward's stream;
+ * kvq_convnet_profile_read waits for the last profiled forward and returns ms[i] = milliseconds of op i (n_ops of them). */
+int kvq_convnet_profile(KvqConvNet* net, int enable);
+int kvq_convnet_profile_read(const KvqConvNet* net, float* ms, int capacity, int* n_ops);
 
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],

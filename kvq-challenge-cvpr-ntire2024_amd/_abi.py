@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def dtype_code(dt) -> int:
@@ -88,7 +88,7 @@ class KvqNetOp(C.Structure):
                 ("stride3", C.c_int32 * 3), ("pad3", C.c_int32 * 3), ("cout", C.c_int32), ("kpad", C.c_int32), ("relu", C.c_int32),
                 ("is_max", C.c_int32), ("dst_coff", C.c_int32), ("per_frame", C.c_int32), ("mean_off", C.c_int32),
                 ("std_off", C.c_int32), ("out_stride", C.c_int64), ("w", p_void), ("bias", p_void), ("t_index", p_void),
-                ("n_index", C.c_int32)]
+                ("n_index", C.c_int32), ("lane", C.c_int32)]
 
 
 NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T = range(6)
@@ -143,6 +143,8 @@ SYMBOLS = {
     "kvq_convnet_destroy": (None, [p_void]),
     "kvq_convnet_workspace_bytes": (sz, [p_void]),
     "kvq_convnet_forward": (i32, [p_void, C.POINTER(p_void), C.POINTER(p_void), p_void, sz, p_void]),
+    "kvq_convnet_profile": (i32, [p_void, i32]),
+    "kvq_convnet_profile_read": (i32, [p_void, C.POINTER(C.c_float), i32, C.POINTER(i32)]),
     "kvq_swin3d_forward_stages": (i32, [p_void, p_void, p_void, i32, i32, p_void, p_void, p_void, sz, p_void]),
     "kvq_swin3d_set_taps": (i32, [p_void, C.POINTER(p_void)]),
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),

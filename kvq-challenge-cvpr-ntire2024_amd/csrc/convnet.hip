@@ -23,6 +23,7 @@ struct NetTensorState {
   size_t bytes, off;
   int last_use;        // index of the last op that reads it (-1: never read -> kept to the end)
   bool placed;
+  unsigned lanes;      // bit l: some op of lane l touches it
 };
 
 struct NetOpState {
@@ -32,6 +33,8 @@ struct NetOpState {
   int Do, Ho, Wo;
   bool pointwise;
   std::vector<int32_t> t_index;
+  int wait_ev;         // two-lane plans: event of the other lane's op this one has to see finished (-1: none)
+  int signal_ev;       //                 event recorded behind this op (-1: nobody on the other lane waits for it)
 };
 
 // pathway packing (SlowFast_features.py:112-135): frames idx[k] of an fp32 (B, C, T, H, W) clip -> (B, C, n, H, W)
@@ -54,6 +57,14 @@ struct KvqConvNet {
   std::vector<void*> owned;
   int n_inputs, n_outputs, dtype;
   size_t ws_bytes, sk_off, sk_bytes;
+  // kvq_convnet_profile: one event before the first op and one after every op of the NEXT forwards (measurement only)
+  mutable std::vector<hipEvent_t> events;
+  mutable bool recorded = false;
+  // ops with lane == 1 run on the plan's own stream (two independent pathways side by side); sync[0] forks it off the
+  // caller's stream, sync[1] joins it back, the others order ops of different lanes that touch the same workspace bytes
+  hipStream_t lane1 = nullptr;
+  std::vector<hipEvent_t> sync;
+  size_t sk_stride = 0;
 };
 
 namespace kvq {
@@ -91,7 +102,34 @@ static std::vector<int32_t> build_taps(const int32_t k3[3], int C, int H, int W,
 extern "C" void kvq_convnet_destroy(KvqConvNet* net) {
   if (!net) return;
   for (void* d : net->owned) (void)hipFree(d);
+  for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : net->sync) (void)hipEventDestroy(e);
+  if (net->lane1) (void)hipStreamDestroy(net->lane1);
   delete net;
+}
+
+extern "C" int kvq_convnet_profile(KvqConvNet* net, int enable) {
+  using namespace kvq;
+  KVQ_REQUIRE(net, KVQ_ERR_NULL, "kvq_convnet_profile: NULL plan");
+  for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+  net->events.clear();
+  net->recorded = false;
+  if (enable) {
+    net->events.resize(net->ops.size() + 1);
+    for (hipEvent_t& e : net->events) KVQ_CHECK_HIP(hipEventCreate(&e));
+  }
+  return KVQ_OK;
+}
+
+extern "C" int kvq_convnet_profile_read(const KvqConvNet* net, float* ms, int capacity, int* n_ops) {
+  using namespace kvq;
+  KVQ_REQUIRE(net && ms && n_ops, KVQ_ERR_NULL, "kvq_convnet_profile_read: NULL pointer");
+  KVQ_REQUIRE(!net->events.empty() && net->recorded, KVQ_ERR_SHAPE, "kvq_convnet_profile_read: no profiled forward (kvq_convnet_profile(net, 1) first)");
+  KVQ_REQUIRE(capacity >= (int)net->ops.size(), KVQ_ERR_WORKSPACE, "kvq_convnet_profile_read: room for %d ops, the plan has %zu", capacity, net->ops.size());
+  KVQ_CHECK_HIP(hipEventSynchronize(net->events.back()));
+  for (size_t i = 0; i < net->ops.size(); ++i) KVQ_CHECK_HIP(hipEventElapsedTime(&ms[i], net->events[i], net->events[i + 1]));
+  *n_ops = (int)net->ops.size();
+  return KVQ_OK;
 }
 
 extern "C" size_t kvq_convnet_workspace_bytes(const KvqConvNet* net) { return net ? net->ws_bytes : 0; }
@@ -106,7 +144,7 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
   net->n_inputs = n_inputs; net->n_outputs = n_outputs; net->dtype = dtype;
   for (int i = 0; i < n_tensors; ++i) {
     NetTensorState t{};
-    t.t = tensors[i]; t.bytes = tensor_bytes(tensors[i]); t.off = 0; t.last_use = -1; t.placed = false;
+    t.t = tensors[i]; t.bytes = tensor_bytes(tensors[i]); t.off = 0; t.last_use = -1; t.placed = false; t.lanes = 0;
     net->tensors.push_back(t);
   }
   auto fail = [&](int code) { kvq_convnet_destroy(net); return code; };
@@ -120,7 +158,8 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
   size_t max_sk = 0;
   for (int i = 0; i < n_ops; ++i) {
     NetOpState o{};
-    o.op = ops[i]; o.d_taps = nullptr; o.tmp = -1; o.pointwise = false;
+    o.op = ops[i]; o.d_taps = nullptr; o.tmp = -1; o.pointwise = false; o.wait_ev = -1; o.signal_ev = -1;
+    NET_REQUIRE(ops[i].lane == 0 || ops[i].lane == 1, "kvq_convnet_create: op %d lane %d", i, ops[i].lane);
     const KvqNetOp& p = ops[i];
     NET_REQUIRE(p.src >= 0 && p.src < (int)net->tensors.size(), "kvq_convnet_create: op %d reads slot %d", i, p.src);
     const KvqNetTensor s = net->tensors[p.src].t;
@@ -195,7 +234,7 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
           tmp.W = s.W + 8; tmp.C = 4;
         }
         NetTensorState ts{};
-        ts.t = tmp; ts.bytes = tensor_bytes(tmp); ts.last_use = i; ts.placed = false;
+        ts.t = tmp; ts.bytes = tensor_bytes(tmp); ts.last_use = i; ts.placed = false; ts.lanes = 0;
         o.tmp = (int)net->tensors.size();
         net->tensors.push_back(ts);
         break;
@@ -219,15 +258,33 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
     net->ops.push_back(o);
   }
 #undef NET_REQUIRE
-  // ---- workspace layout: slots are placed when first written and recycled after their last reader (first fit) ----
-  struct Free { size_t off, bytes; };
+  // ---- which lanes touch which slot ----
+  bool two_lanes = false;
+  auto slots_of = [&](const NetOpState& o, int* rd, int& nr, int* wr, int& nw) {
+    nr = nw = 0;
+    rd[nr++] = o.op.src;
+    if (o.op.kind == KVQ_NET_CONV && o.op.src2 >= 0) rd[nr++] = o.op.src2;
+    if (o.tmp >= 0) { rd[nr++] = o.tmp; wr[nw++] = o.tmp; }
+    if (o.op.kind != KVQ_NET_MEAN_STD) wr[nw++] = o.op.dst;
+    if (o.op.kind == KVQ_NET_CONV && o.op.dst32 >= 0) wr[nw++] = o.op.dst32;
+  };
+  for (const NetOpState& o : net->ops) {
+    int rd[4], wr[4], nr, nw;
+    slots_of(o, rd, nr, wr, nw);
+    for (int k = 0; k < nr; ++k) net->tensors[rd[k]].lanes |= 1u << o.op.lane;
+    for (int k = 0; k < nw; ++k) net->tensors[wr[k]].lanes |= 1u << o.op.lane;
+    two_lanes = two_lanes || o.op.lane == 1;
+  }
+  // ---- workspace layout: slots are placed when first written and recycled after their last reader (first fit).  A released
+  // range is only handed to a slot touched by the SAME lanes, so recycling never makes one pathway wait for the other ----
+  struct Free { size_t off, bytes; unsigned lanes; };
   std::vector<Free> free_list;
   size_t top = 0;
   auto place = [&](int slot) {
     NetTensorState& t = net->tensors[slot];
     if (t.placed || slot < n_inputs) return;
     for (size_t f = 0; f < free_list.size(); ++f)
-      if (free_list[f].bytes >= t.bytes) {
+      if (free_list[f].bytes >= t.bytes && free_list[f].lanes == t.lanes) {
         t.off = free_list[f].off;
         free_list[f].off += t.bytes; free_list[f].bytes -= t.bytes;
         t.placed = true;
@@ -243,13 +300,59 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
     for (int slot = n_inputs; slot < (int)net->tensors.size(); ++slot) {
       NetTensorState& t = net->tensors[slot];
       if (t.placed && t.last_use == i && t.bytes) {
-        free_list.push_back({t.off, t.bytes});
+        free_list.push_back({t.off, t.bytes, t.lanes});
         t.last_use = -2;              // released
       }
     }
   }
+  net->sk_stride = (max_sk + 255) & ~(size_t)255;
   net->sk_off = top; net->sk_bytes = max_sk;
-  net->ws_bytes = top + ((max_sk + 255) & ~(size_t)255);
+  net->ws_bytes = top + net->sk_stride * (two_lanes ? 2 : 1);
+  // ---- two lanes: op i waits for the latest op of the OTHER lane whose workspace bytes it conflicts with (one of the two
+  // accesses a write; the same wide tensor written at different channel offsets counts as a conflict: conservative) ----
+  if (two_lanes) {
+    KVQ_CHECK_HIP(hipStreamCreateWithFlags(&net->lane1, hipStreamNonBlocking));
+    net->sync.resize(2);
+    auto range = [&](int slot, size_t& lo, size_t& hi) {
+      if (slot < n_inputs) return false;            // the caller's inputs are only read
+      lo = net->tensors[slot].off; hi = lo + net->tensors[slot].bytes;
+      return hi > lo;
+    };
+    auto overlap = [&](int a, int b) {
+      size_t la, ha, lb, hb;
+      return range(a, la, ha) && range(b, lb, hb) && la < hb && lb < ha;
+    };
+    int waited[2] = {-1, -1};                        // latest op of the other lane each lane already waits for
+    const int n = (int)net->ops.size();
+    std::vector<int> wait_op(n, -1);
+    for (int i = 0; i < n; ++i) {
+      int ri[4], wi[4], nri, nwi;
+      slots_of(net->ops[i], ri, nri, wi, nwi);
+      const int lane = net->ops[i].op.lane;
+      int dep = -1;
+      for (int j = i - 1; j > waited[lane] && dep < 0; --j) {
+        if (net->ops[j].op.lane == lane) continue;
+        int rj[4], wj[4], nrj, nwj;
+        slots_of(net->ops[j], rj, nrj, wj, nwj);
+        bool hit = false;
+        for (int a = 0; a < nwi && !hit; ++a) {
+          for (int b = 0; b < nrj && !hit; ++b) hit = overlap(wi[a], rj[b]);
+          for (int b = 0; b < nwj && !hit; ++b) hit = overlap(wi[a], wj[b]);
+        }
+        for (int a = 0; a < nri && !hit; ++a)
+          for (int b = 0; b < nwj && !hit; ++b) hit = overlap(ri[a], wj[b]);
+        if (hit) dep = j;
+      }
+      if (dep >= 0) { wait_op[i] = dep; waited[lane] = dep; }
+    }
+    for (int i = 0; i < n; ++i) {
+      if (wait_op[i] < 0) continue;
+      NetOpState& src_op = net->ops[wait_op[i]];
+      if (src_op.signal_ev < 0) { src_op.signal_ev = (int)net->sync.size(); net->sync.push_back(nullptr); }
+      net->ops[i].wait_ev = src_op.signal_ev;
+    }
+    for (hipEvent_t& e : net->sync) KVQ_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   *out = net;
   return KVQ_OK;
 }
@@ -269,8 +372,25 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
   hipStream_t st = (hipStream_t)stream;
   auto ptr_of = [&](int slot) -> void* { return slot < net->n_inputs ? const_cast<void*>(inputs[slot]) : (void*)(ws + net->tensors[slot].off); };
   for (int i = 0; i < net->n_inputs; ++i) KVQ_REQUIRE(inputs[i], KVQ_ERR_NULL, "kvq_convnet_forward: input %d is NULL", i);
+  const bool prof = !net->events.empty();
+  const bool fork = net->lane1 && !prof;          // a profiled forward runs every op on the caller's stream, one after the other
+  const hipStream_t caller = st;
+  if (prof) KVQ_CHECK_HIP(hipEventRecord(net->events[0], st));
+  if (fork) {
+    KVQ_CHECK_HIP(hipEventRecord(net->sync[0], caller));
+    KVQ_CHECK_HIP(hipStreamWaitEvent(net->lane1, net->sync[0], 0));
+  }
+  size_t op_index = 0;
+  int prev_signal = -1;
   for (const NetOpState& o : net->ops) {
+    if (prof && op_index) KVQ_CHECK_HIP(hipEventRecord(net->events[op_index], st));
+    if (fork && prev_signal >= 0) KVQ_CHECK_HIP(hipEventRecord(net->sync[prev_signal], st));     // behind the previous op, on ITS stream
+    ++op_index;
     const KvqNetOp& p = o.op;
+    st = fork && p.lane == 1 ? net->lane1 : caller;
+    if (fork && o.wait_ev >= 0) KVQ_CHECK_HIP(hipStreamWaitEvent(st, net->sync[o.wait_ev], 0));
+    prev_signal = o.signal_ev;
+    unsigned char* const sk_ws = ws + net->sk_off + (fork && p.lane == 1 ? net->sk_stride : 0);
     const KvqNetTensor& s = net->tensors[p.src].t;
     switch (p.kind) {
       case KVQ_NET_CONV: {
@@ -290,7 +410,7 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
           a.resid_bf16 = p.src2 >= 0 && !r32 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
           a.resid_f32 = r32 ? (const float*)ptr_of(p.src2) : nullptr;
           a.ldc = wide ? d.C : 0; a.col_off = wide ? p.dst_coff : 0;
-          if (net->sk_bytes) { a.splitk_ws = ws + net->sk_off; a.splitk_ws_bytes = net->sk_bytes; }
+          if (net->sk_bytes) { a.splitk_ws = sk_ws; a.splitk_ws_bytes = net->sk_bytes; }
           KVQ_TRY(kvq_gemm_bf16(&a, st));
         } else {
           KvqConvArgs a{};
@@ -304,7 +424,7 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
           a.resid_bf16 = p.src2 >= 0 && !r32 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
           a.resid_f32 = r32 ? (const float*)ptr_of(p.src2) : nullptr;
           a.ldc = wide ? d.C : 0; a.col_off = wide ? p.dst_coff : 0;
-          if (net->sk_bytes) { a.splitk_ws = ws + net->sk_off; a.splitk_ws_bytes = net->sk_bytes; }
+          if (net->sk_bytes) { a.splitk_ws = sk_ws; a.splitk_ws_bytes = net->sk_bytes; }
           KVQ_TRY(kvq_conv_implicit(&a, st));
         }
         break;
@@ -355,6 +475,15 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
       default:
         break;
     }
+  }
+  if (fork) {
+    if (prev_signal >= 0) KVQ_CHECK_HIP(hipEventRecord(net->sync[prev_signal], st));
+    KVQ_CHECK_HIP(hipEventRecord(net->sync[1], net->lane1));
+    KVQ_CHECK_HIP(hipStreamWaitEvent(caller, net->sync[1], 0));
+  }
+  if (prof) {
+    KVQ_CHECK_HIP(hipEventRecord(net->events[net->ops.size()], caller));
+    net->recorded = true;
   }
   return KVQ_OK;
 }

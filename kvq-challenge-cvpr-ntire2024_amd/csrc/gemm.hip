@@ -473,6 +473,8 @@ static int splitk_factor(long tiles, int nk, int bk) {
 int gemm_variant(int M, int N, int K) {
   static const int forced = getenv("KVQ_GEMM_TILE") ? atoi(getenv("KVQ_GEMM_TILE")) : 0;   // experiments: 22 | 21 | 12 | 11
   if (forced) return forced * 100 + 32;
+  static const int forced_full = getenv("KVQ_GEMM_VARIANT") ? atoi(getenv("KVQ_GEMM_VARIANT")) : 0;   // experiments: 2264 | 3264 | 2464
+  if (forced_full && K % 64 == 0) return forced_full;
   // Measured per shape of the trunk (B = 4 clips, us: 128x128 / 128x64 / 64x64): fc2 stage 2 (K = 1536) 36.7 / 41.4 /
   // 44.3 although 128x128 makes only 294 workgroups; qkv stage 3 25.6 / 31.0 / 35.1 (450 workgroups); proj stage 2
   // (K = 384, epilogue-dominated) 25.0 / 21.3 / 20.2; merge stage 0 (N = 192 = 1.5 tiles of 128) 28.0 / 24.7 / 28.1.

@@ -139,13 +139,12 @@ class SyntheticSimpleVQADataset(torch.utils.data.Dataset):
                 rows.append(np.concatenate([slow, fast]))
             return torch.from_numpy(np.stack(rows)).float()
         if self.slowfast is not None:          # 8 clips x 32 frames @224^2, mean .45 / std .225 (SlowFast_features.py:173-174)
-            from ..models.backbones.slowfast_model import pack_pathway_output
             rows = []
             with torch.no_grad():
                 for k in range(8):
                     clip = frames_u8[:, k * 32:(k + 1) * 32].to(self.device)
                     x = kernels.resize_bilinear(clip.contiguous(), 224, 224, mean=(0.45 * 255,) * 3, std=(0.225 * 255,) * 3)
-                    slow, fast = self.slowfast(pack_pathway_output(x.unsqueeze(0)))
+                    slow, fast = self.slowfast.forward_clips(x.unsqueeze(0))
                     rows.append(torch.cat([slow.reshape(-1), fast.reshape(-1)]))
             return torch.stack(rows)
         return torch.zeros(8, 2304)

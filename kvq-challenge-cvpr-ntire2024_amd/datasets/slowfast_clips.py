@@ -109,7 +109,6 @@ class VideoDataset_NR_SlowFast_feature(torch.utils.data.Dataset):  # noqa: N801 
 def extract_video(model, clips: List[torch.Tensor], device, batch: int = 8):
     """clips: list of (32, 3, r, r) fp32 -> list of (slow (1,2048,1,1,1), fast (1,256,1,1,1)) numpy pairs, one per clip
     (:189-197).  Clips are stacked ``batch`` at a time (the clips are independent; repeated padding clips are computed once)."""
-    from ..models.backbones.slowfast_model import pack_pathway_output
     uniq, order = [], []
     for c in clips:                       # the padding to 8 clips repeats the LAST clip: compute it once
         if uniq and (uniq[-1] is c or torch.equal(uniq[-1], c)):
@@ -121,7 +120,7 @@ def extract_video(model, clips: List[torch.Tensor], device, batch: int = 8):
     with torch.no_grad():
         for a in range(0, len(uniq), batch):
             ele = torch.stack(uniq[a:a + batch]).permute(0, 2, 1, 3, 4).contiguous().to(device)      # (b, 3, 32, r, r)   (:193)
-            slow, fast = model(pack_pathway_output(ele))
+            slow, fast = model.forward_clips(ele)
             slow, fast = slow.cpu().numpy(), fast.cpu().numpy()
             feats += [(slow[k:k + 1], fast[k:k + 1]) for k in range(slow.shape[0])]
     return [feats[j] for j in order]

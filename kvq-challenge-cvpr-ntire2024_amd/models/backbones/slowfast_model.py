@@ -110,13 +110,18 @@ IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materia
 # tests/test_slowfast.py either way (fp32 accumulation inside every conv; one extra 16-bit rounding per block).
 RESIDUAL16 = os.environ.get("KVQ_SF_RESID16", "1") != "0"
 CONVNET = os.environ.get("KVQ_CONVNET", "1") != "0"                  # 0: the layer-by-layer Python sequencing below
+TWO_LANES = os.environ.get("KVQ_SF_LANES", "1") != "0"                # 0: both pathways on the caller's stream, one op after the other
 STEM_MFMA = os.environ.get("KVQ_STEM_MFMA", "1") != "0"             # 0: fast-pathway stem on the fp32 direct kernel
 
 
 class slowfast(nn.Module):  # noqa: N801  (reference spelling)
-    def __init__(self, operand_dtype=None):
+    def __init__(self, operand_dtype=None, two_lanes=None):
+        """``two_lanes``: the fast pathway on the plan's second HIP stream (default: KVQ_SF_LANES, on).  Measured: 4.35 -> 3.91 ms
+        per video when SlowFast runs alone, but a loss when another branch (the Swin trunk of config C3) already fills the
+        chip from its own stream — that caller passes False."""
         super().__init__()
         self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
+        self.two_lanes = TWO_LANES if two_lanes is None else bool(two_lanes)
         self.table = conv_table()
         for key, (wshape, _, _, cname, nname) in self.table.items():
             base = key.split("#")[0]
@@ -239,12 +244,14 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         stream 16-bit.  One plan + workspace per (geometry, stream): forwards on different streams may overlap."""
         import ctypes as C
         Wt = self._weights(device)
-        key = (B, T, H, W, str(device), self.operand_dtype, _abi.current_stream(), id(Wt))
+        key = (B, T, H, W, str(device), self.operand_dtype, _abi.current_stream(), id(Wt), self.two_lanes)
         hit = self.__dict__.setdefault("_nets", {}).get(key)
         if hit is not None:
             return hit
         fe = "feature_extraction."
-        tens, ops, keep = [], [], []
+        tens, ops, keep, descs = [], [], [], []
+        lane = [0]            # ops built while lane[0] == 1 run on the plan's second stream (the fast pathway)
+        FAST_LANE = 1 if self.two_lanes else 0
 
         def tensor(b, d, h, w, c, kind=_abi.NET_T_ACT16):
             tens.append((b, d, h, w, c, kind))
@@ -254,6 +261,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             o = _abi.KvqNetOp()
             o.kind, o.src, o.dst, o.src2, o.dst32 = kind, src, dst, kw.get("src2", -1), -1
             o.kernel3[:], o.stride3[:], o.pad3[:] = tuple(k), tuple(st), tuple(pd)
+            o.lane = lane[0]
             for f in ("cout", "kpad", "relu", "is_max", "dst_coff", "per_frame", "mean_off", "std_off", "out_stride", "n_index"):
                 if f in kw:
                     setattr(o, f, kw[f])
@@ -265,16 +273,20 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
                 keep.append(arr)
                 o.t_index, o.n_index = C.cast(arr, C.c_void_p), len(kw["t_index"])
             ops.append(o)
+            descs.append(dict(kind=kind, name=kw.get("name", ""), src=tens[src][:5], k=tuple(k), stride=tuple(st),
+                              cout=kw.get("cout", 0), kpad=kw.get("kpad", 0)))
 
         def odim(n, k, st, pd):
             return (n + 2 * pd - k) // st + 1
 
-        def conv(src, spec, dst=None, coff=0, relu=True, src2=-1):
-            wt, bias, k, st, pd = spec
+        def conv(src, key, dst=None, coff=0, relu=True, src2=-1):
+            wt, bias, k, st, pd = Wt[key]
             b, d, h, w, _, _ = tens[src]
             if dst is None:
                 dst = tensor(b, odim(d, k[0], st[0], pd[0]), odim(h, k[1], st[1], pd[1]), odim(w, k[2], st[2], pd[2]), wt.shape[0])
-            op(_abi.NET_CONV, src, dst, k, st, pd, cout=wt.shape[0], kpad=wt.shape[1], relu=int(relu), dst_coff=coff, src2=src2, w=wt, bias=bias)
+            op(_abi.NET_CONV, src, dst, k, st, pd, cout=wt.shape[0], kpad=wt.shape[1], relu=int(relu), dst_coff=coff, src2=src2, w=wt, bias=bias,
+               name=key.replace(fe, ""))
+            descs[-1]["M"] = tens[dst][0] * tens[dst][1] * tens[dst][2] * tens[dst][3]
             return dst
 
         fast_in = tensor(B, T, H, W, 3, _abi.NET_T_F32_PLANAR)                       # slot 0: the caller's clips
@@ -293,36 +305,42 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         slow = tensor(B, T // 4, Hp, Wp, 64 + 2 * FAST_C[0])
         op(_abi.NET_POOL, s_stem, slow, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1, dst_coff=0)
         _, fbias, fk, fst, fpd = Wt[fe + "0.multipathway_blocks.1"]
+        lane[0] = FAST_LANE
         f_stem = tensor(B, T, Hs, Ws, 8)
         op(_abi.NET_STEM_MFMA, fast_in, f_stem, fk, fst, fpd, cout=8, relu=1, w=Wt[fe + "0.multipathway_blocks.1/mfma"], bias=fbias)
         fast = tensor(B, T, Hp, Wp, 8)
         op(_abi.NET_POOL, f_stem, fast, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1)
-        conv(fast, Wt[fe + "0.multipathway_fusion"], dst=slow, coff=64)
+        conv(fast, fe + "0.multipathway_fusion", dst=slow, coff=64)
+        lane[0] = 0
         slow_out = (SLOW["out"], FAST["out"])
         for si in range(4):
             for pi in (0, 1):
+                lane[0] = FAST_LANE if pi == 1 else 0
                 x = slow if pi == 0 else fast
                 for bi in range(DEPTHS[si]):
                     pre = fe + f"{si + 1}.multipathway_blocks.{pi}.res_blocks.{bi}"
-                    a = conv(x, Wt[pre + ".branch2#a"])
-                    b = conv(a, Wt[pre + ".branch2#b"])
-                    ident = conv(x, Wt[pre + "#1"], relu=False) if bi == 0 else x
+                    a = conv(x, pre + ".branch2#a")
+                    b = conv(a, pre + ".branch2#b")
+                    ident = conv(x, pre + "#1", relu=False) if bi == 0 else x
                     last = bi == DEPTHS[si] - 1
                     if pi == 0 and last and si < 3:          # the stage output IS the first Cs channels of the next stage's input
                         bb, d, h, w, _, _ = tens[b]
                         wide = tensor(bb, d, h, w, SLOW["out"][si] + 2 * FAST_C[si + 1])
-                        x = conv(b, Wt[pre + ".branch2#c"], dst=wide, coff=0, src2=ident)
+                        x = conv(b, pre + ".branch2#c", dst=wide, coff=0, src2=ident)
                     else:
-                        x = conv(b, Wt[pre + ".branch2#c"], src2=ident)
+                        x = conv(b, pre + ".branch2#c", src2=ident)
                 if pi == 0:
                     slow = x
                 else:
                     fast = x
             if si < 3:
-                conv(fast, Wt[fe + f"{si + 1}.multipathway_fusion"], dst=slow, coff=SLOW["out"][si])
+                conv(fast, fe + f"{si + 1}.multipathway_fusion", dst=slow, coff=SLOW["out"][si])
+            lane[0] = 0
         # head: AvgPool3d((8,7,7)) / ((32,7,7)) + AdaptiveAvgPool3d(1) = a global mean over the remaining grid
         op(_abi.NET_MEAN_STD, slow, 0, per_frame=0, mean_off=0, std_off=-1, out_stride=tens[slow][4])
+        lane[0] = FAST_LANE
         op(_abi.NET_MEAN_STD, fast, 1, per_frame=0, mean_off=0, std_off=-1, out_stride=tens[fast][4])
+        lane[0] = 0
         ta = (_abi.KvqNetTensor * len(tens))()
         for i, (b, d, h, w, c, kind) in enumerate(tens):
             ta[i].B, ta[i].D, ta[i].H, ta[i].W, ta[i].C, ta[i].kind = b, d, h, w, c, kind
@@ -331,9 +349,32 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         _abi.check(_abi.lib().kvq_convnet_create(oa, len(ops), ta, len(tens), 1, 2, self.operand_dtype, C.byref(handle)), "kvq_convnet_create")
         ws = torch.empty(_abi.lib().kvq_convnet_workspace_bytes(handle), dtype=torch.uint8, device=device)
         torch.cuda.synchronize(device)       # tap tables / packed weights were built on this stream; other streams may run the plan
-        entry = (handle, ws, (tens[slow][4], tens[fast][4]), keep, Wt)
+        entry = (handle, ws, (tens[slow][4], tens[fast][4]), keep, Wt, descs)
         self._nets[key] = entry
         return entry
+
+    def profile_layers(self, fast_in):
+        """measurement only: one forward with every op of the plan bracketed by HIP events -> [{name, kind, M, N, K, ms, tflops}]"""
+        import ctypes as C
+        B, _, T, H, W = fast_in.shape
+        handle, *_rest, descs = self._net(B, T, H, W, fast_in.device)
+        _abi.check(_abi.lib().kvq_convnet_profile(handle, 1), "kvq_convnet_profile")
+        try:
+            self.forward_clips(fast_in)
+            ms = (C.c_float * len(descs))()
+            n = C.c_int32(0)
+            _abi.check(_abi.lib().kvq_convnet_profile_read(handle, ms, len(descs), C.byref(n)), "kvq_convnet_profile_read")
+        finally:
+            _abi.check(_abi.lib().kvq_convnet_profile(handle, 0), "kvq_convnet_profile")
+        kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma",
+                 _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t"}
+        out = []
+        for d, t in zip(descs, ms):
+            k = d["k"][0] * d["k"][1] * d["k"][2] * d["src"][4]
+            fl = 2.0 * d.get("M", 0) * d["cout"] * k
+            out.append(dict(name=d["name"], kind=kinds.get(d["kind"], "?"), M=d.get("M", 0), N=d["cout"], K=k, kernel=d["k"], ms=float(t),
+                            tflops=fl / (t * 1e9) if t > 0 and fl else 0.0))
+        return out
 
     def __del__(self):
         try:
@@ -342,26 +383,38 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
+    @staticmethod
+    def _one_call(fast_in):
+        return CONVNET and STEM_MFMA and RESIDUAL16 and fast_in.shape[1] == 3 and fast_in.shape[2] % 4 == 0
+
+    def forward_clips(self, fast_in):
+        """(B,3,T,H,W) fp32 clips on a HIP device -> (slow_feature, fast_feature), the same values as
+        ``forward(pack_pathway_output(clips))``: ONE C call enqueues the whole network, the slow pathway's frames are selected
+        from the clip on the device (pack_pathway_output's indices, SlowFast_features.py:112-135) — no torch kernel runs."""
+        import ctypes as C
+        if not fast_in.is_cuda:
+            raise _abi.KvqError("slowfast.forward_clips needs the clips on a HIP device; there is no CPU path")
+        if not self._one_call(fast_in):
+            return self.forward(pack_pathway_output(fast_in))
+        fast_in = fast_in.float().contiguous()
+        B, _, T, H, W = fast_in.shape
+        handle, ws, (cs, cf), *_ = self._net(B, T, H, W, fast_in.device)
+        s_out = torch.empty(B, cs, dtype=torch.float32, device=fast_in.device)
+        f_out = torch.empty(B, cf, dtype=torch.float32, device=fast_in.device)
+        ins = (C.c_void_p * 1)(fast_in.data_ptr())
+        outs = (C.c_void_p * 2)(s_out.data_ptr(), f_out.data_ptr())
+        _abi.check(_abi.lib().kvq_convnet_forward(handle, ins, outs, ws.data_ptr(), ws.numel(), _abi.stream_of(fast_in)),
+                   "kvq_convnet_forward")
+        return s_out.reshape(B, cs, 1, 1, 1), f_out.reshape(B, cf, 1, 1, 1)
+
     def forward(self, x):
         """x = [slow (B,3,T/4,H,W), fast (B,3,T,H,W)] fp32 on a HIP device (``pack_pathway_output``)
         -> (slow_feature (B,2048,1,1,1), fast_feature (B,256,1,1,1))."""
         slow_in, fast_in = x
         if not fast_in.is_cuda:
             raise _abi.KvqError("slowfast.forward needs the clips on a HIP device; there is no CPU path")
-        if CONVNET and STEM_MFMA and RESIDUAL16 and fast_in.shape[2] == 4 * slow_in.shape[2] and fast_in.shape[1] == 3:
-            # one C call enqueues the whole network (the slow pathway's frames are re-selected from the fast clip on the device:
-            # pack_pathway_output's indices, SlowFast_features.py:112-135)
-            import ctypes as C
-            fast_in = fast_in.float().contiguous()
-            B, _, T, H, W = fast_in.shape
-            handle, ws, (cs, cf), _, _ = self._net(B, T, H, W, fast_in.device)
-            s_out = torch.empty(B, cs, dtype=torch.float32, device=fast_in.device)
-            f_out = torch.empty(B, cf, dtype=torch.float32, device=fast_in.device)
-            ins = (C.c_void_p * 1)(fast_in.data_ptr())
-            outs = (C.c_void_p * 2)(s_out.data_ptr(), f_out.data_ptr())
-            _abi.check(_abi.lib().kvq_convnet_forward(handle, ins, outs, ws.data_ptr(), ws.numel(), _abi.stream_of(fast_in)),
-                       "kvq_convnet_forward")
-            return s_out.reshape(B, cs, 1, 1, 1), f_out.reshape(B, cf, 1, 1, 1)
+        if self._one_call(fast_in) and fast_in.shape[2] == 4 * slow_in.shape[2]:
+            return self.forward_clips(fast_in)
         W = self._weights(fast_in.device)
         half = _abi.torch_dtype(self.operand_dtype)
         fe = "feature_extraction."

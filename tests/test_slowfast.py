@@ -130,6 +130,42 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
 
 
 @pytest.mark.gpu
+def test_two_lane_plan_equals_one_lane_and_profile_reads_every_op():
+    """The fast pathway on the plan's second stream (KvqNetOp.lane = 1: fork / event-ordered / join inside one forward) against
+    the same plan on the caller's stream alone: bit-identical features, also when forwards follow each other without a host
+    synchronise and from a side stream; ``forward_clips`` (frame selection on the device) == ``forward(pack_pathway_output)``;
+    ``kvq_convnet_profile`` returns one positive time per op and leaves the values unchanged."""
+    import kvq_amd.models.backbones.slowfast_model as M
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}
+    nets = []
+    for lanes in (False, True):
+        m = M.slowfast(two_lanes=lanes)
+        m.load_state_dict(sd)
+        nets.append(m.cuda().eval())
+    xs = [torch.from_numpy(synth.synth_clip(70 + i, 16, 96, 64, batch=2)).cuda() for i in range(3)]
+    with torch.no_grad():
+        ref = [nets[0].forward_clips(x) for x in xs]
+        got = [nets[1].forward_clips(x) for x in xs]                # back to back: the join of forward i orders forward i+1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got_side = [nets[1].forward_clips(x) for x in xs]
+        torch.cuda.synchronize()
+        packed = nets[1](M.pack_pathway_output(xs[0]))
+        rows = nets[1].profile_layers(xs[0])
+        after = nets[1].forward_clips(xs[0])
+    for (s0, f0), (s1, f1), (s2, f2) in zip(ref, got, got_side):
+        assert torch.equal(s0, s1) and torch.equal(f0, f1)
+        assert torch.equal(s0, s2) and torch.equal(f0, f2)
+    assert torch.equal(packed[0], ref[0][0]) and torch.equal(packed[1], ref[0][1])
+    assert torch.equal(after[0], ref[0][0]) and torch.equal(after[1], ref[0][1])
+    convs = [r for r in rows if r["kind"] == "conv"]
+    assert len(convs) == len(M.conv_table()) - 2 and all(r["ms"] > 0 for r in rows)          # every conv but the two stems
+    assert any(r["name"].endswith("multipathway_fusion") for r in convs)
+
+
+@pytest.mark.gpu
 def test_cli_extracts_features_from_a_video_tree(tmp_path):
     """``python SlowFast_features.py --video_root --video_csv --database --feature_save_folder`` (reference CLI, :200-217) over
     two ``.npy`` frame stacks: the on-disk layout the SimpleVQA dataset reads, clip count incl. the 8-clip minimum, and the

@@ -22,7 +22,7 @@ def timed(fn, n=5):
 
 with torch.no_grad():
     t_swin = timed(lambda: net(inputs={"technical": x}, reduce_scores=True))
-    t_sf = timed(lambda: sf(pack_pathway_output(x)))
+    t_sf = timed(lambda: sf.forward_clips(x))
 print(f"C3, one video = 8 clips of 3x32x224x224: Swin3D-T+head {t_swin:.2f} ms, SlowFast-R50 {t_sf:.2f} ms -> "
       f"{1e3 / (t_swin + t_sf):.1f} videos/s with both branches on one GPU")
 
@@ -33,7 +33,7 @@ def both(n):
     s1.wait_stream(main); s2.wait_stream(main)
     for _ in range(n):
         with torch.cuda.stream(s1): net(inputs={"technical": x}, reduce_scores=True)
-        with torch.cuda.stream(s2): sf(pack_pathway_output(x))
+        with torch.cuda.stream(s2): sf.forward_clips(x)
     main.wait_stream(s1); main.wait_stream(s2)
 with torch.no_grad():
     both(2); torch.cuda.synchronize(); t = time.time(); both(10); torch.cuda.synchronize()

@@ -11,9 +11,9 @@ sf = slowfast().to(dev).eval()
 x = torch.from_numpy(synth.synth_clip(8, 32, 224, 224, batch=8)).to(dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 with torch.no_grad():
-    for _ in range(3): sf(pack_pathway_output(x))
+    for _ in range(3): sf.forward_clips(x)
     torch.cuda.synchronize(); t = time.time()
-    for _ in range(n): sf(pack_pathway_output(x))
+    for _ in range(n): sf.forward_clips(x)
     torch.cuda.synchronize()
 dt = (time.time() - t) / n
 fl = 8 * conv_flops()[0]
