@@ -495,7 +495,9 @@ typedef enum {
   KVQ_NET_STEM8 = 2,      /* <= 8-channel fp32 planar input -> packed 8-channel rows -> implicit GEMM with a 1 x kh x kw kernel */
   KVQ_NET_STEM_MFMA = 3,  /* <= 4-channel fp32 planar input, kernel kd x kh x 7, W stride 2, pad 3, 8 outputs (SlowFast fast stem) */
   KVQ_NET_MEAN_STD = 4,   /* mean (and unbiased std) over the positions of every row -> fp32 output `dst` of the caller */
-  KVQ_NET_SELECT_T = 5    /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
+  KVQ_NET_SELECT_T = 5,   /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
+  KVQ_NET_BOTTLENECK = 6  /* one residual block of SlowFast's fast pathway in ONE launch (kvq_fast_bottleneck): w = the packed image,
+                             kpad = inner channels, cout = output channels, n_index = 1 when the block has a projection shortcut */
 } KvqNetOpKind;
 typedef enum {
   KVQ_NET_T_ACT16 = 0,       /* 16-bit channels-last (B,D,H,W,C) */
@@ -543,6 +545,20 @@ int kvq_convnet_forward(const KvqConvNet* net, const void* const* inputs, float*
  * kvq_convnet_profile_read waits for the last profiled forward and returns ms[i] = milliseconds of op i (n_ops of them). */
 int kvq_convnet_profile(KvqConvNet* net, int enable);
 int kvq_convnet_profile_read(const KvqConvNet* net, float* ms, int capacity, int* n_ops);
+
+/* SlowFast fast-pathway residual block, fused (csrc/bottleneck.hip): conv_a 3x1x1 (pad 1,0,0) + BN + ReLU -> conv_b 1x3x3 (pad 0,1,1,
+ * stride 1) + BN + ReLU -> conv_c 1x1x1 + BN -> + shortcut (identity when projection == 0, else the block's 1x1x1 conv + BN) -> ReLU,
+ * as pytorchvideo's ResBlock runs them inside SlowFast_features.py:137-165.  x / out: 16-bit channels-last (B,T,H,W,cin) /
+ * (B,T,H,W,cout), dims4 = {B,T,H,W}.  pack (kvq_fast_bottleneck_pack_bytes bytes, 16-byte aligned) holds the BatchNorm-folded 16-bit
+ * weights as MFMA A fragments — fragment f, lane (m = lane & 31, h = lane >> 5), element e = W[row0 + m][k(f,h,e)], rows / k past the
+ * matrix zero — in this order: conv_a [ceil(3 cin / 16)] with k = 16 f + 8 h + e over (dt, c); conv_b [ceil(9 ci / 16)] with the same
+ * k over (dy, dx, c); conv_c [cout / 32][ceil(ci / 16)] with k = 16 f + 8 (e >> 2) + 4 h + (e & 3) (the accumulator order of conv_b);
+ * the projection [cout / 32][ceil(cin / 16)] with natural k; then fp32 bias_a[32] bias_b[32] bias_c[cout] (+ the projection's bias),
+ * zero padded to a multiple of 1 KB.  Built (cin, ci, cout, projection): (8,8,32,1) (32,8,32,0) (64,16,64,0) (128,32,128,0);
+ * kvq_fast_bottleneck_pack_bytes returns 0 for anything else. */
+size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection);
+int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection, const void* pack,
+                        int dtype, uint16_t* out, void* stream);
 
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],

@@ -91,7 +91,7 @@ class KvqNetOp(C.Structure):
                 ("n_index", C.c_int32), ("lane", C.c_int32)]
 
 
-NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T = range(6)
+NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T, NET_BOTTLENECK = range(7)
 NET_T_ACT16, NET_T_F32_PLANAR, NET_T_ACT32 = 0, 1, 2
 
 
@@ -143,6 +143,8 @@ SYMBOLS = {
     "kvq_convnet_destroy": (None, [p_void]),
     "kvq_convnet_workspace_bytes": (sz, [p_void]),
     "kvq_convnet_forward": (i32, [p_void, C.POINTER(p_void), C.POINTER(p_void), p_void, sz, p_void]),
+    "kvq_fast_bottleneck_pack_bytes": (sz, [i32, i32, i32, i32]),
+    "kvq_fast_bottleneck": (i32, [p_void, C.POINTER(i32), i32, i32, i32, i32, p_void, i32, p_void, p_void]),
     "kvq_convnet_profile": (i32, [p_void, i32]),
     "kvq_convnet_profile_read": (i32, [p_void, C.POINTER(C.c_float), i32, C.POINTER(i32)]),
     "kvq_swin3d_forward_stages": (i32, [p_void, p_void, p_void, i32, i32, p_void, p_void, p_void, sz, p_void]),

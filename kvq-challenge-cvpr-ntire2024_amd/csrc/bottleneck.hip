@@ -1,0 +1,263 @@
+// One launch per residual block of SlowFast's FAST pathway (gfx950): conv_a (3x1x1, temporal) -> BN -> ReLU -> conv_b (1x3x3)
+// -> BN -> ReLU -> conv_c (1x1x1) -> BN -> + shortcut (identity, or the block's 1x1x1 projection + BN) -> ReLU
+// (pytorchvideo's ResBlock / BottleneckBlock as SlowFast_features.py:137-165 runs them; restated in oracle/slowfast_oracle.py).
+//
+// The fast pathway carries beta = 1/8 of the channels (8..32 inner, 32..128 outer) on 4x the frames: as separate implicit-GEMM
+// launches its convolutions are launch-latency / HBM sized — 3-4 launches of 10-40 us per block that each read or write the
+// block's full-resolution tensor, 1.0 ms of a 3.8 ms network for 8 % of its FLOPs (profiles/r02_slowfast_layers.txt).  Fused,
+// a block reads its input once (three frames through L2) and writes its output once.
+//
+// Geometry: a workgroup (4 waves) owns a 14 x 14 output tile of ONE frame (56 / 28 / 14-pixel maps tile exactly).  Everything is
+// TOKEN-PER-LANE as in tail.hip: D[channel][pixel] = W[channel][k] . In[k][pixel] on v_mfma_f32_32x32x16 with the (BatchNorm-
+// folded) weights as the A operand, fragment-major in LDS, and 32 pixels as the 32 columns, so a lane owns ONE pixel:
+//   a: the 16 x 16 halo of the tile (8 column tiles, 2 per wave); B fragments are 16-byte global loads (8 channels of one
+//      (frame, pixel) of the channels-last input); bias + ReLU in registers; the 16-bit result goes to LDS [256 pixels][CI]
+//      (zero outside the image: conv_b's padding);
+//   b: 7 column tiles of output pixels; a B fragment half = the 8 channels of one tap's neighbour pixel, one ds_read_b128;
+//   c: conv_b's accumulators are packed straight into the B operand (k order = accumulator order, folded into the packed
+//      weights), + the shortcut (8-byte loads of the lane's own pixel, or one more MFMA over the input channels), ReLU, 8-byte
+//      stores.
+// Rounding points are those of the unfused launches (16-bit a, b and block output; fp32 accumulation and shortcut add).
+#include "common.hpp"
+
+namespace kvq {
+
+typedef __attribute__((address_space(3))) void* bn_lds_t;
+typedef __attribute__((address_space(1))) const void* bn_gbl_t;
+
+constexpr int BN_T = 14, BN_HALO = 16;
+
+struct BneckParams {
+  const uint16_t* x;
+  uint16_t* out;
+  const unsigned char* pack;
+  int B, T, H, W, tiles_y, tiles_x;
+};
+
+__host__ __device__ constexpr int bn_ks(int k) { return (k + 15) / 16; }
+// packed image (bytes): A fragments | B fragments | C fragments [RT][KSC] | S fragments [RT][KSS] (projection only) | fp32
+// bias_a[32] bias_b[32] bias_c[COUT]  — every part a whole number of 1 KB wave-loads
+template <int CIN, int CI, int COUT, bool SC>
+struct BnLayout {
+  static constexpr int KSA = bn_ks(3 * CIN), KSB = bn_ks(9 * CI), KSC = bn_ks(CI), KSS = SC ? bn_ks(CIN) : 0, RT = COUT / 32;
+  static constexpr int OFF_A = 0, OFF_B = OFF_A + KSA * 1024, OFF_C = OFF_B + KSB * 1024, OFF_S = OFF_C + RT * KSC * 1024;
+  static constexpr int OFF_BIAS = OFF_S + RT * KSS * 1024;
+  static constexpr int BIAS_BYTES = ((64 + COUT) * 4 + 1023) / 1024 * 1024;
+  static constexpr int PACK_BYTES = OFF_BIAS + BIAS_BYTES;
+  static constexpr int OFF_TILE = PACK_BYTES;                           // [256 halo pixels][CI] 16-bit
+  static constexpr int LDS_BYTES = OFF_TILE + BN_HALO * BN_HALO * CI * 2;
+};
+
+template <typename E, int CIN, int CI, int COUT, bool SC>
+__global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) {
+  fp16_saturate_mode();
+  using L = BnLayout<CIN, CI, COUT, SC>;
+  using V8 = typename E::v8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = p.tiles_y * p.tiles_x;
+  const int bt = blockIdx.x / ntile, tile = blockIdx.x - bt * ntile;
+  const int b = bt / p.T, t = bt - b * p.T;
+  const int y0 = (tile / p.tiles_x) * BN_T, x0 = (tile % p.tiles_x) * BN_T;
+  const size_t frame = (size_t)p.H * p.W;
+  const uint16_t* xb = p.x + (size_t)b * p.T * frame * CIN;
+
+  // weights + biases -> LDS (LDS-DMA, 1 KB per wave-load)
+  for (int q = wave; q < L::PACK_BYTES / 1024; q += 4)
+    __builtin_amdgcn_global_load_lds((bn_gbl_t)(p.pack + q * 1024 + lane * 16), (bn_lds_t)(lds + q * 1024), 16, 0, 0);
+  const float* s_ba = reinterpret_cast<const float*>(lds + L::OFF_BIAS);
+  const float* s_bb = s_ba + 32;
+  const float* s_bc = s_ba + 64;
+  uint16_t* a_tile = reinterpret_cast<uint16_t*>(lds + L::OFF_TILE);
+
+  // ---- conv_a on the halo: column tiles 2 wave, 2 wave + 1 ----------------------------------------------------------------
+#pragma unroll 1
+  for (int c2 = 0; c2 < 2; ++c2) {
+    const int ap = (2 * wave + c2) * 32 + j;
+    const int yy = y0 - 1 + (ap >> 4), xx = x0 - 1 + (ap & 15);
+    const bool inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+    const uint16_t* px = xb + ((size_t)(inside ? yy : 0) * p.W + (inside ? xx : 0)) * CIN;
+    V8 bx[L::KSA];
+#pragma unroll
+    for (int s = 0; s < L::KSA; ++s) {
+      const int k0 = 16 * s + 8 * h;                     // per-lane, but dt / c are the same for both halves' structure
+      const int dt = k0 / CIN, c = k0 - dt * CIN, tt = t + dt - 1;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k0 < 3 * CIN && inside && tt >= 0 && tt < p.T) v = *reinterpret_cast<const u32x4*>(px + (size_t)tt * frame * CIN + c);
+      bx[s] = __builtin_bit_cast(V8, v);
+    }
+    if (c2 == 0) {
+      // the weight image has landed (these DMAs are older than nothing this wave still needs in flight) and is visible to all
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < L::KSA; ++s)
+      acc = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_A + s * 1024 + lane * 16), bx[s], acc);
+#pragma unroll
+    for (int q = 0; q < CI / 8; ++q) {
+      const f32x4 ba = *reinterpret_cast<const f32x4*>(s_ba + 8 * q + 4 * h);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(acc[4 * q + e] + ba[e], 0.f) : 0.f;
+      *reinterpret_cast<u32x2*>(a_tile + ap * CI + 8 * q + 4 * h) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+    }
+  }
+  __syncthreads();
+
+  // ---- conv_b, conv_c, shortcut on the 14 x 14 outputs: column tiles wave, wave + 4 ---------------------------------------
+#pragma unroll 1
+  for (int ct = wave; ct < (BN_T * BN_T + 31) / 32; ct += 4) {
+    const int op_raw = ct * 32 + j;
+    const int op = op_raw < BN_T * BN_T ? op_raw : BN_T * BN_T - 1;
+    const int oy = op / BN_T, ox = op - oy * BN_T;
+    const int yy = y0 + oy, xx = x0 + ox;
+    const bool live = op_raw < BN_T * BN_T && yy < p.H && xx < p.W;
+    const size_t pix = ((size_t)t * p.H + (live ? yy : 0)) * p.W + (live ? xx : 0);
+    // shortcut operands first: their latency hides under conv_b
+    V8 sx[SC ? L::KSS : 1];
+    u32x2 idn[SC ? 1 : L::RT * 4];
+    if (SC) {
+#pragma unroll
+      for (int s = 0; s < L::KSS; ++s) {
+        const int k0 = 16 * s + 8 * h;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (k0 < CIN && live) v = *reinterpret_cast<const u32x4*>(xb + pix * CIN + k0);
+        sx[s] = __builtin_bit_cast(V8, v);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < L::RT * 4; ++i) {
+        idn[i] = (u32x2){0u, 0u};
+        if (live) idn[i] = *reinterpret_cast<const u32x2*>(xb + pix * CIN + 8 * i + 4 * h);      // CIN == COUT
+      }
+    }
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < L::KSB; ++s) {
+      const int k0 = 16 * s + 8 * h;
+      const int tap = k0 / CI, ci0 = k0 - tap * CI, dy = tap / 3, dx = tap - 3 * dy;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k0 < 9 * CI) v = *reinterpret_cast<const u32x4*>(a_tile + ((oy + dy) * BN_HALO + ox + dx) * CI + ci0);
+      accb = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_B + s * 1024 + lane * 16), __builtin_bit_cast(V8, v), accb);
+    }
+    // bias + ReLU; accumulator order IS the k order of the packed conv_c weights
+    V8 hb[L::KSC];
+#pragma unroll
+    for (int s = 0; s < L::KSC; ++s) {
+      u32x4 w;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bb + 16 * s + 8 * q + 4 * h);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(accb[8 * s + 4 * q + e] + bb[e], 0.f);
+        w[2 * q] = E::pack2(v[0], v[1]);
+        w[2 * q + 1] = E::pack2(v[2], v[3]);
+      }
+      hb[s] = __builtin_bit_cast(V8, w);
+    }
+    uint16_t* orow = p.out + ((size_t)b * p.T * frame + pix) * COUT;
+#pragma unroll
+    for (int rt = 0; rt < L::RT; ++rt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < L::KSC; ++s)
+        acc = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_C + (rt * L::KSC + s) * 1024 + lane * 16), hb[s], acc);
+      if (SC) {
+#pragma unroll
+        for (int s = 0; s < L::KSS; ++s)
+          acc = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_S + (rt * L::KSS + s) * 1024 + lane * 16), sx[s], acc);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bc = *reinterpret_cast<const f32x4*>(s_bc + 32 * rt + 8 * q + 4 * h);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e] + bc[e];
+        if (!SC) {
+          const u32x2 r2 = idn[rt * 4 + q];
+          v[0] += E::to_f32((uint16_t)(r2[0] & 0xffffu));
+          v[1] += E::to_f32((uint16_t)(r2[0] >> 16));
+          v[2] += E::to_f32((uint16_t)(r2[1] & 0xffffu));
+          v[3] += E::to_f32((uint16_t)(r2[1] >> 16));
+        }
+        if (live)
+          *reinterpret_cast<u32x2*>(orow + 32 * rt + 8 * q + 4 * h) =
+              (u32x2){E::pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), E::pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))};
+      }
+    }
+  }
+}
+
+template <typename E, int CIN, int CI, int COUT, bool SC>
+static int launch_bneck(const BneckParams& p, hipStream_t st) {
+  using L = BnLayout<CIN, CI, COUT, SC>;
+  auto k = fast_bottleneck_kernel<E, CIN, CI, COUT, SC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((long)p.B * p.T * p.tiles_y * p.tiles_x)), dim3(256), L::LDS_BYTES, st, p);
+  KVQ_CHECK_LAUNCH("fast_bottleneck_kernel");
+  return KVQ_OK;
+}
+
+template <int CIN, int CI, int COUT, bool SC>
+static int launch_bneck_dt(const BneckParams& p, int dtype, hipStream_t st) {
+  return dtype == KVQ_DT_FP16 ? launch_bneck<Fp16, CIN, CI, COUT, SC>(p, st) : launch_bneck<Bf16, CIN, CI, COUT, SC>(p, st);
+}
+
+// the supported (input, inner, output) channel triples: SlowFast-R50's fast pathway, res2 .. res4
+static int bneck_variant(int cin, int ci, int cout, int proj) {
+  if (cin == 8 && ci == 8 && cout == 32 && proj) return 1;
+  if (cin == 32 && ci == 8 && cout == 32 && !proj) return 2;
+  if (cin == 64 && ci == 16 && cout == 64 && !proj) return 3;
+  if (cin == 128 && ci == 32 && cout == 128 && !proj) return 4;
+  return 0;
+}
+
+}  // namespace kvq
+
+extern "C" size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection) {
+  using namespace kvq;
+  switch (bneck_variant(cin, ci, cout, projection)) {
+    case 1: return BnLayout<8, 8, 32, true>::PACK_BYTES;
+    case 2: return BnLayout<32, 8, 32, false>::PACK_BYTES;
+    case 3: return BnLayout<64, 16, 64, false>::PACK_BYTES;
+    case 4: return BnLayout<128, 32, 128, false>::PACK_BYTES;
+    default: return 0;
+  }
+}
+
+extern "C" int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection,
+                                   const void* pack, int dtype, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && dims4 && pack && out, KVQ_ERR_NULL, "kvq_fast_bottleneck: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_fast_bottleneck: dtype %d", dtype);
+  const int B = dims4[0], T = dims4[1], H = dims4[2], W = dims4[3];
+  KVQ_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && (long)B * T * ceil_div(H, BN_T) * ceil_div(W, BN_T) < (1L << 31), KVQ_ERR_SHAPE,
+              "kvq_fast_bottleneck: bad shape (%d,%d,%d,%d)", B, T, H, W);
+  const int var = bneck_variant(cin, ci, cout, projection);
+  KVQ_REQUIRE(var, KVQ_ERR_UNSUPPORTED, "kvq_fast_bottleneck: channels (%d -> %d -> %d, projection %d) not in the built set", cin, ci,
+              cout, projection);
+  KVQ_REQUIRE(((size_t)pack & 15) == 0 && ((size_t)x & 15) == 0 && ((size_t)out & 7) == 0, KVQ_ERR_SHAPE,
+              "kvq_fast_bottleneck: x / pack must be 16-byte aligned, out 8-byte");
+  BneckParams p{x, out, (const unsigned char*)pack, B, T, H, W, ceil_div(H, BN_T), ceil_div(W, BN_T)};
+  hipStream_t st = (hipStream_t)stream;
+  switch (var) {
+    case 1: return launch_bneck_dt<8, 8, 32, true>(p, dtype, st);
+    case 2: return launch_bneck_dt<32, 8, 32, false>(p, dtype, st);
+    case 3: return launch_bneck_dt<64, 16, 64, false>(p, dtype, st);
+    default: return launch_bneck_dt<128, 32, 128, false>(p, dtype, st);
+  }
+}

@@ -251,6 +251,13 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
         if (rc) return fail(rc);
         break;
       }
+      case KVQ_NET_BOTTLENECK: {
+        NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && d.kind == KVQ_NET_T_ACT16 && p.w, "kvq_convnet_create: op %d (bottleneck) operand kinds", i);
+        NET_REQUIRE(d.B == s.B && d.D == s.D && d.H == s.H && d.W == s.W && d.C == p.cout, "kvq_convnet_create: op %d (bottleneck) output shape", i);
+        NET_REQUIRE(kvq_fast_bottleneck_pack_bytes(s.C, p.kpad, p.cout, p.n_index) > 0,
+                    "kvq_convnet_create: op %d (bottleneck) channels %d -> %d -> %d (projection %d) not built", i, s.C, p.kpad, p.cout, p.n_index);
+        break;
+      }
       default:
         NET_REQUIRE(false, "kvq_convnet_create: op %d unknown kind %d", i, p.kind);
     }
@@ -458,6 +465,12 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
         const int32_t dims4[4] = {s.B, s.D, s.H, s.W};
         KVQ_TRY(kvq_conv_stem_mfma(x4, dims4, (const uint16_t*)p.w, p.bias, p.kernel3, p.stride3, p.pad3, p.relu, net->dtype,
                                    (uint16_t*)ptr_of(p.dst), st));
+        break;
+      }
+      case KVQ_NET_BOTTLENECK: {
+        const int32_t dims4[4] = {s.B, s.D, s.H, s.W};
+        KVQ_TRY(kvq_fast_bottleneck((const uint16_t*)ptr_of(p.src), dims4, s.C, p.kpad, p.cout, p.n_index, p.w, net->dtype,
+                                    (uint16_t*)ptr_of(p.dst), st));
         break;
       }
       case KVQ_NET_MEAN_STD:

@@ -250,6 +250,19 @@ def pool_nd(x: torch.Tensor, kernel, stride, pad, is_max: bool):
     return out
 
 
+def fast_bottleneck(x: torch.Tensor, pack: torch.Tensor, ci: int, cout: int, projection: bool):
+    """One residual block of SlowFast's fast pathway in one launch (csrc/bottleneck.hip).  x (B,T,H,W,cin) channels-last 16-bit,
+    ``pack`` the uint8 image described in include/kvq_hip.h -> (B,T,H,W,cout)."""
+    _need_gpu(x, pack)
+    assert x.dtype in HALF_TYPES and x.is_contiguous() and x.dim() == 5 and pack.dtype == torch.uint8 and pack.is_contiguous()
+    B, T, H, W, cin = x.shape
+    assert pack.numel() == lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(projection)) > 0, "channel triple not built / wrong image size"
+    out = torch.empty(B, T, H, W, cout, dtype=x.dtype, device=x.device)
+    check(lib().kvq_fast_bottleneck(ptr(x), _i32x((B, T, H, W)), cin, ci, cout, int(projection), ptr(pack), dtype_code(x.dtype), ptr(out),
+                                    stream_of(x)), "kvq_fast_bottleneck")
+    return out
+
+
 def mean_std_pool(x: torch.Tensor, out: torch.Tensor, mean_off: int, std_off: int):
     """x 16-bit [rows, HW, C]; writes fp32 mean/unbiased-std into out[row, mean_off:+C] / out[row, std_off:+C]."""
     _need_gpu(x, out)

@@ -110,8 +110,43 @@ IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materia
 # tests/test_slowfast.py either way (fp32 accumulation inside every conv; one extra 16-bit rounding per block).
 RESIDUAL16 = os.environ.get("KVQ_SF_RESID16", "1") != "0"
 CONVNET = os.environ.get("KVQ_CONVNET", "1") != "0"                  # 0: the layer-by-layer Python sequencing below
+FUSE_FAST = os.environ.get("KVQ_SF_FUSE_FAST", "1") != "0"            # 0: the fast pathway's residual blocks as 3-4 conv launches each
 TWO_LANES = os.environ.get("KVQ_SF_LANES", "1") != "0"                # 0: both pathways on the caller's stream, one op after the other
 STEM_MFMA = os.environ.get("KVQ_STEM_MFMA", "1") != "0"             # 0: fast-pathway stem on the fp32 direct kernel
+
+
+def _fragments(w, k_real, row_tiles, accumulator_order=False):
+    """[R][>= k_real] 16-bit weights -> MFMA A fragments [row_tiles][ceil(k_real / 16)][64 lanes][8]"""
+    dev = w.device
+    ks = -(-k_real // 16)
+    wp = torch.zeros(row_tiles * 32, ks * 16, dtype=w.dtype, device=dev)
+    wp[:w.shape[0], :k_real] = w[:, :k_real]
+    lane, e, f = torch.arange(64, device=dev), torch.arange(8, device=dev), torch.arange(ks, device=dev)
+    m, h = (lane & 31)[None, :, None], (lane >> 5)[None, :, None]
+    if accumulator_order:
+        kk = 16 * f[:, None, None] + 8 * (e >> 2)[None, None, :] + 4 * h + (e & 3)[None, None, :]
+    else:
+        kk = 16 * f[:, None, None] + 8 * h + e[None, None, :]
+    rows = 32 * torch.arange(row_tiles, device=dev)[:, None, None, None] + m[None]
+    return wp[rows.expand(row_tiles, ks, 64, 8), kk[None].expand(row_tiles, ks, 64, 8)].contiguous()
+
+
+def pack_fast_bottleneck(wa, ba, wb, bb, wc, bc, cin, ws=None, bs=None):
+    """The packed image of ``kvq_fast_bottleneck`` (layout: include/kvq_hip.h) from BatchNorm-folded 16-bit weights with
+    (kd, kh, kw, c)-ordered columns — conv_a [ci][>= 3 cin], conv_b [ci][>= 9 ci], conv_c [cout][>= ci], optional projection
+    [cout][>= cin] — and fp32 biases."""
+    ci, cout = wa.shape[0], wc.shape[0]
+    parts = [_fragments(wa, 3 * cin, 1), _fragments(wb, 9 * ci, 1), _fragments(wc, ci, cout // 32, True)]
+    bias_c = bc
+    if ws is not None:
+        parts.append(_fragments(ws, cin, cout // 32))
+        bias_c = bc + bs
+    bias = torch.zeros(-(-(64 + cout) * 4 // 1024) * 256, dtype=torch.float32, device=wa.device)
+    bias[:ci], bias[32:32 + ci], bias[64:64 + cout] = ba, bb, bias_c
+    blob = torch.cat([t.reshape(-1).view(torch.uint8) for t in parts] + [bias.view(torch.uint8)]).contiguous()
+    need = _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(ws is not None))
+    assert need == blob.numel(), (cin, ci, cout, need, blob.numel())
+    return blob
 
 
 class slowfast(nn.Module):  # noqa: N801  (reference spelling)
@@ -165,6 +200,14 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             out[key] = (w.to(half).contiguous(), (b - mu * scale).contiguous(), tuple(wshape[2:]), stride, pad)
         self._wcache = (sig, out)
         return out
+
+    def _bottleneck_pack(self, Wt, pre, projection):
+        key = pre + "/bneck"
+        if key not in Wt:
+            cin = self.table[pre + ".branch2#a"][0][1]
+            proj = Wt[pre + "#1"][:2] if projection else (None, None)
+            Wt[key] = pack_fast_bottleneck(*Wt[pre + ".branch2#a"][:2], *Wt[pre + ".branch2#b"][:2], *Wt[pre + ".branch2#c"][:2], cin, *proj)
+        return Wt[key]
 
     # ---- conv on channels-last 16-bit (B,D,H,W,C) -----------------------------------------------------
     @staticmethod
@@ -319,6 +362,20 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
                 x = slow if pi == 0 else fast
                 for bi in range(DEPTHS[si]):
                     pre = fe + f"{si + 1}.multipathway_blocks.{pi}.res_blocks.{bi}"
+                    if pi == 1 and FUSE_FAST:                # the whole residual block in one launch where the kernel is built
+                        cin, ci, cout = tens[x][4], Wt[pre + ".branch2#a"][0].shape[0], Wt[pre + ".branch2#c"][0].shape[0]
+                        proj = int(bi == 0)
+                        if tuple(Wt[pre + ".branch2#b"][3]) == (1, 1, 1) and _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, proj):
+                            blob = self._bottleneck_pack(Wt, pre, proj)
+                            keep.append(blob)
+                            bb_, d_, h_, w_ = tens[x][:4]
+                            y = tensor(bb_, d_, h_, w_, cout)
+                            op(_abi.NET_BOTTLENECK, x, y, cout=cout, kpad=ci, n_index=proj, w=blob, name=pre.replace(fe, "") + " (fused block)")
+                            m_ = bb_ * d_ * h_ * w_
+                            descs[-1]["flops"] = 2.0 * m_ * (3 * cin * ci + 9 * ci * ci + ci * cout + (cin * cout if proj else 0))
+                            descs[-1]["M"] = m_
+                            x = y
+                            continue
                     a = conv(x, pre + ".branch2#a")
                     b = conv(a, pre + ".branch2#b")
                     ident = conv(x, pre + "#1", relu=False) if bi == 0 else x
@@ -367,11 +424,11 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         finally:
             _abi.check(_abi.lib().kvq_convnet_profile(handle, 0), "kvq_convnet_profile")
         kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma",
-                 _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t"}
+                 _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t", _abi.NET_BOTTLENECK: "bottleneck"}
         out = []
         for d, t in zip(descs, ms):
             k = d["k"][0] * d["k"][1] * d["k"][2] * d["src"][4]
-            fl = 2.0 * d.get("M", 0) * d["cout"] * k
+            fl = d.get("flops", 2.0 * d.get("M", 0) * d["cout"] * k)
             out.append(dict(name=d["name"], kind=kinds.get(d["kind"], "?"), M=d.get("M", 0), N=d["cout"], K=k, kernel=d["k"], ms=float(t),
                             tflops=fl / (t * 1e9) if t > 0 and fl else 0.0))
         return out

@@ -106,14 +106,18 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     m = m.cuda().eval()
     x = torch.from_numpy(synth.synth_clip(77, 16, 96, 64, batch=3)).cuda()
-    with torch.no_grad():
-        s1, f1 = m(M.pack_pathway_output(x))
-        s1b, f1b = m(M.pack_pathway_output(x))
-        M.CONVNET = False
-        try:
-            s0, f0 = m(M.pack_pathway_output(x))
-        finally:
-            M.CONVNET = True
+    M.FUSE_FAST = False          # the layer-by-layer sequencing has one launch per conv: compare like with like
+    try:
+        with torch.no_grad():
+            s1, f1 = m(M.pack_pathway_output(x))
+            s1b, f1b = m(M.pack_pathway_output(x))
+            M.CONVNET = False
+            try:
+                s0, f0 = m(M.pack_pathway_output(x))
+            finally:
+                M.CONVNET = True
+    finally:
+        M.FUSE_FAST = True
     assert m.__dict__.get("_nets"), "the one-call path did not run"
     assert torch.equal(s1, s1b) and torch.equal(f1, f1b)
     assert torch.equal(s1, s0) and torch.equal(f1, f0)
@@ -127,6 +131,77 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     h = C.c_void_p()
     rc = _abi.lib().kvq_convnet_create(o, 1, t, 2, 1, 0, _abi.DT_FP16, C.byref(h))
     assert rc != 0 and b"pool" in _abi.lib().kvq_last_error()
+
+
+def _ref_fast_block(x, wa, ba, wb, bb, wc, bc, ws, bs, half):
+    """fp32 torch restatement of one fast-pathway residual block with the 16-bit rounding points of the HIP path"""
+    import torch.nn.functional as F
+    xf = x.float().permute(0, 4, 1, 2, 3)
+    ci, cin, cout = wa.shape[0], x.shape[-1], wc.shape[0]
+    a = F.relu(F.conv3d(xf, wa.float()[:, :3 * cin].reshape(ci, 3, 1, 1, cin).permute(0, 4, 1, 2, 3), ba, padding=(1, 0, 0))).to(half).float()
+    b = F.relu(F.conv3d(a, wb.float()[:, :9 * ci].reshape(ci, 1, 3, 3, ci).permute(0, 4, 1, 2, 3), bb, padding=(0, 1, 1))).to(half).float()
+    c = F.conv3d(b, wc.float()[:, :ci].reshape(cout, ci, 1, 1, 1), bc)
+    sc = F.conv3d(xf, ws.float()[:, :cin].reshape(cout, cin, 1, 1, 1), bs) if ws is not None else xf
+    return F.relu(c + sc).permute(0, 2, 3, 4, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,ci,cout,proj", [(8, 8, 32, True), (32, 8, 32, False), (64, 16, 64, False), (128, 32, 128, False)])
+@pytest.mark.parametrize("half", [torch.float16, torch.bfloat16])
+def test_fast_bottleneck_kernel_vs_fp32_convs(cin, ci, cout, proj, half):
+    """``kvq_fast_bottleneck`` (conv_a 3x1x1 -> conv_b 1x3x3 -> conv_c 1x1x1 + shortcut, one launch) against torch conv3d in fp32
+    with the same 16-bit rounding of the two inner activations: maps that are not multiples of the 14-pixel tile, temporal and
+    spatial borders, every built channel triple, the projection shortcut; unsupported triples are refused."""
+    from kvq_amd import kernels
+    from kvq_amd.models.backbones.slowfast_model import pack_fast_bottleneck
+    g = torch.Generator().manual_seed(cin * 1000 + ci)
+    B, T, H, W = 2, 5, 17, 30
+    x = torch.randn(B, T, H, W, cin, generator=g).to(half)
+
+    def wgt(rows, k):
+        kpad = -(-k // 32) * 32
+        w = torch.zeros(rows, kpad)
+        w[:, :k] = torch.randn(rows, k, generator=g) * (2.0 / k) ** 0.5
+        return w.to(half)
+    wa, wb, wc = wgt(ci, 3 * cin), wgt(ci, 9 * ci), wgt(cout, ci)
+    ba, bb, bc = (torch.randn(n, generator=g) * 0.2 for n in (ci, ci, cout))
+    ws, bs = (wgt(cout, cin), torch.randn(cout, generator=g) * 0.2) if proj else (None, None)
+    ref = _ref_fast_block(x, wa, ba, wb, bb, wc, bc, ws, bs, half)
+    dev = lambda t: None if t is None else t.cuda()      # noqa: E731
+    pack = pack_fast_bottleneck(dev(wa), dev(ba), dev(wb), dev(bb), dev(wc), dev(bc), cin, dev(ws), dev(bs))
+    got = kernels.fast_bottleneck(x.cuda(), pack, ci, cout, proj).float().cpu()
+    tol = 2e-2 if half == torch.bfloat16 else 3e-3
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+    assert (got - ref).norm().item() / ref.norm().item() < tol / 4
+    with pytest.raises(AssertionError):
+        kernels.fast_bottleneck(x.cuda(), pack, ci + 8, cout, proj)
+
+
+@pytest.mark.gpu
+def test_fused_fast_pathway_blocks_match_the_conv_by_conv_plan():
+    """The network with the fast pathway's residual blocks fused (default) against the same plan with one launch per conv: the
+    same rounding points, so the pooled features agree to accumulation-order noise; the fused plan is the one the oracle parity
+    tests above exercise."""
+    import kvq_amd.models.backbones.slowfast_model as M
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}
+    x = torch.from_numpy(synth.synth_clip(91, 16, 96, 64, batch=2)).cuda()
+    outs = []
+    for fuse in (True, False):
+        M.FUSE_FAST = fuse
+        try:
+            m = M.slowfast()
+            m.load_state_dict(sd)
+            m = m.cuda().eval()
+            with torch.no_grad():
+                outs.append(m.forward_clips(x))
+            rows = m.profile_layers(x)
+            assert any(r["kind"] == "bottleneck" for r in rows) == fuse
+        finally:
+            M.FUSE_FAST = True
+    for a, b in zip(*outs):
+        assert (a - b).norm().item() / b.norm().item() < 1e-3
 
 
 @pytest.mark.gpu
@@ -161,7 +236,8 @@ def test_two_lane_plan_equals_one_lane_and_profile_reads_every_op():
     assert torch.equal(packed[0], ref[0][0]) and torch.equal(packed[1], ref[0][1])
     assert torch.equal(after[0], ref[0][0]) and torch.equal(after[1], ref[0][1])
     convs = [r for r in rows if r["kind"] == "conv"]
-    assert len(convs) == len(M.conv_table()) - 2 and all(r["ms"] > 0 for r in rows)          # every conv but the two stems
+    fused = [r for r in rows if r["kind"] == "bottleneck"]
+    assert all(r["ms"] > 0 for r in rows) and len(convs) + 3 * len(fused) + 1 == len(M.conv_table()) - 2   # every conv but the two stems (one fused block also holds a projection)
     assert any(r["name"].endswith("multipathway_fusion") for r in convs)
 
 
