@@ -46,8 +46,9 @@ def parse():
                     help="headline on pre-sampled fp32 clips (K1 outside the timed region); default: K1 inside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=24, help="clips the CPU oracle is timed on (24 = 3 videos)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams consecutive steps alternate over (independent batches fill each other's launch gaps)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams consecutive steps alternate over (independent batches fill each other's launch gaps; "
+                         "measured 1 / 2 / 3 / 4 / 5 / 6 streams: 2.12 / 1.77 / 1.76 / 1.745 / 1.84 / 1.71-1.84 ms per step)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("KVQ_BENCH_GRAPH", "0")),
                     help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
     ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,c3,c5 ('all', 'c2' = none)")

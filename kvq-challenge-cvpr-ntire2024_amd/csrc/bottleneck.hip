@@ -71,40 +71,47 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   const float* s_bc = s_ba + 64;
   uint16_t* a_tile = reinterpret_cast<uint16_t*>(lds + L::OFF_TILE);
 
-  // ---- conv_a on the halo: column tiles 2 wave, 2 wave + 1 ----------------------------------------------------------------
-#pragma unroll 1
-  for (int c2 = 0; c2 < 2; ++c2) {
-    const int ap = (2 * wave + c2) * 32 + j;
+  // ---- conv_a on the halo: column tiles 2 wave, 2 wave + 1.  The loads of BOTH tiles are in flight before the first wait
+  // where the registers allow it (<= 12 k-steps); 8 waves x 1 tile was measured too: 128 VGPRs spill at 24 k-steps ----------
+  constexpr int NLOAD = L::KSA <= 12 ? 2 : 1;
+  V8 bx[NLOAD][L::KSA];
+  auto load_tile = [&](int c2, V8 (&dst)[L::KSA], bool& inside, int& ap) {
+    ap = (2 * wave + c2) * 32 + j;
     const int yy = y0 - 1 + (ap >> 4), xx = x0 - 1 + (ap & 15);
-    const bool inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+    inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
     const uint16_t* px = xb + ((size_t)(inside ? yy : 0) * p.W + (inside ? xx : 0)) * CIN;
-    V8 bx[L::KSA];
 #pragma unroll
     for (int s = 0; s < L::KSA; ++s) {
-      const int k0 = 16 * s + 8 * h;                     // per-lane, but dt / c are the same for both halves' structure
+      const int k0 = 16 * s + 8 * h;
       const int dt = k0 / CIN, c = k0 - dt * CIN, tt = t + dt - 1;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (k0 < 3 * CIN && inside && tt >= 0 && tt < p.T) v = *reinterpret_cast<const u32x4*>(px + (size_t)tt * frame * CIN + c);
-      bx[s] = __builtin_bit_cast(V8, v);
+      dst[s] = __builtin_bit_cast(V8, v);
     }
-    if (c2 == 0) {
-      // the weight image has landed (these DMAs are older than nothing this wave still needs in flight) and is visible to all
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+  };
+  bool inside[2];
+  int ap[2];
+  load_tile(0, bx[0], inside[0], ap[0]);
+  if (NLOAD == 2) load_tile(1, bx[1], inside[1], ap[1]);
+  // the weight image has landed and is visible to all
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) {
+    if (NLOAD == 1 && c2 == 1) load_tile(1, bx[0], inside[1], ap[1]);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < L::KSA; ++s)
-      acc = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_A + s * 1024 + lane * 16), bx[s], acc);
+      acc = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_A + s * 1024 + lane * 16), bx[NLOAD == 2 ? c2 : 0][s], acc);
 #pragma unroll
     for (int q = 0; q < CI / 8; ++q) {
       const f32x4 ba = *reinterpret_cast<const f32x4*>(s_ba + 8 * q + 4 * h);
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(acc[4 * q + e] + ba[e], 0.f) : 0.f;
-      *reinterpret_cast<u32x2*>(a_tile + ap * CI + 8 * q + 4 * h) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+      for (int e = 0; e < 4; ++e) v[e] = inside[c2] ? fmaxf(acc[4 * q + e] + ba[e], 0.f) : 0.f;
+      *reinterpret_cast<u32x2*>(a_tile + ap[c2] * CI + 8 * q + 4 * h) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
     }
   }
   __syncthreads();
