@@ -9,6 +9,7 @@
 //
 // Tensors are 16-bit channels-last activations (B, D, H, W, C) living in the caller's workspace (slots are recycled after their
 // last reader) or fp32 planar network inputs (B, C, T, H, W); weights are borrowed device pointers.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -201,7 +202,7 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
           NET_REQUIRE(r.kind == KVQ_NET_T_ACT32 && r.C == p.cout && r.B == d.B && r.D == d.D && r.H == d.H && r.W == d.W,
                       "kvq_convnet_create: op %d fp32 copy shape", i);
         }
-        if (!o.pointwise) {
+        if (!o.pointwise && (s.C % 32 != 0 || getenv("KVQ_CONV_TAP_TABLE"))) {     // C % 32 == 0: the kernel walks the taps itself
           int rc = upload_i32(net, build_taps(p.kernel3, s.C, s.H, s.W, p.kpad), &o.d_taps);
           if (rc) return fail(rc);
         }

@@ -36,8 +36,10 @@ struct GemmParams {
   // IMPL (implicit-GEMM convolution): A is the channels-last 16-bit activation (B, D, H, W, Cin) itself; GEMM row m is the
   // output pixel (b, do, ho, wo), K index ((kd*KH + kh)*KW + kw)*Cin + c, zero-padded to K.  taps[K/8]: per 8-channel chunk
   // of K {kd, kh, kw, element offset ((kd*H + kh)*W + kw)*Cin + c0}, offset < 0 = a chunk of the K padding.
+  // taps == NULL (C % 32 == 0, the full kd x kh x kw tap set): the four chunks of a 32-deep slice belong to ONE tap, the same for
+  // every lane — the kernel walks (kd, kh, kw, c) with wave-uniform counters (scalar ALU) and reads no table.
   const int4* taps;
-  int cD, cH, cW, cC, cDo, cHo, cWo, csd, csh, csw, cpd, cph, cpw;
+  int cD, cH, cW, cC, cDo, cHo, cWo, csd, csh, csw, cpd, cph, cpw, ckd, ckh, ckw;
   // split-K: the grid holds ksplit copies of the tile grid; copy s multiplies k-slices [s nk / ksplit, (s + 1) nk / ksplit) and
   // stores its fp32 partial tile at out_f32 + s M N (KVQ_EPI_STORE_F32 instantiation, no bias); splitk_reduce_kernel finishes
   int ksplit;
@@ -77,8 +79,9 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // BK = 32: LDS rows of 64 B, 16-B chunk c of row r at chunk c ^ ((r>>2)&3).  BK = 64 (the "one big tile per CU"
 // variants for long-K shapes): rows of 128 B, chunk c at c ^ ((r>>1)&7) — in both, the 16 lanes of a ds_read_b128
 // service group land on 16 distinct 16-B slots.
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  static_assert(IMPL || !WALK, "WALK is a mode of the implicit-GEMM instantiation");
   fp16_saturate_mode();
   static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
   static_assert(NST == 2 || NST == 3, "ring of 2 or 3 slices");
@@ -110,6 +113,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const uint16_t* b_src[B_PER];
   int a_t0[IMPL ? A_PER : 1], a_y0[IMPL ? A_PER : 1], a_x0[IMPL ? A_PER : 1], a_c[IMPL ? A_PER : 1];   // IMPL: pixel origin, chunk column
   int4 a_tap[IMPL ? A_PER : 1];                                                                          // IMPL: tap of the next slice to issue
+  // IMPL without a table: a table entry is a per-lane VMEM load in the same in-order queue as the slice DMAs, and the s_waitcnt
+  // vmcnt(0) in front of its use drains both slices in flight at every step (1x1x1 over 3072 channels: 60 us as a table-driven
+  // conv against 40 us as the plain GEMM it is).  Uniform walk state of the next slice to issue:
+  // (a compile-time mode: with both in one kernel the table path's pending tap registers make the walk path wait as well)
+  constexpr bool walk = WALK;
+  int u_dd = 0, u_dh = 0, u_dw = 0, u_c8 = 0;
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
@@ -121,7 +130,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       a_t0[i] = dq * p.csd - p.cpd; a_y0[i] = ho * p.csh - p.cph; a_x0[i] = wo * p.csw - p.cpw; a_c[i] = c;
       // element offset of (b, t0, y0, x0, 0): may point before the image; only ever dereferenced with an in-bounds tap added
       a_src[i] = p.A + ((((long)b * p.cD + a_t0[i]) * p.cH + a_y0[i]) * p.cW + a_x0[i]) * (long)p.cC;
-      a_tap[i] = p.taps[(ksl * (p.K / BK) / p.ksplit) * CH + c];
+      if (walk) {
+        a_src[i] += 8 * c;
+        a_tap[i] = (int4){0, 0, 0, 0};
+      } else {
+        a_tap[i] = p.taps[(ksl * (p.K / BK) / p.ksplit) * CH + c];
+      }
     } else {
       a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
     }
@@ -132,20 +146,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
   const int kt0 = ksl * (p.K / BK) / p.ksplit, nk = (ksl + 1) * (p.K / BK) / p.ksplit - kt0;      // this workgroup's k-slices
+  if (walk) {
+    const int C8 = p.cC >> 3;
+    int tap = (kt0 * CH) / C8;
+    u_c8 = kt0 * CH - tap * C8;
+    u_dw = tap % p.ckw; tap /= p.ckw;
+    u_dh = tap % p.ckh; u_dd = tap / p.ckh;
+  }
   auto issue = [&](int kl) {                      // kl: slice index inside the range; ring slot kl % NST
     const int kt = kt0 + kl;
     unsigned char* st = lds + (kl % NST) * ST_BYTES;
     if (IMPL) {
       // issue() is called for consecutive slices: the tap of THIS slice was fetched during the previous call (its L2
       // latency would otherwise sit in front of every DMA), the next slice's is requested now
+      if (walk) {
+        const int toff = ((u_dd * p.cH + u_dh) * p.cW + u_dw) * p.cC + 8 * u_c8;       // wave-uniform
+        const bool tap_ok = u_dd < p.ckd;                                              // past the last tap: the zero padding of K
 #pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const int4 t = a_tap[i];
-        const bool ok = t.w >= 0 && (unsigned)(a_t0[i] + t.x) < (unsigned)p.cD && (unsigned)(a_y0[i] + t.y) < (unsigned)p.cH &&
-                        (unsigned)(a_x0[i] + t.z) < (unsigned)p.cW;
-        const uint16_t* src = ok ? a_src[i] + t.w : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
-        a_tap[i] = p.taps[min(kt + 1, p.K / BK - 1) * CH + a_c[i]];
+        for (int i = 0; i < A_PER; ++i) {
+          const bool ok = tap_ok && (unsigned)(a_t0[i] + u_dd) < (unsigned)p.cD && (unsigned)(a_y0[i] + u_dh) < (unsigned)p.cH &&
+                          (unsigned)(a_x0[i] + u_dw) < (unsigned)p.cW;
+          const uint16_t* src = ok ? a_src[i] + toff : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        u_c8 += CH;
+        if (u_c8 >= (p.cC >> 3)) {
+          u_c8 = 0;
+          if (++u_dw == p.ckw) {
+            u_dw = 0;
+            if (++u_dh == p.ckh) { u_dh = 0; ++u_dd; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          const int4 t = a_tap[i];
+          const bool ok = t.w >= 0 && (unsigned)(a_t0[i] + t.x) < (unsigned)p.cD && (unsigned)(a_y0[i] + t.y) < (unsigned)p.cH &&
+                          (unsigned)(a_x0[i] + t.z) < (unsigned)p.cW;
+          const uint16_t* src = ok ? a_src[i] + t.w : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          a_tap[i] = p.taps[min(kt + 1, p.K / BK - 1) * CH + a_c[i]];
+        }
       }
     } else {
 #pragma unroll
@@ -193,7 +234,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     // slice kt must have landed; up to two younger slices stay in flight
     const int younger = nk - 1 - kt;
     if (NST > 2 && younger >= 1) {
-      gemm_wait_vmcnt<NL + (IMPL ? A_PER : 0)>();     // IMPL: every issue also carries A_PER tap loads
+      if (IMPL && !walk) gemm_wait_vmcnt<NL + A_PER>();     // table-driven: every issue also carries A_PER tap loads
+      else gemm_wait_vmcnt<NL>();
     } else {
       gemm_wait_vmcnt<0>();
     }
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false>
 static int launch_one(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   p.ksplit = p.ksplit < 1 ? 1 : p.ksplit;
@@ -373,7 +415,7 @@ static int launch_one(const GemmParams& p_in, hipStream_t st) {
   constexpr size_t main_bytes = NST * (BM + BN) * BK * 2;               // ring of 2*BK-byte rows
   constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL>;
+  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL, WALK>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -556,6 +598,14 @@ template <typename E, int EPI>
 static int launch_conv_variant(const GemmParams& p, hipStream_t st) {
   int var = gemm_variant(p.M, p.N, p.K) / 100;
   if (var != 22 && var != 21 && var != 12 && var != 11) var = 22;
+  if (!p.taps) {                // C % 32 == 0, full tap set: the kernel walks the taps with wave-uniform counters
+    switch (var) {
+      case 22: return launch_one<E, 2, 2, 32, EPI, KVQ_GEMM_NST, true, true>(p, st);
+      case 21: return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, true, true>(p, st);
+      case 12: return launch_one<E, 1, 2, 32, EPI, KVQ_GEMM_NST, true, true>(p, st);
+      default: return launch_one<E, 1, 1, 32, EPI, KVQ_GEMM_NST, true, true>(p, st);
+    }
+  }
   switch (var) {
     case 22: return launch_one<E, 2, 2, 32, EPI, KVQ_GEMM_NST, true>(p, st);
     case 21: return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, true>(p, st);
@@ -674,7 +724,7 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
 
 extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(a && a->x && a->W && a->taps && (a->epilogue == KVQ_EPI_STORE_F32 ? (const void*)a->out_f32 : (const void*)a->out_bf16),
+  KVQ_REQUIRE(a && a->x && a->W && (a->epilogue == KVQ_EPI_STORE_F32 ? (const void*)a->out_f32 : (const void*)a->out_bf16),
               KVQ_ERR_NULL, "kvq_conv_implicit: NULL pointer");
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_conv_implicit: dtype %d", a->dtype);
   const int B = a->dims5[0], Cin = a->dims5[1], D = a->dims5[2], H = a->dims5[3], W = a->dims5[4];
@@ -698,6 +748,9 @@ extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
   p.out_h = a->out_bf16; p.out_f32 = a->out_f32; p.resid_h = a->resid_bf16; p.resid_f32 = a->resid_f32;
   p.trace = g_trace; p.trace_blocks = g_trace_blocks;
   p.taps = reinterpret_cast<const int4*>(a->taps);
+  p.ckd = a->kernel3[0]; p.ckh = a->kernel3[1]; p.ckw = a->kernel3[2];
+  KVQ_REQUIRE(a->taps || (Cin % 32 == 0 && a->Kpad >= p.ckd * p.ckh * p.ckw * Cin), KVQ_ERR_SHAPE,
+              "kvq_conv_implicit: without a tap table C=%d must be a multiple of 32 and Kpad=%d cover kd*kh*kw*C", Cin, a->Kpad);
   p.cD = D; p.cH = H; p.cW = W; p.cC = Cin; p.cDo = Do; p.cHo = Ho; p.cWo = Wo;
   p.csd = a->stride3[0]; p.csh = a->stride3[1]; p.csw = a->stride3[2];
   p.cpd = a->pad3[0]; p.cph = a->pad3[1]; p.cpw = a->pad3[2];

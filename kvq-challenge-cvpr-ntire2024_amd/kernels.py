@@ -482,6 +482,9 @@ def conv_taps(kernel, Cc: int, H: int, W: int, k_pad: int, device, live=None):
     return t
 
 
+TAP_TABLE = bool(__import__("os").environ.get("KVQ_CONV_TAP_TABLE"))     # experiments: always hand kvq_conv_implicit a tap table
+
+
 def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, relu: bool, resid=None, resid_f32=None,
                   want_f32=False, store_f32=False, live=None):
     """Conv (+ folded BN, + identity, + ReLU) on a channels-last 16-bit activation x (B, D, H, W, C), C % 8 == 0, without a
@@ -500,7 +503,10 @@ def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, r
     out32 = torch.empty(M, N, dtype=torch.float32, device=x.device) if (want_f32 or store_f32) else None
     assert relu or (resid is None and resid_f32 is None and not want_f32), "identity add / fp32 copy: ReLU epilogue only"
     a = _abi.KvqConvArgs()
-    a.x, a.W, a.bias, a.taps = ptr(x), ptr(W), ptr(bias), ptr(conv_taps(kernel, Cc, H, Wd, k_pad, x.device, live))
+    # a tap table only where it is needed: pruned taps (the table DEFINES K) or C % 32 != 0; otherwise the kernel walks the full
+    # tap set with wave-uniform counters (no table loads between the slice DMAs)
+    table = conv_taps(kernel, Cc, H, Wd, k_pad, x.device, live) if (live is not None or Cc % 32 or TAP_TABLE) else None
+    a.x, a.W, a.bias, a.taps = ptr(x), ptr(W), ptr(bias), ptr(table)
     a.dims5[:] = (B, Cc, D, H, Wd)
     a.kernel3[:], a.stride3[:], a.pad3[:] = tuple(kernel), tuple(stride), tuple(pad)
     a.Kpad, a.N = k_pad, N

@@ -159,6 +159,44 @@ def test_conv_implicit_split_k_matches_conv3d():
     assert (got.float().cpu() - ref).abs().max().item() <= 2.0 ** -10 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("shape,Cout,k,stride,pad", [
+    ((2, 5, 9, 11, 64), 48, (3, 1, 1), (1, 1, 1), (1, 0, 0)),       # temporal taps, borders in time
+    ((2, 3, 13, 10, 32), 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)),      # spatial taps, stride 2, one chunk group per tap
+    ((1, 4, 8, 8, 96), 40, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # 27 taps x 3 slices each, K padding behind the last tap
+    ((3, 1, 7, 7, 160), 256, (1, 1, 1), (1, 2, 2), (0, 0, 0)),      # strided 1x1 (projection shortcut)
+])
+def test_conv_implicit_tap_walk_equals_tap_table(shape, Cout, k, stride, pad, half):
+    """C % 32 == 0: the kernel walks (kd, kh, kw, c) with wave-uniform counters instead of reading the tap table — same slices in the
+    same order, so the results are bit-identical to the table-driven instantiation; a table is still required when C % 32 != 0."""
+    g = rng(sum(shape) + Cout)
+    Cc = shape[-1]
+    K = k[0] * k[1] * k[2] * Cc
+    kpad = -(-K // 32) * 32
+    x = dev(torch.from_numpy(g.standard_normal(shape).astype(np.float32)).to(half))
+    w = torch.zeros(Cout, kpad)
+    w[:, :K] = torch.from_numpy((g.standard_normal((Cout, K)) / np.sqrt(K)).astype(np.float32))
+    w, bias = dev(w.to(half)), dev(torch.from_numpy(g.standard_normal(Cout).astype(np.float32)))
+    assert not kernels.TAP_TABLE
+    walked = kernels.conv_implicit(x, w, bias, k, stride, pad, True)
+    kernels.TAP_TABLE = True
+    try:
+        tabled = kernels.conv_implicit(x, w, bias, k, stride, pad, True)
+    finally:
+        kernels.TAP_TABLE = False
+    assert torch.equal(walked, tabled)
+    a = _abi.KvqConvArgs()
+    x8 = dev(torch.zeros(1, 1, 4, 4, 8, dtype=half))
+    w8 = dev(torch.zeros(8, 32, dtype=half))
+    o8 = dev(torch.zeros(16, 8, dtype=half))
+    a.x, a.W, a.out_bf16 = _abi.ptr(x8), _abi.ptr(w8), _abi.ptr(o8)
+    a.dims5[:] = (1, 8, 1, 4, 4)
+    a.kernel3[:], a.stride3[:], a.pad3[:] = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+    a.Kpad, a.N, a.epilogue, a.dtype = 32, 8, _abi.EPI_BIAS_BF16, _abi.dtype_code(half)
+    import ctypes
+    assert _abi.lib().kvq_conv_implicit(ctypes.byref(a), _abi.current_stream()) != 0
+    assert b"tap table" in _abi.lib().kvq_last_error()
+
+
 def test_gemm_rejects_bad_shapes():
     A = torch.zeros(8, 40, dtype=torch.float16, device=DEV)
     W = torch.zeros(32, 40, dtype=torch.float16, device=DEV)
