@@ -21,6 +21,9 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLE
 # C3
 timeout 300 python tools/c3_probe.py > $out/c3_probe.log 2>&1
 timeout 300 python tools/sf_probe.py >> $out/c3_probe.log 2>&1
+timeout 300 python tools/sf_layers.py > $out/slowfast_layers.txt 2>&1
+KVQ_SF_FUSE_FAST=0 KVQ_CONV_TAP_TABLE=1 timeout 300 python tools/sf_layers.py > $out/slowfast_layers_conv_by_conv.txt 2>&1
+timeout 300 python tools/gemm_sweep.py > $out/gemm_sweep.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/c3_trace -o t -- python tools/c3_probe.py > $out/c3_trace.log 2>&1
 db=$(find $out/c3_trace -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/c3_kernel_stats.txt
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/c3_pmc_sq -o s -- python tools/sf_probe.py 2 > $out/c3_pmc_s.log 2>&1
