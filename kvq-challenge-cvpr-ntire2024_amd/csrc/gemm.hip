@@ -146,12 +146,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
   const int kt0 = ksl * (p.K / BK) / p.ksplit, nk = (ksl + 1) * (p.K / BK) / p.ksplit - kt0;      // this workgroup's k-slices
+  // walk: per-lane source of the next slice and its advance per slice (0 for rows whose tap falls outside the image: they keep
+  // reading the zero chunk).  Both only change when the TAP changes (every C / 32 slices): with one workgroup per CU — the late
+  // layers: 100-196 tiles — nothing hides the issue path, and per-slice compares / selects / 64-bit address sums cost what they cost
+  const uint16_t* w_cur[IMPL ? A_PER : 1];
+  int w_step[IMPL ? A_PER : 1];
+  auto retap = [&]() {
+    const int toff = ((u_dd * p.cH + u_dh) * p.cW + u_dw) * p.cC + 8 * u_c8;       // wave-uniform
+    const bool tap_ok = u_dd < p.ckd;                                              // past the last tap: the zero padding of K
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const bool ok = tap_ok && (unsigned)(a_t0[i] + u_dd) < (unsigned)p.cD && (unsigned)(a_y0[i] + u_dh) < (unsigned)p.cH &&
+                      (unsigned)(a_x0[i] + u_dw) < (unsigned)p.cW;
+      w_cur[i] = ok ? a_src[i] + toff : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
+      w_step[i] = ok ? BK : 0;
+    }
+  };
   if (walk) {
     const int C8 = p.cC >> 3;
     int tap = (kt0 * CH) / C8;
     u_c8 = kt0 * CH - tap * C8;
     u_dw = tap % p.ckw; tap /= p.ckw;
     u_dh = tap % p.ckh; u_dd = tap / p.ckh;
+    retap();
   }
   auto issue = [&](int kl) {                      // kl: slice index inside the range; ring slot kl % NST
     const int kt = kt0 + kl;
@@ -160,14 +177,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       // issue() is called for consecutive slices: the tap of THIS slice was fetched during the previous call (its L2
       // latency would otherwise sit in front of every DMA), the next slice's is requested now
       if (walk) {
-        const int toff = ((u_dd * p.cH + u_dh) * p.cW + u_dw) * p.cC + 8 * u_c8;       // wave-uniform
-        const bool tap_ok = u_dd < p.ckd;                                              // past the last tap: the zero padding of K
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-          const bool ok = tap_ok && (unsigned)(a_t0[i] + u_dd) < (unsigned)p.cD && (unsigned)(a_y0[i] + u_dh) < (unsigned)p.cH &&
-                          (unsigned)(a_x0[i] + u_dw) < (unsigned)p.cW;
-          const uint16_t* src = ok ? a_src[i] + toff : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)w_cur[i], (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          w_cur[i] += w_step[i];
         }
         u_c8 += CH;
         if (u_c8 >= (p.cC >> 3)) {
@@ -176,6 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             u_dw = 0;
             if (++u_dh == p.ckh) { u_dh = 0; ++u_dd; }
           }
+          retap();
         }
       } else {
 #pragma unroll
@@ -504,7 +518,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const 
 // round (fc2 of stage 3, K = 3072 over 150 tiles: 43.6 us un-split, 43.8 split in three) — they stay whole.
 static int splitk_factor(long tiles, int nk, int bk) {
   static const int off = getenv("KVQ_GEMM_SPLITK") && atoi(getenv("KVQ_GEMM_SPLITK")) == 0;
-  if (off || bk != 32 || tiles > 200 || nk < 48) return 1;
+  // 196 tiles (res4 of SlowFast's slow pathway) stay whole since the implicit GEMM walks its taps: 1x3x3 / 256 channels 36 us whole,
+  // 40 us split in two; 100 tiles (res5): 58 us whole, 38 us split in five
+  if (off || bk != 32 || tiles > 160 || nk < 48) return 1;
   int S = (int)(512 / tiles);
   S = S > 8 ? 8 : S;
   while (S > 1 && nk / S < 24) --S;

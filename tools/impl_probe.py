@@ -30,4 +30,5 @@ for name, shape, kern, pad in [("1x1x1 C=3072", (8, 8, 14, 14, 3072), (1, 1, 1),
     A = torch.randn(M, K, device=dev).half()
     tc = t_of(lambda: kernels.conv_implicit(x, W, bias, kern, (1, 1, 1), pad, True))
     tg = t_of(lambda: kernels.gemm(A, W, bias, _abi.EPI_BIAS_BF16))
-    print(f"{name}: M={M} K={K}: implicit conv {tc:6.1f} us | plain GEMM {tg:6.1f} us", flush=True)
+    tr = t_of(lambda: kernels.conv_gemm(A, W, bias, True))           # the plain GEMM with the conv path's ReLU epilogue
+    print(f"{name}: M={M} K={K}: implicit conv {tc:6.1f} us | plain GEMM {tg:6.1f} us | plain GEMM + ReLU epilogue {tr:6.1f} us", flush=True)
