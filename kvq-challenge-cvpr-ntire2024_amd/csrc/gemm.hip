@@ -79,17 +79,27 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // BK = 32: LDS rows of 64 B, 16-B chunk c of row r at chunk c ^ ((r>>2)&3).  BK = 64 (the "one big tile per CU"
 // variants for long-K shapes): rows of 128 B, chunk c at c ^ ((r>>1)&7) — in both, the 16 lanes of a ds_read_b128
 // service group land on 16 distinct 16-B slots.
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+// WN: wave columns (2: the 2x2 wave grid; 4: EIGHT waves in a 2x4 grid over the same block tile — two waves per SIMD for launches
+// that put one workgroup on a CU, so a wave's barrier / fragment-read latency is covered by the other's MFMAs).
+// PIPE (the "solo" variants: one workgroup per CU, ring of >= 4 slices): the fragments of slice t+1 are read while the MFMAs of
+// slice t run (two register sets, K loop unrolled by two).  Without it the four waves of a lone workgroup walk in lock step through
+// "all read LDS" / "all multiply": ~800 cycles per 32-deep slice for 256 cycles of MFMA; co-resident workgroups hide that for the
+// multi-round launches, nothing does for the 100-200-tile launches of the late layers.
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false, int WN = 2,
+          bool PIPE = false>
+__global__ __launch_bounds__(128 * WN) void gemm_kernel(GemmParams p) {
+  static_assert(!PIPE || (NST >= 4 && BK == 32), "PIPE: one slice is waited for ahead of its use; lgkmcnt counts <= 15 reads");
   static_assert(IMPL || !WALK, "WALK is a mode of the implicit-GEMM instantiation");
   fp16_saturate_mode();
   static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
-  static_assert(NST == 2 || NST == 3, "ring of 2 or 3 slices");
-  constexpr int BM = 64 * MI, BN = 64 * NI;
+  static_assert(NST >= 2 && NST <= 8, "ring of 2 .. 8 slices");
+  static_assert(WN == 2 || WN == 4, "wave grid 2 x WN");
+  constexpr int NT = 128 * WN;                                         // threads
+  constexpr int BM = 64 * MI, BN = 32 * NI * WN;
   constexpr int RB = BK * 2, CH = RB / 16, KK = BK / 16;             // row bytes, 16-B chunks per row, MFMA k-steps per slice
   constexpr int A_BYTES = BM * RB, ST_BYTES = (BM + BN) * RB;
-  constexpr int A_PER = BM * CH / 256, B_PER = BN * CH / 256, NL = A_PER + B_PER;   // DMAs per thread per slice
-  static_assert((BM * CH) % 256 == 0 && (BN * CH) % 256 == 0, "whole DMA rounds");
+  constexpr int A_PER = BM * CH / NT, B_PER = BN * CH / NT, NL = A_PER + B_PER;   // DMAs per thread per slice
+  static_assert((BM * CH) % NT == 0 && (BN * CH) % NT == 0, "whole DMA rounds");
   auto swz = [](int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2.  Give
   // every XCD a CONTIGUOUS range of the logical tile index (N fastest), so the N-tiles that re-read one A
   // row-panel share an L2 instead of fetching it once per XCD (bijective also when nwg % 8 != 0).
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   int u_dd = 0, u_dh = 0, u_dw = 0, u_c8 = 0;
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
-    const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
+    const int q = i * NT + tid, row = q / CH, c = (q % CH) ^ swz(row);
     if (IMPL) {
       int m = min(m0 + row, p.M - 1);
       const int wo = m % p.cWo; m /= p.cWo;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
-    const int q = i * 256 + tid, row = q / CH, c = (q % CH) ^ swz(row);
+    const int q = i * NT + tid, row = q / CH, c = (q % CH) ^ swz(row);
     b_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.K + c * 8;
   }
   const int kt0 = ksl * (p.K / BK) / p.ksplit, nk = (ksl + 1) * (p.K / BK) / p.ksplit - kt0;      // this workgroup's k-slices
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       if (walk) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)w_cur[i], (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)w_cur[i], (lds_ptr_t)(st + (i * NT + wave * 64) * 16), 16, 0, 0);
           w_cur[i] += w_step[i];
         }
         u_c8 += CH;
@@ -198,20 +208,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
           const bool ok = t.w >= 0 && (unsigned)(a_t0[i] + t.x) < (unsigned)p.cD && (unsigned)(a_y0[i] + t.y) < (unsigned)p.cH &&
                           (unsigned)(a_x0[i] + t.z) < (unsigned)p.cW;
           const uint16_t* src = ok ? a_src[i] + t.w : reinterpret_cast<const uint16_t*>(kvq_zero_chunk);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(st + (i * NT + wave * 64) * 16), 16, 0, 0);
           a_tap[i] = p.taps[min(kt + 1, p.K / BK - 1) * CH + a_c[i]];
         }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(st + (i * 256 + wave * 64) * 16), 16,
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + kt * BK), (lds_ptr_t)(st + (i * NT + wave * 64) * 16), 16,
                                          0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + kt * BK),
-                                       (lds_ptr_t)(st + A_BYTES + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                                       (lds_ptr_t)(st + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
   };
 
   f32x16 acc[MI][NI];
@@ -226,8 +236,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
   (void)bn;
   if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
-  issue(0);
-  if (NST > 2 && nk > 1) issue(1);
+#pragma unroll
+  for (int kl = 0; kl < NST - 1; ++kl)
+    if (kl < nk) issue(kl);
   const int frow = lane & 31, fkg = lane >> 5;
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;          // LDS byte address of the ring
   // per-lane fragment byte offsets inside a slice (swizzled), one per kk
@@ -244,15 +255,104 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) b_off[j][kk] = A_BYTES + row * RB + (((kk * 2 + fkg) ^ swz(row)) << 4);
   }
+  // vmcnt wait for "slice kt has landed": the slices issued behind it (at most `depth`) may still be in flight
+  constexpr int PER = NL + ((IMPL && !walk) ? A_PER : 0);    // table-driven IMPL: every issue also carries A_PER tap loads
+  auto wait_landed = [&](int kt, auto depth_tag) {
+    constexpr int DEPTH = decltype(depth_tag)::value;
+    const int younger = nk - 1 - kt;
+    if (DEPTH >= 1 && younger >= DEPTH) gemm_wait_vmcnt<DEPTH * PER>();
+    else if (DEPTH > 5 && younger == 5) gemm_wait_vmcnt<5 * PER>();
+    else if (DEPTH > 4 && younger == 4) gemm_wait_vmcnt<4 * PER>();
+    else if (DEPTH > 3 && younger == 3) gemm_wait_vmcnt<3 * PER>();
+    else if (DEPTH > 2 && younger == 2) gemm_wait_vmcnt<2 * PER>();
+    else if (DEPTH > 1 && younger == 1) gemm_wait_vmcnt<PER>();
+    else gemm_wait_vmcnt<0>();
+  };
+  if (PIPE) {
+    constexpr int RS = KK * (MI + NI);                       // fragment reads per slice and wave
+    static_assert(!PIPE || RS <= 15, "lgkmcnt is a 4-bit counter");
+    V8 fa[2][KK][MI], fb[2][KK][NI];
+    auto read_slice = [&](int kt, auto buf) {
+      constexpr int B = decltype(buf)::value;
+      const unsigned sbase = lds_base + (kt % NST) * ST_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) lds_read_b128(fa[B][kk][i], sbase + a_off[i][kk]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) lds_read_b128(fb[B][kk][j], sbase + b_off[j][kk]);
+      }
+    };
+    // one slice with a successor (straight-line: the accumulators must not pass through a conditional path, or the register
+    // allocator copies all of them between AGPRs and VGPRs every iteration); buf = the register set that holds slice kt
+    auto step_more = [&](int kt, auto buf) __attribute__((always_inline)) {
+      constexpr int B = decltype(buf)::value;
+      wait_landed(kt + 1, std::integral_constant<int, NST - 3>{});
+      __builtin_amdgcn_s_barrier();                       // slice kt+1 visible; everybody's reads of slice kt-1 have returned
+      if (kt + NST - 1 < nk) issue(kt + NST - 1);         // into the slot of slice kt-1
+      read_slice(kt + 1, std::integral_constant<int, 1 - B>{});
+      // LDS returns in order: "at most RS outstanding" = this slice's fragments are here, the next slice's still in flight
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[B][kk][i]) : "n"(RS) : "memory");
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(fb[B][kk][j]));
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = E::mfma32(fa[B][kk][i], fb[B][kk][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step_last = [&](auto buf) __attribute__((always_inline)) {
+      constexpr int B = decltype(buf)::value;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[B][kk][i])::"memory");
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(fb[B][kk][j]));
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = E::mfma32(fa[B][kk][i], fb[B][kk][j], acc[i][j]);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    wait_landed(0, std::integral_constant<int, NST - 2>{});
+    __builtin_amdgcn_s_barrier();
+    if (tr) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
+    read_slice(0, B0{});
+    // nk odd: pairs (0,1) .. (nk-3, nk-2), then the last slice from set 0; nk even: one slice (set 0) first makes the rest odd
+    int kt = 0;
+    if ((nk & 1) == 0) {           // nk >= 2 here
+      step_more(0, B0{});
+      // the sets are now swapped relative to the slice parity: walk the remaining (odd count) with set 1 leading
+      for (kt = 1; kt + 2 < nk; kt += 2) {
+        step_more(kt, B1{});
+        step_more(kt + 1, B0{});
+      }
+      step_last(B1{});
+    } else {
+      for (; kt + 2 < nk; kt += 2) {
+        step_more(kt, B0{});
+        step_more(kt + 1, B1{});
+      }
+      step_last(B0{});
+    }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // slice kt must have landed; up to two younger slices stay in flight
-    const int younger = nk - 1 - kt;
-    if (NST > 2 && younger >= 1) {
-      if (IMPL && !walk) gemm_wait_vmcnt<NL + A_PER>();     // table-driven: every issue also carries A_PER tap loads
-      else gemm_wait_vmcnt<NL>();
-    } else {
-      gemm_wait_vmcnt<0>();
-    }
+    // (up to NST - 2 younger slices stay in flight; table-driven IMPL: every issue also carries A_PER tap loads)
+    wait_landed(kt, std::integral_constant<int, NST - 2>{});
     __builtin_amdgcn_s_barrier();
     if (tr && kt == 0) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
     if (kt + NST - 1 < nk) issue(kt + NST - 1);
@@ -421,22 +521,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false, int WN = 2,
+          bool PIPE = false>
 static int launch_one(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   p.ksplit = p.ksplit < 1 ? 1 : p.ksplit;
-  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr int BM = 64 * MI, BN = 32 * NI * WN;
   constexpr size_t main_bytes = NST * (BM + BN) * BK * 2;               // ring of 2*BK-byte rows
-  constexpr size_t epi_bytes = 4 * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
+  constexpr size_t epi_bytes = 2 * WN * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL, WALK>;
+  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL, WALK, WN, PIPE>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
-  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN) * p.ksplit), block(256);
+  dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN) * p.ksplit), block(128 * WN);
   hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
   KVQ_CHECK_LAUNCH("gemm_kernel");
   return KVQ_OK;
@@ -594,6 +695,15 @@ static int launch_gemm_variant(const GemmParams& p, hipStream_t st) {
       default: return launch_one<E, 2, 4, 64, EPI>(p, st);
     }
   }
+#ifdef KVQ_GEMM_EXPERIMENTS   // -DKVQ_GEMM_EXPERIMENTS builds only (measured and not adopted): lone-workgroup variants
+  static const int w8 = getenv("KVQ_GEMM_W8") ? atoi(getenv("KVQ_GEMM_W8")) : 0;      // 8 waves (2 x 4) on the 128x128 tile
+  if (w8 && var / 100 == 22) return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, false, false, 4>(p, st);
+  static const int ring = getenv("KVQ_GEMM_RING") ? atoi(getenv("KVQ_GEMM_RING")) : 0;  // ring of 6 / 8 slices; 16 / 18: + PIPE
+  if (ring == 6 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 6>(p, st);
+  if (ring == 8 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 8>(p, st);
+  if (ring == 16 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 6, false, false, 2, true>(p, st);
+  if (ring == 18 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 8, false, false, 2, true>(p, st);
+#endif
   switch (var / 100) {
     case 22: return launch_one<E, 2, 2, 32, EPI>(p, st);
     case 21: return launch_one<E, 2, 1, 32, EPI>(p, st);
@@ -614,6 +724,10 @@ template <typename E, int EPI>
 static int launch_conv_variant(const GemmParams& p, hipStream_t st) {
   int var = gemm_variant(p.M, p.N, p.K) / 100;
   if (var != 22 && var != 21 && var != 12 && var != 11) var = 22;
+#ifdef KVQ_GEMM_EXPERIMENTS
+  static const int w8 = getenv("KVQ_GEMM_W8") ? atoi(getenv("KVQ_GEMM_W8")) : 0;
+  if (!p.taps && w8 && var == 22) return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, true, true, 4>(p, st);
+#endif
   if (!p.taps) {                // C % 32 == 0, full tap set: the kernel walks the taps with wave-uniform counters
     switch (var) {
       case 22: return launch_one<E, 2, 2, 32, EPI, KVQ_GEMM_NST, true, true>(p, st);
