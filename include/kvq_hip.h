@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 14
+#define KVQ_ABI_VERSION 15
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -500,7 +500,8 @@ typedef enum {
   KVQ_NET_MEAN_STD = 4,   /* mean (and unbiased std) over the positions of every row -> fp32 output `dst` of the caller */
   KVQ_NET_SELECT_T = 5,   /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
   KVQ_NET_BOTTLENECK = 6  /* one residual block of SlowFast's fast pathway in ONE launch (kvq_fast_bottleneck): w = the packed image,
-                             kpad = inner channels, cout = output channels, n_index = 1 when the block has a projection shortcut */
+                             kpad = inner channels, cout = output channels, n_index = 1 when the block has a projection shortcut,
+                             stride3[1] = stride3[2] = its spatial stride */
 } KvqNetOpKind;
 typedef enum {
   KVQ_NET_T_ACT16 = 0,       /* 16-bit channels-last (B,D,H,W,C) */
@@ -557,11 +558,13 @@ int kvq_convnet_profile_read(const KvqConvNet* net, float* ms, int capacity, int
  * matrix zero — in this order: conv_a [ceil(3 cin / 16)] with k = 16 f + 8 h + e over (dt, c); conv_b [ceil(9 ci / 16)] with the same
  * k over (dy, dx, c); conv_c [cout / 32][ceil(ci / 16)] with k = 16 f + 8 (e >> 2) + 4 h + (e & 3) (the accumulator order of conv_b);
  * the projection [cout / 32][ceil(cin / 16)] with natural k; then fp32 bias_a[32] bias_b[32] bias_c[cout] (+ the projection's bias),
- * zero padded to a multiple of 1 KB.  Built (cin, ci, cout, projection): (8,8,32,1) (32,8,32,0) (64,16,64,0) (128,32,128,0);
- * kvq_fast_bottleneck_pack_bytes returns 0 for anything else. */
-size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection);
-int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection, const void* pack,
-                        int dtype, uint16_t* out, void* stream);
+ * zero padded to a multiple of 1 KB.  stride (1 | 2) is the spatial stride of conv_b AND of the projection (a stage's first block,
+ * pad 0,1,1: the output map is ceil(H / stride) x ceil(W / stride)).  Built (cin, ci, cout, projection, stride): (8,8,32,1,1)
+ * (32,8,32,0,1) (64,16,64,0,1) (128,32,128,0,1) (32,16,64,1,2) (64,32,128,1,2); kvq_fast_bottleneck_pack_bytes returns 0 for anything
+ * else. */
+size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection, int stride);
+int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection, int stride,
+                        const void* pack, int dtype, uint16_t* out, void* stream);
 
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],

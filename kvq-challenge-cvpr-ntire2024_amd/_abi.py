@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 def dtype_code(dt) -> int:
@@ -143,8 +143,8 @@ SYMBOLS = {
     "kvq_convnet_destroy": (None, [p_void]),
     "kvq_convnet_workspace_bytes": (sz, [p_void]),
     "kvq_convnet_forward": (i32, [p_void, C.POINTER(p_void), C.POINTER(p_void), p_void, sz, p_void]),
-    "kvq_fast_bottleneck_pack_bytes": (sz, [i32, i32, i32, i32]),
-    "kvq_fast_bottleneck": (i32, [p_void, C.POINTER(i32), i32, i32, i32, i32, p_void, i32, p_void, p_void]),
+    "kvq_fast_bottleneck_pack_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "kvq_fast_bottleneck": (i32, [p_void, C.POINTER(i32), i32, i32, i32, i32, i32, p_void, i32, p_void, p_void]),
     "kvq_convnet_profile": (i32, [p_void, i32]),
     "kvq_convnet_profile_read": (i32, [p_void, C.POINTER(C.c_float), i32, C.POINTER(i32)]),
     "kvq_swin3d_forward_stages": (i32, [p_void, p_void, p_void, i32, i32, p_void, p_void, p_void, sz, p_void]),

@@ -7,7 +7,8 @@
 // block's full-resolution tensor, 1.0 ms of a 3.8 ms network for 8 % of its FLOPs (profiles/r02_slowfast_layers.txt).  Fused,
 // a block reads its input once (three frames through L2) and writes its output once.
 //
-// Geometry: a workgroup (4 waves) owns a 14 x 14 output tile of ONE frame (56 / 28 / 14-pixel maps tile exactly).  Everything is
+// Geometry: a workgroup (4 waves) owns a 14 x 14 output tile of ONE frame (56 / 28 / 14-pixel maps tile exactly); the stage's first
+// block, whose conv_b and projection have stride 2, a 7 x 7 tile (its conv_a halo is 15 x 15 input pixels).  Everything is
 // TOKEN-PER-LANE as in tail.hip: D[channel][pixel] = W[channel][k] . In[k][pixel] on v_mfma_f32_32x32x16 with the (BatchNorm-
 // folded) weights as the A operand, fragment-major in LDS, and 32 pixels as the 32 columns, so a lane owns ONE pixel:
 //   a: the 16 x 16 halo of the tile (8 column tiles, 2 per wave); B fragments are 16-byte global loads (8 channels of one
@@ -25,13 +26,14 @@ namespace kvq {
 typedef __attribute__((address_space(3))) void* bn_lds_t;
 typedef __attribute__((address_space(1))) const void* bn_gbl_t;
 
-constexpr int BN_T = 14, BN_HALO = 16;
+constexpr int BN_HALO = 16;
+__host__ __device__ constexpr int bn_tile(int stride) { return stride == 1 ? 14 : 7; }     // outputs per tile edge: halo (T - 1) s + 3 <= 16
 
 struct BneckParams {
   const uint16_t* x;
   uint16_t* out;
   const unsigned char* pack;
-  int B, T, H, W, tiles_y, tiles_x;
+  int B, T, H, W, Ho, Wo, tiles_y, tiles_x;      // input map H x W, output map Ho x Wo (= ceil(H / stride))
 };
 
 __host__ __device__ constexpr int bn_ks(int k) { return (k + 15) / 16; }
@@ -48,8 +50,10 @@ struct BnLayout {
   static constexpr int LDS_BYTES = OFF_TILE + BN_HALO * BN_HALO * CI * 2;
 };
 
-template <typename E, int CIN, int CI, int COUT, bool SC>
+template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE>
 __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) {
+  static_assert(STRIDE == 1 || (STRIDE == 2 && SC), "a strided block has a projection shortcut");
+  constexpr int BN_T = bn_tile(STRIDE);
   fp16_saturate_mode();
   using L = BnLayout<CIN, CI, COUT, SC>;
   using V8 = typename E::v8;
@@ -59,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   const int ntile = p.tiles_y * p.tiles_x;
   const int bt = blockIdx.x / ntile, tile = blockIdx.x - bt * ntile;
   const int b = bt / p.T, t = bt - b * p.T;
-  const int y0 = (tile / p.tiles_x) * BN_T, x0 = (tile % p.tiles_x) * BN_T;
-  const size_t frame = (size_t)p.H * p.W;
+  const int y0 = (tile / p.tiles_x) * BN_T, x0 = (tile % p.tiles_x) * BN_T;          // output coordinates
+  const size_t frame = (size_t)p.H * p.W, oframe = (size_t)p.Ho * p.Wo;
   const uint16_t* xb = p.x + (size_t)b * p.T * frame * CIN;
 
   // weights + biases -> LDS (LDS-DMA, 1 KB per wave-load)
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   V8 bx[NLOAD][L::KSA];
   auto load_tile = [&](int c2, V8 (&dst)[L::KSA], bool& inside, int& ap) {
     ap = (2 * wave + c2) * 32 + j;
-    const int yy = y0 - 1 + (ap >> 4), xx = x0 - 1 + (ap & 15);
+    const int yy = STRIDE * y0 - 1 + (ap >> 4), xx = STRIDE * x0 - 1 + (ap & 15);
     inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
     const uint16_t* px = xb + ((size_t)(inside ? yy : 0) * p.W + (inside ? xx : 0)) * CIN;
 #pragma unroll
@@ -118,13 +122,14 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
 
   // ---- conv_b, conv_c, shortcut on the 14 x 14 outputs: column tiles wave, wave + 4 ---------------------------------------
 #pragma unroll 1
-  for (int ct = wave; ct < (BN_T * BN_T + 31) / 32; ct += 4) {
+  for (int ct = wave; ct < (BN_T * BN_T + 31) / 32; ct += 4) {      // (stride 2: 49 outputs = 2 column tiles, waves 2 and 3 are done)
     const int op_raw = ct * 32 + j;
     const int op = op_raw < BN_T * BN_T ? op_raw : BN_T * BN_T - 1;
     const int oy = op / BN_T, ox = op - oy * BN_T;
     const int yy = y0 + oy, xx = x0 + ox;
-    const bool live = op_raw < BN_T * BN_T && yy < p.H && xx < p.W;
-    const size_t pix = ((size_t)t * p.H + (live ? yy : 0)) * p.W + (live ? xx : 0);
+    const bool live = op_raw < BN_T * BN_T && yy < p.Ho && xx < p.Wo;
+    const size_t pix = ((size_t)t * p.H + (live ? STRIDE * yy : 0)) * p.W + (live ? STRIDE * xx : 0);       // input pixel under it
+    const size_t opix = ((size_t)t * p.Ho + (live ? yy : 0)) * p.Wo + (live ? xx : 0);
     // shortcut operands first: their latency hides under conv_b
     V8 sx[SC ? L::KSS : 1];
     u32x2 idn[SC ? 1 : L::RT * 4];
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
       const int k0 = 16 * s + 8 * h;
       const int tap = k0 / CI, ci0 = k0 - tap * CI, dy = tap / 3, dx = tap - 3 * dy;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (k0 < 9 * CI) v = *reinterpret_cast<const u32x4*>(a_tile + ((oy + dy) * BN_HALO + ox + dx) * CI + ci0);
+      if (k0 < 9 * CI) v = *reinterpret_cast<const u32x4*>(a_tile + ((STRIDE * oy + dy) * BN_HALO + STRIDE * ox + dx) * CI + ci0);
       accb = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_B + s * 1024 + lane * 16), __builtin_bit_cast(V8, v), accb);
     }
     // bias + ReLU; accumulator order IS the k order of the packed conv_c weights
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
       }
       hb[s] = __builtin_bit_cast(V8, w);
     }
-    uint16_t* orow = p.out + ((size_t)b * p.T * frame + pix) * COUT;
+    uint16_t* orow = p.out + ((size_t)b * p.T * oframe + opix) * COUT;
 #pragma unroll
     for (int rt = 0; rt < L::RT; ++rt) {
       f32x16 acc;
@@ -205,10 +210,10 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   }
 }
 
-template <typename E, int CIN, int CI, int COUT, bool SC>
+template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE>
 static int launch_bneck(const BneckParams& p, hipStream_t st) {
   using L = BnLayout<CIN, CI, COUT, SC>;
-  auto k = fast_bottleneck_kernel<E, CIN, CI, COUT, SC>;
+  auto k = fast_bottleneck_kernel<E, CIN, CI, COUT, SC, STRIDE>;
   static bool attr_set = false;
   if (!attr_set) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
@@ -219,52 +224,59 @@ static int launch_bneck(const BneckParams& p, hipStream_t st) {
   return KVQ_OK;
 }
 
-template <int CIN, int CI, int COUT, bool SC>
+template <int CIN, int CI, int COUT, bool SC, int STRIDE = 1>
 static int launch_bneck_dt(const BneckParams& p, int dtype, hipStream_t st) {
-  return dtype == KVQ_DT_FP16 ? launch_bneck<Fp16, CIN, CI, COUT, SC>(p, st) : launch_bneck<Bf16, CIN, CI, COUT, SC>(p, st);
+  return dtype == KVQ_DT_FP16 ? launch_bneck<Fp16, CIN, CI, COUT, SC, STRIDE>(p, st) : launch_bneck<Bf16, CIN, CI, COUT, SC, STRIDE>(p, st);
 }
 
 // the supported (input, inner, output) channel triples: SlowFast-R50's fast pathway, res2 .. res4
-static int bneck_variant(int cin, int ci, int cout, int proj) {
-  if (cin == 8 && ci == 8 && cout == 32 && proj) return 1;
-  if (cin == 32 && ci == 8 && cout == 32 && !proj) return 2;
-  if (cin == 64 && ci == 16 && cout == 64 && !proj) return 3;
-  if (cin == 128 && ci == 32 && cout == 128 && !proj) return 4;
+static int bneck_variant(int cin, int ci, int cout, int proj, int stride) {
+  if (cin == 8 && ci == 8 && cout == 32 && proj && stride == 1) return 1;
+  if (cin == 32 && ci == 8 && cout == 32 && !proj && stride == 1) return 2;
+  if (cin == 64 && ci == 16 && cout == 64 && !proj && stride == 1) return 3;
+  if (cin == 128 && ci == 32 && cout == 128 && !proj && stride == 1) return 4;
+  if (cin == 32 && ci == 16 && cout == 64 && proj && stride == 2) return 5;
+  if (cin == 64 && ci == 32 && cout == 128 && proj && stride == 2) return 6;
   return 0;
 }
 
 }  // namespace kvq
 
-extern "C" size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection) {
+extern "C" size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection, int stride) {
   using namespace kvq;
-  switch (bneck_variant(cin, ci, cout, projection)) {
+  switch (bneck_variant(cin, ci, cout, projection, stride)) {
     case 1: return BnLayout<8, 8, 32, true>::PACK_BYTES;
     case 2: return BnLayout<32, 8, 32, false>::PACK_BYTES;
     case 3: return BnLayout<64, 16, 64, false>::PACK_BYTES;
     case 4: return BnLayout<128, 32, 128, false>::PACK_BYTES;
+    case 5: return BnLayout<32, 16, 64, true>::PACK_BYTES;
+    case 6: return BnLayout<64, 32, 128, true>::PACK_BYTES;
     default: return 0;
   }
 }
 
-extern "C" int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection,
+extern "C" int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection, int stride,
                                    const void* pack, int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(x && dims4 && pack && out, KVQ_ERR_NULL, "kvq_fast_bottleneck: NULL pointer");
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_fast_bottleneck: dtype %d", dtype);
   const int B = dims4[0], T = dims4[1], H = dims4[2], W = dims4[3];
-  KVQ_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && (long)B * T * ceil_div(H, BN_T) * ceil_div(W, BN_T) < (1L << 31), KVQ_ERR_SHAPE,
-              "kvq_fast_bottleneck: bad shape (%d,%d,%d,%d)", B, T, H, W);
-  const int var = bneck_variant(cin, ci, cout, projection);
-  KVQ_REQUIRE(var, KVQ_ERR_UNSUPPORTED, "kvq_fast_bottleneck: channels (%d -> %d -> %d, projection %d) not in the built set", cin, ci,
-              cout, projection);
+  KVQ_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && (long)B * T * ceil_div(H, 7) * ceil_div(W, 7) < (1L << 31),
+              KVQ_ERR_SHAPE, "kvq_fast_bottleneck: bad shape (%d,%d,%d,%d) stride %d", B, T, H, W, stride);
+  const int var = bneck_variant(cin, ci, cout, projection, stride);
+  KVQ_REQUIRE(var, KVQ_ERR_UNSUPPORTED, "kvq_fast_bottleneck: channels (%d -> %d -> %d, projection %d, stride %d) not in the built set", cin,
+              ci, cout, projection, stride);
   KVQ_REQUIRE(((size_t)pack & 15) == 0 && ((size_t)x & 15) == 0 && ((size_t)out & 7) == 0, KVQ_ERR_SHAPE,
               "kvq_fast_bottleneck: x / pack must be 16-byte aligned, out 8-byte");
-  BneckParams p{x, out, (const unsigned char*)pack, B, T, H, W, ceil_div(H, BN_T), ceil_div(W, BN_T)};
+  const int Ho = ceil_div(H, stride), Wo = ceil_div(W, stride), tile = bn_tile(stride);      // (H + 2 - 3) / s + 1
+  BneckParams p{x, out, (const unsigned char*)pack, B, T, H, W, Ho, Wo, ceil_div(Ho, tile), ceil_div(Wo, tile)};
   hipStream_t st = (hipStream_t)stream;
   switch (var) {
     case 1: return launch_bneck_dt<8, 8, 32, true>(p, dtype, st);
     case 2: return launch_bneck_dt<32, 8, 32, false>(p, dtype, st);
     case 3: return launch_bneck_dt<64, 16, 64, false>(p, dtype, st);
-    default: return launch_bneck_dt<128, 32, 128, false>(p, dtype, st);
+    case 4: return launch_bneck_dt<128, 32, 128, false>(p, dtype, st);
+    case 5: return launch_bneck_dt<32, 16, 64, true, 2>(p, dtype, st);
+    default: return launch_bneck_dt<64, 32, 128, true, 2>(p, dtype, st);
   }
 }

@@ -254,9 +254,13 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
       }
       case KVQ_NET_BOTTLENECK: {
         NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && d.kind == KVQ_NET_T_ACT16 && p.w, "kvq_convnet_create: op %d (bottleneck) operand kinds", i);
-        NET_REQUIRE(d.B == s.B && d.D == s.D && d.H == s.H && d.W == s.W && d.C == p.cout, "kvq_convnet_create: op %d (bottleneck) output shape", i);
-        NET_REQUIRE(kvq_fast_bottleneck_pack_bytes(s.C, p.kpad, p.cout, p.n_index) > 0,
-                    "kvq_convnet_create: op %d (bottleneck) channels %d -> %d -> %d (projection %d) not built", i, s.C, p.kpad, p.cout, p.n_index);
+        const int bs = p.stride3[1];
+        NET_REQUIRE(p.stride3[0] == 1 && p.stride3[2] == bs && (bs == 1 || bs == 2), "kvq_convnet_create: op %d (bottleneck) stride", i);
+        NET_REQUIRE(d.B == s.B && d.D == s.D && d.H == (s.H + bs - 1) / bs && d.W == (s.W + bs - 1) / bs && d.C == p.cout,
+                    "kvq_convnet_create: op %d (bottleneck) output shape", i);
+        NET_REQUIRE(kvq_fast_bottleneck_pack_bytes(s.C, p.kpad, p.cout, p.n_index, bs) > 0,
+                    "kvq_convnet_create: op %d (bottleneck) channels %d -> %d -> %d (projection %d, stride %d) not built", i, s.C, p.kpad, p.cout,
+                    p.n_index, bs);
         break;
       }
       default:
@@ -470,7 +474,7 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
       }
       case KVQ_NET_BOTTLENECK: {
         const int32_t dims4[4] = {s.B, s.D, s.H, s.W};
-        KVQ_TRY(kvq_fast_bottleneck((const uint16_t*)ptr_of(p.src), dims4, s.C, p.kpad, p.cout, p.n_index, p.w, net->dtype,
+        KVQ_TRY(kvq_fast_bottleneck((const uint16_t*)ptr_of(p.src), dims4, s.C, p.kpad, p.cout, p.n_index, p.stride3[1], p.w, net->dtype,
                                     (uint16_t*)ptr_of(p.dst), st));
         break;
       }

@@ -250,16 +250,16 @@ def pool_nd(x: torch.Tensor, kernel, stride, pad, is_max: bool):
     return out
 
 
-def fast_bottleneck(x: torch.Tensor, pack: torch.Tensor, ci: int, cout: int, projection: bool):
+def fast_bottleneck(x: torch.Tensor, pack: torch.Tensor, ci: int, cout: int, projection: bool, stride: int = 1):
     """One residual block of SlowFast's fast pathway in one launch (csrc/bottleneck.hip).  x (B,T,H,W,cin) channels-last 16-bit,
-    ``pack`` the uint8 image described in include/kvq_hip.h -> (B,T,H,W,cout)."""
+    ``pack`` the uint8 image described in include/kvq_hip.h -> (B,T,ceil(H/stride),ceil(W/stride),cout)."""
     _need_gpu(x, pack)
     assert x.dtype in HALF_TYPES and x.is_contiguous() and x.dim() == 5 and pack.dtype == torch.uint8 and pack.is_contiguous()
     B, T, H, W, cin = x.shape
-    assert pack.numel() == lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(projection)) > 0, "channel triple not built / wrong image size"
-    out = torch.empty(B, T, H, W, cout, dtype=x.dtype, device=x.device)
-    check(lib().kvq_fast_bottleneck(ptr(x), _i32x((B, T, H, W)), cin, ci, cout, int(projection), ptr(pack), dtype_code(x.dtype), ptr(out),
-                                    stream_of(x)), "kvq_fast_bottleneck")
+    assert pack.numel() == lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(projection), stride) > 0, "block not built / wrong image size"
+    out = torch.empty(B, T, -(-H // stride), -(-W // stride), cout, dtype=x.dtype, device=x.device)
+    check(lib().kvq_fast_bottleneck(ptr(x), _i32x((B, T, H, W)), cin, ci, cout, int(projection), stride, ptr(pack), dtype_code(x.dtype),
+                                    ptr(out), stream_of(x)), "kvq_fast_bottleneck")
     return out
 
 

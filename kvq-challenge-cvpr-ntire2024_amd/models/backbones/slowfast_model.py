@@ -131,7 +131,7 @@ def _fragments(w, k_real, row_tiles, accumulator_order=False):
     return wp[rows.expand(row_tiles, ks, 64, 8), kk[None].expand(row_tiles, ks, 64, 8)].contiguous()
 
 
-def pack_fast_bottleneck(wa, ba, wb, bb, wc, bc, cin, ws=None, bs=None):
+def pack_fast_bottleneck(wa, ba, wb, bb, wc, bc, cin, ws=None, bs=None, stride=1):
     """The packed image of ``kvq_fast_bottleneck`` (layout: include/kvq_hip.h) from BatchNorm-folded 16-bit weights with
     (kd, kh, kw, c)-ordered columns — conv_a [ci][>= 3 cin], conv_b [ci][>= 9 ci], conv_c [cout][>= ci], optional projection
     [cout][>= cin] — and fp32 biases."""
@@ -144,7 +144,7 @@ def pack_fast_bottleneck(wa, ba, wb, bb, wc, bc, cin, ws=None, bs=None):
     bias = torch.zeros(-(-(64 + cout) * 4 // 1024) * 256, dtype=torch.float32, device=wa.device)
     bias[:ci], bias[32:32 + ci], bias[64:64 + cout] = ba, bb, bias_c
     blob = torch.cat([t.reshape(-1).view(torch.uint8) for t in parts] + [bias.view(torch.uint8)]).contiguous()
-    need = _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(ws is not None))
+    need = _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(ws is not None), stride)
     assert need == blob.numel(), (cin, ci, cout, need, blob.numel())
     return blob
 
@@ -201,12 +201,13 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         self._wcache = (sig, out)
         return out
 
-    def _bottleneck_pack(self, Wt, pre, projection):
+    def _bottleneck_pack(self, Wt, pre, projection, stride):
         key = pre + "/bneck"
         if key not in Wt:
             cin = self.table[pre + ".branch2#a"][0][1]
             proj = Wt[pre + "#1"][:2] if projection else (None, None)
-            Wt[key] = pack_fast_bottleneck(*Wt[pre + ".branch2#a"][:2], *Wt[pre + ".branch2#b"][:2], *Wt[pre + ".branch2#c"][:2], cin, *proj)
+            Wt[key] = pack_fast_bottleneck(*Wt[pre + ".branch2#a"][:2], *Wt[pre + ".branch2#b"][:2], *Wt[pre + ".branch2#c"][:2], cin, *proj,
+                                           stride=stride)
         return Wt[key]
 
     # ---- conv on channels-last 16-bit (B,D,H,W,C) -----------------------------------------------------
@@ -365,14 +366,16 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
                     if pi == 1 and FUSE_FAST:                # the whole residual block in one launch where the kernel is built
                         cin, ci, cout = tens[x][4], Wt[pre + ".branch2#a"][0].shape[0], Wt[pre + ".branch2#c"][0].shape[0]
                         proj = int(bi == 0)
-                        if tuple(Wt[pre + ".branch2#b"][3]) == (1, 1, 1) and _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, proj):
-                            blob = self._bottleneck_pack(Wt, pre, proj)
+                        sb = tuple(Wt[pre + ".branch2#b"][3])
+                        if sb[0] == 1 and sb[1] == sb[2] and _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, proj, sb[1]):
+                            blob = self._bottleneck_pack(Wt, pre, proj, sb[1])
                             keep.append(blob)
                             bb_, d_, h_, w_ = tens[x][:4]
-                            y = tensor(bb_, d_, h_, w_, cout)
-                            op(_abi.NET_BOTTLENECK, x, y, cout=cout, kpad=ci, n_index=proj, w=blob, name=pre.replace(fe, "") + " (fused block)")
-                            m_ = bb_ * d_ * h_ * w_
-                            descs[-1]["flops"] = 2.0 * m_ * (3 * cin * ci + 9 * ci * ci + ci * cout + (cin * cout if proj else 0))
+                            ho_, wo_ = -(-h_ // sb[1]), -(-w_ // sb[1])
+                            y = tensor(bb_, d_, ho_, wo_, cout)
+                            op(_abi.NET_BOTTLENECK, x, y, st=sb, cout=cout, kpad=ci, n_index=proj, w=blob, name=pre.replace(fe, "") + " (fused block)")
+                            m_in, m_ = bb_ * d_ * h_ * w_, bb_ * d_ * ho_ * wo_
+                            descs[-1]["flops"] = 2.0 * (m_in * 3 * cin * ci + m_ * (9 * ci * ci + ci * cout + (cin * cout if proj else 0)))
                             descs[-1]["M"] = m_
                             x = y
                             continue

@@ -133,25 +133,28 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     assert rc != 0 and b"pool" in _abi.lib().kvq_last_error()
 
 
-def _ref_fast_block(x, wa, ba, wb, bb, wc, bc, ws, bs, half):
+def _ref_fast_block(x, wa, ba, wb, bb, wc, bc, ws, bs, half, stride=1):
     """fp32 torch restatement of one fast-pathway residual block with the 16-bit rounding points of the HIP path"""
     import torch.nn.functional as F
     xf = x.float().permute(0, 4, 1, 2, 3)
     ci, cin, cout = wa.shape[0], x.shape[-1], wc.shape[0]
     a = F.relu(F.conv3d(xf, wa.float()[:, :3 * cin].reshape(ci, 3, 1, 1, cin).permute(0, 4, 1, 2, 3), ba, padding=(1, 0, 0))).to(half).float()
-    b = F.relu(F.conv3d(a, wb.float()[:, :9 * ci].reshape(ci, 1, 3, 3, ci).permute(0, 4, 1, 2, 3), bb, padding=(0, 1, 1))).to(half).float()
+    b = F.relu(F.conv3d(a, wb.float()[:, :9 * ci].reshape(ci, 1, 3, 3, ci).permute(0, 4, 1, 2, 3), bb, stride=(1, stride, stride),
+                        padding=(0, 1, 1))).to(half).float()
     c = F.conv3d(b, wc.float()[:, :ci].reshape(cout, ci, 1, 1, 1), bc)
-    sc = F.conv3d(xf, ws.float()[:, :cin].reshape(cout, cin, 1, 1, 1), bs) if ws is not None else xf
+    sc = F.conv3d(xf, ws.float()[:, :cin].reshape(cout, cin, 1, 1, 1), bs, stride=(1, stride, stride)) if ws is not None else xf
     return F.relu(c + sc).permute(0, 2, 3, 4, 1)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,ci,cout,proj", [(8, 8, 32, True), (32, 8, 32, False), (64, 16, 64, False), (128, 32, 128, False)])
+@pytest.mark.parametrize("cin,ci,cout,proj,stride", [(8, 8, 32, True, 1), (32, 8, 32, False, 1), (64, 16, 64, False, 1), (128, 32, 128, False, 1),
+                                                     (32, 16, 64, True, 2), (64, 32, 128, True, 2)])
 @pytest.mark.parametrize("half", [torch.float16, torch.bfloat16])
-def test_fast_bottleneck_kernel_vs_fp32_convs(cin, ci, cout, proj, half):
+def test_fast_bottleneck_kernel_vs_fp32_convs(cin, ci, cout, proj, stride, half):
     """``kvq_fast_bottleneck`` (conv_a 3x1x1 -> conv_b 1x3x3 -> conv_c 1x1x1 + shortcut, one launch) against torch conv3d in fp32
-    with the same 16-bit rounding of the two inner activations: maps that are not multiples of the 14-pixel tile, temporal and
-    spatial borders, every built channel triple, the projection shortcut; unsupported triples are refused."""
+    with the same 16-bit rounding of the two inner activations: maps that are not multiples of the tile (odd sizes under stride 2),
+    temporal and spatial borders, every built block (stride-2 first blocks with their strided projection included); unsupported
+    blocks are refused."""
     from kvq_amd import kernels
     from kvq_amd.models.backbones.slowfast_model import pack_fast_bottleneck
     g = torch.Generator().manual_seed(cin * 1000 + ci)
@@ -166,16 +169,17 @@ def test_fast_bottleneck_kernel_vs_fp32_convs(cin, ci, cout, proj, half):
     wa, wb, wc = wgt(ci, 3 * cin), wgt(ci, 9 * ci), wgt(cout, ci)
     ba, bb, bc = (torch.randn(n, generator=g) * 0.2 for n in (ci, ci, cout))
     ws, bs = (wgt(cout, cin), torch.randn(cout, generator=g) * 0.2) if proj else (None, None)
-    ref = _ref_fast_block(x, wa, ba, wb, bb, wc, bc, ws, bs, half)
+    ref = _ref_fast_block(x, wa, ba, wb, bb, wc, bc, ws, bs, half, stride)
     dev = lambda t: None if t is None else t.cuda()      # noqa: E731
-    pack = pack_fast_bottleneck(dev(wa), dev(ba), dev(wb), dev(bb), dev(wc), dev(bc), cin, dev(ws), dev(bs))
-    got = kernels.fast_bottleneck(x.cuda(), pack, ci, cout, proj).float().cpu()
+    pack = pack_fast_bottleneck(dev(wa), dev(ba), dev(wb), dev(bb), dev(wc), dev(bc), cin, dev(ws), dev(bs), stride=stride)
+    got = kernels.fast_bottleneck(x.cuda(), pack, ci, cout, proj, stride).float().cpu()
+    assert got.shape == ref.shape
     tol = 2e-2 if half == torch.bfloat16 else 3e-3
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, err
     assert (got - ref).norm().item() / ref.norm().item() < tol / 4
     with pytest.raises(AssertionError):
-        kernels.fast_bottleneck(x.cuda(), pack, ci + 8, cout, proj)
+        kernels.fast_bottleneck(x.cuda(), pack, ci + 8, cout, proj, stride)
 
 
 @pytest.mark.gpu
@@ -237,7 +241,8 @@ def test_two_lane_plan_equals_one_lane_and_profile_reads_every_op():
     assert torch.equal(after[0], ref[0][0]) and torch.equal(after[1], ref[0][1])
     convs = [r for r in rows if r["kind"] == "conv"]
     fused = [r for r in rows if r["kind"] == "bottleneck"]
-    assert all(r["ms"] > 0 for r in rows) and len(convs) + 3 * len(fused) + 1 == len(M.conv_table()) - 2   # every conv but the two stems (one fused block also holds a projection)
+    n_proj = sum(1 for r in fused if r["name"].split(" ")[0].endswith("res_blocks.0"))
+    assert all(r["ms"] > 0 for r in rows) and len(convs) + 3 * len(fused) + n_proj == len(M.conv_table()) - 2   # every conv but the two stems
     assert any(r["name"].endswith("multipathway_fusion") for r in convs)
 
 
