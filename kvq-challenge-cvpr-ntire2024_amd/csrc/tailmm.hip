@@ -118,8 +118,19 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
 
 // DBG (diagnostic builds of the same kernel, tools/tail_time.py): 1 = no weight stream (no LDS-DMA, no vmcnt waits: stale ring
 // contents), 2 = no MFMAs, 3 = neither, 4 = no fragment reads
-template <typename E, bool EMIT, int DBG = 0>
+// VR (default; KVQ_TAILMM_VR=0 selects the LDS ring described above): a wave's weight fragments are PRIVATE to it, so the LDS ring was
+// only a latency buffer — and plain VGPR loads stream as fast as LDS-DMA (tools/ubench/l2_stream.hip).  The fragments go global ->
+// VGPR and are the MFMA A operand as they arrive: a REGISTER ring of 24 fragments per wave, 20 in flight (80 KB per CU instead of
+// 48), no fragment reads from LDS (648 fewer ds_read_b128 per wave).  Slots are compile-time: every phase consumes a multiple of 24
+// fragments, so phase-local position q lives in slot q % 24.  Plain loads, not inline asm: the compiler's own vmcnt bookkeeping is
+// exact in the unrolled phases (s_waitcnt vmcnt(19 / 18) in the steady state), and an inline-asm load is unsafe under this register
+// pressure (the allocator splits the live range of a value it believes ready; the late data lands in a register handed on).
+// 79 -> 73 us (with the next norm1), 73 -> 64 us (without); bit-identical results.
+constexpr int VR_R = 24, VR_PF = 20;
+template <typename E, bool EMIT, int DBG = 0, bool VR = false>
 __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
+  static_assert(!VR || DBG == 0, "the ablation builds are of the LDS-ring kernel");
+  static_assert(MM_NF_PROJ % VR_R == 0 && MM_NF_FC1 % VR_R == 0 && MM_NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
@@ -146,6 +157,14 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   // (past the end of the list the LAST fragment is requested again, into a slot nobody reads any more: the vmcnt arithmetic
   // stays uniform and the loop bodies stay branch-free)
   int issued = 0;
+  typename E::v8 wr[VR ? VR_R : 1];
+  auto vload = [&](int slot) __attribute__((always_inline)) {        // list position `issued` -> register slot (compile-time after unrolling)
+    const int src = issued < MM_NF ? issued : MM_NF - 1;
+    // a plain load: the compiler counts vmcnt itself (an inline-asm load is unsafe here — under this register pressure the
+    // allocator splits the live range of a value it believes ready, and the late data lands in a register that was handed on)
+    wr[slot] = *reinterpret_cast<const typename E::v8*>(wsrc + (size_t)src * 1024);
+    ++issued;
+  };
   auto issue = [&](int n) __attribute__((always_inline)) {
     if (DBG & 1) { issued += n; return; }
 #pragma unroll
@@ -190,7 +209,12 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     for (int q = wave; q < (MM_PRM_FLOATS * 4) / 1024; q += 4)      // b1 | g2 | b2n | proj_b | b2: 12 KB
       __builtin_amdgcn_global_load_lds((mm_gbl_t)((const unsigned char*)gprm + q * 1024 + lane * 16), (mm_lds_t)(lds + MM_OFF_PRM + q * 1024), 16, 0, 0);
   }
-  issue(3); issue(3); issue(3); issue(3);            // 12 fragments of the weight list in flight from here on
+  if (VR) {
+#pragma unroll
+    for (int q = 0; q < VR_PF; ++q) vload(q);        // 20 fragments of the weight list in flight from here on
+  } else {
+    issue(3); issue(3); issue(3); issue(3);          // 12 fragments of the weight list in flight from here on
+  }
   // ---- accumulators = x + proj bias: tile (ft, tt), register r <-> feature 96 wave + 32 ft + (r&3) + 8 (r>>2) + 4 half ----
   // all 24 row pieces of a lane are requested before anything waits (they queue behind the DMA requests above: one drain)
   f32x16 acc[3][2];
@@ -291,6 +315,33 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
       }
       if (more) cons += NR;
     };
+    if (VR) {
+      // activation fragments of body s+1 are read under the MFMAs of body s; the weight fragments ARE the registers wr[.]: list
+      // position (phase-local) q lives in slot q % 24, the body's own NR fragments are waited for (20 - NR younger requests stay in
+      // flight) and NR new ones requested into the slots of the previous body
+      auto rdb = [&](int buf, int ks, int q) __attribute__((always_inline)) {
+        const int k = q >> 1, tt = q & 1;
+        b[buf][k][tt] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * 2 + tt) * 1024 + lane * 16);
+      };
+      auto body_vr = [&](int s, bool more) __attribute__((always_inline)) {
+        const int u = (s / KU) & 1, base = (s / KU) * NR;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const int k = m / (2 * NA), t = (m % (2 * NA)) >> 1, tt = m & 1;
+          mm(t, tt, wr[(base + k * NA + t) % VR_R], b[u][k][tt]);
+          if (more && m < 2 * KU) rdb(u ^ 1, s + KU, m);
+          if (m >= NM - NR) vload((base + VR_PF + (m - (NM - NR))) % VR_R);
+          between(s * 2 * NA + m);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < 2 * KU; ++q) rdb(0, 0, q);
+#pragma unroll
+      for (int s = 0; s + KU < nk; s += KU) body_vr(s, true);
+      body_vr(nk - KU, false);
+      return;
+    }
     landed();
 #pragma unroll
     for (int q = 0; q < NRD; ++q) rd1(0, 0, q);
@@ -497,6 +548,22 @@ static int launch_mm(const TailParams& p, hipStream_t st) {
     if (dbg == 2) return launch_mm_dbg<E, 2>(p, st);
     if (dbg == 3) return launch_mm_dbg<E, 3>(p, st);
     if (dbg == 4) return launch_mm_dbg<E, 4>(p, st);
+  }
+  static const int vr = getenv("KVQ_TAILMM_VR") ? atoi(getenv("KVQ_TAILMM_VR")) : 1;
+  if (vr) {
+    if (p.next_ln) {
+      auto k = block_tailmm_kernel<E, true, 0, true>;
+      static bool set = false;
+      if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
+      hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
+    } else {
+      auto k = block_tailmm_kernel<E, false, 0, true>;
+      static bool set = false;
+      if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
+      hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
+    }
+    KVQ_CHECK_LAUNCH("block_tailmm_kernel(vr)");
+    return KVQ_OK;
   }
   if (p.next_ln) {
     auto k = block_tailmm_kernel<E, true>;

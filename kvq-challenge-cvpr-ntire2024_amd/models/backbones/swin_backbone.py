@@ -508,7 +508,7 @@ class SwinTransformer3D(nn.Module):
                 if cm == 12:     # C = 384: csrc/tailmm.hip (feature-sliced GEMM chain) unless KVQ_TAILMM=0 -> csrc/tail16.hip
                     emit = str(bool(r.variant % 10)).lower()
                     sym = (f"block_tail16_kernel<{ename}, 24, {emit}>" if os.environ.get("KVQ_TAILMM", "1") == "0"
-                           else f"block_tailmm_kernel<{ename}, {emit}, 0>")
+                           else f"block_tailmm_kernel<{ename}, {emit}, 0, {'false' if os.environ.get('KVQ_TAILMM_VR', '1') == '0' else 'true'}>")
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
