@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 15
+#define KVQ_ABI_VERSION 16
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -287,7 +287,7 @@ typedef struct {
   float* x;                    /* fp32 [n_batch*out_rows][C] residual stream, updated in place           */
   const int32_t* scatter_map;  /* window row -> token within the batch element, <0 = padding; NULL = id. */
   int32_t map_rows, out_rows;  /* rows per batch element in the map / in x                               */
-  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192}; hidden % 32 == 0  */
+  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192} (hidden % 64 == 0), 384 or 512 (hidden = 4 C) */
   const void* pack;            /* kvq_block_tail_pack image                                              */
   const float* next_norm_w;    /* the following four: only with next_ln != NULL                          */
   const float* next_norm_b;
@@ -296,6 +296,10 @@ typedef struct {
   int32_t next_rows;
   float eps;                   /* 1e-5                                                                   */
   int32_t dtype;               /* KvqDtype of attn, the packed weights and next_ln                        */
+  const int32_t* attn_gather;  /* optional, [out_rows]: token -> window row of THIS block's partition (the inverse of scatter_map over
+                                  the real tokens).  When set the launch walks the n_batch*out_rows TOKENS and fetches each one's
+                                  attention row through it, instead of walking the M window rows: padded geometries (Swin-B at
+                                  256x256: 1.2x .. 3x the rows) then do no work on padding rows.  scatter_map is not read. */
 } KvqBlockTailArgs;
 int kvq_block_tail_supported(int C, int hidden);                 /* 1 / 0 */
 size_t kvq_block_tail_pack_bytes(int C, int hidden);             /* 0 when unsupported */

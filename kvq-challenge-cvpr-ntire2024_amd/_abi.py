@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 def dtype_code(dt) -> int:
@@ -99,7 +99,7 @@ class KvqBlockTailArgs(C.Structure):
     _fields_ = [("attn", p_void), ("x", p_void), ("scatter_map", p_void), ("map_rows", C.c_int32),
                 ("out_rows", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("pack", p_void),
                 ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void),
-                ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
+                ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32), ("attn_gather", p_void)]
 
 
 class KvqPatchEmbedArgs(C.Structure):

@@ -26,7 +26,8 @@ struct StageGeom {
   int Dp, Hp, Wp, nW, N, Lp;
   bool shifted_any;
   int32_t* d_src[2];  // [Lp] source token or -1
-  int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row); only when Lp == L (no padding), else nullptr
+  int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row).  A bijection — the next block's norm1 rows can be EMITTED through it —
+                      // only when Lp == L (no padding)
   int32_t* d_tok[2];  // [nW*N][2]
   int32_t* d_merge;   // [L_next][4] or nullptr
   int Dn, Hn, Wn;     // dims after the merge
@@ -132,9 +133,10 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
   int rc = upload(pl, src, &g.d_src[par]);
   if (rc) return rc;
   g.d_dst[par] = nullptr;
-  if (g.Lp == g.L) {
-    std::vector<int32_t> dst((size_t)g.L);
-    for (int i = 0; i < g.Lp; ++i) dst[src[i]] = i;
+  {
+    std::vector<int32_t> dst((size_t)g.L, 0);
+    for (int i = 0; i < g.Lp; ++i)
+      if (src[i] >= 0) dst[src[i]] = i;
     rc = upload(pl, dst, &g.d_dst[par]);
     if (rc) return rc;
   }
@@ -430,7 +432,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     ea.pd = cfg.patch[0]; ea.ph = cfg.patch[1]; ea.pw = cfg.patch[2]; ea.embed_dim = E; ea.pack = w->embed_pack;
     ea.has_norm = w->embed_ln_w ? 1 : 0; ea.out = xa; ea.eps = 1e-5f; ea.dtype = pl->dtype;
     const StageGeom& g0 = pl->st[0];
-    if (g0.d_dst[0] && w->blocks[0].norm1_w && w->blocks[0].norm1_b) {     // + norm1 / partition of the first block
+    if (g0.Lp == g0.L && g0.d_dst[0] && w->blocks[0].norm1_w && w->blocks[0].norm1_b) {     // + norm1 / partition of the first block
       ea.next_norm_w = w->blocks[0].norm1_w; ea.next_norm_b = w->blocks[0].norm1_b; ea.next_dst = g0.d_dst[0];
       ea.next_ln = bln; ea.next_rows = g0.Lp;
       first_ln1_ready = true;
@@ -500,7 +502,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         ta.attn = bo; ta.x = cur; ta.scatter_map = g.d_src[par]; ta.map_rows = g.Lp; ta.out_rows = g.L;
         ta.M = M; ta.C = C; ta.hidden = hidden; ta.pack = bw.tail_pack; ta.eps = 1e-5f; ta.dtype = pl->dtype;
         const int npar = ((b + 1) & 1) && g.shifted_any ? 1 : 0;
-        if (b + 1 < g.depth && g.d_dst[npar]) {
+        if (g.Lp != g.L) ta.attn_gather = g.d_dst[par];      // padded windows: walk the tokens, not the window rows
+        if (b + 1 < g.depth && g.Lp == g.L && g.d_dst[npar]) {
           const KvqSwinBlockW& nb = w->blocks[blk + 1];
           KVQ_REQUIRE(nb.norm1_w && nb.norm1_b, KVQ_ERR_NULL, "kvq_swin3d_forward: block %d norm1 missing", blk + 1);
           ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = g.d_dst[npar]; ta.next_ln = bln;

@@ -155,18 +155,23 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + q * 1024 + lane * 16),
                                        (lds_ptr_t)(lds + NST * SLOT + q * 1024), 16, 0, 0);
   }
-  // this lane's token
+  // this lane's token: row = a window row (through `map` to its token) or, with `gather`, a token (through it to its window row)
   const long row = (long)blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
-  const long rc = row < p.M ? row : p.M - 1;
+  const long nrows = p.gather ? p.n_tok : p.M;
+  long rc = row < nrows ? row : nrows - 1;
   int tb, tloc;
-  if (p.map) {
+  if (p.gather) {
+    tb = (int)(rc / p.out_rows);
+    tloc = (int)(rc - (long)tb * p.out_rows);
+    rc = (long)tb * p.map_rows + p.gather[tloc];           // the attention row of this token
+  } else if (p.map) {
     tb = (int)(rc / p.map_rows);
     tloc = p.map[rc - (long)tb * p.map_rows];
   } else {
     tb = (int)(rc / p.out_rows);
     tloc = (int)(rc - (long)tb * p.out_rows);
   }
-  const bool live = row < p.M && tloc >= 0;
+  const bool live = row < nrows && tloc >= 0;
   tloc = tloc < 0 ? 0 : tloc;
   const long orig = (long)tb * p.out_rows + tloc;
   V8 bx[KS];
@@ -433,7 +438,7 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
   const size_t lds = (size_t)tail_ring(C, NW) * tail_slot_bytes(C) +
                      ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
   KVQ_REQUIRE(lds <= (size_t)163840 / tail_bpc(C, NW), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
-  dim3 grid((unsigned)ceil_div(p.M, 32 * NW)), block(64 * NW);
+  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, 32 * NW)), block(64 * NW);
   if (p.next_ln) {
     auto k = block_tail_kernel<E, CM, NW, true>;
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -478,6 +483,7 @@ extern "C" int kvq_block_tail_supported(int C, int hidden) {
   // hidden/32 even and >= 4: the MLP pipeline rotates two accumulators
   static const bool wide = !(getenv("KVQ_TAIL16") && atoi(getenv("KVQ_TAIL16")) == 0);   // C = 384: csrc/tail16.hip / tailmm.hip
   if (wide && kvq::tail16_supported(C, hidden)) return 1;
+  if (wide && C == 512 && use_tailmm(C, hidden)) return 1;                                // stage 2 of Swin-B: csrc/tailmm.hip, CF = 4
   return (C == 96 || C == 128 || C == 192) && hidden % 64 == 0 && hidden >= 128 ? 1 : 0;
 }
 
@@ -525,6 +531,11 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
   p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;
+  // (the KVQ_TAILMM=0 launch of C = 384 has no token walk: it keeps walking the window rows through scatter_map)
+  if (a->attn_gather && !(tail16_supported(a->C, a->hidden) && !use_tailmm(a->C, a->hidden))) {
+    KVQ_REQUIRE(a->map_rows > 0 && a->M % a->map_rows == 0, KVQ_ERR_SHAPE, "kvq_block_tail: attn_gather needs M = n_batch * map_rows");
+    p.gather = a->attn_gather; p.n_tok = a->M / a->map_rows * a->out_rows; p.map = nullptr;
+  }
   if (use_tailmm(a->C, a->hidden)) return tailmm_launch(p, a->C, a->dtype, (hipStream_t)stream);
   if (tail16_supported(a->C, a->hidden)) return tail16_launch(p, a->C, a->dtype, (hipStream_t)stream);
   return a->dtype == KVQ_DT_FP16 ? launch_tail_e<Fp16>(p, a->C, (hipStream_t)stream)

@@ -9,6 +9,8 @@ struct TailParams {
   const uint16_t* attn;      // [M][C] 16-bit, window order
   float* x;                  // [n_batch*out_rows][C] fp32, in place
   const int32_t* map;        // window row -> token of the batch element (or <0 = padding); NULL = identity
+  const int32_t* gather;     // token -> window row (attn_gather): the launch walks n_tok tokens instead of M window rows
+  int n_tok;
   int map_rows, out_rows, M, hidden;
   const unsigned char* pack; // kvq_block_tail_pack image
   const float* nn_w;         // next block's norm1 (EMIT)

@@ -1,4 +1,5 @@
-// The fused post-attention launch for WIDE rows (C = 384: stage 2 of Swin-T/S) as a register-blocked GEMM chain on
+// The fused post-attention launch for WIDE rows (C = 384: stage 2 of Swin-T/S; C = 512: stage 2 of Swin-B, template CF = 4, numbers
+// below are for C = 384) as a register-blocked GEMM chain on
 // v_mfma_f32_32x32x16 — the replacement of tail16.hip's token-per-lane 16x16x32 design.
 //
 // Same computation (swin_backbone.py:479-516): x += proj(attn) (window-reverse / roll-back / crop through the row map);
@@ -34,34 +35,50 @@ namespace kvq {
 typedef __attribute__((address_space(3))) void* mm_lds_t;
 typedef __attribute__((address_space(1))) const void* mm_gbl_t;
 
-constexpr int MM_C = 384, MM_H = 1536, MM_TOK = 64;
-constexpr int MM_HC = 256, MM_NCH = MM_H / MM_HC;            // hidden chunk, chunks
-constexpr int MM_KS_C = MM_C / 16, MM_KS_H = MM_HC / 16;     // 24 k-steps over C, 16 over a hidden chunk
-constexpr int MM_NF_PROJ = MM_KS_C * 3, MM_NF_FC1 = MM_KS_C * 2, MM_NF_FC2 = MM_KS_H * 3;
-constexpr int MM_NF = MM_NF_PROJ + MM_NCH * (MM_NF_FC1 + MM_NF_FC2);     // 648 fragments per wave
-constexpr int MM_RING = 16, MM_PF = 12;                      // ring slots (1 KB) per wave, fragments in flight
-constexpr int MM_OFF_X = 0;                                  // [24 k-steps][2 token tiles][64 lanes][16 B] = 48 KB
-constexpr int MM_OFF_G = MM_OFF_X + MM_KS_C * 2 * 1024;      // [16][2][64][16 B] = 32 KB
-constexpr int MM_OFF_RING = MM_OFF_G + MM_KS_H * 2 * 1024;   // 4 waves x 16 KB
-constexpr int MM_OFF_PRM = MM_OFF_RING + 4 * MM_RING * 1024; // b1[1536] g2[384] b2n[384] proj_b[384] b2[384] fp32 = 12 KB
-constexpr int MM_PRM_FLOATS = MM_H + 4 * MM_C;
-constexpr int MM_OFF_RED = MM_OFF_PRM + MM_PRM_FLOATS * 4;   // [4 waves][64 tokens] fp32
-constexpr int MM_LDS = MM_OFF_RED + 4 * MM_TOK * 4;
-// packed image: 4 waves x 648 KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
-constexpr size_t MM_PACK_FRAG_BYTES = (size_t)4 * MM_NF * 1024;
-constexpr int MM_PACK_PRM_FLOATS = MM_H + 4 * MM_C;
+constexpr int MM_TOK = 64, MM_HC = 256, MM_KS_H = MM_HC / 16;   // tokens per workgroup, hidden chunk (16 k-steps)
+constexpr int MM_RING = 16, MM_PF = 12;                         // LDS ring (CF = 3 only): slots (1 KB) per wave, fragments in flight
+// Geometry by CF = C / 128 = 32-feature tiles per wave: 3 (C = 384: stage 2 of Swin-T / -S) or 4 (C = 512: stage 2 of Swin-B,
+// register ring only — its 64 KB activation tile leaves no room for an LDS weight ring)
+template <int CF>
+struct MMc {
+  static constexpr int C = 128 * CF, H = 4 * C, W = 32 * CF;            // channels, hidden units, features per wave
+  static constexpr int NCH = H / MM_HC, KS_C = C / 16;                  // hidden chunks, k-steps over C
+  static constexpr int NF_PROJ = KS_C * CF, NF_FC1 = KS_C * 2, NF_FC2 = MM_KS_H * CF;
+  static constexpr int NF = NF_PROJ + NCH * (NF_FC1 + NF_FC2);          // fragments per wave: 648 / 1152
+  static constexpr int OFF_X = 0;                                       // [KS_C k-steps][2 token tiles][64 lanes][16 B] = 48 / 64 KB
+  static constexpr int OFF_G = OFF_X + KS_C * 2 * 1024;                 // [16][2][64][16 B] = 32 KB
+  static constexpr int OFF_RING = OFF_G + MM_KS_H * 2 * 1024;           // 4 waves x 16 KB (CF = 3)
+  static constexpr int OFF_PRM = OFF_RING + (CF == 3 ? 4 * MM_RING * 1024 : 0);     // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
+  static constexpr int PRM_FLOATS = H + 4 * C;
+  static constexpr int OFF_RED = OFF_PRM + PRM_FLOATS * 4;              // [4 waves][64 tokens] fp32
+  static constexpr int LDS = OFF_RED + 4 * MM_TOK * 4;
+  // packed image: 4 waves x NF KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
+  static constexpr size_t PACK_FRAG_BYTES = (size_t)4 * NF * 1024;
+  // register ring: every phase consumes a multiple of VR_R fragments (72 | 48 | 48 of 24; 128 | 64 | 64 of 16 — 32 slots at C = 512
+  // spill: 128 + 64 accumulator registers are there already)
+  static constexpr int VR_R = CF == 3 ? 24 : 16, VR_PF = VR_R - 4;
+  static_assert(NF_PROJ % VR_R == 0 && NF_FC1 % VR_R == 0 && NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
+  static_assert(LDS <= 163840, "LDS");
+};
 
-bool tailmm_supported(int C, int hidden) { return C == MM_C && hidden == MM_H; }
+bool tailmm_supported(int C, int hidden) { return (C == 384 || C == 512) && hidden == 4 * C; }
 size_t tailmm_pack_bytes(int C, int hidden) {
-  return tailmm_supported(C, hidden) ? MM_PACK_FRAG_BYTES + (((size_t)MM_PACK_PRM_FLOATS * 4 + 255) & ~(size_t)255) : 0;
+  if (!tailmm_supported(C, hidden)) return 0;
+  const size_t frag = C == 384 ? MMc<3>::PACK_FRAG_BYTES : MMc<4>::PACK_FRAG_BYTES;
+  return frag + (((size_t)(hidden + 4 * C) * 4 + 255) & ~(size_t)255);
 }
 
 // k offset inside a 16-step of element e of fragment slot group g when the B operand is written from accumulators: a lane
 // (token, half) holds, per 32-row tile, rows 8q + 4 half + i; quads (q even, q odd) of one 16-row half are one slot
 __host__ __device__ inline int mm_kperm(int g, int e) { return e < 4 ? 4 * g + e : 8 + 4 * g + (e - 4); }
 
+template <int CF>
 __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w,
                                    const float* n2b, const float* b1, const float* b2, unsigned char* out) {
+  using K = MMc<CF>;
+  constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_NF = K::NF, MM_NF_PROJ = K::NF_PROJ, MM_NF_FC1 = K::NF_FC1, MM_NF_FC2 = K::NF_FC2;
+  constexpr int MM_PACK_PRM_FLOATS = K::PRM_FLOATS;
+  constexpr size_t MM_PACK_FRAG_BYTES = K::PACK_FRAG_BYTES;
   const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n_slots = (long)4 * MM_NF * 64;
   if (gi < n_slots) {
@@ -72,8 +89,8 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
     for (int e = 0; e < 8; ++e) {
       uint16_t v;
       if (f < MM_NF_PROJ) {                                  // proj: natural k (B fragments come straight from the attention rows)
-        const int ks = f / 3, ft = f % 3;
-        v = wp[(size_t)(96 * w + 32 * ft + i) * MM_C + 16 * ks + 8 * g + e];
+        const int ks = f / CF, ft = f % CF;
+        v = wp[(size_t)(K::W * w + 32 * ft + i) * MM_C + 16 * ks + 8 * g + e];
       } else {
         // consumption order behind proj: fc1(0); then fc1(c+1), fc2(c) for c = 0..4; then fc2(5)
         const int r = f - MM_NF_PROJ;
@@ -89,8 +106,8 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
           const int ks = q / 2, ft = q % 2;
           v = w1[(size_t)(MM_HC * c + 64 * w + 32 * ft + i) * MM_C + 16 * ks + mm_kperm(g, e)];
         } else {                                             // fc2: all C outputs, k = hidden unit of chunk c in accumulator order
-          const int q2 = q - MM_NF_FC1, ks = q2 / 3, ft = q2 % 3;
-          v = w2[(size_t)(96 * w + 32 * ft + i) * MM_H + MM_HC * c + 16 * ks + mm_kperm(g, e)];
+          const int q2 = q - MM_NF_FC1, ks = q2 / CF, ft = q2 % CF;
+          v = w2[(size_t)(K::W * w + 32 * ft + i) * MM_H + MM_HC * c + 16 * ks + mm_kperm(g, e)];
         }
       }
       o[e] = v;
@@ -109,9 +126,13 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
 
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st) {
-  const long total = (long)4 * MM_NF * 64 + MM_PACK_PRM_FLOATS;
-  hipLaunchKernelGGL(tailmm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1,
-                     b2, out);
+  if (C == 512) {
+    const long total = (long)4 * MMc<4>::NF * 64 + MMc<4>::PRM_FLOATS;
+    hipLaunchKernelGGL(tailmm_pack_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
+  } else {
+    const long total = (long)4 * MMc<3>::NF * 64 + MMc<3>::PRM_FLOATS;
+    hipLaunchKernelGGL(tailmm_pack_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
+  }
   KVQ_CHECK_LAUNCH("tailmm_pack_kernel");
   return KVQ_OK;
 }
@@ -126,11 +147,15 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
 // exact in the unrolled phases (s_waitcnt vmcnt(19 / 18) in the steady state), and an inline-asm load is unsafe under this register
 // pressure (the allocator splits the live range of a value it believes ready; the late data lands in a register handed on).
 // 79 -> 73 us (with the next norm1), 73 -> 64 us (without); bit-identical results.
-constexpr int VR_R = 24, VR_PF = 20;
-template <typename E, bool EMIT, int DBG = 0, bool VR = false>
+template <typename E, bool EMIT, int DBG = 0, bool VR = false, int CF = 3>
 __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   static_assert(!VR || DBG == 0, "the ablation builds are of the LDS-ring kernel");
-  static_assert(MM_NF_PROJ % VR_R == 0 && MM_NF_FC1 % VR_R == 0 && MM_NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
+  static_assert(VR || CF == 3, "C = 512 has no room for the LDS weight ring");
+  using K = MMc<CF>;
+  constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_KS_C = K::KS_C, MM_NF = K::NF, VR_R = K::VR_R, VR_PF = K::VR_PF, FW = K::W;
+  constexpr int MM_OFF_X = K::OFF_X, MM_OFF_G = K::OFF_G, MM_OFF_RING = K::OFF_RING, MM_OFF_PRM = K::OFF_PRM, MM_OFF_RED = K::OFF_RED;
+  constexpr int MM_PRM_FLOATS = K::PRM_FLOATS;
+  constexpr size_t MM_PACK_FRAG_BYTES = K::PACK_FRAG_BYTES;
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
@@ -177,33 +202,37 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   };
 
   // ---- this workgroup's rows: token tt*32 + j of 64, window order -> token of the residual stream ----
-  long orig[2];
+  long orig[2], arow[2];
   bool live[2];
   int tloc_[2], tb_[2];
+  const long nrows = p.gather ? p.n_tok : p.M;     // window rows, or (gather) tokens: no work on padding rows
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const long row = (long)blockIdx.x * MM_TOK + 32 * tt + j;
-    const long rc = row < p.M ? row : p.M - 1;
+    const long rc = row < nrows ? row : nrows - 1;
+    arow[tt] = rc;
     int tb, tloc;
-    if (p.map) {
+    if (p.gather) {
+      tb = (int)(rc / p.out_rows);
+      tloc = (int)(rc - (long)tb * p.out_rows);
+      arow[tt] = (long)tb * p.map_rows + p.gather[tloc];
+    } else if (p.map) {
       tb = (int)(rc / p.map_rows);
       tloc = p.map[rc - (long)tb * p.map_rows];
     } else {
       tb = (int)(rc / p.out_rows);
       tloc = (int)(rc - (long)tb * p.out_rows);
     }
-    live[tt] = row < p.M && tloc >= 0;
+    live[tt] = row < nrows && tloc >= 0;
     tloc = tloc < 0 ? 0 : tloc;
     tloc_[tt] = tloc; tb_[tt] = tb;
     orig[tt] = (long)tb * p.out_rows + tloc;
   }
   // ---- attention rows -> B fragments [k-step][token tile] by LDS-DMA (lane (j, half) fetches row j's k 16ks + 8 half ..+7) ----
   {
-    const long row0 = (long)blockIdx.x * MM_TOK;
     for (int fr = wave; fr < MM_KS_C * 2; fr += 4) {
       const int ks = fr >> 1, tt = fr & 1;
-      long row = row0 + 32 * tt + j;
-      row = row < p.M ? row : p.M - 1;
+      const long row = tt ? arow[1] : arow[0];
       __builtin_amdgcn_global_load_lds((mm_gbl_t)(p.attn + (size_t)row * C + 16 * ks + 8 * half), (mm_lds_t)(lds + MM_OFF_X + fr * 1024), 16, 0, 0);
     }
     for (int q = wave; q < (MM_PRM_FLOATS * 4) / 1024; q += 4)      // b1 | g2 | b2n | proj_b | b2: 12 KB
@@ -217,26 +246,26 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   }
   // ---- accumulators = x + proj bias: tile (ft, tt), register r <-> feature 96 wave + 32 ft + (r&3) + 8 (r>>2) + 4 half ----
   // all 24 row pieces of a lane are requested before anything waits (they queue behind the DMA requests above: one drain)
-  f32x16 acc[3][2];
+  f32x16 acc[CF][2];
   {
-    f32x4 xv[3][4][2];
+    f32x4 xv[CF][4][2];
 #pragma unroll
-    for (int ft = 0; ft < 3; ++ft)
+    for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
-          xv[ft][q][tt] = *reinterpret_cast<const f32x4*>(p.x + (size_t)orig[tt] * C + 96 * wave + 32 * ft + 8 * q + 4 * half);
+          xv[ft][q][tt] = *reinterpret_cast<const f32x4*>(p.x + (size_t)orig[tt] * C + FW * wave + 32 * ft + 8 * q + 4 * half);
     __builtin_amdgcn_sched_barrier(0);
     // everything requested so far has landed (the row loads were issued last: vmcnt(0) covers the DMA before them too)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     MM_STAMP(1);
 #pragma unroll
-    for (int ft = 0; ft < 3; ++ft)
+    for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 pb = *reinterpret_cast<const f32x4*>(prm + MM_H + 2 * MM_C + 96 * wave + 32 * ft + 8 * q + 4 * half);
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(prm + MM_H + 2 * MM_C + FW * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : 1, NR = NA * KU;
     constexpr int NM = 2 * NA * KU, NRD = (NA + 2) * KU;          // MFMAs / fragment reads per body
     static_assert(nk % KU == 0 && MM_PF - NR >= 0, "k-steps per body");
-    V8 a[2][KU][3], b[2][KU][2];        // fragments of two bodies: the one in use and the one being read
+    V8 a[2][KU][CF], b[2][KU][2];        // fragments of two bodies: the one in use and the one being read
     // read q of a body (base k-step ks, weight fragments from list position cons): per k-step the order a0 b0 b1 a1 [a2] against
     // the MFMA order (a0 b0) (a0 b1) (a1 b0) (a1 b1) [(a2 b0) (a2 b1)]
     auto rd1 = [&](int buf, int ks, int q) __attribute__((always_inline)) {
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
 #pragma unroll
         for (int k = 0; k < KU; ++k) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) a[u][k][q] = V8{};
+          for (int q = 0; q < CF; ++q) a[u][k][q] = V8{};
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) b[u][k][tt] = V8{};
         }
@@ -356,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   using KH = std::integral_constant<int, MM_KS_H>;
   auto nothing = [](int) {};
   using T2 = std::integral_constant<int, 2>;
-  using T3 = std::integral_constant<int, 3>;
+  using T3 = std::integral_constant<int, CF>;          // weight tiles per wave in proj / fc2
 
   // ---- proj: acc (= x + bias) += Wp . attn^T -------------------------------------------------------------------------
   gemm_phase(T3{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
@@ -368,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     for (int tt = 0; tt < 2; ++tt) {
       float v = 0.f;
 #pragma unroll
-      for (int ft = 0; ft < 3; ++ft)
+      for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
         for (int r = 0; r < 16; ++r) v += term(ft, tt, r);
       v += __shfl_xor(v, 32);
@@ -388,10 +417,10 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   // (acc - mean) * rstd * gamma + beta, 16-bit, written as B fragments: tile ft covers k-steps kbase + 2 ft + {0, 1}
   auto write_norm = [&](const f32x2 mean, const f32x2 rstd, const float* gam, const float* bet, unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ft = 0; ft < 3; ++ft)
+    for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {               // quad pair (2 hp, 2 hp + 1) = 16 features = one k-step
-        const int f0 = 96 * wave + 32 * ft + 16 * hp + 4 * half;
+        const int f0 = FW * wave + 32 * ft + 16 * hp + 4 * half;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + f0), g1 = *reinterpret_cast<const f32x4*>(gam + f0 + 8);
         const f32x4 e0 = *reinterpret_cast<const f32x4*>(bet + f0), e1 = *reinterpret_cast<const f32x4*>(bet + f0 + 8);
 #pragma unroll
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
             y[4 + i] = (acc[ft][tt][8 * hp + 4 + i] - mean[tt]) * rstd[tt] * g1[i] + e1[i];
           }
           const u32x4 w = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3]), E::pack2(y[4], y[5]), E::pack2(y[6], y[7])};
-          const int ks = 6 * wave + 2 * ft + hp;
+          const int ks = 2 * CF * wave + 2 * ft + hp;
           *reinterpret_cast<u32x4*>(dst + (ks * 2 + tt) * 1024 + lane * 16) = w;
         }
       }
@@ -418,10 +447,10 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   }
   // acc becomes the fc2 accumulator: x_mid + fc2 bias
 #pragma unroll
-  for (int ft = 0; ft < 3; ++ft)
+  for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(prm + MM_H + 3 * MM_C + 96 * wave + 32 * ft + 8 * q + 4 * half);
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(prm + MM_H + 3 * MM_C + FW * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     if (more) {
       fc1(c + 1);
       gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); },
-                 [&](int m) { if (m % 3 == 0) gelu_pair(m / 3); });
+                 [&](int m) { if (m % CF == 0) gelu_pair(m / CF); });      // 32 pairs over the 32 CF MFMAs
       MM_BARRIER();                                  // everybody has finished fc2 of chunk c: its GELU rows may go
       write_gelu();
       MM_BARRIER();                                  // GELU rows of chunk c + 1 complete
@@ -489,9 +518,9 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
     if (live[tt]) {
-      float* xr = p.x + (size_t)orig[tt] * C + 96 * wave + 4 * half;
+      float* xr = p.x + (size_t)orig[tt] * C + FW * wave + 4 * half;
 #pragma unroll
-      for (int ft = 0; ft < 3; ++ft)
+      for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(xr + 32 * ft + 8 * q) = (f32x4){acc[ft][tt][4 * q], acc[ft][tt][4 * q + 1], acc[ft][tt][4 * q + 2], acc[ft][tt][4 * q + 3]};
@@ -505,12 +534,12 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     for (int tt = 0; tt < 2; ++tt)
       if (live[tt]) {
         const long drow = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
-        uint16_t* o = p.next_ln + (size_t)drow * C + 96 * wave + 4 * half;
+        uint16_t* o = p.next_ln + (size_t)drow * C + FW * wave + 4 * half;
 #pragma unroll
-        for (int ft = 0; ft < 3; ++ft)
+        for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int f0 = 96 * wave + 32 * ft + 8 * q + 4 * half;
+            const int f0 = FW * wave + 32 * ft + 8 * q + 4 * half;
             const f32x4 gm = *reinterpret_cast<const f32x4*>(p.nn_w + f0), be = *reinterpret_cast<const f32x4*>(p.nn_b + f0);
             float y[4];
 #pragma unroll
@@ -531,7 +560,8 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
 
 template <typename E, int DBG>
 static int launch_mm_dbg(const TailParams& p, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(p.M, MM_TOK)), block(256);
+  constexpr int MM_LDS = MMc<3>::LDS;
+  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
   auto k = block_tailmm_kernel<E, true, DBG>;
   KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS));
   hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
@@ -541,7 +571,7 @@ static int launch_mm_dbg(const TailParams& p, hipStream_t st) {
 
 template <typename E>
 static int launch_mm(const TailParams& p, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(p.M, MM_TOK)), block(256);
+  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
   static const int dbg = getenv("KVQ_MM_DEBUG") ? atoi(getenv("KVQ_MM_DEBUG")) : 0;
   if (dbg && p.next_ln) {
     if (dbg == 1) return launch_mm_dbg<E, 1>(p, st);
@@ -549,6 +579,7 @@ static int launch_mm(const TailParams& p, hipStream_t st) {
     if (dbg == 3) return launch_mm_dbg<E, 3>(p, st);
     if (dbg == 4) return launch_mm_dbg<E, 4>(p, st);
   }
+  constexpr int MM_LDS = MMc<3>::LDS;
   static const int vr = getenv("KVQ_TAILMM_VR") ? atoi(getenv("KVQ_TAILMM_VR")) : 1;
   if (vr) {
     if (p.next_ln) {
@@ -580,8 +611,29 @@ static int launch_mm(const TailParams& p, hipStream_t st) {
   return KVQ_OK;
 }
 
+// C = 512 (CF = 4): the register-ring kernel only
+template <typename E>
+static int launch_mm512(const TailParams& p, hipStream_t st) {
+  constexpr int LDS = MMc<4>::LDS;
+  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
+  if (p.next_ln) {
+    auto k = block_tailmm_kernel<E, true, 0, true, 4>;
+    static bool set = false;
+    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
+    hipLaunchKernelGGL(k, grid, block, LDS, st, p);
+  } else {
+    auto k = block_tailmm_kernel<E, false, 0, true, 4>;
+    static bool set = false;
+    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
+    hipLaunchKernelGGL(k, grid, block, LDS, st, p);
+  }
+  KVQ_CHECK_LAUNCH("block_tailmm_kernel(512)");
+  return KVQ_OK;
+}
+
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
+  if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm512<Fp16>(p, st) : launch_mm512<Bf16>(p, st);
   return dtype == KVQ_DT_FP16 ? launch_mm<Fp16>(p, st) : launch_mm<Bf16>(p, st);
 }
 

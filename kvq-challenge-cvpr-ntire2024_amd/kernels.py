@@ -552,15 +552,15 @@ def block_tail_pack(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b
 
 
 def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: int, *, scatter_map=None, map_rows=0,
-               out_rows=0, next_norm=None, next_dst=None, next_rows=0, eps=1e-5):
+               out_rows=0, next_norm=None, next_dst=None, next_rows=0, eps=1e-5, attn_gather=None):
     """x (fp32 [n_batch*out_rows, C], in place) += proj(attn) scattered; x += Mlp(norm2(x)).
     ``next_norm=(gamma, beta)`` + ``next_dst`` additionally returns norm1_next(x) in the next window order."""
     _need_gpu(attn, x, pack, scatter_map, next_dst)
     assert attn.dtype in HALF_TYPES and attn.is_contiguous() and x.dtype == torch.float32 and x.is_contiguous()
     M, Cc = attn.shape
     a = _abi.KvqBlockTailArgs()
-    a.attn, a.x, a.scatter_map = ptr(attn), ptr(x), ptr(scatter_map)
-    a.map_rows, a.out_rows = (map_rows, out_rows) if scatter_map is not None else (M, M)
+    a.attn, a.x, a.scatter_map, a.attn_gather = ptr(attn), ptr(x), ptr(scatter_map), ptr(attn_gather)
+    a.map_rows, a.out_rows = (map_rows, out_rows) if (scatter_map is not None or attn_gather is not None) else (M, M)
     a.M, a.C, a.hidden, a.pack, a.eps, a.dtype = M, Cc, hidden, ptr(pack), eps, dtype_code(attn.dtype)
     nxt = None
     if next_norm is not None:

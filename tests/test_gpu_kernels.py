@@ -477,7 +477,9 @@ def _tail_reference(A, x, wts, half, lay, B, dims):
                                                    (192, (3, 5, 7), (0, 0, 0), None),      # clamped window, ragged tile
                                                    (384, (8, 14, 14), (0, 0, 0), (4, 3, 3)),   # wide rows: csrc/tail16.hip
                                                    (384, (8, 7, 7), (0, 0, 0), (0, 0, 0)),
-                                                   (384, (4, 10, 9), (4, 3, 3), None)])
+                                                   (384, (4, 10, 9), (4, 3, 3), None),
+                                                   (512, (8, 14, 7), (0, 0, 0), (4, 3, 3)),    # stage 2 of Swin-B: tailmm, CF = 4
+                                                   (512, (4, 10, 9), (4, 3, 3), None)])
 def test_block_tail(C, dims, shift, nxt_shift, half):
     g = rng(C + sum(dims))
     D, H, W = dims
@@ -507,6 +509,15 @@ def test_block_tail(C, dims, shift, nxt_shift, half):
     got = xd.cpu()
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() <= 6 * EPS[half] * scale + 1e-4, ((got - ref).abs().max().item(), scale)
+    if Lp != L:
+        # padded windows: the launch that walks the TOKENS (attn_gather = the inverse of the scatter map) instead of the window
+        # rows computes every real token exactly as before
+        src = lay["src"].astype(np.int64)
+        inv = np.zeros(L, np.int32)
+        inv[src[src >= 0]] = np.nonzero(src >= 0)[0].astype(np.int32)
+        xg = dev(x.clone())
+        kernels.block_tail(dev(A, half), xg, pack, hidden, attn_gather=dev(torch.from_numpy(inv)), map_rows=Lp, out_rows=L)
+        assert torch.equal(xg.cpu(), got)
     if nxt_shift is not None:
         ln = torch.nn.functional.layer_norm(got, (C,), gn, bn).reshape(B, D, H, W, C)
         ref_ln = O.gather_windows(ln, lay2).reshape(-1, C)
