@@ -287,7 +287,7 @@ typedef struct {
   float* x;                    /* fp32 [n_batch*out_rows][C] residual stream, updated in place           */
   const int32_t* scatter_map;  /* window row -> token within the batch element, <0 = padding; NULL = id. */
   int32_t map_rows, out_rows;  /* rows per batch element in the map / in x                               */
-  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192} (hidden % 64 == 0), 384 or 512 (hidden = 4 C) */
+  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192} (hidden % 64 == 0), 256, 384 or 512 (hidden = 4 C) */
   const void* pack;            /* kvq_block_tail_pack image                                              */
   const float* next_norm_w;    /* the following four: only with next_ln != NULL                          */
   const float* next_norm_b;

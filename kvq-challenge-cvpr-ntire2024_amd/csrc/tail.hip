@@ -483,7 +483,7 @@ extern "C" int kvq_block_tail_supported(int C, int hidden) {
   // hidden/32 even and >= 4: the MLP pipeline rotates two accumulators
   static const bool wide = !(getenv("KVQ_TAIL16") && atoi(getenv("KVQ_TAIL16")) == 0);   // C = 384: csrc/tail16.hip / tailmm.hip
   if (wide && kvq::tail16_supported(C, hidden)) return 1;
-  if (wide && C == 512 && use_tailmm(C, hidden)) return 1;                                // stage 2 of Swin-B: csrc/tailmm.hip, CF = 4
+  if (wide && (C == 512 || C == 256) && use_tailmm(C, hidden)) return 1;                  // stages 2 / 1 of Swin-B: csrc/tailmm.hip, CF = 4 / 2
   return (C == 96 || C == 128 || C == 192) && hidden % 64 == 0 && hidden >= 128 ? 1 : 0;
 }
 

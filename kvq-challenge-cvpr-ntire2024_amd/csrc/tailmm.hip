@@ -56,15 +56,15 @@ struct MMc {
   static constexpr size_t PACK_FRAG_BYTES = (size_t)4 * NF * 1024;
   // register ring: every phase consumes a multiple of VR_R fragments (72 | 48 | 48 of 24; 128 | 64 | 64 of 16 — 32 slots at C = 512
   // spill: 128 + 64 accumulator registers are there already)
-  static constexpr int VR_R = CF == 3 ? 24 : 16, VR_PF = VR_R - 4;
+  static constexpr int VR_R = CF == 3 ? 24 : 16, VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
   static_assert(NF_PROJ % VR_R == 0 && NF_FC1 % VR_R == 0 && NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
   static_assert(LDS <= 163840, "LDS");
 };
 
-bool tailmm_supported(int C, int hidden) { return (C == 384 || C == 512) && hidden == 4 * C; }
+bool tailmm_supported(int C, int hidden) { return (C == 256 || C == 384 || C == 512) && hidden == 4 * C; }
 size_t tailmm_pack_bytes(int C, int hidden) {
   if (!tailmm_supported(C, hidden)) return 0;
-  const size_t frag = C == 384 ? MMc<3>::PACK_FRAG_BYTES : MMc<4>::PACK_FRAG_BYTES;
+  const size_t frag = C == 384 ? MMc<3>::PACK_FRAG_BYTES : C == 512 ? MMc<4>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
   return frag + (((size_t)(hidden + 4 * C) * 4 + 255) & ~(size_t)255);
 }
 
@@ -129,6 +129,9 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
   if (C == 512) {
     const long total = (long)4 * MMc<4>::NF * 64 + MMc<4>::PRM_FLOATS;
     hipLaunchKernelGGL(tailmm_pack_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
+  } else if (C == 256) {
+    const long total = (long)4 * MMc<2>::NF * 64 + MMc<2>::PRM_FLOATS;
+    hipLaunchKernelGGL(tailmm_pack_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
   } else {
     const long total = (long)4 * MMc<3>::NF * 64 + MMc<3>::PRM_FLOATS;
     hipLaunchKernelGGL(tailmm_pack_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
@@ -611,29 +614,30 @@ static int launch_mm(const TailParams& p, hipStream_t st) {
   return KVQ_OK;
 }
 
-// C = 512 (CF = 4): the register-ring kernel only
-template <typename E>
-static int launch_mm512(const TailParams& p, hipStream_t st) {
-  constexpr int LDS = MMc<4>::LDS;
+// C = 512 / 256 (CF = 4 / 2): the register-ring kernel only
+template <typename E, int CF>
+static int launch_mm_cf(const TailParams& p, hipStream_t st) {
+  constexpr int LDS = MMc<CF>::LDS;
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
   if (p.next_ln) {
-    auto k = block_tailmm_kernel<E, true, 0, true, 4>;
+    auto k = block_tailmm_kernel<E, true, 0, true, CF>;
     static bool set = false;
     if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   } else {
-    auto k = block_tailmm_kernel<E, false, 0, true, 4>;
+    auto k = block_tailmm_kernel<E, false, 0, true, CF>;
     static bool set = false;
     if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   }
-  KVQ_CHECK_LAUNCH("block_tailmm_kernel(512)");
+  KVQ_CHECK_LAUNCH("block_tailmm_kernel(CF)");
   return KVQ_OK;
 }
 
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
-  if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm512<Fp16>(p, st) : launch_mm512<Bf16>(p, st);
+  if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
+  if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
   return dtype == KVQ_DT_FP16 ? launch_mm<Fp16>(p, st) : launch_mm<Bf16>(p, st);
 }
 

@@ -478,6 +478,8 @@ def _tail_reference(A, x, wts, half, lay, B, dims):
                                                    (384, (8, 14, 14), (0, 0, 0), (4, 3, 3)),   # wide rows: csrc/tail16.hip
                                                    (384, (8, 7, 7), (0, 0, 0), (0, 0, 0)),
                                                    (384, (4, 10, 9), (4, 3, 3), None),
+                                                   (256, (8, 14, 7), (4, 3, 3), (0, 0, 0)),    # stage 1 of Swin-B: tailmm, CF = 2
+                                                   (256, (4, 10, 9), (4, 3, 3), None),
                                                    (512, (8, 14, 7), (0, 0, 0), (4, 3, 3)),    # stage 2 of Swin-B: tailmm, CF = 4
                                                    (512, (4, 10, 9), (4, 3, 3), None)])
 def test_block_tail(C, dims, shift, nxt_shift, half):
