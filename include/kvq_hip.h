@@ -301,6 +301,12 @@ typedef struct {
                                   attention row through it, instead of walking the M window rows: padded geometries (Swin-B at
                                   256x256: 1.2x .. 3x the rows) then do no work on padding rows.  scatter_map is not read. */
 } KvqBlockTailArgs;
+/* Padded window partitions (Swin-B at 256x256, KSVQE at 288x288): the q|k|v of a PADDING row is qkv(0) = bias (the reference pads after
+ * norm1, swin_backbone.py:416-449) and takes part in the softmax of its window as a key.  Instead of multiplying zero rows, the qkv
+ * GEMM runs over the real tokens — KVQ_EPI_QKV_BF16 with scatter_map = token -> window row, map_rows = tokens and out_rows = window rows
+ * per batch element — and this launch writes bias (q scaled) into the n_pad padding rows pad_rows[] of every batch element. */
+int kvq_qkv_fill_pad(void* qkv, const float* qkv_bias, const int32_t* pad_rows, int n_pad, int n_batch, int rows_per_batch,
+                     int num_heads, float q_scale, int dtype, void* stream);
 int kvq_block_tail_supported(int C, int hidden);                 /* 1 / 0 */
 size_t kvq_block_tail_pack_bytes(int C, int hidden);             /* 0 when unsupported */
 /* proj_w [C][C], fc1_w [hidden][C], fc2_w [C][hidden]: 16-bit nn.Linear layouts; the rest fp32. */

@@ -143,6 +143,7 @@ SYMBOLS = {
     "kvq_convnet_destroy": (None, [p_void]),
     "kvq_convnet_workspace_bytes": (sz, [p_void]),
     "kvq_convnet_forward": (i32, [p_void, C.POINTER(p_void), C.POINTER(p_void), p_void, sz, p_void]),
+    "kvq_qkv_fill_pad": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, C.c_float, i32, p_void]),
     "kvq_fast_bottleneck_pack_bytes": (sz, [i32, i32, i32, i32, i32]),
     "kvq_fast_bottleneck": (i32, [p_void, C.POINTER(i32), i32, i32, i32, i32, i32, p_void, i32, p_void, p_void]),
     "kvq_convnet_profile": (i32, [p_void, i32]),

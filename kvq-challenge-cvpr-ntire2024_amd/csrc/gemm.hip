@@ -487,7 +487,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(GemmParams p) {
         } else if (EPI == KVQ_EPI_QKV_BF16) {
 #pragma unroll
           for (int k = 0; k < CW; ++k) v[k] *= scale;
-          dst = p.out_h + ((size_t)(which * p.num_heads + head) * p.M + m) * 32 + e0;
+          // with a row map (token -> window row, padded geometries: the GEMM runs over the tokens only) the head-major buffer has
+          // out_rows rows per batch element; kvq_qkv_fill_pad writes the padding rows
+          size_t mo = m, mtot = p.M;
+          if (p.scatter_map) {
+            const int bq = m / p.map_rows;
+            mo = (size_t)bq * p.out_rows + p.scatter_map[m - bq * p.map_rows];
+            mtot = (size_t)(p.M / p.map_rows) * p.out_rows;
+          }
+          dst = p.out_h + ((size_t)(which * p.num_heads + head) * mtot + mo) * 32 + e0;
         }
         const u32x4 o = {E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4 % CW], v[5 % CW]),
                          E::pack2(v[6 % CW], v[7 % CW])};
@@ -850,6 +858,47 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
       set_error("kvq_gemm_bf16: unknown epilogue %d", a->epilogue);
       return KVQ_ERR_UNSUPPORTED;
   }
+}
+
+namespace kvq {
+// q | k | v of the PADDING rows of a window partition: the reference computes qkv(0) = bias for them (F.pad after norm1,
+// swin_backbone.py:416-449) and they take part in every window's softmax as keys.  One thread = 8 values of one (row, head).
+template <typename E>
+__global__ void qkv_fill_pad_kernel(uint16_t* out, const float* bias, const int32_t* pad_rows, int n_pad, int n_batch, int rows_per_batch,
+                                    int num_heads, float q_scale) {
+  const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)3 * num_heads * n_batch * n_pad * 4;
+  if (gi >= total) return;
+  const int e8 = (int)(gi & 3);
+  long r = gi >> 2;
+  const int pr = (int)(r % n_pad); r /= n_pad;
+  const int b = (int)(r % n_batch); r /= n_batch;
+  const int head = (int)(r % num_heads), which = (int)(r / num_heads);
+  const float sc = which == 0 ? q_scale : 1.f;
+  const float* bs = bias + (size_t)which * num_heads * 32 + head * 32 + 8 * e8;
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs), b1 = *reinterpret_cast<const f32x4*>(bs + 4);
+  const size_t mtot = (size_t)n_batch * rows_per_batch, row = (size_t)b * rows_per_batch + pad_rows[pr];
+  *reinterpret_cast<u32x4*>(out + ((size_t)(which * num_heads + head) * mtot + row) * 32 + 8 * e8) =
+      (u32x4){E::pack2(b0[0] * sc, b0[1] * sc), E::pack2(b0[2] * sc, b0[3] * sc), E::pack2(b1[0] * sc, b1[1] * sc), E::pack2(b1[2] * sc, b1[3] * sc)};
+}
+}  // namespace kvq
+
+extern "C" int kvq_qkv_fill_pad(void* qkv, const float* qkv_bias, const int32_t* pad_rows, int n_pad, int n_batch, int rows_per_batch,
+                                int num_heads, float q_scale, int dtype, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(qkv && qkv_bias && pad_rows, KVQ_ERR_NULL, "kvq_qkv_fill_pad: NULL pointer");
+  KVQ_REQUIRE(n_pad > 0 && n_batch > 0 && rows_per_batch >= n_pad && num_heads > 0, KVQ_ERR_SHAPE, "kvq_qkv_fill_pad: bad shape");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_qkv_fill_pad: dtype %d", dtype);
+  const long total = (long)3 * num_heads * n_batch * n_pad * 4;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == KVQ_DT_FP16)
+    hipLaunchKernelGGL(qkv_fill_pad_kernel<Fp16>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, qkv_bias, pad_rows, n_pad, n_batch,
+                       rows_per_batch, num_heads, q_scale);
+  else
+    hipLaunchKernelGGL(qkv_fill_pad_kernel<Bf16>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, qkv_bias, pad_rows, n_pad, n_batch,
+                       rows_per_batch, num_heads, q_scale);
+  KVQ_CHECK_LAUNCH("qkv_fill_pad_kernel");
+  return KVQ_OK;
 }
 
 extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {

@@ -26,6 +26,7 @@ struct StageGeom {
   int Dp, Hp, Wp, nW, N, Lp;
   bool shifted_any;
   int32_t* d_src[2];  // [Lp] source token or -1
+  int32_t* d_pad[2];  // [Lp - L] the padding rows of the partition (window order), nullptr when Lp == L
   int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row).  A bijection — the next block's norm1 rows can be EMITTED through it —
                       // only when Lp == L (no padding)
   int32_t* d_tok[2];  // [nW*N][2]
@@ -133,12 +134,19 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
   int rc = upload(pl, src, &g.d_src[par]);
   if (rc) return rc;
   g.d_dst[par] = nullptr;
+  g.d_pad[par] = nullptr;
   {
-    std::vector<int32_t> dst((size_t)g.L, 0);
-    for (int i = 0; i < g.Lp; ++i)
+    std::vector<int32_t> dst((size_t)g.L, 0), pad;
+    for (int i = 0; i < g.Lp; ++i) {
       if (src[i] >= 0) dst[src[i]] = i;
+      else pad.push_back(i);
+    }
     rc = upload(pl, dst, &g.d_dst[par]);
     if (rc) return rc;
+    if (!pad.empty()) {
+      rc = upload(pl, pad, &g.d_pad[par]);
+      if (rc) return rc;
+    }
   }
   return upload(pl, tok, &g.d_tok[par]);
 }
@@ -477,10 +485,20 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
                   "kvq_swin3d_forward: block %d weights incomplete", blk);
       const int par = (b & 1) && g.shifted_any ? 1 : 0;
       // norm1 + pad + roll + window_partition
-      if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+      static const bool skip_pad = !(getenv("KVQ_QKV_SKIP_PAD") && atoi(getenv("KVQ_QKV_SKIP_PAD")) == 0);
+      if (skip_pad && g.Lp != g.L && !ln1_ready && bw.qkv_b) {
+        // padded partition: norm1 in TOKEN order, qkv over the tokens only (rows scattered to their window rows by the epilogue);
+        // the padding rows' q | k | v = qkv(0) = bias
+        KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, ML, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
+                     0.17677669529663687f, g.d_dst[par], g.L, g.Lp));
+        KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, 0.17677669529663687f, pl->dtype, st));
+      } else {
+        if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
+                     0.17677669529663687f /* 32^-0.5 */));
+      }
       ln1_ready = false;
-      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
-                   0.17677669529663687f /* 32^-0.5 */));
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
         Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C,
