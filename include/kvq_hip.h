@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 16
+#define KVQ_ABI_VERSION 17
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -344,6 +344,10 @@ int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float*
                               int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
 int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
                                int num_heads, int dtype, uint16_t* out, void* stream);
+/* The same with tile_skip[nW] (or NULL): bit t of tile_skip[w] set = rows 16t .. 16t+15 of window w are padding rows only (padded
+ * partitions); such q-tiles are passed over — their output rows are never read (the consumers walk the tokens). */
+int kvq_window_attention_dense_skip(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N, int num_heads,
+                                    int dtype, uint16_t* out, const uint32_t* tile_skip, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

@@ -430,6 +430,7 @@ struct AttnDenseParams {
   uint16_t* out;
   unsigned long long* trace;   // -DKVQ_ATT_TRACE builds only
   int trace_blocks;
+  const uint32_t* tile_skip;   // optional [nW]: bit t = q-tile t of the window holds padding rows only (its output is never read)
 };
 
 template <typename E>
@@ -511,10 +512,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
 
   // the ticket and the q fragment of the NEXT tile are fetched while this one is computed (both sit on the critical
   // path of a tile's first MFMA otherwise); B operand of S^T = K Q^T: lane (j, g) holds Q[q0+j][8g..8g+7]
+  const uint32_t skip = p.tile_skip ? p.tile_skip[w] : 0u;      // wave-uniform
   auto take = [&]() -> int {
-    int t_ = 0;
-    if (lane == 0) t_ = atomicAdd(ticket, 1);
-    return __builtin_amdgcn_readfirstlane(t_);
+    int t_;
+    do {                                                        // q-tiles of padding rows only are passed over
+      t_ = 0;
+      if (lane == 0) t_ = atomicAdd(ticket, 1);
+      t_ = __builtin_amdgcn_readfirstlane(t_);
+    } while (t_ < q_hi && ((skip >> t_) & 1u));
+    return t_;
   };
   auto q_frag = [&](int t_) -> V8 { return *reinterpret_cast<const V8*>(Qg + (size_t)min(t_ * 16 + j, N - 1) * 32 + g * 8); };
   int qt = take();
@@ -653,6 +659,11 @@ extern "C" int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, c
 
 extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
                                           int num_heads, int dtype, uint16_t* out, void* stream) {
+  return kvq_window_attention_dense_skip(qkv, bias_dense, n_types, BW, nW, N, num_heads, dtype, out, nullptr, stream);
+}
+
+extern "C" int kvq_window_attention_dense_skip(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
+                                               int num_heads, int dtype, uint16_t* out, const uint32_t* tile_skip, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(qkv && bias_dense && out, KVQ_ERR_NULL, "kvq_window_attention_dense: NULL pointer");
   KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
@@ -666,6 +677,6 @@ extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_
   qsplit = qsplit > 4 ? 4 : qsplit;
   qsplit = qsplit > nqt ? nqt : qsplit;
   if (getenv("KVQ_ATT_QSPLIT")) qsplit = atoi(getenv("KVQ_ATT_QSPLIT"));
-  AttnDenseParams p{qkv, (const u32x2*)bias_dense, BW, nW, N, num_heads, n_types, qsplit, out, g_trace, g_trace_blocks};
+  AttnDenseParams p{qkv, (const u32x2*)bias_dense, BW, nW, N, num_heads, n_types, qsplit, out, g_trace, g_trace_blocks, tile_skip};
   return dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16>(p, (hipStream_t)stream) : launch_attn_dense<Bf16>(p, (hipStream_t)stream);
 }

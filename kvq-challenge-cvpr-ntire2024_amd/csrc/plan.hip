@@ -27,6 +27,7 @@ struct StageGeom {
   bool shifted_any;
   int32_t* d_src[2];  // [Lp] source token or -1
   int32_t* d_pad[2];  // [Lp - L] the padding rows of the partition (window order), nullptr when Lp == L
+  int32_t* d_skip[2]; // [nW] bit t: rows 16t..16t+15 of the window are padding only (attention passes such q-tiles over), or nullptr
   int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row).  A bijection — the next block's norm1 rows can be EMITTED through it —
                       // only when Lp == L (no padding)
   int32_t* d_tok[2];  // [nW*N][2]
@@ -143,9 +144,22 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
     }
     rc = upload(pl, dst, &g.d_dst[par]);
     if (rc) return rc;
+    g.d_skip[par] = nullptr;
     if (!pad.empty()) {
       rc = upload(pl, pad, &g.d_pad[par]);
       if (rc) return rc;
+      std::vector<int32_t> skip((size_t)g.nW, 0);
+      bool any = false;
+      for (int wv = 0; wv < g.nW; ++wv)
+        for (int t = 0; t * 16 < g.N && t < 32; ++t) {
+          bool all_pad = true;
+          for (int q = t * 16; q < g.N && q < t * 16 + 16; ++q) all_pad = all_pad && src[(size_t)wv * g.N + q] < 0;
+          if (all_pad) { skip[wv] |= (int32_t)(1u << t); any = true; }
+        }
+      if (any) {
+        rc = upload(pl, skip, &g.d_skip[par]);
+        if (rc) return rc;
+      }
     }
   }
   return upload(pl, tok, &g.d_tok[par]);
@@ -503,8 +517,9 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         // + the dense bias once per step: 4 B per score of every (window, head)
         Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C,
                    2.0 * 4.0 * M * C + (double)kvq_attn_bias_dense_bytes(bias_types(g, par), g.N, g.nH));
-        KVQ_TRY(kvq_window_attention_dense(bbig, bw.bias_dense, bias_types(g, par), B * g.nW, g.nW, g.N, g.nH, pl->dtype, bo,
-                                           st));
+        static const bool skip_q = !(getenv("KVQ_ATT_SKIP_PAD") && atoi(getenv("KVQ_ATT_SKIP_PAD")) == 0);
+        KVQ_TRY(kvq_window_attention_dense_skip(bbig, bw.bias_dense, bias_types(g, par), B * g.nW, g.nW, g.N, g.nH, pl->dtype, bo,
+                                                skip_q ? (const uint32_t*)g.d_skip[par] : nullptr, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);
