@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 17
+#define KVQ_ABI_VERSION 18
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -238,6 +238,10 @@ typedef struct {
   /* 16-bit row-major epilogues (BIAS / GELU / QGELU / RELU): the N columns land at columns col_off .. col_off+N-1 of rows of
    * ldc elements — a channel concatenation (torch.cat along C of channels-last tensors) for free.  ldc = 0: ldc = N, col_off 0. */
   int32_t ldc, col_off;
+  /* Optional row gather of A (plain GEMMs only): GEMM row m reads A row (m / a_rows) * a_phys_rows + a_gather[m % a_rows] — the proj of a
+   * padded window partition run over the real tokens (a_gather = token -> window row) instead of over the padding rows as well. */
+  const int32_t* a_gather;
+  int32_t a_rows, a_phys_rows;
 } KvqGemmArgs;
 /* S the launch would use (1 = no split) and the scratch bytes that S needs */
 int kvq_gemm_splitk_factor(int M, int N, int K);

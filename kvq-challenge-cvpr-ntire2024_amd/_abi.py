@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 def dtype_code(dt) -> int:
@@ -67,7 +67,8 @@ class KvqGemmArgs(C.Structure):
                 ("K", C.c_int32), ("epilogue", C.c_int32), ("out_bf16", p_void), ("out_f32", p_void),
                 ("num_heads", C.c_int32), ("q_scale", C.c_float), ("scatter_map", p_void),
                 ("map_rows", C.c_int32), ("out_rows", C.c_int32), ("dtype", C.c_int32), ("resid_bf16", p_void), ("resid_f32", p_void),
-                ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t), ("ldc", C.c_int32), ("col_off", C.c_int32)]
+                ("splitk_ws", p_void), ("splitk_ws_bytes", C.c_size_t), ("ldc", C.c_int32), ("col_off", C.c_int32),
+                ("a_gather", p_void), ("a_rows", C.c_int32), ("a_phys_rows", C.c_int32)]
 
 
 class KvqConvArgs(C.Structure):

@@ -46,6 +46,8 @@ struct GemmParams {
   int ldc, col_off;            // 16-bit outputs (not QKV): row pitch / first column inside a wider destination (0 = N / 0)
   float* sk_ws;                // host side only: split-K scratch of the caller (NULL = never split) and its size
   size_t sk_bytes;
+  const int32_t* a_gather;     // plain GEMM: row m reads A row (m / a_rows) * a_phys_rows + a_gather[m % a_rows]
+  int a_rows, a_phys_rows;
 };
 
 // what out-of-image / K-padding chunks of an implicit-GEMM A tile are fetched from
@@ -147,7 +149,12 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(GemmParams p) {
         a_tap[i] = p.taps[(ksl * (p.K / BK) / p.ksplit) * CH + c];
       }
     } else {
-      a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.K + c * 8;
+      size_t ar = (size_t)min(m0 + row, p.M - 1);
+      if (p.a_gather) {
+        const int bq = (int)(ar / p.a_rows);
+        ar = (size_t)bq * p.a_phys_rows + p.a_gather[ar - (size_t)bq * p.a_rows];
+      }
+      a_src[i] = p.A + ar * p.K + c * 8;
     }
   }
 #pragma unroll
@@ -824,6 +831,9 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   p.sk_ws = (float*)a->splitk_ws; p.sk_bytes = a->splitk_ws_bytes;
   KVQ_REQUIRE(!p.sk_ws || ((size_t)p.sk_ws & 15) == 0, KVQ_ERR_SHAPE, "kvq_gemm_bf16: splitk_ws must be 16-byte aligned");
   p.ldc = a->ldc; p.col_off = a->col_off;
+  p.a_gather = a->a_gather; p.a_rows = a->a_rows; p.a_phys_rows = a->a_phys_rows;
+  KVQ_REQUIRE(!a->a_gather || (a->a_rows > 0 && a->a_phys_rows >= a->a_rows && a->M % a->a_rows == 0 && !a->splitk_ws), KVQ_ERR_SHAPE,
+              "kvq_gemm_bf16: a_gather needs M = n_batch * a_rows, a_phys_rows >= a_rows, no split-K");
   KVQ_REQUIRE(a->ldc == 0 || (a->epilogue != KVQ_EPI_QKV_BF16 && a->epilogue != KVQ_EPI_RESID_F32 && a->epilogue != KVQ_EPI_STORE_F32 &&
                               a->ldc % 8 == 0 && a->col_off % 8 == 0 && a->col_off >= 0 && a->col_off + a->N <= a->ldc),
               KVQ_ERR_SHAPE, "kvq_gemm_bf16: ldc / col_off need a 16-bit row-major epilogue, multiples of 8, col_off + N <= ldc");

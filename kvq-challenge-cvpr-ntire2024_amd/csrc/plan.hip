@@ -548,9 +548,19 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         KVQ_TRY(kvq_block_tail(&ta, st));
         continue;
       }
-      // proj + window_reverse + roll back + crop + residual
-      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,
-                   g.d_src[par], g.Lp, g.L));
+      // proj + window_reverse + roll back + crop + residual.  Padded partition: over the tokens (A rows gathered through token ->
+      // window row, output in place in token order) instead of over the window rows with the padding rows dropped in the epilogue
+      if (g.Lp != g.L && skip_pad) {
+        KvqGemmArgs pa{};
+        pa.A = bo; pa.W = bw.proj_w; pa.bias = bw.proj_b; pa.M = ML; pa.N = C; pa.K = C; pa.epilogue = KVQ_EPI_RESID_F32; pa.out_f32 = cur;
+        pa.dtype = pl->dtype; pa.a_gather = g.d_dst[par]; pa.a_rows = g.L; pa.a_phys_rows = g.Lp;
+        Bracket br(pl, st, KVQ_K_GEMM_PROJ, gemm_variant(ML, C, C) * 10 + KVQ_EPI_RESID_F32, 2.0 * M * C * C,
+                   2.0 * ((double)ML * C + (double)C * C) + 8.0 * ML * C);
+        KVQ_TRY(kvq_gemm_bf16(&pa, st));
+      } else {
+        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,
+                     g.d_src[par], g.Lp, g.L));
+      }
       // norm2 + fc1 + GELU + fc2 + residual
       KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm2_w, bw.norm2_b, bln, nullptr));
       KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_FC1, bln, bw.fc1_w, bw.fc1_b, ML, cfg.mlp_ratio * C, C, KVQ_EPI_GELU_BF16, bbig,

@@ -505,10 +505,11 @@ class SwinTransformer3D(nn.Module):
                 cm = r.variant // 10
                 nw = os.environ.get("KVQ_TAIL_NW") or 4
                 sym = f"block_tail_kernel<{ename}, {cm}, {nw}, {str(bool(r.variant % 10)).lower()}>"
-                if cm == 12:     # C = 384: csrc/tailmm.hip (feature-sliced GEMM chain) unless KVQ_TAILMM=0 -> csrc/tail16.hip
+                if cm in (8, 12, 16):     # C = 256 / 384 / 512: csrc/tailmm.hip (feature-sliced GEMM chain); C = 384 with KVQ_TAILMM=0 -> tail16.hip
                     emit = str(bool(r.variant % 10)).lower()
-                    sym = (f"block_tail16_kernel<{ename}, 24, {emit}>" if os.environ.get("KVQ_TAILMM", "1") == "0"
-                           else f"block_tailmm_kernel<{ename}, {emit}, 0, {'false' if os.environ.get('KVQ_TAILMM_VR', '1') == '0' else 'true'}>")
+                    vr = "false" if (cm == 12 and os.environ.get("KVQ_TAILMM_VR", "1") == "0") else "true"
+                    sym = (f"block_tail16_kernel<{ename}, 24, {emit}>" if (cm == 12 and os.environ.get("KVQ_TAILMM", "1") == "0")
+                           else f"block_tailmm_kernel<{ename}, {emit}, 0, {vr}, {cm // 4}>")
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
