@@ -60,15 +60,22 @@ def _splitk_scratch(a, M: int, N: int, K: int, device):
 
 
 def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int, *, out=None,
-         num_heads=0, q_scale=1.0, scatter_map=None, map_rows=0, out_rows=0):
-    """A [M,K], W [N,K], both fp16 or both bf16.  Returns the output tensor (allocated unless given)."""
-    _need_gpu(A, W, bias, out, scatter_map)
+         num_heads=0, q_scale=1.0, scatter_map=None, map_rows=0, out_rows=0, a_gather=None, a_rows=0, rows=None):
+    """A [M,K], W [N,K], both fp16 or both bf16.  Returns the output tensor (allocated unless given).
+    ``a_gather`` (+ ``a_rows``, ``rows`` = GEMM rows): row m reads A row (m // a_rows) * (A rows per batch) + a_gather[m % a_rows].
+    QKV epilogue with ``scatter_map``: GEMM row m lands in row (m // map_rows) * out_rows + scatter_map[m % map_rows] of a buffer
+    with out_rows rows per batch element (the other rows are ``qkv_fill_pad``'s)."""
+    _need_gpu(A, W, bias, out, scatter_map, a_gather)
     assert A.dtype in HALF_TYPES and W.dtype == A.dtype and A.is_contiguous() and W.is_contiguous()
     M, K = A.shape
+    a_phys = 0
+    if a_gather is not None:
+        a_phys = A.shape[0] // (rows // a_rows)
+        M = rows
     N = W.shape[0]
     if out is None:
         if epilogue == _abi.EPI_QKV_BF16:
-            out = torch.empty(3, num_heads, M, 32, dtype=A.dtype, device=A.device)
+            out = torch.empty(3, num_heads, M if scatter_map is None else M // map_rows * out_rows, 32, dtype=A.dtype, device=A.device)
         elif epilogue in (_abi.EPI_BIAS_BF16, _abi.EPI_GELU_BF16, _abi.EPI_QGELU_BF16):
             out = torch.empty(M, N, dtype=A.dtype, device=A.device)
         elif epilogue == _abi.EPI_STORE_F32:
@@ -84,10 +91,21 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
         a.out_f32 = ptr(out)
     a.num_heads, a.q_scale = num_heads, q_scale
     a.scatter_map, a.map_rows, a.out_rows = ptr(scatter_map), map_rows, out_rows
+    a.a_gather, a.a_rows, a.a_phys_rows = ptr(a_gather), a_rows, a_phys
     a.dtype = dtype_code(A.dtype)
-    _ws = _splitk_scratch(a, a.M, a.N, a.K, A.device) if a.epilogue != _abi.EPI_QKV_BF16 else None   # noqa: F841
+    _ws = _splitk_scratch(a, a.M, a.N, a.K, A.device) if (a.epilogue != _abi.EPI_QKV_BF16 and a_gather is None) else None   # noqa: F841
     check(lib().kvq_gemm_bf16(C.byref(a), current_stream()), "kvq_gemm_bf16")
     return out
+
+
+def qkv_fill_pad(qkv: torch.Tensor, qkv_bias: torch.Tensor, pad_rows: torch.Tensor, n_batch: int, q_scale: float):
+    """q | k | v = bias (q scaled) in the padding rows ``pad_rows`` (int32, window order) of every batch element of the head-major
+    buffer qkv [3, nH, n_batch * rows, 32] — what the reference computes for rows padded after norm1."""
+    _need_gpu(qkv, qkv_bias, pad_rows)
+    assert qkv.dtype in HALF_TYPES and qkv.is_contiguous() and pad_rows.dtype == torch.int32 and qkv_bias.dtype == torch.float32
+    check(lib().kvq_qkv_fill_pad(ptr(qkv), ptr(qkv_bias), ptr(pad_rows), pad_rows.numel(), n_batch, qkv.shape[2] // n_batch, qkv.shape[1],
+                                 q_scale, dtype_code(qkv.dtype), stream_of(qkv)), "kvq_qkv_fill_pad")
+    return qkv
 
 
 def window_attention(qkv: torch.Tensor, tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor],
@@ -118,16 +136,20 @@ def attn_bias_dense(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Te
     return out
 
 
-def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None):
+def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
+                           tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled) + pre-built bias; returns [BW*N, nH*32].  ``n_types`` (default nW):
-    window w uses bias w % n_types."""
-    _need_gpu(qkv, bias_dense)
+    window w uses bias w % n_types.  ``tile_skip`` int32 [nW]: bit t = q-tile t of the window is passed over (padding rows only);
+    the rows of such tiles keep what ``out`` held."""
+    _need_gpu(qkv, bias_dense, tile_skip, out)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
-    out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
-    check(lib().kvq_window_attention_dense(ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH,
-                                           dtype_code(qkv.dtype), ptr(out), current_stream()), "kvq_window_attention_dense")
+    if out is None:
+        out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
+    check(lib().kvq_window_attention_dense_skip(ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH,
+                                                dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), current_stream()),
+          "kvq_window_attention_dense")
     return out
 
 

@@ -90,6 +90,42 @@ def test_gemm_qkv_epilogue(half):
     assert (out.float().cpu() - ref).abs().max().item() <= EPS[half] * ref.abs().max().item() + 1e-4
 
 
+def test_padded_partition_qkv_over_tokens_and_proj_row_gather(half):
+    """Padded + shifted partition: (i) the qkv GEMM over the TOKENS with its rows scattered to their window rows + ``qkv_fill_pad`` for the
+    padding rows == the qkv GEMM over all window rows of the zero-padded input, bit for bit; (ii) the proj GEMM with ``a_gather``
+    (token -> window row) == the proj GEMM over the window rows with the scatter map, bit for bit."""
+    g = rng(61)
+    lay = O.window_layout(4, 10, 9, (8, 7, 7), (4, 3, 3))
+    Lp, L, B, C, nH = lay["nW"] * lay["N"], 4 * 10 * 9, 2, 96, 3
+    src = lay["src"].astype(np.int64)
+    inv = np.zeros(L, np.int32)
+    inv[src[src >= 0]] = np.nonzero(src >= 0)[0].astype(np.int32)
+    pad = np.nonzero(src < 0)[0].astype(np.int32)
+    tok = rnd(torch.from_numpy(g.standard_normal((B * L, C)).astype(np.float32)), half)          # norm1 output, token order
+    win = torch.zeros(B, Lp, C)
+    win[:, src >= 0] = tok.reshape(B, L, C)[:, src[src >= 0]]                                     # window order, zero padding rows
+    W = rnd(torch.from_numpy(g.standard_normal((3 * C, C)).astype(np.float32) * 0.2), half)
+    b = torch.from_numpy(g.standard_normal(3 * C).astype(np.float32))
+    scale = 32 ** -0.5
+    full = kernels.gemm(dev(win.reshape(B * Lp, C), half), dev(W, half), dev(b), _abi.EPI_QKV_BF16, num_heads=nH, q_scale=scale)
+    part = torch.full_like(full, float("nan"))
+    kernels.gemm(dev(tok, half), dev(W, half), dev(b), _abi.EPI_QKV_BF16, num_heads=nH, q_scale=scale, out=part,
+                 scatter_map=dev(torch.from_numpy(inv)), map_rows=L, out_rows=Lp)
+    kernels.qkv_fill_pad(part, dev(b), dev(torch.from_numpy(pad)), B, scale)
+    assert torch.equal(part, full)
+    # proj
+    A = rnd(torch.from_numpy(g.standard_normal((B * Lp, C)).astype(np.float32)), half)
+    Wp = rnd(torch.from_numpy(g.standard_normal((C, C)).astype(np.float32) * 0.2), half)
+    bp = torch.from_numpy(g.standard_normal(C).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((B * L, C)).astype(np.float32))
+    x_rows, x_tok = dev(x.clone()), dev(x.clone())
+    kernels.gemm(dev(A, half), dev(Wp, half), dev(bp), _abi.EPI_RESID_F32, out=x_rows,
+                 scatter_map=dev(torch.from_numpy(lay["src"].astype(np.int32))), map_rows=Lp, out_rows=L)
+    kernels.gemm(dev(A, half), dev(Wp, half), dev(bp), _abi.EPI_RESID_F32, out=x_tok, a_gather=dev(torch.from_numpy(inv)), a_rows=L,
+                 rows=B * L)
+    assert torch.equal(x_rows, x_tok)
+
+
 def test_gemm_residual_scatter(half):
     g = rng(6)
     lay = O.window_layout(4, 10, 9, (8, 7, 7), (4, 3, 3))       # padded + shifted: rows dropped and permuted
@@ -362,6 +398,16 @@ def test_window_attention_dense_matches_gather_path(dims, window, shifted, gated
     assert (out - ref).abs().mean().item() <= 0.5 * EPS[half]
     gather = kernels.window_attention(qkv, tokd, rpbd, fpbd, center, nW, N, use_mask).float().cpu()
     assert (out - gather).abs().max().item() <= 4.1 * EPS[half] + 2.0 ** -7      # same budget as above
+    # q-tiles marked in tile_skip are passed over: their rows keep the sentinel, every other row is what it was
+    skip = np.zeros(nW, np.int32)
+    nqt = -(-N // 16)
+    for wv in range(nW):
+        skip[wv] = int(g.integers(0, 1 << nqt)) & ~1                       # tile 0 always runs
+    sentinel = torch.full((BW * N, nH * 32), 7.0, dtype=half, device=qkv.device)
+    part = kernels.window_attention_dense(qkv, dense, nW, N, n_types, tile_skip=dev(torch.from_numpy(skip)), out=sentinel).float().cpu()
+    rows = np.arange(BW * N)
+    skipped = torch.from_numpy(((skip[(rows // N) % nW] >> ((rows % N) // 16)) & 1).astype(bool))
+    assert torch.equal(part[~skipped], out[~skipped]) and bool((part[skipped] == 7.0).all()) and bool(skipped.any())
 
 
 def test_window_attention_dense_softmax_extremes(half):
