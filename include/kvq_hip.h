@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 18
+#define KVQ_ABI_VERSION 19
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -248,6 +248,11 @@ int kvq_gemm_splitk_factor(int M, int N, int K);
 size_t kvq_gemm_splitk_bytes(int M, int N, int K);
 
 int kvq_gemm_bf16(const KvqGemmArgs* host_args, void* stream);
+/* Which main loop kvq_gemm_bf16 / kvq_conv_implicit take (process-wide; returns the previous mode): -1 = by shape (default; the
+ * 256 x 256 x 64 eight-phase kernel of csrc/gemm256.hip when the tile grid fills the chip, else the 128 x 128 x 32 ring kernel),
+ * 0 = never the wide tile, 1 = the wide tile whenever the shape is eligible (K % 64 == 0, K >= 128).  Any other value only reads.
+ * Initial value: environment KVQ_GEMM8P.  Used by the parity tests to run every epilogue through both kernels. */
+int kvq_gemm_tile_mode(int mode);
 /* Diagnostic: while dev_buf != NULL every GEMM block b < max_blocks writes uint64 stamps
  * dev_buf[8*b + {0:start, 1:first slice landed, 2:K loop done, 3:epilogue done}] (shader clock) and
  * [4] = XCC id << 32 | HW_ID.  Pass NULL to switch it off. */

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 def dtype_code(dt) -> int:
@@ -162,6 +162,7 @@ SYMBOLS = {
     "kvq_gemm_splitk_factor": (i32, [i32, i32, i32]),
     "kvq_gemm_splitk_bytes": (sz, [i32, i32, i32]),
     "kvq_debug_gemm_trace": (i32, [p_void, i32]),
+    "kvq_gemm_tile_mode": (i32, [i32]),
     "kvq_patch_embed_supported": (i32, [i32] * 8),
     "kvq_patch_embed_pack_bytes": (sz, [i32, i32]),
     "kvq_patch_embed_pack": (i32, [p_void, p_void, p_void, p_void, i32, i32, p_void, p_void]),

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkvq_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "kvq_hip.h")
-SOURCES = ["common.cpp", "gemm.hip", "ln.hip", "attn.hip", "misc.hip", "plan.hip", "conv.hip", "tail.hip", "tail16.hip", "tailmm.hip", "embed.hip", "vit.hip", "convnet.hip", "bottleneck.hip"]
+SOURCES = ["common.cpp", "gemm.hip", "gemm256.hip", "ln.hip", "attn.hip", "misc.hip", "plan.hip", "conv.hip", "tail.hip", "tail16.hip", "tailmm.hip", "embed.hip", "vit.hip", "convnet.hip", "bottleneck.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 # attn.hip is VALU-bound: SLP packing of adjacent f32 ops into v_pk_* costs more v_mov than it saves, and
@@ -37,7 +37,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [HEADER, os.path.join(CSRC, "common.hpp")]
+    deps = sources() + [HEADER] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -65,7 +65,7 @@ def _build_locked(force: bool, verbose: bool, objdir: str) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        hdrs = [HEADER, os.path.join(CSRC, "common.hpp")]
+        hdrs = [HEADER] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
         if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj

@@ -98,6 +98,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     return out
 
 
+def gemm_tile_mode(mode: int) -> int:
+    """-1: main loop by shape (default), 0: never the 256 x 256 eight-phase tile, 1: whenever eligible.  Returns the previous mode."""
+    return lib().kvq_gemm_tile_mode(mode)
+
+
 def qkv_fill_pad(qkv: torch.Tensor, qkv_bias: torch.Tensor, pad_rows: torch.Tensor, n_batch: int, q_scale: float):
     """q | k | v = bias (q scaled) in the padding rows ``pad_rows`` (int32, window order) of every batch element of the head-major
     buffer qkv [3, nH, n_batch * rows, 32] — what the reference computes for rows padded after norm1."""

@@ -48,9 +48,18 @@ def test_library_loads_on_gpu():
 
 
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=[-1, 1], ids=["by-shape", "wide8p"])
+def tile_mode(request):
+    """Every GEMM test runs through the by-shape dispatch and with the 256 x 256 x 64 eight-phase kernel forced on every eligible
+    shape (K % 64 == 0): ragged M / N, all epilogues, scatter / gather maps."""
+    prev = kernels.gemm_tile_mode(request.param)
+    yield request.param
+    kernels.gemm_tile_mode(prev)
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 96, 96), (1000, 288, 96), (130, 768, 3072), (8960, 1152, 384),
-                                    (3136, 64, 768), (64 * 9 + 5, 2304, 768)])
-def test_gemm_store_and_bias(M, N, K, half):
+                                    (3136, 64, 768), (64 * 9 + 5, 2304, 768), (517, 520, 128), (1100, 264, 1024)])
+def test_gemm_store_and_bias(M, N, K, half, tile_mode):
     g = rng(M + N + K)
     A = rnd(torch.from_numpy(g.standard_normal((M, K)).astype(np.float32)), half)
     W = rnd(torch.from_numpy(g.standard_normal((N, K)).astype(np.float32)), half)
@@ -66,7 +75,7 @@ def test_gemm_store_and_bias(M, N, K, half):
     assert (out_g.float().cpu() - ref_g).abs().max().item() <= EPS[half] * ref_g.abs().max().item() + 1e-4
 
 
-def test_gemm_no_bias_and_asymmetric_layout(half):
+def test_gemm_no_bias_and_asymmetric_layout(half, tile_mode):
     # A = I (padded) with an asymmetric W catches a transposed C-write or swapped operands
     M = N = K = 128
     A = torch.eye(M)
@@ -75,9 +84,10 @@ def test_gemm_no_bias_and_asymmetric_layout(half):
     assert torch.equal(out.cpu(), W.t().contiguous())
 
 
-def test_gemm_qkv_epilogue(half):
+@pytest.mark.parametrize("nH", [3, 12])
+def test_gemm_qkv_epilogue(half, tile_mode, nH):
     g = rng(5)
-    nH, M, C = 3, 392 * 2, 96
+    M, C = 392 * 2, 32 * nH
     A = rnd(torch.from_numpy(g.standard_normal((M, C)).astype(np.float32)), half)
     W = rnd(torch.from_numpy(g.standard_normal((3 * C, C)).astype(np.float32) * 0.2), half)
     b = torch.from_numpy(g.standard_normal(3 * C).astype(np.float32))
@@ -90,13 +100,14 @@ def test_gemm_qkv_epilogue(half):
     assert (out.float().cpu() - ref).abs().max().item() <= EPS[half] * ref.abs().max().item() + 1e-4
 
 
-def test_padded_partition_qkv_over_tokens_and_proj_row_gather(half):
+@pytest.mark.parametrize("C", [96, 384])
+def test_padded_partition_qkv_over_tokens_and_proj_row_gather(half, tile_mode, C):
     """Padded + shifted partition: (i) the qkv GEMM over the TOKENS with its rows scattered to their window rows + ``qkv_fill_pad`` for the
     padding rows == the qkv GEMM over all window rows of the zero-padded input, bit for bit; (ii) the proj GEMM with ``a_gather``
     (token -> window row) == the proj GEMM over the window rows with the scatter map, bit for bit."""
     g = rng(61)
     lay = O.window_layout(4, 10, 9, (8, 7, 7), (4, 3, 3))
-    Lp, L, B, C, nH = lay["nW"] * lay["N"], 4 * 10 * 9, 2, 96, 3
+    Lp, L, B, nH = lay["nW"] * lay["N"], 4 * 10 * 9, 2, C // 32
     src = lay["src"].astype(np.int64)
     inv = np.zeros(L, np.int32)
     inv[src[src >= 0]] = np.nonzero(src >= 0)[0].astype(np.int32)
@@ -126,10 +137,11 @@ def test_padded_partition_qkv_over_tokens_and_proj_row_gather(half):
     assert torch.equal(x_rows, x_tok)
 
 
-def test_gemm_residual_scatter(half):
+@pytest.mark.parametrize("C", [96, 256])
+def test_gemm_residual_scatter(half, tile_mode, C):
     g = rng(6)
     lay = O.window_layout(4, 10, 9, (8, 7, 7), (4, 3, 3))       # padded + shifted: rows dropped and permuted
-    Lp, L, B, C = lay["nW"] * lay["N"], 4 * 10 * 9, 2, 96
+    Lp, L, B = lay["nW"] * lay["N"], 4 * 10 * 9, 2
     A = rnd(torch.from_numpy(g.standard_normal((B * Lp, C)).astype(np.float32)), half)
     W = rnd(torch.from_numpy(g.standard_normal((C, C)).astype(np.float32) * 0.2), half)
     b = torch.from_numpy(g.standard_normal(C).astype(np.float32))
@@ -149,7 +161,7 @@ def test_gemm_residual_scatter(half):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (196, 256, 1536), (98, 768, 3072)])
-def test_gemm_split_k_every_epilogue(M, N, K, half):
+def test_gemm_split_k_every_epilogue(M, N, K, half, tile_mode):
     """Long K, few output tiles (the late convolutions of the conv nets, stage 3 of the trunk): the launch cuts K into S ranges,
     partial tiles go to the caller's scratch and a second launch adds them IN ORDER and applies the epilogue.  Every epilogue that
     may split against the fp64 product; and twice the same call -> bit-identical (the order of the partial sums is fixed)."""
