@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 19
+#define KVQ_ABI_VERSION 20
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -357,6 +357,20 @@ int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int 
  * partitions); such q-tiles are passed over — their output rows are never read (the consumers walk the tokens). */
 int kvq_window_attention_dense_skip(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N, int num_heads,
                                     int dtype, uint16_t* out, const uint32_t* tile_skip, void* stream);
+/* The general form.  dsplit_from >= 0 (shifted blocks of the (8,7,7) window, N = 392): windows w >= dsplit_from of every clip are
+ * DEPTH-SPLIT — the cyclic shift put depth positions Dp-4.. and the wrapped 0..3 into one window and the shift mask
+ * (swin_backbone.py:563-579) separates the two halves of 196 tokens — so a q-tile of one half passes over the key tiles of the
+ * other half, whose scores are the image's -100 and leave the exponential as exact zeros: bit-identical to dsplit_from = -1,
+ * 46 % fewer score tiles in those windows.  The caller vouches for the geometry (the plan derives it from the window layout). */
+typedef struct {
+  const uint16_t* qkv;        /* [3][nH][BW*N][32], q pre-scaled */
+  const void* bias_dense;     /* kvq_attn_bias_dense_build image of n_types window types */
+  int32_t n_types, BW, nW, N, num_heads, dtype;
+  uint16_t* out;              /* [BW*N][nH*32] */
+  const uint32_t* tile_skip;  /* optional, as kvq_window_attention_dense_skip */
+  int32_t dsplit_from;        /* -1 = no depth-split windows */
+} KvqAttnDenseArgs;
+int kvq_window_attention_dense_args(const KvqAttnDenseArgs* host_args, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

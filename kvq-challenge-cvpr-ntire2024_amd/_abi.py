@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 def dtype_code(dt) -> int:
@@ -60,6 +60,11 @@ class KvqSwinWeights(C.Structure):
     _fields_ = [("embed_w", p_void), ("embed_b", p_void), ("embed_ln_w", p_void), ("embed_ln_b", p_void),
                 ("embed_pack", p_void), ("blocks", C.POINTER(KvqSwinBlockW)), ("merges", KvqSwinMergeW * (MAX_STAGES - 1)),
                 ("norm_w", p_void), ("norm_b", p_void)]
+
+
+class KvqAttnDenseArgs(C.Structure):
+    _fields_ = [("qkv", p_void), ("bias_dense", p_void), ("n_types", C.c_int32), ("BW", C.c_int32), ("nW", C.c_int32), ("N", C.c_int32),
+                ("num_heads", C.c_int32), ("dtype", C.c_int32), ("out", p_void), ("tile_skip", p_void), ("dsplit_from", C.c_int32)]
 
 
 class KvqGemmArgs(C.Structure):
@@ -178,6 +183,7 @@ SYMBOLS = {
     "kvq_attn_bias_dense_build": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
     "kvq_window_attention_dense": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_window_attention_dense_skip": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
+    "kvq_window_attention_dense_args": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
     "kvq_swin3d_bias_dense_bytes": (sz, [p_void, i32]),
     "kvq_swin3d_bias_dense_build": (i32, [p_void, i32, p_void, p_void, p_void, p_void, p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),

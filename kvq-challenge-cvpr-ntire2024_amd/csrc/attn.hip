@@ -340,8 +340,14 @@ namespace kvq {
 
 constexpr float ATT_DENSE_OFF = -60000.0f;
 constexpr int ATT_D_OFF_V = ATT_KROWS * 64;                       // K: 416 rows x 64 B
-constexpr int ATT_D_OFF_CTR = ATT_D_OFF_V + ATT_NT * 1024;        // V: 13 key blocks x 2 feature halves x 1 KB
-constexpr int ATT_D_LDS = ATT_D_OFF_CTR + 16;                     // 53 264 B: 3 workgroups per CU
+// the q-tile ticket lives in K row 415: rows 400..415 of K are never read (the 26th score tile cannot hold a key < N <= 400), and
+// 2 x 26 KB is then the whole request — 16 bytes more would round up to the next LDS allocation granule and cost the third
+// workgroup per CU if the granule is coarser than 16 B
+constexpr int ATT_D_OFF_CTR = (ATT_KROWS - 1) * 64;
+#ifndef ATT_D_OCC
+#define ATT_D_OCC 3                 // workgroups per CU the register allocation is made for (1 / 2 / 3 per CU: 118 / 93 / 87 us at stage 0)
+#endif
+constexpr int ATT_D_LDS = ATT_D_OFF_V + ATT_NT * 1024;             // V: 13 key blocks x 2 feature halves x 1 KB; 53 248 B in all
 
 struct DenseBuildParams {
   const int32_t* tok;
@@ -431,10 +437,11 @@ struct AttnDenseParams {
   unsigned long long* trace;   // -DKVQ_ATT_TRACE builds only
   int trace_blocks;
   const uint32_t* tile_skip;   // optional [nW]: bit t = q-tile t of the window holds padding rows only (its output is never read)
+  int dsplit_from;             // >= 0: windows w >= dsplit_from of a clip are depth-split at token 196 of 392 (see tile_body); -1: none
 };
 
 template <typename E>
-__global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kernel(AttnDenseParams p) {   // 3 x 52 KB LDS
+__global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_dense_kernel(AttnDenseParams p) {
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Ks = reinterpret_cast<u32x4*>(smem);
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   const int tid = threadIdx.x, N = p.N;
 #ifdef KVQ_ATT_TRACE
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
-  unsigned long long t_s = 0, t_x = 0, t_pv = 0, t_mark = 0;
+  unsigned long long t_s = 0, t_x = 0, t_pv = 0, t_mark = 0, n_tiles = 0;
   if (tr) p.trace[blockIdx.x * 8 + 0] = __builtin_readcyclecounter();
 #define ATT_MARK(acc) { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - t_mark; t_mark = n_; }
 #else
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     // keys N..415 exist only as padding (their bias is the -60000 of the image): finite zeros, never stale LDS
     for (int i = tid; i < (ATT_KROWS - N) * 8; i += ATT_WAVES * 64) {
       const int key = N + (i >> 3), q = i & 7;
-      if (q < 4) Ks[key * 4 + q] = (u32x4){0u, 0u, 0u, 0u};
+      if (q < 4) { if (key < 16 * (ATT_NT - 1)) Ks[key * 4 + q] = (u32x4){0u, 0u, 0u, 0u}; }      // rows 400.. are never read (ticket)
       else *reinterpret_cast<u32x4*>(Vs + (2 * (key >> 5) + ((q >> 1) & 1)) * 1024 + (key & 31) * 32 + (q & 1) * 16) = (u32x4){0u, 0u, 0u, 0u};
     }
   }
@@ -525,33 +532,39 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
   auto q_frag = [&](int t_) -> V8 { return *reinterpret_cast<const V8*>(Qg + (size_t)min(t_ * 16 + j, N - 1) * 32 + g * 8); };
   int qt = take();
   V8 qf = q_frag(qt);
-  while (qt < q_hi) {
+  // One q-tile against the key tiles [T0, T1) (compile-time: the score registers are indexed statically).  [0, 25) is the
+  // whole window.  Depth-split windows (shifted blocks, last window slab along D: the roll puts d = Dp-4.. and the wrapped
+  // d = 0..3 into one window, the mask separates them, swin_backbone.py:563-579) only attend inside their own depth half —
+  // the other half's scores are bias -100 and come out of the exponential as exact zeros — so a q-tile whose 16 queries sit in
+  // one half skips the other half's key tiles (no bias fetch, no MFMA, no exp): [0, 13) or [12, 25) for the (8,7,7) window
+  // split at token 196; the q-tile that straddles token 196 takes the whole range.  Bit-identical to the full range.
+  auto tile_body = [&](auto t0_tag, auto t1_tag, const V8 qf_cur) __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
+    static_assert(T0 % 2 == 0 && T0 >= 0 && T1 <= NTD && T0 < T1, "key tiles pair up into 32-key PV steps");
     const int q0 = qt * 16;
-    const int qt_next = take();
-    const V8 qf_next = q_frag(qt_next);
     const u32x2* bd = dense + (size_t)qt * ATT_NT * 64;
     u32x2 braw[ATT_NT];
 #pragma unroll
-    for (int t = 0; t < NTD; ++t) braw[t] = bd[t * 64];   // all bias tiles requested before anything waits
+    for (int t = T0; t < T1; ++t) braw[t] = bd[t * 64];   // all bias tiles requested before anything waits
     f32x4 S[ATT_NT];
 #pragma unroll
-    for (int t = 0; t < NTD; ++t)
+    for (int t = T0; t < T1; ++t)
       S[t] = (f32x4){Fp16::to_f32((uint16_t)(braw[t][0] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][0] >> 16)),
                      Fp16::to_f32((uint16_t)(braw[t][1] & 0xffffu)), Fp16::to_f32((uint16_t)(braw[t][1] >> 16))};
     // score tile t = keys 16t..16t+15 in natural order: lane (query j, group g) then holds keys 16t+4g..+3, which is the
     // k order the transpose-read gives the V fragments
-    V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(j, g)]), kfN = kfC;
+    V8 kfC = __builtin_bit_cast(V8, Ks[k_slot(16 * T0 + j, g)]), kfN = kfC;
 #pragma unroll
-    for (int t = 0; t < NTD; ++t) {
-      if (t + 1 < NTD) kfN = __builtin_bit_cast(V8, Ks[k_slot(16 * (t + 1 < NTD ? t + 1 : 0) + j, g)]);
-      S[t] = E::mfma16(kfC, qf, S[t]);
+    for (int t = T0; t < T1; ++t) {
+      if (t + 1 < T1) kfN = __builtin_bit_cast(V8, Ks[k_slot(16 * (t + 1 < T1 ? t + 1 : T0) + j, g)]);
+      S[t] = E::mfma16(kfC, qf_cur, S[t]);
       kfC = kfN;
     }
     ATT_MARK(t_s);
     // row max: two chains of 3-input maxima (v_max3_f32: two new scores per instruction, 50 instead of 75 for the 100 scores)
-    float mx = S[0][0], mx1 = S[0][2];
+    float mx = S[T0][0], mx1 = S[T0][2];
 #pragma unroll
-    for (int t = 0; t < NTD; ++t) {
+    for (int t = T0; t < T1; ++t) {
       mx = fmaxf(fmaxf(mx, S[t][0]), S[t][1]);
       mx1 = fmaxf(fmaxf(mx1, S[t][2]), S[t][3]);
     }
@@ -560,19 +573,23 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     // exponent arguments two at a time (v_pk_fma_f32: the kernel is VALU-issue bound, tools/ubench/pipe_share.hip)
     const f32x2 k2 = {kLog2e, kLog2e}, mb2 = {-mx * kLog2e, -mx * kLog2e};
+    constexpr int S0 = T0 / 2, S1 = (T1 + 1) / 2;     // 32-key PV steps that hold a live tile
     uint32_t P[ATT_NT][2];
-    P[ATT_NT - 1][0] = P[ATT_NT - 1][1] = 0u;       // keys 400..415: padding for every supported N (<= 400)
+    if (T1 < 2 * S1) P[T1][0] = P[T1][1] = 0u;        // odd tile count: the step's second tile is skipped / padding keys 400..415
 #pragma unroll
-    for (int t = 0; t < NTD; ++t) {
+    for (int t = T0; t < T1; ++t) {
       const f32x2 x0 = __builtin_elementwise_fma((f32x2){S[t][0], S[t][1]}, k2, mb2);
       const f32x2 x1 = __builtin_elementwise_fma((f32x2){S[t][2], S[t][3]}, k2, mb2);
       P[t][0] = E::pack2_raw(__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1]));
       P[t][1] = E::pack2_raw(__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1]));
     }
     ATT_MARK(t_x);
+    // O^T = V^T P^T: the P registers are equally the B operand (lane (query j, g): keys 8g..8g+7 of the k-step) and the
+    // transpose-read V fragment the A operand, so lane (query j, group g) ends up with features 4g..4g+3 (and 16+4g..) of ITS
+    // query: 8-byte stores, one reciprocal per lane.  The ones-operand MFMA gives every lane its query's row sum.
     f32x4 O0 = {0.f, 0.f, 0.f, 0.f}, O1 = {0.f, 0.f, 0.f, 0.f}, Ls = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < ATT_NT / 2; ++s) {
+    for (int s = S0; s < S1; ++s) {
       const u32x4 pa = {P[2 * s][0], P[2 * s][1], P[2 * s + 1][0], P[2 * s + 1][1]};
       const V8 pf = __builtin_bit_cast(V8, pa);
       // k-step s = keys 32s..32s+31: elements 0-3 = keys 32s+4g+e (rows 0-15 of the subtile), 4-7 = keys 32s+16+4g+e
@@ -580,21 +597,34 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
       const att_s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + (2 * s + 1) * 128), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + (2 * s + 1) * 128 + 64);
       const V8 v0 = __builtin_bit_cast(V8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
       const V8 v1 = __builtin_bit_cast(V8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-      O0 = E::mfma16(pf, v0, O0);
-      O1 = E::mfma16(pf, v1, O1);
-      Ls = E::mfma16(pf, ones, Ls);
+      O0 = E::mfma16(v0, pf, O0);
+      O1 = E::mfma16(v1, pf, O1);
+      Ls = E::mfma16(ones, pf, Ls);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = 4 * g + r;
-      const float inv = 1.0f / Ls[r];
-      if (q0 + qq < N) {
-        uint16_t* o = p.out + ((size_t)bw * N + q0 + qq) * C + h * 32 + j;
-        o[0] = E::cvt(O0[r] * inv);
-        o[16] = E::cvt(O1[r] * inv);
-      }
+    if (q0 + j < N) {
+      const float inv = __builtin_amdgcn_rcpf(Ls[0]);       // the row sum is >= 1 (the row maximum contributes exp(0)): 1 ulp is plenty
+      uint16_t* o = p.out + ((size_t)bw * N + q0 + j) * C + h * 32 + 4 * g;
+      *reinterpret_cast<u32x2*>(o) = (u32x2){E::pack2(O0[0] * inv, O0[1] * inv), E::pack2(O0[2] * inv, O0[3] * inv)};
+      *reinterpret_cast<u32x2*>(o + 16) = (u32x2){E::pack2(O1[0] * inv, O1[1] * inv), E::pack2(O1[2] * inv, O1[3] * inv)};
     }
     ATT_MARK(t_pv);
+  };
+  using TI0 = std::integral_constant<int, 0>;
+  using TI12 = std::integral_constant<int, 12>;
+  using TI13 = std::integral_constant<int, 13>;
+  using TIN = std::integral_constant<int, NTD>;
+  // depth-split window: host-checked geometry (N = 392, halves of 196 tokens): q-tiles 0..11 live in the first half, 13..24 in the
+  // second, q-tile 12 (tokens 192..207) in both
+  const bool dsplit = p.dsplit_from >= 0 && w >= p.dsplit_from;         // wave-uniform
+  while (qt < q_hi) {
+    const int qt_next = take();
+    const V8 qf_next = q_frag(qt_next);
+    if (!dsplit || qt == 12) tile_body(TI0{}, TIN{}, qf);
+    else if (qt < 12) tile_body(TI0{}, TI13{}, qf);
+    else tile_body(TI12{}, TIN{}, qf);
+#ifdef KVQ_ATT_TRACE
+    ++n_tiles;
+#endif
     qt = qt_next;
     qf = qf_next;
   }
@@ -605,6 +635,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void window_attention_dense_kern
     p.trace[blockIdx.x * 8 + 3] = t_s;
     p.trace[blockIdx.x * 8 + 4] = t_x;
     p.trace[blockIdx.x * 8 + 5] = t_pv;
+    p.trace[blockIdx.x * 8 + 6] = n_tiles;
   }
 #endif
 }
@@ -613,9 +644,7 @@ template <typename E>
 static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
   auto kern = window_attention_dense_kernel<E>;
   static bool attr_set = false;
-  // experiment knob: a larger LDS request lowers the workgroups per CU (3 at 53 KB, 2 above 54 KB), leaving room for
-  // another stream's workgroups on the same CU
-  static const int lds_req = getenv("KVQ_ATT_LDS") ? max(atoi(getenv("KVQ_ATT_LDS")), ATT_D_LDS) : ATT_D_LDS;
+  constexpr int lds_req = ATT_D_LDS;
   if (!attr_set) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       lds_req));
@@ -664,19 +693,30 @@ extern "C" int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_
 
 extern "C" int kvq_window_attention_dense_skip(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
                                                int num_heads, int dtype, uint16_t* out, const uint32_t* tile_skip, void* stream) {
+  KvqAttnDenseArgs a{};
+  a.qkv = qkv; a.bias_dense = bias_dense; a.n_types = n_types; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = num_heads; a.dtype = dtype;
+  a.out = out; a.tile_skip = tile_skip; a.dsplit_from = -1;
+  return kvq_window_attention_dense_args(&a, stream);
+}
+
+extern "C" int kvq_window_attention_dense_args(const KvqAttnDenseArgs* a, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(qkv && bias_dense && out, KVQ_ERR_NULL, "kvq_window_attention_dense: NULL pointer");
+  KVQ_REQUIRE(a && a->qkv && a->bias_dense && a->out, KVQ_ERR_NULL, "kvq_window_attention_dense: NULL pointer");
+  const int BW = a->BW, nW = a->nW, N = a->N, num_heads = a->num_heads, n_types = a->n_types;
   KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
               "kvq_window_attention_dense: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
   KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: window of %d tokens unsupported (1..400)", N);
-  KVQ_REQUIRE(((size_t)bias_dense & 7) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_dense: bias_dense must be 8-byte aligned");
-  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: dtype %d", dtype);
+  KVQ_REQUIRE(((size_t)a->bias_dense & 7) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_dense: bias_dense must be 8-byte aligned");
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: dtype %d", a->dtype);
+  KVQ_REQUIRE(a->dsplit_from < 0 || (N == 392 && a->dsplit_from < nW), KVQ_ERR_UNSUPPORTED,
+              "kvq_window_attention_dense: depth-split windows need the (8,7,7) window (N = 392, halves of 196 tokens); got N=%d from=%d",
+              N, a->dsplit_from);
   // 768 = 256 CUs x 3 resident workgroups: fill them when there are fewer (window, head, clip) units than that
   const int units = BW * num_heads, nqt = (N + 15) / 16;
   int qsplit = units >= 768 ? 1 : 768 / units;
   qsplit = qsplit > 4 ? 4 : qsplit;
   qsplit = qsplit > nqt ? nqt : qsplit;
-  if (getenv("KVQ_ATT_QSPLIT")) qsplit = atoi(getenv("KVQ_ATT_QSPLIT"));
-  AttnDenseParams p{qkv, (const u32x2*)bias_dense, BW, nW, N, num_heads, n_types, qsplit, out, g_trace, g_trace_blocks, tile_skip};
-  return dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16>(p, (hipStream_t)stream) : launch_attn_dense<Bf16>(p, (hipStream_t)stream);
+  AttnDenseParams p{a->qkv, (const u32x2*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, g_trace, g_trace_blocks, a->tile_skip,
+                    a->dsplit_from < 0 ? -1 : a->dsplit_from};
+  return a->dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16>(p, (hipStream_t)stream) : launch_attn_dense<Bf16>(p, (hipStream_t)stream);
 }

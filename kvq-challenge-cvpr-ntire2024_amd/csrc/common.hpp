@@ -158,6 +158,8 @@ extern int g_trace_blocks;
 
 // tile variant the GEMM dispatcher picks for a shape: (MI==NI) * 100 + BK  (gemm.hip)
 int gemm_variant(int M, int N, int K);
+// true: kvq_gemm_bf16 takes the 256 x 256 x 64 eight-phase kernel for this shape (gemm256.hip); profile records carry tile code 4464
+bool gemm8p_wanted(int M, int N, int K);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -181,6 +181,5 @@ struct GemmEpilogue {
 // split-K (checked by the caller through gemm8p_wanted()).
 template <typename E, int EPI>
 int launch_gemm8p(const GemmParams& p, hipStream_t st);
-bool gemm8p_wanted(int M, int N, int K);
 
 }  // namespace kvq

@@ -371,7 +371,7 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
   }
   // algorithmic bytes: A + W once, output once (fp32 residual epilogues read-modify-write)
   const double out_b = (epi == KVQ_EPI_RESID_F32) ? 8.0 : (epi == KVQ_EPI_STORE_F32 ? 4.0 : 2.0);
-  Bracket br(pl, st, kind, gemm_variant(M, N, K) * 10 + epi, 2.0 * M * N * K,
+  Bracket br(pl, st, kind, (gemm8p_wanted(M, N, K) ? 4464 : gemm_variant(M, N, K)) * 10 + epi, 2.0 * M * N * K,
              2.0 * ((double)M * K + (double)N * K) + out_b * M * N);
   return kvq_gemm_bf16(&a, st);
 }
@@ -517,9 +517,14 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         // + the dense bias once per step: 4 B per score of every (window, head)
         Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C,
                    2.0 * 4.0 * M * C + (double)kvq_attn_bias_dense_bytes(bias_types(g, par), g.N, g.nH));
-        static const bool skip_q = !(getenv("KVQ_ATT_SKIP_PAD") && atoi(getenv("KVQ_ATT_SKIP_PAD")) == 0);
-        KVQ_TRY(kvq_window_attention_dense_skip(bbig, bw.bias_dense, bias_types(g, par), B * g.nW, g.nW, g.N, g.nH, pl->dtype, bo,
-                                                skip_q ? (const uint32_t*)g.d_skip[par] : nullptr, st));
+        KvqAttnDenseArgs aa{};
+        aa.qkv = bbig; aa.bias_dense = bw.bias_dense; aa.n_types = bias_types(g, par); aa.BW = B * g.nW; aa.nW = g.nW; aa.N = g.N;
+        aa.num_heads = g.nH; aa.dtype = pl->dtype; aa.out = bo; aa.tile_skip = (const uint32_t*)g.d_skip[par];
+        // shifted blocks of the (8,7,7) window with a half-window depth shift: the last window slab along D is depth-split
+        const int slabs = g.Dp / g.ws[0];
+        aa.dsplit_from = (par == 1 && g.N == 392 && g.ws[0] == 8 && g.ws[1] == 7 && g.ws[2] == 7 && g.ss[0] == 4 && slabs >= 1)
+                             ? g.nW - g.nW / slabs : -1;
+        KVQ_TRY(kvq_window_attention_dense_args(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);
@@ -529,7 +534,9 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
                                      st));
       }
       const int hidden = cfg.mlp_ratio * C;
-      if (bw.tail_pack && kvq_block_tail_supported(C, hidden)) {
+      // KVQ_TAIL_MAXC: widest stage that takes the fused tail launch (wider ones run proj / norm2 / fc1 / fc2 as a GEMM chain)
+      static const int tail_maxc = getenv("KVQ_TAIL_MAXC") ? atoi(getenv("KVQ_TAIL_MAXC")) : 1 << 30;
+      if (bw.tail_pack && C <= tail_maxc && kvq_block_tail_supported(C, hidden)) {
         // proj + window_reverse + roll back + crop + residual + norm2 + Mlp + residual [+ the next block's norm1]
         KvqBlockTailArgs ta{};
         ta.attn = bo; ta.x = cur; ta.scatter_map = g.d_src[par]; ta.map_rows = g.Lp; ta.out_rows = g.L;

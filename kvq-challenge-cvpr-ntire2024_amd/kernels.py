@@ -142,19 +142,20 @@ def attn_bias_dense(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Te
 
 
 def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
-                           tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+                           tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1):
     """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled) + pre-built bias; returns [BW*N, nH*32].  ``n_types`` (default nW):
     window w uses bias w % n_types.  ``tile_skip`` int32 [nW]: bit t = q-tile t of the window is passed over (padding rows only);
-    the rows of such tiles keep what ``out`` held."""
+    the rows of such tiles keep what ``out`` held.  ``dsplit_from`` >= 0: windows >= it are depth-split (shifted (8,7,7) blocks)."""
     _need_gpu(qkv, bias_dense, tile_skip, out)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
     if out is None:
         out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
-    check(lib().kvq_window_attention_dense_skip(ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH,
-                                                dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), current_stream()),
-          "kvq_window_attention_dense")
+    a = _abi.KvqAttnDenseArgs()
+    a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH
+    a.dtype, a.out, a.tile_skip, a.dsplit_from = dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), dsplit_from
+    check(lib().kvq_window_attention_dense_args(C.byref(a), current_stream()), "kvq_window_attention_dense")
     return out
 
 

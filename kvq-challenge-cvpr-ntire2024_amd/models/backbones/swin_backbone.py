@@ -493,6 +493,8 @@ class SwinTransformer3D(nn.Module):
                 tile, epi = divmod(r.variant, 10)
                 mn, bk = divmod(tile, 100)
                 sym = f"gemm_kernel<{ename}, {mn // 10}, {mn % 10}, {bk}, {epi}>"
+                if tile == 4464:            # the 256 x 256 x 64 eight-phase kernel (csrc/gemm256.hip)
+                    sym = f"gemm8p_kernel<{ename}, {epi}>"
             elif kind == "attn" and r.variant >= 4:
                 sym = f"window_attention_dense_kernel<{ename}>"
             elif kind == "attn":

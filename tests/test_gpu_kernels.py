@@ -422,6 +422,38 @@ def test_window_attention_dense_matches_gather_path(dims, window, shifted, gated
     assert torch.equal(part[~skipped], out[~skipped]) and bool((part[skipped] == 7.0).all()) and bool(skipped.any())
 
 
+@pytest.mark.parametrize("dims", [(16, 14, 14), (16, 7, 14), (24, 7, 7)])
+def test_window_attention_dense_depth_split_is_bit_identical(dims, half):
+    """Shifted (8,7,7) blocks: the windows of the last slab along D are depth-split (two halves of 196 tokens the shift mask
+    separates).  ``dsplit_from`` lets their q-tiles pass over the other half's key tiles — the output must equal the full
+    launch bit for bit, for every window (split or not), and the plan-side rule (last nW / slabs windows) must be the split set."""
+    g = rng(sum(dims))
+    window, shift = (8, 7, 7), (4, 3, 3)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, nH, B = lay["N"], lay["nW"], 3, 2
+    assert N == 392 and lay["ss"][0] == 4
+    BW = B * nW
+    qkv = dev(rnd(torch.from_numpy(g.standard_normal((3, nH, BW * N, 32)).astype(np.float32)) * 0.7, half), half)
+    tl = 2535
+    rpb = torch.from_numpy((0.5 * g.standard_normal((tl, nH))).astype(np.float32))
+    fpb = torch.from_numpy((0.5 * g.standard_normal((tl, nH))).astype(np.float32))
+    tok, center = _tok_table(lay, window)
+    dense = kernels.attn_bias_dense(dev(torch.from_numpy(tok)), dev(rpb), dev(fpb), center, nW, N, True)
+    full = kernels.window_attention_dense(qkv, dense, nW, N)
+    slabs = -(-dims[0] // 8)
+    first = nW - nW // slabs
+    # the rule's premise, from the layout's own region ids: in exactly those windows no token of the first half shares a
+    # region with a token of the second half
+    region = (tok.reshape(nW, N, 2)[:, :, 1] >> 16) & 0xff
+    for wv in range(nW):
+        a, b = set(region[wv, :196].tolist()), set(region[wv, 196:].tolist())
+        assert (not (a & b)) == (wv >= first), (wv, first)
+    split = kernels.window_attention_dense(qkv, dense, nW, N, dsplit_from=first)
+    assert torch.equal(split, full)
+    with pytest.raises(RuntimeError):
+        kernels.window_attention_dense(qkv[:, :, : BW * 98].contiguous(), dense, nW, 98, dsplit_from=0)     # not the (8,7,7) window
+
+
 def test_window_attention_dense_softmax_extremes(half):
     g = rng(4)
     lay = O.window_layout(8, 14, 14, (8, 7, 7), (4, 3, 3))

@@ -1,0 +1,138 @@
+// Standalone driver for window_attention_dense_kernel (csrc/attn.hip): random q|k|v and a random bias image in the kernel's layout,
+// sampled rows against a host fp64 softmax, then the launch time at a trunk geometry.
+//   ./attn_bench nW nH nclip N n_types [iters]       (stage 0 of C2: 128 3 4 392 64 | shifted: n_types 128)
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <random>
+#include "attn.hip"
+
+namespace kvq {
+void set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
+int hip_fail(hipError_t e, const char* w) { fprintf(stderr, "HIP %s: %s\n", w, hipGetErrorString(e)); return -1; }
+unsigned long long* g_trace = nullptr;
+int g_trace_blocks = 0;
+}
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; __builtin_memcpy(&u, &h, 2); return u; }
+static float h2f(uint16_t u) { _Float16 h; __builtin_memcpy(&h, &u, 2); return (float)h; }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+  const int nW = argc > 1 ? atoi(argv[1]) : 128, nH = argc > 2 ? atoi(argv[2]) : 3, nclip = argc > 3 ? atoi(argv[3]) : 4;
+  const int N = argc > 4 ? atoi(argv[4]) : 392, ntyp = argc > 5 ? atoi(argv[5]) : 64, iters = argc > 6 ? atoi(argv[6]) : 20;
+  const int BW = nclip * nW, nqt = (N + 15) / 16, NT = kvq::ATT_NT;
+  const size_t Mtot = (size_t)BW * N;
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<uint16_t> hq(3 * (size_t)nH * Mtot * 32);
+  for (size_t i = 0; i < hq.size(); ++i) hq[i] = f2h(U(rng) * (i < hq.size() / 3 ? 0.6f : 1.0f));
+  // bias image: pair = (type, head); [pair][qt][t][lane (q = lane & 15, g = lane >> 4)][r]: key 16 t + 4 g + r
+  const size_t img = (size_t)ntyp * nH * nqt * NT * 256;
+  std::vector<uint16_t> hb(img);
+  for (size_t pr = 0; pr < (size_t)ntyp * nH; ++pr)
+    for (int qt = 0; qt < nqt; ++qt)
+      for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * (lane >> 4) + r;
+            float b = -3.f * fabsf(U(rng));
+            if ((rng() & 31) == 0) b = -100.f;             // a masked score now and then
+            if (key >= N) b = kvq::ATT_DENSE_OFF;
+            hb[((pr * nqt + qt) * NT + t) * 256 + lane * 4 + r] = f2h(b);
+          }
+  uint16_t *dq, *db, *dout;
+  CK(hipMalloc(&dq, hq.size() * 2)); CK(hipMalloc(&db, img * 2)); CK(hipMalloc(&dout, Mtot * nH * 32 * 2));
+  CK(hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), img * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(dout, 0xff, Mtot * nH * 32 * 2));
+  {
+    int nb = 0;
+    for (int lds : {kvq::ATT_D_LDS, 49152, 40960, 65536}) {
+      CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kvq::window_attention_dense_kernel<kvq::Fp16>, 256, lds));
+      printf("occupancy API: %d workgroups per CU at %d B of LDS\n", nb, lds);
+    }
+  }
+  auto run = [&]() { return kvq_window_attention_dense_skip(dq, db, ntyp, BW, nW, N, nH, KVQ_DT_FP16, dout, nullptr, nullptr); };
+  if (run()) return 1;
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> ho(Mtot * nH * 32);
+  CK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+  // sampled rows
+  double maxerr = 0; long bad = 0, rows = 0;
+  std::uniform_int_distribution<int> Ubw(0, BW - 1), Uh(0, nH - 1), Uq(0, N - 1);
+  for (int s = 0; s < 400; ++s) {
+    int bw = Ubw(rng), h = Uh(rng), q = Uq(rng);
+    if (s < 8) { bw = s & 1 ? BW - 1 : 0; h = s & 2 ? nH - 1 : 0; q = s & 4 ? N - 1 : 0; }
+    const int w = bw % nW, wt = w % ntyp;
+    const size_t pr = (size_t)wt * nH + h;
+    const uint16_t* Q = &hq[((size_t)(0 * nH + h) * Mtot + (size_t)bw * N + q) * 32];
+    std::vector<double> sc(N);
+    double mx = -1e300;
+    for (int k = 0; k < N; ++k) {
+      const uint16_t* K = &hq[((size_t)(1 * nH + h) * Mtot + (size_t)bw * N + k) * 32];
+      double d = 0;
+      for (int e = 0; e < 32; ++e) d += (double)h2f(Q[e]) * h2f(K[e]);
+      const int qt = q >> 4, t = k >> 4, lane = (q & 15) + 16 * ((k & 15) >> 2), r = k & 3;
+      d += h2f(hb[((pr * nqt + qt) * NT + t) * 256 + lane * 4 + r]);
+      sc[k] = d; mx = d > mx ? d : mx;
+    }
+    double den = 0; std::vector<double> o(32, 0.0);
+    for (int k = 0; k < N; ++k) {
+      const double pk = exp(sc[k] - mx); den += pk;
+      const uint16_t* V = &hq[((size_t)(2 * nH + h) * Mtot + (size_t)bw * N + k) * 32];
+      for (int e = 0; e < 32; ++e) o[e] += pk * h2f(V[e]);
+    }
+    for (int e = 0; e < 32; ++e) {
+      const double ref = o[e] / den, got = h2f(ho[((size_t)bw * N + q) * (nH * 32) + h * 32 + e]);
+      const double err = fabs(got - ref);
+      if (!(err <= 4e-3)) { if (bad < 5) printf("  mismatch bw %d h %d q %d e %d: got %f ref %f\n", bw, h, q, e, got, ref); ++bad; }
+      maxerr = err > maxerr ? err : maxerr;
+    }
+    ++rows;
+  }
+  printf("check: %ld bad of %ld rows, max |err| %.3g\n", bad, rows, maxerr);
+  long diff = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipMemset(dout, 0xff, Mtot * nH * 32 * 2));
+    run(); CK(hipDeviceSynchronize());
+    std::vector<uint16_t> h2(ho.size());
+    CK(hipMemcpy(h2.data(), dout, h2.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h2.size(); ++i) diff += h2[i] != ho[i];
+  }
+  printf("repeat screen: %ld differing elements\n", diff);
+#ifdef KVQ_ATT_TRACE
+  {
+    const int nb = 4096;
+    unsigned long long* dt; CK(hipMalloc(&dt, nb * 64)); CK(hipMemset(dt, 0, nb * 64));
+    kvq::g_trace = dt; kvq::g_trace_blocks = nb;
+    run(); CK(hipDeviceSynchronize());
+    kvq::g_trace = nullptr;
+    std::vector<unsigned long long> ht(nb * 8);
+    CK(hipMemcpy(ht.data(), dt, nb * 64, hipMemcpyDeviceToHost));
+    double st = 0, lp = 0, ts = 0, tx = 0, tp = 0, nt = 0; int n = 0;
+    for (int b = 0; b < nb; ++b) if (ht[b * 8 + 2]) {
+      st += ht[b * 8 + 1] - ht[b * 8]; lp += ht[b * 8 + 2] - ht[b * 8 + 1]; ts += ht[b * 8 + 3]; tx += ht[b * 8 + 4]; tp += ht[b * 8 + 5]; nt += ht[b * 8 + 6]; ++n;
+    }
+    printf("trace (%d workgroups, wave 0): staging %.0f ticks, q-tile loop %.0f ticks, %.2f q-tiles -> per q-tile: bias+QK %.0f, max/exp %.0f, PV+store %.0f = %.0f ticks\n",
+           n, st / n, lp / n, nt / n, ts / nt, tx / nt, tp / nt, (ts + tx + tp) / nt);
+  }
+#endif
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) run();
+  float best = 1e30f, tot = 0;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) run();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    best = ms < best ? ms : best; tot += ms;
+  }
+  const double fl = 4.0 * (double)Mtot * N * nH * 32;
+  const double qtiles = (double)BW * nH * nqt;
+  printf("nW=%d nH=%d clips=%d N=%d types=%d: %.1f us mean, %.1f best -> %.1f TF/s (%.1f best); %.0f q-tiles -> %.0f cycles per q-tile per SIMD at 2.1 GHz\n",
+         nW, nH, nclip, N, ntyp, tot / 5 * 1e3, best * 1e3, fl / (tot / 5 * 1e-3) / 1e12, fl / (best * 1e-3) / 1e12, qtiles,
+         tot / 5 * 1e-3 * 2.1e9 / (qtiles / 1024.0));
+  return bad || diff;
+}
