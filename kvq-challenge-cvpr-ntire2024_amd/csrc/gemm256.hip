@@ -95,7 +95,9 @@ bool gemm8p_wanted(int M, int N, int K) {
   if (mode == 1) return true;
   const long tiles = (long)ceil_div(M, g8::BM) * ceil_div(N, g8::BN);
   const double fill = (double)M * N / ((double)tiles * g8::BM * g8::BN);     // useful part of the tile grid
-  return tiles >= 192 && fill >= 0.8 && K >= 256;
+  // measured (profiles/r03_gemm_sweep*.txt): ahead of the ring kernel from ~120 tiles on (3136 x 3072 x 768, 156 tiles: 22.6 vs
+  // 29.5 us; 3136 x 2304 x 768, 117 tiles: level), behind it below (84 tiles: 20.2 vs 19.0 us; 39-98 tiles of long K: 1.2-2x slower)
+  return tiles >= 128 && fill >= 0.8 && K >= 256;
 }
 
 }  // namespace kvq

@@ -215,6 +215,37 @@ def test_config5_swin_b_padded_windows_vs_oracle():
     assert (score - s_ref).abs().max().item() <= SCORE_TOL, (score, s_ref)
 
 
+@pytest.mark.slow
+def test_config5_swin_b_at_its_own_geometry_vs_oracle():
+    """BASELINE config 5 at ITS geometry: one 3 x 64 x 256 x 256 clip through Swin3D-B, fp16 — the grids whose stage-0 windows pad
+    64 -> 70, the q-tiles of padding rows the attention passes over (``tile_skip``), ``kvq_qkv_fill_pad``, the token-walking
+    C = 256 / 512 tails at 8 192 / 2 048 rows per clip, the dense bias of all 24 blocks (5.4 GiB), the depth-split windows of the
+    shifted blocks and the 256 x 256 x 64 eight-phase GEMM on the qkv / stage-3 shapes — against the CPU oracle run on the box
+    (about a minute on its host cores).  Score within 1e-3, feature map within 6e-3 relative L2."""
+    from kvq_amd.models.backbones.swin_backbone import SwinTransformer3D
+    from kvq_amd.models.head import VQAHead
+    cfg = synth.SWIN_B_GRPB
+    wts = synth.synth_swin_weights(cfg, 31, "stress")
+    hw = synth.synth_vqa_head_weights(cfg.num_features, 64, 31, "stress")
+    bb = SwinTransformer3D(embed_dim=128, depths=list(cfg.depths), num_heads=list(cfg.num_heads))
+    missing = bb.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=False)
+    assert not missing.unexpected_keys
+    head = VQAHead(in_channels=cfg.num_features, hidden_channels=64)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()})
+    bb, head = bb.to(DEV).eval(), head.to(DEV).eval()
+    x = torch.from_numpy(synth.synth_clip(64256, 64, 256, 256, batch=1))
+    with torch.no_grad():
+        feat = bb({"technical": x.to(DEV)})
+        score = head(feat).cpu()
+        assert sum(b is not None for v in bb._dense.values() for b in v) == sum(cfg.depths)      # every block on the dense bias
+        f_ref = O.swin3d_trunk(x, wts, cfg)
+        s_ref = O.vqa_head(f_ref, hw)
+    assert feat.shape == f_ref.shape == (1, 1024, 32, 8, 8)
+    rel = ((feat.cpu() - f_ref).norm() / f_ref.norm()).item()
+    assert rel <= 6e-3, rel
+    assert (score - s_ref).abs().max().item() <= SCORE_TOL, (score, s_ref)
+
+
 def test_config3_trunk_and_slowfast_on_the_same_clips():
     """BASELINE config 3: the Swin trunk and the SlowFast motion branch consume the same 32x224x224 clips in
     one process (no disk round trip of .npy features); both outputs finite and shaped as the reference's."""

@@ -123,6 +123,35 @@ def test_simplevqa_network_vs_reference_golden(golden, case):
 
 
 @gpu
+@pytest.mark.slow
+def test_simplevqa_network_at_c1_size_vs_oracle():
+    """BASELINE configs[0] at ITS OWN size (config/kwai_simpleVQA_test.yml: 8 frames of 448 x 448, 8 x 2304 SlowFast features): the
+    HIP path through VQA_Network against the pinned CPU oracle run here (a few seconds) — score within 1e-3, pooled ResNet features
+    within 5e-3 relative L2, the motion features untouched."""
+    from kvq_amd.models import VQA_Network
+    rng = np.random.Generator(np.random.PCG64(448))
+    frames = torch.from_numpy(rng.standard_normal((1, 3, 8, 448, 448)).astype(np.float32))
+    feat3d = torch.from_numpy(rng.standard_normal((1, 8, 2304)).astype(np.float32))
+    rw, hw = synth.synth_resnet50_weights(4, "stress"), synth.synth_simple_head_weights(9472, 128, 4, "stress")
+    f_ref = RO.simplevqa_features(frames, feat3d, rw)
+    s_ref = O.simple_vqa_head(f_ref, hw)
+    net = VQA_Network({"model": {"args": {"simpleVQA": {"backbone": None, "head": {"in_channels": 9472,
+                                                                                    "hidden_channels": 128}}}}})
+    sd = {f"simpleVQA_backbone.{k}": torch.from_numpy(np.asarray(v)) for k, v in rw.items()}
+    sd.update({f"simpleVQA_head.{k}": torch.from_numpy(v) for k, v in hw.items()})
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        score, feats = net(inputs={"simpleVQA": frames.cuda(), "feat": feat3d.cuda()}, reduce_scores=True, return_pooled_feats=True)
+    f = feats["simpleVQA"].cpu()
+    assert f.shape == f_ref.shape == (1, 8, 9472)
+    rel = ((f[..., :7168] - f_ref[..., :7168]).norm() / f_ref[..., :7168].norm()).item()
+    assert rel <= 5e-3, rel
+    assert torch.equal(f[..., 7168:], f_ref[..., 7168:])
+    assert (score.cpu() - s_ref).abs().max().item() <= 1e-3, (score, s_ref)
+
+
+@gpu
 @pytest.mark.parametrize("C", [40, 6])          # C % 8 == 0: the 8-channel-per-thread kernel; 6: the scalar one
 def test_pool_vector_and_scalar_paths_agree_with_torch(C):
     from kvq_amd import kernels
