@@ -16,6 +16,13 @@ One JSON line on rank 0 with the contract's keys plus
   c3            BASELINE configs[2]: Swin3D-T + SlowFast-R50 on the same 8 clips (1 video per step)
   c5            BASELINE configs[4]: Swin-B on 64x256x256 clips, fp16 (video = 16 clips)
 (the extra legs run at N = 1; ``--legs c2`` skips them).
+
+Timing: the K-step block (barrier + sync, K steps, sync + barrier, max over ranks) is REPEATED until about a second of steps has been
+timed; ``ms_per_step`` / ``value`` are the MEDIAN block, ``repeats`` / ``ms_per_step_min`` / ``ms_per_step_max`` say how the blocks
+spread (a single 20-step block is 30 ms: box-to-box and clock noise are larger than most kernel changes).
+HBM traffic (``roofline.traffic``, ``whole_step_traffic``): measured in this run by two child passes per leg under
+``rocprofv3 --pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` (``bench.py --probe LEG``: a few serial steps of the leg, nothing else), FETCH_SIZE
+doubled as the gfx950 guide prescribes; ``--no-pmc`` skips them (null).
 """
 import argparse
 import json
@@ -54,6 +61,11 @@ def parse():
     ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,c3,c5 ('all', 'c2' = none)")
     ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the K-step block until this many seconds are timed")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic fields = null)")
+    ap.add_argument("--probe", default=None, choices=["c2", "c3", "c5"],
+                    help="internal: run --probe-steps serial steps of one leg and exit (the command the --pmc passes profile)")
+    ap.add_argument("--probe-steps", type=int, default=2)
     return ap.parse_args()
 
 
@@ -150,34 +162,126 @@ def run_lanes(lanes, n, fn):
     return outs
 
 
-def timed(kd, device, fn_steps, steps, warmup, finish=None, first=None):
-    """W untimed steps, barrier + sync, K timed steps (+ ``finish``: the path's exchange step), sync + barrier; max over ranks.
-    ``first``: index of the first TIMED step (default: behind the warm-up steps) — legs that compare scores time the same steps."""
+def timed(kd, device, fn_steps, steps, warmup, finish=None, first=None, min_s=0.0):
+    """W untimed steps, then the timed block — barrier + sync, EXACTLY K steps (+ ``finish``: the path's exchange step), sync +
+    barrier, max over ranks — repeated until ``min_s`` seconds of blocks have been timed (the repeat count follows from the first
+    block's max-over-ranks time, so every rank runs the same number).  Returns (median block seconds, outputs of the last block,
+    finish's result, stats).  ``first``: index of the first TIMED step (default: behind the warm-up steps); every block runs the
+    same steps — legs that compare scores time the same clips."""
     import torch
     first = warmup if first is None else first
     fn_steps(warmup, max(0, first - warmup))
     torch.cuda.synchronize()
-    kd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = fn_steps(steps, first)
-    extra = finish(outs) if finish is not None else None
-    torch.cuda.synchronize()
-    kd.barrier()
-    torch.cuda.synchronize()
-    return kd.max_over_ranks(time.perf_counter() - t0, device), outs, extra
+
+    def block():
+        kd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = fn_steps(steps, first)
+        extra = finish(outs) if finish is not None else None
+        torch.cuda.synchronize()
+        kd.barrier()
+        torch.cuda.synchronize()
+        return kd.max_over_ranks(time.perf_counter() - t0, device), outs, extra
+
+    dt, outs, extra = block()
+    dts = [dt]
+    reps = int(min(200, max(1, -(-min_s // max(dt, 1e-6)))))
+    for _ in range(reps - 1):
+        dt, outs, extra = block()
+        dts.append(dt)
+    srt = sorted(dts)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    stats = {"repeats": len(dts), "ms_per_step_min": 1e3 * srt[0] / steps, "ms_per_step_max": 1e3 * srt[-1] / steps,
+             "timed_s": sum(dts)}
+    return med, outs, extra, stats
 
 
-def c2_roofline(net, inputs, B, profile_steps):
-    import torch
-    bb = net.swin_tiny_grpb_backbone
-    dev = inputs["technical"].device
-    bb.profile(B, 32, 224, 224, dev, True)
-    with torch.no_grad():
-        for _ in range(profile_steps):
-            net(inputs=inputs, reduce_scores=True)
-    recs = bb.profile_read(B, 32, 224, 224, dev)
-    bb.profile(B, 32, 224, 224, dev, False)
+# ---- HBM traffic, measured: child passes of this file under rocprofv3 --pmc ------------------------------------------------
+ONE_TIME_KERNELS = ("bias_dense_kernel", "bias_rowmax_kernel", "tail_pack", "tail16_pack", "pack_", "at::native", "Cijk_", "fill_", "copyBuffer")
+
+
+def kernel_norm(name):
+    """'void kvq::block_tailmm_kernel<kvq::Fp16, true, 0, true, 3>(KvqBlockTailArgs)' -> 'block_tailmm_kernel<kvq::Fp16, true, 0, true, 3>'"""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    if name.endswith(")") and "(" in name:
+        name = name[: name.rfind("(")]
+    return name[5:] if name.startswith("kvq::") else name
+
+
+def kernel_base(name):
+    """... -> 'block_tailmm_kernel' (the rocprof symbol of gemm_kernel carries more template arguments than the profile label)"""
+    name = kernel_norm(name)
+    return name.split("<")[0].split("::")[-1]
+
+
+def pmc_traffic(leg, steps, dtype, batch):
+    """{'per_kernel': {base name: {'bytes_per_launch', 'fetch', 'write', 'launches'}}, 'step_bytes', 'steps'} or {'error': ...}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="kvq_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(var, None)
+    try:
+        for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):      # KB; FETCH_SIZE x2 on gfx950 (MI355X guide, HBM)
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "c", "--", sys.executable, os.path.abspath(__file__),
+                   "--probe", leg, "--probe-steps", str(steps), "--dtype", dtype, "--batch", str(batch)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter or any(k in row["Kernel_Name"] for k in ONE_TIME_KERNELS):
+                    continue
+                for key in {kernel_norm(row["Kernel_Name"]), kernel_base(row["Kernel_Name"])}:
+                    e = acc.setdefault(key, {"fetch": 0.0, "write": 0.0, "n_fetch": 0, "n_write": 0})
+                    e["fetch" if counter == "FETCH_SIZE" else "write"] += scale * float(row["Counter_Value"])
+                    e["n_fetch" if counter == "FETCH_SIZE" else "n_write"] += 1
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per = {}
+    total = 0.0
+    for k, e in acc.items():
+        n = max(e["n_fetch"], e["n_write"], 1)
+        per[k] = {"fetch": e["fetch"] / n, "write": e["write"] / n, "bytes_per_launch": (e["fetch"] + e["write"]) / n, "launches": n}
+        if "<" not in k and "::" not in k:            # every launch is counted once under its base name
+            total += e["fetch"] + e["write"]
+    return {"per_kernel": per, "step_bytes": total / steps, "steps": steps,
+            "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE in separate child passes of `bench.py --probe "
+                      f"{leg}` ({steps} serial steps); one-time builder / torch kernels excluded"}
+
+
+def attach_traffic(roof, pmc):
+    """dominant kernel's measured bytes per launch + the whole step's bytes into a roofline dict"""
+    if roof is None:
+        return
+    if not pmc or "error" in pmc:
+        roof["traffic"] = None
+        roof["traffic_note"] = (pmc or {}).get("error", "skipped (--no-pmc)")
+        return
+    row = pmc["per_kernel"].get(kernel_norm(roof["kernel"])) or pmc["per_kernel"].get(kernel_base(roof["kernel"]))
+    roof["traffic"] = row["bytes_per_launch"] if row else None
+    roof["traffic_detail"] = row
+    roof["whole_step_traffic"] = pmc["step_bytes"]
+    roof["traffic_source"] = pmc["method"]
+
+
+def roofline_from_records(recs, n_steps, gflop_per_step):
+    """recs: [{kernel, ms, flops, bytes}] of n_steps steps, one launch each -> the dominant kernel's roofline (algorithmic flops or
+    bytes of its launches / their hipEvent-measured time) + the per-kernel table + the whole step against the MFMA peak."""
     agg = {}
     for r in recs:
         a = agg.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
@@ -191,32 +295,41 @@ def c2_roofline(net, inputs, B, profile_steps):
     else:
         ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
-    # HBM traffic of that kernel: PMC counters cannot be read from inside this process — they come from a SEPARATE
-    # `rocprofv3 --pmc` pass over this same command (tools/pmc_traffic.py -> profiles/pmc_traffic.json; FETCH_SIZE x2 as the
-    # gfx950 guide prescribes), per launch like `achieved`; null when that file has no row for the kernel
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        row = pmc["kernels"].get(name)
-        if row:
-            roof["traffic"] = row["fetch_bytes"] + row["write_bytes"]
-            roof["traffic_source"] = f"profiles/pmc_traffic.json ({pmc.get('build', 'separate rocprofv3 --pmc pass')})"
-    except (OSError, ValueError, KeyError):
-        pass
-    roof.update({"kernel": name, "launches_per_step": top["n"] / profile_steps, "avg_launch_us": 1e3 * top["ms"] / top["n"],
+    roof.update({"kernel": name, "launches_per_step": top["n"] / n_steps, "avg_launch_us": 1e3 * top["ms"] / top["n"],
                  "share_of_gpu_time": top["ms"] / total_ms, "alg_flops_per_launch": top["flops"] / top["n"],
-                 "alg_bytes_per_launch": top["bytes"] / top["n"], "step_gpu_ms": total_ms / profile_steps,
-                 "whole_step_tflops": SWIN_T_GFLOP_PER_CLIP * B / (total_ms / profile_steps),
-                 "whole_step_frac": SWIN_T_GFLOP_PER_CLIP * B / (total_ms / profile_steps) / MFMA_PEAK_TFLOPS,
-                 "by_kernel_ms_per_step": {k: round(v["ms"] / profile_steps, 4)
+                 "alg_bytes_per_launch": top["bytes"] / top["n"], "step_gpu_ms": total_ms / n_steps,
+                 "whole_step_tflops": gflop_per_step / (total_ms / n_steps),
+                 "whole_step_frac": gflop_per_step / (total_ms / n_steps) / MFMA_PEAK_TFLOPS,
+                 "timing": "hipEvent brackets around every launch, on the stream the launches go to (kvq_swin3d_profile / "
+                           "kvq_convnet_profile), steps run one after the other",
+                 "by_kernel_ms_per_step": {k: round(v["ms"] / n_steps, 4)
                                            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}})
     return roof
 
 
-def leg_c3(args, device, net, src, kd):
+def trunk_records(bb, fwd, B, T, H, W, dev, n_steps):
+    import torch
+    bb.profile(B, T, H, W, dev, True)
+    with torch.no_grad():
+        for _ in range(n_steps):
+            fwd()
+    torch.cuda.synchronize()
+    recs = bb.profile_read(B, T, H, W, dev)
+    bb.profile(B, T, H, W, dev, False)
+    return recs
+
+
+def c2_roofline(net, inputs, B, profile_steps):
+    bb = net.swin_tiny_grpb_backbone
+    recs = trunk_records(bb, lambda: net(inputs=inputs, reduce_scores=True), B, 32, 224, 224, inputs["technical"].device, profile_steps)
+    return roofline_from_records(recs, profile_steps, SWIN_T_GFLOP_PER_CLIP * B)
+
+
+def setup_c3(args, device, net, src):
     """configs[2]: one video (8 clips) per step: K1 -> Swin3D-T + head on one stream, pathway packing + SlowFast-R50 (blocks
     0-4 + pools) on a second stream, both from the same sampled batch; consecutive videos alternate over two lane pairs."""
     import torch
-    from kvq_amd.models.backbones.slowfast_model import conv_flops, slowfast
+    from kvq_amd.models.backbones.slowfast_model import slowfast
     sf = slowfast(operand_dtype=args.dtype, two_lanes=False).to(device).eval()     # the trunk already fills the chip from its stream
     B = 8
     nl = 2
@@ -250,28 +363,56 @@ def leg_c3(args, device, net, src, kd):
             main.wait_stream(st)
         return outs
 
+    def serial(n):      # the probe: the same launches, one after the other on the current stream
+        for s in range(n):
+            src.sample_into(xs[0], s * B)
+            net(inputs={"technical": xs[0]}, reduce_scores=True)
+            sf.forward_clips(xs[0])
+
+    return sf, B, xs, steps, serial
+
+
+def leg_c3(args, device, net, src, kd, pmc):
+    import torch
+    from kvq_amd.models.backbones.slowfast_model import conv_flops
+    sf, B, xs, steps, _ = setup_c3(args, device, net, src)
     k = max(2, min(args.steps, 20))
     with torch.no_grad():
-        dt, outs, _ = timed(kd, device, steps, k, max(2, min(args.warmup, 5)))
+        dt, outs, _, stats = timed(kd, device, steps, k, max(2, min(args.warmup, 5)), min_s=args.min_timed_s)
     sf_flops, _ = conv_flops(32, 224, 224)
     flops = B * (SWIN_T_GFLOP_PER_CLIP * 1e9 + sf_flops)
     ach = flops * k / dt / 1e12
     finite = all(bool(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() and torch.isfinite(o[2]).all()) for o in outs[-2:])
-    return {"workload": "C3: K1 + Swin3D-T(GRPB) trunk + VQAHead and SlowFast-R50 (blocks 0-4 + pools) on the same 8 clips, "
-            "1 video per step, two branches on two HIP streams", "value": k / dt, "unit": "videos/s", "steps": k,
-            "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": args.dtype, "finite": finite,
-            "alg_gflop_per_clip": {"swin3d_t": SWIN_T_GFLOP_PER_CLIP, "slowfast_r50": sf_flops / 1e9,
-                                   "slowfast_counted_from": "kvq_amd.models.backbones.slowfast_model.conv_flops (2*MAC of every Conv3d "
-                                   "of the restated pytorchvideo R50 8x8, the shapes oracle/slowfast_oracle.py runs)"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                         "scope": "whole step (both branches), wall time", "traffic": None,
-                         "per_kernel": "profiles/r02_c3_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/c3_probe.py)"}}
+    # per-kernel view of one video: the trunk's launches (hipEvent brackets) + every op of the SlowFast plan (kvq_convnet_profile)
+    roof = None
+    if args.profile_steps > 0:
+        with torch.no_grad():
+            src.sample_into(xs[0], 0)
+            recs = trunk_records(net.swin_tiny_grpb_backbone, lambda: net(inputs={"technical": xs[0]}, reduce_scores=True), B, 32, 224, 224,
+                                 device, 1)
+            for r in sf.profile_layers(xs[0]):
+                recs.append({"kernel": "slowfast:" + r["kind"] + (f" {r['M']}x{r['N']}x{r['K']}" if r["M"] else " " + r["name"][-24:]),
+                             "ms": r["ms"], "flops": r["tflops"] * 1e12 * r["ms"] * 1e-3, "bytes": 0.0})
+        roof = roofline_from_records(recs, 1, flops / 1e9)
+        attach_traffic(roof, pmc)
+    out = {"workload": "C3: K1 + Swin3D-T(GRPB) trunk + VQAHead and SlowFast-R50 (blocks 0-4 + pools) on the same 8 clips, "
+           "1 video per step, two branches on two HIP streams", "value": k / dt, "unit": "videos/s", "steps": k,
+           "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": args.dtype, "finite": finite,
+           "alg_gflop_per_clip": {"swin3d_t": SWIN_T_GFLOP_PER_CLIP, "slowfast_r50": sf_flops / 1e9,
+                                  "slowfast_counted_from": "kvq_amd.models.backbones.slowfast_model.conv_flops (2*MAC of every Conv3d "
+                                  "of the restated pytorchvideo R50 8x8, the shapes oracle/slowfast_oracle.py runs)"},
+           "whole_step": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                          "scope": "whole step (both branches), wall time"},
+           "roofline": roof}
+    out.update(stats)
+    return out
 
 
-def leg_c5(args, device, kd):
-    """configs[4]: Swin-B (E=128, depths 2/2/18/2, heads 4/8/16/32) on 64x256x256 clips, fp16 operands; video = 16 clips."""
+def setup_c5(args, device):
+    """configs[4]: Swin-B (E=128, depths 2/2/18/2, heads 4/8/16/32) on 64x256x256 clips, fp16 operands; video = 16 clips.  K1 is in
+    the step: every clip is gathered as an 8 x 8 grid of 32 x 32 patches (per-8-frame offsets) out of a uint8 3x64x540x960 source."""
     import torch
-    from kvq_amd import _abi
+    from kvq_amd import _abi, kernels
     from kvq_amd.models.backbones.swin_backbone import SwinTransformer3D
     from kvq_amd.models.head import VQAHead
     from kvq_amd.utils import synth
@@ -282,32 +423,94 @@ def leg_c5(args, device, kd):
     B = 4
     g = torch.Generator(device=device)
     g.manual_seed(77)
-    pool = [torch.randn(B, 3, 64, 256, 256, device=device, generator=g) for _ in range(3)]     # 3 x 201 MB: distinct per step
+    npool = 8                                                                                   # 8 x 99.5 MB of uint8 frames: distinct per step pair
+    clips = [torch.randint(0, 256, (3, 64, SRC_H, SRC_W), dtype=torch.uint8, device=device, generator=g) for _ in range(npool)]
+    gh = torch.tensor([min(SRC_H // 8 * i, SRC_H - 32) for i in range(8)]).view(8, 1, 1)
+    gw = torch.tensor([min(SRC_W // 8 * i, SRC_W - 32) for i in range(8)]).view(1, 8, 1)
+    hoff, woff = [], []
+    for i in range(npool):
+        cg = torch.Generator().manual_seed(7700 + i)
+        hoff.append((torch.randint(SRC_H // 8 - 32, (8, 8, 8), generator=cg) + gh).int().to(device))
+        woff.append((torch.randint(SRC_W // 8 - 32, (8, 8, 8), generator=cg) + gw).int().to(device))
     lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device)]
+    xs = [torch.empty(B, 3, 64, 256, 256, device=device) for _ in lanes]
     with torch.no_grad():
         for st in lanes:
             with torch.cuda.stream(st):
                 bb.prepare(B, 64, 256, 256, device)
         torch.cuda.synchronize()
 
-    def steps(n, first):
-        return run_lanes(lanes, n, lambda s, ln: head(bb({"technical": pool[(first + s) % len(pool)]})))
+    def one(s, ln):
+        for b in range(B):
+            i = (s * B + b) % npool
+            kernels.fragment_gather(clips[i], hoff[i], woff[i], 8, 8, 32, 32, 8, MEAN, STD, out=xs[ln][b])
+        return head(bb({"technical": xs[ln]}))
 
+    def steps(n, first):
+        return run_lanes(lanes, n, lambda s, ln: one(first + s, ln))
+
+    def serial(n):
+        for s in range(n):
+            one(s, 0)
+
+    return bb, head, B, xs, steps, serial
+
+
+def leg_c5(args, device, kd, pmc):
+    import torch
+    bb, head, B, xs, steps, _ = setup_c5(args, device)
     k = max(2, min(args.steps, 10))
     with torch.no_grad():
-        dt, outs, _ = timed(kd, device, steps, k, 2)
+        dt, outs, _, stats = timed(kd, device, steps, k, 2, min_s=args.min_timed_s)
     ach = SWIN_B_GFLOP_PER_CLIP * B * k / dt / 1e3
-    return {"workload": "C5: Swin-B(GRPB) trunk + VQAHead, 3x64x256x256 clips, fp16 operands, video = 16 clips", "value": B * k / 16.0 / dt,
-            "unit": "videos/s", "steps": k, "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": "fp16",
-            "finite": bool(torch.isfinite(torch.cat([o.reshape(-1) for o in outs])).all()),
-            "alg_gflop_per_clip": SWIN_B_GFLOP_PER_CLIP,
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                         "scope": "whole step, wall time", "traffic": None,
-                         "per_kernel": "profiles/r02_c5_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/swinb_probe.py)"}}
+    roof = None
+    if args.profile_steps > 0:
+        recs = trunk_records(bb, lambda: head(bb({"technical": xs[0]})), B, 64, 256, 256, device, 1)
+        roof = roofline_from_records(recs, 1, SWIN_B_GFLOP_PER_CLIP * B)
+        attach_traffic(roof, pmc)
+    out = {"workload": "C5: K1 (8x8 grid of 32x32 patches out of uint8 3x64x540x960) + Swin-B(GRPB) trunk + VQAHead, 3x64x256x256 clips, "
+           "fp16 operands, video = 16 clips", "value": B * k / 16.0 / dt,
+           "unit": "videos/s", "steps": k, "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": "fp16",
+           "finite": bool(torch.isfinite(torch.cat([o.reshape(-1) for o in outs])).all()),
+           "alg_gflop_per_clip": SWIN_B_GFLOP_PER_CLIP,
+           "whole_step": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                          "scope": "whole step, wall time"},
+           "roofline": roof}
+    out.update(stats)
+    return out
+
+
+def run_probe(args):
+    """`bench.py --probe LEG`: what the rocprofv3 --pmc child passes profile — set the leg up, run --probe-steps steps of it one
+    after the other on one stream, exit.  No timing, no JSON."""
+    import torch
+    import kvq_amd  # noqa: F401
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    with torch.no_grad():
+        if args.probe == "c5":
+            *_, serial = setup_c5(args, device)
+            serial(args.probe_steps)
+        else:
+            net, *_ = build_net(args.dtype, device)
+            B = args.batch if args.probe == "c2" else 8
+            src = Source(max(B, 2 * B), device, 1234)
+            if args.probe == "c2":
+                net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
+                x = torch.empty(B, 3, 32, 224, 224, device=device)
+                for s in range(args.probe_steps):
+                    src.sample_into(x, s * B)
+                    net(inputs={"technical": x}, reduce_scores=True)
+            else:
+                *_, serial = setup_c3(args, device, net, src)
+                serial(args.probe_steps)
+    torch.cuda.synchronize()
 
 
 def main():
     args = parse()
+    if args.probe:
+        return run_probe(args)
     import torch
     import kvq_amd  # noqa: F401
     from kvq_amd import _abi, dist as kd
@@ -395,8 +598,8 @@ def main():
 
     sampler_on = not (args.no_sampler or args.graph)
     with torch.no_grad():
-        dt, outs, allscores = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps, args.warmup,
-                                    finish)
+        dt, outs, allscores, tstats = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
+                                            args.warmup, finish, min_s=args.min_timed_s)
     clips = args.steps * B * world
     value = clips / CLIPS_PER_VIDEO / dt
     fp_scores = torch.cat([o.reshape(-1) for o in outs]).float().cpu()
@@ -404,9 +607,11 @@ def main():
     out = None
     if rank == 0:
         roof = None
+        want_pmc = world == 1 and not args.no_pmc and args.profile_steps > 0
         if args.profile_steps > 0:
             src.sample_into(xs[0], 0)
             roof = c2_roofline(net, {"technical": xs[0]}, B, args.profile_steps)
+            attach_traffic(roof, pmc_traffic("c2", 2, args.dtype, B) if want_pmc else None)
         out = {
             "metric": "videos/sec (8-frag x 32 x 224 x 224)", "value": value, "unit": "videos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -420,6 +625,9 @@ def main():
                        "sampler_in_step": sampler_on, "source_pool_clips": src.n, "distinct_clips_per_step": True,
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
                        "streams": nstream, "overlap": "steps" if nstream > 1 else "none", "hipgraph": bool(args.graph)},
+            "repeats": tstats["repeats"], "ms_per_step_min": tstats["ms_per_step_min"], "ms_per_step_max": tstats["ms_per_step_max"],
+            "timed_s": tstats["timed_s"], "timing": "median of `repeats` blocks of exactly `steps` steps, each bracketed by barrier + "
+                                                    "synchronize and reduced to the max over ranks",
             "clips_per_s": clips / dt,
             "model_tflops": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3,
             "whole_job_frac_of_mfma_peak": SWIN_T_GFLOP_PER_CLIP * clips / dt / 1e3 / MFMA_PEAK_TFLOPS / world,
@@ -430,9 +638,9 @@ def main():
     if rank == 0 and world == 1:
         with torch.no_grad():
             if "no_sampler" in legs and sampler_on:
-                dt2, _, _ = timed(kd, device, steps_of(step_presampled), args.steps, min(args.warmup, 5))
+                dt2, _, _, st2 = timed(kd, device, steps_of(step_presampled), args.steps, min(args.warmup, 5), min_s=args.min_timed_s)
                 out["no_sampler"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt2, "unit": "videos/s",
-                                     "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
+                                     "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps, "repeats": st2["repeats"],
                                      "note": "same steps on pre-sampled fp32 clips (K1 outside the timed region, distinct clips per "
                                              "step): the round-1 definition of the step"}
             if "bf16" in legs and args.dtype == "fp16":
@@ -441,11 +649,11 @@ def main():
                     with torch.cuda.stream(st):
                         bb.prepare(B, 32, 224, 224, device)
                 torch.cuda.synchronize()
-                dt3, outs3, _ = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
-                                      min(args.warmup, 5), first=args.warmup)       # the SAME clips as the fp16 line
+                dt3, outs3, _, st3 = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
+                                           min(args.warmup, 5), first=args.warmup, min_s=args.min_timed_s)       # the SAME clips as the fp16 line
                 bf = torch.cat([o.reshape(-1) for o in outs3]).float().cpu()
                 out["bf16"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt3, "unit": "videos/s", "ms_per_step": 1e3 * dt3 / args.steps,
-                               "steps": args.steps, "max_abs_dscore_vs_fp16": float((bf - fp_scores).abs().max()),
+                               "steps": args.steps, "repeats": st3["repeats"], "max_abs_dscore_vs_fp16": float((bf - fp_scores).abs().max()),
                                "parity": "bf16 operands do NOT hold the 1e-3 gate against the fp32 oracle on these 'stress' weights "
                                          "(tests/test_gpu_e2e.py: 1.4e-3..3.1e-3; the 8-bit mantissa is the limit, DESIGN.md §2); fp16 "
                                          "operands do (<= 3.6e-4) and are the default"}
@@ -454,10 +662,11 @@ def main():
                     with torch.cuda.stream(st):
                         bb.prepare(B, 32, 224, 224, device)
                 torch.cuda.synchronize()
-        for name, fn in (("c3", lambda: leg_c3(args, device, net, src, kd)), ("c5", lambda: leg_c5(args, device, kd))):
+        for name, fn in (("c3", lambda pm: leg_c3(args, device, net, src, kd, pm)), ("c5", lambda pm: leg_c5(args, device, kd, pm))):
             if name in legs:
                 try:
-                    out[name] = fn()
+                    pm = pmc_traffic(name, 1, args.dtype, B) if want_pmc else None
+                    out[name] = fn(pm)
                 except Exception as e:  # noqa: BLE001  (an extra leg must not take the headline line down with it)
                     out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 torch.cuda.empty_cache()

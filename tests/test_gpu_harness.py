@@ -113,7 +113,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", KVQ_DIST_BACKEND="gloo",
                KVQ_BENCH_ONE_GPU="1", PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--profile-steps", "0", "--batch", "2"]
+           "--profile-steps", "0", "--batch", "2", "--min-timed-s", "0.05"]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=tmp_path,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
@@ -123,6 +123,8 @@ def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and d["value"] > 0
     assert abs(d["clips_per_s"] - 2 * 3 * 2 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["clips_per_s"]
+    # the K-step block is repeated (same count on both ranks: it follows from the max-over-ranks time) and the median reported
+    assert d["repeats"] >= 1 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
 
 
 def _fake_kvq_tree(tmp_path, n=2, T=96, H=120, W=160):
