@@ -28,6 +28,8 @@ from kvq_amd.models.backbones.slowfast_model import pack_pathway_output, slowfas
 def main(config, video_root, videos_csv):
     device = torch.device("cuda")
     model = slowfast().to(device).eval()
+    if config.small_grid_mean:
+        model.head_small_grid = "mean"
     if config.weights:
         print(model.load_state_dict(torch.load(config.weights, map_location="cpu"), strict=False))
     folder = config.feature_save_folder + "/" + config.database + "/"              # (:179)
@@ -61,6 +63,9 @@ if __name__ == "__main__":
     parser.add_argument("--synthetic", type=int, default=0)
     parser.add_argument("--video_name", default="synthetic_00000")
     parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--small_grid_mean", action="store_true",
+                        help="reduced-size smoke runs: a final grid under the head's AvgPool3d kernel (--resize < 224) gets the global "
+                             "mean instead of the error the reference raises there")
     config = parser.parse_args()
     if not config.synthetic and (config.video_root is None or config.video_csv is None):
         parser.error("--video_root and --video_csv are required (or --synthetic N)")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 20
+#define KVQ_ABI_VERSION 21
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -578,6 +578,10 @@ typedef struct KvqConvNet KvqConvNet;
 int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTensor* tensors, int n_tensors, int n_inputs, int n_outputs,
                        int dtype, KvqConvNet** out);
 void kvq_convnet_destroy(KvqConvNet* net);
+/* Split-K on / off for every launch of the plan (default on).  Whether a convolution splits depends on its tile count, i.e. on the
+ * batch: with it on, a clip's features differ in the last bits with how many clips share its forward.  The feature extractor
+ * (SlowFast_features.py writes per-clip .npy files the reference computes at batch 1) switches it off. */
+int kvq_convnet_splitk(KvqConvNet* net, int enable);
 size_t kvq_convnet_workspace_bytes(const KvqConvNet* net);
 /* inputs[n_inputs]: device pointers of the input slots; outputs[n_outputs]: fp32 device buffers of the MEAN_STD ops */
 int kvq_convnet_forward(const KvqConvNet* net, const void* const* inputs, float* const* outputs, void* workspace,

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 def dtype_code(dt) -> int:
@@ -147,6 +147,7 @@ SYMBOLS = {
     "kvq_conv_implicit": (i32, [C.POINTER(KvqConvArgs), p_void]),
     "kvq_convnet_create": (i32, [C.POINTER(KvqNetOp), i32, C.POINTER(KvqNetTensor), i32, i32, i32, i32, C.POINTER(p_void)]),
     "kvq_convnet_destroy": (None, [p_void]),
+    "kvq_convnet_splitk": (i32, [p_void, i32]),
     "kvq_convnet_workspace_bytes": (sz, [p_void]),
     "kvq_convnet_forward": (i32, [p_void, C.POINTER(p_void), C.POINTER(p_void), p_void, sz, p_void]),
     "kvq_qkv_fill_pad": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, C.c_float, i32, p_void]),

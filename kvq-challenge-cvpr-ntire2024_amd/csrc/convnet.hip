@@ -58,6 +58,7 @@ struct KvqConvNet {
   std::vector<void*> owned;
   int n_inputs, n_outputs, dtype;
   size_t ws_bytes, sk_off, sk_bytes;
+  bool sk_on = true;      // kvq_convnet_splitk: false = no launch of this plan cuts K (results independent of the batch size)
   // kvq_convnet_profile: one event before the first op and one after every op of the NEXT forwards (measurement only)
   mutable std::vector<hipEvent_t> events;
   mutable bool recorded = false;
@@ -394,6 +395,9 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
   }
   size_t op_index = 0;
   int prev_signal = -1;
+  // the ops run inside a lambda: an op that fails must not leave the second stream forked off — the join below runs either way,
+  // so the caller's stream (and whoever frees or reuses the inputs / workspace after the error) is ordered behind lane 1
+  const int rc_ops = [&]() -> int {
   for (const NetOpState& o : net->ops) {
     if (prof && op_index) KVQ_CHECK_HIP(hipEventRecord(net->events[op_index], st));
     if (fork && prev_signal >= 0) KVQ_CHECK_HIP(hipEventRecord(net->sync[prev_signal], st));     // behind the previous op, on ITS stream
@@ -422,7 +426,7 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
           a.resid_bf16 = p.src2 >= 0 && !r32 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
           a.resid_f32 = r32 ? (const float*)ptr_of(p.src2) : nullptr;
           a.ldc = wide ? d.C : 0; a.col_off = wide ? p.dst_coff : 0;
-          if (net->sk_bytes) { a.splitk_ws = sk_ws; a.splitk_ws_bytes = net->sk_bytes; }
+          if (net->sk_on && net->sk_bytes) { a.splitk_ws = sk_ws; a.splitk_ws_bytes = net->sk_bytes; }
           KVQ_TRY(kvq_gemm_bf16(&a, st));
         } else {
           KvqConvArgs a{};
@@ -436,7 +440,7 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
           a.resid_bf16 = p.src2 >= 0 && !r32 ? (const uint16_t*)ptr_of(p.src2) : nullptr;
           a.resid_f32 = r32 ? (const float*)ptr_of(p.src2) : nullptr;
           a.ldc = wide ? d.C : 0; a.col_off = wide ? p.dst_coff : 0;
-          if (net->sk_bytes) { a.splitk_ws = sk_ws; a.splitk_ws_bytes = net->sk_bytes; }
+          if (net->sk_on && net->sk_bytes) { a.splitk_ws = sk_ws; a.splitk_ws_bytes = net->sk_bytes; }
           KVQ_TRY(kvq_conv_implicit(&a, st));
         }
         break;
@@ -494,14 +498,26 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
         break;
     }
   }
+  return KVQ_OK;
+  }();
   if (fork) {
-    if (prev_signal >= 0) KVQ_CHECK_HIP(hipEventRecord(net->sync[prev_signal], st));
-    KVQ_CHECK_HIP(hipEventRecord(net->sync[1], net->lane1));
-    KVQ_CHECK_HIP(hipStreamWaitEvent(caller, net->sync[1], 0));
+    hipError_t je = hipSuccess;
+    if (rc_ops == KVQ_OK && prev_signal >= 0) je = hipEventRecord(net->sync[prev_signal], st);
+    if (je == hipSuccess) je = hipEventRecord(net->sync[1], net->lane1);
+    if (je == hipSuccess) je = hipStreamWaitEvent(caller, net->sync[1], 0);
+    if (je != hipSuccess) (void)hipStreamSynchronize(net->lane1);      // last resort: never return with lane 1 un-joined
+    if (rc_ops == KVQ_OK && je != hipSuccess) return kvq::hip_fail(je, "kvq_convnet_forward: joining the second stream");
   }
+  if (rc_ops) return rc_ops;
   if (prof) {
     KVQ_CHECK_HIP(hipEventRecord(net->events[net->ops.size()], caller));
     net->recorded = true;
   }
+  return KVQ_OK;
+}
+
+extern "C" int kvq_convnet_splitk(KvqConvNet* net, int enable) {
+  KVQ_REQUIRE(net, KVQ_ERR_NULL, "kvq_convnet_splitk: NULL plan");
+  net->sk_on = enable != 0;
   return KVQ_OK;
 }

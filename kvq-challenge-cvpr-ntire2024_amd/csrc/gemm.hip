@@ -684,6 +684,8 @@ extern "C" int kvq_gemm_bf16(const KvqGemmArgs* a, void* stream) {
   p.a_gather = a->a_gather; p.a_rows = a->a_rows; p.a_phys_rows = a->a_phys_rows;
   KVQ_REQUIRE(!a->a_gather || (a->a_rows > 0 && a->a_phys_rows >= a->a_rows && a->M % a->a_rows == 0 && !a->splitk_ws), KVQ_ERR_SHAPE,
               "kvq_gemm_bf16: a_gather needs M = n_batch * a_rows, a_phys_rows >= a_rows, no split-K");
+  KVQ_REQUIRE(a->ldc != 0 || a->col_off == 0, KVQ_ERR_SHAPE, "kvq_gemm_bf16: col_off = %d without ldc (the epilogue would write outside the row)",
+              a->col_off);
   KVQ_REQUIRE(a->ldc == 0 || (a->epilogue != KVQ_EPI_QKV_BF16 && a->epilogue != KVQ_EPI_RESID_F32 && a->epilogue != KVQ_EPI_STORE_F32 &&
                               a->ldc % 8 == 0 && a->col_off % 8 == 0 && a->col_off >= 0 && a->col_off + a->N <= a->ldc),
               KVQ_ERR_SHAPE, "kvq_gemm_bf16: ldc / col_off need a 16-bit row-major epilogue, multiples of 8, col_off + N <= ldc");
@@ -797,6 +799,7 @@ extern "C" int kvq_conv_implicit(const KvqConvArgs* a, void* stream) {
   p.sk_ws = (float*)a->splitk_ws; p.sk_bytes = a->splitk_ws_bytes;
   KVQ_REQUIRE(!p.sk_ws || ((size_t)p.sk_ws & 15) == 0, KVQ_ERR_SHAPE, "kvq_conv_implicit: splitk_ws must be 16-byte aligned");
   p.ldc = a->ldc; p.col_off = a->col_off;
+  KVQ_REQUIRE(a->ldc != 0 || a->col_off == 0, KVQ_ERR_SHAPE, "kvq_conv_implicit: col_off = %d without ldc", a->col_off);
   KVQ_REQUIRE(a->ldc == 0 || (a->epilogue != KVQ_EPI_STORE_F32 && a->ldc % 8 == 0 && a->col_off % 8 == 0 && a->col_off >= 0 &&
                               a->col_off + a->N <= a->ldc),
               KVQ_ERR_SHAPE, "kvq_conv_implicit: ldc / col_off need a 16-bit epilogue, multiples of 8, col_off + N <= ldc");

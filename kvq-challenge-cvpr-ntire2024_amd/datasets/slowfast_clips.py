@@ -117,6 +117,7 @@ def extract_video(model, clips: List[torch.Tensor], device, batch: int = 8):
             order.append(len(uniq))
             uniq.append(c)
     feats = []
+    model.split_k = False           # a clip's features must not depend on which clips share its forward (10 clips run as 8 + 2)
     with torch.no_grad():
         for a in range(0, len(uniq), batch):
             ele = torch.stack(uniq[a:a + batch]).permute(0, 2, 1, 3, 4).contiguous().to(device)      # (b, 3, 32, r, r)   (:193)

@@ -100,7 +100,35 @@ def pack_pathway_output(frames, device=None):
     """Reference ``pack_pathway_output`` (SlowFast_features.py:112-135): [slow, fast]."""
     idx = torch.linspace(0, frames.shape[2] - 1, frames.shape[2] // 4).long().to(frames.device)
     slow = torch.index_select(frames, 2, idx)
-    return [slow if device is None else slow.to(device), frames if device is None else frames.to(device)]
+    out = [slow if device is None else slow.to(device), frames if device is None else frames.to(device)]
+    # provenance tag: slowfast.forward may re-select the slow frames on the device (one C call for the whole network) ONLY for a
+    # slow tensor that IS this selection of that fast tensor; any other slow tensor is consumed as given, like the reference does
+    out[0]._kvq_packed_of = (out[1].data_ptr(), out[1]._version, tuple(out[1].shape))
+    return out
+
+
+def _is_packed_pair(slow_in, fast_in):
+    tag = getattr(slow_in, "_kvq_packed_of", None)
+    return tag is not None and tag == (fast_in.data_ptr(), fast_in._version, tuple(fast_in.shape))
+
+
+def head_pool_kernel(pathway, T):
+    """pytorchvideo's slowfast_r50 head: AvgPool3d((8,7,7)) on the slow pathway, ((32,7,7)) on the fast one, stride 1, no padding
+    (SlowFast_features.py:150-151), followed by AdaptiveAvgPool3d(1) (:152).  The temporal extents are those of the 32-frame model."""
+    return (8, 7, 7) if pathway == 0 else (32, 7, 7)
+
+
+def check_head_grid(pathway, grid, small="error"):
+    """The reference's pool raises when the final grid is smaller than its kernel; equal = a global mean; larger = the mean of the
+    overlapping window means (the real pool is run then).  Returns True when the pool is needed.  ``small`` = "mean": a grid
+    smaller than the kernel gets the global mean instead of the error (reduced-size parity tests only; ``slowfast.head_small_grid``)."""
+    k = head_pool_kernel(pathway, None)
+    if any(g < kk for g, kk in zip(grid, k)):
+        if small == "mean":
+            return False
+        raise _abi.KvqError(f"slowfast head: final {'slow' if pathway == 0 else 'fast'} grid {tuple(grid)} is smaller than the reference's "
+                            f"AvgPool3d kernel {k} (the reference raises here too): clips must be >= 32 frames of >= 224 x 224")
+    return tuple(grid) != k
 
 
 IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
@@ -157,6 +185,12 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         super().__init__()
         self.operand_dtype = _abi.dtype_code(operand_dtype or os.environ.get("KVQ_OPERAND_DTYPE", "fp16"))
         self.two_lanes = TWO_LANES if two_lanes is None else bool(two_lanes)
+        # False: no launch cuts K, so a clip's features do not depend on how many clips share its forward (the feature
+        # extractor writes per-clip files; the reference runs batch 1) — datasets/slowfast_clips.py::extract_video sets it
+        self.split_k = True
+        # final grid smaller than the head's AvgPool3d kernel ((8,7,7) / (32,7,7): clips under 32 x 224 x 224): "error" as the
+        # reference does, or "mean" = the global mean (what oracle/slowfast_oracle.py restates; reduced-size tests set it)
+        self.head_small_grid = "error"
         self.table = conv_table()
         for key, (wshape, _, _, cname, nname) in self.table.items():
             base = key.split("#")[0]
@@ -288,7 +322,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         stream 16-bit.  One plan + workspace per (geometry, stream): forwards on different streams may overlap."""
         import ctypes as C
         Wt = self._weights(device)
-        key = (B, T, H, W, str(device), self.operand_dtype, _abi.current_stream(), id(Wt), self.two_lanes)
+        key = (B, T, H, W, str(device), self.operand_dtype, _abi.current_stream(), id(Wt), self.two_lanes, self.split_k, self.head_small_grid)
         hit = self.__dict__.setdefault("_nets", {}).get(key)
         if hit is not None:
             return hit
@@ -396,10 +430,17 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             if si < 3:
                 conv(fast, fe + f"{si + 1}.multipathway_fusion", dst=slow, coff=SLOW["out"][si])
             lane[0] = 0
-        # head: AvgPool3d((8,7,7)) / ((32,7,7)) + AdaptiveAvgPool3d(1) = a global mean over the remaining grid
-        op(_abi.NET_MEAN_STD, slow, 0, per_frame=0, mean_off=0, std_off=-1, out_stride=tens[slow][4])
-        lane[0] = FAST_LANE
-        op(_abi.NET_MEAN_STD, fast, 1, per_frame=0, mean_off=0, std_off=-1, out_stride=tens[fast][4])
+        # head: AvgPool3d((8,7,7)) / ((32,7,7)), stride 1 + AdaptiveAvgPool3d(1).  On the 32 x 224 x 224 geometry the grid IS the
+        # kernel and the two are one global mean; on a larger grid (--resize 256: 8 x 8 x 8) the real pool runs first
+        for pi, x in ((0, slow), (1, fast)):
+            lane[0] = FAST_LANE if pi == 1 else 0
+            bb, d, h, w, c, _ = tens[x]
+            if check_head_grid(pi, (d, h, w), self.head_small_grid):
+                k = head_pool_kernel(pi, T)
+                pooled = tensor(bb, d - k[0] + 1, h - k[1] + 1, w - k[2] + 1, c)
+                op(_abi.NET_POOL, x, pooled, k, (1, 1, 1), (0, 0, 0), is_max=0)
+                x = pooled
+            op(_abi.NET_MEAN_STD, x, pi, per_frame=0, mean_off=0, std_off=-1, out_stride=c)
         lane[0] = 0
         ta = (_abi.KvqNetTensor * len(tens))()
         for i, (b, d, h, w, c, kind) in enumerate(tens):
@@ -407,6 +448,8 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         oa = (_abi.KvqNetOp * len(ops))(*ops)
         handle = C.c_void_p()
         _abi.check(_abi.lib().kvq_convnet_create(oa, len(ops), ta, len(tens), 1, 2, self.operand_dtype, C.byref(handle)), "kvq_convnet_create")
+        if not self.split_k:
+            _abi.check(_abi.lib().kvq_convnet_splitk(handle, 0), "kvq_convnet_splitk")
         ws = torch.empty(_abi.lib().kvq_convnet_workspace_bytes(handle), dtype=torch.uint8, device=device)
         torch.cuda.synchronize(device)       # tap tables / packed weights were built on this stream; other streams may run the plan
         entry = (handle, ws, (tens[slow][4], tens[fast][4]), keep, Wt, descs)
@@ -473,7 +516,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         slow_in, fast_in = x
         if not fast_in.is_cuda:
             raise _abi.KvqError("slowfast.forward needs the clips on a HIP device; there is no CPU path")
-        if self._one_call(fast_in) and fast_in.shape[2] == 4 * slow_in.shape[2]:
+        if self._one_call(fast_in) and _is_packed_pair(slow_in, fast_in):      # slow_in IS pack_pathway_output's selection of fast_in
             return self.forward_clips(fast_in)
         W = self._weights(fast_in.device)
         half = _abi.torch_dtype(self.operand_dtype)
@@ -490,9 +533,11 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
                 fast, f32 = self._res_block(fast, f32, W, fe + f"{si + 1}.multipathway_blocks.1.res_blocks.{bi}", bi == 0)
             if si < 3:
                 slow = torch.cat([slow, self._conv_relu(fast, W[fe + f"{si + 1}.multipathway_fusion"])], dim=-1)
-        # AvgPool3d((8,7,7)) / ((32,7,7)) + AdaptiveAvgPool3d(1): a global mean over the remaining grid
+        # AvgPool3d((8,7,7)) / ((32,7,7)), stride 1 + AdaptiveAvgPool3d(1): a global mean when the grid is the kernel
         outs = []
-        for y in (slow, fast):
+        for pi, y in enumerate((slow, fast)):
+            if check_head_grid(pi, y.shape[1:4], self.head_small_grid):
+                y = kernels.pool_nd(y.contiguous(), head_pool_kernel(pi, None), (1, 1, 1), (0, 0, 0), False)
             B, D, H, Wd, C = y.shape
             o = torch.empty(B, C, dtype=torch.float32, device=y.device)
             kernels.mean_std_pool(y.reshape(B, D * H * Wd, C), o, 0, -1)

@@ -83,7 +83,14 @@ def slowfast_features(frames: torch.Tensor, params):
             slow, fast = fuse(slow, fast, si + 1)
     # reference: AvgPool3d((8,7,7)) / ((32,7,7)) then AdaptiveAvgPool3d(1) == global mean at 224^2 / 32 frames;
     # for other input sizes the head pools are restated as global means over what remains.
-    return slow.mean((2, 3, 4), keepdim=True), fast.mean((2, 3, 4), keepdim=True)
+    # A grid at least as large as the kernels gets the real pools (overlapping windows, then their mean); a smaller grid — where
+    # the reference raises — gets the global mean: reduced-size parity cases only.
+    outs = []
+    for y, k in ((slow, (8, 7, 7)), (fast, (32, 7, 7))):
+        if all(g >= kk for g, kk in zip(y.shape[2:], k)) and tuple(y.shape[2:]) != k:
+            y = F.avg_pool3d(y, k, stride=1, padding=0)
+        outs.append(y.mean((2, 3, 4), keepdim=True))
+    return outs[0], outs[1]
 
 
 def param_shapes():

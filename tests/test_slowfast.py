@@ -81,6 +81,7 @@ def test_hip_slowfast_full_clip_matches_oracle():
     w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
     x = torch.from_numpy(synth.synth_clip(31, 32, 224, 224, batch=1))
     m = slowfast()
+    m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     m = m.cuda().eval()
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -103,6 +104,7 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     from kvq_amd import _abi
     w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
     m = M.slowfast()
+    m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     m = m.cuda().eval()
     x = torch.from_numpy(synth.synth_clip(77, 16, 96, 64, batch=3)).cuda()
@@ -196,6 +198,7 @@ def test_fused_fast_pathway_blocks_match_the_conv_by_conv_plan():
         M.FUSE_FAST = fuse
         try:
             m = M.slowfast()
+            m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
             m.load_state_dict(sd)
             m = m.cuda().eval()
             with torch.no_grad():
@@ -220,6 +223,7 @@ def test_two_lane_plan_equals_one_lane_and_profile_reads_every_op():
     nets = []
     for lanes in (False, True):
         m = M.slowfast(two_lanes=lanes)
+        m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
         m.load_state_dict(sd)
         nets.append(m.cuda().eval())
     xs = [torch.from_numpy(synth.synth_clip(70 + i, 16, 96, 64, batch=2)).cuda() for i in range(3)]
@@ -267,10 +271,12 @@ def test_cli_extracts_features_from_a_video_tree(tmp_path):
     torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, str(tmp_path / "w.pth"))
     r = subprocess.run([sys.executable, os.path.join(root, "SlowFast_features.py"), "--video_root", str(tmp_path), "--video_csv",
                         str(tmp_path / "v.csv"), "--database", "kvq", "--feature_save_folder", str(tmp_path / "feat"), "--resize", "64",
-                        "--num_workers", "0", "--fps", "30", "--weights", str(tmp_path / "w.pth")], capture_output=True, text=True,
+                        "--num_workers", "0", "--fps", "30", "--weights", str(tmp_path / "w.pth"), "--small_grid_mean"], capture_output=True,
+                       text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     m = slowfast()
+    m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
     m.load_state_dict(torch.load(str(tmp_path / "w.pth")))
     m = m.cuda().eval()
     ds = VideoDataset_NR_SlowFast_feature(types.SimpleNamespace(resize=64, fps=30.0), None, str(tmp_path), str(tmp_path / "v.csv"))
@@ -296,6 +302,7 @@ def test_hip_slowfast_matches_oracle(shape):
     w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(sum(shape))).standard_normal(shape).astype(np.float32))
     m = slowfast()
+    m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     m = m.cuda().eval()
     with torch.no_grad():
@@ -357,3 +364,67 @@ def test_conv_stem_mfma_vs_torch_conv3d(shape, kernel, stride, pad, dtype):
     if cin == 3:
         direct = kernels.conv_stem_direct(x.cuda(), w_kc.cuda(), bias.cuda(), kernel, stride, pad, True, dtype).float().cpu()
         assert (out - direct).abs().max().item() <= (3e-2 if dtype == torch.float16 else 2e-1)
+
+
+@pytest.mark.gpu
+def test_head_pool_follows_the_reference_for_every_grid():
+    """pytorchvideo's head is AvgPool3d((8,7,7)) / ((32,7,7)), stride 1, then AdaptiveAvgPool3d(1) (SlowFast_features.py:150-152).
+    Equal grid (32 x 224 x 224): one global mean.  Larger grid (here 32 x 256 x 224 -> 8 x 8 x 7 / 32 x 8 x 7): the real pool runs —
+    the mean of the overlapping window means, NOT the global mean — in the one-call plan and in the layer-by-layer path alike.
+    Smaller grid: the reference raises; so does the module unless ``head_small_grid = "mean"`` (reduced-size tests).  And
+    ``forward([slow, fast])`` re-selects the slow frames on the device only for a slow tensor that IS pack_pathway_output's
+    selection of that fast tensor: any other slow tensor is consumed as given."""
+    import kvq_amd.models.backbones.slowfast_model as M
+    from kvq_amd import _abi
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    m = M.slowfast()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.synth_clip(5, 32, 256, 224, batch=1))
+    with torch.no_grad():
+        s_ref, f_ref = SF.slowfast_features(x, w)
+        s1, f1 = m.forward_clips(x.cuda())
+        M.CONVNET = False
+        try:
+            s0, f0 = m(M.pack_pathway_output(x.cuda()))
+        finally:
+            M.CONVNET = True
+    for got, ref in ((s1, s_ref), (f1, f_ref), (s0, s_ref), (f0, f_ref)):
+        assert ((got.cpu() - ref).norm() / ref.norm()).item() <= 5e-3
+    with torch.no_grad(), pytest.raises(_abi.KvqError, match="smaller than the reference"):
+        m.forward_clips(torch.zeros(1, 3, 16, 96, 64, device="cuda"))
+    # a slow tensor that is NOT the packed selection is used as given
+    m.head_small_grid = "mean"
+    xs = torch.from_numpy(synth.synth_clip(6, 16, 96, 64, batch=1)).cuda()
+    packed = M.pack_pathway_output(xs)
+    other = [packed[0].flip(2).contiguous(), packed[1]]
+    with torch.no_grad():
+        a_s, a_f = m(packed)
+        b_s, b_f = m(other)
+        M.CONVNET = False
+        try:
+            c_s, c_f = m(other)                 # the layer-by-layer sequencing never re-selects anything
+        finally:
+            M.CONVNET = True
+    assert not torch.equal(a_s, b_s)            # the flipped slow frames went through the network
+    assert torch.equal(b_s, c_s) and torch.equal(b_f, c_f)
+
+
+@pytest.mark.gpu
+def test_extractor_features_do_not_depend_on_the_batch():
+    """extract_video stacks up to 8 unique clips per forward; with split-K on, whether a late convolution cuts K depends on the tile
+    count, i.e. on the batch — the extractor switches it off (kvq_convnet_splitk), so a clip's features are bit-identical whether it
+    runs alone or beside 7 others (the reference runs batch 1)."""
+    from kvq_amd.datasets.slowfast_clips import extract_video
+    from kvq_amd.models.backbones.slowfast_model import slowfast
+    w = synth.synth_params(SF.param_shapes(), 3, "stress", prefix="sf.")
+    m = slowfast()
+    m.head_small_grid = "mean"
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    m = m.cuda().eval()
+    g = np.random.Generator(np.random.PCG64(12))
+    clips = [torch.from_numpy(g.standard_normal((32, 3, 64, 64)).astype(np.float32)) for _ in range(5)]
+    together = extract_video(m, clips, "cuda", batch=8)
+    alone = extract_video(m, clips, "cuda", batch=1)
+    for (s8, f8), (s1, f1) in zip(together, alone):
+        assert np.array_equal(s8, s1) and np.array_equal(f8, f1)
