@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams consecutive steps alternate over (independent batches fill each other's launch gaps; "
                          "measured 1 / 2 / 3 / 4 / 5 / 6 streams: 2.12 / 1.77 / 1.76 / 1.745 / 1.84 / 1.71-1.84 ms per step)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("KVQ_BENCH_GRAPH", "0")),
+    ap.add_argument("--graph", type=int, default=0,
                     help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
     ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,c3,c5 ('all', 'c2' = none)")
     ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")

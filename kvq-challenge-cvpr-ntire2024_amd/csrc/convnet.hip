@@ -203,7 +203,7 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
           NET_REQUIRE(r.kind == KVQ_NET_T_ACT32 && r.C == p.cout && r.B == d.B && r.D == d.D && r.H == d.H && r.W == d.W,
                       "kvq_convnet_create: op %d fp32 copy shape", i);
         }
-        if (!o.pointwise && (s.C % 32 != 0 || getenv("KVQ_CONV_TAP_TABLE"))) {     // C % 32 == 0: the kernel walks the taps itself
+        if (!o.pointwise && s.C % 32 != 0) {     // C % 32 == 0: the kernel walks the taps itself
           int rc = upload_i32(net, build_taps(p.kernel3, s.C, s.H, s.W, p.kpad), &o.d_taps);
           if (rc) return fail(rc);
         }

@@ -49,21 +49,16 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // BK = 32: LDS rows of 64 B, 16-B chunk c of row r at chunk c ^ ((r>>2)&3).  BK = 64 (the "one big tile per CU"
 // variants for long-K shapes): rows of 128 B, chunk c at c ^ ((r>>1)&7) — in both, the 16 lanes of a ds_read_b128
 // service group land on 16 distinct 16-B slots.
-// WN: wave columns (2: the 2x2 wave grid; 4: EIGHT waves in a 2x4 grid over the same block tile — two waves per SIMD for launches
-// that put one workgroup on a CU, so a wave's barrier / fragment-read latency is covered by the other's MFMAs).
-// PIPE (the "solo" variants: one workgroup per CU, ring of >= 4 slices): the fragments of slice t+1 are read while the MFMAs of
-// slice t run (two register sets, K loop unrolled by two).  Without it the four waves of a lone workgroup walk in lock step through
-// "all read LDS" / "all multiply": ~800 cycles per 32-deep slice for 256 cycles of MFMA; co-resident workgroups hide that for the
-// multi-round launches, nothing does for the 100-200-tile launches of the late layers.
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false, int WN = 2,
-          bool PIPE = false>
-__global__ __launch_bounds__(128 * WN) void gemm_kernel(GemmParams p) {
-  static_assert(!PIPE || (NST >= 4 && BK == 32), "PIPE: one slice is waited for ahead of its use; lgkmcnt counts <= 15 reads");
+// (Measured in round 2 and dropped: eight waves in a 2x4 grid over the same tile, rings of 6 / 8 slices, fragment reads of slice t+1
+// under the MFMAs of slice t — all within -8..0 % on the lone-workgroup shapes; what those shapes needed was the wider tile of
+// gemm256.hip.)
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int WN = 2;                                                  // 2 x 2 wave grid
   static_assert(IMPL || !WALK, "WALK is a mode of the implicit-GEMM instantiation");
   fp16_saturate_mode();
   static_assert(BK == 32 || BK == 64, "ring slices are 32 or 64 deep");
   static_assert(NST >= 2 && NST <= 8, "ring of 2 .. 8 slices");
-  static_assert(WN == 2 || WN == 4, "wave grid 2 x WN");
   constexpr int NT = 128 * WN;                                         // threads
   constexpr int BM = 64 * MI, BN = 32 * NI * WN;
   constexpr int RB = BK * 2, CH = RB / 16, KK = BK / 16;             // row bytes, 16-B chunks per row, MFMA k-steps per slice
@@ -243,87 +238,6 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(GemmParams p) {
     else if (DEPTH > 1 && younger == 1) gemm_wait_vmcnt<PER>();
     else gemm_wait_vmcnt<0>();
   };
-  if (PIPE) {
-    constexpr int RS = KK * (MI + NI);                       // fragment reads per slice and wave
-    static_assert(!PIPE || RS <= 15, "lgkmcnt is a 4-bit counter");
-    V8 fa[2][KK][MI], fb[2][KK][NI];
-    auto read_slice = [&](int kt, auto buf) {
-      constexpr int B = decltype(buf)::value;
-      const unsigned sbase = lds_base + (kt % NST) * ST_BYTES;
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) lds_read_b128(fa[B][kk][i], sbase + a_off[i][kk]);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) lds_read_b128(fb[B][kk][j], sbase + b_off[j][kk]);
-      }
-    };
-    // one slice with a successor (straight-line: the accumulators must not pass through a conditional path, or the register
-    // allocator copies all of them between AGPRs and VGPRs every iteration); buf = the register set that holds slice kt
-    auto step_more = [&](int kt, auto buf) __attribute__((always_inline)) {
-      constexpr int B = decltype(buf)::value;
-      wait_landed(kt + 1, std::integral_constant<int, NST - 3>{});
-      __builtin_amdgcn_s_barrier();                       // slice kt+1 visible; everybody's reads of slice kt-1 have returned
-      if (kt + NST - 1 < nk) issue(kt + NST - 1);         // into the slot of slice kt-1
-      read_slice(kt + 1, std::integral_constant<int, 1 - B>{});
-      // LDS returns in order: "at most RS outstanding" = this slice's fragments are here, the next slice's still in flight
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[B][kk][i]) : "n"(RS) : "memory");
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(fb[B][kk][j]));
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = E::mfma32(fa[B][kk][i], fb[B][kk][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto step_last = [&](auto buf) __attribute__((always_inline)) {
-      constexpr int B = decltype(buf)::value;
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[B][kk][i])::"memory");
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(fb[B][kk][j]));
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = E::mfma32(fa[B][kk][i], fb[B][kk][j], acc[i][j]);
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    wait_landed(0, std::integral_constant<int, NST - 2>{});
-    __builtin_amdgcn_s_barrier();
-    if (tr) p.trace[blockIdx.x * 8 + 1] = __builtin_readcyclecounter();
-    read_slice(0, B0{});
-    // nk odd: pairs (0,1) .. (nk-3, nk-2), then the last slice from set 0; nk even: one slice (set 0) first makes the rest odd
-    int kt = 0;
-    if ((nk & 1) == 0) {           // nk >= 2 here
-      step_more(0, B0{});
-      // the sets are now swapped relative to the slice parity: walk the remaining (odd count) with set 1 leading
-      for (kt = 1; kt + 2 < nk; kt += 2) {
-        step_more(kt, B1{});
-        step_more(kt + 1, B0{});
-      }
-      step_last(B1{});
-    } else {
-      for (; kt + 2 < nk; kt += 2) {
-        step_more(kt, B0{});
-        step_more(kt + 1, B1{});
-      }
-      step_last(B0{});
-    }
-  } else
   for (int kt = 0; kt < nk; ++kt) {
     // slice kt must have landed; up to two younger slices stay in flight
     // (up to NST - 2 younger slices stay in flight; table-driven IMPL: every issue also carries A_PER tap loads)
@@ -385,16 +299,16 @@ __global__ __launch_bounds__(128 * WN) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false, int WN = 2,
-          bool PIPE = false>
+template <typename E, int MI, int NI, int BK, int EPI, int NST = KVQ_GEMM_NST, bool IMPL = false, bool WALK = false>
 static int launch_one(const GemmParams& p_in, hipStream_t st) {
+  constexpr int WN = 2;
   GemmParams p = p_in;
   p.ksplit = p.ksplit < 1 ? 1 : p.ksplit;
   constexpr int BM = 64 * MI, BN = 32 * NI * WN;
   constexpr size_t main_bytes = NST * (BM + BN) * BK * 2;               // ring of 2*BK-byte rows
   constexpr size_t epi_bytes = 2 * WN * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL, WALK, WN, PIPE>;
+  auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL, WALK>;
   static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
   if (!attr_set && lds_bytes > 64 * 1024) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -482,10 +396,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, const 
 // The 64-deep variants hold a CU's whole LDS (one workgroup per CU): more than 256 workgroups would only add a second, half-empty
 // round (fc2 of stage 3, K = 3072 over 150 tiles: 43.6 us un-split, 43.8 split in three) — they stay whole.
 static int splitk_factor(long tiles, int nk, int bk) {
-  static const int off = getenv("KVQ_GEMM_SPLITK") && atoi(getenv("KVQ_GEMM_SPLITK")) == 0;
   // 196 tiles (res4 of SlowFast's slow pathway) stay whole since the implicit GEMM walks its taps: 1x3x3 / 256 channels 36 us whole,
   // 40 us split in two; 100 tiles (res5): 58 us whole, 38 us split in five
-  if (off || bk != 32 || tiles > 160 || nk < 48) return 1;
+  if (bk != 32 || tiles > 160 || nk < 48) return 1;
   int S = (int)(512 / tiles);
   S = S > 8 ? 8 : S;
   while (S > 1 && nk / S < 24) --S;
@@ -494,10 +407,6 @@ static int splitk_factor(long tiles, int nk, int bk) {
 
 // tile (MI, NI) for a shape, encoded (10*MI + NI)*100 + BK
 int gemm_variant(int M, int N, int K) {
-  static const int forced = getenv("KVQ_GEMM_TILE") ? atoi(getenv("KVQ_GEMM_TILE")) : 0;   // experiments: 22 | 21 | 12 | 11
-  if (forced) return forced * 100 + 32;
-  static const int forced_full = getenv("KVQ_GEMM_VARIANT") ? atoi(getenv("KVQ_GEMM_VARIANT")) : 0;   // experiments: 2264 | 3264 | 2464
-  if (forced_full && K % 64 == 0) return forced_full;
   // Measured per shape of the trunk (B = 4 clips, us: 128x128 / 128x64 / 64x64): fc2 stage 2 (K = 1536) 36.7 / 41.4 /
   // 44.3 although 128x128 makes only 294 workgroups; qkv stage 3 25.6 / 31.0 / 35.1 (450 workgroups); proj stage 2
   // (K = 384, epilogue-dominated) 25.0 / 21.3 / 20.2; merge stage 0 (N = 192 = 1.5 tiles of 128) 28.0 / 24.7 / 28.1.
@@ -507,10 +416,8 @@ int gemm_variant(int M, int N, int K) {
   // 128x160x64 ... 128x256x64 tiles, 225-294 of them).  First candidate that fits the chip in a single round.
   // Few rows (KSVQE's CLIP tower: 200-800 token rows; one clip's stage 3: 784): 128x128 tiles leave most of the chip idle
   // (12-48 workgroups walking a K of 3072) — 64x64 tiles quadruple the workgroups; operand re-reads are irrelevant at this size.
-  static const int no_small = getenv("KVQ_GEMM_NO_SMALL") ? 1 : 0;
-  if (!no_small && (long)ceil_div(M, 128) * ceil_div(N, 128) < 96) return 11 * 100 + 32;
-  static const int no_deep = getenv("KVQ_GEMM_NO_DEEP") ? 1 : 0;
-  if (!no_deep && K % 64 == 0 && K >= 1024) {      // measured: fc2 stage 3 45 -> 40 us, merges -2 us; K = 768 shapes lose
+  if ((long)ceil_div(M, 128) * ceil_div(N, 128) < 96) return 11 * 100 + 32;
+  if (K % 64 == 0 && K >= 1024) {      // measured: fc2 stage 3 45 -> 40 us, merges -2 us; K = 768 shapes lose
     static const int cand[3][2] = {{2, 2}, {3, 2}, {2, 4}};
     for (auto& c : cand) {
       const long tiles = (long)ceil_div(M, 64 * c[0]) * ceil_div(N, 64 * c[1]);
@@ -560,15 +467,6 @@ static int launch_gemm_variant(const GemmParams& p, hipStream_t st) {
       default: return launch_one<E, 2, 4, 64, EPI>(p, st);
     }
   }
-#ifdef KVQ_GEMM_EXPERIMENTS   // -DKVQ_GEMM_EXPERIMENTS builds only (measured and not adopted): lone-workgroup variants
-  static const int w8 = getenv("KVQ_GEMM_W8") ? atoi(getenv("KVQ_GEMM_W8")) : 0;      // 8 waves (2 x 4) on the 128x128 tile
-  if (w8 && var / 100 == 22) return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, false, false, 4>(p, st);
-  static const int ring = getenv("KVQ_GEMM_RING") ? atoi(getenv("KVQ_GEMM_RING")) : 0;  // ring of 6 / 8 slices; 16 / 18: + PIPE
-  if (ring == 6 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 6>(p, st);
-  if (ring == 8 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 8>(p, st);
-  if (ring == 16 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 6, false, false, 2, true>(p, st);
-  if (ring == 18 && var / 100 == 22) return launch_one<E, 2, 2, 32, EPI, 8, false, false, 2, true>(p, st);
-#endif
   switch (var / 100) {
     case 22: return launch_one<E, 2, 2, 32, EPI>(p, st);
     case 21: return launch_one<E, 2, 1, 32, EPI>(p, st);
@@ -589,10 +487,6 @@ template <typename E, int EPI>
 static int launch_conv_variant(const GemmParams& p, hipStream_t st) {
   int var = gemm_variant(p.M, p.N, p.K) / 100;
   if (var != 22 && var != 21 && var != 12 && var != 11) var = 22;
-#ifdef KVQ_GEMM_EXPERIMENTS
-  static const int w8 = getenv("KVQ_GEMM_W8") ? atoi(getenv("KVQ_GEMM_W8")) : 0;
-  if (!p.taps && w8 && var == 22) return launch_one<E, 2, 1, 32, EPI, KVQ_GEMM_NST, true, true, 4>(p, st);
-#endif
   if (!p.taps) {                // C % 32 == 0, full tap set: the kernel walks the taps with wave-uniform counters
     switch (var) {
       case 22: return launch_one<E, 2, 2, 32, EPI, KVQ_GEMM_NST, true, true>(p, st);

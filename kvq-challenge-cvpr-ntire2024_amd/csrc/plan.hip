@@ -361,14 +361,9 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
   a.A = A; a.W = Wt; a.bias = bias; a.M = M; a.N = N; a.K = K; a.epilogue = epi; a.out_bf16 = obf; a.out_f32 = of32;
   a.num_heads = nH; a.q_scale = qs; a.scatter_map = map; a.map_rows = map_rows; a.out_rows = out_rows;
   a.dtype = pl->dtype;
-  // Split-K stays OFF in the trunk: whether a GEMM splits depends on its row count, i.e. on the batch — a clip's score would
-  // differ in the last bits with what else is in the batch (tests/test_gpu_e2e.py::test_batch_invariance_and_determinism), and
-  // the trunk's only long-K / few-tile shape (fc2 of stage 3) gains nothing from it (43.6 vs 43.8 us).  KVQ_SWIN_SPLITK=1: on.
-  static const bool swin_splitk = getenv("KVQ_SWIN_SPLITK") && atoi(getenv("KVQ_SWIN_SPLITK")) != 0;
-  if (swin_splitk && pl->sk_bytes && pl->run_ws && epi != KVQ_EPI_QKV_BF16) {
-    a.splitk_ws = pl->run_ws + pl->off_sk;
-    a.splitk_ws_bytes = pl->sk_bytes;
-  }
+  // Split-K stays OFF in the trunk (splitk_ws = NULL): whether a GEMM splits depends on its row count, i.e. on the batch — a clip's
+  // score would differ in the last bits with what else is in the batch (tests/test_gpu_e2e.py::test_batch_invariance_and_determinism),
+  // and the trunk's only long-K / few-tile shape (fc2 of stage 3) gains nothing from it (43.6 vs 43.8 us).
   // algorithmic bytes: A + W once, output once (fp32 residual epilogues read-modify-write)
   const double out_b = (epi == KVQ_EPI_RESID_F32) ? 8.0 : (epi == KVQ_EPI_STORE_F32 ? 4.0 : 2.0);
   Bracket br(pl, st, kind, (gemm8p_wanted(M, N, K) ? 4464 : gemm_variant(M, N, K)) * 10 + epi, 2.0 * M * N * K,
@@ -499,8 +494,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
                   "kvq_swin3d_forward: block %d weights incomplete", blk);
       const int par = (b & 1) && g.shifted_any ? 1 : 0;
       // norm1 + pad + roll + window_partition
-      static const bool skip_pad = !(getenv("KVQ_QKV_SKIP_PAD") && atoi(getenv("KVQ_QKV_SKIP_PAD")) == 0);
-      if (skip_pad && g.Lp != g.L && !ln1_ready && bw.qkv_b) {
+      if (g.Lp != g.L && !ln1_ready && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order, qkv over the tokens only (rows scattered to their window rows by the epilogue);
         // the padding rows' q | k | v = qkv(0) = bias
         KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
@@ -557,7 +551,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       }
       // proj + window_reverse + roll back + crop + residual.  Padded partition: over the tokens (A rows gathered through token ->
       // window row, output in place in token order) instead of over the window rows with the padding rows dropped in the epilogue
-      if (g.Lp != g.L && skip_pad) {
+      if (g.Lp != g.L) {
         KvqGemmArgs pa{};
         pa.A = bo; pa.W = bw.proj_w; pa.bias = bw.proj_b; pa.M = ML; pa.N = C; pa.K = C; pa.epilogue = KVQ_EPI_RESID_F32; pa.out_f32 = cur;
         pa.dtype = pl->dtype; pa.a_gather = g.d_dst[par]; pa.a_rows = g.L; pa.a_phys_rows = g.Lp;

@@ -304,11 +304,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   };
   // GELU of accumulator registers 2g, 2g+1 -> dword g of the packed B operand pair
   auto gelu_pair = [&](const f32x16& ha, u32x4 (&hb)[2], int g) {
-#ifdef KVQ_TAIL_NOGELU      // experiment: the MFMA / LDS / barrier floor of the loop without the VALU stream
-    uint32_t w = E::pack2_raw(fmaxf(ha[2 * g], 0.f), fmaxf(ha[2 * g + 1], 0.f));
-#else
     uint32_t w = E::pack2(gelu_fast(ha[2 * g]), gelu_fast(ha[2 * g + 1]));
-#endif
     asm volatile("" : "+v"(w));      // pins the evaluation HERE (between two MFMAs): IR-level sinking would otherwise
     hb[g >> 2][g & 3] = w;           // move the whole GELU next to its first use, after the MFMA stream
   };
@@ -454,17 +450,10 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
 
 template <typename E>
 static int launch_tail_e(const TailParams& p, int C, hipStream_t st) {
-  static const int nw_env = getenv("KVQ_TAIL_NW") ? atoi(getenv("KVQ_TAIL_NW")) : 4;   // experiments: waves per workgroup
-  switch (C) {
-    case 96:
-      if (nw_env == 12) return launch_tail<E, 3, 12>(p, st);
-      return launch_tail<E, 3, 4>(p, st);
-    case 128:
-      if (nw_env == 8) return launch_tail<E, 4, 8>(p, st);
-      return launch_tail<E, 4, 4>(p, st);
-    case 192:
-      if (nw_env == 8) return launch_tail<E, 6, 8>(p, st);
-      return launch_tail<E, 6, 4>(p, st);
+  switch (C) {      // 4 waves per workgroup (8 / 12 measured in round 1: no gain)
+    case 96: return launch_tail<E, 3, 4>(p, st);
+    case 128: return launch_tail<E, 4, 4>(p, st);
+    case 192: return launch_tail<E, 6, 4>(p, st);
     default: break;
   }
   KVQ_REQUIRE(false, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d not in {96,128,192}", C);
@@ -472,25 +461,19 @@ static int launch_tail_e(const TailParams& p, int C, hipStream_t st) {
 
 }  // namespace kvq
 
-// C = 384: csrc/tailmm.hip (32x32x16 GEMM chain) unless KVQ_TAILMM=0 selects csrc/tail16.hip (token-per-lane 16x16x32); the
-// choice is per process: the packed weight images differ
-static bool use_tailmm(int C, int hidden) {
-  static const bool on = !(getenv("KVQ_TAILMM") && atoi(getenv("KVQ_TAILMM")) == 0);
-  return on && kvq::tailmm_supported(C, hidden);
-}
+// C = 256 / 384 / 512: csrc/tailmm.hip (feature-sliced 32x32x16 GEMM chain, weights through a register ring);
+// C = 96 / 128 / 192: the token-per-lane launch of this file
+static bool use_tailmm(int C, int hidden) { return kvq::tailmm_supported(C, hidden); }
 
 extern "C" int kvq_block_tail_supported(int C, int hidden) {
+  if (use_tailmm(C, hidden)) return 1;
   // hidden/32 even and >= 4: the MLP pipeline rotates two accumulators
-  static const bool wide = !(getenv("KVQ_TAIL16") && atoi(getenv("KVQ_TAIL16")) == 0);   // C = 384: csrc/tail16.hip / tailmm.hip
-  if (wide && kvq::tail16_supported(C, hidden)) return 1;
-  if (wide && (C == 512 || C == 256) && use_tailmm(C, hidden)) return 1;                  // stages 2 / 1 of Swin-B: csrc/tailmm.hip, CF = 4 / 2
   return (C == 96 || C == 128 || C == 192) && hidden % 64 == 0 && hidden >= 128 ? 1 : 0;
 }
 
 extern "C" size_t kvq_block_tail_pack_bytes(int C, int hidden) {
   if (!kvq_block_tail_supported(C, hidden)) return 0;
   if (use_tailmm(C, hidden)) return kvq::tailmm_pack_bytes(C, hidden);
-  if (kvq::tail16_supported(C, hidden)) return kvq::tail16_pack_bytes(C, hidden);
   return kvq::tail_items(C, hidden) * kvq::tail_slot_bytes(C) + kvq::tail_param_bytes(C, hidden);
 }
 
@@ -503,9 +486,6 @@ extern "C" int kvq_block_tail_pack(const void* proj_w, const float* proj_b, cons
   KVQ_REQUIRE(kvq_block_tail_supported(C, hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail_pack: C=%d hidden=%d", C, hidden);
   if (use_tailmm(C, hidden))
     return tailmm_pack((const uint16_t*)proj_w, (const uint16_t*)fc1_w, (const uint16_t*)fc2_w, proj_b, norm2_w, norm2_b, fc1_b,
-                       fc2_b, C, hidden, (unsigned char*)pack, (hipStream_t)stream);
-  if (tail16_supported(C, hidden))
-    return tail16_pack((const uint16_t*)proj_w, (const uint16_t*)fc1_w, (const uint16_t*)fc2_w, proj_b, norm2_w, norm2_b, fc1_b,
                        fc2_b, C, hidden, (unsigned char*)pack, (hipStream_t)stream);
   const long n_chunks = (long)tail_items(C, hidden) * tail_slot_bytes(C) / 16;
   const long n_par = (long)tail_param_bytes(C, hidden) / 4;
@@ -531,13 +511,11 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
   p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;
-  // (the KVQ_TAILMM=0 launch of C = 384 has no token walk: it keeps walking the window rows through scatter_map)
-  if (a->attn_gather && !(tail16_supported(a->C, a->hidden) && !use_tailmm(a->C, a->hidden))) {
+  if (a->attn_gather) {
     KVQ_REQUIRE(a->map_rows > 0 && a->M % a->map_rows == 0, KVQ_ERR_SHAPE, "kvq_block_tail: attn_gather needs M = n_batch * map_rows");
     p.gather = a->attn_gather; p.n_tok = a->M / a->map_rows * a->out_rows; p.map = nullptr;
   }
   if (use_tailmm(a->C, a->hidden)) return tailmm_launch(p, a->C, a->dtype, (hipStream_t)stream);
-  if (tail16_supported(a->C, a->hidden)) return tail16_launch(p, a->C, a->dtype, (hipStream_t)stream);
   return a->dtype == KVQ_DT_FP16 ? launch_tail_e<Fp16>(p, a->C, (hipStream_t)stream)
                                  : launch_tail_e<Bf16>(p, a->C, (hipStream_t)stream);
 }

@@ -1,4 +1,4 @@
-// Shared between tail.hip (32x32 MFMA, C <= 192) and tail16.hip (16x16 MFMA, C = 384): launch parameters of the fused
+// Shared between tail.hip (token per lane, C <= 192) and tailmm.hip (feature-sliced GEMM chain, C >= 256): launch parameters of the fused
 // post-attention launch and the entry points of the wide variant.
 #pragma once
 #include "common.hpp"
@@ -23,14 +23,7 @@ struct TailParams {
   int trace_blocks;
 };
 
-// csrc/tail16.hip
-bool tail16_supported(int C, int hidden);
-size_t tail16_pack_bytes(int C, int hidden);
-int tail16_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
-                const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st);
-int tail16_launch(const TailParams& p, int C, int dtype, hipStream_t st);
-
-// csrc/tailmm.hip: the same launch for C = 384 as a register-blocked 32x32x16 GEMM chain (default; KVQ_TAILMM=0 -> tail16.hip)
+// csrc/tailmm.hip: the same launch for C = 256 / 384 / 512 as a register-blocked 32x32x16 GEMM chain
 bool tailmm_supported(int C, int hidden);
 size_t tailmm_pack_bytes(int C, int hidden);
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,

@@ -1,12 +1,12 @@
 // The fused post-attention launch for WIDE rows (C = 384: stage 2 of Swin-T/S; C = 512: stage 2 of Swin-B, template CF = 4, numbers
 // below are for C = 384) as a register-blocked GEMM chain on
-// v_mfma_f32_32x32x16 — the replacement of tail16.hip's token-per-lane 16x16x32 design.
+// v_mfma_f32_32x32x16 (round 1's token-per-lane 16x16x32 launch for C = 384, tail16.hip, was retired in round 3).
 //
 // Same computation (swin_backbone.py:479-516): x += proj(attn) (window-reverse / roll-back / crop through the row map);
 // x += fc2(GELU(fc1(norm2(x)))) [+ the next block's norm1 in ITS window order].
 //
-// Why a second design: tail16 feeds every 16-cycle MFMA with its own 1 KB weight fragment from LDS and has ONE wave per SIMD,
-// so its floor is the wave's instruction stream: 2592 MFMAs x 17 ticks + 2592 fragment reads + the GELU stream, additive on
+// Why not token-per-lane as for C <= 192: at C = 384 that design feeds every 16-cycle MFMA with its own 1 KB weight fragment from LDS
+// and has ONE wave per SIMD, so its floor is the wave's instruction stream: 2592 MFMAs x 17 ticks + 2592 fragment reads + GELU, additive on
 // gfx950 (tools/ubench/pipe_share.hip: VALU and LDS issue of a wave do not hide under that wave's own MFMAs beyond ~4 cycles
 // per 16x16x32 / ~11 per 32x32x16).  Here a workgroup is still 64 tokens x 4 waves, but a wave owns a FEATURE slice for all
 // 64 tokens instead of a token slice for all features:
@@ -14,15 +14,15 @@
 //     a wave's k-step is 3 weight fragments + 2 activation fragments for 6 MFMAs (fc1: 2 + 2 for 4) — 1296 MFMAs of 32
 //     cycles per wave instead of 2592 of 16, and 5 LDS reads per 192 MFMA cycles instead of 12;
 //   * a wave reads only ITS feature rows' weights, so each wave streams its own fragment list (648 x 1 KB, consumption
-//     order, packed by tailmm_pack_kernel) through a PRIVATE LDS ring by LDS-DMA with a counted vmcnt — no workgroup barrier
-//     per ring item, the stream runs 12 fragments ahead across all phases;
+//     order, packed by tailmm_pack_kernel) global -> VGPR through a private REGISTER ring with the compiler's counted vmcnt —
+//     no LDS round trip, no workgroup barrier per fragment; the stream runs 20 fragments ahead across all phases;
 //   * activations go through LDS as ready-made B fragments: the attention rows by LDS-DMA (row gather), norm2's output and
 //     the GELU output written by their producers straight from the accumulator layout (a lane holds one token and, per tile
 //     and register quad pair, 8 k values = one 16-byte fragment slot; the k order inside a 16-step is permuted accordingly in
 //     the packed weights): 3 + 2 x 6 workgroup barriers per launch;
 //   * D keeps a token per lane (column) — residual, LayerNorm statistics (in-lane + lane^32 + a 4-wave exchange through
 //     LDS), bias and GELU are register arithmetic as before.
-// LDS: 48 KB activation tile (attention rows, then norm2 rows) + 32 KB GELU chunk + 4 x 16 KB rings + 12 KB parameters.
+// LDS: 48 KB activation tile (attention rows, then norm2 rows) + 32 KB GELU chunk + 12 KB parameters.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -36,7 +36,6 @@ typedef __attribute__((address_space(3))) void* mm_lds_t;
 typedef __attribute__((address_space(1))) const void* mm_gbl_t;
 
 constexpr int MM_TOK = 64, MM_HC = 256, MM_KS_H = MM_HC / 16;   // tokens per workgroup, hidden chunk (16 k-steps)
-constexpr int MM_RING = 16, MM_PF = 12;                         // LDS ring (CF = 3 only): slots (1 KB) per wave, fragments in flight
 // Geometry by CF = C / 128 = 32-feature tiles per wave: 3 (C = 384: stage 2 of Swin-T / -S) or 4 (C = 512: stage 2 of Swin-B,
 // register ring only — its 64 KB activation tile leaves no room for an LDS weight ring)
 template <int CF>
@@ -47,8 +46,7 @@ struct MMc {
   static constexpr int NF = NF_PROJ + NCH * (NF_FC1 + NF_FC2);          // fragments per wave: 648 / 1152
   static constexpr int OFF_X = 0;                                       // [KS_C k-steps][2 token tiles][64 lanes][16 B] = 48 / 64 KB
   static constexpr int OFF_G = OFF_X + KS_C * 2 * 1024;                 // [16][2][64][16 B] = 32 KB
-  static constexpr int OFF_RING = OFF_G + MM_KS_H * 2 * 1024;           // 4 waves x 16 KB (CF = 3)
-  static constexpr int OFF_PRM = OFF_RING + (CF == 3 ? 4 * MM_RING * 1024 : 0);     // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
+  static constexpr int OFF_PRM = OFF_G + MM_KS_H * 2 * 1024;            // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
   static constexpr int PRM_FLOATS = H + 4 * C;
   static constexpr int OFF_RED = OFF_PRM + PRM_FLOATS * 4;              // [4 waves][64 tokens] fp32
   static constexpr int LDS = OFF_RED + 4 * MM_TOK * 4;
@@ -140,23 +138,19 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
   return KVQ_OK;
 }
 
-// DBG (diagnostic builds of the same kernel, tools/tail_time.py): 1 = no weight stream (no LDS-DMA, no vmcnt waits: stale ring
-// contents), 2 = no MFMAs, 3 = neither, 4 = no fragment reads
-// VR (default; KVQ_TAILMM_VR=0 selects the LDS ring described above): a wave's weight fragments are PRIVATE to it, so the LDS ring was
-// only a latency buffer — and plain VGPR loads stream as fast as LDS-DMA (tools/ubench/l2_stream.hip).  The fragments go global ->
-// VGPR and are the MFMA A operand as they arrive: a REGISTER ring of 24 fragments per wave, 20 in flight (80 KB per CU instead of
-// 48), no fragment reads from LDS (648 fewer ds_read_b128 per wave).  Slots are compile-time: every phase consumes a multiple of 24
-// fragments, so phase-local position q lives in slot q % 24.  Plain loads, not inline asm: the compiler's own vmcnt bookkeeping is
-// exact in the unrolled phases (s_waitcnt vmcnt(19 / 18) in the steady state), and an inline-asm load is unsafe under this register
-// pressure (the allocator splits the live range of a value it believes ready; the late data lands in a register handed on).
-// 79 -> 73 us (with the next norm1), 73 -> 64 us (without); bit-identical results.
-template <typename E, bool EMIT, int DBG = 0, bool VR = false, int CF = 3>
+// The weight stream: a wave's weight fragments are PRIVATE to it, and plain VGPR loads stream as fast as LDS-DMA
+// (tools/ubench/l2_stream.hip), so the fragments go global -> VGPR and are the MFMA A operand as they arrive: a REGISTER ring of
+// VR_R fragments per wave, VR_PF in flight (80 KB per CU at C = 384), no weight reads from LDS.  Slots are compile-time: every phase
+// consumes a multiple of VR_R fragments, so phase-local position q lives in slot q % VR_R.  Plain loads, not inline asm: the
+// compiler's own vmcnt bookkeeping is exact in the unrolled phases (s_waitcnt vmcnt(19 / 18) in the steady state), and an inline-asm
+// load is unsafe under this register pressure (the allocator splits the live range of a value it believes ready; the late data lands
+// in a register handed on).  (Round 2 also carried an LDS-ring form of the stream and ablation builds of it — no weight stream 65 us,
+// no MFMAs 57, neither 43 of 78 — removed in round 3: 79 -> 73 us with the next norm1, 73 -> 64 without, bit-identical.)
+template <typename E, bool EMIT, int CF = 3>
 __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
-  static_assert(!VR || DBG == 0, "the ablation builds are of the LDS-ring kernel");
-  static_assert(VR || CF == 3, "C = 512 has no room for the LDS weight ring");
   using K = MMc<CF>;
   constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_KS_C = K::KS_C, MM_NF = K::NF, VR_R = K::VR_R, VR_PF = K::VR_PF, FW = K::W;
-  constexpr int MM_OFF_X = K::OFF_X, MM_OFF_G = K::OFF_G, MM_OFF_RING = K::OFF_RING, MM_OFF_PRM = K::OFF_PRM, MM_OFF_RED = K::OFF_RED;
+  constexpr int MM_OFF_X = K::OFF_X, MM_OFF_G = K::OFF_G, MM_OFF_PRM = K::OFF_PRM, MM_OFF_RED = K::OFF_RED;
   constexpr int MM_PRM_FLOATS = K::PRM_FLOATS;
   constexpr size_t MM_PACK_FRAG_BYTES = K::PACK_FRAG_BYTES;
   fp16_saturate_mode();
@@ -165,7 +159,6 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   constexpr int C = MM_C;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* ring = lds + MM_OFF_RING + wave * (MM_RING * 1024);
   const unsigned char* wsrc = p.pack + (size_t)wave * MM_NF * 1024 + lane * 16;    // this wave's fragment list
   float* prm = reinterpret_cast<float*>(lds + MM_OFF_PRM);
   float* red = reinterpret_cast<float*>(lds + MM_OFF_RED);
@@ -181,27 +174,15 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
 #endif
   MM_STAMP(0);
 
-  // ---- the weight stream: fragment i of the list lives in ring slot i % 16; `issued` fragments have been requested ----
+  // ---- the weight stream: `issued` fragments of this wave's list have been requested ----
   // (past the end of the list the LAST fragment is requested again, into a slot nobody reads any more: the vmcnt arithmetic
   // stays uniform and the loop bodies stay branch-free)
   int issued = 0;
-  typename E::v8 wr[VR ? VR_R : 1];
+  typename E::v8 wr[VR_R];
   auto vload = [&](int slot) __attribute__((always_inline)) {        // list position `issued` -> register slot (compile-time after unrolling)
     const int src = issued < MM_NF ? issued : MM_NF - 1;
-    // a plain load: the compiler counts vmcnt itself (an inline-asm load is unsafe here — under this register pressure the
-    // allocator splits the live range of a value it believes ready, and the late data lands in a register that was handed on)
     wr[slot] = *reinterpret_cast<const typename E::v8*>(wsrc + (size_t)src * 1024);
     ++issued;
-  };
-  auto issue = [&](int n) __attribute__((always_inline)) {
-    if (DBG & 1) { issued += n; return; }
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (q < n) {
-        const int src = issued < MM_NF ? issued : MM_NF - 1;
-        __builtin_amdgcn_global_load_lds((mm_gbl_t)(wsrc + (size_t)src * 1024), (mm_lds_t)(ring + (issued & (MM_RING - 1)) * 1024), 16, 0, 0);
-        ++issued;
-      }
   };
 
   // ---- this workgroup's rows: token tt*32 + j of 64, window order -> token of the residual stream ----
@@ -241,12 +222,8 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     for (int q = wave; q < (MM_PRM_FLOATS * 4) / 1024; q += 4)      // b1 | g2 | b2n | proj_b | b2: 12 KB
       __builtin_amdgcn_global_load_lds((mm_gbl_t)((const unsigned char*)gprm + q * 1024 + lane * 16), (mm_lds_t)(lds + MM_OFF_PRM + q * 1024), 16, 0, 0);
   }
-  if (VR) {
 #pragma unroll
-    for (int q = 0; q < VR_PF; ++q) vload(q);        // 20 fragments of the weight list in flight from here on
-  } else {
-    issue(3); issue(3); issue(3); issue(3);          // 12 fragments of the weight list in flight from here on
-  }
+  for (int q = 0; q < VR_PF; ++q) vload(q);          // VR_PF fragments of the weight list in flight from here on
   // ---- accumulators = x + proj bias: tile (ft, tt), register r <-> feature 96 wave + 32 ft + (r&3) + 8 (r>>2) + 4 half ----
   // all 24 row pieces of a lane are requested before anything waits (they queue behind the DMA requests above: one drain)
   f32x16 acc[CF][2];
@@ -276,113 +253,37 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
       }
   }
 
-  // One GEMM phase: nk k-steps, NA weight tiles per wave; weight fragments are consumed from the ring at list position
-  // `cons` (advanced), activation fragments from `bbuf` ([k-step][2][1 KB]); mm(ft, tt, a, b) issues one MFMA.
-  // Fragments of k-step s+1 are read while the MFMAs of k-step s run; after the reads have returned, NA new fragments are
-  // requested — the stream stays MM_PF fragments ahead of the reads, counted by vmcnt(MM_PF - NA).
-  int cons = 0;
+  // One GEMM phase: nk k-steps, NA weight tiles per wave; the weight fragments ARE the registers wr[.] (phase-local list position
+  // q lives in slot q % VR_R), activation fragments come from `bbuf` ([k-step][2][1 KB]); mm(ft, tt, a, b) issues one MFMA.
+  // A loop body covers KU k-steps (fc1 has only 4 MFMAs per k-step: two are paired); the activation fragments of body s+1 are read
+  // and NR new weight fragments requested BETWEEN the MFMAs of body s, one at a time: a wave's LDS / VMEM issue hides under its own
+  // MFMAs only ~10 cycles at a time (tools/ubench/pipe_share.hip) — a burst of 5 reads in front of 6 MFMAs does not hide at all.
   auto gemm_phase = [&](auto na_tag, auto nk_tag, const unsigned char* bbuf, auto&& mm, auto&& between) __attribute__((always_inline)) {
-    // NA weight tiles per wave; a loop body covers KU k-steps (fc1 has only 4 MFMAs per k-step: two are paired so that a fragment
-    // is still requested >= 5 MFMAs before its first use); NR fragments of the list per body
     constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : 1, NR = NA * KU;
-    constexpr int NM = 2 * NA * KU, NRD = (NA + 2) * KU;          // MFMAs / fragment reads per body
-    static_assert(nk % KU == 0 && MM_PF - NR >= 0, "k-steps per body");
-    V8 a[2][KU][CF], b[2][KU][2];        // fragments of two bodies: the one in use and the one being read
-    // read q of a body (base k-step ks, weight fragments from list position cons): per k-step the order a0 b0 b1 a1 [a2] against
-    // the MFMA order (a0 b0) (a0 b1) (a1 b0) (a1 b1) [(a2 b0) (a2 b1)]
-    auto rd1 = [&](int buf, int ks, int q) __attribute__((always_inline)) {
-      const int k = q / (NA + 2), r = q % (NA + 2);
-      const int what = r == 0 ? 2 : r <= 2 ? r - 1 : r;            // 0, 1 = activation tile; 2 + i = weight fragment i
-      if (DBG == 4) {
-        if (what < 2) asm volatile("" : "+v"(b[buf][k][what]));
-        else asm volatile("" : "+v"(a[buf][k][what - 2]));
-        return;
-      }
-      if (what < 2) b[buf][k][what] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * 2 + what) * 1024 + lane * 16);
-      else a[buf][k][what - 2] = *reinterpret_cast<const V8*>(ring + ((cons + k * NA + what - 2) & (MM_RING - 1)) * 1024 + lane * 16);
+    constexpr int NM = 2 * NA * KU;                               // MFMAs per body
+    static_assert(nk % KU == 0, "k-steps per body");
+    V8 b[2][KU][2];                      // activation fragments of two bodies: the one in use and the one being read
+    auto rdb = [&](int buf, int ks, int q) __attribute__((always_inline)) {
+      const int k = q >> 1, tt = q & 1;
+      b[buf][k][tt] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * 2 + tt) * 1024 + lane * 16);
     };
-    if (DBG == 4) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int k = 0; k < KU; ++k) {
-#pragma unroll
-          for (int q = 0; q < CF; ++q) a[u][k][q] = V8{};
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) b[u][k][tt] = V8{};
-        }
-    }
-    // the next NR fragments of the list have landed: exactly MM_PF - NR younger requests may still be in flight
-    auto landed = [&]() __attribute__((always_inline)) {
-      if (DBG & 1) return;
-#ifdef KVQ_TAIL_TRACE
-      const unsigned long long t0_ = __builtin_readcyclecounter();
-#endif
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MM_PF - NR) : "memory");
-#ifdef KVQ_TAIL_TRACE
-      wait_dma += __builtin_readcyclecounter() - t0_;
-#endif
-    };
-    auto mfma1 = [&](int u, int m) __attribute__((always_inline)) {        // MFMA m of a body: k-step m / 2NA, weight tile, token tile
-      const int k = m / (2 * NA), t = (m % (2 * NA)) >> 1, tt = m & 1;
-      if (DBG & 2) { asm volatile("" :: "v"(a[u][k][t]), "v"(b[u][k][tt])); }
-      else mm(t, tt, a[u][k][t], b[u][k][tt]);
-    };
-    // A body: the fragments of the NEXT body are read and NR new ones requested BETWEEN the MFMAs of this one, one at a time: a
-    // wave's LDS / VMEM issue hides under its own MFMAs only ~10 cycles at a time (tools/ubench/pipe_share.hip) — a burst of 5
-    // reads in front of 6 MFMAs does not hide at all.  Request i (issued behind MFMA NM - NR + i) overwrites the ring slot of list
-    // position cons - 4 + i: a fragment of the previous body, or one of this body that MFMAs already ISSUED have consumed (NA = 3:
-    // cons-4 = previous body, cons-3 = a0, cons-2 = a1, used by MFMAs 0..3; NA = 2, two k-steps: cons-4+i is used by MFMAs 2i, 2i+1
-    // and overwritten behind MFMA 4+i) — no wait for LDS reads is needed.
-    auto body = [&](int s, bool more) __attribute__((always_inline)) {
-      const int u = (s / KU) & 1;
-      if (more) landed();
+    auto body_vr = [&](int s, bool more) __attribute__((always_inline)) {
+      const int u = (s / KU) & 1, base = (s / KU) * NR;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        mfma1(u, m);
-        if (more && m < NRD) rd1(u ^ 1, s + KU, m);
-        if (more && m >= NM - NR) issue(1);
+        const int k = m / (2 * NA), t = (m % (2 * NA)) >> 1, tt = m & 1;
+        mm(t, tt, wr[(base + k * NA + t) % VR_R], b[u][k][tt]);
+        if (more && m < 2 * KU) rdb(u ^ 1, s + KU, m);
+        if (m >= NM - NR) vload((base + VR_PF + (m - (NM - NR))) % VR_R);
         between(s * 2 * NA + m);                        // VALU work of the caller, placed between two MFMAs
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) cons += NR;
     };
-    if (VR) {
-      // activation fragments of body s+1 are read under the MFMAs of body s; the weight fragments ARE the registers wr[.]: list
-      // position (phase-local) q lives in slot q % 24, the body's own NR fragments are waited for (20 - NR younger requests stay in
-      // flight) and NR new ones requested into the slots of the previous body
-      auto rdb = [&](int buf, int ks, int q) __attribute__((always_inline)) {
-        const int k = q >> 1, tt = q & 1;
-        b[buf][k][tt] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * 2 + tt) * 1024 + lane * 16);
-      };
-      auto body_vr = [&](int s, bool more) __attribute__((always_inline)) {
-        const int u = (s / KU) & 1, base = (s / KU) * NR;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-          const int k = m / (2 * NA), t = (m % (2 * NA)) >> 1, tt = m & 1;
-          mm(t, tt, wr[(base + k * NA + t) % VR_R], b[u][k][tt]);
-          if (more && m < 2 * KU) rdb(u ^ 1, s + KU, m);
-          if (m >= NM - NR) vload((base + VR_PF + (m - (NM - NR))) % VR_R);
-          between(s * 2 * NA + m);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
+    for (int q = 0; q < 2 * KU; ++q) rdb(0, 0, q);
 #pragma unroll
-      for (int q = 0; q < 2 * KU; ++q) rdb(0, 0, q);
-#pragma unroll
-      for (int s = 0; s + KU < nk; s += KU) body_vr(s, true);
-      body_vr(nk - KU, false);
-      return;
-    }
-    landed();
-#pragma unroll
-    for (int q = 0; q < NRD; ++q) rd1(0, 0, q);
-    cons += NR;
-    issue(NR > 3 ? 3 : NR);
-    if (NR > 3) issue(NR - 3);
-#pragma unroll
-    for (int s = 0; s + KU < nk; s += KU) body(s, true);
-    body(nk - KU, false);
+    for (int s = 0; s + KU < nk; s += KU) body_vr(s, true);
+    body_vr(nk - KU, false);
   };
   using KC = std::integral_constant<int, MM_KS_C>;
   using KH = std::integral_constant<int, MM_KS_H>;
@@ -464,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
 
   // ---- MLP over 6 chunks of 256 hidden units: fc1 (wave: 64 units x 64 tokens) -> GELU -> LDS -> fc2 partial.  Software
   // pipeline: fc1 of chunk c+1 runs first, then the GELU of chunk c+1 is evaluated BETWEEN the MFMAs of fc2(chunk c) — one pair
-  // per three MFMAs — so that the VALU stream no longer stops the weight stream (the ring only buffers 12 KB per wave) ----------
+  // per three MFMAs — so that the VALU stream no longer stops the weight stream ----------
   f32x16 hacc[2][2];
   u32x4 gp[2][2][2];                                  // GELU outputs of a chunk, packed: [weight tile][k-step half][token tile]
   auto fc1 = [&](int c) __attribute__((always_inline)) {
@@ -561,76 +462,22 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   MM_STAMP(4);
 }
 
-template <typename E, int DBG>
-static int launch_mm_dbg(const TailParams& p, hipStream_t st) {
-  constexpr int MM_LDS = MMc<3>::LDS;
-  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
-  auto k = block_tailmm_kernel<E, true, DBG>;
-  KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS));
-  hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
-  KVQ_CHECK_LAUNCH("block_tailmm_kernel(dbg)");
-  return KVQ_OK;
-}
-
-template <typename E>
-static int launch_mm(const TailParams& p, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
-  static const int dbg = getenv("KVQ_MM_DEBUG") ? atoi(getenv("KVQ_MM_DEBUG")) : 0;
-  if (dbg && p.next_ln) {
-    if (dbg == 1) return launch_mm_dbg<E, 1>(p, st);
-    if (dbg == 2) return launch_mm_dbg<E, 2>(p, st);
-    if (dbg == 3) return launch_mm_dbg<E, 3>(p, st);
-    if (dbg == 4) return launch_mm_dbg<E, 4>(p, st);
-  }
-  constexpr int MM_LDS = MMc<3>::LDS;
-  static const int vr = getenv("KVQ_TAILMM_VR") ? atoi(getenv("KVQ_TAILMM_VR")) : 1;
-  if (vr) {
-    if (p.next_ln) {
-      auto k = block_tailmm_kernel<E, true, 0, true>;
-      static bool set = false;
-      if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
-      hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
-    } else {
-      auto k = block_tailmm_kernel<E, false, 0, true>;
-      static bool set = false;
-      if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
-      hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
-    }
-    KVQ_CHECK_LAUNCH("block_tailmm_kernel(vr)");
-    return KVQ_OK;
-  }
-  if (p.next_ln) {
-    auto k = block_tailmm_kernel<E, true>;
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
-    hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
-  } else {
-    auto k = block_tailmm_kernel<E, false>;
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS)); set = true; }
-    hipLaunchKernelGGL(k, grid, block, MM_LDS, st, p);
-  }
-  KVQ_CHECK_LAUNCH("block_tailmm_kernel");
-  return KVQ_OK;
-}
-
-// C = 512 / 256 (CF = 4 / 2): the register-ring kernel only
 template <typename E, int CF>
 static int launch_mm_cf(const TailParams& p, hipStream_t st) {
   constexpr int LDS = MMc<CF>::LDS;
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
   if (p.next_ln) {
-    auto k = block_tailmm_kernel<E, true, 0, true, CF>;
+    auto k = block_tailmm_kernel<E, true, CF>;
     static bool set = false;
     if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   } else {
-    auto k = block_tailmm_kernel<E, false, 0, true, CF>;
+    auto k = block_tailmm_kernel<E, false, CF>;
     static bool set = false;
     if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   }
-  KVQ_CHECK_LAUNCH("block_tailmm_kernel(CF)");
+  KVQ_CHECK_LAUNCH("block_tailmm_kernel");
   return KVQ_OK;
 }
 
@@ -638,7 +485,7 @@ int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
   if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
   if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
-  return dtype == KVQ_DT_FP16 ? launch_mm<Fp16>(p, st) : launch_mm<Bf16>(p, st);
+  return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3>(p, st) : launch_mm_cf<Bf16, 3>(p, st);
 }
 
 }  // namespace kvq

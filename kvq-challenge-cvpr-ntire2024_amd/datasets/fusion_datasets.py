@@ -281,7 +281,7 @@ class _Staging:
 
 
 _COPY_POOL = None
-_COPY_THREADS = max(1, int(os.environ.get("KVQ_COPY_THREADS", 4)))
+_COPY_THREADS = 4
 
 
 def _frames_to_device(vr, uniq, device):

@@ -510,7 +510,7 @@ def conv_taps(kernel, Cc: int, H: int, W: int, k_pad: int, device, live=None):
     return t
 
 
-TAP_TABLE = bool(__import__("os").environ.get("KVQ_CONV_TAP_TABLE"))     # experiments: always hand kvq_conv_implicit a tap table
+TAP_TABLE = False      # test hook: True = always hand kvq_conv_implicit a tap table (tap walk vs table: bit-identical)
 
 
 def conv_implicit(x: torch.Tensor, W: torch.Tensor, bias, kernel, stride, pad, relu: bool, resid=None, resid_f32=None,

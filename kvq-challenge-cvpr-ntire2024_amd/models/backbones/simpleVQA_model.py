@@ -15,8 +15,8 @@ from ... import _abi, kernels
 from .swin_backbone import _Affine
 
 
-IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
-CONVNET = os.environ.get("KVQ_CONVNET", "1") != "0"                  # 0: the layer-by-layer Python sequencing
+IMPLICIT_CONV = True     # 0: materialised im2col + GEMM
+CONVNET = True                  # 0: the layer-by-layer Python sequencing
 
 
 class _BN(nn.Module):
@@ -128,7 +128,7 @@ class ResNet(nn.Module):
             # implicit GEMM: the A tiles are fetched from the activation itself (no patch matrix).  On tiny maps (CONTRIQUE's
             # 32x32 patches reach 2x2 and 1x1) most taps of a padded 3x3 only ever read zeros: drop them from K.
             live, wk = None, wb[0]
-            if k > 1 and min(h, w_) < k and os.environ.get("KVQ_PRUNE_TAPS", "1") != "0":
+            if k > 1 and min(h, w_) < k:
                 live = kernels.live_taps((1, h, w_), (1, k, k), (1, stride, stride), (0, pad, pad))
                 if len(live[1]) * len(live[2]) < k * k:
                     cache = self.__dict__.setdefault("_pruned", {})
@@ -304,7 +304,7 @@ class ResNet(nn.Module):
         -> 16-bit channels-last (b*t, ho, wo, 64).  Implicit GEMM over the input packed to 8 channels (no patch matrix: the
         147-column im2col of a 224x224 frame is 12x the frame), or the materialised im2col with KVQ_IMPLICIT_CONV=0."""
         B, T, c, h, w_ = dims5
-        if IMPLICIT_CONV and c <= 8 and os.environ.get("KVQ_STEM_IMPLICIT", "1") != "0":
+        if IMPLICIT_CONV and c <= 8:
             x8 = kernels.pack_channels_last8(x, dims5, strides5, half)
             y = kernels.conv_implicit(x8.reshape(B * T, 1, h, w_, 8), w["stem8"], w["stem"][1], (1, 7, 7), (1, 2, 2), (0, 3, 3), True)
             return y.reshape(B * T, y.shape[2], y.shape[3], 64)

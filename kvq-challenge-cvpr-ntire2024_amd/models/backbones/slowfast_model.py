@@ -131,16 +131,16 @@ def check_head_grid(pathway, grid, small="error"):
     return tuple(grid) != k
 
 
-IMPLICIT_CONV = os.environ.get("KVQ_IMPLICIT_CONV", "1") != "0"     # 0: materialised im2col + GEMM
+IMPLICIT_CONV = True     # 0: materialised im2col + GEMM
 # Residual stream between bottlenecks: 16-bit (default) or fp32.  The conv_c launches that carry it are HBM-bound — per output
 # element an fp32 stream reads 4 B, writes 4 B + the 16-bit copy the next conv_a needs; a 16-bit stream reads 2 B and writes 2 B
 # (17 launches, 0.92 -> ~0.5 ms per video of 8 clips).  HIP vs the fp32 CPU restatement stays within the 5e-3 relative-L2 bar of
 # tests/test_slowfast.py either way (fp32 accumulation inside every conv; one extra 16-bit rounding per block).
-RESIDUAL16 = os.environ.get("KVQ_SF_RESID16", "1") != "0"
-CONVNET = os.environ.get("KVQ_CONVNET", "1") != "0"                  # 0: the layer-by-layer Python sequencing below
-FUSE_FAST = os.environ.get("KVQ_SF_FUSE_FAST", "1") != "0"            # 0: the fast pathway's residual blocks as 3-4 conv launches each
-TWO_LANES = os.environ.get("KVQ_SF_LANES", "1") != "0"                # 0: both pathways on the caller's stream, one op after the other
-STEM_MFMA = os.environ.get("KVQ_STEM_MFMA", "1") != "0"             # 0: fast-pathway stem on the fp32 direct kernel
+RESIDUAL16 = True
+CONVNET = True                  # 0: the layer-by-layer Python sequencing below
+FUSE_FAST = True            # 0: the fast pathway's residual blocks as 3-4 conv launches each
+TWO_LANES = True                # 0: both pathways on the caller's stream, one op after the other
+STEM_MFMA = True             # 0: fast-pathway stem on the fp32 direct kernel
 
 
 def _fragments(w, k_real, row_tiles, accumulator_order=False):
@@ -297,7 +297,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             y = kernels.conv_stem_mfma(x.contiguous(), mfma, bias, k, stride, pad, True)
         elif direct is not None:
             y = kernels.conv_stem_direct(x, direct, bias, k, stride, pad, True, half)
-        elif IMPLICIT_CONV and C <= 8 and k[0] == 1 and os.environ.get("KVQ_STEM_IMPLICIT", "1") != "0":
+        elif IMPLICIT_CONV and C <= 8 and k[0] == 1:
             # slow pathway: 3 -> 64 channels, k 1x7x7: implicit GEMM over the clip packed to 8 channels (no 147-column patch matrix)
             x8 = kernels.pack_channels_last8(x, (B, T, C, H, W), (C * T * H * W, H * W, T * H * W, W, 1), half)
             w8 = self.__dict__.setdefault("_stem8", {})

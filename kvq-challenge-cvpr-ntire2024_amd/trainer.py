@@ -115,7 +115,7 @@ class Trainer:
         # hipGraph replay of the per-video forward (kvq_amd/graph.py): default for KSVQE (~360 launches per video) and
         # SimpleVQA (~70 launches for 8 frames), which are enqueue-bound (tools/harness_probe*.py: 101 vs 62 and 283 vs 213
         # videos/s end to end); the Swin trunk alone is not (+1 %).  KVQ_GRAPH=1 / 0 forces it on / off for any model
-        want = str(self.config.get("hipgraph", os.environ.get("KVQ_GRAPH", "auto"))).lower()
+        want = str(self.config.get("hipgraph", "auto")).lower()
         use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] in ("KSVQE", "simpleVQA"))
         # lanes: 3 eager streams; 4 graph lanes = one per hardware queue (measured, tools/harness_probe.py: 2 / 3 / 4 / 5 lanes ->
         # 238 / 270 / 284 / 240 videos/s on 96-frame KSVQE samples: a fifth lane shares a queue and its graph serialises)
@@ -125,7 +125,7 @@ class Trainer:
         # default: 2 when the forwards are enqueued eagerly (their ~6 ms of host work per video would otherwise wait for the
         # item), 0 under graph replay (a launch is 0.3 ms of host time, the replay already overlaps the next item's build;
         # measured 101 vs 92 videos/s end to end)
-        depth = int(self.config.get("prefetch", os.environ.get("KVQ_PREFETCH", 0 if use_graph else 2)))
+        depth = int(self.config.get("prefetch", 0 if use_graph else 2))
         if use_graph:
             from .graph import LaneGraphs
             cached = getattr(self, "_lane_graphs", None)           # recordings outlive one call (inferece_test + inferece_val)

@@ -565,7 +565,7 @@ def _tail_reference(A, x, wts, half, lay, B, dims):
                                                    (128, (8, 7, 14), (4, 3, 3), (0, 0, 0)),
                                                    (192, (8, 14, 7), (0, 0, 0), (4, 3, 3)),
                                                    (192, (3, 5, 7), (0, 0, 0), None),      # clamped window, ragged tile
-                                                   (384, (8, 14, 14), (0, 0, 0), (4, 3, 3)),   # wide rows: csrc/tail16.hip
+                                                   (384, (8, 14, 14), (0, 0, 0), (4, 3, 3)),   # wide rows: csrc/tailmm.hip
                                                    (384, (8, 7, 7), (0, 0, 0), (0, 0, 0)),
                                                    (384, (4, 10, 9), (4, 3, 3), None),
                                                    (256, (8, 14, 7), (4, 3, 3), (0, 0, 0)),    # stage 1 of Swin-B: tailmm, CF = 2
