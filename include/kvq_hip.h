@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 21
+#define KVQ_ABI_VERSION 22
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -369,6 +369,15 @@ typedef struct {
   uint16_t* out;              /* [BW*N][nH*32] */
   const uint32_t* tile_skip;  /* optional, as kvq_window_attention_dense_skip */
   int32_t dsplit_from;        /* -1 = no depth-split windows */
+  /* Fused qkv projection (x_ln != NULL; C = 32 num_heads = 96; always one workgroup per (window, head)): the workgroup of a (window,
+   * head) computes its q | k | v from the window's norm1 rows — x_ln 16-bit [BW*N][C] in window order (no padding rows: un-padded
+   * partitions only), w_qkv 16-bit [3C][C], b_qkv fp32 [3C] (swin_backbone.py:252-260) — instead of reading them: k and v go
+   * straight into the LDS images, q (scaled by q_scale) into the q third of `qkv` ([num_heads][BW*N][32]; the k / v thirds are not
+   * touched and need not exist).  Replaces kvq_gemm_bf16(KVQ_EPI_QKV_BF16) for the stages where that launch is HBM-bound. */
+  const uint16_t* x_ln;
+  const uint16_t* w_qkv;
+  const float* b_qkv;
+  float q_scale;
 } KvqAttnDenseArgs;
 int kvq_window_attention_dense_args(const KvqAttnDenseArgs* host_args, void* stream);
 

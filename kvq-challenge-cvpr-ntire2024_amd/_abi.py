@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 def dtype_code(dt) -> int:
@@ -64,7 +64,8 @@ class KvqSwinWeights(C.Structure):
 
 class KvqAttnDenseArgs(C.Structure):
     _fields_ = [("qkv", p_void), ("bias_dense", p_void), ("n_types", C.c_int32), ("BW", C.c_int32), ("nW", C.c_int32), ("N", C.c_int32),
-                ("num_heads", C.c_int32), ("dtype", C.c_int32), ("out", p_void), ("tile_skip", p_void), ("dsplit_from", C.c_int32)]
+                ("num_heads", C.c_int32), ("dtype", C.c_int32), ("out", p_void), ("tile_skip", p_void), ("dsplit_from", C.c_int32),
+                ("x_ln", p_void), ("w_qkv", p_void), ("b_qkv", p_void), ("q_scale", C.c_float)]
 
 
 class KvqGemmArgs(C.Structure):

@@ -438,9 +438,94 @@ struct AttnDenseParams {
   int trace_blocks;
   const uint32_t* tile_skip;   // optional [nW]: bit t = q-tile t of the window holds padding rows only (its output is never read)
   int dsplit_from;             // >= 0: windows w >= dsplit_from of a clip are depth-split at token 196 of 392 (see tile_body); -1: none
+  // fused qkv projection (x_ln != NULL): q | k | v of this (window, head) are computed in the prologue from the window's norm1 rows
+  const uint16_t* x_ln;        // [BW*N][C] 16-bit, window order
+  const uint16_t* w_qkv;       // [3C][C] 16-bit
+  const float* b_qkv;          // [3C]
+  int C_in;                    // = 32 nH
+  float q_scale;
+  uint16_t* q_out;             // = the q third of `qkv`: [nH][BW*N][32], written here and read back per q-tile
 };
 
-template <typename E>
+// Fused qkv projection (swin_backbone.py:252-260) for one (window, head): D^T[feature][row] = W[feature][:] . x[row][:] on
+// v_mfma_f32_16x16x32 (weights = A operand, the window's norm1 rows = B operand), so a lane ends up with 4 CONSECUTIVE features of
+// ONE row: + bias, (q: x head_dim^-0.5), 16-bit rounding as the qkv GEMM's epilogue does, then 8 bytes straight into the K image
+// (XOR-swizzled rows), the V image ([32 keys][16 features] subtiles) or the q scratch.  Stages 0 / 1 (C = 96 / 192): the qkv GEMM
+// there is an HBM-bound launch that writes 77-115 MB the attention launch reads right back; here the rows are read once per head
+// (L2 hits) and q | k | v never exist in HBM (q: 25 KB per workgroup, L2-resident).  Wave w takes row tiles w, w+4, ...; all six
+// 16-feature column tiles (q0 q1 k0 k1 v0 v1) in ONE pass over the rows (C <= 128: their 72-96 weight-fragment registers stay resident;
+// the per-CU load path, 64 B/clk, is what bounds this prologue: at C = 192 the rows would be read twice and the launch loses to the GEMM).
+template <typename E, int KS>
+__device__ __forceinline__ void fused_qkv_prologue(const AttnDenseParams& p, unsigned char* smem, unsigned char* Vs, int bw, int h, int N) {
+  using V8 = typename E::v8;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = KS * 32;
+  const size_t Mtot = (size_t)p.BW * N;
+  const uint16_t* xw = p.x_ln + (size_t)bw * N * C;
+  uint16_t* qo = p.q_out + ((size_t)h * Mtot + (size_t)bw * N) * 32;
+  constexpr int CP = KS <= 4 ? 6 : 3;            // column tiles per pass: their weight fragments (CP x KS x 4 registers) stay resident
+#pragma unroll 1
+  for (int pass = 0; pass < 6 / CP; ++pass) {
+    V8 wf[CP][KS];
+    float bias[CP][4];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const int ct = CP * pass + c, which = ct >> 1, half = ct & 1;
+      const int frow = which * C + h * 32 + half * 16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wf[c][ks] = *reinterpret_cast<const V8*>(p.w_qkv + (size_t)(frow + j) * C + 32 * ks + 8 * g);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b_qkv + frow + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[c][r] = b4[r];
+    }
+    // the row fragments of tile i+1 are requested before tile i is multiplied (an L2 round trip each: un-pipelined, seven
+    // dependent round trips per pass were a fifth of the workgroup's life)
+    const int nrt = (N + 15) / 16;
+    V8 xn[KS];
+    {
+      const int rowc = min(16 * wave + j, N - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
+    }
+#pragma unroll 1
+    for (int rt = wave; rt < nrt; rt += ATT_WAVES) {
+      const int row = 16 * rt + j;
+      V8 xf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[ks] = xn[ks];
+      if (rt + ATT_WAVES < nrt) {
+        const int rowc = min(row + 16 * ATT_WAVES, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
+      }
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        const int ct = CP * pass + c, which = ct >> 1, half = ct & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = E::mfma16(wf[c][ks], xf[ks], acc);
+        const float sc = which == 0 ? p.q_scale : 1.f;
+        const u32x2 v = {E::pack2((acc[0] + bias[c][0]) * sc, (acc[1] + bias[c][1]) * sc),
+                         E::pack2((acc[2] + bias[c][2]) * sc, (acc[3] + bias[c][3]) * sc)};
+        if (row < N) {                                    // rows N.. are the zero padding written by the caller
+          if (which == 0) {
+            *reinterpret_cast<u32x2*>(qo + (size_t)row * 32 + half * 16 + 4 * g) = v;
+          } else if (which == 1) {
+            *reinterpret_cast<u32x2*>(smem + k_slot(row, half * 2 + (g >> 1)) * 16 + (g & 1) * 8) = v;
+          } else {
+            *reinterpret_cast<u32x2*>(Vs + (2 * (row >> 5) + half) * 1024 + (row & 31) * 32 + 8 * g) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// FUSED: the qkv projection in the prologue; DSPLIT: depth-split windows take the half-range q-tile bodies (three bodies instead of
+// one: compile-time variants, so that launches without such windows keep the single body's register allocation)
+template <typename E, bool FUSED = false, bool DSPLIT = false>
 __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_dense_kernel(AttnDenseParams p) {
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -454,8 +539,19 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
   // Small grids (late stages: few windows) split a unit's q-tiles over qsplit workgroups, each staging K/V again.
   const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH, per_pair = nclip * nrep * p.qsplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pair = (slot / per_pair) * 8 + xcd, sub = slot % per_pair;     // pair = (window type, head): one bias
-  const int clip = sub % nclip, rep = (sub / nclip) % nrep, part = sub / (nclip * nrep);
+  int pair, clip, rep, part;
+  if (FUSED) {
+    // fused qkv projection: the heads of one window read the same norm1 rows — they run back to back on ONE XCD (an XCD takes
+    // whole window types: the three-to-six biases of a type and the rows of its windows share that L2), heads fastest
+    const int per_type = p.nH * nclip * nrep, wt_ = (slot / per_type) * 8 + xcd, sub = slot % per_type;
+    if (wt_ >= p.n_types) return;
+    const int h_ = sub % p.nH, rest = sub / p.nH;
+    pair = wt_ * p.nH + h_; clip = rest % nclip; rep = rest / nclip; part = 0;
+  } else {
+    const int sub = slot % per_pair;
+    pair = (slot / per_pair) * 8 + xcd;                                    // pair = (window type, head): one bias
+    clip = sub % nclip; rep = (sub / nclip) % nrep; part = sub / (nclip * nrep);
+  }
   if (pair >= npair) return;
   const int wt = pair / p.nH, h = pair - wt * p.nH, w = rep * p.n_types + wt, bw = clip * p.nW + w;
   const int tid = threadIdx.x, N = p.N;
@@ -477,7 +573,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
   // wave-uniform base), so every lane picks the SOURCE chunk that belongs at its LDS position: K row-major with the
   // XOR swizzle of k_slot(); V row-major too — the PV step reads it through the hardware transpose (ds_read_b64_tr_b16),
   // which wants [32 keys][16 features] subtiles (32-B rows: the four lane groups of a read land on disjoint banks).
-  {
+  if (FUSED) {           // q | k | v computed here (fused_qkv_prologue)
+    fused_qkv_prologue<E, 3>(p, smem, Vs, bw, h, N);
+  } else {
     const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int it = wave_; it < ATT_KROWS * 4 / 64; it += ATT_WAVES) {
       const int c = it * 64 + lane_, row = c >> 2, gs = c & 3, g = gs ^ ((-(row >> 3)) & 3);
@@ -489,6 +587,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
       if (key < N)
         __builtin_amdgcn_global_load_lds((att_gbl_t)(Vg + (size_t)key * 32 + feat), (att_lds_t)(Vs + it * 1024), 16, 0, 0);
     }
+  }
+  {
     // keys N..415 exist only as padding (their bias is the -60000 of the image): finite zeros, never stale LDS
     for (int i = tid; i < (ATT_KROWS - N) * 8; i += ATT_WAVES * 64) {
       const int key = N + (i >> 3), q = i & 7;
@@ -615,11 +715,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
   using TIN = std::integral_constant<int, NTD>;
   // depth-split window: host-checked geometry (N = 392, halves of 196 tokens): q-tiles 0..11 live in the first half, 13..24 in the
   // second, q-tile 12 (tokens 192..207) in both
-  const bool dsplit = p.dsplit_from >= 0 && w >= p.dsplit_from;         // wave-uniform
+  const bool dsplit = DSPLIT && p.dsplit_from >= 0 && w >= p.dsplit_from;         // wave-uniform
   while (qt < q_hi) {
     const int qt_next = take();
     const V8 qf_next = q_frag(qt_next);
-    if (!dsplit || qt == 12) tile_body(TI0{}, TIN{}, qf);
+    if (!DSPLIT || !dsplit || qt == 12) tile_body(TI0{}, TIN{}, qf);
     else if (qt < 12) tile_body(TI0{}, TI13{}, qf);
     else tile_body(TI12{}, TIN{}, qf);
 #ifdef KVQ_ATT_TRACE
@@ -640,9 +740,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
 #endif
 }
 
-template <typename E>
-static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
-  auto kern = window_attention_dense_kernel<E>;
+template <typename E, bool FUSED, bool DSPLIT>
+static int launch_attn_dense_v(const AttnDenseParams& p, hipStream_t st) {
+  auto kern = window_attention_dense_kernel<E, FUSED, DSPLIT>;
   static bool attr_set = false;
   constexpr int lds_req = ATT_D_LDS;
   if (!attr_set) {
@@ -652,9 +752,15 @@ static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
   }
   const int nclip = p.BW / p.nW, npair = p.n_types * p.nH;
   dim3 grid((unsigned)(8 * ceil_div(npair, 8) * nclip * (p.nW / p.n_types) * p.qsplit)), block(ATT_WAVES * 64);
+  if (p.x_ln) grid.x = (unsigned)(8 * ceil_div(p.n_types, 8) * p.nH * nclip * (p.nW / p.n_types));     // XCDs take whole window types
   hipLaunchKernelGGL(kern, grid, block, lds_req, st, p);
   KVQ_CHECK_LAUNCH("window_attention_dense_kernel");
   return KVQ_OK;
+}
+
+template <typename E, bool FUSED = false>
+static int launch_attn_dense(const AttnDenseParams& p, hipStream_t st) {
+  return p.dsplit_from >= 0 ? launch_attn_dense_v<E, FUSED, true>(p, st) : launch_attn_dense_v<E, FUSED, false>(p, st);
 }
 
 }  // namespace kvq
@@ -718,5 +824,16 @@ extern "C" int kvq_window_attention_dense_args(const KvqAttnDenseArgs* a, void* 
   qsplit = qsplit > nqt ? nqt : qsplit;
   AttnDenseParams p{a->qkv, (const u32x2*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, g_trace, g_trace_blocks, a->tile_skip,
                     a->dsplit_from < 0 ? -1 : a->dsplit_from};
+  if (a->x_ln) {
+    const int C = 32 * num_heads;
+    KVQ_REQUIRE(a->w_qkv && a->b_qkv, KVQ_ERR_NULL, "kvq_window_attention_dense: x_ln without w_qkv / b_qkv");
+    KVQ_REQUIRE(C == 96, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_dense: the fused qkv projection is built for C = 96 (got %d)", C);
+    p.qsplit = 1;      // one workgroup per (window, head) whatever the batch: which path a block takes (and with it the last bits of
+                       // a clip's score) must not depend on how many clips share the launch
+    KVQ_REQUIRE((((size_t)a->x_ln | (size_t)a->w_qkv | (size_t)a->b_qkv) & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_dense: x_ln / w_qkv / b_qkv must be 16-byte aligned");
+    p.x_ln = a->x_ln; p.w_qkv = a->w_qkv; p.b_qkv = a->b_qkv; p.C_in = C; p.q_scale = a->q_scale;
+    p.q_out = const_cast<uint16_t*>(a->qkv);
+    return a->dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16, true>(p, (hipStream_t)stream) : launch_attn_dense<Bf16, true>(p, (hipStream_t)stream);
+  }
   return a->dtype == KVQ_DT_FP16 ? launch_attn_dense<Fp16>(p, (hipStream_t)stream) : launch_attn_dense<Bf16>(p, (hipStream_t)stream);
 }

@@ -493,6 +493,12 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       KVQ_REQUIRE(bw.norm1_w && bw.rpb_table && bw.qkv_w && bw.proj_w && bw.fc1_w && bw.fc2_w, KVQ_ERR_NULL,
                   "kvq_swin3d_forward: block %d weights incomplete", blk);
       const int par = (b & 1) && g.shifted_any ? 1 : 0;
+      // Narrow stages (C <= 128; measured at C = 192: the fused launch loses 19 us to GEMM + attention — the rows would be read twice
+      // through the CU's 64 B/clk load path): the qkv GEMM is an HBM-bound launch whose 6 C bytes per row the attention launch reads right
+      // back): the attention workgroup of a (window, head) computes its own q | k | v from the norm1 rows (attn.hip,
+      // fused_qkv_prologue).  Un-padded partitions on the dense bias only.  Measured (bench.py --legs c2,no_sampler, two runs each,
+      // same box): 300.4 -> 314.6 videos/s with the sampler in the step, 315.5 -> 330.1 without; stage-0 launch 133.5 -> 117.3 us.
+      const bool fuse_qkv = bw.bias_dense && bw.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // by geometry only, never by batch
       // norm1 + pad + roll + window_partition
       if (g.Lp != g.L && !ln1_ready && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order, qkv over the tokens only (rows scattered to their window rows by the epilogue);
@@ -503,14 +509,15 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, 0.17677669529663687f, pl->dtype, st));
       } else {
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
-        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
-                     0.17677669529663687f /* 32^-0.5 */));
+        if (!fuse_qkv)
+          KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
+                       0.17677669529663687f /* 32^-0.5 */));
       }
       ln1_ready = false;
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
-        Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C,
-                   2.0 * 4.0 * M * C + (double)kvq_attn_bias_dense_bytes(bias_types(g, par), g.N, g.nH));
+        Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
+                   (fuse_qkv ? 2.0 * 2.0 * M * C + 6.0 * C * C : 2.0 * 4.0 * M * C) + (double)kvq_attn_bias_dense_bytes(bias_types(g, par), g.N, g.nH));
         KvqAttnDenseArgs aa{};
         aa.qkv = bbig; aa.bias_dense = bw.bias_dense; aa.n_types = bias_types(g, par); aa.BW = B * g.nW; aa.nW = g.nW; aa.N = g.N;
         aa.num_heads = g.nH; aa.dtype = pl->dtype; aa.out = bo; aa.tile_skip = (const uint32_t*)g.d_skip[par];
@@ -518,6 +525,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         const int slabs = g.Dp / g.ws[0];
         aa.dsplit_from = (par == 1 && g.N == 392 && g.ws[0] == 8 && g.ws[1] == 7 && g.ws[2] == 7 && g.ss[0] == 4 && slabs >= 1)
                              ? g.nW - g.nW / slabs : -1;
+        if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = 0.17677669529663687f; }
         KVQ_TRY(kvq_window_attention_dense_args(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)

@@ -142,10 +142,14 @@ def attn_bias_dense(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Te
 
 
 def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
-                           tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1):
+                           tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1,
+                           x_ln: Optional[torch.Tensor] = None, w_qkv: Optional[torch.Tensor] = None, b_qkv: Optional[torch.Tensor] = None,
+                           q_scale: float = 1.0):
     """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled) + pre-built bias; returns [BW*N, nH*32].  ``n_types`` (default nW):
     window w uses bias w % n_types.  ``tile_skip`` int32 [nW]: bit t = q-tile t of the window is passed over (padding rows only);
-    the rows of such tiles keep what ``out`` held.  ``dsplit_from`` >= 0: windows >= it are depth-split (shifted (8,7,7) blocks)."""
+    the rows of such tiles keep what ``out`` held.  ``dsplit_from`` >= 0: windows >= it are depth-split (shifted (8,7,7) blocks).
+    ``x_ln`` [BW*N, C] + ``w_qkv`` [3C, C] + ``b_qkv`` [3C]: the launch computes q | k | v itself (``qkv`` = a [1|3, nH, BW*N, 32]
+    buffer whose first third receives q)."""
     _need_gpu(qkv, bias_dense, tile_skip, out)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
@@ -155,6 +159,10 @@ def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int,
     a = _abi.KvqAttnDenseArgs()
     a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH
     a.dtype, a.out, a.tile_skip, a.dsplit_from = dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), dsplit_from
+    if x_ln is not None:      # fused qkv projection: ``qkv`` only lends its q third as scratch ([nH, BW*N, 32] is enough)
+        _need_gpu(x_ln, w_qkv, b_qkv)
+        assert x_ln.dtype == qkv.dtype == w_qkv.dtype and x_ln.is_contiguous() and w_qkv.is_contiguous() and b_qkv.dtype == torch.float32
+        a.x_ln, a.w_qkv, a.b_qkv, a.q_scale = ptr(x_ln), ptr(w_qkv), ptr(b_qkv), q_scale
     check(lib().kvq_window_attention_dense_args(C.byref(a), current_stream()), "kvq_window_attention_dense")
     return out
 

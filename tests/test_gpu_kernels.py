@@ -454,6 +454,43 @@ def test_window_attention_dense_depth_split_is_bit_identical(dims, half):
         kernels.window_attention_dense(qkv[:, :, : BW * 98].contiguous(), dense, nW, 98, dsplit_from=0)     # not the (8,7,7) window
 
 
+@pytest.mark.parametrize("C,dims,shift", [(96, (16, 14, 14), (0, 0, 0)), (96, (16, 14, 14), (4, 3, 3)), (96, (8, 21, 14), (0, 0, 0))])
+def test_window_attention_dense_fused_qkv_projection(C, dims, shift, half):
+    """The attention launch that computes its own q | k | v from the norm1 rows (stages with C <= 192) against the qkv GEMM followed by
+    the plain launch: the same fp32 accumulation over C and the same 16-bit rounding of q | k | v, a different MFMA shape — the
+    outputs agree to the output's own rounding; and against the fp32 oracle within the dense path's budget."""
+    g = rng(C + sum(dims) + sum(shift))
+    window = (8, 7, 7)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, nH = lay["N"], lay["nW"], C // 32
+    B = 2
+    BW = B * nW
+    x = rnd(torch.from_numpy(g.standard_normal((BW * N, C)).astype(np.float32)), half)
+    Wq = rnd(torch.from_numpy((g.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32)), half)
+    bq = torch.from_numpy(0.3 * g.standard_normal(3 * C).astype(np.float32))
+    scale = 32 ** -0.5
+    rpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
+    tok, center = _tok_table(lay, window)
+    use_mask = any(s > 0 for s in lay["ss"])
+    n_types = nW if use_mask else nW // (-(-dims[0] // lay["ws"][0]))
+    dense = kernels.attn_bias_dense(dev(torch.from_numpy(tok))[: n_types * N], dev(rpb), None, center, n_types, N, use_mask)
+    qkv = kernels.gemm(dev(x, half), dev(Wq, half), dev(bq), _abi.EPI_QKV_BF16, num_heads=nH, q_scale=scale)
+    ref = kernels.window_attention_dense(qkv, dense, nW, N, n_types).float().cpu()
+    scratch = torch.full((1, nH, BW * N, 32), float("nan"), dtype=half, device=DEV)
+    out = kernels.window_attention_dense(scratch, dense, nW, N, n_types, x_ln=dev(x, half), w_qkv=dev(Wq, half), b_qkv=dev(bq),
+                                         q_scale=scale).float().cpu()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 3.0 * EPS[half] * max(1.0, ref.abs().max().item())
+    assert (out - ref).abs().mean().item() <= 0.2 * EPS[half]
+    # q went through the scratch exactly as the GEMM writes it (up to the accumulation order)
+    assert (scratch[0].float() - qkv[0].float()).abs().max().item() <= 2.0 * EPS[half] * qkv[0].float().abs().max().item()
+    # any other width is refused, with a message
+    with pytest.raises(RuntimeError, match="C = 96"):
+        kernels.window_attention_dense(torch.empty(1, 6, BW * N, 32, dtype=half, device=DEV), dense, nW, N, n_types,
+                                       x_ln=torch.empty(BW * N, 192, dtype=half, device=DEV), w_qkv=torch.empty(576, 192, dtype=half, device=DEV),
+                                       b_qkv=torch.empty(576, device=DEV), q_scale=scale)
+
+
 def test_window_attention_dense_softmax_extremes(half):
     g = rng(4)
     lay = O.window_layout(8, 14, 14, (8, 7, 7), (4, 3, 3))

@@ -22,6 +22,7 @@ static float h2f(uint16_t u) { _Float16 h; __builtin_memcpy(&h, &u, 2); return (
 int main(int argc, char** argv) {
   const int nW = argc > 1 ? atoi(argv[1]) : 128, nH = argc > 2 ? atoi(argv[2]) : 3, nclip = argc > 3 ? atoi(argv[3]) : 4;
   const int N = argc > 4 ? atoi(argv[4]) : 392, ntyp = argc > 5 ? atoi(argv[5]) : 64, iters = argc > 6 ? atoi(argv[6]) : 20;
+  const int dsplit = argc > 7 ? atoi(argv[7]) : -1;          // >= 0: windows >= it are depth-split (their cross-half bias entries are set to -100 below)
   const int BW = nclip * nW, nqt = (N + 15) / 16, NT = kvq::ATT_NT;
   const size_t Mtot = (size_t)BW * N;
   std::mt19937 rng(7);
@@ -39,6 +40,10 @@ int main(int argc, char** argv) {
             const int key = 16 * t + 4 * (lane >> 4) + r;
             float b = -3.f * fabsf(U(rng));
             if ((rng() & 31) == 0) b = -100.f;             // a masked score now and then
+            if (dsplit >= 0 && (int)(pr / nH) >= dsplit) {  // a depth-split window type: the two halves of 196 tokens never see each other
+              const int q = 16 * qt + (lane & 15);
+              if ((q < 196) != (key < 196)) b = -100.f;
+            }
             if (key >= N) b = kvq::ATT_DENSE_OFF;
             hb[((pr * nqt + qt) * NT + t) * 256 + lane * 4 + r] = f2h(b);
           }
@@ -54,7 +59,12 @@ int main(int argc, char** argv) {
       printf("occupancy API: %d workgroups per CU at %d B of LDS\n", nb, lds);
     }
   }
-  auto run = [&]() { return kvq_window_attention_dense_skip(dq, db, ntyp, BW, nW, N, nH, KVQ_DT_FP16, dout, nullptr, nullptr); };
+  auto run = [&]() {
+    KvqAttnDenseArgs a{};
+    a.qkv = dq; a.bias_dense = db; a.n_types = ntyp; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = nH; a.dtype = KVQ_DT_FP16; a.out = dout;
+    a.dsplit_from = dsplit;
+    return kvq_window_attention_dense_args(&a, nullptr);
+  };
   if (run()) return 1;
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> ho(Mtot * nH * 32);
