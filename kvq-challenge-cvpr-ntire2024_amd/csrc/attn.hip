@@ -356,70 +356,76 @@ struct DenseBuildParams {
   int table_len, center, nW, N, nH, use_mask;
   uint16_t* out;
   unsigned* max_abs;         // optional: bit pattern of max |bias| over the real (un-masked, in-range) entries
-  float* rowmax;             // [n_types][nH][N]: max over the un-masked keys of a query's bias row
+  float* rowmax;             // unused (round 2's two-kernel builder kept the row maxima in global memory; the image's tail still reserves them)
 };
 
-// bias(q, key) of window type w, head h — exactly the gather path's arithmetic; masked = true -> the shift mask hits
-__device__ __forceinline__ float dense_bias_value(const DenseBuildParams& p, int w, int h, int2 tq, int key, bool* masked) {
-  const int2 tk = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + key) * 2);
-  const int idx = tq.x - tk.x + p.center;
-  const float rr = p.rpb[(size_t)idx * p.nH + h];
-  float b = rr;
-  if (p.fpb) {                          // f + g * (r - f), one fma
-    const float f = p.fpb[(size_t)idx * p.nH + h];
+// The builder: one workgroup per (window type, head).  The head's table pairs (f, r - f) — (r, 0) without a fragment table — and
+// the window's token descriptors are staged in LDS once; pass 1 finds every query's row maximum over its un-masked keys, pass 2
+// writes the tiles in the attention kernel's accumulator layout (8 bytes per lane, 512 contiguous bytes per wave and tile).  bias(q,
+// key) is exactly the gather path's arithmetic: idx = code_q - code_k + center, b = fma(gate, r - f, f) with gate = the byte SAD of
+// the fragment ids, the shift mask REPLACES it by -100.  (Round 2's pair of kernels evaluated every entry from global memory: 75 ms
+// for Swin-B's 5.4 GiB at 64 x 256 x 256 — a start-up stall on every new clip geometry; this one is bound by writing the image.)
+__global__ __launch_bounds__(256) void bias_dense_build_kernel(DenseBuildParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  f32x2* tab = reinterpret_cast<f32x2*>(bsm);                                   // [table_len] (f, r - f)
+  int2* tokL = reinterpret_cast<int2*>(bsm + (size_t)p.table_len * 8);           // [N]
+  float* rmax = reinterpret_cast<float*>(bsm + (size_t)p.table_len * 8 + (size_t)p.N * 8);      // [N]
+  const int h = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, N = p.N;
+  for (int i = tid; i < p.table_len; i += 256) {
+    const float r = p.rpb[(size_t)i * p.nH + h];
+    const float f = p.fpb ? p.fpb[(size_t)i * p.nH + h] : r;
+    tab[i] = (f32x2){f, p.fpb ? r - f : 0.f};
+  }
+  for (int i = tid; i < N; i += 256) tokL[i] = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * N + i) * 2);
+  __syncthreads();
+  auto value = [&](int2 tq, int key, bool* masked) -> float {
+    const int2 tk = tokL[key];
+    const f32x2 e = tab[tq.x - tk.x + p.center];
     const float gate = (float)__builtin_amdgcn_sad_u8((unsigned)(tq.y & 0xffff), (unsigned)(tk.y & 0xffff), 0u);
-    b = fmaf(gate, rr - f, f);
-  }
-  *masked = p.use_mask && ((tq.y >> 16) & 0xff) != ((tk.y >> 16) & 0xff);
-  return b;
-}
-
-__global__ __launch_bounds__(64) void bias_rowmax_kernel(DenseBuildParams p) {
-  const int q = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, w = blockIdx.z;
-  if (q >= p.N) return;
-  const int2 tq = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + q) * 2);
-  float mx = -INFINITY;
-  for (int key = 0; key < p.N; ++key) {
-    bool masked;
-    const float b = dense_bias_value(p, w, h, tq, key, &masked);
-    if (!masked) mx = fmaxf(mx, b);
-  }
-  p.rowmax[((size_t)w * p.nH + h) * p.N + q] = mx;      // the query itself is never masked: finite
-}
-
-__global__ __launch_bounds__(64) void bias_dense_kernel(DenseBuildParams p) {
-  const int nqt = (p.N + 15) >> 4;
-  const int qt = blockIdx.x / ATT_NT, t = blockIdx.x % ATT_NT, h = blockIdx.y, w = blockIdx.z;
-  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
-  const int q = 16 * qt + j;
-  float v[4];
+    *masked = p.use_mask && ((tq.y >> 16) & 0xff) != ((tk.y >> 16) & 0xff);
+    return fmaf(gate, e[1], e[0]);
+  };
   float big = 0.f;
-  int2 tq = make_int2(0, 0);
-  if (q < p.N) tq = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * p.N + q) * 2);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int key = 16 * t + 4 * g + r;     // this lane's keys of score tile t: tiles cover keys in natural order
-    float b = 0.f;
-    if (key >= p.N) {
-      b = ATT_DENSE_OFF;
-    } else if (q < p.N) {
+  for (int q = tid; q < N; q += 256) {
+    const int2 tq = tokL[q];
+    float mx = -INFINITY;
+    for (int key = 0; key < N; ++key) {
       bool masked;
-      const float shift = p.rowmax[((size_t)w * p.nH + h) * p.N + q];
-      b = dense_bias_value(p, w, h, tq, key, &masked);
-      if (masked) b = -100.0f;          // REPLACES the bias, as in the gather path
-      else big = fmaxf(big, fabsf(b));
-      b -= shift;
+      const float b = value(tq, key, &masked);
+      if (!masked) { mx = fmaxf(mx, b); big = fmaxf(big, fabsf(b)); }
     }
-    v[r] = b;
+    rmax[q] = mx;                        // the query itself is never masked: finite
   }
   if (p.max_abs) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) big = fmaxf(big, __shfl_xor(big, o));
-    if (lane == 0) atomicMax(p.max_abs, __float_as_uint(big));      // non-negative floats order like their bit patterns
+    if ((tid & 63) == 0) atomicMax(p.max_abs, __float_as_uint(big));      // non-negative floats order like their bit patterns
   }
-  // fp16 whatever the operand type; un-masked entries are <= 0 after the row shift, the largest exactly 0
-  *reinterpret_cast<u32x2*>(p.out + ((((size_t)w * p.nH + h) * nqt + qt) * ATT_NT + t) * 256 + lane * 4) =
-      (u32x2){Fp16::pack2_raw(v[0], v[1]), Fp16::pack2_raw(v[2], v[3])};
+  __syncthreads();
+  const int nqt = (N + 15) >> 4, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  uint16_t* img = p.out + ((size_t)w * p.nH + h) * nqt * ATT_NT * 256;
+  for (int tile = wave; tile < nqt * ATT_NT; tile += 4) {
+    const int qt = tile / ATT_NT, t = tile - qt * ATT_NT, q = 16 * qt + j;
+    const int2 tq = tokL[q < N ? q : N - 1];
+    const float shift = rmax[q < N ? q : N - 1];
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;     // this lane's keys of score tile t: tiles cover keys in natural order
+      float b = 0.f;
+      if (key >= N) {
+        b = ATT_DENSE_OFF;
+      } else if (q < N) {
+        bool masked;
+        b = value(tq, key, &masked);
+        if (masked) b = -100.0f;          // REPLACES the bias, as in the gather path
+        b -= shift;
+      }
+      v[r] = b;
+    }
+    // fp16 whatever the operand type; un-masked entries are <= 0 after the row shift, the largest exactly 0
+    *reinterpret_cast<u32x2*>(img + (size_t)tile * 256 + lane * 4) = (u32x2){Fp16::pack2_raw(v[0], v[1]), Fp16::pack2_raw(v[2], v[3])};
+  }
 }
 
 typedef __attribute__((ext_vector_type(4))) short att_s4;
@@ -781,14 +787,11 @@ extern "C" int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, c
   KVQ_REQUIRE(tok && rpb && out, KVQ_ERR_NULL, "kvq_attn_bias_dense_build: NULL pointer");
   KVQ_REQUIRE(kvq_attn_bias_dense_bytes(nW, N, num_heads) > 0 && table_len > 0, KVQ_ERR_SHAPE,
               "kvq_attn_bias_dense_build: bad shape nW=%d N=%d nH=%d", nW, N, num_heads);
-  DenseBuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (uint16_t*)out, (unsigned*)max_abs,
-                     (float*)((unsigned char*)out + dense_image_bytes(nW, N, num_heads))};
-  hipLaunchKernelGGL(bias_rowmax_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)num_heads, (unsigned)nW), dim3(64), 0,
-                     (hipStream_t)stream, p);
-  KVQ_CHECK_LAUNCH("bias_rowmax_kernel");
-  dim3 grid((unsigned)(((N + 15) / 16) * ATT_NT), (unsigned)num_heads, (unsigned)nW), block(64);
-  hipLaunchKernelGGL(bias_dense_kernel, grid, block, 0, (hipStream_t)stream, p);
-  KVQ_CHECK_LAUNCH("bias_dense_kernel");
+  DenseBuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (uint16_t*)out, (unsigned*)max_abs, nullptr};
+  const size_t lds = (size_t)table_len * 8 + (size_t)N * 12;
+  KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_attn_bias_dense_build: table of %d entries does not fit the builder's LDS", table_len);
+  hipLaunchKernelGGL(bias_dense_build_kernel, dim3((unsigned)num_heads, (unsigned)nW), dim3(256), lds, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("bias_dense_build_kernel");
   return KVQ_OK;
 }
 
