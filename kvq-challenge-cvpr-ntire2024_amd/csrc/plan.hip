@@ -30,6 +30,7 @@ struct StageGeom {
   int32_t* d_skip[2]; // [nW] bit t: rows 16t..16t+15 of the window are padding only (attention passes such q-tiles over), or nullptr
   int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row).  A bijection — the next block's norm1 rows can be EMITTED through it —
                       // only when Lp == L (no padding)
+  int32_t* d_iota;    // [L] identity (padded partitions: the next block's norm1 rows are emitted in TOKEN order), or nullptr
   int32_t* d_tok[2];  // [nW*N][2]
   int32_t* d_merge;   // [L_next][4] or nullptr
   int Dn, Hn, Wn;     // dims after the merge
@@ -145,6 +146,13 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
     rc = upload(pl, dst, &g.d_dst[par]);
     if (rc) return rc;
     g.d_skip[par] = nullptr;
+    if (par == 0) g.d_iota = nullptr;
+    if (!pad.empty() && !g.d_iota) {
+      std::vector<int32_t> iota((size_t)g.L);
+      for (int i = 0; i < g.L; ++i) iota[i] = i;
+      rc = upload(pl, iota, &g.d_iota);
+      if (rc) return rc;
+    }
     if (!pad.empty()) {
       rc = upload(pl, pad, &g.d_pad[par]);
       if (rc) return rc;
@@ -500,10 +508,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       // same box): 300.4 -> 314.6 videos/s with the sampler in the step, 315.5 -> 330.1 without; stage-0 launch 133.5 -> 117.3 us.
       const bool fuse_qkv = bw.bias_dense && bw.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // by geometry only, never by batch
       // norm1 + pad + roll + window_partition
-      if (g.Lp != g.L && !ln1_ready && bw.qkv_b) {
-        // padded partition: norm1 in TOKEN order, qkv over the tokens only (rows scattered to their window rows by the epilogue);
-        // the padding rows' q | k | v = qkv(0) = bias
-        KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+      if (g.Lp != g.L && bw.qkv_b) {
+        // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
+        // (rows scattered to their window rows by the epilogue); the padding rows' q | k | v = qkv(0) = bias
+        if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
         KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, ML, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                      0.17677669529663687f, g.d_dst[par], g.L, g.Lp));
         KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, 0.17677669529663687f, pl->dtype, st));
@@ -545,11 +553,16 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         ta.M = M; ta.C = C; ta.hidden = hidden; ta.pack = bw.tail_pack; ta.eps = 1e-5f; ta.dtype = pl->dtype;
         const int npar = ((b + 1) & 1) && g.shifted_any ? 1 : 0;
         if (g.Lp != g.L) ta.attn_gather = g.d_dst[par];      // padded windows: walk the tokens, not the window rows
-        if (b + 1 < g.depth && g.Lp == g.L && g.d_dst[npar]) {
+        // the next block's norm1 rows in ITS window order (un-padded partitions: token -> window row is a bijection).  Padded
+        // partitions could take them in token order (identity map d_iota; measured on C5: 19 LayerNorm launches / 0.51 ms saved,
+        // but the emitting form of the C = 512 tail costs +25 us per launch (it spills): 12.9 vs 13.0 ms serial, 20.9 vs 21.2-22.0
+        // videos/s with two steps in flight) — not taken.
+        const int32_t* nmap = g.Lp == g.L ? g.d_dst[npar] : nullptr;
+        if (b + 1 < g.depth && nmap) {
           const KvqSwinBlockW& nb = w->blocks[blk + 1];
           KVQ_REQUIRE(nb.norm1_w && nb.norm1_b, KVQ_ERR_NULL, "kvq_swin3d_forward: block %d norm1 missing", blk + 1);
-          ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = g.d_dst[npar]; ta.next_ln = bln;
-          ta.next_rows = g.Lp;
+          ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = nmap; ta.next_ln = bln;
+          ta.next_rows = g.Lp == g.L ? g.Lp : g.L;
           ln1_ready = true;
         }
         Bracket br(pl, st, KVQ_K_TAIL, (C / 32) * 10 + (ln1_ready ? 1 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden,
