@@ -20,7 +20,7 @@ print(f"{'kernel':72} {'n':>4} " + " ".join(f"{c[3:][:12]:>12}" for c in cols) +
 rows = []
 for k, d in acc.items():
     if not k.startswith(("gemm_kernel", "window_attention", "layernorm", "block_tail", "patch_embed", "vqa_head", "conv_stem", "splitk",
-                         "pool_nd", "mean_std", "fragment_gather", "pack_")):
+                         "pool_nd", "mean_std", "fragment_gather", "pack_", "gemm8p", "fast_bottleneck", "select_frames")):
         continue
     avg = {c: (sum(d[c]) / len(d[c]) if d.get(c) else 0.0) for c in cols}
     n = len(d.get(cols[2], []))
