@@ -214,26 +214,41 @@ struct FragParams {
   float* out;
 };
 
+// One thread = VW consecutive output pixels of one row of one (channel, frame) plane (VW = 4 when the patch width is a multiple of
+// 4: the four pixels then sit in one patch, i.e. in one 4-byte run of the source row, and leave as one 16-byte store; the plane is
+// blockIdx.y, so the per-pixel index arithmetic is two small divisions per thread instead of five 64-bit ones per pixel — the
+// one-pixel-per-thread form of rounds 1-2 spent 30 us per clip on 24 MB of traffic).  (v - mean) / std stays the IEEE fp32 divide:
+// bit-equal to the reference's normalisation (fusion_datasets.py:1017-1020).
+template <int VW>
 __global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p) {
-  const int OH = p.Fh * p.fsh, OW = p.Fw * p.fsw;
+  const int OH = p.Fh * p.fsh, OW = p.Fw * p.fsw, QW = OW / VW;
   const int nt = p.T / p.aligned;
-  const long total = (long)p.C * p.T * OH * OW;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long r = i;
-    const int ox = (int)(r % OW); r /= OW;
-    const int oy = (int)(r % OH); r /= OH;
-    const int t = (int)(r % p.T);
-    const int c = (int)(r / p.T);
-    const int fi = oy / p.fsh, fj = ox / p.fsw;
-    const int tb = t / p.aligned;
-    const int o = (fi * p.Fw + fj) * nt + tb;
-    const int sy = p.hoff[o] + (oy - fi * p.fsh), sx = p.woff[o] + (ox - fj * p.fsw);
-    const size_t src = (((size_t)c * p.T + t) * p.H + sy) * p.W + sx;
-    float v = p.src_is_u8 ? (float)reinterpret_cast<const uint8_t*>(p.video)[src]
-                          : reinterpret_cast<const float*>(p.video)[src];
-    if (p.normalise) v = (v - p.mean[c]) / p.std[c];   // IEEE fp32 divide: bit-equal to the reference's (v-mean)/std
-    p.out[i] = v;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= OH * QW) return;
+  const int ct = blockIdx.y, c = ct / p.T, t = ct - c * p.T;           // wave-uniform
+  const int oy = q / QW, ox = (q - oy * QW) * VW;
+  const int fi = oy / p.fsh, fj = ox / p.fsw;
+  const int o = (fi * p.Fw + fj) * nt + t / p.aligned;
+  const int sy = p.hoff[o] + (oy - fi * p.fsh), sx = p.woff[o] + (ox - fj * p.fsw);
+  const size_t src = (((size_t)c * p.T + t) * p.H + sy) * p.W + sx;
+  float v[VW];
+  if (p.src_is_u8) {
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(p.video) + src;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) v[e] = (float)s8[e];
+  } else {
+    const float* s32 = reinterpret_cast<const float*>(p.video) + src;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) v[e] = s32[e];
   }
+  if (p.normalise) {
+    const float m = p.mean[c], sd = p.std[c];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) v[e] = (v[e] - m) / sd;                 // IEEE fp32 divide
+  }
+  float* dst = p.out + ((size_t)ct * OH + oy) * OW + ox;
+  if (VW == 4) *reinterpret_cast<f32x4*>(dst) = (f32x4){v[0], v[1], v[2 % VW], v[3 % VW]};
+  else dst[0] = v[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,9 +394,11 @@ extern "C" int kvq_fragment_gather(const void* video, int src_is_u8, int C, int 
     p.std[c] = host_std ? host_std[c] : 1.f;
   }
   p.out = out;
-  const long total = (long)C * T * Fh * fs_h * Fw * fs_w;
-  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-  hipLaunchKernelGGL(fragment_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  const long plane = (long)Fh * fs_h * Fw * fs_w;
+  KVQ_REQUIRE(plane < (1L << 30) && (long)C * T < 65536, KVQ_ERR_SHAPE, "kvq_fragment_gather: output plane / plane count too large");
+  const bool vec = fs_w % 4 == 0 && ((size_t)out & 15) == 0;
+  if (vec) hipLaunchKernelGGL(fragment_gather_kernel<4>, dim3((unsigned)((plane / 4 + 255) / 256), (unsigned)(C * T)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(fragment_gather_kernel<1>, dim3((unsigned)((plane + 255) / 256), (unsigned)(C * T)), dim3(256), 0, (hipStream_t)stream, p);
   KVQ_CHECK_LAUNCH("fragment_gather_kernel");
   return KVQ_OK;
 }
