@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void mean_std_pool_kernel(const uint16_t* __re
   const float mean = tot / (float)HW;
   __syncthreads();
   float q = 0.f;
-  if (live)
+  if (live && std_off >= 0)
     for (int i = grp; i < HW; i += GR) {
       const float d = E::to_f32(xr[(size_t)i * C + c]) - mean;
       q += d * d;
@@ -259,15 +259,17 @@ __global__ __launch_bounds__(256) void mean_std_pool_vec8_kernel(const uint16_t*
     mean[e] = s[e] / (float)HW;
     q[e] = 0.f;
   }
-  for (int i = tid; i < HW; i += 256) {
-    load8(i, f);
+  if (std_off >= 0) {                                    // mean-only callers (the SlowFast head pools) read the map once
+    for (int i = tid; i < HW; i += 256) {
+      load8(i, f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float d = f[e] - mean[e];
-      q[e] = fmaf(d, d, q[e]);
+      for (int e = 0; e < 8; ++e) {
+        const float d = f[e] - mean[e];
+        q[e] = fmaf(d, d, q[e]);
+      }
     }
+    block_sum8(q);
   }
-  block_sum8(q);
   if (tid < 8) {
     out[(size_t)row * out_stride + mean_off + c0 + tid] = mean[tid];
     if (std_off >= 0) out[(size_t)row * out_stride + std_off + c0 + tid] = sqrtf(q[tid] / (float)(HW - 1));
@@ -603,7 +605,10 @@ extern "C" int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW,
   KVQ_REQUIRE(rows > 0 && HW > 0 && C > 0 && (std_off < 0 || HW > 1), KVQ_ERR_SHAPE, "kvq_mean_std_pool: bad shape");
   const bool narrow = (long)rows * ceil_div(C, 64) < 128 && HW >= 256;
   hipStream_t st = (hipStream_t)stream;
-  if (narrow && HW >= 1024 && C % 8 == 0 && ((size_t)x & 15) == 0) {
+  // 16-byte loads, a block per 8 channels: few rows x thousands of positions (KSVQE), or a few hundred positions when 64-channel
+  // blocks would leave most of the chip idle (SlowFast's slow head pool: 8 rows x 392 positions x 2048 channels: 45.8 -> 8 us)
+  const bool wide = C % 8 == 0 && ((size_t)x & 15) == 0 && ((narrow && HW >= 1024) || (HW >= 256 && (long)rows * ceil_div(C, 64) < 1024));
+  if (wide) {
     dim3 g8(rows, C / 8);
     if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(mean_std_pool_vec8_kernel<Fp16>, g8, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
     else hipLaunchKernelGGL(mean_std_pool_vec8_kernel<Bf16>, g8, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);
