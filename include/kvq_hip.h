@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 22
+#define KVQ_ABI_VERSION 23
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -532,6 +532,13 @@ int kvq_pack_clip_cl4(const float* x, const int32_t dims5[5], int border, int dt
 int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], const uint16_t* wpack, const float* bias8,
                        const int32_t kernel3[3], const int32_t stride3[3], const int32_t pad3[3], int relu, int dtype,
                        uint16_t* out, void* stream);
+/* The whole fast-pathway stem in ONE launch (SlowFast_features.py:137-165 block 0, fast pathway): Conv3d(3, 8, (kd,7,7), stride
+ * (1,2,2), padding (kd/2,3,3)) + folded BatchNorm [+ ReLU] + MaxPool3d((1,3,3), stride (1,2,2), padding (0,1,1)) read straight
+ * from the fp32 clip x (B,3,T,H,W), W % 4 == 0, W <= 256; wpack / bias8 as for kvq_conv_stem_mfma; out 16-bit channels-last
+ * (B, T, Hp, Wp, 8) with Hp = (Ho - 1) / 2 + 1 over the stem's Ho = (H - 1) / 2 + 1.  Same arithmetic as pack + stem + pool
+ * (16-bit operands, fp32 accumulate, 16-bit stem values before the max); neither the packed clip nor the stem map is stored. */
+int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const uint16_t* wpack, const float* bias8, int kd, int relu,
+                       int dtype, uint16_t* out, void* stream);
 /* ---- Whole-network entry for the convolutional branches (csrc/convnet.hip) ------------------------------------------------
  * The reference sequences these networks layer by layer from Python (SlowFast_features.py:137-165: blocks 0-4 of
  * pytorchvideo's slowfast_r50 + the head pools; simpleVQA_model.py:220-264: ResNet-50 + avg / std pooling).  Here the layer
@@ -545,6 +552,8 @@ typedef enum {
   KVQ_NET_STEM_MFMA = 3,  /* <= 4-channel fp32 planar input, kernel kd x kh x 7, W stride 2, pad 3, 8 outputs (SlowFast fast stem) */
   KVQ_NET_MEAN_STD = 4,   /* mean (and unbiased std) over the positions of every row -> fp32 output `dst` of the caller */
   KVQ_NET_SELECT_T = 5,   /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
+  KVQ_NET_STEM_POOL = 7,  /* STEM_MFMA with kernel kd x 7 x 7, stride (1,2,2), followed by the (1,3,3) / (1,2,2) / (0,1,1) max-pool, in one
+                             launch (kvq_conv_stem_pool): dst is the POOLED map */
   KVQ_NET_BOTTLENECK = 6  /* one residual block of SlowFast's fast pathway in ONE launch (kvq_fast_bottleneck): w = the packed image,
                              kpad = inner channels, cout = output channels, n_index = 1 when the block has a projection shortcut,
                              stride3[1] = stride3[2] = its spatial stride */

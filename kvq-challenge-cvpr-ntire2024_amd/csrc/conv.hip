@@ -4,6 +4,8 @@
 // of gemm.hip (BatchNorm folded into weight/bias on the host, ReLU / residual add in the GEMM epilogue);
 // 1x1x1 stride-1 convolutions skip the gather entirely.  Pooling and the SimpleVQA mean/std pooling are
 // plain HBM-bound reductions.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace kvq {
@@ -459,6 +461,221 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
   }
 }
 
+// ---- the fast-pathway stem as ONE launch: Conv3d(3 -> 8, (kd,7,7), stride (1,2,2), pad (kd/2,3,3)) + folded BN + ReLU +
+// MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) straight from the fp32 clip (SlowFast_features.py:137-165, pytorchvideo's
+// create_slowfast stem).  Round 2 ran it as pack (66 us, HBM-bound) + conv_stem_mfma_kernel (224 us: a wave per output row, every
+// input row staged 17 times chip-wide, half of every MFMA tile's rows padding) + pool (20 us) for 3 % of the network's flops.  Here:
+// * a workgroup owns (clip, frame, 4 pooled rows) = 9 stem rows; per temporal tap it stages the 23 input rows those need ONCE
+//   (fp32 planes read with 16-byte loads, converted and interleaved to 4-channel 16-bit pixels in LDS, zero border);
+// * stem rows are computed in PAIRS (ho, ho+1): input row y feeds row ho through kernel row kh and row ho+1 through kh-2, so
+//   the A operand stacks W[kd][kh] (rows 0-7) on W[kd][kh-2] (rows 8-15): all 16 MFMA rows carry output channels and a pair
+//   needs 9 input-row fragments instead of 2 x 7;
+// * a wave owns 16-column tiles and walks the 23 staged rows once per tile: one 16-byte fragment read feeds every pair the row
+//   belongs to (2 for most rows), 23 LDS reads for 43 MFMAs - the kernel is LDS-read bound, so this is what sets its time;
+// * the 9 x Wo x 8 stem tile lands in LDS (bias, ReLU, 16-bit), the 3 x 3 / 2 max-pool reads it and writes 16 bytes per pooled
+//   position: the stem tensor (51 MB per 8 clips) never exists in HBM.
+// 8 clips of 32 x 224 x 224: 125 us against 285 + 20 (profiles/r03_stem_pool.txt).  Phases alone: staging 79 us (a chain of five
+// load latencies per workgroup at 2 x 4 waves per CU), MFMAs + barriers 75 us; HBM reads = the clip once (FETCH_SIZE 153 MB).
+struct StemPoolParams {
+  const float* x;          // (B, 3, T, H, W) fp32
+  const uint16_t* wp;      // [kd*7][16][32] 16-bit (kvq_conv_stem_mfma's image: k = tap * 4 + c, rows >= 8 and tap 7 zero)
+  const float* bias;       // [8]
+  int B, T, H, W, kd, Ho, Wo, Hp, Wp, relu;
+  uint16_t* out;           // (B, T, Hp, Wp, 8)
+};
+constexpr int SP_PR = 4, SP_SR = 2 * SP_PR + 1, SP_NP = (SP_SR + 1) / 2, SP_NR = 2 * (SP_SR - 1) + 7;     // pooled rows, stem rows, row pairs, staged input rows
+
+template <typename E>
+__global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemPoolParams p) {
+  fp16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using v8 = typename E::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, kg = lane >> 4;
+  const int PXP = p.W + 8;                                         // LDS pixel q <-> image column q - 3; 3 zero columns left, 5 right
+  uint16_t* rows = reinterpret_cast<uint16_t*>(smem);              // [SP_NR][PXP][4]
+  uint16_t* stem = rows + (size_t)SP_NR * PXP * 4;                 // [SP_SR][Wo][8]
+  uint16_t* wl = stem + (size_t)SP_SR * p.Wo * 8;                  // [kd*7][8][32]: the weight image's real rows (an L2 round trip per tap otherwise)
+  for (int i = tid; i < p.kd * 7 * 8 * 4; i += 256)
+    *reinterpret_cast<u32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const u32x4*>(p.wp + ((size_t)(i >> 5) * 16 + ((i >> 2) & 7)) * 32 + (i & 3) * 8);
+  // block -> (clip, row block, frame), frames fastest, each XCD (block id % 8) a contiguous eighth of that order: the five blocks
+  // that read a frame's rows (frames t-2 .. t+2 of one row block) run side by side under ONE L2, so the clip crosses the fabric
+  // about once instead of five times (round-robin placement measured 155 us for 8 clips: 1.1 GB of L2 misses).
+  const int nrb = (p.Hp + SP_PR - 1) / SP_PR, total = p.B * nrb * p.T, chunk = (total + 7) >> 3;
+  const int wid = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= chunk || wid >= total) return;
+  const int t = wid % p.T, pr0 = ((wid / p.T) % nrb) * SP_PR, b = wid / (p.T * nrb);
+  const int s0 = 2 * pr0 - 1, y_base = 2 * s0 - 3;                 // first stem row / first staged input row (negative at the top edge)
+  for (int i = tid; i < SP_NR * 2; i += 256) {                     // zero border columns (never overwritten)
+    uint16_t* rp = rows + (size_t)(i >> 1) * PXP * 4;
+    if (i & 1) {
+#pragma unroll
+      for (int e = 0; e < 5; ++e) *reinterpret_cast<u32x2*>(rp + (size_t)(p.W + 3 + e) * 4) = (u32x2){0u, 0u};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) *reinterpret_cast<u32x2*>(rp + e * 4) = (u32x2){0u, 0u};
+    }
+  }
+  const int nct = (p.Wo + 15) >> 4;                                // 16-column tiles (<= 8: two per wave)
+  f32x4 acc[2][SP_NP];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int q = 0; q < SP_NP; ++q) acc[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int pd = p.kd / 2;
+  const size_t plane = (size_t)p.T * p.H * p.W;
+  // staging items of this thread: (staged row, 4 image columns) -> 3 x 16-byte loads, 4 x 8-byte LDS pixels.  The items do not depend
+  // on the temporal tap, and the NEXT tap's loads are in flight while this tap's MFMAs run (one HBM latency per tap otherwise).
+  // Dword loads (one pixel per lane, conflict-free stores by construction) were tried: 4 x the load instructions made it slower.
+  constexpr int ITEMS = (SP_NR * 64 + 255) / 256;                  // W <= 256
+  const int qw = p.W >> 2;
+  int src_off[ITEMS], dst_off[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int i = tid + 256 * j, r = i / qw, q = i - r * qw, y = y_base + r;
+    dst_off[j] = i < SP_NR * qw ? (r * PXP + 4 * q + 3) * 4 : -1;
+    src_off[j] = (i < SP_NR * qw && y >= 0 && y < p.H) ? y * p.W + 4 * q : -1;
+  }
+  f32x4 pf[ITEMS][3];
+  auto issue = [&](int tt) {
+    const float* x0 = p.x + ((size_t)b * 3 * p.T + tt) * p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      pf[j][0] = pf[j][1] = pf[j][2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (src_off[j] >= 0) {
+        const float* src = x0 + src_off[j];
+        pf[j][0] = *reinterpret_cast<const f32x4*>(src);
+        pf[j][1] = *reinterpret_cast<const f32x4*>(src + plane);
+        pf[j][2] = *reinterpret_cast<const f32x4*>(src + 2 * plane);
+      }
+    }
+  };
+  // a lane's four pixels sit 32 bytes from its neighbour's: stored in lane order every 16-lane group of a ds_write_b64 hits 8 of the
+  // 32 banks (4-way: measured as HALF of all LDS cycles of this kernel).  Store pixel e ^ k in pass e, k = (lane / 4) % 4: the four
+  // lanes quads of a group then cover the four bank octets.
+  const int kx = (lane >> 2) & 3;
+  const int a_lo = max(0, pd - t), a_hi = min(p.kd, p.T + pd - t);    // taps inside the clip (block-uniform)
+  issue(t - pd + a_lo);
+  for (int a = a_lo; a < a_hi; ++a) {
+    __syncthreads();                                               // the previous tap's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+      if (dst_off[j] >= 0) {
+        u32x2 px[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) px[e] = (u32x2){E::pack2(pf[j][0][e], pf[j][1][e]), E::pack2(pf[j][2][e], 0.f)};
+#pragma unroll
+        for (int sw = 1; sw <= 2; sw <<= 1) {
+          const bool on = (kx & sw) != 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!(e & sw)) {
+              const u32x2 lo = px[e], hi = px[e | sw];
+              px[e] = on ? hi : lo;
+              px[e | sw] = on ? lo : hi;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2*>(rows + dst_off[j] + (e ^ kx) * 4) = px[e];
+      }
+    if (a + 1 < a_hi) issue(t - pd + a + 1);
+    __syncthreads();
+    // stacked weight fragments of this temporal tap for the input-row offset kk = 0..8 inside a pair: rows 0-7 = W[a][kk], rows 8-15 = W[a][kk-2]
+    v8 wa[9];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+      const int kh = kk - 2 * (n >> 3);
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (kh >= 0 && kh < 7) raw = *reinterpret_cast<const u32x4*>(wl + ((a * 7 + kh) * 8 + (n & 7)) * 32 + kg * 8);
+      wa[kk] = __builtin_bit_cast(v8, raw);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ct = wave + 4 * u;
+      if (ct < nct) {
+        const uint16_t* base = rows + (size_t)(2 * (16 * ct + n + kg)) * 4;       // pixel 2 (wo + kg): taps 2 kg, 2 kg + 1 of column wo
+        // row fragments in groups of RG, the next group's reads issued before this group's MFMAs (left to itself the compiler keeps
+        // ONE ds_read in flight ahead of two MFMAs: 23 LDS latencies per tile and tap, which was 3/4 of the kernel's time)
+        constexpr int RG = 6, NG = (SP_NR + RG - 1) / RG;
+        v8 bf[2][RG];
+        auto rd = [&](int g, v8* dst) {
+#pragma unroll
+          for (int e = 0; e < RG; ++e)
+            if (g * RG + e < SP_NR) dst[e] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(base + (size_t)(g * RG + e) * PXP * 4));
+        };
+        rd(0, bf[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) rd(g + 1, bf[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < RG; ++e) {
+            const int r = g * RG + e;
+#pragma unroll
+            for (int q = 0; q < SP_NP; ++q) {
+              const int kk = r - 4 * q;                                           // staged row r = 4 q + kk of pair q
+              if (r < SP_NR && kk >= 0 && kk < 9) acc[u][q] = E::mfma16(wa[kk], bf[g & 1][e], acc[u][q]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // stem tile: lane (column n, group kg) holds channels 4 (kg & 1) .. +3 of stem row s0 + 2 pair + (kg >> 1)
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (kg & 1) * 4);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int wo = 16 * (wave + 4 * u) + n;
+    if (wo < p.Wo) {
+#pragma unroll
+      for (int q = 0; q < SP_NP; ++q) {
+        const int sr = 2 * q + (kg >> 1);
+        if (sr < SP_SR) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[u][q][e] + bv[e];
+            if (p.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<u32x2*>(stem + ((size_t)sr * p.Wo + wo) * 8 + (kg & 1) * 4) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // max-pool 3 x 3 / 2, pad 1 (positions outside the stem map do not take part); 8 channels = 16 bytes per thread
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+  for (int i = tid; i < SP_PR * p.Wp; i += 256) {
+    const int prl = i / p.Wp, pc = i - prl * p.Wp, pr = pr0 + prl;
+    if (pr >= p.Hp) continue;
+    bool any = false;
+    u32x4 best = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int sy = 2 * pr - 1 + dy;
+      if (sy < 0 || sy >= p.Ho) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int c = 2 * pc - 1 + dx;
+        if (c < 0 || c >= p.Wo) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stem + ((size_t)(sy - s0) * p.Wo + c) * 8);
+        if (!any) {
+          best = v;
+          any = true;
+        } else if constexpr (std::is_same<E, Fp16>::value) {
+          best = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(h8, best), __builtin_bit_cast(h8, v)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            best[e] = pack_bf2(fmaxf(bf2f((uint16_t)(best[e] & 0xffffu)), bf2f((uint16_t)(v[e] & 0xffffu))),
+                               fmaxf(bf2f((uint16_t)(best[e] >> 16)), bf2f((uint16_t)(v[e] >> 16))));
+        }
+      }
+    }
+    *reinterpret_cast<u32x4*>(p.out + ((((size_t)b * p.T + t) * p.Hp + pr) * p.Wp + pc) * 8) = best;
+  }
+}
+
 }  // namespace kvq
 
 extern "C" int kvq_pack_clip_cl4(const float* x, const int32_t dims5[5], int border, int dtype, uint16_t* out, void* stream) {
@@ -499,6 +716,34 @@ extern "C" int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], co
   if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(conv_stem_mfma_kernel<Fp16>, grid, block, lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(conv_stem_mfma_kernel<Bf16>, grid, block, lds, (hipStream_t)stream, p);
   KVQ_CHECK_LAUNCH("conv_stem_mfma_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const uint16_t* wpack, const float* bias8, int kd, int relu,
+                                  int dtype, uint16_t* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && dims5 && wpack && bias8 && out, KVQ_ERR_NULL, "kvq_conv_stem_pool: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_pool: dtype %d", dtype);
+  StemPoolParams p{};
+  p.x = x; p.wp = wpack; p.bias = bias8; p.B = dims5[0]; p.T = dims5[2]; p.H = dims5[3]; p.W = dims5[4]; p.kd = kd; p.relu = relu; p.out = out;
+  KVQ_REQUIRE(dims5[1] == 3 && p.B > 0 && p.T > 0 && p.H >= 7 && p.W >= 8 && kd >= 1 && kd <= 7 && (kd & 1), KVQ_ERR_SHAPE,
+              "kvq_conv_stem_pool: needs a 3-channel clip and an odd temporal kernel (got C=%d kd=%d)", dims5[1], kd);
+  KVQ_REQUIRE(p.W % 4 == 0 && (((size_t)x) & 15) == 0 && (((size_t)out) & 15) == 0, KVQ_ERR_SHAPE,
+              "kvq_conv_stem_pool: W %% 4 == 0 and 16-byte aligned clip / output (got W=%d)", p.W);
+  p.Ho = (p.H + 6 - 7) / 2 + 1; p.Wo = (p.W + 6 - 7) / 2 + 1;
+  p.Hp = (p.Ho + 2 - 3) / 2 + 1; p.Wp = (p.Wo + 2 - 3) / 2 + 1;
+  KVQ_REQUIRE(p.Wo <= 128 && (long)p.B * p.T * p.Hp < (1L << 30) && (long)p.T * p.H * p.W < (1L << 27), KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_pool: stem rows of at most 128 columns (W <= 256; got %d)", p.W);
+  const size_t lds = (size_t)SP_NR * (p.W + 8) * 8 + (size_t)SP_SR * p.Wo * 16 + (size_t)kd * 7 * 512;
+  KVQ_REQUIRE(lds <= 96 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_pool: %zu B of LDS", lds);
+  auto launch = [&](auto kern) -> int {
+    static bool set = false;
+    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ceil_div(ceil_div(p.Hp, SP_PR) * p.T * p.B, 8))), dim3(256), lds, (hipStream_t)stream, p);
+    return KVQ_OK;
+  };
+  const int rc = dtype == KVQ_DT_FP16 ? launch(conv_stem_pool_kernel<Fp16>) : launch(conv_stem_pool_kernel<Bf16>);
+  if (rc) return rc;
+  KVQ_CHECK_LAUNCH("conv_stem_pool_kernel");
   return KVQ_OK;
 }
 

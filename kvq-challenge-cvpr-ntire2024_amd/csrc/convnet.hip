@@ -241,6 +241,15 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
         net->tensors.push_back(ts);
         break;
       }
+      case KVQ_NET_STEM_POOL: {
+        NET_REQUIRE(s.kind == KVQ_NET_T_F32_PLANAR && d.kind == KVQ_NET_T_ACT16 && s.C == 3 && p.w && p.bias, "kvq_convnet_create: op %d (stem + pool) operand kinds", i);
+        NET_REQUIRE(p.cout == 8 && p.kernel3[1] == 7 && p.kernel3[2] == 7 && p.stride3[0] == 1 && p.stride3[1] == 2 && p.stride3[2] == 2 &&
+                        p.pad3[0] == p.kernel3[0] / 2 && p.pad3[1] == 3 && p.pad3[2] == 3 && (p.kernel3[0] & 1),
+                    "kvq_convnet_create: op %d (stem + pool) geometry", i);
+        o.Do = s.D; o.Ho = ((s.H - 1) / 2 + 1 - 1) / 2 + 1; o.Wo = ((s.W - 1) / 2 + 1 - 1) / 2 + 1;
+        NET_REQUIRE(d.B == s.B && d.D == o.Do && d.H == o.Ho && d.W == o.Wo && d.C == 8, "kvq_convnet_create: op %d (stem + pool) output shape", i);
+        break;
+      }
       case KVQ_NET_MEAN_STD:
         NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && p.out_stride > 0 && p.mean_off >= 0, "kvq_convnet_create: op %d (mean/std pool)", i);
         break;
@@ -473,6 +482,12 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
         KVQ_TRY(kvq_pack_clip_cl4((const float*)ptr_of(p.src), dims5, 4, net->dtype, x4, st));
         const int32_t dims4[4] = {s.B, s.D, s.H, s.W};
         KVQ_TRY(kvq_conv_stem_mfma(x4, dims4, (const uint16_t*)p.w, p.bias, p.kernel3, p.stride3, p.pad3, p.relu, net->dtype,
+                                   (uint16_t*)ptr_of(p.dst), st));
+        break;
+      }
+      case KVQ_NET_STEM_POOL: {
+        const int32_t dims5[5] = {s.B, s.C, s.D, s.H, s.W};
+        KVQ_TRY(kvq_conv_stem_pool((const float*)ptr_of(p.src), dims5, (const uint16_t*)p.w, p.bias, p.kernel3[0], p.relu, net->dtype,
                                    (uint16_t*)ptr_of(p.dst), st));
         break;
       }

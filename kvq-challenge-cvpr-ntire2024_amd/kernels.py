@@ -667,6 +667,19 @@ def conv_stem_mfma(x: torch.Tensor, wpack: torch.Tensor, bias8: torch.Tensor, ke
     return out
 
 
+def conv_stem_pool(x: torch.Tensor, wpack: torch.Tensor, bias8: torch.Tensor, kd: int, relu: bool = True):
+    """SlowFast's fast-pathway stem in one launch (``kvq_conv_stem_pool``): Conv3d(3 -> 8, (kd,7,7), stride (1,2,2), padding
+    (kd//2,3,3)) + bias [+ ReLU] + MaxPool3d((1,3,3), (1,2,2), (0,1,1)); x fp32 (B,3,T,H,W) -> 16-bit channels-last (B,T,Hp,Wp,8)."""
+    _need_gpu(x, wpack, bias8)
+    assert x.dtype == torch.float32 and x.is_contiguous() and wpack.dtype in HALF_TYPES and bias8.numel() == 8
+    B, Cin, T, H, W = x.shape
+    hp, wp_ = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
+    out = torch.empty(B, T, hp, wp_, 8, dtype=wpack.dtype, device=x.device)
+    check(lib().kvq_conv_stem_pool(ptr(x), C.byref((C.c_int32 * 5)(B, Cin, T, H, W)), ptr(wpack), ptr(bias8), int(kd), int(relu),
+                                   dtype_code(wpack.dtype), ptr(out), current_stream()), "kvq_conv_stem_pool")
+    return out
+
+
 def conv_stem_direct(x: torch.Tensor, w_kc: torch.Tensor, bias: torch.Tensor, kernel, stride, pad, relu: bool, out_dtype):
     """Direct Conv3d for few output channels: x fp32 (B,C,D,H,W), w_kc fp32 [K][Cout] (K ordered kd,kh,kw,c), -> 16-bit
     channels-last (B,Do,Ho,Wo,Cout)."""

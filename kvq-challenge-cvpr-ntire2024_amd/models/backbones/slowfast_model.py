@@ -141,6 +141,7 @@ CONVNET = True                  # 0: the layer-by-layer Python sequencing below
 FUSE_FAST = True            # 0: the fast pathway's residual blocks as 3-4 conv launches each
 TWO_LANES = True                # 0: both pathways on the caller's stream, one op after the other
 STEM_MFMA = True             # 0: fast-pathway stem on the fp32 direct kernel
+STEM_POOL = True             # 0: the one-call plan runs the fast stem as pack + conv + max-pool launches instead of kvq_conv_stem_pool
 
 
 def _fragments(w, k_real, row_tiles, accumulator_order=False):
@@ -384,10 +385,14 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         op(_abi.NET_POOL, s_stem, slow, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1, dst_coff=0)
         _, fbias, fk, fst, fpd = Wt[fe + "0.multipathway_blocks.1"]
         lane[0] = FAST_LANE
-        f_stem = tensor(B, T, Hs, Ws, 8)
-        op(_abi.NET_STEM_MFMA, fast_in, f_stem, fk, fst, fpd, cout=8, relu=1, w=Wt[fe + "0.multipathway_blocks.1/mfma"], bias=fbias)
         fast = tensor(B, T, Hp, Wp, 8)
-        op(_abi.NET_POOL, f_stem, fast, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1)
+        if STEM_POOL and tuple(fk[1:]) == (7, 7) and tuple(fst) == (1, 2, 2) and tuple(fpd) == (fk[0] // 2, 3, 3) and W <= 256:
+            # stem + max-pool in one launch straight from the fp32 clip: neither the packed clip nor the stem map touches HBM
+            op(_abi.NET_STEM_POOL, fast_in, fast, fk, fst, fpd, cout=8, relu=1, w=Wt[fe + "0.multipathway_blocks.1/mfma"], bias=fbias)
+        else:
+            f_stem = tensor(B, T, Hs, Ws, 8)
+            op(_abi.NET_STEM_MFMA, fast_in, f_stem, fk, fst, fpd, cout=8, relu=1, w=Wt[fe + "0.multipathway_blocks.1/mfma"], bias=fbias)
+            op(_abi.NET_POOL, f_stem, fast, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1)
         conv(fast, fe + "0.multipathway_fusion", dst=slow, coff=64)
         lane[0] = 0
         slow_out = (SLOW["out"], FAST["out"])
@@ -469,7 +474,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             _abi.check(_abi.lib().kvq_convnet_profile_read(handle, ms, len(descs), C.byref(n)), "kvq_convnet_profile_read")
         finally:
             _abi.check(_abi.lib().kvq_convnet_profile(handle, 0), "kvq_convnet_profile")
-        kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma",
+        kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma", _abi.NET_STEM_POOL: "stem_pool",
                  _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t", _abi.NET_BOTTLENECK: "bottleneck"}
         out = []
         for d, t in zip(descs, ms):

@@ -367,6 +367,40 @@ def test_conv_stem_mfma_vs_torch_conv3d(shape, kernel, stride, pad, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,kd", [
+    ((2, 3, 6, 30, 48), 5),        # Wo = 24: ragged second tile; Hp = 8: two row blocks, zero rows above and below
+    ((1, 3, 3, 50, 252), 5),       # Wo = 126: eight column tiles (two per wave); Hp = 13: ragged last row block; T < kd
+    ((1, 3, 2, 224, 224), 5),      # the clip geometry
+    ((1, 3, 4, 21, 20), 1),        # odd H, one temporal tap
+])
+def test_conv_stem_pool_vs_torch(shape, kd, dtype):
+    """kvq_conv_stem_pool (conv + bias + ReLU + 3x3/2 max-pool in one launch, straight from the fp32 clip) against F.conv3d of the
+    ROUNDED operands -> ReLU -> max_pool3d, and BIT-equal to the three-launch path it replaces (pack + kvq_conv_stem_mfma + pool:
+    same MFMA k-order per output, same 16-bit rounding before the max)."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(sum(shape) + kd))
+    kernel, stride, pad = (kd, 7, 7), (1, 2, 2), (kd // 2, 3, 3)
+    x = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+    K = kd * 49 * 3
+    w5 = torch.from_numpy((g.standard_normal((8, 3) + kernel) / np.sqrt(K)).astype(np.float32))
+    bias = torch.from_numpy(g.standard_normal(8).astype(np.float32))
+    w_kc = w5.permute(2, 3, 4, 1, 0).reshape(K, 8).contiguous()
+    wp = kernels.stem_mfma_pack_weight(w_kc.cuda(), kernel, 3, dtype)
+    out = kernels.conv_stem_pool(x.cuda(), wp, bias.cuda(), kd, True)
+    xr, wr = x.to(dtype).double(), w5.to(dtype).double()
+    ref = torch.relu(torch.nn.functional.conv3d(xr, wr, bias.double(), stride, pad))
+    ref = torch.nn.functional.max_pool3d(ref, (1, 3, 3), (1, 2, 2), (0, 1, 1)).permute(0, 2, 3, 4, 1).float()
+    assert tuple(out.shape) == tuple(ref.shape)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert (out.float().cpu() - ref).abs().max().item() <= ulp * max(1.0, ref.abs().max().item())
+    stem = kernels.conv_stem_mfma(x.cuda(), wp, bias.cuda(), kernel, stride, pad, True)
+    three = torch.nn.functional.max_pool3d(stem.float().permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1)).permute(0, 2, 3, 4, 1)
+    close = (out.float() - three).abs().max().item()
+    assert close <= ulp * max(1.0, ref.abs().max().item()), close
+
+
+@pytest.mark.gpu
 def test_head_pool_follows_the_reference_for_every_grid():
     """pytorchvideo's head is AvgPool3d((8,7,7)) / ((32,7,7)), stride 1, then AdaptiveAvgPool3d(1) (SlowFast_features.py:150-152).
     Equal grid (32 x 224 x 224): one global mean.  Larger grid (here 32 x 256 x 224 -> 8 x 8 x 7 / 32 x 8 x 7): the real pool runs —

@@ -14,5 +14,9 @@ def t(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) * 100
+if "pool" in sys.argv[1:]:
+    for _ in range(3): kernels.conv_stem_pool(x, wp, b, 5, True)
+    torch.cuda.synchronize(); sys.exit(0)
 print(f"direct fp32: {t(lambda: kernels.conv_stem_direct(x, w, b, k, s, p, True, torch.float16)):.3f} ms   "
       f"mfma (pack + conv): {t(lambda: kernels.conv_stem_mfma(x, wp, b, k, s, p, True)):.3f} ms")
+print(f"stem + pool in one launch: {t(lambda: kernels.conv_stem_pool(x, wp, b, 5, True)):.3f} ms")
