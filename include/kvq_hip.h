@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 23
+#define KVQ_ABI_VERSION 24
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -539,6 +539,13 @@ int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], const uint16_
  * (16-bit operands, fp32 accumulate, 16-bit stem values before the max); neither the packed clip nor the stem map is stored. */
 int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const uint16_t* wpack, const float* bias8, int kd, int relu,
                        int dtype, uint16_t* out, void* stream);
+/* The slow-pathway stem in ONE launch (SlowFast_features.py:112-165: pack_pathway_output's frame selection, then block 0 of the slow
+ * pathway): frames t_index[0 .. n_frames) (device int32; NULL = frames 0 .. n_frames-1) of the fp32 clip x (B,3,T,H,W) ->
+ * Conv3d(3, 64, (1,7,7), stride (1,2,2), padding (0,3,3)) + folded BatchNorm [+ ReLU] + MaxPool3d((1,3,3), (1,2,2), (0,1,1)).
+ * wimg 16-bit [7][64][32], entry [kh][o][kw*4 + c] = w[o][c][0][kh][kw] (kw 7 and c 3 zero); bias64 fp32 [64]; W % 4 == 0, W <= 224.
+ * out 16-bit channels-last (B, n_frames, Hp, Wp, out_C): channels out_coff .. out_coff + 63 are written (out_C, out_coff % 8 == 0). */
+int kvq_conv_stem64_pool(const float* x, const int32_t dims5[5], const int32_t* t_index, int n_frames, const uint16_t* wimg,
+                         const float* bias64, int relu, int dtype, uint16_t* out, int out_C, int out_coff, void* stream);
 /* ---- Whole-network entry for the convolutional branches (csrc/convnet.hip) ------------------------------------------------
  * The reference sequences these networks layer by layer from Python (SlowFast_features.py:137-165: blocks 0-4 of
  * pytorchvideo's slowfast_r50 + the head pools; simpleVQA_model.py:220-264: ResNet-50 + avg / std pooling).  Here the layer
@@ -554,6 +561,8 @@ typedef enum {
   KVQ_NET_SELECT_T = 5,   /* frames t_index[k] of an fp32 planar clip (pathway packing, SlowFast_features.py:112-135) */
   KVQ_NET_STEM_POOL = 7,  /* STEM_MFMA with kernel kd x 7 x 7, stride (1,2,2), followed by the (1,3,3) / (1,2,2) / (0,1,1) max-pool, in one
                              launch (kvq_conv_stem_pool): dst is the POOLED map */
+  KVQ_NET_STEM64_POOL = 8, /* frame selection (t_index / n_index) + 3 -> 64 stem (1 x 7 x 7, stride (1,2,2)) + the (1,3,3) max-pool in one launch
+                             (kvq_conv_stem64_pool): src the fp32 clip, dst the POOLED map (channels dst_coff .. dst_coff + 63), w its weight image */
   KVQ_NET_BOTTLENECK = 6  /* one residual block of SlowFast's fast pathway in ONE launch (kvq_fast_bottleneck): w = the packed image,
                              kpad = inner channels, cout = output channels, n_index = 1 when the block has a projection shortcut,
                              stride3[1] = stride3[2] = its spatial stride */

@@ -461,6 +461,21 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
   }
 }
 
+// elementwise max of eight 16-bit values (one 16-byte channel chunk)
+template <typename E>
+__device__ __forceinline__ u32x4 max8(u32x4 a, u32x4 b) {
+  if constexpr (std::is_same<E, Fp16>::value) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b)));
+  } else {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      r[e] = pack_bf2(fmaxf(bf2f((uint16_t)(a[e] & 0xffffu)), bf2f((uint16_t)(b[e] & 0xffffu))), fmaxf(bf2f((uint16_t)(a[e] >> 16)), bf2f((uint16_t)(b[e] >> 16))));
+    return r;
+  }
+}
+
 // ---- the fast-pathway stem as ONE launch: Conv3d(3 -> 8, (kd,7,7), stride (1,2,2), pad (kd/2,3,3)) + folded BN + ReLU +
 // MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) straight from the fp32 clip (SlowFast_features.py:137-165, pytorchvideo's
 // create_slowfast stem).  Round 2 ran it as pack (66 us, HBM-bound) + conv_stem_mfma_kernel (224 us: a wave per output row, every
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaParams p) {
 //   belongs to (2 for most rows), 23 LDS reads for 43 MFMAs - the kernel is LDS-read bound, so this is what sets its time;
 // * the 9 x Wo x 8 stem tile lands in LDS (bias, ReLU, 16-bit), the 3 x 3 / 2 max-pool reads it and writes 16 bytes per pooled
 //   position: the stem tensor (51 MB per 8 clips) never exists in HBM.
-// 8 clips of 32 x 224 x 224: 125 us against 285 + 20 (profiles/r03_stem_pool.txt).  Phases alone: staging 79 us (a chain of five
+// 8 clips of 32 x 224 x 224: 125 us against 285 + 20 (profiles/r03_stem_pool_pmc.txt).  Phases alone: staging 79 us (a chain of five
 // load latencies per workgroup at 2 x 4 waves per CU), MFMAs + barriers 75 us; HBM reads = the clip once (FETCH_SIZE 153 MB).
 struct StemPoolParams {
   const float* x;          // (B, 3, T, H, W) fp32
@@ -644,7 +659,6 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemPoolParams p
   }
   __syncthreads();
   // max-pool 3 x 3 / 2, pad 1 (positions outside the stem map do not take part); 8 channels = 16 bytes per thread
-  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
   for (int i = tid; i < SP_PR * p.Wp; i += 256) {
     const int prl = i / p.Wp, pc = i - prl * p.Wp, pr = pr0 + prl;
     if (pr >= p.Hp) continue;
@@ -659,20 +673,213 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemPoolParams p
         const int c = 2 * pc - 1 + dx;
         if (c < 0 || c >= p.Wo) continue;
         const u32x4 v = *reinterpret_cast<const u32x4*>(stem + ((size_t)(sy - s0) * p.Wo + c) * 8);
-        if (!any) {
-          best = v;
-          any = true;
-        } else if constexpr (std::is_same<E, Fp16>::value) {
-          best = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(h8, best), __builtin_bit_cast(h8, v)));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            best[e] = pack_bf2(fmaxf(bf2f((uint16_t)(best[e] & 0xffffu)), bf2f((uint16_t)(v[e] & 0xffffu))),
-                               fmaxf(bf2f((uint16_t)(best[e] >> 16)), bf2f((uint16_t)(v[e] >> 16))));
-        }
+        best = any ? max8<E>(best, v) : v;
+        any = true;
       }
     }
     *reinterpret_cast<u32x4*>(p.out + ((((size_t)b * p.T + t) * p.Hp + pr) * p.Wp + pc) * 8) = best;
+  }
+}
+
+// ---- the slow-pathway stem as ONE launch: frame selection + Conv3d(3 -> 64, (1,7,7), stride (1,2,2), pad (0,3,3)) + folded BN + ReLU
+// + MaxPool3d((1,3,3), (1,2,2), (0,1,1)) from the fp32 clip (SlowFast_features.py:112-165: pack_pathway_output's index_select, then
+// block 0 of the slow pathway).  It ran as select_t (17 us) + pack + implicit GEMM (110 us, 103 MB stem map written) + pool (37 us, the
+// map read back) per 8 clips for 9 us of MFMA work.  A workgroup of 14 waves owns (clip, selected frame, 2 pooled rows) = 5 stem rows:
+// 15 input rows staged once as 4-channel 16-bit pixels (as conv_stem_pool_kernel), wave = (16-column tile, 32-channel half); each row
+// fragment feeds the 3-4 stem rows it belongs to.  Pool: vertical max in registers (max commutes with the bias add, ReLU and the
+// 16-bit rounding, all monotonic), the 2 x Wo x 64 result through LDS (8-byte slots XOR-swizzled by column), horizontal max and a
+// 16-byte store into the caller's channel slice.  8 clips (1792 items): 50 us against 164; by removal: MFMA + vertical max 28 us (40 % MFMA
+// utilisation - 14 waves in lockstep between two barriers per item), row loads 7, pool stores 7 (128 of every 160-byte pixel), staging 3.5.
+struct Stem64Params {
+  const float* x;          // (B, 3, T, H, W) fp32
+  const int32_t* t_index;  // device, F selected frames (NULL: frames 0 .. F-1)
+  const uint16_t* wimg;    // [7][64][32] 16-bit: [kh][o][kw * 4 + c], kw 7 and c 3 zero
+  const float* bias;       // [64]
+  int B, T, H, W, F, Ho, Wo, Hp, Wp, relu, out_C, out_coff;
+  uint16_t* out;           // (B, F, Hp, Wp, out_C), channels out_coff .. out_coff + 63
+};
+constexpr int S6_PR = 2, S6_SR = 2 * S6_PR + 1, S6_NR = 2 * (S6_SR - 1) + 7, S6_THREADS = 896;
+constexpr int S6_ITEMS = (S6_NR * 56 + S6_THREADS - 1) / S6_THREADS;             // (row, 4 columns) staging items per thread at W <= 224
+
+template <typename E>
+__global__ __launch_bounds__(S6_THREADS) void conv_stem64_pool_kernel(Stem64Params p) {
+  fp16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using v8 = typename E::v8;
+  typedef __attribute__((address_space(3))) void* s6_lds_t;
+  typedef const __attribute__((address_space(1))) void* s6_gbl_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, kg = lane >> 4;
+  const int PXP = p.W + 8;
+  uint16_t* rows = reinterpret_cast<uint16_t*>(smem);              // [S6_NR][PXP][4]
+  uint16_t* vm = rows + (size_t)S6_NR * PXP * 4;                   // [S6_PR][Wo][64], 8-byte slot s of column c at slot s ^ ((c & 7) << 1)
+  float* raw = reinterpret_cast<float*>(vm + (size_t)S6_PR * p.Wo * 64);       // [3][S6_ITEMS][S6_THREADS][4] fp32: rows in flight
+  uint16_t* wl = reinterpret_cast<uint16_t*>(raw + (size_t)3 * S6_ITEMS * S6_THREADS * 4);         // [7][64][32] weight image
+  // persistent workgroups: one per CU walks its (clip, frame, row block) items, rows two items ahead in flight - a workgroup of 14
+  // waves fills a CU alone, so one item per workgroup exposed an HBM latency, the weight fetch and a dispatch per item.  The rows
+  // travel global -> LDS without passing through registers (global_load_lds, 16 bytes per lane), and the weight image sits in LDS
+  // with a wave reading 7 fragments per channel tile: anything held in registers across the item loop spilled (128 per wave here).
+  const int nrb = (p.Hp + S6_PR - 1) / S6_PR, total = p.B * p.F * nrb, step = gridDim.x;
+  const size_t plane = (size_t)p.T * p.H * p.W;
+  const int qw = p.W >> 2;
+  int dst_off[S6_ITEMS], src_row[S6_ITEMS], src_col[S6_ITEMS];
+#pragma unroll
+  for (int j = 0; j < S6_ITEMS; ++j) {
+    const int i = tid + S6_THREADS * j, r = i / qw, q = i - r * qw;
+    dst_off[j] = i < S6_NR * qw ? (r * PXP + 4 * q + 3) * 4 : -1;
+    src_row[j] = r;
+    src_col[j] = 4 * q;
+  }
+  auto issue = [&](int it) {                                       // fp32 rows of item `it`: global -> raw
+    const int rb = it % nrb, f = (it / nrb) % p.F, b = it / (nrb * p.F);
+    const int tt = p.t_index ? p.t_index[f] : f;
+    const float* x0 = p.x + ((size_t)b * 3 * p.T + tt) * p.H * p.W;
+    const int yb = 2 * (2 * rb * S6_PR - 1) - 3;
+#pragma unroll
+    for (int j = 0; j < S6_ITEMS; ++j) {
+      const int y = yb + src_row[j];
+      if (dst_off[j] >= 0 && y >= 0 && y < p.H) {
+        const float* src = x0 + (size_t)y * p.W + src_col[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          __builtin_amdgcn_global_load_lds((s6_gbl_t)(src + c * plane), (s6_lds_t)(raw + ((size_t)(c * S6_ITEMS + j) * S6_THREADS + wave * 64) * 4), 16, 0, 0);
+      }
+    }
+  };
+  const int kx = (lane >> 2) & 3;                                  // store pixel e ^ kx in pass e: conflict-free ds_write_b64 (see conv_stem_pool_kernel)
+  auto commit = [&](int it) {                                      // raw -> 4-channel 16-bit pixels in `rows` (zero rows outside the image)
+    const int yb = 2 * (2 * (it % nrb) * S6_PR - 1) - 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // a wave reads back the raw slots its own lanes loaded: no barrier
+#pragma unroll
+    for (int j = 0; j < S6_ITEMS; ++j)
+      if (dst_off[j] >= 0) {
+        const int y = yb + src_row[j];
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+        if (y >= 0 && y < p.H) {
+          c0 = *reinterpret_cast<const f32x4*>(raw + ((size_t)(0 * S6_ITEMS + j) * S6_THREADS + tid) * 4);
+          c1 = *reinterpret_cast<const f32x4*>(raw + ((size_t)(1 * S6_ITEMS + j) * S6_THREADS + tid) * 4);
+          c2 = *reinterpret_cast<const f32x4*>(raw + ((size_t)(2 * S6_ITEMS + j) * S6_THREADS + tid) * 4);
+        }
+        u32x2 px[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) px[e] = (u32x2){E::pack2(c0[e], c1[e]), E::pack2(c2[e], 0.f)};
+#pragma unroll
+        for (int sw = 1; sw <= 2; sw <<= 1) {
+          const bool on = (kx & sw) != 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!(e & sw)) {
+              const u32x2 lo = px[e], hi = px[e | sw];
+              px[e] = on ? hi : lo;
+              px[e | sw] = on ? lo : hi;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2*>(rows + dst_off[j] + (e ^ kx) * 4) = px[e];
+      }
+  };
+  int item = blockIdx.x;
+  if (item >= total) return;
+  issue(item);
+  for (int i = tid; i < 7 * 64 * 4; i += S6_THREADS) *reinterpret_cast<u32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const u32x4*>(p.wimg + (size_t)i * 8);
+  for (int i = tid; i < S6_NR * 2; i += S6_THREADS) {              // zero border columns (never overwritten)
+    uint16_t* rp = rows + (size_t)(i >> 1) * PXP * 4;
+    if (i & 1) {
+#pragma unroll
+      for (int e = 0; e < 5; ++e) *reinterpret_cast<u32x2*>(rp + (size_t)(p.W + 3 + e) * 4) = (u32x2){0u, 0u};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) *reinterpret_cast<u32x2*>(rp + e * 4) = (u32x2){0u, 0u};
+    }
+  }
+  commit(item);
+  if (item + step < total) issue(item + step);
+  __syncthreads();
+  const int nct = (p.Wo + 15) >> 4, ct = wave % 7, half = wave / 7, col = 16 * ct + n;
+  for (; item < total; item += step) {
+    const int rb = item % nrb, f = (item / nrb) % p.F, b = item / (nrb * p.F);
+    const int pr0 = rb * S6_PR, s0 = 2 * pr0 - 1;
+    // the wave's two 16-channel tiles one after the other: 7 weight fragments + 5 accumulators live at a time
+#pragma unroll 1
+    for (int c2 = 0; c2 < 2; ++c2) {
+      if (ct >= nct) break;
+      const int ch0 = 32 * half + 16 * c2;
+      v8 wa[7];
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) wa[kh] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(wl + ((size_t)(kh * 64 + ch0 + n)) * 32 + kg * 8));
+      f32x4 acc[S6_SR];
+#pragma unroll
+      for (int s = 0; s < S6_SR; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const uint16_t* base = rows + (size_t)(2 * (16 * ct + n + kg)) * 4;
+      constexpr int RG = 5, NG = S6_NR / RG;
+      v8 bf[2][RG];
+      auto rd = [&](int g, v8* dst) {
+#pragma unroll
+        for (int e = 0; e < RG; ++e) dst[e] = __builtin_bit_cast(v8, *reinterpret_cast<const u32x4*>(base + (size_t)(g * RG + e) * PXP * 4));
+      };
+      rd(0, bf[0]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) rd(g + 1, bf[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < RG; ++e) {
+          const int r = g * RG + e;
+#pragma unroll
+          for (int s = 0; s < S6_SR; ++s) {
+            const int kh = r - 2 * s;                              // staged row r = 2 s + kh of stem row s0 + s
+            if (kh >= 0 && kh < 7) acc[s] = E::mfma16(wa[kh], bf[g & 1][e], acc[s]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // vertical max: lane (column n, group kg) holds channels ch0 + 4 kg .. +3 of every stem row
+      if (col < p.Wo) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch0 + 4 * kg);
+#pragma unroll
+        for (int prl = 0; prl < S6_PR; ++prl) {
+          float v[4];
+          bool any = false;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int sr = 2 * prl + dy;
+            if (s0 + sr < 0 || s0 + sr >= p.Ho) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = any ? fmaxf(v[e], acc[sr][e]) : acc[sr][e];
+            any = true;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += bv[e];
+            if (p.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          const int slot = (8 * half + 4 * c2 + kg) ^ ((col & 7) << 1);
+          *reinterpret_cast<u32x2*>(vm + ((size_t)prl * p.Wo + col) * 64 + slot * 4) = (u32x2){E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+        }
+      }
+    }
+    __syncthreads();                                               // every wave is done with `rows`; `vm` is complete
+    // the next item's rows are converted BEFORE this item's pool stores are issued: the wait on the row loads then does not also wait
+    // for stores issued a moment ago (vmcnt is one in-order counter), and the stores drain under the next item's MFMAs
+    if (item + step < total) {
+      commit(item + step);
+      if (item + 2 * step < total) issue(item + 2 * step);
+    }
+    for (int i = tid; i < S6_PR * p.Wp * 8; i += S6_THREADS) {
+      const int prl = i / (p.Wp * 8), rem = i - prl * p.Wp * 8, pc = rem >> 3, ch = rem & 7, pr = pr0 + prl;
+      if (pr >= p.Hp) continue;
+      bool any = false;
+      u32x4 best = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int c = 2 * pc - 1 + dx;
+        if (c < 0 || c >= p.Wo) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(vm + ((size_t)prl * p.Wo + c) * 64 + (ch ^ (c & 7)) * 8);
+        best = any ? max8<E>(best, v) : v;
+        any = true;
+      }
+      *reinterpret_cast<u32x4*>(p.out + ((((size_t)b * p.F + f) * p.Hp + pr) * p.Wp + pc) * p.out_C + p.out_coff + ch * 8) = best;
+    }
+    __syncthreads();                                               // `rows` hold the next item; `vm` may be overwritten
   }
 }
 
@@ -744,6 +951,36 @@ extern "C" int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const 
   const int rc = dtype == KVQ_DT_FP16 ? launch(conv_stem_pool_kernel<Fp16>) : launch(conv_stem_pool_kernel<Bf16>);
   if (rc) return rc;
   KVQ_CHECK_LAUNCH("conv_stem_pool_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_conv_stem64_pool(const float* x, const int32_t dims5[5], const int32_t* t_index, int n_frames, const uint16_t* wimg,
+                                    const float* bias64, int relu, int dtype, uint16_t* out, int out_C, int out_coff, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(x && dims5 && wimg && bias64 && out, KVQ_ERR_NULL, "kvq_conv_stem64_pool: NULL pointer");
+  KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem64_pool: dtype %d", dtype);
+  Stem64Params p{};
+  p.x = x; p.t_index = t_index; p.wimg = wimg; p.bias = bias64; p.B = dims5[0]; p.T = dims5[2]; p.H = dims5[3]; p.W = dims5[4];
+  p.F = n_frames; p.relu = relu; p.out = out; p.out_C = out_C; p.out_coff = out_coff;
+  KVQ_REQUIRE(dims5[1] == 3 && p.B > 0 && p.T > 0 && p.H >= 7 && p.W >= 8 && n_frames > 0 && (t_index || n_frames <= p.T), KVQ_ERR_SHAPE,
+              "kvq_conv_stem64_pool: needs a 3-channel clip (got C=%d, %d frames of %d)", dims5[1], n_frames, p.T);
+  KVQ_REQUIRE(p.W % 4 == 0 && p.W <= 224 && (((size_t)x) & 15) == 0 && (((size_t)out) & 15) == 0 && out_C % 8 == 0 && out_coff % 8 == 0 &&
+                  out_coff >= 0 && out_coff + 64 <= out_C, KVQ_ERR_SHAPE,
+              "kvq_conv_stem64_pool: W %% 4 == 0, W <= 224, 16-byte aligned clip / output channel slice (got W=%d, C=%d, offset %d)", p.W, out_C, out_coff);
+  p.Ho = (p.H - 1) / 2 + 1; p.Wo = (p.W - 1) / 2 + 1;
+  p.Hp = (p.Ho - 1) / 2 + 1; p.Wp = (p.Wo - 1) / 2 + 1;
+  KVQ_REQUIRE((long)p.B * p.F * p.Hp < (1L << 30), KVQ_ERR_UNSUPPORTED, "kvq_conv_stem64_pool: %d clips x %d frames", p.B, p.F);
+  const size_t lds = (size_t)S6_NR * (p.W + 8) * 8 + (size_t)S6_PR * p.Wo * 128 + (size_t)3 * S6_ITEMS * S6_THREADS * 16 + 7 * 64 * 64;
+  auto launch = [&](auto kern) -> int {
+    static bool set = false;
+    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); set = true; }
+    const int total = ceil_div(p.Hp, S6_PR) * p.F * p.B;          // one persistent workgroup per CU (256 on gfx950)
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min(total, 256)), dim3(S6_THREADS), lds, (hipStream_t)stream, p);
+    return KVQ_OK;
+  };
+  const int rc = dtype == KVQ_DT_FP16 ? launch(conv_stem64_pool_kernel<Fp16>) : launch(conv_stem64_pool_kernel<Bf16>);
+  if (rc) return rc;
+  KVQ_CHECK_LAUNCH("conv_stem64_pool_kernel");
   return KVQ_OK;
 }
 

@@ -250,6 +250,21 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
         NET_REQUIRE(d.B == s.B && d.D == o.Do && d.H == o.Ho && d.W == o.Wo && d.C == 8, "kvq_convnet_create: op %d (stem + pool) output shape", i);
         break;
       }
+      case KVQ_NET_STEM64_POOL: {
+        NET_REQUIRE(s.kind == KVQ_NET_T_F32_PLANAR && d.kind == KVQ_NET_T_ACT16 && s.C == 3 && p.w && p.bias && p.t_index && p.n_index > 0,
+                    "kvq_convnet_create: op %d (stem64 + pool) operands", i);
+        NET_REQUIRE(p.cout == 64 && p.kernel3[0] == 1 && p.kernel3[1] == 7 && p.kernel3[2] == 7 && p.stride3[0] == 1 && p.stride3[1] == 2 &&
+                        p.stride3[2] == 2 && p.pad3[0] == 0 && p.pad3[1] == 3 && p.pad3[2] == 3 && s.W <= 224 && s.W % 4 == 0,
+                    "kvq_convnet_create: op %d (stem64 + pool) geometry", i);
+        o.Do = p.n_index; o.Ho = ((s.H - 1) / 2 + 1 - 1) / 2 + 1; o.Wo = ((s.W - 1) / 2 + 1 - 1) / 2 + 1;
+        NET_REQUIRE(d.B == s.B && d.D == o.Do && d.H == o.Ho && d.W == o.Wo && p.dst_coff % 8 == 0 && d.C % 8 == 0 && p.dst_coff + 64 <= d.C,
+                    "kvq_convnet_create: op %d (stem64 + pool) output shape", i);
+        for (int k = 0; k < p.n_index; ++k) NET_REQUIRE(p.t_index[k] >= 0 && p.t_index[k] < s.D, "kvq_convnet_create: op %d frame index %d", i, p.t_index[k]);
+        o.t_index.assign(p.t_index, p.t_index + p.n_index);
+        int rc = upload_i32(net, o.t_index, &o.d_taps);
+        if (rc) return fail(rc);
+        break;
+      }
       case KVQ_NET_MEAN_STD:
         NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && p.out_stride > 0 && p.mean_off >= 0, "kvq_convnet_create: op %d (mean/std pool)", i);
         break;
@@ -489,6 +504,12 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
         const int32_t dims5[5] = {s.B, s.C, s.D, s.H, s.W};
         KVQ_TRY(kvq_conv_stem_pool((const float*)ptr_of(p.src), dims5, (const uint16_t*)p.w, p.bias, p.kernel3[0], p.relu, net->dtype,
                                    (uint16_t*)ptr_of(p.dst), st));
+        break;
+      }
+      case KVQ_NET_STEM64_POOL: {
+        const int32_t dims5[5] = {s.B, s.C, s.D, s.H, s.W};
+        KVQ_TRY(kvq_conv_stem64_pool((const float*)ptr_of(p.src), dims5, o.d_taps, p.n_index, (const uint16_t*)p.w, p.bias, p.relu, net->dtype,
+                                     (uint16_t*)ptr_of(p.dst), net->tensors[p.dst].t.C, p.dst_coff, st));
         break;
       }
       case KVQ_NET_BOTTLENECK: {

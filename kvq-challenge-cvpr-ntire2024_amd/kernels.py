@@ -680,6 +680,36 @@ def conv_stem_pool(x: torch.Tensor, wpack: torch.Tensor, bias8: torch.Tensor, kd
     return out
 
 
+def stem64_pack_weight(w_ok: torch.Tensor, out_dtype):
+    """[64][>= 147] stem weight (K ordered kh,kw,c over a 1x7x7 kernel, 3 input channels) -> the 16-bit [7][64][32] image of
+    ``kvq_conv_stem64_pool``: entry [kh][o][kw * 4 + c], tap 7 and channel 3 zero."""
+    assert w_ok.shape[0] == 64 and w_ok.shape[1] >= 147
+    img = torch.zeros(7, 64, 8, 4, dtype=torch.float32, device=w_ok.device)
+    img[:, :, :7, :3] = w_ok[:, :147].float().reshape(64, 7, 7, 3).permute(1, 0, 2, 3)
+    if out_dtype == torch.float16:
+        img = img.clamp(-65504.0, 65504.0)
+    return img.reshape(7, 64, 32).to(out_dtype).contiguous()
+
+
+def conv_stem64_pool(x: torch.Tensor, t_index, wimg: torch.Tensor, bias64: torch.Tensor, relu: bool = True, out=None, out_coff: int = 0):
+    """SlowFast's slow-pathway stem in one launch (``kvq_conv_stem64_pool``): frames ``t_index`` of the fp32 clip x (B,3,T,H,W) ->
+    Conv3d(3 -> 64, (1,7,7), (1,2,2), (0,3,3)) + bias [+ ReLU] + MaxPool3d((1,3,3), (1,2,2), (0,1,1)); 16-bit channels-last
+    (B,F,Hp,Wp,64), or channels out_coff .. out_coff+63 of ``out`` (B,F,Hp,Wp,C)."""
+    _need_gpu(x, wimg, bias64)
+    assert x.dtype == torch.float32 and x.is_contiguous() and wimg.dtype in HALF_TYPES and bias64.numel() == 64
+    B, Cin, T, H, W = x.shape
+    ti = None if t_index is None else torch.as_tensor(t_index, dtype=torch.int32).to(x.device)
+    F_ = T if ti is None else ti.numel()
+    hp, wp_ = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
+    if out is None:
+        out = torch.empty(B, F_, hp, wp_, 64, dtype=wimg.dtype, device=x.device)
+    assert tuple(out.shape[:4]) == (B, F_, hp, wp_) and out.is_contiguous() and out.dtype == wimg.dtype
+    check(lib().kvq_conv_stem64_pool(ptr(x), C.byref((C.c_int32 * 5)(B, Cin, T, H, W)), ptr(ti) if ti is not None else None, F_, ptr(wimg),
+                                     ptr(bias64), int(relu), dtype_code(wimg.dtype), ptr(out), out.shape[4], out_coff, current_stream()),
+          "kvq_conv_stem64_pool")
+    return out
+
+
 def conv_stem_direct(x: torch.Tensor, w_kc: torch.Tensor, bias: torch.Tensor, kernel, stride, pad, relu: bool, out_dtype):
     """Direct Conv3d for few output channels: x fp32 (B,C,D,H,W), w_kc fp32 [K][Cout] (K ordered kd,kh,kw,c), -> 16-bit
     channels-last (B,Do,Ho,Wo,Cout)."""

@@ -369,20 +369,27 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             return dst
 
         fast_in = tensor(B, T, H, W, 3, _abi.NET_T_F32_PLANAR)                       # slot 0: the caller's clips
-        slow_in = tensor(B, T // 4, H, W, 3, _abi.NET_T_F32_PLANAR)
-        op(_abi.NET_SELECT_T, fast_in, slow_in, t_index=[int(v) for v in torch.linspace(0, T - 1, T // 4).long().tolist()])
+        t_sel = [int(v) for v in torch.linspace(0, T - 1, T // 4).long().tolist()]
         Hs, Ws = odim(H, 7, 2, 3), odim(W, 7, 2, 3)
         Hp, Wp = odim(Hs, 3, 2, 1), odim(Ws, 3, 2, 1)
-        # stems: slow 3 -> 64 (1x7x7 over the 8-channel packed frames), fast 3 -> 8 (5x7x7 on the matrix cores); max-pools
+        # stems: slow 3 -> 64 (1x7x7), fast 3 -> 8 (5x7x7), each followed by the (1,3,3) max-pool
         wt, bias, k, st, pd = Wt[fe + "0.multipathway_blocks.0"]
-        taps = k[1] * k[2]
-        w8 = torch.zeros(wt.shape[0], -(-taps * 8 // 32) * 32, dtype=wt.dtype, device=device)
-        w8[:, :taps * 8].view(wt.shape[0], taps, 8)[:, :, :3] = wt[:, :taps * 3].reshape(wt.shape[0], taps, 3)
-        keep.append(w8)
-        s_stem = tensor(B, T // 4, Hs, Ws, 64)
-        op(_abi.NET_STEM8, slow_in, s_stem, k, st, pd, cout=64, kpad=w8.shape[1], relu=1, w=w8, bias=bias)
         slow = tensor(B, T // 4, Hp, Wp, 64 + 2 * FAST_C[0])
-        op(_abi.NET_POOL, s_stem, slow, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1, dst_coff=0)
+        if STEM_POOL and tuple(k) == (1, 7, 7) and tuple(st) == (1, 2, 2) and tuple(pd) == (0, 3, 3) and wt.shape[0] == 64 and W <= 224:
+            # frame selection + stem + max-pool in one launch straight from the fp32 clip (no slow clip, no 64-channel stem map in HBM)
+            wimg = kernels.stem64_pack_weight(wt, wt.dtype)
+            keep.append(wimg)
+            op(_abi.NET_STEM64_POOL, fast_in, slow, k, st, pd, cout=64, relu=1, w=wimg, bias=bias, t_index=t_sel, dst_coff=0)
+        else:
+            slow_in = tensor(B, T // 4, H, W, 3, _abi.NET_T_F32_PLANAR)
+            op(_abi.NET_SELECT_T, fast_in, slow_in, t_index=t_sel)
+            taps = k[1] * k[2]
+            w8 = torch.zeros(wt.shape[0], -(-taps * 8 // 32) * 32, dtype=wt.dtype, device=device)
+            w8[:, :taps * 8].view(wt.shape[0], taps, 8)[:, :, :3] = wt[:, :taps * 3].reshape(wt.shape[0], taps, 3)
+            keep.append(w8)
+            s_stem = tensor(B, T // 4, Hs, Ws, 64)
+            op(_abi.NET_STEM8, slow_in, s_stem, k, st, pd, cout=64, kpad=w8.shape[1], relu=1, w=w8, bias=bias)
+            op(_abi.NET_POOL, s_stem, slow, (1, 3, 3), (1, 2, 2), (0, 1, 1), is_max=1, dst_coff=0)
         _, fbias, fk, fst, fpd = Wt[fe + "0.multipathway_blocks.1"]
         lane[0] = FAST_LANE
         fast = tensor(B, T, Hp, Wp, 8)
@@ -474,7 +481,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
             _abi.check(_abi.lib().kvq_convnet_profile_read(handle, ms, len(descs), C.byref(n)), "kvq_convnet_profile_read")
         finally:
             _abi.check(_abi.lib().kvq_convnet_profile(handle, 0), "kvq_convnet_profile")
-        kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma", _abi.NET_STEM_POOL: "stem_pool",
+        kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma", _abi.NET_STEM_POOL: "stem_pool", _abi.NET_STEM64_POOL: "stem64_pool",
                  _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t", _abi.NET_BOTTLENECK: "bottleneck"}
         out = []
         for d, t in zip(descs, ms):

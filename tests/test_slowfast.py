@@ -108,7 +108,7 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     m = m.cuda().eval()
     x = torch.from_numpy(synth.synth_clip(77, 16, 96, 64, batch=3)).cuda()
-    M.FUSE_FAST = False          # the layer-by-layer sequencing has one launch per conv: compare like with like
+    M.FUSE_FAST = M.STEM_POOL = False          # the layer-by-layer sequencing has one launch per conv / pool: compare like with like
     try:
         with torch.no_grad():
             s1, f1 = m(M.pack_pathway_output(x))
@@ -119,10 +119,18 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
             finally:
                 M.CONVNET = True
     finally:
-        M.FUSE_FAST = True
+        M.FUSE_FAST = M.STEM_POOL = True
     assert m.__dict__.get("_nets"), "the one-call path did not run"
     assert torch.equal(s1, s1b) and torch.equal(f1, f1b)
     assert torch.equal(s1, s0) and torch.equal(f1, f0)
+    # the shipped plan (stems fused with their max-pools, fast blocks fused): same network, other accumulation order inside the stems
+    for handle, *_ in m._nets.values():
+        _abi.lib().kvq_convnet_destroy(handle)
+    m._nets.clear()
+    with torch.no_grad():
+        s2, f2 = m(M.pack_pathway_output(x))
+    for a, b_ in ((s2, s0), (f2, f0)):
+        assert (a.float() - b_.float()).abs().max().item() <= 2e-2 * max(1.0, b_.float().abs().max().item())
     # a layer table whose shapes do not chain is rejected at plan creation, with a message
     t = (_abi.KvqNetTensor * 2)()
     t[0].B, t[0].D, t[0].H, t[0].W, t[0].C, t[0].kind = 1, 4, 8, 8, 16, _abi.NET_T_ACT16
@@ -376,8 +384,8 @@ def test_conv_stem_mfma_vs_torch_conv3d(shape, kernel, stride, pad, dtype):
 ])
 def test_conv_stem_pool_vs_torch(shape, kd, dtype):
     """kvq_conv_stem_pool (conv + bias + ReLU + 3x3/2 max-pool in one launch, straight from the fp32 clip) against F.conv3d of the
-    ROUNDED operands -> ReLU -> max_pool3d, and BIT-equal to the three-launch path it replaces (pack + kvq_conv_stem_mfma + pool:
-    same MFMA k-order per output, same 16-bit rounding before the max)."""
+    ROUNDED operands -> ReLU -> max_pool3d, and within one 16-bit rounding of the three-launch path it replaces (pack +
+    kvq_conv_stem_mfma + pool: same operands, fp32 accumulation in another order)."""
     from kvq_amd import kernels
     g = np.random.Generator(np.random.PCG64(sum(shape) + kd))
     kernel, stride, pad = (kd, 7, 7), (1, 2, 2), (kd // 2, 3, 3)
@@ -398,6 +406,39 @@ def test_conv_stem_pool_vs_torch(shape, kd, dtype):
     three = torch.nn.functional.max_pool3d(stem.float().permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1)).permute(0, 2, 3, 4, 1)
     close = (out.float() - three).abs().max().item()
     assert close <= ulp * max(1.0, ref.abs().max().item()), close
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,t_index,coff", [
+    ((2, 3, 8, 30, 48), [0, 2, 5, 7], 0),        # Wo = 24 (ragged second tile), Hp = 8
+    ((1, 3, 4, 50, 220), [3, 0], 16),            # Wo = 110: seven tiles, the last ragged; Hp = 13: ragged last row block; channel slice
+    ((1, 3, 8, 224, 224), [0, 7], 0),            # the clip geometry
+    ((1, 3, 2, 21, 20), None, 0),                # odd H, every frame
+])
+def test_conv_stem64_pool_vs_torch(shape, t_index, coff, dtype):
+    """kvq_conv_stem64_pool (frame selection + 1x7x7 conv + bias + ReLU + 3x3/2 max-pool in one launch from the fp32 clip) against
+    index_select -> F.conv3d of the ROUNDED operands -> ReLU -> max_pool3d; a channel slice leaves the other channels alone."""
+    from kvq_amd import kernels
+    g = np.random.Generator(np.random.PCG64(sum(shape)))
+    x = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+    w5 = torch.from_numpy((g.standard_normal((64, 3, 1, 7, 7)) / np.sqrt(147)).astype(np.float32))
+    bias = torch.from_numpy(g.standard_normal(64).astype(np.float32))
+    w_ok = w5.permute(0, 2, 3, 4, 1).reshape(64, 147).contiguous()
+    wimg = kernels.stem64_pack_weight(w_ok.cuda(), dtype)
+    xs = x if t_index is None else x.index_select(2, torch.tensor(t_index))
+    ref = torch.relu(torch.nn.functional.conv3d(xs.to(dtype).double(), w5.to(dtype).double(), bias.double(), (1, 2, 2), (0, 3, 3)))
+    ref = torch.nn.functional.max_pool3d(ref, (1, 3, 3), (1, 2, 2), (0, 1, 1)).permute(0, 2, 3, 4, 1).float()
+    out = None
+    if coff:
+        out = torch.full(tuple(ref.shape[:4]) + (96,), 7.0, dtype=dtype, device="cuda")
+    got = kernels.conv_stem64_pool(x.cuda(), t_index, wimg, bias.cuda(), True, out=out, out_coff=coff)
+    if coff:
+        assert (got[..., :coff] == 7.0).all() and (got[..., coff + 64:] == 7.0).all()
+        got = got[..., coff:coff + 64]
+    assert tuple(got.shape) == tuple(ref.shape)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert (got.float().cpu() - ref).abs().max().item() <= ulp * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.gpu

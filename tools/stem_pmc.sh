@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / L2 counters of the fused fast-stem kernel (separate --pmc passes; no trace domains).  usage: stem_pmc.sh tag
+# SQ / L2 counters of the fused stem kernels (separate --pmc passes; no trace domains).  usage: stem_pmc.sh tag
 tag=$1
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/stem_pmc_$tag
@@ -12,5 +12,5 @@ for P in "$P1" "$P2" "$P3" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $P --output-format csv -d $out/p$i -o c -- python $root/tools/stem_probe.py pool > $out/p$i.log 2>&1
 done
-python $root/tools/pmc_kernel.py conv_stem_pool $(find $out -name "*counter_collection.csv") > $root/gpurun_out/stem_pmc_$tag.txt
+python $root/tools/pmc_kernel.py conv_stem $(find $out -name "*counter_collection.csv") > $root/gpurun_out/stem_pmc_$tag.txt
 cat $root/gpurun_out/stem_pmc_$tag.txt
