@@ -50,8 +50,9 @@ struct BnLayout {
   static constexpr int LDS_BYTES = OFF_TILE + BN_HALO * BN_HALO * CI * 2;
 };
 
-template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE>
-__global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) {
+template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void fast_bottleneck_kernel(BneckParams p) {
+  static_assert(NW == 4 || NW == 8, "4 waves (two conv_a column tiles each) or 8 (one each)");
   static_assert(STRIDE == 1 || (STRIDE == 2 && SC), "a strided block has a projection shortcut");
   constexpr int BN_T = bn_tile(STRIDE);
   fp16_saturate_mode();
@@ -68,19 +69,21 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   const uint16_t* xb = p.x + (size_t)b * p.T * frame * CIN;
 
   // weights + biases -> LDS (LDS-DMA, 1 KB per wave-load)
-  for (int q = wave; q < L::PACK_BYTES / 1024; q += 4)
+  for (int q = wave; q < L::PACK_BYTES / 1024; q += NW)
     __builtin_amdgcn_global_load_lds((bn_gbl_t)(p.pack + q * 1024 + lane * 16), (bn_lds_t)(lds + q * 1024), 16, 0, 0);
   const float* s_ba = reinterpret_cast<const float*>(lds + L::OFF_BIAS);
   const float* s_bb = s_ba + 32;
   const float* s_bc = s_ba + 64;
   uint16_t* a_tile = reinterpret_cast<uint16_t*>(lds + L::OFF_TILE);
 
-  // ---- conv_a on the halo: column tiles 2 wave, 2 wave + 1.  The loads of BOTH tiles are in flight before the first wait
-  // where the registers allow it (<= 12 k-steps); 8 waves x 1 tile was measured too: 128 VGPRs spill at 24 k-steps ----------
-  constexpr int NLOAD = L::KSA <= 12 ? 2 : 1;
+  // ---- conv_a on the halo: 8 column tiles, TPW per wave.  4 waves: the loads of BOTH tiles are in flight before the first wait
+  // where the registers allow it (<= 12 k-steps).  8 waves (one workgroup per CU, 256 registers per wave): one tile each - for the
+  // 14 x 14 maps of res4, where a launch is ONE tile per CU and its time is the workgroup's serial chain, not throughput ----------
+  constexpr int TPW = 8 / NW;
+  constexpr int NLOAD = (TPW == 2 && L::KSA <= 12) ? 2 : 1;
   V8 bx[NLOAD][L::KSA];
   auto load_tile = [&](int c2, V8 (&dst)[L::KSA], bool& inside, int& ap) {
-    ap = (2 * wave + c2) * 32 + j;
+    ap = (TPW * wave + c2) * 32 + j;
     const int yy = STRIDE * y0 - 1 + (ap >> 4), xx = STRIDE * x0 - 1 + (ap & 15);
     inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
     const uint16_t* px = xb + ((size_t)(inside ? yy : 0) * p.W + (inside ? xx : 0)) * CIN;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
-  for (int c2 = 0; c2 < 2; ++c2) {
+  for (int c2 = 0; c2 < TPW; ++c2) {
     if (NLOAD == 1 && c2 == 1) load_tile(1, bx[0], inside[1], ap[1]);
     f32x16 acc;
 #pragma unroll
@@ -121,8 +124,11 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   __syncthreads();
 
   // ---- conv_b, conv_c, shortcut on the 14 x 14 outputs: column tiles wave, wave + 4 ---------------------------------------
+  int n_ct = (BN_T * BN_T + 31) / 32;
+  if (NW == 8) asm volatile("" : "+s"(n_ct));      // opaque trip count: with 8 waves the loop has one trip, and peeled into straight-line code the
+                                      // scheduler hoisted every LDS weight read above the shortcut loads and spilled 1 KB per lane
 #pragma unroll 1
-  for (int ct = wave; ct < (BN_T * BN_T + 31) / 32; ct += 4) {      // (stride 2: 49 outputs = 2 column tiles, waves 2 and 3 are done)
+  for (int ct = wave; ct < n_ct; ct += NW) {      // (stride 2: 49 outputs = 2 column tiles, waves 2 and 3 are done)
     const int op_raw = ct * 32 + j;
     const int op = op_raw < BN_T * BN_T ? op_raw : BN_T * BN_T - 1;
     const int oy = op / BN_T, ox = op - oy * BN_T;
@@ -210,23 +216,23 @@ __global__ __launch_bounds__(256, 2) void fast_bottleneck_kernel(BneckParams p) 
   }
 }
 
-template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE>
+template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE, int NW>
 static int launch_bneck(const BneckParams& p, hipStream_t st) {
   using L = BnLayout<CIN, CI, COUT, SC>;
-  auto k = fast_bottleneck_kernel<E, CIN, CI, COUT, SC, STRIDE>;
+  auto k = fast_bottleneck_kernel<E, CIN, CI, COUT, SC, STRIDE, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)((long)p.B * p.T * p.tiles_y * p.tiles_x)), dim3(256), L::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)((long)p.B * p.T * p.tiles_y * p.tiles_x)), dim3(NW * 64), L::LDS_BYTES, st, p);
   KVQ_CHECK_LAUNCH("fast_bottleneck_kernel");
   return KVQ_OK;
 }
 
-template <int CIN, int CI, int COUT, bool SC, int STRIDE = 1>
+template <int CIN, int CI, int COUT, bool SC, int STRIDE = 1, int NW = 4>
 static int launch_bneck_dt(const BneckParams& p, int dtype, hipStream_t st) {
-  return dtype == KVQ_DT_FP16 ? launch_bneck<Fp16, CIN, CI, COUT, SC, STRIDE>(p, st) : launch_bneck<Bf16, CIN, CI, COUT, SC, STRIDE>(p, st);
+  return dtype == KVQ_DT_FP16 ? launch_bneck<Fp16, CIN, CI, COUT, SC, STRIDE, NW>(p, st) : launch_bneck<Bf16, CIN, CI, COUT, SC, STRIDE, NW>(p, st);
 }
 
 // the supported (input, inner, output) channel triples: SlowFast-R50's fast pathway, res2 .. res4
@@ -275,7 +281,9 @@ extern "C" int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], in
     case 1: return launch_bneck_dt<8, 8, 32, true>(p, dtype, st);
     case 2: return launch_bneck_dt<32, 8, 32, false>(p, dtype, st);
     case 3: return launch_bneck_dt<64, 16, 64, false>(p, dtype, st);
-    case 4: return launch_bneck_dt<128, 32, 128, false>(p, dtype, st);
+    case 4:      // res4: 14 x 14 maps, one tile per frame - few tiles: the 8-wave form (one conv_a tile per wave, b / c tiles in one round)
+      return (long)p.B * p.T * p.tiles_y * p.tiles_x <= 512 ? launch_bneck_dt<128, 32, 128, false, 1, 8>(p, dtype, st)
+                                                             : launch_bneck_dt<128, 32, 128, false>(p, dtype, st);
     case 5: return launch_bneck_dt<32, 16, 64, true, 2>(p, dtype, st);
     default: return launch_bneck_dt<64, 32, 128, true, 2>(p, dtype, st);
   }
