@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 24
+#define KVQ_ABI_VERSION 25
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -563,6 +563,8 @@ typedef enum {
                              launch (kvq_conv_stem_pool): dst is the POOLED map */
   KVQ_NET_STEM64_POOL = 8, /* frame selection (t_index / n_index) + 3 -> 64 stem (1 x 7 x 7, stride (1,2,2)) + the (1,3,3) max-pool in one launch
                              (kvq_conv_stem64_pool): src the fp32 clip, dst the POOLED map (channels dst_coff .. dst_coff + 63), w its weight image */
+  KVQ_NET_BOTTLENECK_S = 9, /* one identity residual block of the SLOW pathway (conv_a 1x1x1) in one launch (kvq_slow_bottleneck): w = the
+                             packed image, kpad = inner channels, cout = output channels (written at channel 0 of dst rows) */
   KVQ_NET_BOTTLENECK = 6  /* one residual block of SlowFast's fast pathway in ONE launch (kvq_fast_bottleneck): w = the packed image,
                              kpad = inner channels, cout = output channels, n_index = 1 when the block has a projection shortcut,
                              stride3[1] = stride3[2] = its spatial stride */
@@ -633,6 +635,17 @@ int kvq_convnet_profile_read(const KvqConvNet* net, float* ms, int capacity, int
 size_t kvq_fast_bottleneck_pack_bytes(int cin, int ci, int cout, int projection, int stride);
 int kvq_fast_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, int projection, int stride,
                         const void* pack, int dtype, uint16_t* out, void* stream);
+
+/* SlowFast SLOW-pathway identity residual block at res2, fused (csrc/slowneck.hip): conv_a 1x1x1 + BN + ReLU -> conv_b 1x3x3 (pad 0,1,1,
+ * stride 1) + BN + ReLU -> conv_c 1x1x1 + BN -> + x -> ReLU (SlowFast_features.py:137-165, blocks 1 .. of the slow pathway's res2).
+ * x 16-bit channels-last (B,T,H,W,cin), dims4 = {B,T,H,W}; out rows of out_C >= cout channels (out_C <= 0: dense), channels 0 .. cout-1
+ * written (a stage's last block writes into the lateral-concat tensor).  pack as for kvq_fast_bottleneck with conv_a's k over c only and
+ * TWO row tiles for conv_a / conv_b: conv_a [2][cin / 16] | conv_b [2][9 ci / 16] | conv_c [cout / 32][ci / 16] (accumulator order) |
+ * fp32 bias_a[64] bias_b[64] bias_c[cout], padded to 2 KB.  Built (cin, ci, cout): (256, 64, 256); kvq_slow_bottleneck_pack_bytes returns 0
+ * for anything else. */
+size_t kvq_slow_bottleneck_pack_bytes(int cin, int ci, int cout);
+int kvq_slow_bottleneck(const uint16_t* x, const int32_t dims4[4], int cin, int ci, int cout, const void* pack, int dtype,
+                        uint16_t* out, int out_C, void* stream);
 
 /* nn.MaxPool / nn.AvgPool (count_include_pad) on channels-last 16-bit (B,D,H,W,C). */
 int kvq_pool_nd(const uint16_t* x, int dtype, const int32_t dims5[5], const int32_t kernel3[3],

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 def dtype_code(dt) -> int:
@@ -98,7 +98,7 @@ class KvqNetOp(C.Structure):
                 ("n_index", C.c_int32), ("lane", C.c_int32)]
 
 
-NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T, NET_BOTTLENECK, NET_STEM_POOL, NET_STEM64_POOL = range(9)
+NET_CONV, NET_POOL, NET_STEM8, NET_STEM_MFMA, NET_MEAN_STD, NET_SELECT_T, NET_BOTTLENECK, NET_STEM_POOL, NET_STEM64_POOL, NET_BOTTLENECK_S = range(10)
 NET_T_ACT16, NET_T_F32_PLANAR, NET_T_ACT32 = 0, 1, 2
 
 
@@ -203,6 +203,8 @@ SYMBOLS = {
     "kvq_pack_clip_cl4": (i32, [p_void, C.POINTER(i32 * 5), i32, i32, p_void, p_void]),
     "kvq_conv_stem_pool": (i32, [p_void, C.POINTER(i32 * 5), p_void, p_void, i32, i32, i32, p_void, p_void]),
     "kvq_conv_stem64_pool": (i32, [p_void, C.POINTER(i32 * 5), p_void, i32, p_void, p_void, i32, i32, p_void, i32, i32, p_void]),
+    "kvq_slow_bottleneck_pack_bytes": (C.c_size_t, [i32, i32, i32]),
+    "kvq_slow_bottleneck": (i32, [p_void, C.POINTER(i32 * 4), i32, i32, i32, p_void, i32, p_void, i32, p_void]),
     "kvq_conv_stem_mfma": (i32, [p_void, C.POINTER(i32 * 4), p_void, p_void, C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
                                  i32, i32, p_void, p_void]),
     "kvq_pool_nd": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),

@@ -277,6 +277,13 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
         if (rc) return fail(rc);
         break;
       }
+      case KVQ_NET_BOTTLENECK_S: {
+        NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && d.kind == KVQ_NET_T_ACT16 && p.w, "kvq_convnet_create: op %d (slow bottleneck) operand kinds", i);
+        NET_REQUIRE(kvq_slow_bottleneck_pack_bytes(s.C, p.kpad, p.cout) && d.B == s.B && d.D == s.D && d.H == s.H && d.W == s.W && d.C >= p.cout &&
+                        d.C % 8 == 0 && p.dst_coff == 0,
+                    "kvq_convnet_create: op %d (slow bottleneck %d -> %d -> %d) shape", i, s.C, p.kpad, p.cout);
+        break;
+      }
       case KVQ_NET_BOTTLENECK: {
         NET_REQUIRE(s.kind == KVQ_NET_T_ACT16 && d.kind == KVQ_NET_T_ACT16 && p.w, "kvq_convnet_create: op %d (bottleneck) operand kinds", i);
         const int bs = p.stride3[1];
@@ -510,6 +517,12 @@ extern "C" int kvq_convnet_forward(const KvqConvNet* net, const void* const* inp
         const int32_t dims5[5] = {s.B, s.C, s.D, s.H, s.W};
         KVQ_TRY(kvq_conv_stem64_pool((const float*)ptr_of(p.src), dims5, o.d_taps, p.n_index, (const uint16_t*)p.w, p.bias, p.relu, net->dtype,
                                      (uint16_t*)ptr_of(p.dst), net->tensors[p.dst].t.C, p.dst_coff, st));
+        break;
+      }
+      case KVQ_NET_BOTTLENECK_S: {
+        const int32_t dims4[4] = {s.B, s.D, s.H, s.W};
+        KVQ_TRY(kvq_slow_bottleneck((const uint16_t*)ptr_of(p.src), dims4, s.C, p.kpad, p.cout, p.w, net->dtype, (uint16_t*)ptr_of(p.dst),
+                                    net->tensors[p.dst].t.C, st));
         break;
       }
       case KVQ_NET_BOTTLENECK: {

@@ -286,6 +286,21 @@ def pool_nd(x: torch.Tensor, kernel, stride, pad, is_max: bool):
     return out
 
 
+def slow_bottleneck(x: torch.Tensor, pack: torch.Tensor, ci: int, cout: int, out=None):
+    """One identity residual block of SlowFast's slow pathway (res2) in one launch (csrc/slowneck.hip).  x (B,T,H,W,cin) channels-last
+    16-bit; ``pack`` from ``models.backbones.slowfast_model.pack_slow_bottleneck``; ``out`` (B,T,H,W,C >= cout) receives channels 0..cout-1."""
+    _need_gpu(x, pack)
+    B, T, H, W, cin = x.shape
+    assert x.is_contiguous() and x.dtype in HALF_TYPES
+    assert pack.numel() == lib().kvq_slow_bottleneck_pack_bytes(cin, ci, cout) > 0, "block not built / wrong image size"
+    if out is None:
+        out = torch.empty(B, T, H, W, cout, dtype=x.dtype, device=x.device)
+    assert tuple(out.shape[:4]) == (B, T, H, W) and out.is_contiguous() and out.dtype == x.dtype
+    check(lib().kvq_slow_bottleneck(ptr(x), _i32x((B, T, H, W)), cin, ci, cout, ptr(pack), dtype_code(x.dtype), ptr(out), out.shape[4],
+                                    stream_of(x)), "kvq_slow_bottleneck")
+    return out
+
+
 def fast_bottleneck(x: torch.Tensor, pack: torch.Tensor, ci: int, cout: int, projection: bool, stride: int = 1):
     """One residual block of SlowFast's fast pathway in one launch (csrc/bottleneck.hip).  x (B,T,H,W,cin) channels-last 16-bit,
     ``pack`` the uint8 image described in include/kvq_hip.h -> (B,T,ceil(H/stride),ceil(W/stride),cout)."""

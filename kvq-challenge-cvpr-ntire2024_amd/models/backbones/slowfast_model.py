@@ -139,6 +139,7 @@ IMPLICIT_CONV = True     # 0: materialised im2col + GEMM
 RESIDUAL16 = True
 CONVNET = True                  # 0: the layer-by-layer Python sequencing below
 FUSE_FAST = True            # 0: the fast pathway's residual blocks as 3-4 conv launches each
+FUSE_SLOW = True            # 0: the slow pathway's res2 identity blocks as three conv launches each
 TWO_LANES = True                # 0: both pathways on the caller's stream, one op after the other
 STEM_MFMA = True             # 0: fast-pathway stem on the fp32 direct kernel
 STEM_POOL = True             # 0: the one-call plan runs the fast stem as pack + conv + max-pool launches instead of kvq_conv_stem_pool
@@ -174,6 +175,19 @@ def pack_fast_bottleneck(wa, ba, wb, bb, wc, bc, cin, ws=None, bs=None, stride=1
     bias[:ci], bias[32:32 + ci], bias[64:64 + cout] = ba, bb, bias_c
     blob = torch.cat([t.reshape(-1).view(torch.uint8) for t in parts] + [bias.view(torch.uint8)]).contiguous()
     need = _abi.lib().kvq_fast_bottleneck_pack_bytes(cin, ci, cout, int(ws is not None), stride)
+    assert need == blob.numel(), (cin, ci, cout, need, blob.numel())
+    return blob
+
+
+def pack_slow_bottleneck(wa, ba, wb, bb, wc, bc):
+    """The packed image of ``kvq_slow_bottleneck`` (layout: include/kvq_hip.h) from BatchNorm-folded 16-bit weights with (kd, kh, kw, c)-
+    ordered columns — conv_a [64][>= 256], conv_b [64][>= 576], conv_c [256][>= 64] — and fp32 biases."""
+    ci, cout, cin = wa.shape[0], wc.shape[0], 256
+    parts = [_fragments(wa, cin, 2), _fragments(wb, 9 * ci, 2), _fragments(wc, ci, cout // 32, True)]
+    bias = torch.zeros(512, dtype=torch.float32, device=wa.device)
+    bias[:ci], bias[64:64 + ci], bias[128:128 + cout] = ba, bb, bc
+    blob = torch.cat([t.reshape(-1).view(torch.uint8) for t in parts] + [bias.view(torch.uint8)]).contiguous()
+    need = _abi.lib().kvq_slow_bottleneck_pack_bytes(cin, ci, cout)
     assert need == blob.numel(), (cin, ci, cout, need, blob.numel())
     return blob
 
@@ -425,6 +439,23 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
                             descs[-1]["M"] = m_
                             x = y
                             continue
+                    if pi == 0 and FUSE_SLOW and bi > 0 and RESIDUAL16:
+                        cin, ci, cout = tens[x][4], Wt[pre + ".branch2#a"][0].shape[0], Wt[pre + ".branch2#c"][0].shape[0]
+                        ka, kb, sb = tuple(Wt[pre + ".branch2#a"][2]), tuple(Wt[pre + ".branch2#b"][2]), tuple(Wt[pre + ".branch2#b"][3])
+                        if ka == (1, 1, 1) and kb == (1, 3, 3) and sb == (1, 1, 1) and _abi.lib().kvq_slow_bottleneck_pack_bytes(cin, ci, cout):
+                            skey = pre + "/sneck"
+                            if skey not in Wt:
+                                Wt[skey] = pack_slow_bottleneck(*Wt[pre + ".branch2#a"][:2], *Wt[pre + ".branch2#b"][:2], *Wt[pre + ".branch2#c"][:2])
+                            keep.append(Wt[skey])
+                            bb_, d_, h_, w_ = tens[x][:4]
+                            last = bi == DEPTHS[si] - 1
+                            y = tensor(bb_, d_, h_, w_, SLOW["out"][si] + 2 * FAST_C[si + 1] if (last and si < 3) else cout)
+                            op(_abi.NET_BOTTLENECK_S, x, y, cout=cout, kpad=ci, w=Wt[skey], name=pre.replace(fe, "") + " (fused block)")
+                            m_ = bb_ * d_ * h_ * w_
+                            descs[-1]["flops"] = 2.0 * m_ * (cin * ci + 9 * ci * ci + ci * cout)
+                            descs[-1]["M"] = m_
+                            x = y
+                            continue
                     a = conv(x, pre + ".branch2#a")
                     b = conv(a, pre + ".branch2#b")
                     ident = conv(x, pre + "#1", relu=False) if bi == 0 else x
@@ -482,7 +513,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         finally:
             _abi.check(_abi.lib().kvq_convnet_profile(handle, 0), "kvq_convnet_profile")
         kinds = {_abi.NET_CONV: "conv", _abi.NET_POOL: "pool", _abi.NET_STEM8: "stem8", _abi.NET_STEM_MFMA: "stem_mfma", _abi.NET_STEM_POOL: "stem_pool", _abi.NET_STEM64_POOL: "stem64_pool",
-                 _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t", _abi.NET_BOTTLENECK: "bottleneck"}
+                 _abi.NET_MEAN_STD: "mean", _abi.NET_SELECT_T: "select_t", _abi.NET_BOTTLENECK: "bottleneck", _abi.NET_BOTTLENECK_S: "bottleneck"}
         out = []
         for d, t in zip(descs, ms):
             k = d["k"][0] * d["k"][1] * d["k"][2] * d["src"][4]

@@ -108,7 +108,7 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     m = m.cuda().eval()
     x = torch.from_numpy(synth.synth_clip(77, 16, 96, 64, batch=3)).cuda()
-    M.FUSE_FAST = M.STEM_POOL = False          # the layer-by-layer sequencing has one launch per conv / pool: compare like with like
+    M.FUSE_FAST = M.FUSE_SLOW = M.STEM_POOL = False          # the layer-by-layer sequencing has one launch per conv / pool: compare like with like
     try:
         with torch.no_grad():
             s1, f1 = m(M.pack_pathway_output(x))
@@ -119,7 +119,7 @@ def test_one_call_network_equals_layer_by_layer_sequencing():
             finally:
                 M.CONVNET = True
     finally:
-        M.FUSE_FAST = M.STEM_POOL = True
+        M.FUSE_FAST = M.FUSE_SLOW = M.STEM_POOL = True
     assert m.__dict__.get("_nets"), "the one-call path did not run"
     assert torch.equal(s1, s1b) and torch.equal(f1, f1b)
     assert torch.equal(s1, s0) and torch.equal(f1, f0)
@@ -193,8 +193,45 @@ def test_fast_bottleneck_kernel_vs_fp32_convs(cin, ci, cout, proj, stride, half)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("half", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dims,out_c", [((2, 3, 17, 30), 256), ((1, 2, 56, 56), 320), ((1, 1, 14, 14), 256)])
+def test_slow_bottleneck_kernel_vs_fp32_convs(dims, out_c, half):
+    """``kvq_slow_bottleneck`` (conv_a 1x1x1 -> conv_b 1x3x3 -> conv_c 1x1x1 + identity, one launch; 256 -> 64 -> 256) against torch
+    conv3d in fp32 with the same 16-bit rounding of the two inner activations: maps that are not multiples of the 14 x 14 tile,
+    spatial borders, an output row wider than the block's channels (the stage's last block writes into the lateral-concat tensor: the
+    other channels stay untouched); other channel counts are refused."""
+    import torch.nn.functional as F
+    from kvq_amd import kernels
+    from kvq_amd.models.backbones.slowfast_model import pack_slow_bottleneck
+    cin, ci, cout = 256, 64, 256
+    g = torch.Generator().manual_seed(sum(dims) + out_c)
+    B, T, H, W = dims
+    x = torch.randn(B, T, H, W, cin, generator=g).to(half)
+
+    def wgt(rows, k):
+        return (torch.randn(rows, k, generator=g) * (2.0 / k) ** 0.5).to(half)
+    wa, wb, wc = wgt(ci, cin), wgt(ci, 9 * ci), wgt(cout, ci)
+    ba, bb, bc = (torch.randn(n, generator=g) * 0.2 for n in (ci, ci, cout))
+    xf = x.float().permute(0, 4, 1, 2, 3)
+    a = F.relu(F.conv3d(xf, wa.float().reshape(ci, cin, 1, 1, 1), ba)).to(half).float()
+    b = F.relu(F.conv3d(a, wb.float().reshape(ci, 1, 3, 3, ci).permute(0, 4, 1, 2, 3), bb, padding=(0, 1, 1))).to(half).float()
+    ref = F.relu(F.conv3d(b, wc.float().reshape(cout, ci, 1, 1, 1), bc) + xf).permute(0, 2, 3, 4, 1)
+    pack = pack_slow_bottleneck(wa.cuda(), ba.cuda(), wb.cuda(), bb.cuda(), wc.cuda(), bc.cuda())
+    out = torch.full((B, T, H, W, out_c), 3.0, dtype=half, device="cuda")
+    got = kernels.slow_bottleneck(x.cuda(), pack, ci, cout, out=out)
+    assert (got[..., cout:] == 3.0).all()
+    got = got[..., :cout].float().cpu()
+    tol = 2e-2 if half == torch.bfloat16 else 3e-3
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+    assert (got - ref).norm().item() / ref.norm().item() < tol / 4
+    with pytest.raises(AssertionError):
+        kernels.slow_bottleneck(x.cuda(), pack, ci + 8, cout)
+
+
+@pytest.mark.gpu
 def test_fused_fast_pathway_blocks_match_the_conv_by_conv_plan():
-    """The network with the fast pathway's residual blocks fused (default) against the same plan with one launch per conv: the
+    """The network with the fast pathway's residual blocks and the slow pathway's res2 identity blocks fused (default) against the same plan with one launch per conv: the
     same rounding points, so the pooled features agree to accumulation-order noise; the fused plan is the one the oracle parity
     tests above exercise."""
     import kvq_amd.models.backbones.slowfast_model as M
@@ -203,7 +240,7 @@ def test_fused_fast_pathway_blocks_match_the_conv_by_conv_plan():
     x = torch.from_numpy(synth.synth_clip(91, 16, 96, 64, batch=2)).cuda()
     outs = []
     for fuse in (True, False):
-        M.FUSE_FAST = fuse
+        M.FUSE_FAST = M.FUSE_SLOW = fuse
         try:
             m = M.slowfast()
             m.head_small_grid = "mean"          # reduced-size clip: final grid under the head's (8,7,7) kernel
@@ -213,8 +250,9 @@ def test_fused_fast_pathway_blocks_match_the_conv_by_conv_plan():
                 outs.append(m.forward_clips(x))
             rows = m.profile_layers(x)
             assert any(r["kind"] == "bottleneck" for r in rows) == fuse
+            assert any("0.res_blocks.1 (fused" in r["name"] for r in rows) == fuse          # a slow-pathway res2 identity block
         finally:
-            M.FUSE_FAST = True
+            M.FUSE_FAST = M.FUSE_SLOW = True
     for a, b in zip(*outs):
         assert (a - b).norm().item() / b.norm().item() < 1e-3
 
