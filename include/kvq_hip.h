@@ -543,6 +543,7 @@ int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const uint16_t* w
  * pathway): frames t_index[0 .. n_frames) (device int32; NULL = frames 0 .. n_frames-1) of the fp32 clip x (B,3,T,H,W) ->
  * Conv3d(3, 64, (1,7,7), stride (1,2,2), padding (0,3,3)) + folded BatchNorm [+ ReLU] + MaxPool3d((1,3,3), (1,2,2), (0,1,1)).
  * wimg 16-bit [7][64][32], entry [kh][o][kw*4 + c] = w[o][c][0][kh][kw] (kw 7 and c 3 zero); bias64 fp32 [64]; W % 4 == 0, W <= 224.
+ * t_index lives on the device: its entries must be in [0, T) (the library cannot check them; kvq_convnet_create does for its plans).
  * out 16-bit channels-last (B, n_frames, Hp, Wp, out_C): channels out_coff .. out_coff + 63 are written (out_C, out_coff % 8 == 0). */
 int kvq_conv_stem64_pool(const float* x, const int32_t dims5[5], const int32_t* t_index, int n_frames, const uint16_t* wimg,
                          const float* bias64, int relu, int dtype, uint16_t* out, int out_C, int out_coff, void* stream);

@@ -389,7 +389,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         # stems: slow 3 -> 64 (1x7x7), fast 3 -> 8 (5x7x7), each followed by the (1,3,3) max-pool
         wt, bias, k, st, pd = Wt[fe + "0.multipathway_blocks.0"]
         slow = tensor(B, T // 4, Hp, Wp, 64 + 2 * FAST_C[0])
-        if STEM_POOL and tuple(k) == (1, 7, 7) and tuple(st) == (1, 2, 2) and tuple(pd) == (0, 3, 3) and wt.shape[0] == 64 and W <= 224:
+        if STEM_POOL and tuple(k) == (1, 7, 7) and tuple(st) == (1, 2, 2) and tuple(pd) == (0, 3, 3) and wt.shape[0] == 64 and W <= 224 and W % 4 == 0:
             # frame selection + stem + max-pool in one launch straight from the fp32 clip (no slow clip, no 64-channel stem map in HBM)
             wimg = kernels.stem64_pack_weight(wt, wt.dtype)
             keep.append(wimg)
@@ -407,7 +407,7 @@ class slowfast(nn.Module):  # noqa: N801  (reference spelling)
         _, fbias, fk, fst, fpd = Wt[fe + "0.multipathway_blocks.1"]
         lane[0] = FAST_LANE
         fast = tensor(B, T, Hp, Wp, 8)
-        if STEM_POOL and tuple(fk[1:]) == (7, 7) and tuple(fst) == (1, 2, 2) and tuple(fpd) == (fk[0] // 2, 3, 3) and W <= 256:
+        if STEM_POOL and tuple(fk[1:]) == (7, 7) and tuple(fst) == (1, 2, 2) and tuple(fpd) == (fk[0] // 2, 3, 3) and W <= 256 and W % 4 == 0:
             # stem + max-pool in one launch straight from the fp32 clip: neither the packed clip nor the stem map touches HBM
             op(_abi.NET_STEM_POOL, fast_in, fast, fk, fst, fpd, cout=8, relu=1, w=Wt[fe + "0.multipathway_blocks.1/mfma"], bias=fbias)
         else:
