@@ -35,6 +35,49 @@ def test_architecture_invariants():
     assert s.shape == (1, 2048, 1, 1, 1) and f.shape == (1, 256, 1, 1, 1)
 
 
+def test_weight_images_of_the_fused_stems_and_blocks_on_the_host():
+    """The packed weight images handed to the fused SlowFast launches, checked entry by entry on the host (no GPU): the slow stem's
+    [7][64][32] image (``kvq_conv_stem64_pool``), the fast stem's [kd*7][16][32] image (``kvq_conv_stem_pool`` / ``kvq_conv_stem_mfma``),
+    and the MFMA A-fragment layout + bias block of the slow pathway's fused res2 block (``kvq_slow_bottleneck``): fragment f of row tile
+    t holds, for lane (m = lane & 31, h = lane >> 5), the eight weights W[32 t + m][k(f, h, e)]."""
+    from kvq_amd import kernels, _abi
+    from kvq_amd.models.backbones.slowfast_model import pack_slow_bottleneck
+    g = torch.Generator().manual_seed(5)
+    w5 = torch.randn(64, 3, 1, 7, 7, generator=g)
+    img = kernels.stem64_pack_weight(w5.permute(0, 2, 3, 4, 1).reshape(64, 147).contiguous(), torch.float16).float()
+    assert tuple(img.shape) == (7, 64, 32)
+    for kh, o, kw, c in ((0, 0, 0, 0), (3, 17, 6, 2), (6, 63, 4, 1)):
+        assert img[kh, o, kw * 4 + c] == w5[o, c, 0, kh, kw].half().float()
+    assert (img.reshape(7, 64, 8, 4)[:, :, 7, :] == 0).all() and (img.reshape(7, 64, 8, 4)[:, :, :, 3] == 0).all()
+    wf = torch.randn(8, 3, 5, 7, 7, generator=g)
+    imf = kernels.stem_mfma_pack_weight(wf.permute(2, 3, 4, 1, 0).reshape(735, 8).contiguous(), (5, 7, 7), 3, torch.float16).float()
+    assert tuple(imf.shape) == (35, 16, 32) and (imf[:, 8:] == 0).all()
+    for a, r, o, kw, c in ((0, 0, 0, 0, 0), (4, 6, 7, 6, 2), (2, 3, 5, 1, 1)):
+        assert imf[a * 7 + r, o, kw * 4 + c] == wf[o, c, a, r, kw].half().float()
+    wa, wb, wc = torch.randn(64, 256, generator=g).half(), torch.randn(64, 576, generator=g).half(), torch.randn(256, 64, generator=g).half()
+    ba, bb, bc = torch.randn(64, generator=g), torch.randn(64, generator=g), torch.randn(256, generator=g)
+    blob = pack_slow_bottleneck(wa, ba, wb, bb, wc, bc)
+    assert blob.numel() == _abi.lib().kvq_slow_bottleneck_pack_bytes(256, 64, 256) == (32 + 72 + 32 + 2) * 1024
+    assert _abi.lib().kvq_slow_bottleneck_pack_bytes(512, 128, 512) == 0
+    frag = blob[: (32 + 72 + 32) * 1024].view(torch.float16).reshape(-1, 64, 8).float()          # [fragment][lane][e]
+
+    def entry(base, ks, t, f, lane, e, acc_order=False):
+        m, h = lane & 31, lane >> 5
+        k = 16 * f + (8 * (e >> 2) + 4 * h + (e & 3) if acc_order else 8 * h + e)
+        return frag[base + t * ks + f, lane, e], 32 * t + m, k
+    for t, f, lane, e in ((0, 0, 0, 0), (1, 15, 63, 7), (1, 7, 37, 3)):
+        v, row, k = entry(0, 16, t, f, lane, e)
+        assert v == wa[row, k].float()
+    for t, f, lane, e in ((0, 0, 1, 1), (1, 35, 40, 6)):
+        v, row, k = entry(32, 36, t, f, lane, e)
+        assert v == wb[row, k].float()
+    for t, f, lane, e in ((0, 0, 2, 5), (7, 3, 62, 2)):
+        v, row, k = entry(32 + 72, 4, t, f, lane, e, acc_order=True)
+        assert v == wc[row, k].float()
+    bias = blob[(32 + 72 + 32) * 1024:].view(torch.float32)
+    assert torch.equal(bias[:64], ba) and torch.equal(bias[64:128], bb) and torch.equal(bias[128:384], bc) and (bias[384:] == 0).all()
+
+
 def test_clip_assembly_vs_reference_golden(golden):
     """``clip_frame_indices`` against the frame indices the reference's own ``VideoDataset_NR_SlowFast_feature.__getitem__``
     (SlowFast_features.py:52-107) produced over a fake capture (tests/golden/make_golden.py::sec_sfclips): per-second 32-frame
