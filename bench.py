@@ -507,17 +507,32 @@ def run_probe(args):
     torch.cuda.synchronize()
 
 
+def relaunch_ranks(args):
+    """``python bench.py --gpus N`` without a rank environment: become ``torch.distributed.run`` with N ranks on this node (one per
+    GPU, RCCL over xGMI) — a single process must never report itself as an N-GPU run (nor silently fall back to one GPU)."""
+    port = os.environ.get("MASTER_PORT") or str(20000 + (os.getpid() * 7919) % 20000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
     if args.probe:
         return run_probe(args)
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_ranks(args)
     import torch
     import kvq_amd  # noqa: F401
     from kvq_amd import _abi, dist as kd
     from kvq_amd.utils import synth
 
     rank, local_rank, world = kd.init()
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # KVQ_BENCH_ONE_GPU=1 (tests): all ranks share cuda:0 so the N>1 code path can run on a 1-GPU box
     device = torch.device("cuda", 0 if os.environ.get("KVQ_BENCH_ONE_GPU") else local_rank)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 25
+#define KVQ_ABI_VERSION 26
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -380,6 +380,23 @@ typedef struct {
   float q_scale;
 } KvqAttnDenseArgs;
 int kvq_window_attention_dense_args(const KvqAttnDenseArgs* host_args, void* stream);
+
+/* The STREAMING form of the same attention (csrc/attn32.hip; replaces swin_backbone.py:261-322 like the two above): 32 x 32 score
+ * blocks on v_mfma_f32_32x32x16, the bias widened / scaled / shifted by the row's running maximum in one v_fma_mix_f32 per score
+ * (flash-attention running maximum with a deferred rescale, threshold 2^8), persistent workgroups (one per CU) whose loader wave
+ * streams K | V of the (window, head) units into a three-slot LDS ring ahead of eight consumer waves that pull (unit, 32-query
+ * block) items from a ticket.  Differences to kvq_window_attention_dense_args:
+ *   - q must arrive scaled by head_dim^-0.5 * log2(e) (scores are kept in log2 units; the bias image stays in natural units);
+ *   - the image comes from kvq_attn_bias_stream_build: [n_types][nH][ceil(N/32)][13][2][64 lanes][8] fp16 + one 2 KB pad block —
+ *     register r = 8 half + e of lane (q = lane & 31, hi = lane >> 5) is key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi, 16-byte aligned;
+ *   - no fused qkv projection (x_ln must be NULL); tile_skip and dsplit_from mean what they mean above (a q-block of 32 rows is
+ *     passed over when both its 16-row tiles are padding only; depth-split windows skip the other half's 32-key blocks).
+ * Results agree with the dense kernel to the 16-bit rounding of the probabilities (the normaliser is the sum of the ROUNDED
+ * probabilities in both), not bit for bit. */
+size_t kvq_attn_bias_stream_bytes(int n_types, int N, int num_heads);
+int kvq_attn_bias_stream_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
+                               int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
+int kvq_window_attention_stream(const KvqAttnDenseArgs* host_args, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

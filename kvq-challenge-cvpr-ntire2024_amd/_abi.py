@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 def dtype_code(dt) -> int:
@@ -186,6 +186,9 @@ SYMBOLS = {
     "kvq_window_attention_dense": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_window_attention_dense_skip": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
     "kvq_window_attention_dense_args": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
+    "kvq_attn_bias_stream_bytes": (sz, [i32, i32, i32]),
+    "kvq_attn_bias_stream_build": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
+    "kvq_window_attention_stream": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
     "kvq_swin3d_bias_dense_bytes": (sz, [p_void, i32]),
     "kvq_swin3d_bias_dense_build": (i32, [p_void, i32, p_void, p_void, p_void, p_void, p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),

@@ -1,0 +1,599 @@
+// Streaming window attention for head_dim 32 on gfx950: 32 x 32 score blocks, running row maximum, persistent workgroups.
+//
+// Replaces WindowAttention3D.forward's core (swin_backbone.py:261-322) with the bias PRE-BUILT per (window type, head) as in attn.hip's
+// dense variant, restructured around what bounds it — per-score VALU issue (attn.hip spends 5.7 VALU slots per score and lane):
+//   * S^T = K Q^T on v_mfma_f32_32x32x16 (two k-steps of 16 = head_dim 32): a lane holds 16 keys of ONE query (lane & 31) per
+//     32-key block, half the matrix-pipe issue time per flop of the 16 x 16 form and a quarter of its LDS fragment reads;
+//   * the bias tile is widened, scaled by log2(e) and shifted by the row's RUNNING maximum in one v_fma_mix_f32 per score — it is the
+//     MFMA's C operand, so the accumulator comes out as the exponent argument: no subtract, no separate conversion.  q arrives
+//     pre-scaled by head_dim^-0.5 * log2(e) (the qkv GEMM's epilogue scale), so S is in log2 units;
+//   * the running maximum is the flash-attention scheme with a deferred rescale: a block whose scores stay within 2^THR of the
+//     current maximum is exponentiated as it is (P <= 2^THR, fp16 / bf16 hold that at full relative precision; the normaliser is the
+//     sum of the ROUNDED probabilities, so the scale cancels exactly); only a growth past THR — or the row's first block — takes
+//     the rescale path (O, l, the pending score accumulators all move by the same 2^-d).  Masked scores (-100) and padding keys
+//     (-60000) leave the exponential as zeros whatever the maximum;
+//   * row sums by v_dot2c on the packed probabilities (one VALU per two scores), P V as O^T = V^T P^T with the packed P registers
+//     as the B operand and V through the hardware transpose read (row-major V in LDS = a plain copy of the global rows);
+//   * the q-block loop is software-pipelined inside the wave: the score MFMAs of block t+1 and the P V MFMAs of block t-1 are in the
+//     matrix pipe while the VALU runs max / exp / pack of block t.
+// Work distribution: one PERSISTENT workgroup per CU (8 consumer waves + 1 loader wave).  The loader streams K | V of the
+// workgroup's (window, head) entries into a two-slot LDS ring by LDS-DMA, one entry ahead of the consumers, so no launch ever has
+// every workgroup in its prologue at once (stages 1-3 of the trunk are ONE round of workgroups in attn.hip's form); consumers pull
+// (entry, 32-query block) items from an LDS ticket, so the 13 q-blocks of a window never quantise over a fixed wave count.  XCDs
+// take whole (window type, head) pairs: the clips that share a bias image run on one L2 at the same time.
+#include "common.hpp"
+
+#if (A32_ABL & 2)      // diagnostic builds (A32_ABL bit mask): 2 = no exponentials
+#define A32_EXP(x) ((x) * 0.001f + 1.0f)
+#else
+#define A32_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
+
+namespace kvq {
+
+constexpr int A32_KB = 13;                         // 32-key blocks: 416 key positions (N <= 400 supported, 392 used)
+constexpr int A32_ROWS = 400;                      // key rows a slot holds; rows 400..415 of the 13th block are read from the zero block
+constexpr int A32_K_BYTES = A32_ROWS * 64;         // 25 600: K rows (XOR-swizzled 16-B chunks), then as many of V (row-major)
+constexpr int A32_SLOT = 2 * A32_K_BYTES;
+constexpr int A32_NSLOT = 3;                       // the loader runs up to two entries ahead of the consumers
+constexpr int A32_OFF_ZERO = A32_NSLOT * A32_SLOT; // 1 KB of zeros
+constexpr int A32_OFF_CTL = A32_OFF_ZERO + 1024;   // control words: [0] ticket, [1..3] items done per slot, [4..6] entry landed per slot
+constexpr int A32_OFF_TAB = A32_OFF_CTL + 64;      // entry table: 32 B per entry
+constexpr int A32_MAX_ENTRIES = 128;               // per workgroup and launch
+constexpr int A32_LDS = A32_OFF_TAB + A32_MAX_ENTRIES * 32;
+#ifndef A32_ABL
+#define A32_ABL 0
+#endif
+#ifndef A32_SUM
+#define A32_SUM 0
+#endif
+#ifndef A32_BR
+#define A32_BR 0
+#endif
+#ifndef A32_CW_DEFAULT
+#define A32_CW_DEFAULT 8
+#endif
+constexpr int A32_CW = A32_CW_DEFAULT;             // consumer waves
+constexpr int A32_THREADS = (A32_CW + 1) * 64;
+constexpr float A32_THR = 8.0f;                    // log2 units: a block is exponentiated against a maximum at most 2^8 too small
+constexpr float A32_OFF = -60000.0f;               // padding keys (as attn.hip's ATT_DENSE_OFF)
+
+typedef __attribute__((ext_vector_type(4))) short a32_s4;
+typedef __attribute__((address_space(3))) a32_s4* a32_tr_t;
+typedef __attribute__((address_space(3))) void* a32_lds_t;
+
+typedef __attribute__((address_space(1))) const void* a32_gbl_t;
+
+struct Attn32Params {
+  const uint16_t* qkv;         // [3][nH][BW*N][32], q pre-scaled by head_dim^-0.5 * log2(e)
+  const u32x4* image;          // [n_types*nH][NQB][13][2][64 lanes] x 16 B (kvq_attn_bias_stream_build)
+  int BW, nW, N, nH, n_types, qsplit;
+  uint16_t* out;               // [BW*N][nH*32]
+  const uint32_t* tile_skip;   // optional [nW]: bit t = rows 16t..16t+15 of the window are padding only
+  int dsplit_from;             // >= 0: windows >= it are depth-split at token 196 of 392
+  int wg_per_xcd;
+  unsigned n_max_magic;        // ceil(2^32 / items per entry): ticket -> entry by one multiply (0: one item per entry)
+  unsigned long long* trace;   // -DKVQ_A32_TRACE builds: per consumer wave {life, fetch, ready wait, q-blocks, items}
+};
+
+// A 32-query block keeps a row in lanes q and q + 32: v_permlane32_swap hands each half the other's value without an LDS round
+// trip (new vdst = {own low half, partner's low half}, new vsrc = {partner's high half, own high half}: every lane sees both values)
+__device__ __forceinline__ float a32_pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float a32_pair_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// one entry = one (window, head, clip, q-part): K | V staged once, n_max q-block items
+struct A32Entry { int pair, h, bw, w, q_lo, q_hi; };
+
+__device__ __forceinline__ A32Entry a32_decode(const Attn32Params& p, int xcd, int j, int nqb) {
+  const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, per_pair = nclip * nrep * p.qsplit;
+  const int pi = j / per_pair, sub = j - pi * per_pair;
+  A32Entry e;
+  e.pair = pi * 8 + xcd;
+  const int wt = e.pair / p.nH;
+  e.h = e.pair - wt * p.nH;
+  const int clip = sub % nclip, rep = (sub / nclip) % nrep, part = sub / (nclip * nrep);
+  e.w = rep * p.n_types + wt;
+  e.bw = clip * p.nW + e.w;
+  e.q_lo = part * nqb / p.qsplit;
+  e.q_hi = (part + 1) * nqb / p.qsplit;
+  return e;
+}
+
+// One 32-query block against the key blocks [T0, T1) of the ring slot at `slot`.  Compile-time range: the score / probability /
+// bias registers rotate through statically indexed sets.
+template <typename E, int T0, int T1>
+__device__ __forceinline__ void a32_qblock(const Attn32Params& p, const unsigned char* slot, const int zero, const u32x4* bd, const typename E::v8 qf0,
+                                           const typename E::v8 qf1, const u32x4 (&pre)[2], uint16_t* orow, const bool store) {
+  using V8 = typename E::v8;
+  static_assert(T0 >= 0 && T0 < T1 && T1 <= A32_KB, "key block range");
+  const int lane = threadIdx.x & 63, q = lane & 31, hi = lane >> 5;
+  const float kLog2e = 1.4426950408889634f;
+  const int sw = (q >> 2) & 3;
+  const u32x4* Ks = reinterpret_cast<const u32x4*>(slot);
+  const int ka0 = q * 4 + (hi ^ sw), ka1 = q * 4 + ((2 + hi) ^ sw);          // + 128 per key block
+  // the 13th block: rows 384..399 of the slot, then the zero block (`zero` = its offset from the slot, in 16-B units)
+  const int kz0 = q < 16 ? ka0 + (A32_KB - 1) * 128 : zero + (q - 16) * 4 + (hi ^ sw), kz1 = q < 16 ? ka1 + (A32_KB - 1) * 128 : zero + (q - 16) * 4 + ((2 + hi) ^ sw);
+  const a32_tr_t vtr = (a32_tr_t)(slot + A32_K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+  const uint32_t one2 = (uint32_t)E::cvt(1.0f) * 0x10001u;
+
+  u32x4 braw[3][2];
+  auto load_bias = [&](int t) __attribute__((always_inline)) {
+#if (A32_ABL & 1)     // diagnostic: no bias stream (one tile, loaded once per q-block)
+    if (t != T0) { braw[t % 3][0] = braw[T0 % 3][0]; braw[t % 3][1] = braw[T0 % 3][1]; return; }
+#endif
+    braw[t % 3][0] = bd[t * 128];
+    braw[t % 3][1] = bd[t * 128 + 64];
+  };
+  // C operand of block t: bias * log2(e) - m, straight from the packed fp16 pairs (v_fma_mix_f32)
+  auto mix = [&](int t, float nm) __attribute__((always_inline)) -> f32x16 {
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t u = braw[t % 3][r >> 3][(r & 7) >> 1];
+      const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((r & 1) ? (u >> 16) : (u & 0xffffu)));
+      c[r] = (A32_ABL & 32) ? nm : __builtin_fmaf((float)hv, kLog2e, nm);
+    }
+    return c;
+  };
+  auto kfrag = [&](int t, int m) __attribute__((always_inline)) -> V8 {
+    if (t == A32_KB - 1) return __builtin_bit_cast(V8, Ks[(m ? kz1 : kz0)]);          // key rows 400..415 come from the zero block
+    return __builtin_bit_cast(V8, Ks[(m ? ka1 : ka0) + ((A32_ABL & 16) ? 0 : t) * 128]);
+  };
+
+  f32x16 S[2];
+  uint32_t P[2][8];
+  a32_s4 vf[2][4];                                                            // V fragments of block t: read during block t, used by P V one block later
+  f32x16 O;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) O[r] = 0.f;
+  float ls = 0.f, ls1 = 0.f, nm = 0.f;                                        // nm = -(running maximum), log2 units
+
+  braw[T0 % 3][0] = pre[0]; braw[T0 % 3][1] = pre[1];        // block T0: requested while the previous q-block was computed
+  if (T0 + 1 < T1) load_bias(T0 + 1);
+  {
+    const V8 k0 = kfrag(T0, 0), k1 = kfrag(T0, 1);
+    const f32x16 c = mix(T0, 0.f);
+    S[T0 & 1] = E::mfma32(k0, qf0, c);
+    S[T0 & 1] = E::mfma32(k1, qf1, S[T0 & 1]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = T0; t <= T1; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    // ---- requests first: K fragments of block t+1, V fragments of block t, the bias of block t+2 ----
+    V8 kn0, kn1;
+    if (t + 1 < T1) { kn0 = kfrag(t + 1, 0); kn1 = kfrag(t + 1, 1); }
+    if (t < T1 && !((A32_ABL & 16) && t > T0)) {
+      vf[cur][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + t * 256);
+      vf[cur][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + t * 256 + 64);
+      if (t != A32_KB - 1) {                             // keys 400..415 are padding whatever N <= 400 is: their probabilities are zeros
+        vf[cur][2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + t * 256 + 128);
+        vf[cur][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + t * 256 + 192);
+      }
+    }
+    if (t + 2 < T1) load_bias(t + 2);
+    // ---- P V of block t-1 in the matrix pipe under the row maximum of block t (two new scores per v_max3_f32) ----
+    float mx = 0.f;
+    if (t > T0 && !(A32_ABL & 4))
+      O = E::mfma32(__builtin_bit_cast(V8, __builtin_shufflevector(vf[(A32_ABL & 16) ? (T0 & 1) : nxt][0], vf[(A32_ABL & 16) ? (T0 & 1) : nxt][1], 0, 1, 2, 3, 4, 5, 6, 7)),
+                    __builtin_bit_cast(V8, (u32x4){P[nxt][0], P[nxt][1], P[nxt][2], P[nxt][3]}), O);
+    if (t < T1) {
+      mx = fmaxf(fmaxf(S[cur][0], S[cur][1]), S[cur][2]);
+#pragma unroll
+      for (int r = 3; r < ((A32_ABL & 128) ? 4 : 15); r += 2) mx = fmaxf(fmaxf(mx, S[cur][r]), S[cur][r + 1]);
+      mx = fmaxf(mx, S[cur][15]);
+    }
+    if (t > T0 && t - 1 != A32_KB - 1 && !(A32_ABL & 4))
+      O = E::mfma32(__builtin_bit_cast(V8, __builtin_shufflevector(vf[(A32_ABL & 16) ? (T0 & 1) : nxt][2], vf[(A32_ABL & 16) ? (T0 & 1) : nxt][3], 0, 1, 2, 3, 4, 5, 6, 7)),
+                    __builtin_bit_cast(V8, (u32x4){P[nxt][4], P[nxt][5], P[nxt][6], P[nxt][7]}), O);
+    if (t == T1) break;
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#if A32_BR == 1
+    // the comparison is issued here, the branch on its (scalar) result only after the C operand of block t+1 has been built:
+    // the VALU -> SGPR -> branch latency is covered by 16 independent instructions
+    const unsigned long long grow = (A32_ABL & 8) ? 0ull : __builtin_amdgcn_ballot_w64(mx > A32_THR);
+    f32x16 cn;
+    if (t + 1 < T1) cn = mix(t + 1, nm);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t == T0 || grow != 0) {
+      const float mr = a32_pair_max(mx);
+      const float d = (t == T0 || mr > A32_THR) ? mr : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[cur][r] -= d;
+      if (t + 1 < T1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cn[r] -= d;
+      }
+      if (t != T0) {
+        const float f = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] *= f;
+        ls *= f;
+        ls1 *= f;
+      }
+      nm -= d;
+    }
+    if (t + 1 < T1) S[nxt] = E::mfma32(kn0, qf0, cn);
+#else
+    if (t == T0 || (!(A32_ABL & 8) && __builtin_amdgcn_ballot_w64(mx > A32_THR) != 0)) {
+      // rescale path: the row's first block (exact maximum) or a growth past THR.  Everything still at the old maximum moves by
+      // the same 2^-d: O and l (they hold blocks .. t-1 completely) and the scores of block t; block t+1's C operand is built below
+      const float mr = a32_pair_max(mx);                            // the row lives in lanes q and q + 32
+      const float d = (t == T0 || mr > A32_THR) ? mr : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[cur][r] -= d;
+      if (t != T0) {                       // the first block: O = l = 0, and 2^-d may be infinite (a masked row start)
+        const float f = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] *= f;
+        ls *= f;
+        ls1 *= f;
+      }
+      nm -= d;
+    }
+    // ---- the score block t+1 in the matrix pipe under exp / pack / row sum of block t ----
+    if (t + 1 < T1) {
+      const f32x16 cn = mix(t + 1, nm);
+      S[nxt] = E::mfma32(kn0, qf0, cn);
+    }
+#endif
+#if A32_SUM == 1
+    {
+      float ex[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ex[r] = A32_EXP(S[cur][r]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P[cur][i] = E::pack2_raw(ex[2 * i], ex[2 * i + 1]);
+      if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
+#pragma unroll
+      for (int i = 4; i < 8; ++i) P[cur][i] = E::pack2_raw(ex[2 * i], ex[2 * i + 1]);
+      f32x2 a2 = {ls, ls1};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a2 += (f32x2){ex[2 * i], ex[2 * i + 1]};
+      ls = a2[0]; ls1 = a2[1];
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) P[cur][i] = E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1]));
+    if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
+#pragma unroll
+    for (int i = 4; i < 8; ++i) P[cur][i] = E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1]));
+#pragma unroll
+    for (int i = 0; i < ((A32_ABL & 64) ? 1 : 8); i += 2) {          // two chains: v_dot2c accumulates in place
+      ls = E::dot2(P[cur][i], one2, ls);
+      ls1 = E::dot2(P[cur][i + 1], one2, ls1);
+    }
+#endif
+    if (t + 1 < T1) {
+      __builtin_amdgcn_sched_group_barrier(0x002, A32_BR == 1 ? 1 : 16, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x002, 12, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- normalise + store: lane (query q, half hi) holds features 8j + 4hi .. +3, j = 0..3 ----
+  ls += ls1;
+  ls = a32_pair_sum(ls);
+  if (store) {
+    const float inv = __builtin_amdgcn_rcpf(ls);        // >= 2^-THR-ish and finite: the row maximum contributes >= 2^-THR
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<u32x2*>(orow + 8 * j + 4 * hi) =
+          (u32x2){E::pack2(O[4 * j] * inv, O[4 * j + 1] * inv), E::pack2(O[4 * j + 2] * inv, O[4 * j + 3] * inv)};
+  }
+}
+
+template <typename E, bool DSPLIT>
+__global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(Attn32Params p) {
+  fp16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* ctl = reinterpret_cast<int*>(smem + A32_OFF_CTL);       // [0] ticket, [1..2] items done per slot, [3..4] entry landed per slot
+  int4* etab = reinterpret_cast<int4*>(smem + A32_OFF_TAB);    // per entry: {pair, h, bw, w}, {q_lo, q_hi, -, -}
+  using V8 = typename E::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, nqb = (N + 31) >> 5;
+  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int npair = p.n_types * p.nH, nclip = p.BW / p.nW, per_pair = nclip * (p.nW / p.n_types) * p.qsplit;
+  const int e_x = ((npair - xcd + 7) >> 3) * per_pair;          // entries of this XCD
+  const int e_wg = s < e_x ? (e_x - s + p.wg_per_xcd - 1) / p.wg_per_xcd : 0;
+  const int n_max = (nqb + p.qsplit - 1) / p.qsplit;            // items per entry (parts one q-block short pad with empty items)
+  if (e_wg == 0) return;
+  const size_t Mtot = (size_t)p.BW * N;
+
+  // the zero block (key rows 400..415 of the 13th block); rows N..399 of a slot are zero-filled by the DMA itself (loader)
+  if (tid < 64) *reinterpret_cast<u32x4*>(smem + A32_OFF_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  // the entry table (the integer divisions of the decode, once per entry instead of per item and wave)
+  for (int e = tid; e < e_wg; e += A32_THREADS) {
+    const A32Entry en = a32_decode(p, xcd, s + e * p.wg_per_xcd, nqb);
+    etab[2 * e] = make_int4(en.pair, en.h, en.bw, en.w);
+    etab[2 * e + 1] = make_int4(en.q_lo, en.q_hi, p.tile_skip ? (int)p.tile_skip[en.w] : 0, 0);
+  }
+  if (tid < 1 + 2 * A32_NSLOT) ctl[tid] = tid < 1 + A32_NSLOT ? 0 : -1;
+  __syncthreads();
+
+#ifdef KVQ_A32_TRACE
+  const unsigned long long tr_k0 = __builtin_readcyclecounter();
+#endif
+  if (wave == A32_CW) {
+    // ---------------- loader: entry e into slot e % 3 once entry e - 3 has been consumed; entry e's requests are issued before
+    // entry e - 1's landing is waited for (counted vmcnt), so the stream never drains between entries ----------------
+    // Buffer-resource LDS-DMA: the per-lane byte offset is a constant, the row block the scalar offset — no VALU and no branch
+    // on the issue path — and rows past N read zeros (so the slot's rows N..399 are rewritten as zeros by every fill).  K lands
+    // with its 16-B chunks XOR-swizzled by (row >> 2) & 3, V as a plain copy.  Top priority: two VALU-bound consumer waves share
+    // this wave's SIMD and would otherwise leave it one issue slot in a dozen (18 k cycles per fill measured).
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned vo_k = (unsigned)(lane >> 2) * 64u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u, vo_v = (unsigned)lane * 16u;
+    for (int e = 0; e < e_wg; ++e) {
+      const int b = e % A32_NSLOT;
+      if (e >= A32_NSLOT) {
+        const int target = n_max * (e / A32_NSLOT);
+        while (__hip_atomic_load(&ctl[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(4);
+        asm volatile("" ::: "memory");
+      }
+      const int4 e0 = etab[2 * e];
+      const int eh = __builtin_amdgcn_readfirstlane(e0.y), ebw = __builtin_amdgcn_readfirstlane(e0.z);
+      const uint16_t* Kg = p.qkv + ((size_t)(1 * p.nH + eh) * Mtot + (size_t)ebw * N) * 32;
+      const uint16_t* Vg = p.qkv + ((size_t)(2 * p.nH + eh) * Mtot + (size_t)ebw * N) * 32;
+      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Kg), 0, N * 64, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Vg), 0, N * 64, 0x00020000);
+      unsigned char* dst = smem + b * A32_SLOT;
+#pragma unroll
+      for (int it = 0; it < A32_ROWS / 16; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (a32_lds_t)(dst + it * 1024), 16, vo_k, it * 1024, 0, 0);
+#pragma unroll
+      for (int it = 0; it < A32_ROWS / 16; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (a32_lds_t)(dst + A32_K_BYTES + it * 1024), 16, vo_v, it * 1024, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&ctl[1 + A32_NSLOT + b], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef KVQ_A32_TRACE
+      if (p.trace && lane == 0 && e < 8) p.trace[((size_t)blockIdx.x * (A32_CW + 1) + A32_CW) * 8 + e] = __builtin_readcyclecounter() - tr_k0;
+#endif
+    }
+    return;
+  }
+
+  // ---------------- consumers ----------------
+  // An item = (entry, q-block).  The NEXT item's ticket, q fragments and first two bias tiles are requested before the current
+  // item is computed: none of them sits on the critical path of an item's first MFMA.  Two item records alternate (no copies: a
+  // register move of loaded values would make the compiler drain the whole memory queue, the output stores included).
+  struct Item {
+    int e, qb, t0, w;
+    bool live, store;
+    const u32x4* bd;
+    uint16_t* orow;
+    V8 qf0, qf1;
+    u32x4 pre[2];
+  };
+  const int q = lane & 31, hi = lane >> 5;
+  const int C = p.nH * 32;
+  auto fetch = [&](Item& it) __attribute__((always_inline)) {
+    int g = 0;
+    if (lane == 0) g = atomicAdd(&ctl[0], 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    it.e = p.n_max_magic ? (int)(((unsigned long long)(unsigned)g * p.n_max_magic) >> 32) : g;      // magic 0: one item per entry
+    const int idx = g - it.e * n_max;
+    it.live = false;
+    if (it.e >= e_wg) return;
+    const int4 e0 = etab[2 * it.e], e1 = etab[2 * it.e + 1];
+    const int pair = __builtin_amdgcn_readfirstlane(e0.x), h = __builtin_amdgcn_readfirstlane(e0.y), bw = __builtin_amdgcn_readfirstlane(e0.z);
+    it.w = __builtin_amdgcn_readfirstlane(e0.w);
+    const int q_lo = __builtin_amdgcn_readfirstlane(e1.x), q_hi = __builtin_amdgcn_readfirstlane(e1.y);
+    it.qb = q_lo + idx;
+    it.live = it.qb < q_hi;
+    const uint32_t sk = (uint32_t)__builtin_amdgcn_readfirstlane(e1.z);      // bit t: rows 16t..16t+15 of the window are padding only
+    it.live = it.live && !(((sk >> (2 * it.qb)) & 1u) && (((sk >> (2 * it.qb + 1)) & 1u) || 32 * it.qb + 16 >= N));
+    if (!it.live) return;
+    // depth-split window (host-checked geometry: N = 392, halves of 196 tokens): q-blocks 0..5 live in the first half (key blocks
+    // 0..6), 7..12 in the second (key blocks 6..12), q-block 6 (tokens 192..223) in both
+    it.t0 = (DSPLIT && p.dsplit_from >= 0 && it.w >= p.dsplit_from && it.qb > 6) ? 6 : 0;
+    const uint16_t* Qg = p.qkv + ((size_t)h * Mtot + (size_t)bw * N) * 32;
+    const int qrow = min(32 * it.qb + q, N - 1);
+    it.qf0 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 8 * hi);
+    it.qf1 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 16 + 8 * hi);
+    it.bd = p.image + ((size_t)pair * nqb + it.qb) * (A32_KB * 128) + lane;
+    it.pre[0] = it.bd[it.t0 * 128]; it.pre[1] = it.bd[it.t0 * 128 + 64];
+    it.orow = p.out + ((size_t)bw * N + 32 * it.qb + q) * C + h * 32;
+    it.store = 32 * it.qb + q < N && !(A32_ABL & 256);
+  };
+#ifdef KVQ_A32_TRACE
+  unsigned long long tr_f = 0, tr_w = 0, tr_q = 0, tr_n = 0, tr_m, tr_w0 = 0;
+  const unsigned long long tr_0 = __builtin_readcyclecounter();
+#define A32_MARK(acc) { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - tr_m; tr_m = n_; }
+  tr_m = tr_0;
+#else
+#define A32_MARK(acc)
+#endif
+  auto process = [&](Item& it) __attribute__((always_inline)) {
+    A32_MARK(tr_f);
+    const int b = it.e % A32_NSLOT;
+    if (it.live) {
+      while (__hip_atomic_load(&ctl[1 + A32_NSLOT + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it.e) __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+      A32_MARK(tr_w);
+#ifdef KVQ_A32_TRACE
+      if (tr_n == 0) tr_w0 = tr_w;
+#endif
+      const unsigned char* slot = smem + b * A32_SLOT;
+      const int zero = (A32_OFF_ZERO - b * A32_SLOT) >> 4;
+      if (DSPLIT && p.dsplit_from >= 0 && it.w >= p.dsplit_from && it.qb != 6) {
+        if (it.qb < 6) a32_qblock<E, 0, 7>(p, slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
+        else a32_qblock<E, 6, A32_KB>(p, slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
+      } else {
+        a32_qblock<E, 0, A32_KB>(p, slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
+      }
+    }
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&ctl[1 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef KVQ_A32_TRACE
+    A32_MARK(tr_q);
+    tr_n += it.live;
+#endif
+  };
+  Item ia, ib;
+  fetch(ia);
+  while (ia.e < e_wg) {
+    fetch(ib);
+    process(ia);
+    if (ib.e >= e_wg) break;
+    fetch(ia);
+    process(ib);
+  }
+#ifdef KVQ_A32_TRACE
+  if (p.trace && lane == 0) {
+    unsigned long long* t = p.trace + ((size_t)blockIdx.x * (A32_CW + 1) + wave) * 8;
+    t[0] = __builtin_readcyclecounter() - tr_0; t[1] = tr_f; t[2] = tr_w; t[3] = tr_q; t[4] = tr_n; t[5] = tr_w0; t[6] = tr_0 - tr_k0;
+  }
+#endif
+}
+
+// The image builder (one workgroup per (window type, head)): attn.hip's bias arithmetic — idx = code_q - code_k + center,
+// b = fma(gate, r - f, f), the shift mask REPLACES it by -100 — minus the row maximum over the un-masked keys, fp16, in the
+// streaming kernel's accumulator layout: [qb][kb][half][lane (q = lane & 31, hi = lane >> 5)][8]: register r = 8 half + e of the
+// 32 x 32 score block = key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi.
+struct Stream32BuildParams {
+  const int32_t* tok;
+  const float* rpb;
+  const float* fpb;
+  int table_len, center, nW, N, nH, use_mask;
+  uint16_t* out;
+  unsigned* max_abs;
+};
+
+__global__ __launch_bounds__(256) void bias_stream_build_kernel(Stream32BuildParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  f32x2* tab = reinterpret_cast<f32x2*>(bsm);
+  int2* tokL = reinterpret_cast<int2*>(bsm + (size_t)p.table_len * 8);
+  float* rmax = reinterpret_cast<float*>(bsm + (size_t)p.table_len * 8 + (size_t)p.N * 8);
+  const int h = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, N = p.N;
+  for (int i = tid; i < p.table_len; i += 256) {
+    const float r = p.rpb[(size_t)i * p.nH + h];
+    const float f = p.fpb ? p.fpb[(size_t)i * p.nH + h] : r;
+    tab[i] = (f32x2){f, p.fpb ? r - f : 0.f};
+  }
+  for (int i = tid; i < N; i += 256) tokL[i] = *reinterpret_cast<const int2*>(p.tok + ((size_t)w * N + i) * 2);
+  __syncthreads();
+  auto value = [&](int2 tq, int key, bool* masked) -> float {
+    const int2 tk = tokL[key];
+    const f32x2 e = tab[tq.x - tk.x + p.center];
+    const float gate = (float)__builtin_amdgcn_sad_u8((unsigned)(tq.y & 0xffff), (unsigned)(tk.y & 0xffff), 0u);
+    *masked = p.use_mask && ((tq.y >> 16) & 0xff) != ((tk.y >> 16) & 0xff);
+    return fmaf(gate, e[1], e[0]);
+  };
+  float big = 0.f;
+  for (int qq = tid; qq < N; qq += 256) {
+    const int2 tq = tokL[qq];
+    float mx = -INFINITY;
+    for (int key = 0; key < N; ++key) {
+      bool masked;
+      const float b = value(tq, key, &masked);
+      if (!masked) { mx = fmaxf(mx, b); big = fmaxf(big, fabsf(b)); }
+    }
+    rmax[qq] = mx;
+  }
+  if (p.max_abs) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = fmaxf(big, __shfl_xor(big, o));
+    if ((tid & 63) == 0) atomicMax(p.max_abs, __float_as_uint(big));
+  }
+  __syncthreads();
+  const int nqb = (N + 31) >> 5, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hi = lane >> 5;
+  uint16_t* img = p.out + ((size_t)w * p.nH + h) * nqb * A32_KB * 1024;
+  for (int tile = wave; tile < nqb * A32_KB * 2; tile += 4) {
+    const int half = tile & 1, blk = tile >> 1, qb = blk / A32_KB, kb = blk - qb * A32_KB, qq = 32 * qb + ql;
+    const int2 tq = tokL[qq < N ? qq : N - 1];
+    const float shift = rmax[qq < N ? qq : N - 1];
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * half + e, key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float b = 0.f;
+      if (key >= N) {
+        b = A32_OFF;
+      } else if (qq < N) {
+        bool masked;
+        b = value(tq, key, &masked);
+        if (masked) b = -100.0f;
+        b -= shift;
+      }
+      v[e] = b;
+    }
+    *reinterpret_cast<u32x4*>(img + (size_t)tile * 512 + lane * 8) =
+        (u32x4){Fp16::pack2_raw(v[0], v[1]), Fp16::pack2_raw(v[2], v[3]), Fp16::pack2_raw(v[4], v[5]), Fp16::pack2_raw(v[6], v[7])};
+  }
+}
+
+template <typename E, bool DSPLIT>
+static int launch_attn32(const Attn32Params& p, hipStream_t st) {
+  auto kern = window_attention_stream_kernel<E, DSPLIT>;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  KVQ_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, A32_LDS));
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * p.wg_per_xcd)), dim3(A32_THREADS), A32_LDS, st, p);
+  KVQ_CHECK_LAUNCH("window_attention_stream_kernel");
+  return KVQ_OK;
+}
+
+}  // namespace kvq
+
+extern "C" size_t kvq_attn_bias_stream_bytes(int n_types, int N, int num_heads) {
+  if (n_types <= 0 || N < 1 || N > 400 || num_heads <= 0) return 0;
+  return (size_t)n_types * num_heads * ((N + 31) / 32) * kvq::A32_KB * 2048 + 2048;     // + one block: the kernel requests block t0 + 1 unconditionally
+}
+
+extern "C" int kvq_attn_bias_stream_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
+                                          int nW, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(tok && rpb && out, KVQ_ERR_NULL, "kvq_attn_bias_stream_build: NULL pointer");
+  KVQ_REQUIRE(kvq_attn_bias_stream_bytes(nW, N, num_heads) > 0 && table_len > 0, KVQ_ERR_SHAPE,
+              "kvq_attn_bias_stream_build: bad shape nW=%d N=%d nH=%d", nW, N, num_heads);
+  KVQ_REQUIRE(((size_t)out & 15) == 0, KVQ_ERR_SHAPE, "kvq_attn_bias_stream_build: out must be 16-byte aligned");
+  Stream32BuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (uint16_t*)out, (unsigned*)max_abs};
+  const size_t lds = (size_t)table_len * 8 + (size_t)N * 12;
+  KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_attn_bias_stream_build: table of %d entries does not fit the builder's LDS", table_len);
+  hipLaunchKernelGGL(bias_stream_build_kernel, dim3((unsigned)num_heads, (unsigned)nW), dim3(256), lds, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("bias_stream_build_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_window_attention_stream(const KvqAttnDenseArgs* a, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(a && a->qkv && a->bias_dense && a->out, KVQ_ERR_NULL, "kvq_window_attention_stream: NULL pointer");
+  const int BW = a->BW, nW = a->nW, N = a->N, num_heads = a->num_heads, n_types = a->n_types;
+  KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
+              "kvq_window_attention_stream: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
+  KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_stream: window of %d tokens unsupported (1..400)", N);
+  KVQ_REQUIRE(((size_t)a->bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_stream: the bias image must be 16-byte aligned");
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_stream: dtype %d", a->dtype);
+  KVQ_REQUIRE(!a->x_ln, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_stream: no fused qkv projection in this kernel");
+  KVQ_REQUIRE(a->dsplit_from < 0 || (N == 392 && a->dsplit_from < nW), KVQ_ERR_UNSUPPORTED,
+              "kvq_window_attention_stream: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
+  // entries = (window, head, clip) units, cut into q-parts while there are fewer than three per CU
+  const int units = BW * num_heads, nqb = (N + 31) / 32;
+  int qsplit = units >= 768 ? 1 : 768 / units;
+  qsplit = qsplit > 4 ? 4 : qsplit;
+  qsplit = qsplit > nqb ? nqb : qsplit;
+  const int npair = n_types * num_heads, per_pair = (BW / n_types) * qsplit;
+  const int e_x0 = ((npair + 7) / 8) * per_pair;       // entries of the fullest XCD
+  const int n_max = (nqb + qsplit - 1) / qsplit;
+  Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
+                 a->dsplit_from < 0 ? -1 : a->dsplit_from, e_x0 < 32 ? e_x0 : 32, n_max == 1 ? 0u : (unsigned)((0x100000000ull + n_max - 1) / n_max), g_trace};
+  KVQ_REQUIRE((e_x0 + p.wg_per_xcd - 1) / p.wg_per_xcd <= A32_MAX_ENTRIES, KVQ_ERR_UNSUPPORTED,
+              "kvq_window_attention_stream: %d (window, head, clip) units exceed one launch", units);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == KVQ_DT_FP16)
+    return p.dsplit_from >= 0 ? launch_attn32<Fp16, true>(p, st) : launch_attn32<Fp16, false>(p, st);
+  return p.dsplit_from >= 0 ? launch_attn32<Bf16, true>(p, st) : launch_attn32<Bf16, false>(p, st);
+}

@@ -72,6 +72,10 @@ struct Bf16 {
   static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
+  // acc + a.lo * b.lo + a.hi * b.hi on packed pairs (v_dot2c_f32_bf16)
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+  }
 };
 
 // fp32 -> fp16 conversions must SATURATE (a value past 65504 would become inf and poison the row): instead of a
@@ -104,6 +108,9 @@ struct Fp16 {
   }
   static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {      // v_dot2c_f32_f16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), acc, false);
   }
 };
 

@@ -294,13 +294,24 @@ namespace kvq {
 // position codes, fragment ids and — absent — mask regions of their tokens are identical); windows are ordered
 // depth-major, so window w has type w % n_types
 static int bias_types(const StageGeom& g, int par) { return par == 0 ? g.nW / (g.Dp / g.ws[0]) : g.nW; }
+// Which attention kernel consumes a block's dense bias — by geometry only (the image layout follows it, and a block's path must
+// never depend on the batch): the un-padded C = 96 stage keeps attn.hip's dense kernel, whose workgroups compute their own
+// q | k | v (the qkv GEMM there is an HBM-bound launch); every other stage takes the streaming kernel (attn32.hip).
+// KVQ_ATTN_STREAM=0 keeps attn.hip everywhere (A/B runs).
+static bool attn_stream(const StageGeom& g) {
+  static const bool on = !(getenv("KVQ_ATTN_STREAM") && atoi(getenv("KVQ_ATTN_STREAM")) == 0);
+  return on && g.N <= 400 && !(g.Lp == g.L && g.C == 96);
+}
+constexpr float kQScale = 0.17677669529663687f;              // head_dim^-0.5 = 32^-0.5 (swin_backbone.py:208)
+constexpr float kQScaleLog2 = 0.17677669529663687f * 1.4426950408889634f;      // the streaming kernel keeps scores in log2 units
 }  // namespace kvq
 
 extern "C" size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* pl, int block) {
   int i = 0, par = 0;
   if (!pl || !kvq::locate_block(pl, block, &i, &par)) return 0;
   const kvq::StageGeom& g = pl->st[i];
-  return kvq_attn_bias_dense_bytes(kvq::bias_types(g, par), g.N, g.nH);
+  return kvq::attn_stream(g) ? kvq_attn_bias_stream_bytes(kvq::bias_types(g, par), g.N, g.nH)
+                             : kvq_attn_bias_dense_bytes(kvq::bias_types(g, par), g.N, g.nH);
 }
 
 extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, const float* rpb, const float* fpb, void* out,
@@ -310,6 +321,9 @@ extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, con
   KVQ_REQUIRE(pl && rpb && out, KVQ_ERR_NULL, "kvq_swin3d_bias_dense_build: NULL pointer");
   KVQ_REQUIRE(locate_block(pl, block, &i, &par), KVQ_ERR_SHAPE, "kvq_swin3d_bias_dense_build: no block %d", block);
   const StageGeom& g = pl->st[i];
+  if (attn_stream(g))
+    return kvq_attn_bias_stream_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
+                                      bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
   return kvq_attn_bias_dense_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
                                    bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
 }
@@ -507,25 +521,26 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       // fused_qkv_prologue).  Un-padded partitions on the dense bias only.  Measured (bench.py --legs c2,no_sampler, two runs each,
       // same box): 300.4 -> 314.6 videos/s with the sampler in the step, 315.5 -> 330.1 without; stage-0 launch 133.5 -> 117.3 us.
       const bool fuse_qkv = bw.bias_dense && bw.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // by geometry only, never by batch
+      const bool stream = bw.bias_dense && attn_stream(g);       // the image's layout follows the same rule (kvq_swin3d_bias_dense_build)
+      const float qs = stream ? kQScaleLog2 : kQScale;
       // norm1 + pad + roll + window_partition
       if (g.Lp != g.L && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
         // (rows scattered to their window rows by the epilogue); the padding rows' q | k | v = qkv(0) = bias
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
         KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, ML, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
-                     0.17677669529663687f, g.d_dst[par], g.L, g.Lp));
-        KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, 0.17677669529663687f, pl->dtype, st));
+                     qs, g.d_dst[par], g.L, g.Lp));
+        KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, qs, pl->dtype, st));
       } else {
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
         if (!fuse_qkv)
-          KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
-                       0.17677669529663687f /* 32^-0.5 */));
+          KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH, qs));
       }
       ln1_ready = false;
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
-        Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
-                   (fuse_qkv ? 2.0 * 2.0 * M * C + 6.0 * C * C : 2.0 * 4.0 * M * C) + (double)kvq_attn_bias_dense_bytes(bias_types(g, par), g.N, g.nH));
+        Bracket br(pl, st, KVQ_K_ATTN, (stream ? 8 : 4) + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
+                   (fuse_qkv ? 2.0 * 2.0 * M * C + 6.0 * C * C : 2.0 * 4.0 * M * C) + (double)kvq_swin3d_bias_dense_bytes(pl, blk));
         KvqAttnDenseArgs aa{};
         aa.qkv = bbig; aa.bias_dense = bw.bias_dense; aa.n_types = bias_types(g, par); aa.BW = B * g.nW; aa.nW = g.nW; aa.N = g.N;
         aa.num_heads = g.nH; aa.dtype = pl->dtype; aa.out = bo; aa.tile_skip = (const uint32_t*)g.d_skip[par];
@@ -533,8 +548,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         const int slabs = g.Dp / g.ws[0];
         aa.dsplit_from = (par == 1 && g.N == 392 && g.ws[0] == 8 && g.ws[1] == 7 && g.ws[2] == 7 && g.ss[0] == 4 && slabs >= 1)
                              ? g.nW - g.nW / slabs : -1;
-        if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = 0.17677669529663687f; }
-        KVQ_TRY(kvq_window_attention_dense_args(&aa, st));
+        if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = kQScale; }
+        KVQ_TRY(stream ? kvq_window_attention_stream(&aa, st) : kvq_window_attention_dense_args(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);

@@ -167,6 +167,39 @@ def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int,
     return out
 
 
+LOG2E = 1.4426950408889634
+
+
+def attn_bias_stream(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor], center: int, nW: int, N: int,
+                     use_mask: bool):
+    """The bias image of ``window_attention_stream`` (32 x 32 score blocks; include/kvq_hip.h); arguments as ``attn_bias_dense``."""
+    _need_gpu(tok, rpb, fpb)
+    nH = rpb.shape[1]
+    out = torch.empty(lib().kvq_attn_bias_stream_bytes(nW, N, nH), dtype=torch.uint8, device=rpb.device)
+    big = torch.zeros(1, dtype=torch.float32, device=rpb.device)
+    check(lib().kvq_attn_bias_stream_build(ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, nW, N, nH, int(use_mask),
+                                           ptr(out), ptr(big), current_stream()), "kvq_attn_bias_stream_build")
+    out.max_abs_bias = big
+    return out
+
+
+def window_attention_stream(qkv: torch.Tensor, bias_stream: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
+                            tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1):
+    """The streaming attention kernel (csrc/attn32.hip): qkv fp16|bf16 [3,nH,BW*N,32] with q pre-scaled by
+    head_dim^-0.5 * log2(e), the image of ``attn_bias_stream``; returns [BW*N, nH*32].  Other arguments as ``window_attention_dense``."""
+    _need_gpu(qkv, bias_stream, tile_skip, out)
+    assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
+    nH = qkv.shape[1]
+    BW = qkv.shape[2] // N
+    if out is None:
+        out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
+    a = _abi.KvqAttnDenseArgs()
+    a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(bias_stream), nW if n_types is None else n_types, BW, nW, N, nH
+    a.dtype, a.out, a.tile_skip, a.dsplit_from = dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), dsplit_from
+    check(lib().kvq_window_attention_stream(C.byref(a), current_stream()), "kvq_window_attention_stream")
+    return out
+
+
 def patch_im2col(x: torch.Tensor, patch: Sequence[int], out_dtype=torch.float16):
     _need_gpu(x)
     assert x.dtype == torch.float32 and x.is_contiguous()

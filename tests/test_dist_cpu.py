@@ -50,3 +50,24 @@ def test_single_process_is_identity():
     assert kd.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     x = torch.arange(5, dtype=torch.float32)
     assert torch.equal(kd.gather_scores(x, 5, 0, 1), x)
+
+
+def test_bench_gpus_n_without_rank_environment_launches_n_ranks_or_fails():
+    """``python bench.py --gpus 2`` with no RANK / WORLD_SIZE must never come back as a one-GPU run: it re-executes itself under
+    torch.distributed.run with two ranks (which, on this GPU-less box, both fail on "needs a GPU": a non-zero exit and no
+    result line), and a rank environment that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert all(ln.get("n_gpus") == 2 for ln in lines), r.stdout
+    assert lines or r.returncode != 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    if not lines:      # no GPU here: the ranks were started (torch.distributed.run reports its failed children) and said why
+        assert "ChildFailedError" in r.stderr or "needs a GPU" in r.stderr, r.stderr[-800:]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in r.stderr and not r.stdout.strip()

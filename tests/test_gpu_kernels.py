@@ -454,6 +454,115 @@ def test_window_attention_dense_depth_split_is_bit_identical(dims, half):
         kernels.window_attention_dense(qkv[:, :, : BW * 98].contiguous(), dense, nW, 98, dsplit_from=0)     # not the (8,7,7) window
 
 
+@pytest.mark.parametrize("dims,window,shifted,gated,nH", [
+    ((8, 14, 14), (8, 7, 7), False, True, 3),
+    ((8, 14, 14), (8, 7, 7), True, True, 3),
+    ((16, 7, 7), (8, 7, 7), True, False, 2),
+    ((4, 10, 9), (8, 7, 7), True, True, 1),       # clamped depth (N = 196: 7 key blocks, the last one 4 keys wide) + padding
+    ((8, 8, 8), (4, 4, 4), True, False, 2),       # N = 64: two key blocks
+    ((16, 14, 7), (8, 7, 7), False, True, 2),     # two windows deep, un-shifted: the depth copies share one bias
+    ((16, 28, 28), (8, 7, 7), True, True, 6),     # stage-1 like: 32 windows x 6 heads, several entries per workgroup
+])
+def test_window_attention_stream_vs_oracle(dims, window, shifted, gated, nH, half):
+    """The streaming kernel (32 x 32 score blocks, running maximum, persistent workgroups; csrc/attn32.hip) against the fp32 oracle and
+    against the dense kernel it replaces.  q reaches it scaled by log2(e) (scores in log2 units): the oracle gets the same rounded q
+    divided by log2(e) in fp32."""
+    g = rng(sum(dims) + nH + 200)
+    shift = tuple(w // 2 for w in window) if shifted else (0, 0, 0)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, B = lay["N"], lay["nW"], 3
+    BW = B * nW
+    tl = (2 * window[0] - 1) * (2 * window[1] - 1) * (2 * window[2] - 1)
+    q2 = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)) * (0.6 * kernels.LOG2E), half)
+    k = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)), half)
+    v = rnd(torch.from_numpy(g.standard_normal((BW, nH, N, 32)).astype(np.float32)), half)
+    rpb = torch.from_numpy((0.5 * g.standard_normal((tl, nH))).astype(np.float32))
+    fpb = torch.from_numpy((0.5 * g.standard_normal((tl, nH))).astype(np.float32)) if gated else None
+    ref = O.attention_core(q2 / kernels.LOG2E, k, v, rpb, fpb, window, lay).reshape(BW * N, nH * 32)
+    tok, center = _tok_table(lay, window)
+    qkv = dev(torch.stack([q2, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, BW * N, 32).contiguous(), half)
+    use_mask = any(s > 0 for s in lay["ss"])
+    tokd, rpbd, fpbd = dev(torch.from_numpy(tok)), dev(rpb), None if fpb is None else dev(fpb)
+    n_types = nW if use_mask else nW // (-(-dims[0] // lay["ws"][0]))
+    image = kernels.attn_bias_stream(tokd[: n_types * N], rpbd, fpbd, center, n_types, N, use_mask)
+    out = kernels.window_attention_stream(qkv, image, nW, N, n_types).float().cpu()
+    assert torch.isfinite(out).all()
+    assert 0 < float(image.max_abs_bias) <= 32.0
+    # the same budget as the dense kernel's test: fp16 row-max-shifted bias (<= 2^-11 x distance below the row's largest) on top of the
+    # 16-bit rounding of the probabilities and the output
+    assert (out - ref).abs().max().item() <= 6.4 * EPS[half] + 2.0 ** -7
+    assert (out - ref).abs().mean().item() <= 0.5 * EPS[half]
+    # q-blocks whose two 16-row tiles are both marked in tile_skip are passed over: their rows keep the sentinel
+    skip = np.zeros(nW, np.int32)
+    nqt = -(-N // 16)
+    for wv in range(nW):
+        skip[wv] = int(g.integers(0, 1 << nqt)) & ~3                       # q-block 0 always runs
+    sentinel = torch.full((BW * N, nH * 32), 7.0, dtype=half, device=qkv.device)
+    part = kernels.window_attention_stream(qkv, image, nW, N, n_types, tile_skip=dev(torch.from_numpy(skip)), out=sentinel).float().cpu()
+    rows = np.arange(BW * N)
+    t0 = 2 * ((rows % N) // 32)
+    sk = skip[(rows // N) % nW]
+    both = ((sk >> t0) & 1) & (((sk >> (t0 + 1)) & 1) | (16 * (t0 + 1) >= N))
+    skipped = torch.from_numpy(both.astype(bool))
+    assert torch.equal(part[~skipped], out[~skipped]) and bool((part[skipped] == 7.0).all())
+
+
+def test_window_attention_stream_extremes_and_rescale(half):
+    """Rows whose maximum grows by far more than the rescale threshold in the middle of the key range (a dominant key in a late
+    block), rows that START masked (shifted windows: the first key blocks of some queries hold -100 only), and a key that dominates
+    by > 80: finite, and within the rounding budget of the oracle."""
+    g = rng(31)
+    window, shift = (8, 7, 7), (4, 3, 3)
+    lay = O.window_layout(16, 14, 14, window, shift)
+    N, nW, nH = lay["N"], lay["nW"], 2
+    q = torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32)) * 0.6
+    k = torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32))
+    q[:, 1, :, 0] = 16.0
+    k[:, 1, :, 0] = 0.0
+    k[:, 1, 300, 0] = 6.0                       # head 1: key 300 (block 9) wins every un-masked row by ~96
+    k[:, 0, 40::57] *= 9.0                      # head 0: a few loud keys spread over the blocks
+    q2, k, v = rnd(q * kernels.LOG2E, half), rnd(k, half), rnd(torch.from_numpy(g.standard_normal((nW, nH, N, 32)).astype(np.float32)), half)
+    rpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
+    rpb[:, 1] = 0.0          # head 1: biases 0 / -100 only — exact in the fp16 image (a +96 logit against a rounded -100.3 would make
+                             # the test measure the image's rounding under cancellation, which the dense kernel shares)
+    ref = O.attention_core(q2 / kernels.LOG2E, k, v, rpb, None, window, lay).reshape(nW * N, nH * 32)
+    tok, center = _tok_table(lay, window)
+    qkv = dev(torch.stack([q2, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, nW * N, 32).contiguous(), half)
+    image = kernels.attn_bias_stream(dev(torch.from_numpy(tok)), dev(rpb), None, center, nW, N, True)
+    out = kernels.window_attention_stream(qkv, image, nW, N).float().cpu()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 6.4 * EPS[half] + 2.0 ** -7
+
+
+@pytest.mark.parametrize("dims", [(16, 14, 14), (24, 7, 7)])
+def test_window_attention_stream_depth_split(dims, half):
+    """dsplit_from: depth-split windows pass over the other half's 32-key blocks.  Their scores are the image's -100 and leave the
+    exponential as zeros against any maximum the row's own half produces.  Windows that are not split and the first-half rows of split
+    windows (their skipped blocks come LAST: exact zeros added) agree bit for bit; second-half rows start their running maximum at
+    another block (the full launch rescales once, from the masked blocks' level), so their exponent arguments round differently in the
+    last fp32 bit: equal to one 16-bit rounding of the output."""
+    g = rng(sum(dims) + 7)
+    window, shift = (8, 7, 7), (4, 3, 3)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, nH, B = lay["N"], lay["nW"], 3, 2
+    BW = B * nW
+    qkv = dev(rnd(torch.from_numpy(g.standard_normal((3, nH, BW * N, 32)).astype(np.float32)) * 0.7, half), half)
+    rpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
+    fpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
+    tok, center = _tok_table(lay, window)
+    image = kernels.attn_bias_stream(dev(torch.from_numpy(tok)), dev(rpb), dev(fpb), center, nW, N, True)
+    full = kernels.window_attention_stream(qkv, image, nW, N)
+    first = nW - nW // (-(-dims[0] // 8))
+    split = kernels.window_attention_stream(qkv, image, nW, N, dsplit_from=first)
+    rows = torch.arange(BW * N)
+    same = (((rows // N) % nW) < first) | ((rows % N) < 192)
+    assert torch.equal(split.cpu()[same], full.cpu()[same])
+    assert (split.float() - full.float()).abs().max().item() <= 2.0 * EPS[half] * float(full.float().abs().max())
+    assert not torch.equal(split, torch.zeros_like(split))
+    with pytest.raises(RuntimeError):
+        kernels.window_attention_stream(qkv[:, :, : BW * 98].contiguous(), image, nW, 98, dsplit_from=0)     # not the (8,7,7) window
+
+
 @pytest.mark.parametrize("C,dims,shift", [(96, (16, 14, 14), (0, 0, 0)), (96, (16, 14, 14), (4, 3, 3)), (96, (8, 21, 14), (0, 0, 0))])
 def test_window_attention_dense_fused_qkv_projection(C, dims, shift, half):
     """The attention launch that computes its own q | k | v from the norm1 rows (stages with C <= 192) against the qkv GEMM followed by

@@ -1,0 +1,153 @@
+// Standalone driver for window_attention_stream_kernel (csrc/attn32.hip): random q|k|v and a random bias image in the kernel's layout,
+// sampled rows against a host fp64 softmax, then the launch time at a trunk geometry.
+//   ./attn32_bench nW nH nclip N n_types [iters] [dsplit_from] [spike]     (stage 0 of C2: 128 3 4 392 64 | shifted: n_types 128)
+// spike = 1: some K rows are scaled up so that the running maximum grows past the rescale threshold in the middle of a row.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <random>
+#include "attn32.hip"
+
+namespace kvq {
+void set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
+int hip_fail(hipError_t e, const char* w) { fprintf(stderr, "HIP %s: %s\n", w, hipGetErrorString(e)); return -1; }
+unsigned long long* g_trace = nullptr;
+int g_trace_blocks = 0;
+}
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; __builtin_memcpy(&u, &h, 2); return u; }
+static float h2f(uint16_t u) { _Float16 h; __builtin_memcpy(&h, &u, 2); return (float)h; }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+  const int nW = argc > 1 ? atoi(argv[1]) : 128, nH = argc > 2 ? atoi(argv[2]) : 3, nclip = argc > 3 ? atoi(argv[3]) : 4;
+  const int N = argc > 4 ? atoi(argv[4]) : 392, ntyp = argc > 5 ? atoi(argv[5]) : 64, iters = argc > 6 ? atoi(argv[6]) : 20;
+  const int dsplit = argc > 7 ? atoi(argv[7]) : -1;
+  const int spike = argc > 8 ? atoi(argv[8]) : 0;
+  const int BW = nclip * nW, nqb = (N + 31) / 32, KB = kvq::A32_KB;
+  const size_t Mtot = (size_t)BW * N;
+  const double LOG2E = 1.4426950408889634;
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<uint16_t> hq(3 * (size_t)nH * Mtot * 32);
+  for (size_t i = 0; i < hq.size(); ++i) {
+    float v = U(rng) * (i < hq.size() / 3 ? 0.6f * (float)LOG2E : 1.0f);
+    if (spike && i >= hq.size() / 3 && i < 2 * (hq.size() / 3)) {          // K rows 200.. of every 7th window: 12x
+      const size_t row = (i - hq.size() / 3) / 32 % Mtot;
+      if ((row / N) % 7 == 3 && (row % N) >= 200 && (row % N) % 50 == 0) v *= 12.f;
+    }
+    hq[i] = f2h(v);
+  }
+  // image: [pair][qb][kb][half][lane (q = lane & 31, hi = lane >> 5)][e]: r = 8 half + e, key = 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
+  const size_t img = (size_t)ntyp * nH * nqb * KB * 1024 + 1024;
+  std::vector<uint16_t> hb(img);
+  auto bias_at = [&](size_t pr, int q, int key) -> size_t {
+    const int qb = q >> 5, kb = key >> 5, kk = key & 31, hi = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+    return (((pr * nqb + qb) * KB + kb) * 2 + (r >> 3)) * 512 + (size_t)((q & 31) + 32 * hi) * 8 + (r & 7);
+  };
+  for (size_t pr = 0; pr < (size_t)ntyp * nH; ++pr)
+    for (int q = 0; q < 32 * nqb; ++q)
+      for (int key = 0; key < 32 * KB; ++key) {
+        float b = -3.f * fabsf(U(rng));
+        if ((rng() & 31) == 0) b = -100.f;
+        if (dsplit >= 0 && (int)(pr / nH) >= dsplit && (q < 196) != (key < 196)) b = -100.f;
+        if (key >= N) b = kvq::A32_OFF;
+        hb[bias_at(pr, q, key)] = f2h(b);
+      }
+  uint16_t *dq, *db, *dout;
+  CK(hipMalloc(&dq, hq.size() * 2)); CK(hipMalloc(&db, img * 2)); CK(hipMalloc(&dout, Mtot * nH * 32 * 2));
+  CK(hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), img * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(dout, 0xff, Mtot * nH * 32 * 2));
+  auto run = [&]() {
+    KvqAttnDenseArgs a{};
+    a.qkv = dq; a.bias_dense = db; a.n_types = ntyp; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = nH; a.dtype = KVQ_DT_FP16; a.out = dout;
+    a.dsplit_from = dsplit;
+    return kvq_window_attention_stream(&a, nullptr);
+  };
+  if (run()) return 1;
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> ho(Mtot * nH * 32);
+  CK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+  double maxerr = 0; long bad = 0, rows = 0;
+  std::uniform_int_distribution<int> Ubw(0, BW - 1), Uh(0, nH - 1), Uq(0, N - 1);
+  for (int s = 0; s < 600; ++s) {
+    int bw = Ubw(rng), h = Uh(rng), q = Uq(rng);
+    if (s < 8) { bw = s & 1 ? BW - 1 : 0; h = s & 2 ? nH - 1 : 0; q = s & 4 ? N - 1 : 0; }
+    if (spike && s >= 8 && s < 300) bw = (bw / 7) * 7 + 3 < BW ? (bw / 7) * 7 + 3 : bw;
+    const int w = bw % nW, wt = w % ntyp;
+    const size_t pr = (size_t)wt * nH + h;
+    const uint16_t* Q = &hq[((size_t)(0 * nH + h) * Mtot + (size_t)bw * N + q) * 32];
+    std::vector<double> sc(N);
+    double mx = -1e300;
+    for (int k = 0; k < N; ++k) {
+      const uint16_t* K = &hq[((size_t)(1 * nH + h) * Mtot + (size_t)bw * N + k) * 32];
+      double d = 0;
+      for (int e = 0; e < 32; ++e) d += (double)h2f(Q[e]) * h2f(K[e]);
+      d += (double)h2f(hb[bias_at(pr, q, k)]) * LOG2E;
+      sc[k] = d; mx = d > mx ? d : mx;
+    }
+    double den = 0; std::vector<double> o(32, 0.0);
+    for (int k = 0; k < N; ++k) {
+      const double pk = exp2(sc[k] - mx); den += pk;
+      const uint16_t* V = &hq[((size_t)(2 * nH + h) * Mtot + (size_t)bw * N + k) * 32];
+      for (int e = 0; e < 32; ++e) o[e] += pk * h2f(V[e]);
+    }
+    for (int e = 0; e < 32; ++e) {
+      const double ref = o[e] / den, got = h2f(ho[((size_t)bw * N + q) * (nH * 32) + h * 32 + e]);
+      const double err = fabs(got - ref);
+      if (!(err <= 4e-3)) { if (bad < 5) printf("  mismatch bw %d h %d q %d e %d: got %f ref %f\n", bw, h, q, e, got, ref); ++bad; }
+      maxerr = err > maxerr ? err : maxerr;
+    }
+    ++rows;
+  }
+  printf("check: %ld bad of %ld rows, max |err| %.3g\n", bad, rows, maxerr);
+  long diff = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipMemset(dout, 0xff, Mtot * nH * 32 * 2));
+    run(); CK(hipDeviceSynchronize());
+    std::vector<uint16_t> h2(ho.size());
+    CK(hipMemcpy(h2.data(), dout, h2.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h2.size(); ++i) diff += h2[i] != ho[i];
+  }
+  printf("repeat screen: %ld differing elements\n", diff);
+#ifdef KVQ_A32_TRACE
+  {
+    const int per = kvq::A32_CW + 1, nw = 256 * per;
+    unsigned long long* dt; CK(hipMalloc(&dt, nw * 64)); CK(hipMemset(dt, 0, nw * 64));
+    kvq::g_trace = dt;
+    run(); CK(hipDeviceSynchronize());
+    kvq::g_trace = nullptr;
+    std::vector<unsigned long long> ht(nw * 8);
+    CK(hipMemcpy(ht.data(), dt, nw * 64, hipMemcpyDeviceToHost));
+    double life = 0, f = 0, w = 0, qq = 0, n = 0, lmax = 0, w0 = 0, st = 0; int cnt = 0;
+    double ld[8] = {0}; int ldn[8] = {0};
+    for (int i = 0; i < nw; ++i) {
+      if (i % per == kvq::A32_CW) { for (int k = 0; k < 8; ++k) if (ht[i * 8 + k]) { ld[k] += ht[i * 8 + k]; ++ldn[k]; } continue; }
+      if (ht[i * 8]) { life += ht[i * 8]; f += ht[i * 8 + 1]; w += ht[i * 8 + 2]; qq += ht[i * 8 + 3]; n += ht[i * 8 + 4]; w0 += ht[i * 8 + 5]; st += ht[i * 8 + 6]; lmax = ht[i * 8] > lmax ? ht[i * 8] : lmax; ++cnt; }
+    }
+    printf("trace (%d consumer waves): start %.0f, life %.0f (max %.0f) ticks, per wave: fetch %.0f, ready wait %.0f (first item %.0f), q-blocks %.0f over %.2f items -> %.0f ticks per item\n",
+           cnt, st / cnt, life / cnt, lmax, f / cnt, w / cnt, w0 / cnt, qq / cnt, n / cnt, qq / n);
+    printf("loader: entries landed at");
+    for (int k = 0; k < 8; ++k) if (ldn[k]) printf(" %.0f", ld[k] / ldn[k]);
+    printf(" ticks after kernel start\n");
+  }
+#endif
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) run();
+  float best = 1e30f, tot = 0;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) run();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    best = ms < best ? ms : best; tot += ms;
+  }
+  const double fl = 4.0 * (double)Mtot * N * nH * 32;
+  const double blocks = (double)BW * nH * nqb * KB;
+  printf("STREAM nW=%d nH=%d clips=%d N=%d types=%d dsplit=%d: %.1f us mean, %.1f best -> %.1f TF/s (%.1f best); %.0f cycles per 32x32 block per SIMD at 2.1 GHz\n",
+         nW, nH, nclip, N, ntyp, dsplit, tot / 5 * 1e3, best * 1e3, fl / (tot / 5 * 1e-3) / 1e12, fl / (best * 1e-3) / 1e12,
+         tot / 5 * 1e-3 * 2.1e9 / (blocks / 1024.0));
+  return bad || diff;
+}
