@@ -47,6 +47,9 @@ constexpr int A32_LDS = A32_OFF_TAB + A32_MAX_ENTRIES * 32;
 #ifndef A32_SUM
 #define A32_SUM 0
 #endif
+#ifndef A32_BDEPTH
+#define A32_BDEPTH 2          // bias tiles requested ahead of the block being multiplied (ring of A32_BDEPTH + 1 tiles, 8 registers each)
+#endif
 #ifndef A32_BR
 #define A32_BR 0
 #endif
@@ -88,7 +91,7 @@ __device__ __forceinline__ float a32_pair_sum(float x) {
 }
 
 // one entry = one (window, head, clip, q-part): K | V staged once, n_max q-block items
-struct A32Entry { int pair, h, bw, w, q_lo, q_hi; };
+struct A32Entry { int pair, h, bw, w, q_lo, q_hi, inst; };     // inst: index among the (clip, depth copy) instances that share this (pair, q-part)
 
 __device__ __forceinline__ A32Entry a32_decode(const Attn32Params& p, int xcd, int j, int nqb) {
   const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, per_pair = nclip * nrep * p.qsplit;
@@ -102,6 +105,7 @@ __device__ __forceinline__ A32Entry a32_decode(const Attn32Params& p, int xcd, i
   e.bw = clip * p.nW + e.w;
   e.q_lo = part * nqb / p.qsplit;
   e.q_hi = (part + 1) * nqb / p.qsplit;
+  e.inst = sub % (nclip * nrep);
   return e;
 }
 
@@ -122,20 +126,21 @@ __device__ __forceinline__ void a32_qblock(const Attn32Params& p, const unsigned
   const a32_tr_t vtr = (a32_tr_t)(slot + A32_K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
   const uint32_t one2 = (uint32_t)E::cvt(1.0f) * 0x10001u;
 
-  u32x4 braw[3][2];
+  constexpr int BR = A32_BDEPTH + 1;
+  u32x4 braw[BR][2];
   auto load_bias = [&](int t) __attribute__((always_inline)) {
 #if (A32_ABL & 1)     // diagnostic: no bias stream (one tile, loaded once per q-block)
-    if (t != T0) { braw[t % 3][0] = braw[T0 % 3][0]; braw[t % 3][1] = braw[T0 % 3][1]; return; }
+    if (t != T0) { braw[t % BR][0] = braw[T0 % BR][0]; braw[t % BR][1] = braw[T0 % BR][1]; return; }
 #endif
-    braw[t % 3][0] = bd[t * 128];
-    braw[t % 3][1] = bd[t * 128 + 64];
+    braw[t % BR][0] = bd[t * 128];
+    braw[t % BR][1] = bd[t * 128 + 64];
   };
   // C operand of block t: bias * log2(e) - m, straight from the packed fp16 pairs (v_fma_mix_f32)
   auto mix = [&](int t, float nm) __attribute__((always_inline)) -> f32x16 {
     f32x16 c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const uint32_t u = braw[t % 3][r >> 3][(r & 7) >> 1];
+      const uint32_t u = braw[t % BR][r >> 3][(r & 7) >> 1];
       const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((r & 1) ? (u >> 16) : (u & 0xffffu)));
       c[r] = (A32_ABL & 32) ? nm : __builtin_fmaf((float)hv, kLog2e, nm);
     }
@@ -154,8 +159,10 @@ __device__ __forceinline__ void a32_qblock(const Attn32Params& p, const unsigned
   for (int r = 0; r < 16; ++r) O[r] = 0.f;
   float ls = 0.f, ls1 = 0.f, nm = 0.f;                                        // nm = -(running maximum), log2 units
 
-  braw[T0 % 3][0] = pre[0]; braw[T0 % 3][1] = pre[1];        // block T0: requested while the previous q-block was computed
-  if (T0 + 1 < T1) load_bias(T0 + 1);
+  braw[T0 % BR][0] = pre[0]; braw[T0 % BR][1] = pre[1];        // block T0: requested while the previous q-block was computed
+#pragma unroll
+  for (int a = 1; a < A32_BDEPTH; ++a)
+    if (T0 + a < T1) load_bias(T0 + a);
   {
     const V8 k0 = kfrag(T0, 0), k1 = kfrag(T0, 1);
     const f32x16 c = mix(T0, 0.f);
@@ -177,7 +184,7 @@ __device__ __forceinline__ void a32_qblock(const Attn32Params& p, const unsigned
         vf[cur][3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vtr + t * 256 + 192);
       }
     }
-    if (t + 2 < T1) load_bias(t + 2);
+    if (t + A32_BDEPTH < T1) load_bias(t + A32_BDEPTH);
     // ---- P V of block t-1 in the matrix pipe under the row maximum of block t (two new scores per v_max3_f32) ----
     float mx = 0.f;
     if (t > T0 && !(A32_ABL & 4))
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(At
   for (int e = tid; e < e_wg; e += A32_THREADS) {
     const A32Entry en = a32_decode(p, xcd, s + e * p.wg_per_xcd, nqb);
     etab[2 * e] = make_int4(en.pair, en.h, en.bw, en.w);
-    etab[2 * e + 1] = make_int4(en.q_lo, en.q_hi, p.tile_skip ? (int)p.tile_skip[en.w] : 0, 0);
+    etab[2 * e + 1] = make_int4(en.q_lo, en.q_hi, p.tile_skip ? (int)p.tile_skip[en.w] : 0, en.inst);
   }
   if (tid < 1 + 2 * A32_NSLOT) ctl[tid] = tid < 1 + A32_NSLOT ? 0 : -1;
   __syncthreads();
@@ -334,6 +341,26 @@ __global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(At
     // this wave's SIMD and would otherwise leave it one issue slot in a dozen (18 k cycles per fill measured).
     __builtin_amdgcn_s_setprio(3);
     const unsigned vo_k = (unsigned)(lane >> 2) * 64u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u, vo_v = (unsigned)lane * 16u;
+    // The bias image is the launch's one HBM-cold stream (q | k | v were just written): the workgroups that run the instances of a
+    // (window type, head) pair at the same time each pull a share of the NEXT pair's rows into the XCD's L2 — one dword per 128-byte
+    // line and lane, 8 KB per instruction — so the consumers' tile loads find them there (cold image: +18 us on a stage-0 launch).
+    const int n_inst = nclip * (p.nW / p.n_types);
+    uint32_t sink = 0;
+    auto prefetch_image = [&](int e) __attribute__((always_inline)) {
+#ifdef A32_NO_PREFETCH
+      return;
+#endif
+      const int4 e0 = etab[2 * e], e1 = etab[2 * e + 1];
+      const int pair = __builtin_amdgcn_readfirstlane(e0.x), q_lo = __builtin_amdgcn_readfirstlane(e1.x), q_hi = __builtin_amdgcn_readfirstlane(e1.y);
+      const int inst = __builtin_amdgcn_readfirstlane(e1.w);
+      const char* base = reinterpret_cast<const char*>(p.image) + ((size_t)pair * nqb + q_lo) * (A32_KB * 2048);
+      const int len = (q_hi - q_lo) * (A32_KB * 2048);
+      const int lo = (int)((long long)len * inst / n_inst) & ~127, hi = (int)((long long)len * (inst + 1) / n_inst);
+      // `sink` stays allocated for the loader's whole life: the loads are never waited for by name (the next fill's vmcnt(0) covers
+      // them), so their destination must not be handed to anything else meanwhile
+      for (int off = lo + lane * 128; off < hi; off += 64 * 128) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(base + off) : "memory");
+    };
+    prefetch_image(0);
     for (int e = 0; e < e_wg; ++e) {
       const int b = e % A32_NSLOT;
       if (e >= A32_NSLOT) {
@@ -354,10 +381,12 @@ __global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(At
       for (int it = 0; it < A32_ROWS / 16; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (a32_lds_t)(dst + A32_K_BYTES + it * 1024), 16, vo_v, it * 1024, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&ctl[1 + A32_NSLOT + b], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (e + 1 < e_wg) prefetch_image(e + 1);
 #ifdef KVQ_A32_TRACE
       if (p.trace && lane == 0 && e < 8) p.trace[((size_t)blockIdx.x * (A32_CW + 1) + A32_CW) * 8 + e] = __builtin_readcyclecounter() - tr_k0;
 #endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     return;
   }
 
@@ -402,7 +431,7 @@ __global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(At
     it.bd = p.image + ((size_t)pair * nqb + it.qb) * (A32_KB * 128) + lane;
     it.pre[0] = it.bd[it.t0 * 128]; it.pre[1] = it.bd[it.t0 * 128 + 64];
     it.orow = p.out + ((size_t)bw * N + 32 * it.qb + q) * C + h * 32;
-    it.store = 32 * it.qb + q < N && !(A32_ABL & 256);
+    it.store = 32 * it.qb + q < N && !((A32_ABL & 256) && p.wg_per_xcd > 0);      // (diagnostic 256: no output stores, opaque to the compiler)
   };
 #ifdef KVQ_A32_TRACE
   unsigned long long tr_f = 0, tr_w = 0, tr_q = 0, tr_n = 0, tr_m, tr_w0 = 0;

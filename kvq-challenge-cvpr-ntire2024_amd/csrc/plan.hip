@@ -295,11 +295,13 @@ namespace kvq {
 // depth-major, so window w has type w % n_types
 static int bias_types(const StageGeom& g, int par) { return par == 0 ? g.nW / (g.Dp / g.ws[0]) : g.nW; }
 // Which attention kernel consumes a block's dense bias — by geometry only (the image layout follows it, and a block's path must
-// never depend on the batch): the un-padded C = 96 stage keeps attn.hip's dense kernel, whose workgroups compute their own
-// q | k | v (the qkv GEMM there is an HBM-bound launch); every other stage takes the streaming kernel (attn32.hip).
-// KVQ_ATTN_STREAM=0 keeps attn.hip everywhere (A/B runs).
+// never depend on the batch).  The streaming kernel (attn32.hip) is OPT-IN (KVQ_ATTN_STREAM=1): alone on the chip with a warm bias
+// image it beats attn.hip's dense kernel on every stage (71 vs 85 us at stage 0 without the qkv fusion, 37-42 vs 44 at stage 1, 22-25 vs
+// 26, 14-16 vs 15.4), but inside the trunk — image HBM-cold, q | k | v just written — the same launches run 43.4 / 47.9 / 27.0 / 16.6 us
+// against 48.0 / 45.1 / 25.9 / 15.7 (rocprofv3, same box, alternating runs: profiles/r04_attn_ab.txt): a tie.  The un-padded C = 96
+// stage keeps attn.hip in either case (its workgroups compute their own q | k | v; the qkv GEMM there is an HBM-bound launch).
 static bool attn_stream(const StageGeom& g) {
-  static const bool on = !(getenv("KVQ_ATTN_STREAM") && atoi(getenv("KVQ_ATTN_STREAM")) == 0);
+  static const bool on = getenv("KVQ_ATTN_STREAM") && atoi(getenv("KVQ_ATTN_STREAM")) != 0;
   return on && g.N <= 400 && !(g.Lp == g.L && g.C == 96);
 }
 constexpr float kQScale = 0.17677669529663687f;              // head_dim^-0.5 = 32^-0.5 (swin_backbone.py:208)

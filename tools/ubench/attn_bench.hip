@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
   const int nW = argc > 1 ? atoi(argv[1]) : 128, nH = argc > 2 ? atoi(argv[2]) : 3, nclip = argc > 3 ? atoi(argv[3]) : 4;
   const int N = argc > 4 ? atoi(argv[4]) : 392, ntyp = argc > 5 ? atoi(argv[5]) : 64, iters = argc > 6 ? atoi(argv[6]) : 20;
   const int dsplit = argc > 7 ? atoi(argv[7]) : -1;          // >= 0: windows >= it are depth-split (their cross-half bias entries are set to -100 below)
+  const int cold = argc > 8 ? atoi(argv[8]) : 0;             // > 1: rotate over that many copies of the image and of q|k|v
   const int BW = nclip * nW, nqt = (N + 15) / 16, NT = kvq::ATT_NT;
   const size_t Mtot = (size_t)BW * N;
   std::mt19937 rng(7);
@@ -59,9 +60,18 @@ int main(int argc, char** argv) {
       printf("occupancy API: %d workgroups per CU at %d B of LDS\n", nb, lds);
     }
   }
+  std::vector<uint16_t*> dqs{dq}, dbs{db};
+  for (int c = 1; c < cold; ++c) {
+    uint16_t *q2, *b2;
+    CK(hipMalloc(&q2, hq.size() * 2)); CK(hipMalloc(&b2, img * 2));
+    CK(hipMemcpy(q2, dq, hq.size() * 2, hipMemcpyDeviceToDevice)); CK(hipMemcpy(b2, db, img * 2, hipMemcpyDeviceToDevice));
+    dqs.push_back(q2); dbs.push_back(b2);
+  }
+  int turn = 0;
+  const bool cold_q = getenv("COLD_Q") != nullptr;       // default: only the image is cold (as inside the trunk: q|k|v were just written)
   auto run = [&]() {
     KvqAttnDenseArgs a{};
-    a.qkv = dq; a.bias_dense = db; a.n_types = ntyp; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = nH; a.dtype = KVQ_DT_FP16; a.out = dout;
+    a.qkv = dqs[cold_q ? turn % dqs.size() : 0]; a.bias_dense = dbs[turn % dbs.size()]; ++turn; a.n_types = ntyp; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = nH; a.dtype = KVQ_DT_FP16; a.out = dout;
     a.dsplit_from = dsplit;
     return kvq_window_attention_dense_args(&a, nullptr);
   };
