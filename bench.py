@@ -58,12 +58,12 @@ def parse():
                          "measured 1 / 2 / 3 / 4 / 5 / 6 streams: 2.12 / 1.77 / 1.76 / 1.745 / 1.84 / 1.71-1.84 ms per step)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
-    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,batch8,c3,c5 ('all', 'c2' = none)")
+    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,batch8,c3,c5,ksvqe ('all', 'c2' = none)")
     ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the K-step block until this many seconds are timed")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic fields = null)")
-    ap.add_argument("--probe", default=None, choices=["c2", "c3", "c5"],
+    ap.add_argument("--probe", default=None, choices=["c2", "c3", "c5", "ksvqe", "ksvqe96"],
                     help="internal: run --probe-steps serial steps of one leg and exit (the command the --pmc passes profile)")
     ap.add_argument("--probe-steps", type=int, default=2)
     return ap.parse_args()
@@ -198,7 +198,7 @@ def timed(kd, device, fn_steps, steps, warmup, finish=None, first=None, min_s=0.
 
 
 # ---- HBM traffic, measured: child passes of this file under rocprofv3 --pmc ------------------------------------------------
-ONE_TIME_KERNELS = ("bias_dense_build_kernel", "tail_pack", "pack_", "at::native", "Cijk_", "fill_", "copyBuffer")
+ONE_TIME_KERNELS = ("bias_dense_build_kernel", "bias_stream_build_kernel", "tail_pack", "pack_", "at::native", "Cijk_", "fill_", "copyBuffer")
 
 
 def kernel_norm(name):
@@ -408,6 +408,83 @@ def leg_c3(args, device, net, src, kd, pmc):
     return out
 
 
+KSVQE_GFLOP_PER_SAMPLE = 367.8          # one 32-frame KSVQE sample (CLIP ViT-B/16 on 16 key frames + QRS + CONTRIQUE + trunk + CDM)
+
+
+def setup_ksvqe(args, device, B, T):
+    """The f1 path (KSVQE_model.py:1389-1500): CLIP visual tower + QRS + CONTRIQUE + the Swin3D-T(GRPB) trunk with CDM modulation + head,
+    B samples of T frames per forward, random-init weights of the architecture, synthetic inputs of the dataset's shapes.  Forwards of
+    consecutive batches replay recorded hipGraphs on 4 lanes, as Trainer._score_all runs the model (kvq_amd/graph.py)."""
+    import torch
+    from kvq_amd.graph import LaneGraphs
+    from kvq_amd.models import VQA_Network
+    from kvq_amd.utils import synth
+    cfg = {"model": {"type": "KSVQE", "args": {"KSVQE": {"backbone": dict(checkpoint=True, pretrained=None, num_samples=1, sample_type="topkpertubation",
+           CLIP_location=8, cls_use=True, tuning_stage=2, qls_swin=True, frozen3D=False, frozen_stages=-1),
+           "head": {"in_channels": 768, "hidden_channels": 64}}}}}
+    net = VQA_Network(cfg)
+    sd = {"KSVQE_backbone." + k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_weights(3).items()}
+    sd.update({"KSVQE_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_head_weights(768, 64, 3, "stress").items()})
+    net.load_state_dict(sd, strict=False)
+    net = net.to(device).eval()
+    net.KSVQE_backbone.aux_loss = False               # the harness discards the loss (Trainer._score_all)
+    pool = [{k: torch.from_numpy(v).to(device) for k, v in synth.synth_ksvqe_inputs(11 + i, B, T).items()} for i in range(4)]
+
+    def fwd(inputs):
+        with torch.no_grad():
+            return net(inputs=dict(inputs), reduce_scores=True)[0]
+
+    lanes = [torch.cuda.Stream(device=device) for _ in range(4)]
+    graphs = LaneGraphs(fwd, lanes)
+
+    def steps(n, first):
+        main = torch.cuda.current_stream()
+        for st in lanes:
+            st.wait_stream(main)
+        outs = []
+        for s in range(n):
+            ln = s % len(lanes)
+            o = graphs.run(ln, pool[(first + s) % len(pool)])
+            with torch.cuda.stream(lanes[ln]):
+                outs.append(o.clone())
+        for st in lanes:
+            main.wait_stream(st)
+        return outs
+
+    def serial(n):
+        for s in range(n):
+            fwd(pool[s % len(pool)])
+
+    return net, steps, serial, graphs
+
+
+def leg_ksvqe(args, device, kd, pmc, T):
+    import torch
+    B = 4 if T == 32 else 1
+    net, steps, serial, graphs = setup_ksvqe(args, device, B, T)
+    k = max(8, args.steps)
+    dt, outs, _, stats = timed(kd, device, steps, k, 8, min_s=args.min_timed_s)
+    gf = KSVQE_GFLOP_PER_SAMPLE * (T / 32.0)          # every part of the forward is linear in the frame count at fixed resolution
+    ach = gf * B * k / dt / 1e3
+    out = {"workload": f"KSVQE (f1): CLIP visual tower + QRS + CONTRIQUE + Swin3D-T(GRPB) trunk + CDM + head, {B} sample(s) of {T} frames per "
+                       "forward, hipGraph replay on 4 lanes (Trainer._score_all's path), random-init weights, synthetic inputs",
+           "value": B * k / dt, "unit": "samples/s", "steps": k, "ms_per_step": 1e3 * dt / k, "samples_per_step": B, "frames": T,
+           "dtype": "fp16", "finite": bool(torch.isfinite(torch.cat([o.reshape(-1) for o in outs])).all()),
+           "graph_replays": graphs.replays, "eager_runs": graphs.eager_runs,
+           "alg_gflop_per_sample": gf,
+           "whole_step": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                          "scope": "whole forward (all five parts), wall time over 4 lanes"}}
+    if pmc is not None:
+        out["whole_step_traffic"] = pmc.get("step_bytes") if "error" not in pmc else None
+        out["traffic_note"] = pmc.get("method") or pmc.get("error")
+        if "per_kernel" in pmc:       # the heaviest kernels by measured HBM bytes per forward
+            top = sorted(((v["bytes_per_launch"] * v["launches"], k_) for k_, v in pmc["per_kernel"].items() if "<" not in k_ and "::" not in k_), reverse=True)[:6]
+            out["traffic_by_kernel_MB_per_forward"] = {k_: round(b / pmc["steps"] / 1e6, 1) for b, k_ in top}
+    out.update(stats)
+    del net, graphs
+    return out
+
+
 def setup_c5(args, device):
     """configs[4]: Swin-B (E=128, depths 2/2/18/2, heads 4/8/16/32) on 64x256x256 clips, fp16 operands; video = 16 clips.  K1 is in
     the step: every clip is gathered as an 8 x 8 grid of 32 x 32 patches (per-8-frame offsets) out of a uint8 3x64x540x960 source."""
@@ -491,6 +568,10 @@ def run_probe(args):
         if args.probe == "c5":
             *_, serial = setup_c5(args, device)
             serial(args.probe_steps)
+        elif args.probe in ("ksvqe", "ksvqe96"):
+            T = 32 if args.probe == "ksvqe" else 96
+            _, _, serial, _ = setup_ksvqe(args, device, 4 if T == 32 else 1, T)
+            serial(args.probe_steps)       # (the one-time builder kernels of the first forward are excluded by name, ONE_TIME_KERNELS)
         else:
             net, *_ = build_net(args.dtype, device)
             B = args.batch if args.probe == "c2" else 8
@@ -542,7 +623,7 @@ def main():
     B = args.batch
     nstream = max(1, args.streams)
     lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
-    legs = {"no_sampler", "bf16", "batch8", "c3", "c5"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
+    legs = {"no_sampler", "bf16", "batch8", "c3", "c5", "ksvqe"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
     if world > 1:
         legs = set()
 
@@ -698,8 +779,9 @@ def main():
                                          "batch = 4, reported beside it"}
                 del xs8
                 torch.cuda.empty_cache()
-        for name, fn in (("c3", lambda pm: leg_c3(args, device, net, src, kd, pm)), ("c5", lambda pm: leg_c5(args, device, kd, pm))):
-            if name in legs:
+        for name, fn in (("c3", lambda pm: leg_c3(args, device, net, src, kd, pm)), ("c5", lambda pm: leg_c5(args, device, kd, pm)),
+                         ("ksvqe", lambda pm: leg_ksvqe(args, device, kd, pm, 32)), ("ksvqe96", lambda pm: leg_ksvqe(args, device, kd, pm, 96))):
+            if name in legs or (name == "ksvqe96" and "ksvqe" in legs):
                 try:
                     pm = pmc_traffic(name, 1, args.dtype, B) if want_pmc else None
                     out[name] = fn(pm)

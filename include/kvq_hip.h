@@ -360,7 +360,9 @@ int kvq_window_attention_dense_skip(const uint16_t* qkv, const void* bias_dense,
 /* The general form.  dsplit_from >= 0 (shifted blocks of the (8,7,7) window, N = 392): windows w >= dsplit_from of every clip are
  * DEPTH-SPLIT — the cyclic shift put depth positions Dp-4.. and the wrapped 0..3 into one window and the shift mask
  * (swin_backbone.py:563-579) separates the two halves of 196 tokens — so a q-tile of one half passes over the key tiles of the
- * other half, whose scores are the image's -100 and leave the exponential as exact zeros: bit-identical to dsplit_from = -1,
+ * other half, whose scores are the image's -100 and leave the exponential as exact zeros: bit-identical to dsplit_from = -1 as long
+ * as a row's logits (q.k + bias) spread by less than ~80 — exp(-100 + spread) must flush to zero, and the row maximum is taken over the
+ * row's own half only; beyond that the two launches differ in the last bits (as the reference's own -100 mask then leaks weight) —
  * 46 % fewer score tiles in those windows.  The caller vouches for the geometry (the plan derives it from the window layout). */
 typedef struct {
   const uint16_t* qkv;        /* [3][nH][BW*N][32], q pre-scaled */

@@ -268,12 +268,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void window_attention_kernel(Att
 template <typename E, bool GATED, bool MASK, bool FULL>
 static int launch_attn2(const AttnParams& p, size_t lds, hipStream_t st) {
   auto kern = window_attention_kernel<E, GATED, MASK, FULL>;
-  static size_t attr_bytes = 0;   // per instantiation: opt in to > 64 KiB of dynamic LDS once
-  if (lds > attr_bytes) {
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_bytes = lds;
-  }
+  static LdsOptIn opt;            // per instantiation and device: opt in to > 64 KiB of dynamic LDS once
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), (int)lds)) return rc;
   dim3 grid((unsigned)(p.BW * p.nH)), block(ATT_WAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);
   KVQ_CHECK_LAUNCH("window_attention_kernel");
@@ -643,7 +639,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
   // d = 0..3 into one window, the mask separates them, swin_backbone.py:563-579) only attend inside their own depth half —
   // the other half's scores are bias -100 and come out of the exponential as exact zeros — so a q-tile whose 16 queries sit in
   // one half skips the other half's key tiles (no bias fetch, no MFMA, no exp): [0, 13) or [12, 25) for the (8,7,7) window
-  // split at token 196; the q-tile that straddles token 196 takes the whole range.  Bit-identical to the full range.
+  // split at token 196; the q-tile that straddles token 196 takes the whole range.  Bit-identical to the full range while the
+  // row's logits spread by less than ~80 (the skipped scores must flush to zero in the full launch too; its row maximum could
+  // otherwise come from the other half).
   auto tile_body = [&](auto t0_tag, auto t1_tag, const V8 qf_cur) __attribute__((always_inline)) {
     constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
     static_assert(T0 % 2 == 0 && T0 >= 0 && T1 <= NTD && T0 < T1, "key tiles pair up into 32-key PV steps");
@@ -749,13 +747,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64, ATT_D_OCC) void window_attention_de
 template <typename E, bool FUSED, bool DSPLIT>
 static int launch_attn_dense_v(const AttnDenseParams& p, hipStream_t st) {
   auto kern = window_attention_dense_kernel<E, FUSED, DSPLIT>;
-  static bool attr_set = false;
+  static LdsOptIn opt;
   constexpr int lds_req = ATT_D_LDS;
-  if (!attr_set) {
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      lds_req));
-    attr_set = true;
-  }
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), lds_req)) return rc;
   const int nclip = p.BW / p.nW, npair = p.n_types * p.nH;
   dim3 grid((unsigned)(8 * ceil_div(npair, 8) * nclip * (p.nW / p.n_types) * p.qsplit)), block(ATT_WAVES * 64);
   if (p.x_ln) grid.x = (unsigned)(8 * ceil_div(p.n_types, 8) * p.nH * nclip * (p.nW / p.n_types));     // XCDs take whole window types

@@ -563,13 +563,8 @@ __global__ __launch_bounds__(256) void bias_stream_build_kernel(Stream32BuildPar
 template <typename E, bool DSPLIT>
 static int launch_attn32(const Attn32Params& p, hipStream_t st) {
   auto kern = window_attention_stream_kernel<E, DSPLIT>;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  KVQ_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, A32_LDS));
-    if (dev >= 0 && dev < 16) attr_set[dev] = true;
-  }
+  static LdsOptIn opt;
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), A32_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * p.wg_per_xcd)), dim3(A32_THREADS), A32_LDS, st, p);
   KVQ_CHECK_LAUNCH("window_attention_stream_kernel");
   return KVQ_OK;

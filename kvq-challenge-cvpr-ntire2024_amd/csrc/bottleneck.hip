@@ -220,11 +220,8 @@ template <typename E, int CIN, int CI, int COUT, bool SC, int STRIDE, int NW>
 static int launch_bneck(const BneckParams& p, hipStream_t st) {
   using L = BnLayout<CIN, CI, COUT, SC>;
   auto k = fast_bottleneck_kernel<E, CIN, CI, COUT, SC, STRIDE, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
-    attr_set = true;
-  }
+  static LdsOptIn opt;
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(k), L::LDS_BYTES)) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)((long)p.B * p.T * p.tiles_y * p.tiles_x)), dim3(NW * 64), L::LDS_BYTES, st, p);
   KVQ_CHECK_LAUNCH("fast_bottleneck_kernel");
   return KVQ_OK;

@@ -17,6 +17,15 @@ int hip_fail(hipError_t e, const char* what) {
   set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
   return KVQ_ERR_HIP;
 }
+int LdsOptIn::ensure(const void* kernel, int want) {
+  int dev = 0;
+  KVQ_CHECK_HIP(hipGetDevice(&dev));
+  const bool known = dev >= 0 && dev < 16;
+  if (known && bytes[dev] >= want) return KVQ_OK;
+  KVQ_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want));
+  if (known) bytes[dev] = want;
+  return KVQ_OK;
+}
 }  // namespace kvq
 
 extern "C" int kvq_abi_version(void) { return KVQ_ABI_VERSION; }

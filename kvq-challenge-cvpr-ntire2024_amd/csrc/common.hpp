@@ -168,6 +168,16 @@ int gemm_variant(int M, int N, int K);
 // true: kvq_gemm_bf16 takes the 256 x 256 x 64 eight-phase kernel for this shape (gemm256.hip); profile records carry tile code 4464
 bool gemm8p_wanted(int M, int N, int K);
 
+// The opt-in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel:
+// one `LdsOptIn` per kernel instantiation remembers, per device ordinal, the largest request made so far.
+struct LdsOptIn {
+  int bytes[16] = {};
+  int ensure(const void* kernel, int want);      // KVQ_OK, or the HIP failure
+};
+
+// shape limits of the fused fast-pathway stem (conv.hip::kvq_conv_stem_pool), pointer alignment aside
+bool stem_pool_shape_ok(int B, int T, int H, int W, int kd);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

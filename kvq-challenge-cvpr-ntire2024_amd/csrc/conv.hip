@@ -926,6 +926,15 @@ extern "C" int kvq_conv_stem_mfma(const uint16_t* x4, const int32_t dims4[4], co
   return KVQ_OK;
 }
 
+// the shape limits of kvq_conv_stem_pool (everything but the pointers' alignment): also asked by kvq_convnet_create, so that a plan
+// outside them is refused when it is built, not inside every forward
+bool kvq::stem_pool_shape_ok(int B, int T, int H, int W, int kd) {
+  if (!(B > 0 && T > 0 && H >= 7 && W >= 8 && kd >= 1 && kd <= 7 && (kd & 1) && W % 4 == 0)) return false;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1;
+  if (!(Wo <= 128 && (long)B * T * Hp < (1L << 30) && (long)T * H * W < (1L << 27))) return false;
+  return (size_t)SP_NR * (W + 8) * 8 + (size_t)SP_SR * Wo * 16 + (size_t)kd * 7 * 512 <= 96 * 1024;
+}
+
 extern "C" int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const uint16_t* wpack, const float* bias8, int kd, int relu,
                                   int dtype, uint16_t* out, void* stream) {
   using namespace kvq;
@@ -943,8 +952,8 @@ extern "C" int kvq_conv_stem_pool(const float* x, const int32_t dims5[5], const 
   const size_t lds = (size_t)SP_NR * (p.W + 8) * 8 + (size_t)SP_SR * p.Wo * 16 + (size_t)kd * 7 * 512;
   KVQ_REQUIRE(lds <= 96 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_conv_stem_pool: %zu B of LDS", lds);
   auto launch = [&](auto kern) -> int {
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); set = true; }
+    static LdsOptIn opt;
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), 96 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ceil_div(ceil_div(p.Hp, SP_PR) * p.T * p.B, 8))), dim3(256), lds, (hipStream_t)stream, p);
     return KVQ_OK;
   };
@@ -972,8 +981,8 @@ extern "C" int kvq_conv_stem64_pool(const float* x, const int32_t dims5[5], cons
   KVQ_REQUIRE((long)p.B * p.F * p.Hp < (1L << 30), KVQ_ERR_UNSUPPORTED, "kvq_conv_stem64_pool: %d clips x %d frames", p.B, p.F);
   const size_t lds = (size_t)S6_NR * (p.W + 8) * 8 + (size_t)S6_PR * p.Wo * 128 + (size_t)3 * S6_ITEMS * S6_THREADS * 16 + 7 * 64 * 64;
   auto launch = [&](auto kern) -> int {
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); set = true; }
+    static LdsOptIn opt;
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), 144 * 1024)) return rc;
     const int total = ceil_div(p.Hp, S6_PR) * p.F * p.B;          // one persistent workgroup per CU (256 on gfx950)
     hipLaunchKernelGGL(kern, dim3((unsigned)std::min(total, 256)), dim3(S6_THREADS), lds, (hipStream_t)stream, p);
     return KVQ_OK;
@@ -1085,11 +1094,14 @@ extern "C" int kvq_mean_std_pool(const uint16_t* x, int dtype, int rows, int HW,
   KVQ_REQUIRE(x && out, KVQ_ERR_NULL, "kvq_mean_std_pool: NULL pointer");
   KVQ_REQUIRE(dtype == KVQ_DT_BF16 || dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_mean_std_pool: dtype %d", dtype);
   KVQ_REQUIRE(rows > 0 && HW > 0 && C > 0 && (std_off < 0 || HW > 1), KVQ_ERR_SHAPE, "kvq_mean_std_pool: bad shape");
-  const bool narrow = (long)rows * ceil_div(C, 64) < 128 && HW >= 256;
+  // The kernel (and with it the order the positions are summed in) is chosen from HW, C and the pointer's alignment ONLY — never
+  // from `rows`, which is the batch in the extractors' head pools: a clip's features must not change in their last bits with what
+  // else shares the launch (kvq_convnet_splitk is off there for the same reason).
   hipStream_t st = (hipStream_t)stream;
-  // 16-byte loads, a block per 8 channels: few rows x thousands of positions (KSVQE), or a few hundred positions when 64-channel
-  // blocks would leave most of the chip idle (SlowFast's slow head pool: 8 rows x 392 positions x 2048 channels: 45.8 -> 8 us)
-  const bool wide = C % 8 == 0 && ((size_t)x & 15) == 0 && ((narrow && HW >= 1024) || (HW >= 256 && (long)rows * ceil_div(C, 64) < 1024));
+  // 16-byte loads, a block per 8 channels: maps of >= 256 positions (KSVQE: 4 rows x 3136 positions; SlowFast's slow head pool:
+  // 8 rows x 392 positions x 2048 channels, 45.8 -> 8 us); 16-channel tiles when the channels cannot be taken 8 at a time
+  const bool wide = C % 8 == 0 && ((size_t)x & 15) == 0 && HW >= 256;
+  const bool narrow = HW >= 256;
   if (wide) {
     dim3 g8(rows, C / 8);
     if (dtype == KVQ_DT_FP16) hipLaunchKernelGGL(mean_std_pool_vec8_kernel<Fp16>, g8, dim3(256), 0, st, x, HW, C, out, (long)out_stride, mean_off, std_off);

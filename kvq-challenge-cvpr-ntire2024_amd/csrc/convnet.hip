@@ -246,6 +246,9 @@ extern "C" int kvq_convnet_create(const KvqNetOp* ops, int n_ops, const KvqNetTe
         NET_REQUIRE(p.cout == 8 && p.kernel3[1] == 7 && p.kernel3[2] == 7 && p.stride3[0] == 1 && p.stride3[1] == 2 && p.stride3[2] == 2 &&
                         p.pad3[0] == p.kernel3[0] / 2 && p.pad3[1] == 3 && p.pad3[2] == 3 && (p.kernel3[0] & 1),
                     "kvq_convnet_create: op %d (stem + pool) geometry", i);
+        NET_REQUIRE(stem_pool_shape_ok(s.B, s.D, s.H, s.W, p.kernel3[0]),
+                    "kvq_convnet_create: op %d (stem + pool): clip %d x %d x %d with a %d-frame kernel is outside the fused stem's limits (W %% 4 == 0, "
+                    "W <= 256, temporal kernel <= 7, 96 KB of LDS)", i, s.D, s.H, s.W, p.kernel3[0]);
         o.Do = s.D; o.Ho = ((s.H - 1) / 2 + 1 - 1) / 2 + 1; o.Wo = ((s.W - 1) / 2 + 1 - 1) / 2 + 1;
         NET_REQUIRE(d.B == s.B && d.D == o.Do && d.H == o.Ho && d.W == o.Wo && d.C == 8, "kvq_convnet_create: op %d (stem + pool) output shape", i);
         break;

@@ -309,12 +309,9 @@ static int launch_one(const GemmParams& p_in, hipStream_t st) {
   constexpr size_t epi_bytes = 2 * WN * 32 * (32 * NI) * sizeof(float);     // one fp32 slab per wave
   constexpr size_t lds_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   auto kern = gemm_kernel<E, MI, NI, BK, EPI, NST, IMPL, WALK>;
-  static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
-  if (!attr_set && lds_bytes > 64 * 1024) {
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  static LdsOptIn opt;            // > 64 KiB of LDS needs the opt-in attribute (once per instantiation and device)
+  if (lds_bytes > 64 * 1024)
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), (int)lds_bytes)) return rc;
   dim3 grid(ceil_div(p.M, BM) * ceil_div(p.N, BN) * p.ksplit), block(128 * WN);
   hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
   KVQ_CHECK_LAUNCH("gemm_kernel");

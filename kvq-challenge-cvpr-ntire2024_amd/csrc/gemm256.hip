@@ -59,11 +59,8 @@ int launch_gemm8p(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   p.ksplit = p.ksplit < 1 ? 1 : p.ksplit;
   auto kern = gemm8p_kernel<E, EPI>;
-  static bool attr_set = false;   // > 64 KiB of LDS needs the opt-in attribute (one-time, per instantiation)
-  if (!attr_set) {
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES));
-    attr_set = true;
-  }
+  static LdsOptIn opt;            // > 64 KiB of LDS needs the opt-in attribute (once per instantiation and device)
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), g8::LDS_BYTES)) return rc;
   dim3 grid(ceil_div(p.M, g8::BM) * ceil_div(p.N, g8::BN) * p.ksplit), block(512);
   hipLaunchKernelGGL(kern, grid, block, g8::LDS_BYTES, st, p);
   KVQ_CHECK_LAUNCH("gemm8p_kernel");

@@ -57,7 +57,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, si
 }
 
 // Operand source of the main loop.  Plain row-major [rows][K] operands: voffset = row * K * 2 + chunk * 16, the K position
-// is the scalar offset.  (The implicit-GEMM source lives in gemm256.hip.)
+// is the scalar offset.  (An implicit-convolution source would plug in here: same issue<H>() / advance() interface; none exists yet.)
 struct PlainSrc {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned vo[2][2];                          // [half][q] per-lane byte offsets

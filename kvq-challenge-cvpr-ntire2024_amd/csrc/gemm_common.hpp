@@ -177,8 +177,8 @@ struct GemmEpilogue {
   }
 };
 
-// gemm256.hip: the 256 x 256 x 64 eight-phase kernel behind the same parameters.  eligible(): K % 64 == 0, no a_gather / taps /
-// split-K (checked by the caller through gemm8p_wanted()).
+// gemm256.hip: the 256 x 256 x 64 eight-phase kernel behind the same parameters (a_gather and split-K included; no conv taps).
+// The caller asks gemm8p_wanted() for the shapes that take it: K % 64 == 0, K >= 256, a tile grid that fills the chip.
 template <typename E, int EPI>
 int launch_gemm8p(const GemmParams& p, hipStream_t st);
 

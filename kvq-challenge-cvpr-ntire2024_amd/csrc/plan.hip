@@ -30,7 +30,6 @@ struct StageGeom {
   int32_t* d_skip[2]; // [nW] bit t: rows 16t..16t+15 of the window are padding only (attention passes such q-tiles over), or nullptr
   int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row).  A bijection — the next block's norm1 rows can be EMITTED through it —
                       // only when Lp == L (no padding)
-  int32_t* d_iota;    // [L] identity (padded partitions: the next block's norm1 rows are emitted in TOKEN order), or nullptr
   int32_t* d_tok[2];  // [nW*N][2]
   int32_t* d_merge;   // [L_next][4] or nullptr
   int Dn, Hn, Wn;     // dims after the merge
@@ -146,13 +145,6 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
     rc = upload(pl, dst, &g.d_dst[par]);
     if (rc) return rc;
     g.d_skip[par] = nullptr;
-    if (par == 0) g.d_iota = nullptr;
-    if (!pad.empty() && !g.d_iota) {
-      std::vector<int32_t> iota((size_t)g.L);
-      for (int i = 0; i < g.L; ++i) iota[i] = i;
-      rc = upload(pl, iota, &g.d_iota);
-      if (rc) return rc;
-    }
     if (!pad.empty()) {
       rc = upload(pl, pad, &g.d_pad[par]);
       if (rc) return rc;
@@ -571,7 +563,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         const int npar = ((b + 1) & 1) && g.shifted_any ? 1 : 0;
         if (g.Lp != g.L) ta.attn_gather = g.d_dst[par];      // padded windows: walk the tokens, not the window rows
         // the next block's norm1 rows in ITS window order (un-padded partitions: token -> window row is a bijection).  Padded
-        // partitions could take them in token order (identity map d_iota; measured on C5: 19 LayerNorm launches / 0.51 ms saved,
+        // partitions could take them in token order (through an identity map; measured on C5: 19 LayerNorm launches / 0.51 ms saved,
         // but the emitting form of the C = 512 tail costs +25 us per launch (it spills): 12.9 vs 13.0 ms serial, 20.9 vs 21.2-22.0
         // videos/s with two steps in flight) — not taken.
         const int32_t* nmap = g.Lp == g.L ? g.d_dst[npar] : nullptr;

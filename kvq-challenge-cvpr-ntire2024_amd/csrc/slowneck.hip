@@ -249,8 +249,8 @@ extern "C" int kvq_slow_bottleneck(const uint16_t* x, const int32_t dims4[4], in
   const long blocks = (long)p.B * p.T * p.tiles_y * p.tiles_x;
   KVQ_REQUIRE(blocks < (1L << 31), KVQ_ERR_UNSUPPORTED, "kvq_slow_bottleneck: %ld tiles", blocks);
   auto launch = [&](auto kern) -> int {
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SN_LDS_BYTES)); set = true; }
+    static LdsOptIn opt;
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), SN_LDS_BYTES)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SN_WAVES * 64), SN_LDS_BYTES, (hipStream_t)stream, p);
     return KVQ_OK;
   };

@@ -468,13 +468,13 @@ static int launch_mm_cf(const TailParams& p, hipStream_t st) {
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
   if (p.next_ln) {
     auto k = block_tailmm_kernel<E, true, CF>;
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
+    static LdsOptIn opt;
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   } else {
     auto k = block_tailmm_kernel<E, false, CF>;
-    static bool set = false;
-    if (!set) { KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set = true; }
+    static LdsOptIn opt;
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   }
   KVQ_CHECK_LAUNCH("block_tailmm_kernel");

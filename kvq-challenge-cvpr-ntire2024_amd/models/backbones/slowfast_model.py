@@ -12,6 +12,8 @@ from __future__ import annotations
 import os
 from collections import OrderedDict
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -103,13 +105,15 @@ def pack_pathway_output(frames, device=None):
     out = [slow if device is None else slow.to(device), frames if device is None else frames.to(device)]
     # provenance tag: slowfast.forward may re-select the slow frames on the device (one C call for the whole network) ONLY for a
     # slow tensor that IS this selection of that fast tensor; any other slow tensor is consumed as given, like the reference does
-    out[0]._kvq_packed_of = (out[1].data_ptr(), out[1]._version, tuple(out[1].shape))
+    # (the fast tensor by identity — a weak reference, so a freed tensor whose address is reused cannot match — plus both tensors'
+    # versions: an in-place edit of either after the packing makes the pair an ordinary one)
+    out[0]._kvq_packed_of = (weakref.ref(out[1]), out[1]._version, out[0]._version)
     return out
 
 
 def _is_packed_pair(slow_in, fast_in):
     tag = getattr(slow_in, "_kvq_packed_of", None)
-    return tag is not None and tag == (fast_in.data_ptr(), fast_in._version, tuple(fast_in.shape))
+    return tag is not None and tag[0]() is fast_in and tag[1] == fast_in._version and tag[2] == slow_in._version
 
 
 def head_pool_kernel(pathway, T):

@@ -211,12 +211,34 @@ def attention_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], w
     return bias
 
 
-def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 64, rq=_ident) -> torch.Tensor:
+def image_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], window, layout) -> torch.Tensor:
+    """The additive term as the HIP kernels' pre-built bias image stores it (csrc/attn.hip bias_dense_build_kernel, csrc/attn32.hip
+    bias_stream_build_kernel): per query row the table bias minus its maximum over the un-masked keys, masked entries REPLACED by
+    -100 (minus the same shift), everything rounded to fp16.  Softmax is invariant to the per-row shift, so what this emulates is the
+    image's 2^-11 relative rounding of (bias - row maximum) — test infrastructure for the kernels' tolerance, not a reference path."""
+    N, nW, nH = layout["N"], layout["nW"], rpb_table.shape[1]
+    rpi = _t(rel_pos_index(window, N)).reshape(-1)
+    rpb = rpb_table[rpi].reshape(N, N, nH).permute(2, 0, 1)
+    if fpb_table is not None:
+        g = _t(frag_gate(layout)).to(torch.float32)
+        fpb = fpb_table[rpi].reshape(N, N, nH).permute(2, 0, 1)
+        bias = rpb[None] * g[:, None] + fpb[None] * (1.0 - g[:, None])
+    else:
+        bias = rpb[None].expand(nW, -1, -1, -1).clone()
+    m = shift_mask(layout)
+    masked = torch.zeros(nW, 1, N, N, dtype=torch.bool) if m is None else (_t(m)[:, None] != 0)
+    shift = bias.masked_fill(masked, float("-inf")).max(-1, keepdim=True).values
+    img = torch.where(masked, torch.full_like(bias, -100.0), bias) - shift
+    return img.to(torch.float16).to(torch.float32)
+
+
+def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 64, rq=_ident, image: bool = False) -> torch.Tensor:
     """q (pre-scaled), k, v: (B*nW, nH, N, hd) -> (B*nW, N, nH*hd).  ``rq`` rounds the un-normalised
-    probabilities the way the kernel does (P is an MFMA operand); identity = exact softmax."""
+    probabilities the way the kernel does (P is an MFMA operand); identity = exact softmax.  ``image``: the bias as the kernels'
+    fp16 image holds it (``image_bias``) instead of the exact fp32 term."""
     BW, nH, N, hd = q.shape
     nW = layout["nW"]
-    bias = attention_bias(rpb_table, fpb_table, window, layout)
+    bias = image_bias(rpb_table, fpb_table, window, layout) if image else attention_bias(rpb_table, fpb_table, window, layout)
     out = torch.empty(BW, N, nH * hd, dtype=q.dtype)
     widx = torch.arange(BW) % nW
     for s in range(0, BW, chunk):

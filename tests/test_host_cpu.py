@@ -129,3 +129,22 @@ def test_reference_named_datasets_parse_like_the_reference(tmp_path, capsys):
         open_video(str(tmp_path / "missing.mp4"))
     with pytest.raises(NotImplementedError):
         ViewDecompositionDataset_KVQ(dict(anno_file=[], data_prefix="", phase="train", sample_types={}))
+
+
+def test_pack_pathway_output_provenance_tag():
+    """slowfast.forward re-selects the slow frames on the device only for a slow tensor that IS pack_pathway_output's selection of
+    that very fast tensor: an in-place edit of either tensor, or another tensor at the same address, makes the pair an ordinary one
+    (the reference consumes slow as given, SlowFast_features.py:112-135)."""
+    import torch
+    from kvq_amd.models.backbones import slowfast_model as sf
+    frames = torch.arange(2 * 3 * 32 * 4 * 4, dtype=torch.float32).reshape(2, 3, 32, 4, 4)
+    slow, fast = sf.pack_pathway_output(frames)
+    assert sf._is_packed_pair(slow, fast) and slow.shape[2] == 8
+    assert not sf._is_packed_pair(slow, fast.clone())                 # same values, another tensor
+    other = sf.pack_pathway_output(frames.clone())
+    assert not sf._is_packed_pair(slow, other[1]) and not sf._is_packed_pair(other[0], fast)
+    slow.mul_(2.0)                                                    # the caller edited the slow pathway: consume it as given
+    assert not sf._is_packed_pair(slow, fast)
+    slow2, fast2 = sf.pack_pathway_output(frames)
+    fast2.add_(1.0)
+    assert not sf._is_packed_pair(slow2, fast2)

@@ -584,3 +584,9 @@ def test_extractor_features_do_not_depend_on_the_batch():
     alone = extract_video(m, clips, "cuda", batch=1)
     for (s8, f8), (s1, f1) in zip(together, alone):
         assert np.array_equal(s8, s1) and np.array_equal(f8, f1)
+    # a batch past every row-count threshold the pools ever had (the (mean, std) head pools chose their kernel — and with it the
+    # summation order — from rows x channels until round 4): 40 clips in one forward against the same clips alone
+    many = clips * 8
+    big = extract_video(m, many, "cuda", batch=40)
+    for i, (s40, f40) in enumerate(big):
+        assert np.array_equal(s40, alone[i % 5][0]) and np.array_equal(f40, alone[i % 5][1])
