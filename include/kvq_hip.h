@@ -399,6 +399,11 @@ size_t kvq_attn_bias_stream_bytes(int n_types, int N, int num_heads);
 int kvq_attn_bias_stream_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
                                int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
 int kvq_window_attention_stream(const KvqAttnDenseArgs* host_args, void* stream);
+/* The same 32-query block body inside kvq_window_attention_dense_args' launch geometry (csrc/attn32.hip, "per-unit" form): one workgroup
+ * of four waves per (window, head, clip[, q-part]), three per CU, K | V staged by LDS-DMA in the prologue, q-blocks from an LDS ticket —
+ * and the fused qkv projection (x_ln / w_qkv / b_qkv as in KvqAttnDenseArgs; q_scale = head_dim^-0.5 * log2(e); C = 96).  Image and q
+ * scaling as kvq_window_attention_stream.  The trunk's default. */
+int kvq_window_attention_unit32(const KvqAttnDenseArgs* host_args, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

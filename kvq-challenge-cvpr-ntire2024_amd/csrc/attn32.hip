@@ -112,7 +112,7 @@ __device__ __forceinline__ A32Entry a32_decode(const Attn32Params& p, int xcd, i
 // One 32-query block against the key blocks [T0, T1) of the ring slot at `slot`.  Compile-time range: the score / probability /
 // bias registers rotate through statically indexed sets.
 template <typename E, int T0, int T1>
-__device__ __forceinline__ void a32_qblock(const Attn32Params& p, const unsigned char* slot, const int zero, const u32x4* bd, const typename E::v8 qf0,
+__device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int zero, const u32x4* bd, const typename E::v8 qf0,
                                            const typename E::v8 qf1, const u32x4 (&pre)[2], uint16_t* orow, const bool store) {
   using V8 = typename E::v8;
   static_assert(T0 >= 0 && T0 < T1 && T1 <= A32_KB, "key block range");
@@ -454,10 +454,10 @@ __global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(At
       const unsigned char* slot = smem + b * A32_SLOT;
       const int zero = (A32_OFF_ZERO - b * A32_SLOT) >> 4;
       if (DSPLIT && p.dsplit_from >= 0 && it.w >= p.dsplit_from && it.qb != 6) {
-        if (it.qb < 6) a32_qblock<E, 0, 7>(p, slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
-        else a32_qblock<E, 6, A32_KB>(p, slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
+        if (it.qb < 6) a32_qblock<E, 0, 7>(slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
+        else a32_qblock<E, 6, A32_KB>(slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
       } else {
-        a32_qblock<E, 0, A32_KB>(p, slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
+        a32_qblock<E, 0, A32_KB>(slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
       }
     }
     asm volatile("" ::: "memory");
@@ -482,6 +482,198 @@ __global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(At
     t[0] = __builtin_readcyclecounter() - tr_0; t[1] = tr_f; t[2] = tr_w; t[3] = tr_q; t[4] = tr_n; t[5] = tr_w0; t[6] = tr_0 - tr_k0;
   }
 #endif
+}
+
+// ================================================================================================================================
+// The per-unit form: the same 32-query block body inside attn.hip's launch geometry — one workgroup of 4 waves per (window, head,
+// clip[, q-part]), three of them per CU (52 KB of LDS each), K | V staged once by LDS-DMA in the prologue, q-blocks pulled from an LDS
+// ticket.  The persistent form above wins alone on the chip; inside the trunk (the bias image HBM-cold, few units at the late stages)
+// the short-lived workgroups of this form overlap each other's prologues and memory stalls as attn.hip's do.  FUSED (C = 96): the
+// workgroup computes its own q | k | v from the window's norm1 rows (swin_backbone.py:252-260), k / v straight into the LDS images.
+constexpr int A32U_WAVES = 4;
+constexpr int A32U_OFF_ZERO = A32_SLOT;                    // K | V rows 0..399, then the zero block, then the ticket
+constexpr int A32U_OFF_CTR = A32U_OFF_ZERO + 1024;
+constexpr int A32U_LDS = A32U_OFF_CTR + 16;                // 52 240 B: three workgroups per CU
+
+struct Attn32UnitParams {
+  const uint16_t* qkv;
+  const u32x4* image;
+  int BW, nW, N, nH, n_types, qsplit;
+  uint16_t* out;
+  const uint32_t* tile_skip;
+  int dsplit_from;
+  // fused qkv projection (x_ln != NULL)
+  const uint16_t* x_ln;        // [BW*N][C] 16-bit, window order
+  const uint16_t* w_qkv;       // [3C][C]
+  const float* b_qkv;          // [3C]
+  float q_scale;               // head_dim^-0.5 * log2(e)
+  uint16_t* q_out;             // = the q third of qkv
+};
+
+// q | k | v of one (window, head) from the window's norm1 rows (C = 32 KS): D^T[feature][row] = W[feature][:] . x[row][:] on
+// v_mfma_f32_16x16x32 — a lane ends up with 4 consecutive features of one row: + bias (q: x q_scale), the 16-bit rounding the qkv GEMM's
+// epilogue applies, then 8 bytes into the K image (rows of 64 B, 16-B chunks XOR-swizzled by (row >> 2) & 3), the V image (plain rows) or
+// the q scratch.  Wave w takes row tiles w, w + 4, ...; all six 16-feature column tiles (q0 q1 k0 k1 v0 v1) in one pass over the rows.
+template <typename E, int KS>
+__device__ __forceinline__ void a32_fused_qkv(const Attn32UnitParams& p, unsigned char* slot, int bw, int h, int N) {
+  using V8 = typename E::v8;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = KS * 32;
+  const size_t Mtot = (size_t)p.BW * N;
+  const uint16_t* xw = p.x_ln + (size_t)bw * N * C;
+  uint16_t* qo = p.q_out + ((size_t)h * Mtot + (size_t)bw * N) * 32;
+  V8 wf[6][KS];
+  float bias[6][4];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int which = c >> 1, half = c & 1, frow = which * C + h * 32 + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[c][ks] = *reinterpret_cast<const V8*>(p.w_qkv + (size_t)(frow + j) * C + 32 * ks + 8 * g);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b_qkv + frow + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[c][r] = b4[r];
+  }
+  const int nrt = (N + 15) / 16;
+  V8 xn[KS];
+  {
+    const int rowc = min(16 * wave + j, N - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
+  }
+#pragma unroll 1
+  for (int rt = wave; rt < nrt; rt += A32U_WAVES) {
+    const int row = 16 * rt + j;
+    V8 xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = xn[ks];
+    if (rt + A32U_WAVES < nrt) {                                   // the next tile's rows are requested before this one is multiplied
+      const int rowc = min(row + 16 * A32U_WAVES, N - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int which = c >> 1, half = c & 1;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = E::mfma16(wf[c][ks], xf[ks], acc);
+      const float sc = which == 0 ? p.q_scale : 1.f;
+      const u32x2 v = {E::pack2((acc[0] + bias[c][0]) * sc, (acc[1] + bias[c][1]) * sc),
+                       E::pack2((acc[2] + bias[c][2]) * sc, (acc[3] + bias[c][3]) * sc)};
+      if (row < N) {
+        if (which == 0) {
+          *reinterpret_cast<u32x2*>(qo + (size_t)row * 32 + half * 16 + 4 * g) = v;
+        } else if (which == 1) {                                   // features 16 half + 4g ..: chunk 2 half + (g >> 1), 8 bytes into it
+          *reinterpret_cast<u32x2*>(slot + row * 64 + (((2 * half + (g >> 1)) ^ ((row >> 2) & 3)) << 4) + (g & 1) * 8) = v;
+        } else {
+          *reinterpret_cast<u32x2*>(slot + A32_K_BYTES + row * 64 + (16 * half + 4 * g) * 2) = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename E, bool FUSED, bool DSPLIT>
+__global__ __launch_bounds__(A32U_WAVES * 64, 3) void window_attention_unit32_kernel(Attn32UnitParams p) {
+  fp16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* ticket = reinterpret_cast<int*>(smem + A32U_OFF_CTR);
+  using V8 = typename E::v8;
+  // Block order as attn.hip's dense kernel: the workgroups that share one (window type, head) bias run on the SAME XCD back to back
+  // (workgroup b -> XCD b % 8); FUSED: an XCD takes whole window types, heads fastest (they read the same norm1 rows).
+  const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH, per_pair = nclip * nrep * p.qsplit;
+  const int xcd = blockIdx.x & 7, slot_i = blockIdx.x >> 3;
+  int pair, clip, rep, part;
+  if (FUSED) {
+    const int per_type = p.nH * nclip * nrep, wt_ = (slot_i / per_type) * 8 + xcd, sub = slot_i % per_type;
+    if (wt_ >= p.n_types) return;
+    const int h_ = sub % p.nH, rest = sub / p.nH;
+    pair = wt_ * p.nH + h_; clip = rest % nclip; rep = rest / nclip; part = 0;
+  } else {
+    const int sub = slot_i % per_pair;
+    pair = (slot_i / per_pair) * 8 + xcd;
+    clip = sub % nclip; rep = (sub / nclip) % nrep; part = sub / (nclip * nrep);
+  }
+  if (pair >= npair) return;
+  const int wt = pair / p.nH, h = pair - wt * p.nH, w = rep * p.n_types + wt, bw = clip * p.nW + w;
+  const int tid = threadIdx.x, lane = tid & 63, N = p.N, nqb = (N + 31) >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t Mtot = (size_t)p.BW * N;
+  const int C = p.nH * 32;
+  const uint16_t* Qg = p.qkv + ((size_t)h * Mtot + (size_t)bw * N) * 32;
+
+  if (tid < 64) *reinterpret_cast<u32x4*>(smem + A32U_OFF_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (FUSED) {
+    // rows N..399 of both images: zeros (the projection writes rows < N only)
+    for (int i = tid; i < (A32_ROWS - N) * 8; i += A32U_WAVES * 64)
+      *reinterpret_cast<u32x4*>(smem + (i & 4 ? A32_K_BYTES : 0) + (N + (i >> 3)) * 64 + (i & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    a32_fused_qkv<E, 3>(p, smem, bw, h, N);
+  } else {
+    // K | V by buffer-resource LDS-DMA (rows past N read zeros): K with its 16-B chunks XOR-swizzled by (row >> 2) & 3, V as it lies
+    const uint16_t* Kg = p.qkv + ((size_t)(1 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
+    const uint16_t* Vg = p.qkv + ((size_t)(2 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Kg), 0, N * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Vg), 0, N * 64, 0x00020000);
+    const unsigned vo_k = (unsigned)(lane >> 2) * 64u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u, vo_v = (unsigned)lane * 16u;
+    for (int it = wave; it < A32_ROWS / 16; it += A32U_WAVES) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (a32_lds_t)(smem + it * 1024), 16, vo_k, it * 1024, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (a32_lds_t)(smem + A32_K_BYTES + it * 1024), 16, vo_v, it * 1024, 0, 0);
+    }
+  }
+  const int q_lo = part * nqb / p.qsplit, q_hi = (part + 1) * nqb / p.qsplit;
+  if (tid == 0) *ticket = q_lo;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int q = lane & 31, hi = lane >> 5;
+  const uint32_t skip = p.tile_skip ? p.tile_skip[w] : 0u;
+  auto take = [&]() -> int {
+    int t_;
+    do {                                                        // q-blocks whose two 16-row tiles are padding only are passed over
+      t_ = 0;
+      if (lane == 0) t_ = atomicAdd(ticket, 1);
+      t_ = __builtin_amdgcn_readfirstlane(t_);
+    } while (t_ < q_hi && ((skip >> (2 * t_)) & 1u) && (((skip >> (2 * t_ + 1)) & 1u) || 32 * t_ + 16 >= N));
+    return t_;
+  };
+  const bool dsplit = DSPLIT && p.dsplit_from >= 0 && w >= p.dsplit_from;
+  const u32x4* img = p.image + (size_t)pair * nqb * (A32_KB * 128) + lane;
+  // the ticket, the q fragments and the first bias tile of the NEXT q-block are requested while this one is computed
+  struct Req { V8 qf0, qf1; u32x4 pre[2]; };
+  auto request = [&](int qb, Req& r) __attribute__((always_inline)) {
+    const int qrow = min(32 * qb + q, N - 1);
+    r.qf0 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 8 * hi);
+    r.qf1 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 16 + 8 * hi);
+    const int t0 = (dsplit && qb > 6) ? 6 : 0;
+    const u32x4* bd = img + (size_t)min(qb, nqb - 1) * (A32_KB * 128) + t0 * 128;
+    r.pre[0] = bd[0]; r.pre[1] = bd[64];
+  };
+  auto run = [&](int qb, const Req& r) __attribute__((always_inline)) {
+    const u32x4* bd = img + (size_t)qb * (A32_KB * 128);
+    uint16_t* orow = p.out + ((size_t)bw * N + 32 * qb + q) * C + h * 32;
+    const bool store = 32 * qb + q < N;
+    const int zero = A32U_OFF_ZERO >> 4;
+    // depth-split window (N = 392, halves of 196 tokens): q-blocks 0..5 see key blocks 0..6, 7..12 see 6..12, q-block 6 all of them
+    if (dsplit && qb != 6) {
+      if (qb < 6) a32_qblock<E, 0, 7>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
+      else a32_qblock<E, 6, A32_KB>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
+    } else {
+      a32_qblock<E, 0, A32_KB>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
+    }
+  };
+  Req ra, rb;
+  int qa = take(), qbn;
+  if (qa < q_hi) request(qa, ra);
+  while (qa < q_hi) {
+    qbn = take();
+    if (qbn < q_hi) request(qbn, rb);
+    run(qa, ra);
+    if (qbn >= q_hi) break;
+    qa = take();
+    if (qa < q_hi) request(qa, ra);
+    run(qbn, rb);
+  }
 }
 
 // The image builder (one workgroup per (window type, head)): attn.hip's bias arithmetic — idx = code_q - code_k + center,
@@ -570,6 +762,25 @@ static int launch_attn32(const Attn32Params& p, hipStream_t st) {
   return KVQ_OK;
 }
 
+template <typename E, bool FUSED, bool DSPLIT>
+static int launch_unit32(const Attn32UnitParams& p, hipStream_t st) {
+  auto kern = window_attention_unit32_kernel<E, FUSED, DSPLIT>;
+  static LdsOptIn opt;
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), A32U_LDS)) return rc;
+  const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH;
+  unsigned grid = (unsigned)(8 * ceil_div(npair, 8) * nclip * nrep * p.qsplit);
+  if (FUSED) grid = (unsigned)(8 * ceil_div(p.n_types, 8) * p.nH * nclip * nrep);      // XCDs take whole window types
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(A32U_WAVES * 64), A32U_LDS, st, p);
+  KVQ_CHECK_LAUNCH("window_attention_unit32_kernel");
+  return KVQ_OK;
+}
+
+template <typename E>
+static int launch_unit32_e(const Attn32UnitParams& p, hipStream_t st) {
+  if (p.x_ln) return p.dsplit_from >= 0 ? launch_unit32<E, true, true>(p, st) : launch_unit32<E, true, false>(p, st);
+  return p.dsplit_from >= 0 ? launch_unit32<E, false, true>(p, st) : launch_unit32<E, false, false>(p, st);
+}
+
 }  // namespace kvq
 
 extern "C" size_t kvq_attn_bias_stream_bytes(int n_types, int N, int num_heads) {
@@ -620,4 +831,34 @@ extern "C" int kvq_window_attention_stream(const KvqAttnDenseArgs* a, void* stre
   if (a->dtype == KVQ_DT_FP16)
     return p.dsplit_from >= 0 ? launch_attn32<Fp16, true>(p, st) : launch_attn32<Fp16, false>(p, st);
   return p.dsplit_from >= 0 ? launch_attn32<Bf16, true>(p, st) : launch_attn32<Bf16, false>(p, st);
+}
+
+extern "C" int kvq_window_attention_unit32(const KvqAttnDenseArgs* a, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(a && a->qkv && a->bias_dense && a->out, KVQ_ERR_NULL, "kvq_window_attention_unit32: NULL pointer");
+  const int BW = a->BW, nW = a->nW, N = a->N, num_heads = a->num_heads, n_types = a->n_types;
+  KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
+              "kvq_window_attention_unit32: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
+  KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_unit32: window of %d tokens unsupported (1..400)", N);
+  KVQ_REQUIRE(((size_t)a->bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_unit32: the bias image must be 16-byte aligned");
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_unit32: dtype %d", a->dtype);
+  KVQ_REQUIRE(a->dsplit_from < 0 || (N == 392 && a->dsplit_from < nW), KVQ_ERR_UNSUPPORTED,
+              "kvq_window_attention_unit32: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
+  const int units = BW * num_heads, nqb = (N + 31) / 32;
+  int qsplit = units >= 768 ? 1 : 768 / units;        // 768 = 256 CUs x 3 resident workgroups
+  qsplit = qsplit > 4 ? 4 : qsplit;
+  qsplit = qsplit > nqb ? nqb : qsplit;
+  Attn32UnitParams p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
+                     a->dsplit_from < 0 ? -1 : a->dsplit_from};
+  if (a->x_ln) {
+    const int C = 32 * num_heads;
+    KVQ_REQUIRE(a->w_qkv && a->b_qkv, KVQ_ERR_NULL, "kvq_window_attention_unit32: x_ln without w_qkv / b_qkv");
+    KVQ_REQUIRE(C == 96, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_unit32: the fused qkv projection is built for C = 96 (got %d)", C);
+    KVQ_REQUIRE((((size_t)a->x_ln | (size_t)a->w_qkv | (size_t)a->b_qkv) & 15) == 0, KVQ_ERR_SHAPE,
+                "kvq_window_attention_unit32: x_ln / w_qkv / b_qkv must be 16-byte aligned");
+    p.qsplit = 1;       // one workgroup per (window, head) whatever the batch: a block's path must not depend on what shares the launch
+    p.x_ln = a->x_ln; p.w_qkv = a->w_qkv; p.b_qkv = a->b_qkv; p.q_scale = a->q_scale; p.q_out = const_cast<uint16_t*>(a->qkv);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return a->dtype == KVQ_DT_FP16 ? launch_unit32_e<Fp16>(p, st) : launch_unit32_e<Bf16>(p, st);
 }

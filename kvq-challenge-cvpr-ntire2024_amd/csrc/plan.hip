@@ -287,14 +287,18 @@ namespace kvq {
 // depth-major, so window w has type w % n_types
 static int bias_types(const StageGeom& g, int par) { return par == 0 ? g.nW / (g.Dp / g.ws[0]) : g.nW; }
 // Which attention kernel consumes a block's dense bias — by geometry only (the image layout follows it, and a block's path must
-// never depend on the batch).  The streaming kernel (attn32.hip) is OPT-IN (KVQ_ATTN_STREAM=1): alone on the chip with a warm bias
-// image it beats attn.hip's dense kernel on every stage (71 vs 85 us at stage 0 without the qkv fusion, 37-42 vs 44 at stage 1, 22-25 vs
-// 26, 14-16 vs 15.4), but inside the trunk — image HBM-cold, q | k | v just written — the same launches run 43.4 / 47.9 / 27.0 / 16.6 us
-// against 48.0 / 45.1 / 25.9 / 15.7 (rocprofv3, same box, alternating runs: profiles/r04_attn_ab.txt): a tie.  The un-padded C = 96
-// stage keeps attn.hip in either case (its workgroups compute their own q | k | v; the qkv GEMM there is an HBM-bound launch).
-static bool attn_stream(const StageGeom& g) {
-  static const bool on = getenv("KVQ_ATTN_STREAM") && atoi(getenv("KVQ_ATTN_STREAM")) != 0;
-  return on && g.N <= 400 && !(g.Lp == g.L && g.C == 96);
+// never depend on the batch).  KVQ_ATTN selects the family (A/B runs; default 2):
+//   2  attn32.hip's per-unit kernel (32 x 32 score blocks on v_mfma_f32_32x32x16, running maximum) on every stage, with the qkv
+//      projection fused at the un-padded C = 96 stage;
+//   1  attn32.hip's persistent (streaming) form where no qkv fusion applies, attn.hip's dense kernel at the fused stage;
+//   0  attn.hip's dense kernel (16 x 16 score tiles) everywhere.
+static int attn_family() {
+  static const int f = getenv("KVQ_ATTN") ? atoi(getenv("KVQ_ATTN")) : 2;
+  return f;
+}
+static bool attn_b32(const StageGeom& g) {        // true: the 32 x 32 image layout, q scaled by log2(e)
+  const int f = attn_family();
+  return f != 0 && g.N <= 400 && (f == 2 || !(g.Lp == g.L && g.C == 96));
 }
 constexpr float kQScale = 0.17677669529663687f;              // head_dim^-0.5 = 32^-0.5 (swin_backbone.py:208)
 constexpr float kQScaleLog2 = 0.17677669529663687f * 1.4426950408889634f;      // the streaming kernel keeps scores in log2 units
@@ -304,7 +308,7 @@ extern "C" size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* pl, int block) 
   int i = 0, par = 0;
   if (!pl || !kvq::locate_block(pl, block, &i, &par)) return 0;
   const kvq::StageGeom& g = pl->st[i];
-  return kvq::attn_stream(g) ? kvq_attn_bias_stream_bytes(kvq::bias_types(g, par), g.N, g.nH)
+  return kvq::attn_b32(g) ? kvq_attn_bias_stream_bytes(kvq::bias_types(g, par), g.N, g.nH)
                              : kvq_attn_bias_dense_bytes(kvq::bias_types(g, par), g.N, g.nH);
 }
 
@@ -315,7 +319,7 @@ extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, con
   KVQ_REQUIRE(pl && rpb && out, KVQ_ERR_NULL, "kvq_swin3d_bias_dense_build: NULL pointer");
   KVQ_REQUIRE(locate_block(pl, block, &i, &par), KVQ_ERR_SHAPE, "kvq_swin3d_bias_dense_build: no block %d", block);
   const StageGeom& g = pl->st[i];
-  if (attn_stream(g))
+  if (attn_b32(g))
     return kvq_attn_bias_stream_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
                                       bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
   return kvq_attn_bias_dense_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
@@ -515,8 +519,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       // fused_qkv_prologue).  Un-padded partitions on the dense bias only.  Measured (bench.py --legs c2,no_sampler, two runs each,
       // same box): 300.4 -> 314.6 videos/s with the sampler in the step, 315.5 -> 330.1 without; stage-0 launch 133.5 -> 117.3 us.
       const bool fuse_qkv = bw.bias_dense && bw.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // by geometry only, never by batch
-      const bool stream = bw.bias_dense && attn_stream(g);       // the image's layout follows the same rule (kvq_swin3d_bias_dense_build)
-      const float qs = stream ? kQScaleLog2 : kQScale;
+      const bool b32 = bw.bias_dense && attn_b32(g);             // the image's layout follows the same rule (kvq_swin3d_bias_dense_build)
+      const float qs = b32 ? kQScaleLog2 : kQScale;
       // norm1 + pad + roll + window_partition
       if (g.Lp != g.L && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
@@ -533,7 +537,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       ln1_ready = false;
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
-        Bracket br(pl, st, KVQ_K_ATTN, (stream ? 8 : 4) + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
+        Bracket br(pl, st, KVQ_K_ATTN, (b32 ? 4 + 4 * attn_family() : 4) + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
                    (fuse_qkv ? 2.0 * 2.0 * M * C + 6.0 * C * C : 2.0 * 4.0 * M * C) + (double)kvq_swin3d_bias_dense_bytes(pl, blk));
         KvqAttnDenseArgs aa{};
         aa.qkv = bbig; aa.bias_dense = bw.bias_dense; aa.n_types = bias_types(g, par); aa.BW = B * g.nW; aa.nW = g.nW; aa.N = g.N;
@@ -542,8 +546,9 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         const int slabs = g.Dp / g.ws[0];
         aa.dsplit_from = (par == 1 && g.N == 392 && g.ws[0] == 8 && g.ws[1] == 7 && g.ws[2] == 7 && g.ss[0] == 4 && slabs >= 1)
                              ? g.nW - g.nW / slabs : -1;
-        if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = kQScale; }
-        KVQ_TRY(stream ? kvq_window_attention_stream(&aa, st) : kvq_window_attention_dense_args(&aa, st));
+        if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = qs; }
+        KVQ_TRY(!b32 ? kvq_window_attention_dense_args(&aa, st)
+                     : attn_family() == 1 ? kvq_window_attention_stream(&aa, st) : kvq_window_attention_unit32(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);

@@ -184,9 +184,13 @@ def attn_bias_stream(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.T
 
 
 def window_attention_stream(qkv: torch.Tensor, bias_stream: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
-                            tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1):
+                            tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1,
+                            unit: bool = False, x_ln: Optional[torch.Tensor] = None, w_qkv: Optional[torch.Tensor] = None,
+                            b_qkv: Optional[torch.Tensor] = None, q_scale: float = 1.0):
     """The streaming attention kernel (csrc/attn32.hip): qkv fp16|bf16 [3,nH,BW*N,32] with q pre-scaled by
-    head_dim^-0.5 * log2(e), the image of ``attn_bias_stream``; returns [BW*N, nH*32].  Other arguments as ``window_attention_dense``."""
+    head_dim^-0.5 * log2(e), the image of ``attn_bias_stream``; returns [BW*N, nH*32].  Other arguments as ``window_attention_dense``.
+    ``unit``: the per-unit form (``kvq_window_attention_unit32``: the trunk's default), which also takes the fused qkv projection
+    (``x_ln`` / ``w_qkv`` / ``b_qkv`` / ``q_scale`` as ``window_attention_dense``)."""
     _need_gpu(qkv, bias_stream, tile_skip, out)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
@@ -196,7 +200,15 @@ def window_attention_stream(qkv: torch.Tensor, bias_stream: torch.Tensor, nW: in
     a = _abi.KvqAttnDenseArgs()
     a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(bias_stream), nW if n_types is None else n_types, BW, nW, N, nH
     a.dtype, a.out, a.tile_skip, a.dsplit_from = dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), dsplit_from
-    check(lib().kvq_window_attention_stream(C.byref(a), current_stream()), "kvq_window_attention_stream")
+    if x_ln is not None:
+        assert unit, "the fused qkv projection exists in the per-unit form only"
+        _need_gpu(x_ln, w_qkv, b_qkv)
+        assert x_ln.dtype == qkv.dtype == w_qkv.dtype and x_ln.is_contiguous() and w_qkv.is_contiguous() and b_qkv.dtype == torch.float32
+        a.x_ln, a.w_qkv, a.b_qkv, a.q_scale = ptr(x_ln), ptr(w_qkv), ptr(b_qkv), q_scale
+    if unit:
+        check(lib().kvq_window_attention_unit32(C.byref(a), current_stream()), "kvq_window_attention_unit32")
+    else:
+        check(lib().kvq_window_attention_stream(C.byref(a), current_stream()), "kvq_window_attention_stream")
     return out
 
 

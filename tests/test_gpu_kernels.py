@@ -467,7 +467,8 @@ def test_window_attention_dense_depth_split_is_bit_identical(dims, half):
     ((16, 14, 7), (8, 7, 7), False, True, 2),     # two windows deep, un-shifted: the depth copies share one bias
     ((16, 28, 28), (8, 7, 7), True, True, 6),     # stage-1 like: 32 windows x 6 heads, several entries per workgroup
 ])
-def test_window_attention_stream_vs_oracle(dims, window, shifted, gated, nH, half):
+@pytest.mark.parametrize("unit", [False, True], ids=["persistent", "unit"])
+def test_window_attention_stream_vs_oracle(dims, window, shifted, gated, nH, half, unit):
     """The streaming kernel (32 x 32 score blocks, running maximum, persistent workgroups; csrc/attn32.hip) against the fp32 oracle and
     against the dense kernel it replaces.  q reaches it scaled by log2(e) (scores in log2 units): the oracle gets the same rounded q
     divided by log2(e) in fp32."""
@@ -489,7 +490,7 @@ def test_window_attention_stream_vs_oracle(dims, window, shifted, gated, nH, hal
     tokd, rpbd, fpbd = dev(torch.from_numpy(tok)), dev(rpb), None if fpb is None else dev(fpb)
     n_types = nW if use_mask else nW // (-(-dims[0] // lay["ws"][0]))
     image = kernels.attn_bias_stream(tokd[: n_types * N], rpbd, fpbd, center, n_types, N, use_mask)
-    out = kernels.window_attention_stream(qkv, image, nW, N, n_types).float().cpu()
+    out = kernels.window_attention_stream(qkv, image, nW, N, n_types, unit=unit).float().cpu()
     assert torch.isfinite(out).all()
     assert 0 < float(image.max_abs_bias) <= 32.0
     # against the oracle fed the bias as the image holds it (fp16 of bias - row maximum): the 16-bit rounding of the probabilities and of
@@ -504,7 +505,7 @@ def test_window_attention_stream_vs_oracle(dims, window, shifted, gated, nH, hal
     for wv in range(nW):
         skip[wv] = int(g.integers(0, 1 << nqt)) & ~3                       # q-block 0 always runs
     sentinel = torch.full((BW * N, nH * 32), 7.0, dtype=half, device=qkv.device)
-    part = kernels.window_attention_stream(qkv, image, nW, N, n_types, tile_skip=dev(torch.from_numpy(skip)), out=sentinel).float().cpu()
+    part = kernels.window_attention_stream(qkv, image, nW, N, n_types, tile_skip=dev(torch.from_numpy(skip)), out=sentinel, unit=unit).float().cpu()
     rows = np.arange(BW * N)
     t0 = 2 * ((rows % N) // 32)
     sk = skip[(rows // N) % nW]
@@ -513,7 +514,8 @@ def test_window_attention_stream_vs_oracle(dims, window, shifted, gated, nH, hal
     assert torch.equal(part[~skipped], out[~skipped]) and bool((part[skipped] == 7.0).all())
 
 
-def test_window_attention_stream_extremes_and_rescale(half):
+@pytest.mark.parametrize("unit", [False, True], ids=["persistent", "unit"])
+def test_window_attention_stream_extremes_and_rescale(half, unit):
     """Rows whose maximum grows by far more than the rescale threshold in the middle of the key range (a dominant key in a late
     block), rows that START masked (shifted windows: the first key blocks of some queries hold -100 only), and a key that dominates
     by > 80: finite, and within the rounding budget of the oracle."""
@@ -535,13 +537,14 @@ def test_window_attention_stream_extremes_and_rescale(half):
     tok, center = _tok_table(lay, window)
     qkv = dev(torch.stack([q2, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, nW * N, 32).contiguous(), half)
     image = kernels.attn_bias_stream(dev(torch.from_numpy(tok)), dev(rpb), None, center, nW, N, True)
-    out = kernels.window_attention_stream(qkv, image, nW, N).float().cpu()
+    out = kernels.window_attention_stream(qkv, image, nW, N, unit=unit).float().cpu()
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() <= 6.4 * EPS[half] + 2.0 ** -7
 
 
+@pytest.mark.parametrize("unit", [False, True], ids=["persistent", "unit"])
 @pytest.mark.parametrize("dims", [(16, 14, 14), (24, 7, 7)])
-def test_window_attention_stream_depth_split(dims, half):
+def test_window_attention_stream_depth_split(dims, half, unit):
     """dsplit_from: depth-split windows pass over the other half's 32-key blocks.  Their scores are the image's -100 and leave the
     exponential as zeros against any maximum the row's own half produces.  Windows that are not split and the first-half rows of split
     windows (their skipped blocks come LAST: exact zeros added) agree bit for bit; second-half rows start their running maximum at
@@ -557,16 +560,16 @@ def test_window_attention_stream_depth_split(dims, half):
     fpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
     tok, center = _tok_table(lay, window)
     image = kernels.attn_bias_stream(dev(torch.from_numpy(tok)), dev(rpb), dev(fpb), center, nW, N, True)
-    full = kernels.window_attention_stream(qkv, image, nW, N)
+    full = kernels.window_attention_stream(qkv, image, nW, N, unit=unit)
     first = nW - nW // (-(-dims[0] // 8))
-    split = kernels.window_attention_stream(qkv, image, nW, N, dsplit_from=first)
+    split = kernels.window_attention_stream(qkv, image, nW, N, dsplit_from=first, unit=unit)
     rows = torch.arange(BW * N)
     same = (((rows // N) % nW) < first) | ((rows % N) < 192)
     assert torch.equal(split.cpu()[same], full.cpu()[same])
     assert (split.float() - full.float()).abs().max().item() <= 2.0 * EPS[half] * float(full.float().abs().max())
     assert not torch.equal(split, torch.zeros_like(split))
     with pytest.raises(RuntimeError):
-        kernels.window_attention_stream(qkv[:, :, : BW * 98].contiguous(), image, nW, 98, dsplit_from=0)     # not the (8,7,7) window
+        kernels.window_attention_stream(qkv[:, :, : BW * 98].contiguous(), image, nW, 98, dsplit_from=0, unit=unit)     # not the (8,7,7) window
 
 
 @pytest.mark.parametrize("C,dims,shift", [(96, (16, 14, 14), (0, 0, 0)), (96, (16, 14, 14), (4, 3, 3)), (96, (8, 21, 14), (0, 0, 0))])
@@ -604,6 +607,43 @@ def test_window_attention_dense_fused_qkv_projection(C, dims, shift, half):
         kernels.window_attention_dense(torch.empty(1, 6, BW * N, 32, dtype=half, device=DEV), dense, nW, N, n_types,
                                        x_ln=torch.empty(BW * N, 192, dtype=half, device=DEV), w_qkv=torch.empty(576, 192, dtype=half, device=DEV),
                                        b_qkv=torch.empty(576, device=DEV), q_scale=scale)
+
+
+@pytest.mark.parametrize("dims,shift", [((16, 14, 14), (0, 0, 0)), ((16, 14, 14), (4, 3, 3)), ((8, 21, 14), (0, 0, 0))])
+def test_window_attention_unit32_fused_qkv_projection(dims, shift, half):
+    """The per-unit 32-block kernel computing its own q | k | v (C = 96) against the qkv GEMM (q scaled by head_dim^-0.5 * log2(e))
+    followed by the plain launch of the same kernel: the same fp32 accumulation over C and the same 16-bit rounding of q | k | v."""
+    C = 96
+    g = rng(C + sum(dims) + sum(shift) + 5)
+    window = (8, 7, 7)
+    lay = O.window_layout(*dims, window, shift)
+    N, nW, nH = lay["N"], lay["nW"], C // 32
+    B = 2
+    BW = B * nW
+    x = rnd(torch.from_numpy(g.standard_normal((BW * N, C)).astype(np.float32)), half)
+    Wq = rnd(torch.from_numpy((g.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32)), half)
+    bq = torch.from_numpy(0.3 * g.standard_normal(3 * C).astype(np.float32))
+    scale = 32 ** -0.5 * kernels.LOG2E
+    rpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
+    tok, center = _tok_table(lay, window)
+    use_mask = any(s > 0 for s in lay["ss"])
+    n_types = nW if use_mask else nW // (-(-dims[0] // lay["ws"][0]))
+    image = kernels.attn_bias_stream(dev(torch.from_numpy(tok))[: n_types * N], dev(rpb), None, center, n_types, N, use_mask)
+    qkv = kernels.gemm(dev(x, half), dev(Wq, half), dev(bq), _abi.EPI_QKV_BF16, num_heads=nH, q_scale=scale)
+    slabs = -(-dims[0] // 8)
+    ds = nW - nW // slabs if use_mask else -1
+    ref = kernels.window_attention_stream(qkv, image, nW, N, n_types, unit=True, dsplit_from=ds).float().cpu()
+    scratch = torch.full((1, nH, BW * N, 32), float("nan"), dtype=half, device=DEV)
+    out = kernels.window_attention_stream(scratch, image, nW, N, n_types, unit=True, dsplit_from=ds, x_ln=dev(x, half), w_qkv=dev(Wq, half),
+                                          b_qkv=dev(bq), q_scale=scale).float().cpu()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 3.0 * EPS[half] * max(1.0, ref.abs().max().item())
+    assert (out - ref).abs().mean().item() <= 0.2 * EPS[half]
+    assert (scratch[0].float() - qkv[0].float()).abs().max().item() <= 2.0 * EPS[half] * qkv[0].float().abs().max().item()
+    with pytest.raises(RuntimeError, match="C = 96"):
+        kernels.window_attention_stream(torch.empty(1, 6, BW * N, 32, dtype=half, device=DEV), image, nW, N, n_types, unit=True,
+                                        x_ln=torch.empty(BW * N, 192, dtype=half, device=DEV), w_qkv=torch.empty(576, 192, dtype=half, device=DEV),
+                                        b_qkv=torch.empty(576, device=DEV), q_scale=scale)
 
 
 def test_window_attention_dense_softmax_extremes(half):

@@ -13,6 +13,8 @@
 namespace kvq {
 void set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 int hip_fail(hipError_t e, const char* w) { fprintf(stderr, "HIP %s: %s\n", w, hipGetErrorString(e)); return -1; }
+int LdsOptIn::ensure(const void* kernel, int want) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess ? 0 : -1; }
+bool stem_pool_shape_ok(int, int, int, int, int) { return false; }
 unsigned long long* g_trace = nullptr;
 int g_trace_blocks = 0;
 }
@@ -74,7 +76,7 @@ int main(int argc, char** argv) {
     KvqAttnDenseArgs a{};
     a.qkv = dqs[cold_q ? turn % dqs.size() : 0]; a.bias_dense = dbs[turn % dbs.size()]; ++turn; a.n_types = ntyp; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = nH; a.dtype = KVQ_DT_FP16; a.out = dout;
     a.dsplit_from = dsplit;
-    return kvq_window_attention_stream(&a, nullptr);
+    return getenv("UNIT32") ? kvq_window_attention_unit32(&a, nullptr) : kvq_window_attention_stream(&a, nullptr);
   };
   if (run()) return 1;
   CK(hipDeviceSynchronize());

@@ -9,6 +9,8 @@
 namespace kvq {
 void set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 int hip_fail(hipError_t e, const char* w) { fprintf(stderr, "HIP %s: %s\n", w, hipGetErrorString(e)); return -1; }
+int LdsOptIn::ensure(const void* kernel, int want) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess ? 0 : -1; }
+bool stem_pool_shape_ok(int, int, int, int, int) { return false; }
 unsigned long long* g_trace = nullptr;
 int g_trace_blocks = 0;
 
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256 * W) void loop_kernel(Attn32Params p, int iters
   const u32x4 pre[2] = {bd[0], bd[64]};
   uint16_t* orow = p.out + (size_t)tid * 64;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int it = 0; it < iters; ++it) a32_qblock<Fp16, 0, A32_KB>(p, smem, A32_SLOT >> 4, bd, qf0, qf1, pre, orow, do_store != 0);
+  for (int it = 0; it < iters; ++it) a32_qblock<Fp16, 0, A32_KB>(smem, A32_SLOT >> 4, bd, qf0, qf1, pre, orow, do_store != 0);
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long t1 = __builtin_readcyclecounter();
   if (lane == 0) cyc[tid >> 6] = t1 - t0;
