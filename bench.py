@@ -783,7 +783,7 @@ def main():
                          ("ksvqe", lambda pm: leg_ksvqe(args, device, kd, pm, 32)), ("ksvqe96", lambda pm: leg_ksvqe(args, device, kd, pm, 96))):
             if name in legs or (name == "ksvqe96" and "ksvqe" in legs):
                 try:
-                    pm = pmc_traffic(name, 1, args.dtype, B) if want_pmc else None
+                    pm = pmc_traffic(name, 3 if name.startswith("ksvqe") else 1, args.dtype, B) if want_pmc else None
                     out[name] = fn(pm)
                 except Exception as e:  # noqa: BLE001  (an extra leg must not take the headline line down with it)
                     out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}

@@ -91,8 +91,8 @@ typedef struct {
                               C in {96,128,192}) -> proj+residual+norm2+Mlp+residual run as ONE launch
                               (kvq_block_tail); NULL -> GEMM/LayerNorm launches */
   const void* bias_dense;  /* optional, derived, valid ONLY with the plan it was built for
-                              (kvq_swin3d_bias_dense_build): the block's attention bias per (window, head), gate,
-                              shift mask and padding included.  Non-NULL -> kvq_window_attention_dense; NULL -> the
+                              (kvq_swin3d_bias_dense_build): the block's attention bias per (window type, head), gate,
+                              shift mask and padding included.  Non-NULL -> kvq_window_attention32; NULL -> the
                               bias is rebuilt per score from the tables (kvq_window_attention) */
 } KvqSwinBlockW;
 
@@ -158,11 +158,11 @@ int kvq_resize_trilinear_cl(const float* src, int B, int D, int H, int W, int C,
 int kvq_swin3d_forward_stages(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, int stage_lo, int stage_hi,
                               float* io, float* feat, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Dense attention bias of weights->blocks[block] for this plan's geometry (see kvq_attn_bias_dense_build): size
+/* Dense attention bias of weights->blocks[block] for this plan's geometry (see kvq_attn_bias32_build): size
  * and builder.  Independent of the batch size; rebuild when the block's tables change. */
 size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* plan, int block);
 int kvq_swin3d_bias_dense_build(const KvqSwinPlan* plan, int block, const float* rpb_table, const float* fpb_table,
-                                void* out, float* max_abs /* device, may be NULL: see kvq_attn_bias_dense_build */,
+                                void* out, float* max_abs /* device, may be NULL: see kvq_attn_bias32_build */,
                                 void* stream);
 
 /* Per-kernel-class GPU time of the most recent profiled forward.  Profiling brackets every
@@ -337,73 +337,51 @@ int kvq_window_attention(const uint16_t* qkv, const int32_t* tok, const float* r
                          const float* bias_pack, int table_len, int center, int BW, int nW, int N, int num_heads, int use_mask,
                          int dtype, uint16_t* out, void* stream);
 
-/* The same attention with the bias PRE-BUILT per (window, head): bias[w][h][i][j] = what kvq_window_attention
- * rebuilds per score (table gather, fragment gate, -100 shift mask), stored as fp16 in the kernel's MFMA accumulator
- * layout [n_types][nH][ceil(N/16)][26][64 lanes][4]; keys >= N hold -60000.  A q-tile loads its bias tiles and widens
- * them into the score accumulators: no per-score LDS work is left, and of the VALU work only widen / max / exp / pack.
- * 2 B per score of HBM/L2 traffic, shared by all clips of a step and by the windows of one TYPE: n_types <= nW
- * divides nW and window w uses bias w % n_types (un-shifted windows that differ only in depth index share one; pass
- * the descriptors of the first n_types windows to the builder).  Stored is bias - max_key bias of the query's row
- * (softmax is invariant to a per-row shift): the entries that carry the probability mass sit next to 0, where fp16
- * resolves them to <= 2^-11.  The builder also reports max |bias| (un-masked entries) through max_abs (device
- * float, zero it first; NULL = skip); the host mirror keeps the exact per-score path above a (generous) cap.
- *   tok, rpb, fpb, table_len, center, use_mask: as kvq_window_attention (fpb NULL = no gate). */
-size_t kvq_attn_bias_dense_bytes(int n_types, int N, int num_heads);
-int kvq_attn_bias_dense_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
-                              int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
-int kvq_window_attention_dense(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N,
-                               int num_heads, int dtype, uint16_t* out, void* stream);
-/* The same with tile_skip[nW] (or NULL): bit t of tile_skip[w] set = rows 16t .. 16t+15 of window w are padding rows only (padded
- * partitions); such q-tiles are passed over — their output rows are never read (the consumers walk the tokens). */
-int kvq_window_attention_dense_skip(const uint16_t* qkv, const void* bias_dense, int n_types, int BW, int nW, int N, int num_heads,
-                                    int dtype, uint16_t* out, const uint32_t* tile_skip, void* stream);
-/* The general form.  dsplit_from >= 0 (shifted blocks of the (8,7,7) window, N = 392): windows w >= dsplit_from of every clip are
- * DEPTH-SPLIT — the cyclic shift put depth positions Dp-4.. and the wrapped 0..3 into one window and the shift mask
- * (swin_backbone.py:563-579) separates the two halves of 196 tokens — so a q-tile of one half passes over the key tiles of the
- * other half, whose scores are the image's -100 and leave the exponential as exact zeros: bit-identical to dsplit_from = -1 as long
- * as a row's logits (q.k + bias) spread by less than ~80 — exp(-100 + spread) must flush to zero, and the row maximum is taken over the
- * row's own half only; beyond that the two launches differ in the last bits (as the reference's own -100 mask then leaks weight) —
- * 46 % fewer score tiles in those windows.  The caller vouches for the geometry (the plan derives it from the window layout). */
+/* The same attention with the bias PRE-BUILT per (window type, head) (csrc/attn32.hip; the trunk's default): bias[w][h][i][j] = what
+ * kvq_window_attention rebuilds per score (table gather, fragment gate, -100 shift mask), stored as an fp16 image in the kernel's MFMA
+ * accumulator layout — [n_types][nH][ceil(N/32)][13][2][64 lanes][8] + one 2 KB pad block, 16-byte aligned: register r = 8 half + e of lane
+ * (q = lane & 31, hi = lane >> 5) of the 32 x 32 score block (qb, kb) is query 32 qb + q against key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi;
+ * keys >= N hold -60000.  2 B per score of HBM / L2 traffic, shared by all clips of a step and by the windows of one TYPE: n_types <= nW
+ * divides nW and window w uses bias w % n_types (un-shifted windows that differ only in depth index share one; pass the descriptors of
+ * the first n_types windows to the builder).  Stored is bias - max_key bias of the query's row (softmax is invariant to a per-row shift):
+ * the entries that carry the probability mass sit next to 0, where fp16 resolves them to <= 2^-11.  The builder also reports max |bias|
+ * (un-masked entries) through max_abs (device float, zero it first; NULL = skip); the host mirror keeps the exact per-score path above a
+ * (generous) cap.  tok, rpb, fpb, table_len, center, use_mask: as kvq_window_attention (fpb NULL = no gate).
+ *
+ * The kernel: S^T = K Q^T on v_mfma_f32_32x32x16, the bias tile widened / scaled by log2(e) / shifted by the row's running maximum in one
+ * v_fma_mix_f32 per score as the MFMA's C operand (flash-attention running maximum with a deferred rescale, threshold 2^8), row sums
+ * by v_dot2c on the packed probabilities, O^T = V^T P^T through the hardware transpose read; one workgroup of four waves per (window,
+ * head, clip[, q-part]), K | V staged by LDS-DMA, 32-query blocks from an LDS ticket.
+ *   - q must arrive scaled by head_dim^-0.5 * log2(e) (scores are kept in log2 units; the image stays in natural units);
+ *   - tile_skip[nW] (or NULL): bit t of tile_skip[w] set = rows 16t .. 16t+15 of window w are padding rows only (padded partitions); a
+ *     32-row q-block is passed over when both its 16-row tiles are — its output rows are never read (the consumers walk the tokens);
+ *   - dsplit_from >= 0 (shifted blocks of the (8,7,7) window, N = 392): windows w >= dsplit_from of every clip are DEPTH-SPLIT — the
+ *     cyclic shift put depth positions Dp-4.. and the wrapped 0..3 into one window and the shift mask (swin_backbone.py:563-579)
+ *     separates the two halves of 196 tokens — so a q-block of one half passes over the 32-key blocks of the other half, whose scores
+ *     are the image's -100 and leave the exponential as zeros (46 % fewer score blocks in those windows).  First-half rows come out bit
+ *     for bit as with dsplit_from = -1; second-half rows start their running maximum at another block and may differ in the last bit of
+ *     the 16-bit output.  The caller vouches for the geometry (the plan derives it from the window layout). */
+size_t kvq_attn_bias32_bytes(int n_types, int N, int num_heads);      /* 0 for N > 400 */
+int kvq_attn_bias32_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
+                          int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
 typedef struct {
-  const uint16_t* qkv;        /* [3][nH][BW*N][32], q pre-scaled */
-  const void* bias_dense;     /* kvq_attn_bias_dense_build image of n_types window types */
+  const uint16_t* qkv;        /* [3][nH][BW*N][32], q scaled by head_dim^-0.5 * log2(e) */
+  const void* bias_dense;     /* kvq_attn_bias32_build image of n_types window types */
   int32_t n_types, BW, nW, N, num_heads, dtype;
   uint16_t* out;              /* [BW*N][nH*32] */
-  const uint32_t* tile_skip;  /* optional, as kvq_window_attention_dense_skip */
+  const uint32_t* tile_skip;  /* optional, see above */
   int32_t dsplit_from;        /* -1 = no depth-split windows */
   /* Fused qkv projection (x_ln != NULL; C = 32 num_heads = 96; always one workgroup per (window, head)): the workgroup of a (window,
    * head) computes its q | k | v from the window's norm1 rows — x_ln 16-bit [BW*N][C] in window order (no padding rows: un-padded
    * partitions only), w_qkv 16-bit [3C][C], b_qkv fp32 [3C] (swin_backbone.py:252-260) — instead of reading them: k and v go
-   * straight into the LDS images, q (scaled by q_scale) into the q third of `qkv` ([num_heads][BW*N][32]; the k / v thirds are not
-   * touched and need not exist).  Replaces kvq_gemm_bf16(KVQ_EPI_QKV_BF16) for the stages where that launch is HBM-bound. */
+   * straight into the LDS images, q (scaled by q_scale = head_dim^-0.5 * log2(e)) into the q third of `qkv` ([num_heads][BW*N][32];
+   * the k / v thirds are not touched and need not exist).  Replaces kvq_gemm_bf16(KVQ_EPI_QKV_BF16) where that launch is HBM-bound. */
   const uint16_t* x_ln;
   const uint16_t* w_qkv;
   const float* b_qkv;
   float q_scale;
 } KvqAttnDenseArgs;
-int kvq_window_attention_dense_args(const KvqAttnDenseArgs* host_args, void* stream);
-
-/* The STREAMING form of the same attention (csrc/attn32.hip; replaces swin_backbone.py:261-322 like the two above): 32 x 32 score
- * blocks on v_mfma_f32_32x32x16, the bias widened / scaled / shifted by the row's running maximum in one v_fma_mix_f32 per score
- * (flash-attention running maximum with a deferred rescale, threshold 2^8), persistent workgroups (one per CU) whose loader wave
- * streams K | V of the (window, head) units into a three-slot LDS ring ahead of eight consumer waves that pull (unit, 32-query
- * block) items from a ticket.  Differences to kvq_window_attention_dense_args:
- *   - q must arrive scaled by head_dim^-0.5 * log2(e) (scores are kept in log2 units; the bias image stays in natural units);
- *   - the image comes from kvq_attn_bias_stream_build: [n_types][nH][ceil(N/32)][13][2][64 lanes][8] fp16 + one 2 KB pad block —
- *     register r = 8 half + e of lane (q = lane & 31, hi = lane >> 5) is key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi, 16-byte aligned;
- *   - no fused qkv projection (x_ln must be NULL); tile_skip and dsplit_from mean what they mean above (a q-block of 32 rows is
- *     passed over when both its 16-row tiles are padding only; depth-split windows skip the other half's 32-key blocks).
- * Results agree with the dense kernel to the 16-bit rounding of the probabilities (the normaliser is the sum of the ROUNDED
- * probabilities in both), not bit for bit. */
-size_t kvq_attn_bias_stream_bytes(int n_types, int N, int num_heads);
-int kvq_attn_bias_stream_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
-                               int n_types, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream);
-int kvq_window_attention_stream(const KvqAttnDenseArgs* host_args, void* stream);
-/* The same 32-query block body inside kvq_window_attention_dense_args' launch geometry (csrc/attn32.hip, "per-unit" form): one workgroup
- * of four waves per (window, head, clip[, q-part]), three per CU, K | V staged by LDS-DMA in the prologue, q-blocks from an LDS ticket —
- * and the fused qkv projection (x_ln / w_qkv / b_qkv as in KvqAttnDenseArgs; q_scale = head_dim^-0.5 * log2(e); C = 96).  Image and q
- * scaling as kvq_window_attention_stream.  The trunk's default. */
-int kvq_window_attention_unit32(const KvqAttnDenseArgs* host_args, void* stream);
+int kvq_window_attention32(const KvqAttnDenseArgs* host_args, void* stream);
 
 /* im2col of PatchEmbed3D's stride==kernel Conv3d (swin_backbone.py:715-726): zero pads the tail
  * of each axis, emits bf16 rows [B*D*H'*W'][in*pd*ph*pw] in (c,kd,kh,kw) order. */

@@ -181,15 +181,9 @@ SYMBOLS = {
     "kvq_block_tail": (i32, [C.POINTER(KvqBlockTailArgs), p_void]),
     "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
                                    p_void]),
-    "kvq_attn_bias_dense_bytes": (sz, [i32, i32, i32]),
-    "kvq_attn_bias_dense_build": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
-    "kvq_window_attention_dense": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void]),
-    "kvq_window_attention_dense_skip": (i32, [p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
-    "kvq_window_attention_dense_args": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
-    "kvq_attn_bias_stream_bytes": (sz, [i32, i32, i32]),
-    "kvq_attn_bias_stream_build": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
-    "kvq_window_attention_stream": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
-    "kvq_window_attention_unit32": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
+    "kvq_attn_bias32_bytes": (sz, [i32, i32, i32]),
+    "kvq_attn_bias32_build": (i32, [p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, p_void, p_void, p_void]),
+    "kvq_window_attention32": (i32, [C.POINTER(KvqAttnDenseArgs), p_void]),
     "kvq_swin3d_bias_dense_bytes": (sz, [p_void, i32]),
     "kvq_swin3d_bias_dense_build": (i32, [p_void, i32, p_void, p_void, p_void, p_void, p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),

@@ -1,29 +1,41 @@
-// Streaming window attention for head_dim 32 on gfx950: 32 x 32 score blocks, running row maximum, persistent workgroups.
+// Window attention for head_dim 32 on gfx950 with the bias PRE-BUILT per (window type, head): 32 x 32 score blocks, running row maximum.
 //
-// Replaces WindowAttention3D.forward's core (swin_backbone.py:261-322) with the bias PRE-BUILT per (window type, head) as in attn.hip's
-// dense variant, restructured around what bounds it — per-score VALU issue (attn.hip spends 5.7 VALU slots per score and lane):
-//   * S^T = K Q^T on v_mfma_f32_32x32x16 (two k-steps of 16 = head_dim 32): a lane holds 16 keys of ONE query (lane & 31) per
-//     32-key block, half the matrix-pipe issue time per flop of the 16 x 16 form and a quarter of its LDS fragment reads;
-//   * the bias tile is widened, scaled by log2(e) and shifted by the row's RUNNING maximum in one v_fma_mix_f32 per score — it is the
-//     MFMA's C operand, so the accumulator comes out as the exponent argument: no subtract, no separate conversion.  q arrives
-//     pre-scaled by head_dim^-0.5 * log2(e) (the qkv GEMM's epilogue scale), so S is in log2 units;
-//   * the running maximum is the flash-attention scheme with a deferred rescale: a block whose scores stay within 2^THR of the
-//     current maximum is exponentiated as it is (P <= 2^THR, fp16 / bf16 hold that at full relative precision; the normaliser is the
-//     sum of the ROUNDED probabilities, so the scale cancels exactly); only a growth past THR — or the row's first block — takes
-//     the rescale path (O, l, the pending score accumulators all move by the same 2^-d).  Masked scores (-100) and padding keys
-//     (-60000) leave the exponential as zeros whatever the maximum;
-//   * row sums by v_dot2c on the packed probabilities (one VALU per two scores), P V as O^T = V^T P^T with the packed P registers
-//     as the B operand and V through the hardware transpose read (row-major V in LDS = a plain copy of the global rows);
-//   * the q-block loop is software-pipelined inside the wave: the score MFMAs of block t+1 and the P V MFMAs of block t-1 are in the
-//     matrix pipe while the VALU runs max / exp / pack of block t.
-// Work distribution: one PERSISTENT workgroup per CU (8 consumer waves + 1 loader wave).  The loader streams K | V of the
-// workgroup's (window, head) entries into a two-slot LDS ring by LDS-DMA, one entry ahead of the consumers, so no launch ever has
-// every workgroup in its prologue at once (stages 1-3 of the trunk are ONE round of workgroups in attn.hip's form); consumers pull
-// (entry, 32-query block) items from an LDS ticket, so the 13 q-blocks of a window never quantise over a fixed wave count.  XCDs
-// take whole (window type, head) pairs: the clips that share a bias image run on one L2 at the same time.
+// Replaces WindowAttention3D.forward's core (swin_backbone.py:261-322).  The bias of a (window, head) depends only on the block's tables
+// and the window's position in the clip, not on the clip: it is built once per weight set and plan geometry by bias32_build_kernel and
+// streamed from HBM / L2 (2 B per score; one image per window TYPE: un-shifted windows that differ only in their depth index share one)
+// while the kernel is bound by per-score VALU issue.  attn.hip keeps the exact per-score gather path (tables past max |bias| 16, or images
+// that would dwarf the activations).  What the kernel is built around:
+//   * S^T = K Q^T on v_mfma_f32_32x32x16 (two k-steps of 16 = head_dim 32): a lane holds 16 keys of ONE query (lane & 31) per 32-key
+//     block — half the matrix-pipe issue time per flop of a 16 x 16 tiling and a quarter of its LDS fragment reads;
+//   * the bias tile (fp16, row-max shifted: the entries that carry the probability mass sit next to 0, where fp16 resolves them to
+//     <= 2^-11; the -100 shift mask and the "key >= N" exclusion, -60000, baked in) is widened, scaled by log2(e) and shifted by the row's
+//     RUNNING maximum in one v_fma_mix_f32 per score — it is the MFMA's C operand, so the accumulator comes out as the exponent argument:
+//     no subtract, no separate conversion.  q arrives scaled by head_dim^-0.5 * log2(e) (the qkv epilogue's scale): S is in log2 units;
+//   * the running maximum is the flash-attention scheme with a deferred rescale: a block whose scores stay within 2^THR of the current
+//     maximum is exponentiated as it is (P <= 2^THR: fp16 / bf16 hold that at full relative precision, and the normaliser is the sum of the
+//     ROUNDED probabilities, so the scale cancels); only a growth past THR — or the row's first block — takes the rescale path (O, l and the
+//     scores of the block move by the same 2^-d).  Masked scores (-100) and padding keys leave the exponential as zeros whatever the maximum;
+//   * row sums by v_dot2c on the packed probabilities (one VALU per two scores); P V as O^T = V^T P^T with the packed P registers as the B
+//     operand and V through the hardware transpose read (row-major V in LDS = a plain copy of the global rows);
+//   * the key-block loop is software-pipelined inside the wave: the score MFMAs of block t+1 and the P V MFMAs of block t-1 are in the matrix
+//     pipe while the VALU runs max / exp / pack of block t; bias tiles are requested two blocks ahead, the next q-block's ticket, q fragments
+//     and first tile while the current one is computed.
+// One workgroup (4 waves) per (window, head, clip[, q-part]), three per CU (52 KB of LDS): K (16-B chunks XOR-swizzled by (row >> 2) & 3)
+// and V staged once by buffer-resource LDS-DMA (rows past N read zeros), 32-query blocks pulled from an LDS ticket.  FUSED (un-padded
+// C = 96 stage): the workgroup computes its own q | k | v from the window's norm1 rows, k / v straight into the LDS images.
+//
+// Round 4 measured this body in three launch geometries (profiles/r04_attn_ab.txt): this one; a persistent form (one workgroup per CU, a
+// loader wave streaming K | V into a three-slot LDS ring ahead of eight consumer waves) that wins alone on the chip with a warm image
+// (71 vs 85-90 us at stage 0 un-fused) and loses inside the trunk, where the image is HBM-cold and the late stages hold few units; and the
+// 16 x 16 tiling it replaces (attn.hip's dense kernel of rounds 2-3: 475 -> 449 us of attention per 4-clip step).
+#include <stdlib.h>
+
 #include "common.hpp"
 
-#if (A32_ABL & 2)      // diagnostic builds (A32_ABL bit mask): 2 = no exponentials
+#ifndef A32_ABL
+#define A32_ABL 0           // diagnostic builds (tools/ubench/attn32_loop.hip), bit mask: 1 no bias stream, 2 no exponentials, 4 no P V MFMAs,
+#endif                      // 8 no growth check, 16 no LDS fragment reads, 32 no v_fma_mix, 64 no row sums, 128 no row-maximum chain
+#if (A32_ABL & 2)
 #define A32_EXP(x) ((x) * 0.001f + 1.0f)
 #else
 #define A32_EXP(x) __builtin_amdgcn_exp2f(x)
@@ -32,52 +44,20 @@
 namespace kvq {
 
 constexpr int A32_KB = 13;                         // 32-key blocks: 416 key positions (N <= 400 supported, 392 used)
-constexpr int A32_ROWS = 400;                      // key rows a slot holds; rows 400..415 of the 13th block are read from the zero block
+constexpr int A32_ROWS = 400;                      // key rows the LDS images hold; rows 400..415 of the 13th block come from the zero block
 constexpr int A32_K_BYTES = A32_ROWS * 64;         // 25 600: K rows (XOR-swizzled 16-B chunks), then as many of V (row-major)
 constexpr int A32_SLOT = 2 * A32_K_BYTES;
-constexpr int A32_NSLOT = 3;                       // the loader runs up to two entries ahead of the consumers
-constexpr int A32_OFF_ZERO = A32_NSLOT * A32_SLOT; // 1 KB of zeros
-constexpr int A32_OFF_CTL = A32_OFF_ZERO + 1024;   // control words: [0] ticket, [1..3] items done per slot, [4..6] entry landed per slot
-constexpr int A32_OFF_TAB = A32_OFF_CTL + 64;      // entry table: 32 B per entry
-constexpr int A32_MAX_ENTRIES = 128;               // per workgroup and launch
-constexpr int A32_LDS = A32_OFF_TAB + A32_MAX_ENTRIES * 32;
-#ifndef A32_ABL
-#define A32_ABL 0
-#endif
-#ifndef A32_SUM
-#define A32_SUM 0
-#endif
-#ifndef A32_BDEPTH
-#define A32_BDEPTH 2          // bias tiles requested ahead of the block being multiplied (ring of A32_BDEPTH + 1 tiles, 8 registers each)
-#endif
-#ifndef A32_BR
-#define A32_BR 0
-#endif
-#ifndef A32_CW_DEFAULT
-#define A32_CW_DEFAULT 8
-#endif
-constexpr int A32_CW = A32_CW_DEFAULT;             // consumer waves
-constexpr int A32_THREADS = (A32_CW + 1) * 64;
+constexpr int A32_WAVES = 4;
+constexpr int A32_OFF_ZERO = A32_SLOT;             // 1 KB of zeros, then the q-block ticket
+constexpr int A32_OFF_CTR = A32_OFF_ZERO + 1024;
+constexpr int A32_LDS = A32_OFF_CTR + 16;          // 52 240 B: three workgroups per CU
+constexpr int A32_BDEPTH = 2;                      // bias tiles requested ahead of the block being multiplied (3 / 5 / 7 measured: no gain)
 constexpr float A32_THR = 8.0f;                    // log2 units: a block is exponentiated against a maximum at most 2^8 too small
-constexpr float A32_OFF = -60000.0f;               // padding keys (as attn.hip's ATT_DENSE_OFF)
+constexpr float A32_OFF = -60000.0f;               // padding keys: exp2 underflows to exactly 0
 
 typedef __attribute__((ext_vector_type(4))) short a32_s4;
 typedef __attribute__((address_space(3))) a32_s4* a32_tr_t;
 typedef __attribute__((address_space(3))) void* a32_lds_t;
-
-typedef __attribute__((address_space(1))) const void* a32_gbl_t;
-
-struct Attn32Params {
-  const uint16_t* qkv;         // [3][nH][BW*N][32], q pre-scaled by head_dim^-0.5 * log2(e)
-  const u32x4* image;          // [n_types*nH][NQB][13][2][64 lanes] x 16 B (kvq_attn_bias_stream_build)
-  int BW, nW, N, nH, n_types, qsplit;
-  uint16_t* out;               // [BW*N][nH*32]
-  const uint32_t* tile_skip;   // optional [nW]: bit t = rows 16t..16t+15 of the window are padding only
-  int dsplit_from;             // >= 0: windows >= it are depth-split at token 196 of 392
-  int wg_per_xcd;
-  unsigned n_max_magic;        // ceil(2^32 / items per entry): ticket -> entry by one multiply (0: one item per entry)
-  unsigned long long* trace;   // -DKVQ_A32_TRACE builds: per consumer wave {life, fetch, ready wait, q-blocks, items}
-};
 
 // A 32-query block keeps a row in lanes q and q + 32: v_permlane32_swap hands each half the other's value without an LDS round
 // trip (new vdst = {own low half, partner's low half}, new vsrc = {partner's high half, own high half}: every lane sees both values)
@@ -90,26 +70,7 @@ __device__ __forceinline__ float a32_pair_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// one entry = one (window, head, clip, q-part): K | V staged once, n_max q-block items
-struct A32Entry { int pair, h, bw, w, q_lo, q_hi, inst; };     // inst: index among the (clip, depth copy) instances that share this (pair, q-part)
-
-__device__ __forceinline__ A32Entry a32_decode(const Attn32Params& p, int xcd, int j, int nqb) {
-  const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, per_pair = nclip * nrep * p.qsplit;
-  const int pi = j / per_pair, sub = j - pi * per_pair;
-  A32Entry e;
-  e.pair = pi * 8 + xcd;
-  const int wt = e.pair / p.nH;
-  e.h = e.pair - wt * p.nH;
-  const int clip = sub % nclip, rep = (sub / nclip) % nrep, part = sub / (nclip * nrep);
-  e.w = rep * p.n_types + wt;
-  e.bw = clip * p.nW + e.w;
-  e.q_lo = part * nqb / p.qsplit;
-  e.q_hi = (part + 1) * nqb / p.qsplit;
-  e.inst = sub % (nclip * nrep);
-  return e;
-}
-
-// One 32-query block against the key blocks [T0, T1) of the ring slot at `slot`.  Compile-time range: the score / probability /
+// One 32-query block against the key blocks [T0, T1) of the LDS images at `slot`.  Compile-time range: the score / probability /
 // bias registers rotate through statically indexed sets.
 template <typename E, int T0, int T1>
 __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int zero, const u32x4* bd, const typename E::v8 qf0,
@@ -205,33 +166,6 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#if A32_BR == 1
-    // the comparison is issued here, the branch on its (scalar) result only after the C operand of block t+1 has been built:
-    // the VALU -> SGPR -> branch latency is covered by 16 independent instructions
-    const unsigned long long grow = (A32_ABL & 8) ? 0ull : __builtin_amdgcn_ballot_w64(mx > A32_THR);
-    f32x16 cn;
-    if (t + 1 < T1) cn = mix(t + 1, nm);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t == T0 || grow != 0) {
-      const float mr = a32_pair_max(mx);
-      const float d = (t == T0 || mr > A32_THR) ? mr : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[cur][r] -= d;
-      if (t + 1 < T1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cn[r] -= d;
-      }
-      if (t != T0) {
-        const float f = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[r] *= f;
-        ls *= f;
-        ls1 *= f;
-      }
-      nm -= d;
-    }
-    if (t + 1 < T1) S[nxt] = E::mfma32(kn0, qf0, cn);
-#else
     if (t == T0 || (!(A32_ABL & 8) && __builtin_amdgcn_ballot_w64(mx > A32_THR) != 0)) {
       // rescale path: the row's first block (exact maximum) or a growth past THR.  Everything still at the old maximum moves by
       // the same 2^-d: O and l (they hold blocks .. t-1 completely) and the scores of block t; block t+1's C operand is built below
@@ -253,23 +187,6 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
       const f32x16 cn = mix(t + 1, nm);
       S[nxt] = E::mfma32(kn0, qf0, cn);
     }
-#endif
-#if A32_SUM == 1
-    {
-      float ex[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ex[r] = A32_EXP(S[cur][r]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) P[cur][i] = E::pack2_raw(ex[2 * i], ex[2 * i + 1]);
-      if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
-#pragma unroll
-      for (int i = 4; i < 8; ++i) P[cur][i] = E::pack2_raw(ex[2 * i], ex[2 * i + 1]);
-      f32x2 a2 = {ls, ls1};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a2 += (f32x2){ex[2 * i], ex[2 * i + 1]};
-      ls = a2[0]; ls1 = a2[1];
-    }
-#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) P[cur][i] = E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1]));
     if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
@@ -280,228 +197,49 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
       ls = E::dot2(P[cur][i], one2, ls);
       ls1 = E::dot2(P[cur][i + 1], one2, ls1);
     }
-#endif
     if (t + 1 < T1) {
-      __builtin_amdgcn_sched_group_barrier(0x002, A32_BR == 1 ? 1 : 16, 1);
+      __builtin_amdgcn_sched_group_barrier(0x002, 16, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       __builtin_amdgcn_sched_group_barrier(0x002, 12, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // ---- normalise + store: lane (query q, half hi) holds features 8j + 4hi .. +3, j = 0..3 ----
+  // ---- normalise + store.  Lane (query q, half hi) holds features 8j + 4hi .. +3, j = 0..3: four 8-byte pieces of the row's 64 bytes,
+  // interleaved with the partner lane's.  Two v_permlane32_swap per dword pair hand lane q features 0..15 and lane q + 32 features
+  // 16..31: two 16-byte stores of 32 contiguous bytes per lane instead of four 8-byte ones (the store tail is issue-bound) ----
   ls += ls1;
   ls = a32_pair_sum(ls);
+  const float inv = __builtin_amdgcn_rcpf(ls);          // >= 2^-THR-ish and finite: the row maximum contributes >= 2^-THR
+  uint32_t pk[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pk[j][0] = E::pack2(O[4 * j] * inv, O[4 * j + 1] * inv);
+    pk[j][1] = E::pack2(O[4 * j + 2] * inv, O[4 * j + 3] * inv);
+  }
+  u32x4 w0, w1;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    // swap(vdst = piece j, vsrc = piece j + 2): low lanes end with {own piece j, partner's piece j}, high lanes with {partner's piece
+    // j + 2, own piece j + 2} — in both cases consecutive features
+    const auto a = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[2][d], false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(pk[1][d], pk[3][d], false, false);
+    w0[d] = a[0]; w0[2 + d] = a[1];
+    w1[d] = b[0]; w1[2 + d] = b[1];
+  }
   if (store) {
-    const float inv = __builtin_amdgcn_rcpf(ls);        // >= 2^-THR-ish and finite: the row maximum contributes >= 2^-THR
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<u32x2*>(orow + 8 * j + 4 * hi) =
-          (u32x2){E::pack2(O[4 * j] * inv, O[4 * j + 1] * inv), E::pack2(O[4 * j + 2] * inv, O[4 * j + 3] * inv)};
+    *reinterpret_cast<u32x4*>(orow + 16 * hi) = w0;
+    *reinterpret_cast<u32x4*>(orow + 16 * hi + 8) = w1;
   }
 }
 
-template <typename E, bool DSPLIT>
-__global__ __launch_bounds__(A32_THREADS) void window_attention_stream_kernel(Attn32Params p) {
-  fp16_saturate_mode();
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* ctl = reinterpret_cast<int*>(smem + A32_OFF_CTL);       // [0] ticket, [1..2] items done per slot, [3..4] entry landed per slot
-  int4* etab = reinterpret_cast<int4*>(smem + A32_OFF_TAB);    // per entry: {pair, h, bw, w}, {q_lo, q_hi, -, -}
-  using V8 = typename E::v8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int N = p.N, nqb = (N + 31) >> 5;
-  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-  const int npair = p.n_types * p.nH, nclip = p.BW / p.nW, per_pair = nclip * (p.nW / p.n_types) * p.qsplit;
-  const int e_x = ((npair - xcd + 7) >> 3) * per_pair;          // entries of this XCD
-  const int e_wg = s < e_x ? (e_x - s + p.wg_per_xcd - 1) / p.wg_per_xcd : 0;
-  const int n_max = (nqb + p.qsplit - 1) / p.qsplit;            // items per entry (parts one q-block short pad with empty items)
-  if (e_wg == 0) return;
-  const size_t Mtot = (size_t)p.BW * N;
-
-  // the zero block (key rows 400..415 of the 13th block); rows N..399 of a slot are zero-filled by the DMA itself (loader)
-  if (tid < 64) *reinterpret_cast<u32x4*>(smem + A32_OFF_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-  // the entry table (the integer divisions of the decode, once per entry instead of per item and wave)
-  for (int e = tid; e < e_wg; e += A32_THREADS) {
-    const A32Entry en = a32_decode(p, xcd, s + e * p.wg_per_xcd, nqb);
-    etab[2 * e] = make_int4(en.pair, en.h, en.bw, en.w);
-    etab[2 * e + 1] = make_int4(en.q_lo, en.q_hi, p.tile_skip ? (int)p.tile_skip[en.w] : 0, en.inst);
-  }
-  if (tid < 1 + 2 * A32_NSLOT) ctl[tid] = tid < 1 + A32_NSLOT ? 0 : -1;
-  __syncthreads();
-
-#ifdef KVQ_A32_TRACE
-  const unsigned long long tr_k0 = __builtin_readcyclecounter();
-#endif
-  if (wave == A32_CW) {
-    // ---------------- loader: entry e into slot e % 3 once entry e - 3 has been consumed; entry e's requests are issued before
-    // entry e - 1's landing is waited for (counted vmcnt), so the stream never drains between entries ----------------
-    // Buffer-resource LDS-DMA: the per-lane byte offset is a constant, the row block the scalar offset — no VALU and no branch
-    // on the issue path — and rows past N read zeros (so the slot's rows N..399 are rewritten as zeros by every fill).  K lands
-    // with its 16-B chunks XOR-swizzled by (row >> 2) & 3, V as a plain copy.  Top priority: two VALU-bound consumer waves share
-    // this wave's SIMD and would otherwise leave it one issue slot in a dozen (18 k cycles per fill measured).
-    __builtin_amdgcn_s_setprio(3);
-    const unsigned vo_k = (unsigned)(lane >> 2) * 64u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u, vo_v = (unsigned)lane * 16u;
-    // The bias image is the launch's one HBM-cold stream (q | k | v were just written): the workgroups that run the instances of a
-    // (window type, head) pair at the same time each pull a share of the NEXT pair's rows into the XCD's L2 — one dword per 128-byte
-    // line and lane, 8 KB per instruction — so the consumers' tile loads find them there (cold image: +18 us on a stage-0 launch).
-    const int n_inst = nclip * (p.nW / p.n_types);
-    uint32_t sink = 0;
-    auto prefetch_image = [&](int e) __attribute__((always_inline)) {
-#ifdef A32_NO_PREFETCH
-      return;
-#endif
-      const int4 e0 = etab[2 * e], e1 = etab[2 * e + 1];
-      const int pair = __builtin_amdgcn_readfirstlane(e0.x), q_lo = __builtin_amdgcn_readfirstlane(e1.x), q_hi = __builtin_amdgcn_readfirstlane(e1.y);
-      const int inst = __builtin_amdgcn_readfirstlane(e1.w);
-      const char* base = reinterpret_cast<const char*>(p.image) + ((size_t)pair * nqb + q_lo) * (A32_KB * 2048);
-      const int len = (q_hi - q_lo) * (A32_KB * 2048);
-      const int lo = (int)((long long)len * inst / n_inst) & ~127, hi = (int)((long long)len * (inst + 1) / n_inst);
-      // `sink` stays allocated for the loader's whole life: the loads are never waited for by name (the next fill's vmcnt(0) covers
-      // them), so their destination must not be handed to anything else meanwhile
-      for (int off = lo + lane * 128; off < hi; off += 64 * 128) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(base + off) : "memory");
-    };
-    prefetch_image(0);
-    for (int e = 0; e < e_wg; ++e) {
-      const int b = e % A32_NSLOT;
-      if (e >= A32_NSLOT) {
-        const int target = n_max * (e / A32_NSLOT);
-        while (__hip_atomic_load(&ctl[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(4);
-        asm volatile("" ::: "memory");
-      }
-      const int4 e0 = etab[2 * e];
-      const int eh = __builtin_amdgcn_readfirstlane(e0.y), ebw = __builtin_amdgcn_readfirstlane(e0.z);
-      const uint16_t* Kg = p.qkv + ((size_t)(1 * p.nH + eh) * Mtot + (size_t)ebw * N) * 32;
-      const uint16_t* Vg = p.qkv + ((size_t)(2 * p.nH + eh) * Mtot + (size_t)ebw * N) * 32;
-      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Kg), 0, N * 64, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Vg), 0, N * 64, 0x00020000);
-      unsigned char* dst = smem + b * A32_SLOT;
-#pragma unroll
-      for (int it = 0; it < A32_ROWS / 16; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (a32_lds_t)(dst + it * 1024), 16, vo_k, it * 1024, 0, 0);
-#pragma unroll
-      for (int it = 0; it < A32_ROWS / 16; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (a32_lds_t)(dst + A32_K_BYTES + it * 1024), 16, vo_v, it * 1024, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&ctl[1 + A32_NSLOT + b], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (e + 1 < e_wg) prefetch_image(e + 1);
-#ifdef KVQ_A32_TRACE
-      if (p.trace && lane == 0 && e < 8) p.trace[((size_t)blockIdx.x * (A32_CW + 1) + A32_CW) * 8 + e] = __builtin_readcyclecounter() - tr_k0;
-#endif
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
-    return;
-  }
-
-  // ---------------- consumers ----------------
-  // An item = (entry, q-block).  The NEXT item's ticket, q fragments and first two bias tiles are requested before the current
-  // item is computed: none of them sits on the critical path of an item's first MFMA.  Two item records alternate (no copies: a
-  // register move of loaded values would make the compiler drain the whole memory queue, the output stores included).
-  struct Item {
-    int e, qb, t0, w;
-    bool live, store;
-    const u32x4* bd;
-    uint16_t* orow;
-    V8 qf0, qf1;
-    u32x4 pre[2];
-  };
-  const int q = lane & 31, hi = lane >> 5;
-  const int C = p.nH * 32;
-  auto fetch = [&](Item& it) __attribute__((always_inline)) {
-    int g = 0;
-    if (lane == 0) g = atomicAdd(&ctl[0], 1);
-    g = __builtin_amdgcn_readfirstlane(g);
-    it.e = p.n_max_magic ? (int)(((unsigned long long)(unsigned)g * p.n_max_magic) >> 32) : g;      // magic 0: one item per entry
-    const int idx = g - it.e * n_max;
-    it.live = false;
-    if (it.e >= e_wg) return;
-    const int4 e0 = etab[2 * it.e], e1 = etab[2 * it.e + 1];
-    const int pair = __builtin_amdgcn_readfirstlane(e0.x), h = __builtin_amdgcn_readfirstlane(e0.y), bw = __builtin_amdgcn_readfirstlane(e0.z);
-    it.w = __builtin_amdgcn_readfirstlane(e0.w);
-    const int q_lo = __builtin_amdgcn_readfirstlane(e1.x), q_hi = __builtin_amdgcn_readfirstlane(e1.y);
-    it.qb = q_lo + idx;
-    it.live = it.qb < q_hi;
-    const uint32_t sk = (uint32_t)__builtin_amdgcn_readfirstlane(e1.z);      // bit t: rows 16t..16t+15 of the window are padding only
-    it.live = it.live && !(((sk >> (2 * it.qb)) & 1u) && (((sk >> (2 * it.qb + 1)) & 1u) || 32 * it.qb + 16 >= N));
-    if (!it.live) return;
-    // depth-split window (host-checked geometry: N = 392, halves of 196 tokens): q-blocks 0..5 live in the first half (key blocks
-    // 0..6), 7..12 in the second (key blocks 6..12), q-block 6 (tokens 192..223) in both
-    it.t0 = (DSPLIT && p.dsplit_from >= 0 && it.w >= p.dsplit_from && it.qb > 6) ? 6 : 0;
-    const uint16_t* Qg = p.qkv + ((size_t)h * Mtot + (size_t)bw * N) * 32;
-    const int qrow = min(32 * it.qb + q, N - 1);
-    it.qf0 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 8 * hi);
-    it.qf1 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 16 + 8 * hi);
-    it.bd = p.image + ((size_t)pair * nqb + it.qb) * (A32_KB * 128) + lane;
-    it.pre[0] = it.bd[it.t0 * 128]; it.pre[1] = it.bd[it.t0 * 128 + 64];
-    it.orow = p.out + ((size_t)bw * N + 32 * it.qb + q) * C + h * 32;
-    it.store = 32 * it.qb + q < N && !((A32_ABL & 256) && p.wg_per_xcd > 0);      // (diagnostic 256: no output stores, opaque to the compiler)
-  };
-#ifdef KVQ_A32_TRACE
-  unsigned long long tr_f = 0, tr_w = 0, tr_q = 0, tr_n = 0, tr_m, tr_w0 = 0;
-  const unsigned long long tr_0 = __builtin_readcyclecounter();
-#define A32_MARK(acc) { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - tr_m; tr_m = n_; }
-  tr_m = tr_0;
-#else
-#define A32_MARK(acc)
-#endif
-  auto process = [&](Item& it) __attribute__((always_inline)) {
-    A32_MARK(tr_f);
-    const int b = it.e % A32_NSLOT;
-    if (it.live) {
-      while (__hip_atomic_load(&ctl[1 + A32_NSLOT + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it.e) __builtin_amdgcn_s_sleep(2);
-      asm volatile("" ::: "memory");
-      A32_MARK(tr_w);
-#ifdef KVQ_A32_TRACE
-      if (tr_n == 0) tr_w0 = tr_w;
-#endif
-      const unsigned char* slot = smem + b * A32_SLOT;
-      const int zero = (A32_OFF_ZERO - b * A32_SLOT) >> 4;
-      if (DSPLIT && p.dsplit_from >= 0 && it.w >= p.dsplit_from && it.qb != 6) {
-        if (it.qb < 6) a32_qblock<E, 0, 7>(slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
-        else a32_qblock<E, 6, A32_KB>(slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
-      } else {
-        a32_qblock<E, 0, A32_KB>(slot, zero, it.bd, it.qf0, it.qf1, it.pre, it.orow, it.store);
-      }
-    }
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(&ctl[1 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef KVQ_A32_TRACE
-    A32_MARK(tr_q);
-    tr_n += it.live;
-#endif
-  };
-  Item ia, ib;
-  fetch(ia);
-  while (ia.e < e_wg) {
-    fetch(ib);
-    process(ia);
-    if (ib.e >= e_wg) break;
-    fetch(ia);
-    process(ib);
-  }
-#ifdef KVQ_A32_TRACE
-  if (p.trace && lane == 0) {
-    unsigned long long* t = p.trace + ((size_t)blockIdx.x * (A32_CW + 1) + wave) * 8;
-    t[0] = __builtin_readcyclecounter() - tr_0; t[1] = tr_f; t[2] = tr_w; t[3] = tr_q; t[4] = tr_n; t[5] = tr_w0; t[6] = tr_0 - tr_k0;
-  }
-#endif
-}
-
-// ================================================================================================================================
-// The per-unit form: the same 32-query block body inside attn.hip's launch geometry — one workgroup of 4 waves per (window, head,
-// clip[, q-part]), three of them per CU (52 KB of LDS each), K | V staged once by LDS-DMA in the prologue, q-blocks pulled from an LDS
-// ticket.  The persistent form above wins alone on the chip; inside the trunk (the bias image HBM-cold, few units at the late stages)
-// the short-lived workgroups of this form overlap each other's prologues and memory stalls as attn.hip's do.  FUSED (C = 96): the
-// workgroup computes its own q | k | v from the window's norm1 rows (swin_backbone.py:252-260), k / v straight into the LDS images.
-constexpr int A32U_WAVES = 4;
-constexpr int A32U_OFF_ZERO = A32_SLOT;                    // K | V rows 0..399, then the zero block, then the ticket
-constexpr int A32U_OFF_CTR = A32U_OFF_ZERO + 1024;
-constexpr int A32U_LDS = A32U_OFF_CTR + 16;                // 52 240 B: three workgroups per CU
-
-struct Attn32UnitParams {
-  const uint16_t* qkv;
-  const u32x4* image;
+struct Attn32Params {
+  const uint16_t* qkv;         // [3][nH][BW*N][32], q scaled by head_dim^-0.5 * log2(e)
+  const u32x4* image;          // [n_types*nH][ceil(N/32)][13][2][64 lanes] x 16 B (kvq_attn_bias32_build)
   int BW, nW, N, nH, n_types, qsplit;
-  uint16_t* out;
-  const uint32_t* tile_skip;
-  int dsplit_from;
+  uint16_t* out;               // [BW*N][nH*32]
+  const uint32_t* tile_skip;   // optional [nW]: bit t = rows 16t..16t+15 of the window are padding only
+  int dsplit_from;             // >= 0: windows >= it are depth-split at token 196 of 392
   // fused qkv projection (x_ln != NULL)
   const uint16_t* x_ln;        // [BW*N][C] 16-bit, window order
   const uint16_t* w_qkv;       // [3C][C]
@@ -515,7 +253,7 @@ struct Attn32UnitParams {
 // epilogue applies, then 8 bytes into the K image (rows of 64 B, 16-B chunks XOR-swizzled by (row >> 2) & 3), the V image (plain rows) or
 // the q scratch.  Wave w takes row tiles w, w + 4, ...; all six 16-feature column tiles (q0 q1 k0 k1 v0 v1) in one pass over the rows.
 template <typename E, int KS>
-__device__ __forceinline__ void a32_fused_qkv(const Attn32UnitParams& p, unsigned char* slot, int bw, int h, int N) {
+__device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned char* slot, int bw, int h, int N) {
   using V8 = typename E::v8;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -542,13 +280,13 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32UnitParams& p, unsigne
     for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
   }
 #pragma unroll 1
-  for (int rt = wave; rt < nrt; rt += A32U_WAVES) {
+  for (int rt = wave; rt < nrt; rt += A32_WAVES) {
     const int row = 16 * rt + j;
     V8 xf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = xn[ks];
-    if (rt + A32U_WAVES < nrt) {                                   // the next tile's rows are requested before this one is multiplied
-      const int rowc = min(row + 16 * A32U_WAVES, N - 1);
+    if (rt + A32_WAVES < nrt) {                                   // the next tile's rows are requested before this one is multiplied
+      const int rowc = min(row + 16 * A32_WAVES, N - 1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
     }
@@ -575,10 +313,10 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32UnitParams& p, unsigne
 }
 
 template <typename E, bool FUSED, bool DSPLIT>
-__global__ __launch_bounds__(A32U_WAVES * 64, 3) void window_attention_unit32_kernel(Attn32UnitParams p) {
+__global__ __launch_bounds__(A32_WAVES * 64, 3) void window_attention32_kernel(Attn32Params p) {
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* ticket = reinterpret_cast<int*>(smem + A32U_OFF_CTR);
+  int* ticket = reinterpret_cast<int*>(smem + A32_OFF_CTR);
   using V8 = typename E::v8;
   // Block order as attn.hip's dense kernel: the workgroups that share one (window type, head) bias run on the SAME XCD back to back
   // (workgroup b -> XCD b % 8); FUSED: an XCD takes whole window types, heads fastest (they read the same norm1 rows).
@@ -603,10 +341,10 @@ __global__ __launch_bounds__(A32U_WAVES * 64, 3) void window_attention_unit32_ke
   const int C = p.nH * 32;
   const uint16_t* Qg = p.qkv + ((size_t)h * Mtot + (size_t)bw * N) * 32;
 
-  if (tid < 64) *reinterpret_cast<u32x4*>(smem + A32U_OFF_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (tid < 64) *reinterpret_cast<u32x4*>(smem + A32_OFF_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
   if (FUSED) {
     // rows N..399 of both images: zeros (the projection writes rows < N only)
-    for (int i = tid; i < (A32_ROWS - N) * 8; i += A32U_WAVES * 64)
+    for (int i = tid; i < (A32_ROWS - N) * 8; i += A32_WAVES * 64)
       *reinterpret_cast<u32x4*>(smem + (i & 4 ? A32_K_BYTES : 0) + (N + (i >> 3)) * 64 + (i & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
     a32_fused_qkv<E, 3>(p, smem, bw, h, N);
   } else {
@@ -616,7 +354,7 @@ __global__ __launch_bounds__(A32U_WAVES * 64, 3) void window_attention_unit32_ke
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Kg), 0, N * 64, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Vg), 0, N * 64, 0x00020000);
     const unsigned vo_k = (unsigned)(lane >> 2) * 64u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u, vo_v = (unsigned)lane * 16u;
-    for (int it = wave; it < A32_ROWS / 16; it += A32U_WAVES) {
+    for (int it = wave; it < A32_ROWS / 16; it += A32_WAVES) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (a32_lds_t)(smem + it * 1024), 16, vo_k, it * 1024, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (a32_lds_t)(smem + A32_K_BYTES + it * 1024), 16, vo_v, it * 1024, 0, 0);
     }
@@ -653,7 +391,7 @@ __global__ __launch_bounds__(A32U_WAVES * 64, 3) void window_attention_unit32_ke
     const u32x4* bd = img + (size_t)qb * (A32_KB * 128);
     uint16_t* orow = p.out + ((size_t)bw * N + 32 * qb + q) * C + h * 32;
     const bool store = 32 * qb + q < N;
-    const int zero = A32U_OFF_ZERO >> 4;
+    const int zero = A32_OFF_ZERO >> 4;
     // depth-split window (N = 392, halves of 196 tokens): q-blocks 0..5 see key blocks 0..6, 7..12 see 6..12, q-block 6 all of them
     if (dsplit && qb != 6) {
       if (qb < 6) a32_qblock<E, 0, 7>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
@@ -678,9 +416,9 @@ __global__ __launch_bounds__(A32U_WAVES * 64, 3) void window_attention_unit32_ke
 
 // The image builder (one workgroup per (window type, head)): attn.hip's bias arithmetic — idx = code_q - code_k + center,
 // b = fma(gate, r - f, f), the shift mask REPLACES it by -100 — minus the row maximum over the un-masked keys, fp16, in the
-// streaming kernel's accumulator layout: [qb][kb][half][lane (q = lane & 31, hi = lane >> 5)][8]: register r = 8 half + e of the
+// kernel's accumulator layout: [qb][kb][half][lane (q = lane & 31, hi = lane >> 5)][8]: register r = 8 half + e of the
 // 32 x 32 score block = key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi.
-struct Stream32BuildParams {
+struct Bias32BuildParams {
   const int32_t* tok;
   const float* rpb;
   const float* fpb;
@@ -689,7 +427,7 @@ struct Stream32BuildParams {
   unsigned* max_abs;
 };
 
-__global__ __launch_bounds__(256) void bias_stream_build_kernel(Stream32BuildParams p) {
+__global__ __launch_bounds__(256) void bias32_build_kernel(Bias32BuildParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   f32x2* tab = reinterpret_cast<f32x2*>(bsm);
   int2* tokL = reinterpret_cast<int2*>(bsm + (size_t)p.table_len * 8);
@@ -752,113 +490,73 @@ __global__ __launch_bounds__(256) void bias_stream_build_kernel(Stream32BuildPar
   }
 }
 
-template <typename E, bool DSPLIT>
+template <typename E, bool FUSED, bool DSPLIT>
 static int launch_attn32(const Attn32Params& p, hipStream_t st) {
-  auto kern = window_attention_stream_kernel<E, DSPLIT>;
+  auto kern = window_attention32_kernel<E, FUSED, DSPLIT>;
   static LdsOptIn opt;
   if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), A32_LDS)) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * p.wg_per_xcd)), dim3(A32_THREADS), A32_LDS, st, p);
-  KVQ_CHECK_LAUNCH("window_attention_stream_kernel");
-  return KVQ_OK;
-}
-
-template <typename E, bool FUSED, bool DSPLIT>
-static int launch_unit32(const Attn32UnitParams& p, hipStream_t st) {
-  auto kern = window_attention_unit32_kernel<E, FUSED, DSPLIT>;
-  static LdsOptIn opt;
-  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), A32U_LDS)) return rc;
   const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH;
   unsigned grid = (unsigned)(8 * ceil_div(npair, 8) * nclip * nrep * p.qsplit);
   if (FUSED) grid = (unsigned)(8 * ceil_div(p.n_types, 8) * p.nH * nclip * nrep);      // XCDs take whole window types
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(A32U_WAVES * 64), A32U_LDS, st, p);
-  KVQ_CHECK_LAUNCH("window_attention_unit32_kernel");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(A32_WAVES * 64), A32_LDS, st, p);
+  KVQ_CHECK_LAUNCH("window_attention32_kernel");
   return KVQ_OK;
 }
 
 template <typename E>
-static int launch_unit32_e(const Attn32UnitParams& p, hipStream_t st) {
-  if (p.x_ln) return p.dsplit_from >= 0 ? launch_unit32<E, true, true>(p, st) : launch_unit32<E, true, false>(p, st);
-  return p.dsplit_from >= 0 ? launch_unit32<E, false, true>(p, st) : launch_unit32<E, false, false>(p, st);
+static int launch_attn32_e(const Attn32Params& p, hipStream_t st) {
+  if (p.x_ln) return p.dsplit_from >= 0 ? launch_attn32<E, true, true>(p, st) : launch_attn32<E, true, false>(p, st);
+  return p.dsplit_from >= 0 ? launch_attn32<E, false, true>(p, st) : launch_attn32<E, false, false>(p, st);
 }
 
 }  // namespace kvq
 
-extern "C" size_t kvq_attn_bias_stream_bytes(int n_types, int N, int num_heads) {
+extern "C" size_t kvq_attn_bias32_bytes(int n_types, int N, int num_heads) {
   if (n_types <= 0 || N < 1 || N > 400 || num_heads <= 0) return 0;
   return (size_t)n_types * num_heads * ((N + 31) / 32) * kvq::A32_KB * 2048 + 2048;     // + one block: the kernel requests block t0 + 1 unconditionally
 }
 
-extern "C" int kvq_attn_bias_stream_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
+extern "C" int kvq_attn_bias32_build(const int32_t* tok, const float* rpb, const float* fpb, int table_len, int center,
                                           int nW, int N, int num_heads, int use_mask, void* out, float* max_abs, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(tok && rpb && out, KVQ_ERR_NULL, "kvq_attn_bias_stream_build: NULL pointer");
-  KVQ_REQUIRE(kvq_attn_bias_stream_bytes(nW, N, num_heads) > 0 && table_len > 0, KVQ_ERR_SHAPE,
-              "kvq_attn_bias_stream_build: bad shape nW=%d N=%d nH=%d", nW, N, num_heads);
-  KVQ_REQUIRE(((size_t)out & 15) == 0, KVQ_ERR_SHAPE, "kvq_attn_bias_stream_build: out must be 16-byte aligned");
-  Stream32BuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (uint16_t*)out, (unsigned*)max_abs};
+  KVQ_REQUIRE(tok && rpb && out, KVQ_ERR_NULL, "kvq_attn_bias32_build: NULL pointer");
+  KVQ_REQUIRE(kvq_attn_bias32_bytes(nW, N, num_heads) > 0 && table_len > 0, KVQ_ERR_SHAPE,
+              "kvq_attn_bias32_build: bad shape nW=%d N=%d nH=%d", nW, N, num_heads);
+  KVQ_REQUIRE(((size_t)out & 15) == 0, KVQ_ERR_SHAPE, "kvq_attn_bias32_build: out must be 16-byte aligned");
+  Bias32BuildParams p{tok, rpb, fpb, table_len, center, nW, N, num_heads, use_mask, (uint16_t*)out, (unsigned*)max_abs};
   const size_t lds = (size_t)table_len * 8 + (size_t)N * 12;
-  KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_attn_bias_stream_build: table of %d entries does not fit the builder's LDS", table_len);
-  hipLaunchKernelGGL(bias_stream_build_kernel, dim3((unsigned)num_heads, (unsigned)nW), dim3(256), lds, (hipStream_t)stream, p);
-  KVQ_CHECK_LAUNCH("bias_stream_build_kernel");
+  KVQ_REQUIRE(lds <= 64 * 1024, KVQ_ERR_UNSUPPORTED, "kvq_attn_bias32_build: table of %d entries does not fit the builder's LDS", table_len);
+  hipLaunchKernelGGL(bias32_build_kernel, dim3((unsigned)num_heads, (unsigned)nW), dim3(256), lds, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("bias32_build_kernel");
   return KVQ_OK;
 }
 
-extern "C" int kvq_window_attention_stream(const KvqAttnDenseArgs* a, void* stream) {
+extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(a && a->qkv && a->bias_dense && a->out, KVQ_ERR_NULL, "kvq_window_attention_stream: NULL pointer");
+  KVQ_REQUIRE(a && a->qkv && a->bias_dense && a->out, KVQ_ERR_NULL, "kvq_window_attention32: NULL pointer");
   const int BW = a->BW, nW = a->nW, N = a->N, num_heads = a->num_heads, n_types = a->n_types;
   KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
-              "kvq_window_attention_stream: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
-  KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_stream: window of %d tokens unsupported (1..400)", N);
-  KVQ_REQUIRE(((size_t)a->bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_stream: the bias image must be 16-byte aligned");
-  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_stream: dtype %d", a->dtype);
-  KVQ_REQUIRE(!a->x_ln, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_stream: no fused qkv projection in this kernel");
+              "kvq_window_attention32: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
+  KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention32: window of %d tokens unsupported (1..400)", N);
+  KVQ_REQUIRE(((size_t)a->bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention32: the bias image must be 16-byte aligned");
+  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention32: dtype %d", a->dtype);
   KVQ_REQUIRE(a->dsplit_from < 0 || (N == 392 && a->dsplit_from < nW), KVQ_ERR_UNSUPPORTED,
-              "kvq_window_attention_stream: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
-  // entries = (window, head, clip) units, cut into q-parts while there are fewer than three per CU
-  const int units = BW * num_heads, nqb = (N + 31) / 32;
-  int qsplit = units >= 768 ? 1 : 768 / units;
-  qsplit = qsplit > 4 ? 4 : qsplit;
-  qsplit = qsplit > nqb ? nqb : qsplit;
-  const int npair = n_types * num_heads, per_pair = (BW / n_types) * qsplit;
-  const int e_x0 = ((npair + 7) / 8) * per_pair;       // entries of the fullest XCD
-  const int n_max = (nqb + qsplit - 1) / qsplit;
-  Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
-                 a->dsplit_from < 0 ? -1 : a->dsplit_from, e_x0 < 32 ? e_x0 : 32, n_max == 1 ? 0u : (unsigned)((0x100000000ull + n_max - 1) / n_max), g_trace};
-  KVQ_REQUIRE((e_x0 + p.wg_per_xcd - 1) / p.wg_per_xcd <= A32_MAX_ENTRIES, KVQ_ERR_UNSUPPORTED,
-              "kvq_window_attention_stream: %d (window, head, clip) units exceed one launch", units);
-  hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == KVQ_DT_FP16)
-    return p.dsplit_from >= 0 ? launch_attn32<Fp16, true>(p, st) : launch_attn32<Fp16, false>(p, st);
-  return p.dsplit_from >= 0 ? launch_attn32<Bf16, true>(p, st) : launch_attn32<Bf16, false>(p, st);
-}
-
-extern "C" int kvq_window_attention_unit32(const KvqAttnDenseArgs* a, void* stream) {
-  using namespace kvq;
-  KVQ_REQUIRE(a && a->qkv && a->bias_dense && a->out, KVQ_ERR_NULL, "kvq_window_attention_unit32: NULL pointer");
-  const int BW = a->BW, nW = a->nW, N = a->N, num_heads = a->num_heads, n_types = a->n_types;
-  KVQ_REQUIRE(BW > 0 && nW > 0 && BW % nW == 0 && num_heads > 0 && n_types > 0 && nW % n_types == 0, KVQ_ERR_SHAPE,
-              "kvq_window_attention_unit32: bad shape BW=%d nW=%d n_types=%d nH=%d", BW, nW, n_types, num_heads);
-  KVQ_REQUIRE(N >= 1 && N <= 400, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_unit32: window of %d tokens unsupported (1..400)", N);
-  KVQ_REQUIRE(((size_t)a->bias_dense & 15) == 0, KVQ_ERR_SHAPE, "kvq_window_attention_unit32: the bias image must be 16-byte aligned");
-  KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_unit32: dtype %d", a->dtype);
-  KVQ_REQUIRE(a->dsplit_from < 0 || (N == 392 && a->dsplit_from < nW), KVQ_ERR_UNSUPPORTED,
-              "kvq_window_attention_unit32: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
+              "kvq_window_attention32: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
   const int units = BW * num_heads, nqb = (N + 31) / 32;
   int qsplit = units >= 768 ? 1 : 768 / units;        // 768 = 256 CUs x 3 resident workgroups
   qsplit = qsplit > 4 ? 4 : qsplit;
   qsplit = qsplit > nqb ? nqb : qsplit;
-  Attn32UnitParams p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
+  Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
                      a->dsplit_from < 0 ? -1 : a->dsplit_from};
   if (a->x_ln) {
     const int C = 32 * num_heads;
-    KVQ_REQUIRE(a->w_qkv && a->b_qkv, KVQ_ERR_NULL, "kvq_window_attention_unit32: x_ln without w_qkv / b_qkv");
-    KVQ_REQUIRE(C == 96, KVQ_ERR_UNSUPPORTED, "kvq_window_attention_unit32: the fused qkv projection is built for C = 96 (got %d)", C);
+    KVQ_REQUIRE(a->w_qkv && a->b_qkv, KVQ_ERR_NULL, "kvq_window_attention32: x_ln without w_qkv / b_qkv");
+    KVQ_REQUIRE(C == 96, KVQ_ERR_UNSUPPORTED, "kvq_window_attention32: the fused qkv projection is built for C = 96 (got %d)", C);
     KVQ_REQUIRE((((size_t)a->x_ln | (size_t)a->w_qkv | (size_t)a->b_qkv) & 15) == 0, KVQ_ERR_SHAPE,
-                "kvq_window_attention_unit32: x_ln / w_qkv / b_qkv must be 16-byte aligned");
+                "kvq_window_attention32: x_ln / w_qkv / b_qkv must be 16-byte aligned");
     p.qsplit = 1;       // one workgroup per (window, head) whatever the batch: a block's path must not depend on what shares the launch
     p.x_ln = a->x_ln; p.w_qkv = a->w_qkv; p.b_qkv = a->b_qkv; p.q_scale = a->q_scale; p.q_out = const_cast<uint16_t*>(a->qkv);
   }
   hipStream_t st = (hipStream_t)stream;
-  return a->dtype == KVQ_DT_FP16 ? launch_unit32_e<Fp16>(p, st) : launch_unit32_e<Bf16>(p, st);
+  return a->dtype == KVQ_DT_FP16 ? launch_attn32_e<Fp16>(p, st) : launch_attn32_e<Bf16>(p, st);
 }

@@ -286,20 +286,6 @@ namespace kvq {
 // position codes, fragment ids and — absent — mask regions of their tokens are identical); windows are ordered
 // depth-major, so window w has type w % n_types
 static int bias_types(const StageGeom& g, int par) { return par == 0 ? g.nW / (g.Dp / g.ws[0]) : g.nW; }
-// Which attention kernel consumes a block's dense bias — by geometry only (the image layout follows it, and a block's path must
-// never depend on the batch).  KVQ_ATTN selects the family (A/B runs; default 2):
-//   2  attn32.hip's per-unit kernel (32 x 32 score blocks on v_mfma_f32_32x32x16, running maximum) on every stage, with the qkv
-//      projection fused at the un-padded C = 96 stage;
-//   1  attn32.hip's persistent (streaming) form where no qkv fusion applies, attn.hip's dense kernel at the fused stage;
-//   0  attn.hip's dense kernel (16 x 16 score tiles) everywhere.
-static int attn_family() {
-  static const int f = getenv("KVQ_ATTN") ? atoi(getenv("KVQ_ATTN")) : 2;
-  return f;
-}
-static bool attn_b32(const StageGeom& g) {        // true: the 32 x 32 image layout, q scaled by log2(e)
-  const int f = attn_family();
-  return f != 0 && g.N <= 400 && (f == 2 || !(g.Lp == g.L && g.C == 96));
-}
 constexpr float kQScale = 0.17677669529663687f;              // head_dim^-0.5 = 32^-0.5 (swin_backbone.py:208)
 constexpr float kQScaleLog2 = 0.17677669529663687f * 1.4426950408889634f;      // the streaming kernel keeps scores in log2 units
 }  // namespace kvq
@@ -308,8 +294,7 @@ extern "C" size_t kvq_swin3d_bias_dense_bytes(const KvqSwinPlan* pl, int block) 
   int i = 0, par = 0;
   if (!pl || !kvq::locate_block(pl, block, &i, &par)) return 0;
   const kvq::StageGeom& g = pl->st[i];
-  return kvq::attn_b32(g) ? kvq_attn_bias_stream_bytes(kvq::bias_types(g, par), g.N, g.nH)
-                             : kvq_attn_bias_dense_bytes(kvq::bias_types(g, par), g.N, g.nH);
+  return kvq_attn_bias32_bytes(kvq::bias_types(g, par), g.N, g.nH);        // 0 past 400 tokens per window: such blocks keep the gather path
 }
 
 extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, const float* rpb, const float* fpb, void* out,
@@ -319,11 +304,8 @@ extern "C" int kvq_swin3d_bias_dense_build(const KvqSwinPlan* pl, int block, con
   KVQ_REQUIRE(pl && rpb && out, KVQ_ERR_NULL, "kvq_swin3d_bias_dense_build: NULL pointer");
   KVQ_REQUIRE(locate_block(pl, block, &i, &par), KVQ_ERR_SHAPE, "kvq_swin3d_bias_dense_build: no block %d", block);
   const StageGeom& g = pl->st[i];
-  if (attn_b32(g))
-    return kvq_attn_bias_stream_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
-                                      bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
-  return kvq_attn_bias_dense_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
-                                   bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
+  return kvq_attn_bias32_build(g.d_tok[par], rpb, pl->cfg.frag_bias[i] ? fpb : nullptr, pl->table_len, pl->center,
+                               bias_types(g, par), g.N, g.nH, par, out, max_abs, stream);
 }
 
 extern "C" int kvq_swin3d_profile(KvqSwinPlan* pl, int enable) {
@@ -519,8 +501,9 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       // fused_qkv_prologue).  Un-padded partitions on the dense bias only.  Measured (bench.py --legs c2,no_sampler, two runs each,
       // same box): 300.4 -> 314.6 videos/s with the sampler in the step, 315.5 -> 330.1 without; stage-0 launch 133.5 -> 117.3 us.
       const bool fuse_qkv = bw.bias_dense && bw.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // by geometry only, never by batch
-      const bool b32 = bw.bias_dense && attn_b32(g);             // the image's layout follows the same rule (kvq_swin3d_bias_dense_build)
-      const float qs = b32 ? kQScaleLog2 : kQScale;
+      // attn32.hip (bias image) keeps its scores in log2 units: q is scaled by head_dim^-0.5 * log2(e) there; the gather path takes
+      // head_dim^-0.5.  Which one a block takes depends on its weights and geometry only, never on the batch.
+      const float qs = bw.bias_dense ? kQScaleLog2 : kQScale;
       // norm1 + pad + roll + window_partition
       if (g.Lp != g.L && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
@@ -537,7 +520,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       ln1_ready = false;
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
-        Bracket br(pl, st, KVQ_K_ATTN, (b32 ? 4 + 4 * attn_family() : 4) + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
+        Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
                    (fuse_qkv ? 2.0 * 2.0 * M * C + 6.0 * C * C : 2.0 * 4.0 * M * C) + (double)kvq_swin3d_bias_dense_bytes(pl, blk));
         KvqAttnDenseArgs aa{};
         aa.qkv = bbig; aa.bias_dense = bw.bias_dense; aa.n_types = bias_types(g, par); aa.BW = B * g.nW; aa.nW = g.nW; aa.N = g.N;
@@ -547,8 +530,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         aa.dsplit_from = (par == 1 && g.N == 392 && g.ws[0] == 8 && g.ws[1] == 7 && g.ws[2] == 7 && g.ss[0] == 4 && slabs >= 1)
                              ? g.nW - g.nW / slabs : -1;
         if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = qs; }
-        KVQ_TRY(!b32 ? kvq_window_attention_dense_args(&aa, st)
-                     : attn_family() == 1 ? kvq_window_attention_stream(&aa, st) : kvq_window_attention_unit32(&aa, st));
+        KVQ_TRY(kvq_window_attention32(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);

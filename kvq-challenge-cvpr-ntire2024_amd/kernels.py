@@ -127,88 +127,46 @@ def window_attention(qkv: torch.Tensor, tok: torch.Tensor, rpb: torch.Tensor, fp
     return out
 
 
-def attn_bias_dense(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor], center: int, nW: int, N: int,
-                    use_mask: bool):
-    """Dense attention bias of one block for ``window_attention_dense`` (include/kvq_hip.h); ``nW`` = the number of
-    window TYPES to build (the first nW windows' descriptors of ``tok``)."""
+LOG2E = 1.4426950408889634
+
+
+def attn_bias32(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor], center: int, nW: int, N: int, use_mask: bool):
+    """The attention bias image of one block for ``window_attention32`` (include/kvq_hip.h); ``nW`` = the number of window TYPES
+    to build (the first nW windows' descriptors of ``tok``)."""
     _need_gpu(tok, rpb, fpb)
     nH = rpb.shape[1]
-    out = torch.empty(lib().kvq_attn_bias_dense_bytes(nW, N, nH), dtype=torch.uint8, device=rpb.device)
+    out = torch.empty(lib().kvq_attn_bias32_bytes(nW, N, nH), dtype=torch.uint8, device=rpb.device)
     big = torch.zeros(1, dtype=torch.float32, device=rpb.device)
-    check(lib().kvq_attn_bias_dense_build(ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, nW, N, nH, int(use_mask),
-                                          ptr(out), ptr(big), current_stream()), "kvq_attn_bias_dense_build")
+    check(lib().kvq_attn_bias32_build(ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, nW, N, nH, int(use_mask),
+                                      ptr(out), ptr(big), current_stream()), "kvq_attn_bias32_build")
     out.max_abs_bias = big          # device scalar: largest un-masked |bias| (fp16 storage rounds by 2^-11 of it)
     return out
 
 
-def window_attention_dense(qkv: torch.Tensor, bias_dense: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
-                           tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1,
-                           x_ln: Optional[torch.Tensor] = None, w_qkv: Optional[torch.Tensor] = None, b_qkv: Optional[torch.Tensor] = None,
-                           q_scale: float = 1.0):
-    """qkv fp16|bf16 [3,nH,BW*N,32] (q pre-scaled) + pre-built bias; returns [BW*N, nH*32].  ``n_types`` (default nW):
-    window w uses bias w % n_types.  ``tile_skip`` int32 [nW]: bit t = q-tile t of the window is passed over (padding rows only);
-    the rows of such tiles keep what ``out`` held.  ``dsplit_from`` >= 0: windows >= it are depth-split (shifted (8,7,7) blocks).
-    ``x_ln`` [BW*N, C] + ``w_qkv`` [3C, C] + ``b_qkv`` [3C]: the launch computes q | k | v itself (``qkv`` = a [1|3, nH, BW*N, 32]
-    buffer whose first third receives q)."""
-    _need_gpu(qkv, bias_dense, tile_skip, out)
+def window_attention32(qkv: torch.Tensor, image: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
+                       tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1,
+                       x_ln: Optional[torch.Tensor] = None, w_qkv: Optional[torch.Tensor] = None, b_qkv: Optional[torch.Tensor] = None,
+                       q_scale: float = 1.0):
+    """qkv fp16|bf16 [3,nH,BW*N,32] with q scaled by head_dim^-0.5 * log2(e) + the pre-built bias image of ``attn_bias32``; returns
+    [BW*N, nH*32].  ``n_types`` (default nW): window w uses bias w % n_types.  ``tile_skip`` int32 [nW]: bit t = rows 16t..16t+15 of the
+    window are padding only (a 32-row q-block is passed over when both its tiles are; such rows keep what ``out`` held).
+    ``dsplit_from`` >= 0: windows >= it are depth-split (shifted (8,7,7) blocks).  ``x_ln`` [BW*N, C] + ``w_qkv`` [3C, C] + ``b_qkv`` [3C]:
+    the launch computes q | k | v itself (``qkv`` = a [1|3, nH, BW*N, 32] buffer whose first third receives q; ``q_scale`` =
+    head_dim^-0.5 * log2(e))."""
+    _need_gpu(qkv, image, tile_skip, out)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
     if out is None:
         out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
     a = _abi.KvqAttnDenseArgs()
-    a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(bias_dense), nW if n_types is None else n_types, BW, nW, N, nH
+    a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(image), nW if n_types is None else n_types, BW, nW, N, nH
     a.dtype, a.out, a.tile_skip, a.dsplit_from = dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), dsplit_from
     if x_ln is not None:      # fused qkv projection: ``qkv`` only lends its q third as scratch ([nH, BW*N, 32] is enough)
         _need_gpu(x_ln, w_qkv, b_qkv)
         assert x_ln.dtype == qkv.dtype == w_qkv.dtype and x_ln.is_contiguous() and w_qkv.is_contiguous() and b_qkv.dtype == torch.float32
         a.x_ln, a.w_qkv, a.b_qkv, a.q_scale = ptr(x_ln), ptr(w_qkv), ptr(b_qkv), q_scale
-    check(lib().kvq_window_attention_dense_args(C.byref(a), current_stream()), "kvq_window_attention_dense")
-    return out
-
-
-LOG2E = 1.4426950408889634
-
-
-def attn_bias_stream(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor], center: int, nW: int, N: int,
-                     use_mask: bool):
-    """The bias image of ``window_attention_stream`` (32 x 32 score blocks; include/kvq_hip.h); arguments as ``attn_bias_dense``."""
-    _need_gpu(tok, rpb, fpb)
-    nH = rpb.shape[1]
-    out = torch.empty(lib().kvq_attn_bias_stream_bytes(nW, N, nH), dtype=torch.uint8, device=rpb.device)
-    big = torch.zeros(1, dtype=torch.float32, device=rpb.device)
-    check(lib().kvq_attn_bias_stream_build(ptr(tok), ptr(rpb), ptr(fpb), rpb.shape[0], center, nW, N, nH, int(use_mask),
-                                           ptr(out), ptr(big), current_stream()), "kvq_attn_bias_stream_build")
-    out.max_abs_bias = big
-    return out
-
-
-def window_attention_stream(qkv: torch.Tensor, bias_stream: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
-                            tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1,
-                            unit: bool = False, x_ln: Optional[torch.Tensor] = None, w_qkv: Optional[torch.Tensor] = None,
-                            b_qkv: Optional[torch.Tensor] = None, q_scale: float = 1.0):
-    """The streaming attention kernel (csrc/attn32.hip): qkv fp16|bf16 [3,nH,BW*N,32] with q pre-scaled by
-    head_dim^-0.5 * log2(e), the image of ``attn_bias_stream``; returns [BW*N, nH*32].  Other arguments as ``window_attention_dense``.
-    ``unit``: the per-unit form (``kvq_window_attention_unit32``: the trunk's default), which also takes the fused qkv projection
-    (``x_ln`` / ``w_qkv`` / ``b_qkv`` / ``q_scale`` as ``window_attention_dense``)."""
-    _need_gpu(qkv, bias_stream, tile_skip, out)
-    assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
-    nH = qkv.shape[1]
-    BW = qkv.shape[2] // N
-    if out is None:
-        out = torch.empty(BW * N, nH * 32, dtype=qkv.dtype, device=qkv.device)
-    a = _abi.KvqAttnDenseArgs()
-    a.qkv, a.bias_dense, a.n_types, a.BW, a.nW, a.N, a.num_heads = ptr(qkv), ptr(bias_stream), nW if n_types is None else n_types, BW, nW, N, nH
-    a.dtype, a.out, a.tile_skip, a.dsplit_from = dtype_code(qkv.dtype), ptr(out), ptr(tile_skip), dsplit_from
-    if x_ln is not None:
-        assert unit, "the fused qkv projection exists in the per-unit form only"
-        _need_gpu(x_ln, w_qkv, b_qkv)
-        assert x_ln.dtype == qkv.dtype == w_qkv.dtype and x_ln.is_contiguous() and w_qkv.is_contiguous() and b_qkv.dtype == torch.float32
-        a.x_ln, a.w_qkv, a.b_qkv, a.q_scale = ptr(x_ln), ptr(w_qkv), ptr(b_qkv), q_scale
-    if unit:
-        check(lib().kvq_window_attention_unit32(C.byref(a), current_stream()), "kvq_window_attention_unit32")
-    else:
-        check(lib().kvq_window_attention_stream(C.byref(a), current_stream()), "kvq_window_attention_stream")
+    check(lib().kvq_window_attention32(C.byref(a), current_stream()), "kvq_window_attention32")
     return out
 
 

@@ -495,7 +495,7 @@ class SwinTransformer3D(nn.Module):
                 if tile == 4464:            # the 256 x 256 x 64 eight-phase kernel (csrc/gemm256.hip)
                     sym = f"gemm8p_kernel<{ename}, {epi}>"
             elif kind == "attn" and r.variant >= 4:
-                sym = f"window_attention_dense_kernel<{ename}>"
+                sym = f"window_attention32_kernel<{ename}>"
             elif kind == "attn":
                 sym = f"window_attention_kernel<{ename}, {str(bool(r.variant & 2)).lower()}, {str(bool(r.variant & 1)).lower()}>"
             elif kind == "layernorm":

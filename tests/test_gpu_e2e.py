@@ -158,20 +158,6 @@ def test_unfused_launch_chain_and_gather_attention_vs_reference_golden(golden, c
     assert np.abs(scores[0] - scores[1]).max() <= 3e-4
 
 
-@pytest.mark.parametrize("family", ["0", "1"])
-def test_other_attention_families_end_to_end_vs_reference_golden(family):
-    """KVQ_ATTN (read once per process: a child runs it) = 0: attn.hip's dense kernel (16 x 16 score tiles) on every stage; 1: the
-    persistent streaming form of attn32.hip where no qkv fusion applies.  The default (2: the per-unit 32-block kernel everywhere) is what
-    every other test of this file runs.  The reference's golden scores at the gate, full-size and padded / clamped cases, fp16."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, KVQ_ATTN=family)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "test_trunk_and_score_vs_reference_golden and fp16"], env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
-
-
 def test_full_size_vs_oracle_on_box():
     """Fresh seeds (not in the fixtures): oracle runs on this box's CPU, full 32x224x224, B=2."""
     cfg = synth.SWIN_T_GRPB

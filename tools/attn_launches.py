@@ -8,7 +8,7 @@ f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "window_attention" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-names = [("stream" if "stream" in r["Kernel_Name"] else "unit32" if "unit32" in r["Kernel_Name"] else "dense") for r in rows]
+names = [("a32" if "attention32" in r["Kernel_Name"] else "gather") for r in rows]
 n = len(dur) // per
 dur, names = dur[-per * (n - 1):], names[-per * (n - 1):]        # drop the first (warm-up) step
 steps = len(dur) // per

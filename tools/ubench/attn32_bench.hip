@@ -1,6 +1,6 @@
-// Standalone driver for window_attention_stream_kernel (csrc/attn32.hip): random q|k|v and a random bias image in the kernel's layout,
+// Standalone driver for window_attention32_kernel (csrc/attn32.hip): random q|k|v and a random bias image in the kernel's layout,
 // sampled rows against a host fp64 softmax, then the launch time at a trunk geometry.
-//   ./attn32_bench nW nH nclip N n_types [iters] [dsplit_from] [spike]     (stage 0 of C2: 128 3 4 392 64 | shifted: n_types 128)
+//   ./attn32_bench nW nH nclip N n_types [iters] [dsplit_from] [spike] [cold]     (stage 0 of C2: 128 3 4 392 64 | shifted: n_types 128)
 // spike = 1: some K rows are scaled up so that the running maximum grows past the rescale threshold in the middle of a row.
 #include <stdio.h>
 #include <stdlib.h>
@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
     KvqAttnDenseArgs a{};
     a.qkv = dqs[cold_q ? turn % dqs.size() : 0]; a.bias_dense = dbs[turn % dbs.size()]; ++turn; a.n_types = ntyp; a.BW = BW; a.nW = nW; a.N = N; a.num_heads = nH; a.dtype = KVQ_DT_FP16; a.out = dout;
     a.dsplit_from = dsplit;
-    return getenv("UNIT32") ? kvq_window_attention_unit32(&a, nullptr) : kvq_window_attention_stream(&a, nullptr);
+    return kvq_window_attention32(&a, nullptr);
   };
   if (run()) return 1;
   CK(hipDeviceSynchronize());
@@ -124,28 +124,6 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < h2.size(); ++i) diff += h2[i] != ho[i];
   }
   printf("repeat screen: %ld differing elements\n", diff);
-#ifdef KVQ_A32_TRACE
-  {
-    const int per = kvq::A32_CW + 1, nw = 256 * per;
-    unsigned long long* dt; CK(hipMalloc(&dt, nw * 64)); CK(hipMemset(dt, 0, nw * 64));
-    kvq::g_trace = dt;
-    run(); CK(hipDeviceSynchronize());
-    kvq::g_trace = nullptr;
-    std::vector<unsigned long long> ht(nw * 8);
-    CK(hipMemcpy(ht.data(), dt, nw * 64, hipMemcpyDeviceToHost));
-    double life = 0, f = 0, w = 0, qq = 0, n = 0, lmax = 0, w0 = 0, st = 0; int cnt = 0;
-    double ld[8] = {0}; int ldn[8] = {0};
-    for (int i = 0; i < nw; ++i) {
-      if (i % per == kvq::A32_CW) { for (int k = 0; k < 8; ++k) if (ht[i * 8 + k]) { ld[k] += ht[i * 8 + k]; ++ldn[k]; } continue; }
-      if (ht[i * 8]) { life += ht[i * 8]; f += ht[i * 8 + 1]; w += ht[i * 8 + 2]; qq += ht[i * 8 + 3]; n += ht[i * 8 + 4]; w0 += ht[i * 8 + 5]; st += ht[i * 8 + 6]; lmax = ht[i * 8] > lmax ? ht[i * 8] : lmax; ++cnt; }
-    }
-    printf("trace (%d consumer waves): start %.0f, life %.0f (max %.0f) ticks, per wave: fetch %.0f, ready wait %.0f (first item %.0f), q-blocks %.0f over %.2f items -> %.0f ticks per item\n",
-           cnt, st / cnt, life / cnt, lmax, f / cnt, w / cnt, w0 / cnt, qq / cnt, n / cnt, qq / n);
-    printf("loader: entries landed at");
-    for (int k = 0; k < 8; ++k) if (ldn[k]) printf(" %.0f", ld[k] / ldn[k]);
-    printf(" ticks after kernel start\n");
-  }
-#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) run();
   float best = 1e30f, tot = 0;
@@ -158,7 +136,7 @@ int main(int argc, char** argv) {
   }
   const double fl = 4.0 * (double)Mtot * N * nH * 32;
   const double blocks = (double)BW * nH * nqb * KB;
-  printf("STREAM%s nW=%d nH=%d clips=%d N=%d types=%d dsplit=%d: %.1f us mean, %.1f best -> %.1f TF/s (%.1f best); %.0f cycles per 32x32 block per SIMD at 2.1 GHz\n",
+  printf("ATTN32%s nW=%d nH=%d clips=%d N=%d types=%d dsplit=%d: %.1f us mean, %.1f best -> %.1f TF/s (%.1f best); %.0f cycles per 32x32 block per SIMD at 2.1 GHz\n",
          cold > 1 ? "(cold)" : "", nW, nH, nclip, N, ntyp, dsplit, tot / 5 * 1e3, best * 1e3, fl / (tot / 5 * 1e-3) / 1e12, fl / (best * 1e-3) / 1e12,
          tot / 5 * 1e-3 * 2.1e9 / (blocks / 1024.0));
   return bad || diff;

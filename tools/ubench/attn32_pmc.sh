@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / TCC counters of one attention geometry (separate --pmc passes; no trace domains).  usage: attn32_pmc.sh bin "128 3 4 392 64" tag [kernel name part]
-bin=$1; geo=$2; tag=$3; kname=${4:-window_attention_stream}
+bin=$1; geo=$2; tag=$3; kname=${4:-window_attention32}
 root=$(cd "$(dirname "$0")/../.." && pwd)
 out=$root/gpurun_out/attn_pmc_$tag
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
