@@ -412,11 +412,12 @@ def test_window_attention32_vs_oracle_and_gather_path(dims, window, shifted, gat
     assert (out - ref_img).abs().max().item() <= 6.4 * EPS[half]
     assert (ref_img - ref).abs().max().item() <= 2.0 ** -7
     assert (out - ref).abs().mean().item() <= 0.5 * EPS[half]
-    # the exact per-score path on the same inputs (its q un-scaled: one more 16-bit rounding of q): the two kernels' roundings + the image's
+    # the exact per-score path on the same inputs: the two kernels' roundings + the image's + ONE MORE 16-bit rounding of q (the gather
+    # kernel takes q un-scaled; re-rounding q moves every logit by up to 2^-9 (bf16) / 2^-12 (fp16) of its size)
     qg = rnd(q2 / kernels.LOG2E, half)
     qkv_g = dev(torch.stack([qg, k, v]).permute(0, 2, 1, 3, 4).reshape(3, nH, BW * N, 32).contiguous(), half)
     gather = kernels.window_attention(qkv_g, tokd, rpbd, fpbd, center, nW, N, use_mask).float().cpu()
-    assert (out - gather).abs().max().item() <= 6.0 * EPS[half] + (ref_img - ref).abs().max().item()
+    assert (out - gather).abs().max().item() <= 12.0 * EPS[half] + (ref_img - ref).abs().max().item()
     # q-blocks whose two 16-row tiles are both marked in tile_skip are passed over: their rows keep the sentinel
     skip = np.zeros(nW, np.int32)
     nqt = -(-N // 16)
