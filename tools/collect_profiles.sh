@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiling evidence of a round, collected on the GPU box (through gpurun, from the repo root):  bash tools/collect_profiles.sh r03
+# Profiling evidence of a round, collected on the GPU box (through gpurun, from the repo root):  bash tools/collect_profiles.sh r04
 # Outputs under gpurun_out/<tag>/ (the summaries are then copied into profiles/ as <tag>_*):
 #   bench_line.json        the default bench line (sampler in the step, all legs, rocprofv3 --pmc traffic passes, CPU baseline)
 #   bench_line_serial.json one stream
@@ -8,7 +8,7 @@
 #   pmc_sq.txt             rocprofv3 --pmc SQ_* (separate pass) of the same command
 #   c3_*, c5_*             the same for the C3 probe (bench.py --probe c3) and the C5 probe (bench.py --probe c5)
 #   gemm_sweep.txt, slowfast_layers.txt, attention / bias-build probes
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -31,6 +31,17 @@ timeout 300 python tools/sf_layers.py > $out/slowfast_layers.txt 2>&1
 timeout 300 python tools/gemm_sweep.py > $out/gemm_sweep.txt 2>&1
 timeout 300 python tools/swinb_probe.py 4 table > $out/c5_launches.txt 2>&1
 timeout 300 python tools/bias_build_probe.py > $out/bias_build.txt 2>&1
+# attention alone on the chip (tools/ubench/*.bin are built on the build host: hipcc ... attn32_bench.hip / attn32_loop.hip) and its counters
+if [ -x tools/ubench/attn32_bench.bin ]; then
+  (cd tools/ubench && ./attn32_run.sh attn32_bench.bin) > $out/attn32_standalone.txt 2>&1
+  (cd tools/ubench && for g in "128 3 4 392 64 20 -1" "32 6 4 392 32 20 16" "8 12 4 392 4 20 -1" "2 24 4 392 2 20 1"; do ./attn32_bench.bin $g 0 8 | tail -1; done) > $out/attn32_cold.txt 2>&1
+  [ -x tools/ubench/attn32_loop.bin ] && tools/ubench/attn32_loop.bin 50 > $out/attn32_loop.txt 2>&1
+  bash tools/ubench/attn32_pmc.sh attn32_bench.bin "128 3 4 392 64" $tag > /dev/null 2>&1; cp gpurun_out/attn_pmc_$tag.txt $out/attn32_pmc.txt 2>/dev/null
+fi
+for s in 0 1; do
+  rm -rf /tmp/tr_attn; TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_attn -o t -- $C2 --steps 8 --warmup 2 --min-timed-s 0 > /dev/null 2>&1
+  python tools/attn_launches.py /tmp/tr_attn >> $out/attn_launches.txt 2>&1
+done
 find $out -name "*.db" -size +20M -delete
 find $out -name "*counter_collection.csv" -size +20M -delete
 ls $out
