@@ -380,6 +380,12 @@ typedef struct {
   const uint16_t* w_qkv;
   const float* b_qkv;
   float q_scale;
+  /* Padded partitions (pad_mask != NULL, with b_qkv): uint32 [nW][13], bit (r & 31) of word r >> 5 of window w set = window row r is a
+   * PADDING row.  The reference computes qkv(0) = bias for such rows (F.pad after norm1, swin_backbone.py:416-449) and they take part in
+   * their window's softmax as keys: the kernel writes k | v = the 16-bit rounding of b_qkv's k / v thirds into those rows of its LDS
+   * images itself (what kvq_qkv_fill_pad would have put into `qkv`: those rows of `qkv` are then never read as keys) and takes their q as
+   * zero (their output rows are never read).  Saves the fill launch and its HBM round trip (Swin-B at 256 x 256: 79 MB per block). */
+  const uint32_t* pad_mask;
 } KvqAttnDenseArgs;
 int kvq_window_attention32(const KvqAttnDenseArgs* host_args, void* stream);
 

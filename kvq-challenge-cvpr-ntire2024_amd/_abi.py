@@ -65,7 +65,7 @@ class KvqSwinWeights(C.Structure):
 class KvqAttnDenseArgs(C.Structure):
     _fields_ = [("qkv", p_void), ("bias_dense", p_void), ("n_types", C.c_int32), ("BW", C.c_int32), ("nW", C.c_int32), ("N", C.c_int32),
                 ("num_heads", C.c_int32), ("dtype", C.c_int32), ("out", p_void), ("tile_skip", p_void), ("dsplit_from", C.c_int32),
-                ("x_ln", p_void), ("w_qkv", p_void), ("b_qkv", p_void), ("q_scale", C.c_float)]
+                ("x_ln", p_void), ("w_qkv", p_void), ("b_qkv", p_void), ("q_scale", C.c_float), ("pad_mask", p_void)]
 
 
 class KvqGemmArgs(C.Structure):

@@ -246,6 +246,7 @@ struct Attn32Params {
   const float* b_qkv;          // [3C]
   float q_scale;               // head_dim^-0.5 * log2(e)
   uint16_t* q_out;             // = the q third of qkv
+  const uint32_t* pad_mask;    // optional [nW][13]: bit r & 31 of word r >> 5 = window row r is a padding row (k | v = b_qkv's thirds, q = 0)
 };
 
 // q | k | v of one (window, head) from the window's norm1 rows (C = 32 KS): D^T[feature][row] = W[feature][:] . x[row][:] on
@@ -363,6 +364,22 @@ __global__ __launch_bounds__(A32_WAVES * 64, 3) void window_attention32_kernel(A
   if (tid == 0) *ticket = q_lo;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (!FUSED && p.pad_mask) {
+    // padded partition: the padding rows of the window are keys with k | v = qkv(0) = the bias (swin_backbone.py:416-449); their rows of
+    // the qkv buffer were never written — the images get the 16-bit rounding of the bias here (thread = one 16-B chunk of a row)
+    const uint32_t* pm = p.pad_mask + (size_t)w * A32_KB;
+    const int c = tid & 3;
+    const float* kb = p.b_qkv + C + h * 32 + 8 * c;
+    const float* vb = p.b_qkv + 2 * C + h * 32 + 8 * c;
+    const u32x4 kc = {E::pack2(kb[0], kb[1]), E::pack2(kb[2], kb[3]), E::pack2(kb[4], kb[5]), E::pack2(kb[6], kb[7])};
+    const u32x4 vc = {E::pack2(vb[0], vb[1]), E::pack2(vb[2], vb[3]), E::pack2(vb[4], vb[5]), E::pack2(vb[6], vb[7])};
+    for (int r = tid >> 2; r < N; r += A32_WAVES * 16)
+      if ((pm[r >> 5] >> (r & 31)) & 1u) {
+        *reinterpret_cast<u32x4*>(smem + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) = kc;
+        *reinterpret_cast<u32x4*>(smem + A32_K_BYTES + r * 64 + c * 16) = vc;
+      }
+    __syncthreads();
+  }
 
   const int q = lane & 31, hi = lane >> 5;
   const uint32_t skip = p.tile_skip ? p.tile_skip[w] : 0u;
@@ -383,6 +400,10 @@ __global__ __launch_bounds__(A32_WAVES * 64, 3) void window_attention32_kernel(A
     const int qrow = min(32 * qb + q, N - 1);
     r.qf0 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 8 * hi);
     r.qf1 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 16 + 8 * hi);
+    if (!FUSED && p.pad_mask && ((p.pad_mask[(size_t)w * A32_KB + qb] >> q) & 1u)) {      // a padding row's q was never written: take zero
+      r.qf0 = __builtin_bit_cast(V8, (u32x4){0u, 0u, 0u, 0u});
+      r.qf1 = r.qf0;
+    }
     const int t0 = (dsplit && qb > 6) ? 6 : 0;
     const u32x4* bd = img + (size_t)min(qb, nqb - 1) * (A32_KB * 128) + t0 * 128;
     r.pre[0] = bd[0]; r.pre[1] = bd[64];
@@ -548,6 +569,10 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
                      a->dsplit_from < 0 ? -1 : a->dsplit_from};
+  if (a->pad_mask) {
+    KVQ_REQUIRE(a->b_qkv && !a->x_ln, KVQ_ERR_NULL, "kvq_window_attention32: pad_mask needs b_qkv (and excludes the fused projection)");
+    p.pad_mask = a->pad_mask; p.b_qkv = a->b_qkv;
+  }
   if (a->x_ln) {
     const int C = 32 * num_heads;
     KVQ_REQUIRE(a->w_qkv && a->b_qkv, KVQ_ERR_NULL, "kvq_window_attention32: x_ln without w_qkv / b_qkv");

@@ -28,6 +28,7 @@ struct StageGeom {
   int32_t* d_src[2];  // [Lp] source token or -1
   int32_t* d_pad[2];  // [Lp - L] the padding rows of the partition (window order), nullptr when Lp == L
   int32_t* d_skip[2]; // [nW] bit t: rows 16t..16t+15 of the window are padding only (attention passes such q-tiles over), or nullptr
+  int32_t* d_padmask[2];  // [nW][13] bit r & 31 of word r >> 5: window row r is a padding row (attention32 writes its k | v itself), or nullptr
   int32_t* d_dst[2];  // [L] inverse of d_src (token -> window row).  A bijection — the next block's norm1 rows can be EMITTED through it —
                       // only when Lp == L (no padding)
   int32_t* d_tok[2];  // [nW*N][2]
@@ -145,9 +146,16 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
     rc = upload(pl, dst, &g.d_dst[par]);
     if (rc) return rc;
     g.d_skip[par] = nullptr;
+    g.d_padmask[par] = nullptr;
     if (!pad.empty()) {
       rc = upload(pl, pad, &g.d_pad[par]);
       if (rc) return rc;
+      if (g.N <= 13 * 32) {
+        std::vector<int32_t> pm((size_t)g.nW * 13, 0);
+        for (int i : pad) pm[(size_t)(i / g.N) * 13 + ((i % g.N) >> 5)] |= (int32_t)(1u << ((i % g.N) & 31));
+        rc = upload(pl, pm, &g.d_padmask[par]);
+        if (rc) return rc;
+      }
       std::vector<int32_t> skip((size_t)g.nW, 0);
       bool any = false;
       for (int wv = 0; wv < g.nW; ++wv)
@@ -511,7 +519,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
         KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, ML, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                      qs, g.d_dst[par], g.L, g.Lp));
-        KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, qs, pl->dtype, st));
+        // the padding rows' q | k | v = qkv(0) = bias: attention32 writes them into its own K | V images (pad_mask); the gather path
+        // reads them from the buffer
+        if (!(bw.bias_dense && g.d_padmask[par]))
+          KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, qs, pl->dtype, st));
       } else {
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
         if (!fuse_qkv)
@@ -530,6 +541,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         aa.dsplit_from = (par == 1 && g.N == 392 && g.ws[0] == 8 && g.ws[1] == 7 && g.ws[2] == 7 && g.ss[0] == 4 && slabs >= 1)
                              ? g.nW - g.nW / slabs : -1;
         if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = qs; }
+        if (g.Lp != g.L && bw.qkv_b && g.d_padmask[par]) { aa.pad_mask = (const uint32_t*)g.d_padmask[par]; aa.b_qkv = bw.qkv_b; }
         KVQ_TRY(kvq_window_attention32(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)

@@ -146,14 +146,15 @@ def attn_bias32(tok: torch.Tensor, rpb: torch.Tensor, fpb: Optional[torch.Tensor
 def window_attention32(qkv: torch.Tensor, image: torch.Tensor, nW: int, N: int, n_types: Optional[int] = None,
                        tile_skip: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, dsplit_from: int = -1,
                        x_ln: Optional[torch.Tensor] = None, w_qkv: Optional[torch.Tensor] = None, b_qkv: Optional[torch.Tensor] = None,
-                       q_scale: float = 1.0):
+                       q_scale: float = 1.0, pad_mask: Optional[torch.Tensor] = None):
     """qkv fp16|bf16 [3,nH,BW*N,32] with q scaled by head_dim^-0.5 * log2(e) + the pre-built bias image of ``attn_bias32``; returns
     [BW*N, nH*32].  ``n_types`` (default nW): window w uses bias w % n_types.  ``tile_skip`` int32 [nW]: bit t = rows 16t..16t+15 of the
     window are padding only (a 32-row q-block is passed over when both its tiles are; such rows keep what ``out`` held).
     ``dsplit_from`` >= 0: windows >= it are depth-split (shifted (8,7,7) blocks).  ``x_ln`` [BW*N, C] + ``w_qkv`` [3C, C] + ``b_qkv`` [3C]:
     the launch computes q | k | v itself (``qkv`` = a [1|3, nH, BW*N, 32] buffer whose first third receives q; ``q_scale`` =
-    head_dim^-0.5 * log2(e))."""
-    _need_gpu(qkv, image, tile_skip, out)
+    head_dim^-0.5 * log2(e)).  ``pad_mask`` int32 [nW, 13] (+ ``b_qkv``): bit r of window w = row r is a padding row — its k | v are
+    written by the kernel (= the bias), its q taken as zero; those rows of ``qkv`` are not read."""
+    _need_gpu(qkv, image, tile_skip, out, pad_mask)
     assert qkv.dtype in HALF_TYPES and qkv.is_contiguous()
     nH = qkv.shape[1]
     BW = qkv.shape[2] // N
@@ -166,6 +167,10 @@ def window_attention32(qkv: torch.Tensor, image: torch.Tensor, nW: int, N: int, 
         _need_gpu(x_ln, w_qkv, b_qkv)
         assert x_ln.dtype == qkv.dtype == w_qkv.dtype and x_ln.is_contiguous() and w_qkv.is_contiguous() and b_qkv.dtype == torch.float32
         a.x_ln, a.w_qkv, a.b_qkv, a.q_scale = ptr(x_ln), ptr(w_qkv), ptr(b_qkv), q_scale
+    if pad_mask is not None:
+        _need_gpu(b_qkv)
+        assert pad_mask.dtype == torch.int32 and pad_mask.is_contiguous() and (b_qkv is None or b_qkv.dtype == torch.float32)
+        a.pad_mask, a.b_qkv = ptr(pad_mask), ptr(b_qkv)
     check(lib().kvq_window_attention32(C.byref(a), current_stream()), "kvq_window_attention32")
     return out
 

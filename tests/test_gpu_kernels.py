@@ -527,6 +527,44 @@ def test_window_attention32_fused_qkv_projection(dims, shift, half):
                                    b_qkv=torch.empty(576, device=DEV), q_scale=scale)
 
 
+def test_window_attention32_writes_padding_rows_itself(half):
+    """Padded partitions: with ``pad_mask`` the kernel puts k | v = the qkv bias into the padding rows of its own K | V images and takes their
+    q as zero, instead of reading rows a separate launch (kvq_qkv_fill_pad) wrote into the buffer.  Same output, bit for bit, on every row
+    that is not a padding row — whatever the buffer holds in the padding rows (here: NaN)."""
+    g = rng(77)
+    dims, window = (8, 10, 9), (8, 7, 7)                        # H, W pad to 14: most windows hold padding rows
+    lay = O.window_layout(*dims, window, (4, 3, 3))
+    N, nW, nH, B = lay["N"], lay["nW"], 2, 2
+    BW = B * nW
+    C = 32 * nH
+    pad = torch.from_numpy(lay["src"].reshape(nW, N) < 0)
+    assert bool(pad.any()) and not bool(pad.all(1).any())
+    bq = torch.from_numpy(0.4 * g.standard_normal(3 * C).astype(np.float32))
+    qkv = rnd(torch.from_numpy(g.standard_normal((3, nH, BW, N, 32)).astype(np.float32)) * 0.7, half)
+    padb = pad[None, None].expand(nH, B, nW, N).reshape(nH, BW, N)
+    filled = qkv.clone()
+    for which in (1, 2):                                        # what kvq_qkv_fill_pad writes: the 16-bit rounding of the bias
+        bias = rnd(bq[which * C:(which + 1) * C].reshape(nH, 1, 1, 32), half).expand(nH, BW, N, 32)
+        filled[which][padb] = bias[padb]
+    filled[0][padb] = 0.0
+    holes = qkv.clone()
+    holes[:, padb] = float("nan")
+    rpb = torch.from_numpy((0.5 * g.standard_normal((2535, nH))).astype(np.float32))
+    tok, center = _tok_table(lay, window)
+    image = kernels.attn_bias32(dev(torch.from_numpy(tok)), dev(rpb), None, center, nW, N, True)
+    mask = np.zeros((nW, 13), np.uint32)
+    for wv in range(nW):
+        for r in np.nonzero(pad[wv].numpy())[0]:
+            mask[wv, r >> 5] |= np.uint32(1) << np.uint32(r & 31)
+    ref = kernels.window_attention32(dev(filled.reshape(3, nH, BW * N, 32), half), image, nW, N).float().cpu()
+    out = kernels.window_attention32(dev(holes.reshape(3, nH, BW * N, 32), half), image, nW, N, b_qkv=dev(bq),
+                                     pad_mask=dev(torch.from_numpy(mask.view(np.int32)))).float().cpu()
+    keep = ~pad[None].expand(B, nW, N).reshape(-1)
+    assert torch.isfinite(out[keep]).all() and torch.equal(out[keep], ref[keep])
+    with pytest.raises(RuntimeError, match="b_qkv"):
+        kernels.window_attention32(dev(holes.reshape(3, nH, BW * N, 32), half), image, nW, N, pad_mask=dev(torch.from_numpy(mask.view(np.int32))))
+
+
 def test_window_attention_rejects_large_window():
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.window_attention(torch.zeros(3, 1, 512, 32, dtype=torch.float16, device=DEV),
