@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("KVQ_OPERAND_DTYPE", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-sampler", action="store_true",
                     help="headline on pre-sampled fp32 clips (K1 outside the timed region); default: K1 inside it")
+    ap.add_argument("--two-launch-sampler", action="store_true",
+                    help="K1 as its own launches (kvq_fragment_gather per clip -> the fp32 batch tensor -> forward) instead of the "
+                         "default: the forward reads the patch-embedding operand through the sampler (kvq_swin3d_forward_fragments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=24, help="clips the CPU oracle is timed on (24 = 3 videos)")
     ap.add_argument("--streams", type=int, default=4,
@@ -58,7 +61,7 @@ def parse():
                          "measured 1 / 2 / 3 / 4 / 5 / 6 streams: 2.12 / 1.77 / 1.76 / 1.745 / 1.84 / 1.71-1.84 ms per step)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
-    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,bf16,batch8,c3,c5,ksvqe ('all', 'c2' = none)")
+    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,two_launch,bf16,batch8,c3,c5,ksvqe ('all', 'c2' = none)")
     ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the K-step block until this many seconds are timed")
@@ -137,6 +140,17 @@ class Source:
             self.hoff.append((rh + gh).int().to(device))
             self.woff.append((rw + gw).int().to(device))
         self.n = n
+        self._fs = {}
+
+    def fragments(self, first, B):
+        """clips first .. first+B-1 (mod pool) as a FragmentSource: K1's arguments, for the forward that reads through the sampler"""
+        from kvq_amd import kernels
+        key = (first % self.n, B)
+        if key not in self._fs:
+            idx = [(first + b) % self.n for b in range(B)]
+            self._fs[key] = kernels.FragmentSource([self.clips[i] for i in idx], [self.hoff[i] for i in idx],
+                                                   [self.woff[i] for i in idx], 7, 7, 32, 32, 8, mean=MEAN, std=STD)
+        return self._fs[key]
 
     def sample_into(self, x, first):
         """K1: clips first .. first+B-1 (mod pool) -> the (B, 3, 32, 224, 224) fp32 batch tensor ``x``, normalised."""
@@ -237,6 +251,8 @@ def pmc_traffic(leg, steps, dtype, batch):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "c", "--", sys.executable, os.path.abspath(__file__),
                    "--probe", leg, "--probe-steps", str(steps), "--dtype", dtype, "--batch", str(batch)]
+            if "--two-launch-sampler" in sys.argv:
+                cmd.append("--two-launch-sampler")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -517,9 +533,16 @@ def setup_c5(args, device):
                 bb.prepare(B, 64, 256, 256, device)
         torch.cuda.synchronize()
 
+    frs = {}
+
     def one(s, ln):
-        for b in range(B):
-            i = (s * B + b) % npool
+        idx = [(s * B + b) % npool for b in range(B)]
+        if not args.two_launch_sampler:          # the embedding launch reads through the sampler
+            if idx[0] not in frs:
+                frs[idx[0]] = kernels.FragmentSource([clips[i] for i in idx], [hoff[i] for i in idx], [woff[i] for i in idx],
+                                                     8, 8, 32, 32, 8, mean=MEAN, std=STD)
+            return head(bb({"technical": frs[idx[0]]}))
+        for b, i in enumerate(idx):
             kernels.fragment_gather(clips[i], hoff[i], woff[i], 8, 8, 32, 32, 8, MEAN, STD, out=xs[ln][b])
         return head(bb({"technical": xs[ln]}))
 
@@ -580,8 +603,11 @@ def run_probe(args):
                 net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
                 x = torch.empty(B, 3, 32, 224, 224, device=device)
                 for s in range(args.probe_steps):
-                    src.sample_into(x, s * B)
-                    net(inputs={"technical": x}, reduce_scores=True)
+                    if args.two_launch_sampler:
+                        src.sample_into(x, s * B)
+                        net(inputs={"technical": x}, reduce_scores=True)
+                    else:
+                        net(inputs={"technical": src.fragments(s * B, B)}, reduce_scores=True)
             else:
                 *_, serial = setup_c3(args, device, net, src)
                 serial(args.probe_steps)
@@ -623,7 +649,7 @@ def main():
     B = args.batch
     nstream = max(1, args.streams)
     lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
-    legs = {"no_sampler", "bf16", "batch8", "c3", "c5", "ksvqe"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
+    legs = {"no_sampler", "two_launch", "bf16", "batch8", "c3", "c5", "ksvqe"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
     if world > 1:
         legs = set()
 
@@ -637,9 +663,14 @@ def main():
                 bb.prepare(B, 32, 224, 224, device)
         torch.cuda.synchronize()
 
-    def step_sampled(s, ln):
+    def step_two_launch(s, ln):
         src.sample_into(xs[ln], s * B)
         return net(inputs={"technical": xs[ln]}, reduce_scores=True)
+
+    def step_fused(s, ln):
+        return net(inputs={"technical": src.fragments(s * B, B)}, reduce_scores=True)
+
+    step_sampled = step_two_launch if args.two_launch_sampler else step_fused
 
     # pre-sampled clips for the --no-sampler definition: K1 run once, outside the timed region, distinct per step
     pre = None
@@ -706,7 +737,8 @@ def main():
         want_pmc = world == 1 and not args.no_pmc and args.profile_steps > 0
         if args.profile_steps > 0:
             src.sample_into(xs[0], 0)
-            roof = c2_roofline(net, {"technical": xs[0]}, B, args.profile_steps)
+            fused = sampler_on and not args.two_launch_sampler
+            roof = c2_roofline(net, {"technical": src.fragments(0, B) if fused else xs[0]}, B, args.profile_steps)
             attach_traffic(roof, pmc_traffic("c2", 2, args.dtype, B) if want_pmc else None)
         out = {
             "metric": "videos/sec (8-frag x 32 x 224 x 224)", "value": value, "unit": "videos/s",
@@ -716,9 +748,14 @@ def main():
                     "all resident in HBM before the timed region)",
             "config": {"workload": "C2: KSVQE Swin3D-T(GRPB) trunk + VQAHead, 3x32x224x224 clips, video = 8 clips"
                                    + (", fragment sampler K1 (uint8 3x32x540x960 per clip -> 7x7 grid of 32x32 patches, normalised) "
-                                      "inside the step" if sampler_on else ", pre-sampled fp32 clips (K1 outside the step)"),
+                                      "inside the step" + (" as its own launches" if args.two_launch_sampler else
+                                                           ", read through by the patch-embedding launch (no fp32 clip in HBM)")
+                                      if sampler_on else ", pre-sampled fp32 clips (K1 outside the step)"),
                        "clips_per_gpu_per_step": B, "operand_dtype": args.dtype, "accumulate": "fp32",
-                       "sampler_in_step": sampler_on, "source_pool_clips": src.n, "distinct_clips_per_step": True,
+                       "sampler_in_step": sampler_on,
+                       "sampler": ("kvq_fragment_gather per clip, then the forward" if args.two_launch_sampler or not sampler_on
+                                   else "kvq_swin3d_forward_fragments (K1 fused into the embedding's operand read; bit-identical scores)"),
+                       "source_pool_clips": src.n, "distinct_clips_per_step": True,
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
                        "streams": nstream, "overlap": "steps" if nstream > 1 else "none", "hipgraph": bool(args.graph)},
             "repeats": tstats["repeats"], "ms_per_step_min": tstats["ms_per_step_min"], "ms_per_step_max": tstats["ms_per_step_max"],
@@ -739,6 +776,15 @@ def main():
                                      "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps, "repeats": st2["repeats"],
                                      "note": "same steps on pre-sampled fp32 clips (K1 outside the timed region, distinct clips per "
                                              "step): the round-1 definition of the step"}
+            if "two_launch" in legs and sampler_on and not args.two_launch_sampler:
+                dt4, outs4, _, st4 = timed(kd, device, steps_of(step_two_launch), args.steps, min(args.warmup, 5), first=args.warmup,
+                                           min_s=args.min_timed_s)
+                s4 = torch.cat([o.reshape(-1) for o in outs4]).float().cpu()
+                out["two_launch_sampler"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt4, "unit": "videos/s",
+                                             "ms_per_step": 1e3 * dt4 / args.steps, "steps": args.steps, "repeats": st4["repeats"],
+                                             "scores_equal_headline": bool(torch.equal(s4, fp_scores)),
+                                             "note": "the same steps with K1 as its own launches (kvq_fragment_gather per clip writes the "
+                                                     "fp32 batch tensor, the forward reads it back): rounds 2-4's step"}
             if "bf16" in legs and args.dtype == "fp16":
                 bb.operand_dtype = _abi.dtype_code("bf16")
                 for st in lanes:
@@ -768,6 +814,8 @@ def main():
                 torch.cuda.synchronize()
 
                 def step8(s, ln):
+                    if not args.two_launch_sampler:
+                        return net(inputs={"technical": src.fragments(s * B8, B8)}, reduce_scores=True)
                     src.sample_into(xs8[ln], s * B8)
                     return net(inputs={"technical": xs8[ln]}, reduce_scores=True)
                 k8 = max(4, args.steps // 2)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 26
+#define KVQ_ABI_VERSION 27
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -128,6 +128,20 @@ size_t kvq_swin3d_workspace_bytes(const KvqSwinPlan* plan);
 /* Output geometry: C_out, D, H', W' of the (B, C_out, D, H', W') feature map. */
 int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
 
+#define KVQ_FRAG_MAX_CLIPS 16
+/* A batch of clips that is still (decoded frames, sampler draws): what kvq_fragment_gather would be called with, clip by clip.
+ * kvq_patch_embed / kvq_swin3d_forward_fragments read the patch-embedding operand straight from it — get_spatial_fragments
+ * (fusion_datasets.py:22-121) + (v - mean) / std (:1017-1020) happen in registers, with the same fp32 arithmetic, and the fp32
+ * (B,3,T,H,W) clip (4 B/pixel written, 4 B/pixel read back) never exists. */
+typedef struct {
+  const void* video[KVQ_FRAG_MAX_CLIPS];     /* clip b: uint8 (C, T, Hs, Ws), device                                */
+  const int32_t* hoff[KVQ_FRAG_MAX_CLIPS];   /* clip b: int32 [Fh][Fw][T/aligned] absolute patch origins, device    */
+  const int32_t* woff[KVQ_FRAG_MAX_CLIPS];
+  int32_t n_clips, src_is_u8, Hs, Ws, Fh, Fw, fs_h, fs_w, aligned;
+  int32_t normalise;                         /* 0: raw pixel values                                                  */
+  float mean[4], std[4];
+} KvqFragmentSource;
+
 /* SwinTransformer3D.forward (swin_backbone.py:1044-1080), multi=False, layer=-1.
  *   x     fp32 (B,3,T,H,W) contiguous                      — batch['technical']
  *   feat  fp32 channels-LAST (B, D, H', W', C_out); the host wrapper returns the
@@ -135,6 +149,12 @@ int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
  * When score != NULL the VQAHead (models/head.py:60-68) is applied too (see kvq_vqa_head). */
 int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, float* feat,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward on a batch that is still (frames, sampler draws) (KvqFragmentSource above): K1 fused into the patch
+ * embedding's operand read.  Bit-identical to kvq_fragment_gather per clip + kvq_swin3d_forward.  KVQ_ERR_UNSUPPORTED when
+ * the plan does not take the fused embedding launch or kvq_patch_embed_fragments_supported says no (the caller then runs
+ * the two calls). */
+int kvq_swin3d_forward_fragments(const KvqSwinPlan* plan, const KvqSwinWeights* w, const KvqFragmentSource* src,
+                                 float* feat, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Feature taps of SwinTransformer3D.forward (swin_backbone.py:1060-1078: ``feats = [embed, stage 0, ..., stage n-1]``,
  * read by ``multi=True`` and ``layer > -1``).  taps[i] (i = 0..num_stages) is NULL or a caller-owned fp32 channels-LAST
@@ -263,7 +283,7 @@ int kvq_debug_gemm_trace(void* dev_buf, int max_blocks);
  * first block's norm1 in its window order.  Fused shape: patch (pd,4,4), in_chans*pd == 6, E in {96,128}, clip
  * dimensions multiples of the patch (anything else takes the im2col + GEMM + LayerNorm launches). */
 typedef struct {
-  const float* x;              /* fp32 (B, in_chans, T, H, W)                                           */
+  const float* x;              /* fp32 (B, in_chans, T, H, W); NULL when frag is set                    */
   int32_t B, in_chans, T, H, W;
   int32_t pd, ph, pw, embed_dim;
   const void* pack;            /* kvq_patch_embed_pack image                                            */
@@ -276,8 +296,12 @@ typedef struct {
   int32_t next_rows;
   float eps;
   int32_t dtype;
+  const KvqFragmentSource* frag; /* host struct or NULL: read the clip through the sampler (T, H, W = the sampled clip's) */
 } KvqPatchEmbedArgs;
 int kvq_patch_embed_supported(int in_chans, int pd, int ph, int pw, int embed_dim, int T, int H, int W);
+/* 1 when the fused read applies to a (B, in_chans, T, H, W) batch sampled from src: uint8 frames, 4 x 4 patches inside the
+ * mini-patches (fs_h, fs_w multiples of 4), Fh*fs_h == H, Fw*fs_w == W, source >= canvas, one clip per 32 tokens. */
+int kvq_patch_embed_fragments_supported(const KvqFragmentSource* src, int B, int in_chans, int pd, int T, int H, int W);
 size_t kvq_patch_embed_pack_bytes(int embed_dim, int K);
 /* w: 16-bit [E][K = in_chans*pd*ph*pw] (Conv3d weight order); ln_w / ln_b may be NULL (no norm). */
 int kvq_patch_embed_pack(const void* w, const float* bias, const float* ln_w, const float* ln_b, int embed_dim, int K,

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 def dtype_code(dt) -> int:
@@ -109,12 +109,22 @@ class KvqBlockTailArgs(C.Structure):
                 ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32), ("attn_gather", p_void)]
 
 
+FRAG_MAX_CLIPS = 16
+
+
+class KvqFragmentSource(C.Structure):
+    _fields_ = [("video", p_void * FRAG_MAX_CLIPS), ("hoff", p_void * FRAG_MAX_CLIPS), ("woff", p_void * FRAG_MAX_CLIPS),
+                ("n_clips", C.c_int32), ("src_is_u8", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Fh", C.c_int32),
+                ("Fw", C.c_int32), ("fs_h", C.c_int32), ("fs_w", C.c_int32), ("aligned", C.c_int32), ("normalise", C.c_int32),
+                ("mean", C.c_float * 4), ("std", C.c_float * 4)]
+
+
 class KvqPatchEmbedArgs(C.Structure):
     _fields_ = [("x", p_void), ("B", C.c_int32), ("in_chans", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
                 ("W", C.c_int32), ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32), ("embed_dim", C.c_int32),
                 ("pack", p_void), ("has_norm", C.c_int32), ("out", p_void), ("next_norm_w", p_void),
                 ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void), ("next_rows", C.c_int32),
-                ("eps", C.c_float), ("dtype", C.c_int32)]
+                ("eps", C.c_float), ("dtype", C.c_int32), ("frag", C.POINTER(KvqFragmentSource))]
 
 
 class KvqProfRecord(C.Structure):
@@ -161,6 +171,8 @@ SYMBOLS = {
     "kvq_swin3d_tap_dims": (i32, [p_void, i32, C.POINTER(i32 * 4)]),
     "kvq_resize_trilinear_cl": (i32, [p_void, i32, i32, i32, i32, i32, p_void, i32, i32, i32, i32, i32, p_void]),
     "kvq_swin3d_forward": (i32, [p_void, C.POINTER(KvqSwinWeights), p_void, p_void, p_void, sz, p_void]),
+    "kvq_swin3d_forward_fragments": (i32, [p_void, C.POINTER(KvqSwinWeights), C.POINTER(KvqFragmentSource), p_void, p_void, sz,
+                                           p_void]),
     "kvq_swin3d_profile": (i32, [p_void, i32]),
     "kvq_swin3d_profile_read": (i32, [p_void, C.POINTER(KvqProfRecord), i32, C.POINTER(i32)]),
     "kvq_layernorm_rows": (i32, [p_void, p_void, i32, i32, i32, i32, i32, p_void, p_void, f32, p_void, i32, p_void,
@@ -171,6 +183,7 @@ SYMBOLS = {
     "kvq_debug_gemm_trace": (i32, [p_void, i32]),
     "kvq_gemm_tile_mode": (i32, [i32]),
     "kvq_patch_embed_supported": (i32, [i32] * 8),
+    "kvq_patch_embed_fragments_supported": (i32, [C.POINTER(KvqFragmentSource), i32, i32, i32, i32, i32, i32]),
     "kvq_patch_embed_pack_bytes": (sz, [i32, i32]),
     "kvq_patch_embed_pack": (i32, [p_void, p_void, p_void, p_void, i32, i32, p_void, p_void]),
     "kvq_patch_embed": (i32, [C.POINTER(KvqPatchEmbedArgs), p_void]),

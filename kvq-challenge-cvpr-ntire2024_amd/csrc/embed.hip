@@ -7,12 +7,27 @@
 // h takes patch rows 2h, 2h+1 — two 16-B loads (4 fp32 pixels each) that are contiguous across the 32 lanes of a
 // token row.  No im2col buffer, no separate LayerNorm launch: the clip is read once (4 B/pixel) and the residual
 // stream written once, instead of im2col (write 2 B/px) + GEMM (read 2, write 4·E/K) + LayerNorm (read/write 4·E/K).
+//
+// FRAG variant: the clip is never materialised.  The B operand comes straight out of the decoded uint8 frames through
+// the fragment sampler's patch origins (get_spatial_fragments, fusion_datasets.py:22-121: a 4 x 4 patch lies inside one
+// fs_h x fs_w mini-patch, so its rows are two 4-byte runs of a source row) and is normalised in registers with the same
+// IEEE fp32 (v - mean) / std as kvq_fragment_gather — the operands are bit-identical to the two-launch sequence, which
+// wrote the fp32 clip (4 B/px) and read it back (4 B/px).
 #include "common.hpp"
 
 namespace kvq {
 
+struct FragSrc {
+  const uint8_t* video[KVQ_FRAG_MAX_CLIPS];   // clip b: (Cin, T, Hs, Ws)
+  const int32_t* hoff[KVQ_FRAG_MAX_CLIPS];    // clip b: [Fh][Fw][T / aligned] patch origins
+  const int32_t* woff[KVQ_FRAG_MAX_CLIPS];
+  int Hs, Ws, Fw, fsh, fsw, aligned;
+  float mean[4], std[4];
+};
+
 struct EmbedParams {
-  const float* x;            // (B, Cin, T, H, W)
+  const float* x;            // (B, Cin, T, H, W); unused by the FRAG variant
+  FragSrc frag;
   int B, Cin, T, H, W, pd, D0, H0, W0;
   const unsigned char* pack; // kvq_patch_embed_pack image
   int has_ln;                // patch_embed.norm present
@@ -47,7 +62,7 @@ __global__ void embed_pack_kernel(const uint16_t* w, const float* bias, const fl
   }
 }
 
-template <typename E_, int CM, int KS, bool EMIT>
+template <typename E_, int CM, int KS, bool EMIT, bool FRAG>
 __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
   fp16_saturate_mode();
   constexpr int E = 32 * CM, WBYTES = CM * KS * 1024;
@@ -72,7 +87,32 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
   const int d = tl / (p.H0 * p.W0), hw = tl - d * (p.H0 * p.W0), hh = hw / p.W0, ww = hw - hh * p.W0;
   const bool live = row < total;
   V8 bx[KS];
-  {
+  uint32_t raw[FRAG ? KS : 1][2];
+  float* s_nn = reinterpret_cast<float*>(lds + NQ * 1024);    // past the DMA image (its last KB is padding)
+  float* s_tab = s_nn + 2 * E;                                // FRAG: [Cin <= 4][256] normalised pixel values
+  if constexpr (FRAG) {
+    // a wave's 32 tokens lie in one clip (L0 % 32 == 0, checked on the host): the per-clip pointers are scalar loads
+    const FragSrc& f = p.frag;
+    const int bu = __builtin_amdgcn_readfirstlane(b);
+    const int oy = hh * 4 + 2 * h, ox = ww * 4;
+    const int fi = oy / f.fsh, fj = ox / f.fsw;
+    const int nt = p.T / f.aligned;
+    const int32_t* ho = f.hoff[bu] + (fi * f.Fw + fj) * nt;
+    const int32_t* wo = f.woff[bu] + (fi * f.Fw + fj) * nt;
+    const size_t plane = (size_t)f.Hs * f.Ws;
+    const uint8_t* vb = f.video[bu];
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = s / p.pd, t = d * p.pd + (s - c * p.pd), g = t / f.aligned;
+      const uint8_t* src = vb + ((size_t)c * p.T + t) * plane + (size_t)(ho[g] + (oy - fi * f.fsh)) * f.Ws + (wo[g] + (ox - fj * f.fsw));
+      raw[s][0] = *reinterpret_cast<const u32u*>(src);
+      raw[s][1] = *reinterpret_cast<const u32u*>(src + f.Ws);
+    }
+    // a pixel is one of 256 bytes: (v - mean) / std — the IEEE fp32 divide of fragment_gather_kernel — once per byte value
+    // and channel (Cin divides per thread) instead of once per pixel (8 * KS per lane); looked up below, behind the barrier
+    for (int c = 0; c < p.Cin; ++c) s_tab[c * 256 + tid] = ((float)tid - f.mean[c]) / f.std[c];
+  } else {
     const size_t plane = (size_t)p.H * p.W;
     const float* base = p.x + (size_t)b * p.Cin * p.T * plane + (size_t)(d * p.pd) * plane + (size_t)(hh * 4 + 2 * h) * p.W + ww * 4;
 #pragma unroll
@@ -85,10 +125,20 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
       bx[s] = __builtin_bit_cast(V8, w);
     }
   }
-  float* s_nn = reinterpret_cast<float*>(lds + NQ * 1024);    // past the DMA image (its last KB is padding)
   if (EMIT && tid < E / 2) *reinterpret_cast<f32x4*>(s_nn + 4 * tid) = nn_reg;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (FRAG) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float* tab = s_tab + (s / p.pd) * 256;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tab[(raw[s][e >> 2] >> (8 * (e & 3))) & 255u];
+      const u32x4 w = {E_::pack2(v[0], v[1]), E_::pack2(v[2], v[3]), E_::pack2(v[4], v[5]), E_::pack2(v[6], v[7])};
+      bx[s] = __builtin_bit_cast(V8, w);
+    }
+  }
 
   f32x16 acc[CM];
 #pragma unroll
@@ -172,11 +222,16 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
 
 template <typename E_, int CM, int KS>
 static int launch_embed(const EmbedParams& p, hipStream_t st) {
-  const size_t lds = (size_t)CM * KS * 1024 + (size_t)5 * 32 * CM * 4 + 1024;
+  const size_t lds = (size_t)CM * KS * 1024 + (size_t)5 * 32 * CM * 4 + 1024 + (p.x ? 0 : 4 * 256 * 4);
   const long total = (long)p.B * p.D0 * p.H0 * p.W0;
   dim3 grid((unsigned)((total + 127) / 128)), block(256);
-  if (p.next_ln) hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, true>), grid, block, lds, st, p);
-  else hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, false>), grid, block, lds, st, p);
+  if (p.x == nullptr) {
+    if (p.next_ln) hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, false, true>), grid, block, lds, st, p);
+  } else {
+    if (p.next_ln) hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, true, false>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, false, false>), grid, block, lds, st, p);
+  }
   KVQ_CHECK_LAUNCH("patch_embed_kernel");
   return KVQ_OK;
 }
@@ -206,9 +261,19 @@ extern "C" int kvq_patch_embed_pack(const void* w, const float* bias, const floa
   return KVQ_OK;
 }
 
+extern "C" int kvq_patch_embed_fragments_supported(const KvqFragmentSource* f, int B, int in_chans, int pd, int T, int H, int W) {
+  // uint8 frames; whole 4 x 4 patches inside a mini-patch; one clip per wave of 32 tokens; frames of a token in range
+  if (!f || !f->src_is_u8 || f->n_clips != B || B > KVQ_FRAG_MAX_CLIPS || in_chans > 4 || pd <= 0) return 0;
+  if (f->fs_h <= 0 || f->fs_w <= 0 || f->fs_h % 4 || f->fs_w % 4 || f->Fh * f->fs_h != H || f->Fw * f->fs_w != W) return 0;
+  if (f->aligned <= 0 || T % f->aligned || T % pd) return 0;
+  if (f->Hs < H || f->Ws < W) return 0;                      // the upsample fallback is not in the hot path (as kvq_fragment_gather)
+  return ((long)(T / pd) * (H / 4) * (W / 4)) % 32 == 0 ? 1 : 0;
+}
+
 extern "C" int kvq_patch_embed(const KvqPatchEmbedArgs* a, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(a && a->x && a->pack && a->out, KVQ_ERR_NULL, "kvq_patch_embed: NULL pointer");
+  KVQ_REQUIRE(a && (a->x || a->frag) && a->pack && a->out, KVQ_ERR_NULL, "kvq_patch_embed: NULL pointer");
+  KVQ_REQUIRE(!(a->x && a->frag), KVQ_ERR_UNSUPPORTED, "kvq_patch_embed: both a clip and a fragment source");
   KVQ_REQUIRE(kvq_patch_embed_supported(a->in_chans, a->pd, a->ph, a->pw, a->embed_dim, a->T, a->H, a->W), KVQ_ERR_UNSUPPORTED,
               "kvq_patch_embed: patch (%d,%d,%d) x %d channels -> %d on %dx%dx%d is not the fused shape", a->pd, a->ph, a->pw,
               a->in_chans, a->embed_dim, a->T, a->H, a->W);
@@ -217,6 +282,18 @@ extern "C" int kvq_patch_embed(const KvqPatchEmbedArgs* a, void* stream) {
               "kvq_patch_embed: next_ln without its norm / map");
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_patch_embed: dtype %d", a->dtype);
   EmbedParams p{};
+  if (a->frag) {
+    const KvqFragmentSource* f = a->frag;
+    KVQ_REQUIRE(kvq_patch_embed_fragments_supported(f, a->B, a->in_chans, a->pd, a->T, a->H, a->W), KVQ_ERR_UNSUPPORTED,
+                "kvq_patch_embed: fragment source (%d clips, u8=%d, %dx%d patches of %dx%d, aligned %d) does not fit the fused read "
+                "of a %dx%dx%dx%d batch", f->n_clips, f->src_is_u8, f->Fh, f->Fw, f->fs_h, f->fs_w, f->aligned, a->B, a->T, a->H, a->W);
+    for (int b = 0; b < a->B; ++b) {
+      KVQ_REQUIRE(f->video[b] && f->hoff[b] && f->woff[b], KVQ_ERR_NULL, "kvq_patch_embed: fragment source clip %d has a NULL pointer", b);
+      p.frag.video[b] = (const uint8_t*)f->video[b]; p.frag.hoff[b] = f->hoff[b]; p.frag.woff[b] = f->woff[b];
+    }
+    p.frag.Hs = f->Hs; p.frag.Ws = f->Ws; p.frag.Fw = f->Fw; p.frag.fsh = f->fs_h; p.frag.fsw = f->fs_w; p.frag.aligned = f->aligned;
+    for (int c = 0; c < 4; ++c) { p.frag.mean[c] = f->normalise ? f->mean[c] : 0.f; p.frag.std[c] = f->normalise ? f->std[c] : 1.f; }   // (v - 0) / 1 == v
+  }
   p.x = a->x; p.B = a->B; p.Cin = a->in_chans; p.T = a->T; p.H = a->H; p.W = a->W; p.pd = a->pd;
   p.D0 = a->T / a->pd; p.H0 = a->H / 4; p.W0 = a->W / 4;
   p.pack = (const unsigned char*)a->pack; p.has_ln = a->has_norm; p.out = a->out; p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b;

@@ -420,7 +420,7 @@ extern "C" int kvq_swin3d_tap_dims(const KvqSwinPlan* pl, int index, int32_t out
 // the residual stream `io` (fp32 channels-last (B, D, H_lo, W_lo, C_lo), copied into the workspace).  Afterwards `io`, when
 // given, receives the residual stream behind stage_hi (incl. its PatchMerging), and — stage_hi being the last stage — `feat`,
 // when given, the final LayerNorm of it.
-static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float* x, int stage_lo, int stage_hi, float* io,
+static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float* x, const KvqFragmentSource* frag, int stage_lo, int stage_hi, float* io,
                     float* feat, void* workspace, size_t workspace_bytes, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(cpl && w && workspace, KVQ_ERR_NULL, "kvq_swin3d_forward: NULL pointer");
@@ -429,7 +429,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   KvqSwinPlan* pl = const_cast<KvqSwinPlan*>(cpl);   // profiling state only
   KVQ_REQUIRE(stage_lo >= 0 && stage_lo <= stage_hi && stage_hi < pl->cfg.num_stages, KVQ_ERR_SHAPE,
               "kvq_swin3d_forward: stages %d..%d of %d", stage_lo, stage_hi, pl->cfg.num_stages);
-  KVQ_REQUIRE(stage_lo == 0 ? x != nullptr : io != nullptr, KVQ_ERR_NULL, "kvq_swin3d_forward: no input for stage %d", stage_lo);
+  KVQ_REQUIRE(stage_lo == 0 ? (x != nullptr || frag != nullptr) : io != nullptr, KVQ_ERR_NULL, "kvq_swin3d_forward: no input for stage %d", stage_lo);
   KVQ_REQUIRE(io || (feat && stage_hi == pl->cfg.num_stages - 1), KVQ_ERR_NULL, "kvq_swin3d_forward: no output buffer");
   KVQ_REQUIRE(workspace_bytes >= pl->ws_bytes, KVQ_ERR_WORKSPACE, "kvq_swin3d_forward: workspace %zu < %zu bytes",
               workspace_bytes, pl->ws_bytes);
@@ -455,7 +455,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     KVQ_CHECK_HIP(hipMemcpyAsync(xa, io, (size_t)B * g0.L * g0.C * sizeof(float), hipMemcpyDeviceToDevice, st));
   } else if (w->embed_pack && kvq_patch_embed_supported(cfg.in_chans, cfg.patch[0], cfg.patch[1], cfg.patch[2], E, pl->T, pl->H, pl->W)) {
     KvqPatchEmbedArgs ea{};
-    ea.x = x; ea.B = B; ea.in_chans = cfg.in_chans; ea.T = pl->T; ea.H = pl->H; ea.W = pl->W;
+    ea.x = x; ea.frag = frag; ea.B = B; ea.in_chans = cfg.in_chans; ea.T = pl->T; ea.H = pl->H; ea.W = pl->W;
     ea.pd = cfg.patch[0]; ea.ph = cfg.patch[1]; ea.pw = cfg.patch[2]; ea.embed_dim = E; ea.pack = w->embed_pack;
     ea.has_norm = w->embed_ln_w ? 1 : 0; ea.out = xa; ea.eps = 1e-5f; ea.dtype = pl->dtype;
     const StageGeom& g0 = pl->st[0];
@@ -465,10 +465,11 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       first_ln1_ready = true;
     }
     const double px = (double)B * L0 * pl->K0;
-    Bracket br(pl, st, KVQ_K_EMBED, first_ln1_ready ? 1 : 0, 2.0 * B * L0 * (double)E * pl->K0,
-               px * 4.0 + (double)B * L0 * E * (4.0 + (first_ln1_ready ? 2.0 : 0.0)));
+    Bracket br(pl, st, KVQ_K_EMBED, (first_ln1_ready ? 1 : 0) + (frag ? 2 : 0), 2.0 * B * L0 * (double)E * pl->K0,
+               px * (frag ? 1.0 : 4.0) + (double)B * L0 * E * (4.0 + (first_ln1_ready ? 2.0 : 0.0)));
     KVQ_TRY(kvq_patch_embed(&ea, st));
   } else {
+    KVQ_REQUIRE(!frag, KVQ_ERR_UNSUPPORTED, "kvq_swin3d_forward_fragments: this plan does not take the fused patch-embedding launch");
     {
       const double px = (double)B * pl->D0 * pl->H0 * pl->W0 * pl->K0;
       Bracket br(pl, st, KVQ_K_IM2COL, 0, 0.0, px * 6.0);
@@ -623,11 +624,20 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
 extern "C" int kvq_swin3d_forward(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, float* feat, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   KVQ_REQUIRE(plan && x && feat, KVQ_ERR_NULL, "kvq_swin3d_forward: NULL pointer");
-  return swin_run(plan, w, x, 0, plan->cfg.num_stages - 1, nullptr, feat, workspace, workspace_bytes, stream);
+  return swin_run(plan, w, x, nullptr, 0, plan->cfg.num_stages - 1, nullptr, feat, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kvq_swin3d_forward_fragments(const KvqSwinPlan* plan, const KvqSwinWeights* w, const KvqFragmentSource* src, float* feat,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  KVQ_REQUIRE(plan && src && feat, KVQ_ERR_NULL, "kvq_swin3d_forward_fragments: NULL pointer");
+  KVQ_REQUIRE(kvq_patch_embed_fragments_supported(src, plan->B, plan->cfg.in_chans, plan->cfg.patch[0], plan->T, plan->H, plan->W),
+              KVQ_ERR_UNSUPPORTED, "kvq_swin3d_forward_fragments: the source does not fit the fused read of a %dx%dx%dx%d batch",
+              plan->B, plan->T, plan->H, plan->W);
+  return swin_run(plan, w, nullptr, src, 0, plan->cfg.num_stages - 1, nullptr, feat, workspace, workspace_bytes, stream);
 }
 
 extern "C" int kvq_swin3d_forward_stages(const KvqSwinPlan* plan, const KvqSwinWeights* w, const float* x, int stage_lo,
                                          int stage_hi, float* io, float* feat, void* workspace, size_t workspace_bytes,
                                          void* stream) {
-  return swin_run(plan, w, x, stage_lo, stage_hi, io, feat, workspace, workspace_bytes, stream);
+  return swin_run(plan, w, x, nullptr, stage_lo, stage_hi, io, feat, workspace, workspace_bytes, stream);
 }

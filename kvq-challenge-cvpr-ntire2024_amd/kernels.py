@@ -241,6 +241,70 @@ def fragment_gather(video: torch.Tensor, hoff: torch.Tensor, woff: torch.Tensor,
     return out
 
 
+class FragmentSource:
+    """A batch of technical-branch clips that is still (decoded uint8 frames, sampler draws): the arguments ``fragment_gather``
+    would get, clip by clip.  ``SwinTransformer3D.forward`` reads its patch-embedding operand straight out of it (K1 fused
+    into the embedding launch: the fp32 clip is neither written nor read back); ``materialise()`` is the two-step form, for
+    consumers that want the tensor.  Bit-identical either way.
+
+    videos: uint8 (C,T,Hs,Ws) device tensors of one shape; hoffs / woffs: int32 (Fh,Fw,T//aligned) device tensors of ABSOLUTE
+    patch origins (as ``fragment_gather``)."""
+
+    def __init__(self, videos, hoffs, woffs, fragments_h, fragments_w, fsize_h, fsize_w, aligned, mean=None, std=None):
+        videos, hoffs, woffs = list(videos), [h.contiguous() for h in hoffs], [w.contiguous() for w in woffs]
+        assert len(videos) == len(hoffs) == len(woffs) and 0 < len(videos)
+        _need_gpu(*videos, *hoffs, *woffs)
+        v0 = videos[0]
+        nt = v0.shape[1] // aligned
+        for v, h, w in zip(videos, hoffs, woffs):
+            assert v.shape == v0.shape and v.dtype == v0.dtype and v.is_contiguous() and v.device == v0.device
+            assert h.dtype == w.dtype == torch.int32 and tuple(h.shape) == tuple(w.shape) == (fragments_h, fragments_w, nt)
+        assert (mean is None) == (std is None)
+        self.videos, self.hoffs, self.woffs = videos, hoffs, woffs
+        self.geometry = (fragments_h, fragments_w, fsize_h, fsize_w, aligned)
+        self.mean, self.std = mean, std
+        self.device, self.is_cuda, self.dtype = v0.device, True, torch.float32
+        Cc, T = v0.shape[:2]
+        self.shape = (len(videos), Cc, T, fragments_h * fsize_h, fragments_w * fsize_w)
+        self._c = None
+
+    @staticmethod
+    def cat(sources):
+        """the batch of several sources (same geometry / normalisation), in order"""
+        s0 = sources[0]
+        assert all(s.geometry == s0.geometry and s.mean == s0.mean and s.std == s0.std for s in sources)
+        return FragmentSource([v for s in sources for v in s.videos], [h for s in sources for h in s.hoffs],
+                              [w for s in sources for w in s.woffs], *s0.geometry, mean=s0.mean, std=s0.std)
+
+    def c_struct(self):
+        """KvqFragmentSource (keep ``self`` alive while a launch that got it is in flight) or None when the batch has more
+        clips than the struct holds / the frames are not uint8."""
+        v0 = self.videos[0]
+        if len(self.videos) > _abi.FRAG_MAX_CLIPS or v0.dtype != torch.uint8:
+            return None
+        if self._c is not None:
+            return self._c
+        f = _abi.KvqFragmentSource()
+        for i, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
+            f.video[i], f.hoff[i], f.woff[i] = ptr(v), ptr(h), ptr(w)
+        f.n_clips, f.src_is_u8, f.Hs, f.Ws = len(self.videos), 1, v0.shape[2], v0.shape[3]
+        f.Fh, f.Fw, f.fs_h, f.fs_w, f.aligned = self.geometry
+        f.normalise = int(self.mean is not None)
+        if self.mean is not None:
+            for c in range(v0.shape[0]):
+                f.mean[c], f.std[c] = self.mean[c], self.std[c]
+        self._c = f
+        return f
+
+    def materialise(self, out=None):
+        """the fp32 (B,C,T,H,W) batch: one ``fragment_gather`` per clip"""
+        if out is None:
+            out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        for b, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
+            fragment_gather(v, h, w, *self.geometry, mean=self.mean, std=self.std, out=out[b])
+        return out
+
+
 # ------------------------------------------------------------------------------------------------
 # convolution front-ends (channels-last 16-bit activations (B,D,H,W,C))
 # ------------------------------------------------------------------------------------------------
@@ -631,12 +695,20 @@ def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: 
     return nxt
 
 
-def patch_embed(x: torch.Tensor, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, next_dst=None, next_rows=0,
+def patch_embed(x, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, next_dst=None, next_rows=0,
                 eps=1e-5):
-    """PatchEmbed3D as one launch: x fp32 (B,Cin,T,H,W), w 16-bit [E][Cin*pd*ph*pw] -> fp32 [B*D0*H0*W0, E]
-    (+ the first block's norm1 rows when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
-    _need_gpu(x, w, bias, ln_w, ln_b, next_dst)
-    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype in HALF_TYPES and w.is_contiguous()
+    """PatchEmbed3D as one launch: x fp32 (B,Cin,T,H,W) or a ``FragmentSource``, w 16-bit [E][Cin*pd*ph*pw] -> fp32
+    [B*D0*H0*W0, E] (+ the first block's norm1 rows when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
+    frag = None
+    if isinstance(x, FragmentSource):
+        frag = x.c_struct()
+        if frag is None:
+            raise _abi.KvqError("kvq_patch_embed: this FragmentSource has no fused read (materialise() it)")
+        _need_gpu(w, bias, ln_w, ln_b, next_dst)
+    else:
+        _need_gpu(x, w, bias, ln_w, ln_b, next_dst)
+        assert x.dtype == torch.float32 and x.is_contiguous()
+    assert w.dtype in HALF_TYPES and w.is_contiguous()
     B, Cin, T, H, W = x.shape
     pd, ph, pw = patch
     Ed, K = w.shape
@@ -648,7 +720,9 @@ def patch_embed(x: torch.Tensor, w: torch.Tensor, bias, ln_w, ln_b, patch, *, ne
     L0 = (T // pd) * (H // ph) * (W // pw)
     out = torch.empty(B * L0, Ed, dtype=torch.float32, device=x.device)
     a = _abi.KvqPatchEmbedArgs()
-    a.x, a.B, a.in_chans, a.T, a.H, a.W, a.pd, a.ph, a.pw, a.embed_dim = ptr(x), B, Cin, T, H, W, pd, ph, pw, Ed
+    a.x, a.B, a.in_chans, a.T, a.H, a.W, a.pd, a.ph, a.pw, a.embed_dim = (None if frag else ptr(x)), B, Cin, T, H, W, pd, ph, pw, Ed
+    if frag is not None:
+        a.frag = C.pointer(frag)
     a.pack, a.has_norm, a.out, a.eps, a.dtype = ptr(pack), int(ln_w is not None), ptr(out), eps, dtype_code(w.dtype)
     nxt = None
     if next_norm is not None:

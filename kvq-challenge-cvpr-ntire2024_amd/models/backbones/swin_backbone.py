@@ -18,7 +18,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from ... import _abi
+from ... import _abi, kernels
 from ..._abi import KvqSwinBlockW, KvqSwinCfg, KvqSwinWeights, check, current_stream, lib, ptr
 
 
@@ -30,6 +30,11 @@ def _rel_pos_index(window) -> torch.Tensor:
     c = torch.stack([n // (Wh * Ww), (n // Ww) % Wh, n % Ww])
     d = c[:, :, None] - c[:, None, :]
     return ((d[0] + Wd - 1) * (2 * Wh - 1) * (2 * Ww - 1) + (d[1] + Wh - 1) * (2 * Ww - 1) + d[2] + Ww - 1)
+
+
+# test hook: False -> a FragmentSource batch is materialised (kvq_fragment_gather per clip) before the forward instead of
+# being read through the sampler by the embedding launch; the two sequencings are bit-identical (tests/test_gpu_e2e.py)
+FUSE_SAMPLER = True
 
 
 class _Affine(nn.Module):
@@ -395,7 +400,18 @@ class SwinTransformer3D(nn.Module):
         x = batch["technical"]
         if not x.is_cuda:
             raise _abi.KvqError("SwinTransformer3D.forward needs the clip on a HIP device; there is no CPU path")
-        x = x.to(torch.float32).contiguous()
+        frag = None
+        if isinstance(x, kernels.FragmentSource):
+            # the batch is still (frames, sampler draws): the embedding launch reads through the sampler when it can
+            B, _, T, H, W = x.shape
+            frag = x.c_struct() if self.fused_tail and FUSE_SAMPLER else None
+            if frag is not None and not lib().kvq_patch_embed_fragments_supported(
+                    C.byref(frag), B, self.in_chans, self.patch_size[0], T, H, W):
+                frag = None
+            if frag is None:
+                x = x.materialise()
+        else:
+            x = x.to(torch.float32).contiguous()
         B, _, T, H, W = x.shape
         handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device)
         w = self._weights(x.device)
@@ -416,8 +432,12 @@ class SwinTransformer3D(nn.Module):
                 arr[i] = ptr(taps[i])
             check(lib().kvq_swin3d_set_taps(handle, arr), "kvq_swin3d_set_taps")
         try:
-            check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), _abi.stream_of(x)),
-                  "kvq_swin3d_forward")
+            if frag is not None:
+                check(lib().kvq_swin3d_forward_fragments(handle, C.byref(w), C.byref(frag), ptr(feat), ptr(ws), ws.numel(),
+                                                         current_stream()), "kvq_swin3d_forward_fragments")
+            else:
+                check(lib().kvq_swin3d_forward(handle, C.byref(w), ptr(x), ptr(feat), ptr(ws), ws.numel(), _abi.stream_of(x)),
+                      "kvq_swin3d_forward")
         finally:
             if taps is not None:
                 check(lib().kvq_swin3d_set_taps(handle, None), "kvq_swin3d_set_taps")
@@ -501,7 +521,8 @@ class SwinTransformer3D(nn.Module):
             elif kind == "layernorm":
                 sym = "layernorm_rows_kernel"
             elif kind == "embed":
-                sym = f"patch_embed_kernel<{ename}, {self.embed_dim // 32}, 6, {str(bool(r.variant)).lower()}>"
+                sym = (f"patch_embed_kernel<{ename}, {self.embed_dim // 32}, 6, {str(bool(r.variant & 1)).lower()}, "
+                       f"{str(bool(r.variant & 2)).lower()}>")          # ..., + norm1 of block 0, reads through the sampler
             elif kind == "tail":
                 cm = r.variant // 10
                 emit = str(bool(r.variant % 10)).lower()

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in kvq_hip.h but not exported"
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
-    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 26
+    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 27
 
 
 def test_struct_layouts_match_header_sizes():
@@ -32,7 +32,9 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_abi.KvqSwinBlockW) == 17 * 8
     assert C.sizeof(_abi.KvqBlockTailArgs) == 112
     assert C.sizeof(_abi.KvqSwinWeights) == 5 * 8 + 8 + 3 * 3 * 8 + 2 * 8
-    assert C.sizeof(_abi.KvqPatchEmbedArgs) == 120
+    assert C.sizeof(_abi.KvqPatchEmbedArgs) == 128
+    assert C.sizeof(_abi.KvqFragmentSource) == 3 * 16 * 8 + 10 * 4 + 2 * 16
+    assert C.sizeof(_abi.KvqAttnDenseArgs) == 104
     assert C.sizeof(_abi.KvqGemmArgs) == 144
     assert C.sizeof(_abi.KvqConvArgs) == 160
     assert _abi.dtype_code('bf16') == 0 and _abi.dtype_code(torch.float16) == 1

@@ -182,6 +182,45 @@ def test_batch_invariance_and_determinism():
     assert torch.equal(s3[1:2], s1)
 
 
+def test_forward_on_a_fragment_source_equals_sampler_then_forward():
+    """``inputs['technical']`` as a FragmentSource (frames + sampler draws; K1 fused into the embedding launch) gives the
+    scores of kvq_fragment_gather per clip followed by the forward on the fp32 clip — bit for bit, both operand types, and also
+    when the batch has to be materialised (hook off) or cannot be read through (fp32 frames)."""
+    from kvq_amd import kernels
+    from kvq_amd.models.backbones import swin_backbone
+    g = torch.Generator().manual_seed(77)
+    Hs, Ws, n = 300, 420, 3
+    vids = [torch.randint(0, 256, (3, 32, Hs, Ws), dtype=torch.uint8, generator=g).to(DEV) for _ in range(n)]
+    gh = torch.tensor([min(Hs // 7 * i, Hs - 32) for i in range(7)]).view(7, 1, 1)
+    gw = torch.tensor([min(Ws // 7 * i, Ws - 32) for i in range(7)]).view(1, 7, 1)
+    hs = [(torch.randint(Hs // 7 - 32, (7, 7, 4), generator=g) + gh).int().to(DEV) for _ in range(n)]
+    ws = [(torch.randint(Ws // 7 - 32, (7, 7, 4), generator=g) + gw).int().to(DEV) for _ in range(n)]
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    src = kernels.FragmentSource(vids, hs, ws, 7, 7, 32, 32, 8, mean=mean, std=std)
+    for dtype in ("fp16", "bf16"):
+        net, key = build_network("SWIN_T_GRPB", 0, "stress", dtype)
+        bb = getattr(net, key + "_backbone")
+        with torch.no_grad():
+            two_step = net(inputs={"technical": src.materialise()}, reduce_scores=True)
+            bb.profile(n, 32, 224, 224, torch.device(DEV), True)
+            fused = net(inputs={"technical": src}, reduce_scores=True)
+            recs = bb.profile_read(n, 32, 224, 224, torch.device(DEV))
+            bb.profile(n, 32, 224, 224, torch.device(DEV), False)
+            swin_backbone.FUSE_SAMPLER = False
+            try:
+                hook_off = net(inputs={"technical": src}, reduce_scores=True)
+            finally:
+                swin_backbone.FUSE_SAMPLER = True
+            f32 = kernels.FragmentSource([v.float() for v in vids], hs, ws, 7, 7, 32, 32, 8, mean=mean, std=std)
+            from_f32 = net(inputs={"technical": f32}, reduce_scores=True)
+        assert torch.equal(two_step, fused) and torch.equal(two_step, hook_off) and torch.equal(two_step, from_f32)
+        emb = [r["kernel"] for r in recs if r["kind"] == "embed"]
+        assert len(emb) == 1 and emb[0].endswith("true, true>")        # one embedding launch, reading through the sampler
+    parts = kernels.FragmentSource.cat([kernels.FragmentSource(vids[i:i + 1], hs[i:i + 1], ws[i:i + 1], 7, 7, 32, 32, 8,
+                                                               mean=mean, std=std) for i in range(n)])
+    assert torch.equal(parts.materialise(), src.materialise())
+
+
 def test_forward_structure_matches_reference_api():
     """VQA_Network.forward return structure (models/model.py:105-121)."""
     net, key = build_network("SWIN_T_GRPB", 0, "init")

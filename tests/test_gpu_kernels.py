@@ -765,6 +765,73 @@ def test_patch_embed_fused(shape, E, with_ln, emit, half):
         assert (nxt.float().cpu() - ref_ln).abs().max().item() <= 2 * EPS[half] * ref_ln.abs().max().item() + 1e-5
 
 
+def _fragment_source(seed, n_clips, T=16, Hs=270, Ws=480, grid=7, fs=32, aligned=8, normalise=True):
+    """random uint8 clips + the sampler's draws (grid origin + offset inside the cell, fusion_datasets.py:64-98)"""
+    g = torch.Generator().manual_seed(seed)
+    vids = [torch.randint(0, 256, (3, T, Hs, Ws), dtype=torch.uint8, generator=g).to(DEV) for _ in range(n_clips)]
+    gh = torch.tensor([min(Hs // grid * i, Hs - fs) for i in range(grid)]).view(grid, 1, 1)
+    gw = torch.tensor([min(Ws // grid * i, Ws - fs) for i in range(grid)]).view(1, grid, 1)
+    hs = [(torch.randint(Hs // grid - fs, (grid, grid, T // aligned), generator=g) + gh).int().to(DEV) for _ in range(n_clips)]
+    ws = [(torch.randint(Ws // grid - fs, (grid, grid, T // aligned), generator=g) + gw).int().to(DEV) for _ in range(n_clips)]
+    mean, std = ((123.675, 116.28, 103.53), (58.395, 57.12, 57.375)) if normalise else (None, None)
+    return kernels.FragmentSource(vids, hs, ws, grid, grid, fs, fs, aligned, mean=mean, std=std)
+
+
+@pytest.mark.parametrize("normalise", [True, False])
+@pytest.mark.parametrize("emit", [False, True])
+def test_patch_embed_reads_through_the_sampler(normalise, emit, half):
+    """The embedding launch fed by a FragmentSource (uint8 frames + the sampler's patch origins: K1 fused into its operand
+    read) against the same launch on the materialised fp32 clip (kvq_fragment_gather, pinned to get_spatial_fragments by
+    test_fragment_gather_*): the 16-bit operands are the same numbers, so every output bit is."""
+    src = _fragment_source(11 + emit, 3, normalise=normalise)
+    assert src.shape == (3, 3, 16, 224, 224)
+    g = rng(5)
+    E = 96
+    w = dev(torch.from_numpy((g.standard_normal((E, 96)) * 0.1).astype(np.float32)), half)
+    b = dev(torch.from_numpy((g.standard_normal(E) * 0.2).astype(np.float32)))
+    lw = dev(torch.from_numpy((1 + 0.2 * g.standard_normal(E)).astype(np.float32)))
+    lb = dev(torch.from_numpy((0.2 * g.standard_normal(E)).astype(np.float32)))
+    kw = {}
+    if emit:
+        lay = O.window_layout(8, 56, 56, (8, 7, 7), (0, 0, 0))
+        L = 8 * 56 * 56
+        dst = np.empty(L, np.int32)
+        dst[lay["src"]] = np.arange(L, dtype=np.int32)
+        kw = dict(next_norm=(lw, lb), next_dst=dev(torch.from_numpy(dst)), next_rows=L)
+    clip = src.materialise()
+    if not normalise:                                   # raw pixel values: exactly the bytes
+        v, h, wo = src.videos[1], src.hoffs[1].cpu(), src.woffs[1].cpu()
+        assert torch.equal(clip[1, :, 9, 32:64, 64:96].cpu(),
+                           v[:, 9, h[1, 2, 1]:h[1, 2, 1] + 32, wo[1, 2, 1]:wo[1, 2, 1] + 32].float().cpu())
+    out_a, nxt_a = kernels.patch_embed(clip, w, b, lw, lb, (2, 4, 4), **kw)
+    out_b, nxt_b = kernels.patch_embed(src, w, b, lw, lb, (2, 4, 4), **kw)
+    assert torch.equal(out_a, out_b)
+    if emit:
+        assert torch.equal(nxt_a, nxt_b)
+
+
+def test_patch_embed_fragment_source_guards():
+    """no fused read: mini-patches that do not hold whole 4 x 4 patches, fp32 frames, a source smaller than the canvas"""
+    src = _fragment_source(3, 1, T=8, Hs=100, Ws=120, grid=2, fs=32, aligned=8)
+    f = src.c_struct()
+    lib = _abi.lib()
+    assert lib.kvq_patch_embed_fragments_supported(f, 1, 3, 2, 8, 64, 64) == 1
+    assert lib.kvq_patch_embed_fragments_supported(f, 2, 3, 2, 8, 64, 64) == 0          # batch != clips
+    assert lib.kvq_patch_embed_fragments_supported(f, 1, 3, 2, 8, 64, 96) == 0          # canvas != grid * fs
+    f.fs_h, f.Fh = 16, 4
+    assert lib.kvq_patch_embed_fragments_supported(f, 1, 3, 2, 8, 64, 64) == 1
+    f.fs_h, f.Fh = 2, 32
+    assert lib.kvq_patch_embed_fragments_supported(f, 1, 3, 2, 8, 64, 64) == 0          # patch rows span mini-patches
+    f = src.c_struct()
+    f.Hs = 48
+    assert lib.kvq_patch_embed_fragments_supported(f, 1, 3, 2, 8, 64, 64) == 0          # source < canvas
+    f32 = kernels.FragmentSource([v.float() for v in src.videos], src.hoffs, src.woffs, *src.geometry)
+    assert f32.c_struct() is None and f32.materialise().shape == (1, 3, 8, 64, 64)
+    with pytest.raises(_abi.KvqError, match="no fused read"):
+        kernels.patch_embed(f32, torch.zeros(96, 96, dtype=torch.float16, device=DEV), torch.zeros(96, device=DEV), None, None,
+                            (2, 4, 4))
+
+
 def test_patch_embed_fused_rejects_padded_clip():
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.patch_embed(torch.zeros(1, 3, 7, 30, 27, device=DEV), torch.zeros(96, 96, dtype=torch.float16, device=DEV),
