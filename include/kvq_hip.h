@@ -134,9 +134,11 @@ int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
  * (fusion_datasets.py:22-121) + (v - mean) / std (:1017-1020) happen in registers, with the same fp32 arithmetic, and the fp32
  * (B,3,T,H,W) clip (4 B/pixel written, 4 B/pixel read back) never exists. */
 typedef struct {
-  const void* video[KVQ_FRAG_MAX_CLIPS];     /* clip b: uint8 (C, T, Hs, Ws), device                                */
+  const void* video[KVQ_FRAG_MAX_CLIPS];     /* clip b: uint8 (C, T, Hs, Ws), device; frames contiguous, channel planes
+                                                chan_stride bytes apart (a clip may be a run of frames of a longer video) */
   const int32_t* hoff[KVQ_FRAG_MAX_CLIPS];   /* clip b: int32 [Fh][Fw][T/aligned] absolute patch origins, device    */
   const int32_t* woff[KVQ_FRAG_MAX_CLIPS];
+  int64_t chan_stride;                       /* 0 = T * Hs * Ws (contiguous clips)                                   */
   int32_t n_clips, src_is_u8, Hs, Ws, Fh, Fw, fs_h, fs_w, aligned;
   int32_t normalise;                         /* 0: raw pixel values                                                  */
   float mean[4], std[4];

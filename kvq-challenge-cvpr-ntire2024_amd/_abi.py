@@ -114,7 +114,7 @@ FRAG_MAX_CLIPS = 16
 
 class KvqFragmentSource(C.Structure):
     _fields_ = [("video", p_void * FRAG_MAX_CLIPS), ("hoff", p_void * FRAG_MAX_CLIPS), ("woff", p_void * FRAG_MAX_CLIPS),
-                ("n_clips", C.c_int32), ("src_is_u8", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Fh", C.c_int32),
+                ("chan_stride", C.c_int64), ("n_clips", C.c_int32), ("src_is_u8", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Fh", C.c_int32),
                 ("Fw", C.c_int32), ("fs_h", C.c_int32), ("fs_w", C.c_int32), ("aligned", C.c_int32), ("normalise", C.c_int32),
                 ("mean", C.c_float * 4), ("std", C.c_float * 4)]
 

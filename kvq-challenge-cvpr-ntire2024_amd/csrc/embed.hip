@@ -21,6 +21,7 @@ struct FragSrc {
   const uint8_t* video[KVQ_FRAG_MAX_CLIPS];   // clip b: (Cin, T, Hs, Ws)
   const int32_t* hoff[KVQ_FRAG_MAX_CLIPS];    // clip b: [Fh][Fw][T / aligned] patch origins
   const int32_t* woff[KVQ_FRAG_MAX_CLIPS];
+  long chan_stride;
   int Hs, Ws, Fw, fsh, fsw, aligned;
   float mean[4], std[4];
 };
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c = s / p.pd, t = d * p.pd + (s - c * p.pd), g = t / f.aligned;
-      const uint8_t* src = vb + ((size_t)c * p.T + t) * plane + (size_t)(ho[g] + (oy - fi * f.fsh)) * f.Ws + (wo[g] + (ox - fj * f.fsw));
+      const uint8_t* src = vb + (size_t)c * f.chan_stride + (size_t)t * plane + (size_t)(ho[g] + (oy - fi * f.fsh)) * f.Ws + (wo[g] + (ox - fj * f.fsw));
       raw[s][0] = *reinterpret_cast<const u32u*>(src);
       raw[s][1] = *reinterpret_cast<const u32u*>(src + f.Ws);
     }
@@ -266,6 +267,7 @@ extern "C" int kvq_patch_embed_fragments_supported(const KvqFragmentSource* f, i
   if (!f || !f->src_is_u8 || f->n_clips != B || B > KVQ_FRAG_MAX_CLIPS || in_chans > 4 || pd <= 0) return 0;
   if (f->fs_h <= 0 || f->fs_w <= 0 || f->fs_h % 4 || f->fs_w % 4 || f->Fh * f->fs_h != H || f->Fw * f->fs_w != W) return 0;
   if (f->aligned <= 0 || T % f->aligned || T % pd) return 0;
+  if (f->chan_stride < 0 || (f->chan_stride && f->chan_stride < (long)T * f->Hs * f->Ws)) return 0;
   if (f->Hs < H || f->Ws < W) return 0;                      // the upsample fallback is not in the hot path (as kvq_fragment_gather)
   return ((long)(T / pd) * (H / 4) * (W / 4)) % 32 == 0 ? 1 : 0;
 }
@@ -291,6 +293,7 @@ extern "C" int kvq_patch_embed(const KvqPatchEmbedArgs* a, void* stream) {
       KVQ_REQUIRE(f->video[b] && f->hoff[b] && f->woff[b], KVQ_ERR_NULL, "kvq_patch_embed: fragment source clip %d has a NULL pointer", b);
       p.frag.video[b] = (const uint8_t*)f->video[b]; p.frag.hoff[b] = f->hoff[b]; p.frag.woff[b] = f->woff[b];
     }
+    p.frag.chan_stride = f->chan_stride ? f->chan_stride : (long)a->T * f->Hs * f->Ws;
     p.frag.Hs = f->Hs; p.frag.Ws = f->Ws; p.frag.Fw = f->Fw; p.frag.fsh = f->fs_h; p.frag.fsw = f->fs_w; p.frag.aligned = f->aligned;
     for (int c = 0; c < 4; ++c) { p.frag.mean[c] = f->normalise ? f->mean[c] : 0.f; p.frag.std[c] = f->normalise ? f->std[c] : 1.f; }   // (v - 0) / 1 == v
   }

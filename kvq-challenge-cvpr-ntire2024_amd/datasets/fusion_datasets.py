@@ -38,8 +38,9 @@ def _grid(res: int, fragments: int, fsize: int):
 
 def get_spatial_fragments(video, fragments_h=7, fragments_w=7, fsize_h=32, fsize_w=32, aligned=32, nfrags=1,
                           random=False, random_upsample=False, fallback_type="upsample", rnd_h=None, rnd_w=None,
-                          mean=None, std=None, **kwargs):
-    """video (C,T,H,W) uint8|fp32 on a HIP device -> fp32 (C,T,Fh*fs,Fw*fs).
+                          mean=None, std=None, lazy=False, **kwargs):
+    """video (C,T,H,W) uint8|fp32 on a HIP device -> fp32 (C,T,Fh*fs,Fw*fs); ``lazy=True`` -> the draws and the frames as a
+    one-entry ``kernels.FragmentSource`` (the trunk's embedding launch samples while it reads; ``.materialise()[0]`` is the tensor).
 
     ``rnd_h``/``rnd_w`` (Fh,Fw,T//aligned): offsets inside each grid cell; drawn with the reference's
     ``torch.randint`` calls when omitted.  ``mean``/``std`` fuse the dataset's normalisation (:1017-1020)."""
@@ -63,6 +64,9 @@ def get_spatial_fragments(video, fragments_h=7, fragments_w=7, fsize_h=32, fsize
     rnd_w = torch.as_tensor(np.asarray(rnd_w)) if not torch.is_tensor(rnd_w) else rnd_w
     hoff = (rnd_h.cpu().long() + torch.tensor(_grid(H, fragments_h, fsize_h)).view(-1, 1, 1)).int()
     woff = (rnd_w.cpu().long() + torch.tensor(_grid(W, fragments_w, fsize_w)).view(1, -1, 1)).int()
+    if lazy:
+        return kernels.FragmentSource([video.contiguous()], [hoff.to(video.device)], [woff.to(video.device)], fragments_h,
+                                      fragments_w, fsize_h, fsize_w, aligned, mean=mean, std=std)
     return kernels.fragment_gather(video.contiguous(), hoff.to(video.device), woff.to(video.device), fragments_h,
                                    fragments_w, fsize_h, fsize_w, aligned, mean=mean, std=std)
 
@@ -219,7 +223,7 @@ class SyntheticKVQDataset(torch.utils.data.Dataset):
         inds = self.sampler(self.frames)
         clip = frames[:, torch.from_numpy(inds.astype(np.int64))].to(self.device)
         tech = get_spatial_fragments(clip, s["fragments_h"], s["fragments_w"], s["fsize_h"], s["fsize_w"],
-                                     aligned=s.get("aligned", 8), mean=KVQ_MEAN, std=KVQ_STD)
+                                     aligned=s.get("aligned", 8), mean=KVQ_MEAN, std=KVQ_STD, lazy=bool(s.get("lazy", False)))
         return {"technical": tech, "num_clips": {"technical": s.get("num_clips", 1)}, "frame_inds": inds,
                 "label": float(self.labels[i]), "name": f"synthetic_{i:05d}", "video_name": f"synthetic_{i:05d}.mp4"}
 

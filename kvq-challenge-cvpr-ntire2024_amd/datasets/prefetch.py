@@ -63,7 +63,7 @@ class DevicePrefetcher:
     @staticmethod
     def hand_over(item, stream):
         for v in item.values():
-            if torch.is_tensor(v) and v.is_cuda:
+            if (torch.is_tensor(v) and v.is_cuda) or hasattr(v, "split_clips"):      # tensors and kernels.FragmentSource
                 v.record_stream(stream)
 
     def close(self):

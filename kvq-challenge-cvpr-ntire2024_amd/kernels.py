@@ -247,24 +247,26 @@ class FragmentSource:
     into the embedding launch: the fp32 clip is neither written nor read back); ``materialise()`` is the two-step form, for
     consumers that want the tensor.  Bit-identical either way.
 
-    videos: uint8 (C,T,Hs,Ws) device tensors of one shape; hoffs / woffs: int32 (Fh,Fw,T//aligned) device tensors of ABSOLUTE
-    patch origins (as ``fragment_gather``)."""
+    videos: uint8 (C,T,Hs,Ws) device tensors of one shape — contiguous, or runs of frames of a longer video (frames
+    contiguous, one common channel stride: what ``split_clips`` makes); hoffs / woffs: int32 (Fh,Fw,T//aligned) device tensors
+    of ABSOLUTE patch origins (as ``fragment_gather``)."""
 
     def __init__(self, videos, hoffs, woffs, fragments_h, fragments_w, fsize_h, fsize_w, aligned, mean=None, std=None):
         videos, hoffs, woffs = list(videos), [h.contiguous() for h in hoffs], [w.contiguous() for w in woffs]
         assert len(videos) == len(hoffs) == len(woffs) and 0 < len(videos)
         _need_gpu(*videos, *hoffs, *woffs)
         v0 = videos[0]
-        nt = v0.shape[1] // aligned
+        Cc, T, Hs, Ws = v0.shape
+        nt = T // aligned
         for v, h, w in zip(videos, hoffs, woffs):
-            assert v.shape == v0.shape and v.dtype == v0.dtype and v.is_contiguous() and v.device == v0.device
+            assert v.shape == v0.shape and v.dtype == v0.dtype and v.device == v0.device
+            assert v.stride()[1:] == (Hs * Ws, Ws, 1) and v.stride(0) == v0.stride(0) >= T * Hs * Ws, "frames must be contiguous"
             assert h.dtype == w.dtype == torch.int32 and tuple(h.shape) == tuple(w.shape) == (fragments_h, fragments_w, nt)
         assert (mean is None) == (std is None)
         self.videos, self.hoffs, self.woffs = videos, hoffs, woffs
         self.geometry = (fragments_h, fragments_w, fsize_h, fsize_w, aligned)
         self.mean, self.std = mean, std
         self.device, self.is_cuda, self.dtype = v0.device, True, torch.float32
-        Cc, T = v0.shape[:2]
         self.shape = (len(videos), Cc, T, fragments_h * fsize_h, fragments_w * fsize_w)
         self._c = None
 
@@ -276,9 +278,29 @@ class FragmentSource:
         return FragmentSource([v for s in sources for v in s.videos], [h for s in sources for h in s.hoffs],
                               [w for s in sources for w in s.woffs], *s0.geometry, mean=s0.mean, std=s0.std)
 
+    def split_clips(self, num_clips):
+        """every T-frame entry as ``num_clips`` clips of T/num_clips consecutive frames — the harness's clip reshape
+        (trainer.py:306-319: (b,c,nc*t,h,w) -> (b*nc,c,t,h,w)) without moving a byte: the clips are views of the frames."""
+        if num_clips == 1:
+            return self
+        _, _, T, _, _ = self.shape
+        aligned = self.geometry[4]
+        assert T % num_clips == 0 and (T // num_clips) % aligned == 0, "a clip must hold whole aligned frame groups"
+        t, nt = T // num_clips, T // num_clips // aligned
+        vs, hs, ws = [], [], []
+        for v, h, w in zip(self.videos, self.hoffs, self.woffs):
+            for k in range(num_clips):
+                vs.append(v[:, k * t:(k + 1) * t])
+                hs.append(h[:, :, k * nt:(k + 1) * nt])
+                ws.append(w[:, :, k * nt:(k + 1) * nt])
+        return FragmentSource(vs, hs, ws, *self.geometry, mean=self.mean, std=self.std)
+
+    def record_stream(self, stream):
+        for t in self.videos + self.hoffs + self.woffs:
+            t.record_stream(stream)
+
     def c_struct(self):
-        """KvqFragmentSource (keep ``self`` alive while a launch that got it is in flight) or None when the batch has more
-        clips than the struct holds / the frames are not uint8."""
+        """KvqFragmentSource, or None when the batch has more clips than the struct holds / the frames are not uint8."""
         v0 = self.videos[0]
         if len(self.videos) > _abi.FRAG_MAX_CLIPS or v0.dtype != torch.uint8:
             return None
@@ -287,6 +309,7 @@ class FragmentSource:
         f = _abi.KvqFragmentSource()
         for i, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
             f.video[i], f.hoff[i], f.woff[i] = ptr(v), ptr(h), ptr(w)
+        f.chan_stride = v0.stride(0)
         f.n_clips, f.src_is_u8, f.Hs, f.Ws = len(self.videos), 1, v0.shape[2], v0.shape[3]
         f.Fh, f.Fw, f.fs_h, f.fs_w, f.aligned = self.geometry
         f.normalise = int(self.mean is not None)
@@ -301,7 +324,7 @@ class FragmentSource:
         if out is None:
             out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         for b, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
-            fragment_gather(v, h, w, *self.geometry, mean=self.mean, std=self.std, out=out[b])
+            fragment_gather(v.contiguous(), h, w, *self.geometry, mean=self.mean, std=self.std, out=out[b])
         return out
 
 

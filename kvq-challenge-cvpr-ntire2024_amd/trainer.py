@@ -18,6 +18,7 @@ import torch
 
 from . import datasets as _datasets
 from . import dist as kd
+from . import kernels
 from .models.model import VQA_Network
 
 
@@ -71,6 +72,12 @@ class Trainer:
         for key in ([] if ksvqe else list(data)):
             if key in self.key_list or key == "technical":
                 x = data[key]
+                if isinstance(x, kernels.FragmentSource):
+                    # a lazily sampled view (``lazy: true`` in its sample_types entry): the clips stay views of the uint8 frames
+                    # and the trunk's embedding launch samples while it reads — no fp32 sample, no reshape copy
+                    nc = int(data.get("num_clips", {}).get(key, 1)) if isinstance(data.get("num_clips"), dict) else 1
+                    inputs[key] = x.split_clips(nc)
+                    continue
                 if not torch.is_tensor(x) or x.dim() not in (4, 5):
                     continue
                 x = x.to(self.device)
@@ -84,7 +91,7 @@ class Trainer:
             # the DataLoader of the reference adds the batch dimension (batch_size 1) and the whole T-frame sample goes to
             # KSVQE as ONE clip (trainer.py:306-326): resize_video / fragment (1, 3, T, h, w), dis_label (1,)
             for k in ("resize_video", "fragment"):
-                v = data[k].to(self.device)
+                v = data[k].materialise() if isinstance(data[k], kernels.FragmentSource) else data[k].to(self.device)
                 inputs[k] = v.unsqueeze(0) if v.dim() == 4 else v
             inputs["dis_label"] = torch.as_tensor(data["dis_label"]).reshape(-1).to(self.device)
         elif "feat" in data and torch.is_tensor(data["feat"]):

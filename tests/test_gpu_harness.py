@@ -62,15 +62,17 @@ def test_cli_drop_in_scores_match_oracle(tmp_path):
     np.random.seed(123)
     ds = SyntheticKVQDataset(a, None, device="cuda:0")
     item = ds[1]
-    tech = item["technical"].cpu()
+    assert hasattr(item["technical"], "split_clips")         # the config samples lazily: (uint8 frames, draws), no fp32 sample yet
+    tech = item["technical"].materialise()[0].cpu()
     frames = synth.synth_video_u8(1234 + 1, 64, 300, 400)[:, item["frame_inds"].astype(np.int64)]
     assert tech.shape == (3, 64, 224, 224)
     x = torch.from_numpy(SO.split_clips(tech.numpy()[None], 2))
     net = net.cuda().eval()
     with torch.no_grad():
         s_gpu = net(inputs={"technical": x.cuda()}, reduce_scores=True).cpu()
+        s_lazy = net(inputs={"technical": item["technical"].split_clips(2)}, reduce_scores=True).cpu()     # what the CLI's harness feeds
         s_ref = O.vqa_head(O.swin3d_trunk(x, wts, synth.SWIN_T_GRPB), hw)
-    assert (s_gpu - s_ref).abs().max().item() <= 1e-3
+    assert (s_gpu - s_ref).abs().max().item() <= 1e-3 and torch.equal(s_gpu, s_lazy)
     assert np.isfinite(got).all()
     # fragments really are patches of the seeded frames, normalised
     raw = tech.numpy() * np.asarray(KVQ_STD, np.float32).reshape(3, 1, 1, 1) + np.asarray(KVQ_MEAN, np.float32).reshape(3, 1, 1, 1)
@@ -380,7 +382,7 @@ def test_c4_rehearsal_900_videos_one_and_two_ranks(tmp_path):
     ds = SyntheticKVQDataset(a, device="cuda:0")
     torch.set_num_threads(min(32, torch.get_num_threads()))
     for i in list(range(0, 900, 29))[:32]:
-        x = ds[i]["technical"].cpu()
+        x = ds[i]["technical"].materialise()[0].cpu()         # the CLI above ran on the lazy form of the same items
         c, t, h, w = x.shape
         clips = x.reshape(c, 2, t // 2, h, w).permute(1, 0, 2, 3, 4).contiguous()
         with torch.no_grad():
