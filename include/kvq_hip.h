@@ -422,10 +422,13 @@ int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd
 
 /* VQAHead.forward in eval mode (models/head.py:60-68): fp32 throughout.
  *   feat  fp32 with explicit element strides (so both (B,C,D,H,W) and channels-last work)
- *   w1t   fc_hid.weight TRANSPOSED: fp32 [C][hidden] (lane j of a wave owns hidden unit j)
+ *   w1t   fc_hid.weight TRANSPOSED: fp32 [C][hidden] (lane j of a wave owns hidden unit j) — the VALU kernel's layout
+ *   w1    fc_hid.weight as it is: fp32 [hidden][C], or NULL.  With hidden == 64, channels-last features (stride_c == 1),
+ *         C % 64 == 0 and 16-byte aligned rows the head runs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: fp32 products
+ *         and sums, a different summation order) and reads w1; w1t may then be NULL.
  *   score fp32 [B] = mean_tokens( w2 . gelu(W1 f + b1) + b2 ).  scratch: fp32 [B*L]. */
 int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l,
-                 int64_t stride_c, const float* w1t, const float* b1, int hidden, const float* w2,
+                 int64_t stride_c, const float* w1t, const float* w1, const float* b1, int hidden, const float* w2,
                  const float* b2, float* scratch, float* score, void* stream);
 
 /* simpleVQAHead.forward (models/head.py:28-31): Linear(Cin->hidden) -> Linear(hidden->1), mean over

@@ -200,7 +200,7 @@ SYMBOLS = {
     "kvq_swin3d_bias_dense_bytes": (sz, [p_void, i32]),
     "kvq_swin3d_bias_dense_build": (i32, [p_void, i32, p_void, p_void, p_void, p_void, p_void]),
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
-    "kvq_vqa_head": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, i32, p_void, p_void, p_void,
+    "kvq_vqa_head": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, p_void, i32, p_void, p_void, p_void,
                            p_void, p_void]),
     "kvq_simple_vqa_head": (i32, [p_void, i32, i32, i32, p_void, p_void, i32, p_void, p_void, p_void, p_void,
                                   p_void]),

@@ -155,6 +155,71 @@ __global__ __launch_bounds__(256) void vqa_head_token_kernel(const float* __rest
   }
 }
 
+// The same head on the fp32 matrix pipe, for hidden == 64 and channels-last features: Out^T[64 hidden][16 tokens] =
+// W1[64][C] * X^T[C][16 tokens] by v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate: no rounding the VALU form does not
+// have).  A lane's 16-byte load is four consecutive channels of its W1 row / of its token, and k-step s of a 16-channel
+// macro-step takes element s of every lane's quad (k index = the lane's quad number) — W1 is read in its PyTorch layout, no
+// packing.  The four waves split the channels; the partial tiles meet in LDS in a fixed order.  196 workgroups of 16 tokens
+// for 4 clips: 12.8 us against 22.2 for the VALU form (784 workgroups that each stream all of W1^T in 12 dependent steps).
+// Eight waves with 64 channels of operands requested ahead measured 13.9: the launch is a fixed ~5 us (a 4-workgroup
+// mean_rows_kernel takes 4.6) + one workgroup's 192 MFMAs per SIMD + its first load.
+__global__ __launch_bounds__(256) void vqa_head_mfma_kernel(const float* __restrict__ feat, int B, int L, int C, long sb, long sl,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, float* __restrict__ tok_score) {
+  __shared__ float part[4][64][17];
+  __shared__ float red[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tok = lane & 15, kq = lane >> 4;
+  const long total = (long)B * L;
+  const long tk = min((long)blockIdx.x * 16 + tok, total - 1);
+  const long b = tk / L, l = tk - b * L;
+  const int cw = C / 4, c0 = wave * cw;
+  const float* xr = feat + b * sb + l * sl + c0 + 4 * kq;
+  const float* wr = w1 + (size_t)tok * C + c0 + 4 * kq;          // + 16 hb rows
+  const size_t hbs = (size_t)16 * C;
+  f32x4 acc[4];
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 xv = *reinterpret_cast<const f32x4*>(xr), wv[4];
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) wv[hb] = *reinterpret_cast<const f32x4*>(wr + hb * hbs);
+  for (int c = 0; c < cw; c += 16) {
+    f32x4 xn = xv, wn[4] = {wv[0], wv[1], wv[2], wv[3]};
+    if (c + 16 < cw) {                                             // the next macro-step's operands, under this one's MFMAs
+      xn = *reinterpret_cast<const f32x4*>(xr + c + 16);
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) wn[hb] = *reinterpret_cast<const f32x4*>(wr + hb * hbs + c + 16);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) acc[hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[hb][s], xv[s], acc[hb], 0, 0, 0);
+    xv = xn;
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) wv[hb] = wn[hb];
+  }
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][16 * hb + 4 * kq + r][tok] = acc[hb][r];
+  __syncthreads();
+  // thread = (token tid & 15, hidden quad tid >> 4): channel partials in wave order, bias, GELU, times w2
+  const int t2 = tid & 15, hg = tid >> 4;
+  float v = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int h = 4 * hg + r;
+    const float full = (part[0][h][t2] + part[1][h][t2]) + (part[2][h][t2] + part[3][h][t2]);
+    v = fmaf(w2[h], gelu_erf(full + b1[h]), v);
+  }
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  if (lane < 16) red[wave][lane] = v;
+  __syncthreads();
+  if (tid < 16 && (long)blockIdx.x * 16 + tid < total)
+    tok_score[(long)blockIdx.x * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 // score[b] = mean_l tok_score[b*L + l] + b2   (deterministic tree, one block per batch element)
 __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ v, int L, const float* b2,
                                                         float* __restrict__ out) {
@@ -344,15 +409,24 @@ extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, in
 }
 
 extern "C" int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l,
-                            int64_t stride_c, const float* w1t, const float* b1, int hidden, const float* w2,
+                            int64_t stride_c, const float* w1t, const float* w1, const float* b1, int hidden, const float* w2,
                             const float* b2, float* scratch, float* score, void* stream) {
   using namespace kvq;
-  KVQ_REQUIRE(feat && w1t && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head: NULL pointer");
+  KVQ_REQUIRE(feat && (w1t || w1) && b1 && w2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head: NULL pointer");
   KVQ_REQUIRE(B > 0 && L > 0 && C > 0 && hidden > 0, KVQ_ERR_SHAPE, "kvq_vqa_head: bad shape");
-  const int grid = (int)(((long)B * L + HEAD_TOK - 1) / HEAD_TOK);
-  hipLaunchKernelGGL(vqa_head_token_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, B, L, C,
-                     (long)stride_b, (long)stride_l, (long)stride_c, w1t, b1, hidden, w2, scratch);
-  KVQ_CHECK_LAUNCH("vqa_head_token_kernel");
+  const bool mfma = w1 && stride_c == 1 && hidden == 64 && C % 64 == 0 && stride_b % 4 == 0 && stride_l % 4 == 0 &&
+                    (((size_t)feat | (size_t)w1) & 15) == 0;
+  KVQ_REQUIRE(mfma || w1t, KVQ_ERR_NULL, "kvq_vqa_head: this shape takes the VALU kernel, which reads w1t");
+  if (mfma) {
+    hipLaunchKernelGGL(vqa_head_mfma_kernel, dim3((unsigned)(((long)B * L + 15) / 16)), dim3(256), 0, (hipStream_t)stream, feat, B, L, C,
+                       (long)stride_b, (long)stride_l, w1, b1, w2, scratch);
+    KVQ_CHECK_LAUNCH("vqa_head_mfma_kernel");
+  } else {
+    const int grid = (int)(((long)B * L + HEAD_TOK - 1) / HEAD_TOK);
+    hipLaunchKernelGGL(vqa_head_token_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, B, L, C,
+                       (long)stride_b, (long)stride_l, (long)stride_c, w1t, b1, hidden, w2, scratch);
+    KVQ_CHECK_LAUNCH("vqa_head_token_kernel");
+  }
   hipLaunchKernelGGL(mean_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scratch, L, b2, score);
   KVQ_CHECK_LAUNCH("mean_rows_kernel");
   return KVQ_OK;

@@ -189,7 +189,8 @@ def patch_im2col(x: torch.Tensor, patch: Sequence[int], out_dtype=torch.float16)
 
 def vqa_head(feat: torch.Tensor, w1, b1, w2, b2, w1t=None):
     """feat fp32 (B,C,D,H,W) with ANY strides over a dense token grid -> score fp32 [B,1].
-    ``w1`` [hidden,C] (transposed here) or ``w1t`` [C,hidden] already in the kernel's layout."""
+    ``w1`` [hidden,C] (what the fp32-MFMA kernel reads: hidden == 64, channels-last features) and / or ``w1t`` [C,hidden]
+    (the VALU kernel's layout; made here from ``w1`` when missing)."""
     _need_gpu(feat, w1, b1, w2, b2, w1t)
     assert feat.dtype == torch.float32 and feat.dim() == 5
     B, Cc, D, H, W = feat.shape
@@ -198,12 +199,14 @@ def vqa_head(feat: torch.Tensor, w1, b1, w2, b2, w1t=None):
     if not (sh == W * sw and sd == H * sh):          # tokens must be addressable with one stride
         feat = feat.contiguous()
         sb, sc, sd, sh, sw = feat.stride()
+    if w1 is not None:
+        w1 = w1.reshape(w1.shape[0], -1).contiguous()
     if w1t is None:
-        w1t = w1.t().contiguous()               # [C][hidden]: what the kernel streams (kvq_hip.h)
+        w1t = w1.t().contiguous()               # [C][hidden]: what the VALU kernel streams (kvq_hip.h)
     hidden = w1t.shape[1]
     scratch = torch.empty(B * L, dtype=torch.float32, device=feat.device)
     score = torch.empty(B, dtype=torch.float32, device=feat.device)
-    check(lib().kvq_vqa_head(ptr(feat), B, L, Cc, sb, sw, sc, ptr(w1t), ptr(b1), hidden, ptr(w2), ptr(b2),
+    check(lib().kvq_vqa_head(ptr(feat), B, L, Cc, sb, sw, sc, ptr(w1t), ptr(w1), ptr(b1), hidden, ptr(w2), ptr(b2),
                              ptr(scratch), ptr(score), current_stream()), "kvq_vqa_head")
     return score.reshape(B, 1)
 

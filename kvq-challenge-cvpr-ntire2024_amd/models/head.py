@@ -25,20 +25,21 @@ class VQAHead(nn.Module):
             nn.init.trunc_normal_(self.fc_last.weight, std=0.02)
 
     def _prepared(self, device):
-        """fp32 device copies in the layout the kernel streams (W1 transposed), rebuilt only when a
+        """fp32 device copies in the layouts the kernels stream (W1 as it is and transposed), rebuilt only when a
         parameter changed (version / data_ptr) — no per-forward conversion kernels."""
         ps = (self.fc_hid.weight, self.fc_hid.bias, self.fc_last.weight, self.fc_last.bias)
         sig = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_cache", None) is None or self._cache[0] != sig:
             f32 = lambda p: p.detach().to(device=device, dtype=torch.float32)  # noqa: E731
-            self._cache = (sig, (f32(ps[0]).reshape(self.hidden_channels, -1).t().contiguous(), f32(ps[1]).contiguous(),
-                                 f32(ps[2]).reshape(-1).contiguous(), f32(ps[3]).contiguous()))
+            w1 = f32(ps[0]).reshape(self.hidden_channels, -1).contiguous()
+            self._cache = (sig, (w1.t().contiguous(), f32(ps[1]).contiguous(), f32(ps[2]).reshape(-1).contiguous(),
+                                 f32(ps[3]).contiguous(), w1))
         return self._cache[1]
 
     def forward(self, x, rois=None):
         """x (B, C, D, H, W) fp32 (any strides) -> (B, 1)."""
-        w1t, b1, w2, b2 = self._prepared(x.device)
-        return kernels.vqa_head(x.to(torch.float32), None, b1, w2, b2, w1t=w1t)
+        w1t, b1, w2, b2, w1 = self._prepared(x.device)
+        return kernels.vqa_head(x.to(torch.float32), w1, b1, w2, b2, w1t=w1t)
 
 
 class simpleVQAHead(nn.Module):  # noqa: N801  (reference spelling)

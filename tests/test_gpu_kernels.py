@@ -585,18 +585,25 @@ def test_patch_im2col(shape, half):
     assert torch.equal(out, rnd(ref, half))
 
 
-def test_vqa_head_layouts():
-    g = rng(77)
-    feat = torch.from_numpy(g.standard_normal((3, 768, 4, 7, 7)).astype(np.float32))
-    hw = synth.synth_vqa_head_weights(768, 64, 5, "stress")
+@pytest.mark.parametrize("shape,hidden", [((3, 768, 4, 7, 7), 64), ((2, 1024, 1, 5, 5), 64), ((1, 768, 2, 3, 3), 32), ((2, 96, 2, 4, 4), 64)])
+def test_vqa_head_layouts(shape, hidden):
+    """channels-first features take the VALU kernel, channels-last ones with 64 hidden units and C % 64 == 0 the fp32-MFMA
+    kernel (ragged last 16-token tile included); both are fp32 arithmetic on the oracle's numbers."""
+    g = rng(77 + shape[1])
+    Cc = shape[1]
+    feat = torch.from_numpy(g.standard_normal(shape).astype(np.float32))
+    hw = synth.synth_vqa_head_weights(Cc, hidden, 5, "stress")
     ref = O.vqa_head(feat, hw)
     w = {k: dev(torch.from_numpy(v)) for k, v in hw.items()}
-    args = (w["fc_hid.weight"].reshape(64, 768), w["fc_hid.bias"], w["fc_last.weight"].reshape(-1), w["fc_last.bias"])
+    args = (w["fc_hid.weight"].reshape(hidden, Cc), w["fc_hid.bias"], w["fc_last.weight"].reshape(-1), w["fc_last.bias"])
     out_cf = kernels.vqa_head(dev(feat), *args)                                         # (B,C,D,H,W) contiguous
     cl = dev(feat).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)          # channels-last view
     out_cl = kernels.vqa_head(cl, *args)
     assert (out_cf.cpu() - ref).abs().max().item() <= 2e-5
     assert (out_cl.cpu() - ref).abs().max().item() <= 2e-5
+    # a clip's score does not depend on its neighbours in the batch (a 16-token tile may straddle two clips)
+    one = kernels.vqa_head(cl[-1:], *args)
+    assert torch.equal(one, out_cl[-1:])
 
 
 def test_simple_vqa_head():
