@@ -212,7 +212,7 @@ def timed(kd, device, fn_steps, steps, warmup, finish=None, first=None, min_s=0.
 
 
 # ---- HBM traffic, measured: child passes of this file under rocprofv3 --pmc ------------------------------------------------
-ONE_TIME_KERNELS = ("bias_dense_build_kernel", "bias_stream_build_kernel", "tail_pack", "pack_", "at::native", "Cijk_", "fill_", "copyBuffer")
+ONE_TIME_KERNELS = ("bias32_build_kernel", "tail_pack", "pack_", "at::native", "Cijk_", "fill_", "copyBuffer")
 
 
 def kernel_norm(name):

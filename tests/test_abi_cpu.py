@@ -40,6 +40,38 @@ def test_struct_layouts_match_header_sizes():
     assert _abi.dtype_code('bf16') == 0 and _abi.dtype_code(torch.float16) == 1
 
 
+def test_fragment_source_eligibility_is_host_logic():
+    """kvq_patch_embed_fragments_supported decides on the host whether the embedding launch may read through the sampler
+    (include/kvq_hip.h): uint8 frames, 4 x 4 patches inside the mini-patches, canvas = grid x mini-patch, source >= canvas,
+    whole aligned frame groups, one clip per 32 tokens, a sane channel stride."""
+    handle = _abi.lib()
+    f = _abi.KvqFragmentSource()
+    f.n_clips, f.src_is_u8, f.Hs, f.Ws, f.Fh, f.Fw, f.fs_h, f.fs_w, f.aligned = 4, 1, 540, 960, 7, 7, 32, 32, 8
+    ok = lambda *a: handle.kvq_patch_embed_fragments_supported(f, *a)          # noqa: E731  (B, in_chans, pd, T, H, W)
+    assert ok(4, 3, 2, 32, 224, 224) == 1
+    assert ok(3, 3, 2, 32, 224, 224) == 0 and ok(17, 3, 2, 32, 224, 224) == 0       # batch != clips; more clips than the struct holds
+    assert ok(4, 3, 2, 32, 224, 256) == 0                                            # canvas != grid x mini-patch
+    assert ok(4, 3, 2, 30, 224, 224) == 0                                            # T % aligned
+    assert ok(4, 5, 2, 32, 224, 224) == 0                                            # mean / std hold 4 channels
+    f.chan_stride = 32 * 540 * 960 - 1
+    assert ok(4, 3, 2, 32, 224, 224) == 0                                            # planes would overlap
+    f.chan_stride = 256 * 540 * 960
+    assert ok(4, 3, 2, 32, 224, 224) == 1                                            # clips = runs of frames of a 256-frame video
+    f.src_is_u8 = 0
+    assert ok(4, 3, 2, 32, 224, 224) == 0
+    f.src_is_u8, f.fs_h, f.Fh = 1, 14, 16
+    assert ok(4, 3, 2, 32, 224, 224) == 0                                            # patch rows would span two mini-patches
+    f.fs_h, f.Fh, f.Hs = 32, 7, 200
+    assert ok(4, 3, 2, 32, 224, 224) == 0                                            # source smaller than the canvas
+    f.Hs, f.Fh, f.Fw = 540, 1, 1
+    assert ok(4, 3, 2, 8, 32, 32) == 1                                               # 4 x 8 x 8 = 256 tokens per clip
+    f.fs_h = f.fs_w = 12
+    f.aligned = 2
+    assert ok(4, 3, 2, 2, 12, 12) == 0                                               # 9 tokens per clip: a wave of 32 would straddle clips
+    assert ok(4, 3, 2, 64, 12, 12) == 1                                              # 32 x 9 tokens
+    assert handle.kvq_patch_embed_fragments_supported(None, 4, 3, 2, 32, 224, 224) == 0
+
+
 def test_error_paths_without_gpu():
     handle = _abi.lib()
     rc = handle.kvq_gemm_bf16(None, None)

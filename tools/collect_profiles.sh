@@ -7,7 +7,7 @@
 #   kernel_stats.txt       rocprofv3 --kernel-trace --stats of the serial C2 bench (the durations roofline.avg_launch_us must agree with)
 #   pmc_sq.txt             rocprofv3 --pmc SQ_* (separate pass) of the same command
 #   c3_*, c5_*             the same for the C3 probe (bench.py --probe c3) and the C5 probe (bench.py --probe c5)
-#   gemm_sweep.txt, slowfast_layers.txt, attention / bias-build probes
+#   gemm_sweep.txt, slowfast_layers.txt, attention / bias-build probes, embed_sampler_pmc.txt (HBM bytes of K1 + embedding, both sequencings)
 tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -31,6 +31,7 @@ timeout 300 python tools/sf_layers.py > $out/slowfast_layers.txt 2>&1
 timeout 300 python tools/gemm_sweep.py > $out/gemm_sweep.txt 2>&1
 timeout 300 python tools/swinb_probe.py 4 table > $out/c5_launches.txt 2>&1
 timeout 300 python tools/bias_build_probe.py > $out/bias_build.txt 2>&1
+timeout 1200 bash tools/pmc_embed.sh > $out/embed_sampler_pmc.txt 2>&1
 # attention alone on the chip (tools/ubench/*.bin are built on the build host: hipcc ... attn32_bench.hip / attn32_loop.hip) and its counters
 if [ -x tools/ubench/attn32_bench.bin ]; then
   (cd tools/ubench && ./attn32_run.sh attn32_bench.bin) > $out/attn32_standalone.txt 2>&1

@@ -17,11 +17,15 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--clip-tensor", action="store_true", help="feed a pre-sampled fp32 clip instead of (uint8 frames, sampler draws)")
     a = ap.parse_args()
     from kvq_amd.utils import synth
     dev = torch.device("cuda", 0)
     net, cfg, wts, hw = bench.build_net(a.dtype, dev)
-    x = torch.from_numpy(synth.synth_clip(1234, 32, 224, 224, batch=a.batch)).to(dev)
+    if a.clip_tensor:
+        x = torch.from_numpy(synth.synth_clip(1234, 32, 224, 224, batch=a.batch)).to(dev)
+    else:       # the bench's step: the embedding launch reads through the fragment sampler
+        x = bench.Source(a.batch, dev, 1234).fragments(0, a.batch)
     bb = net.swin_tiny_grpb_backbone
     with torch.no_grad():
         for _ in range(2):
