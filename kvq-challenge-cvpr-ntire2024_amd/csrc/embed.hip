@@ -13,8 +13,6 @@
 // fs_h x fs_w mini-patch, so its rows are two 4-byte runs of a source row) and is normalised in registers with the same
 // IEEE fp32 (v - mean) / std as kvq_fragment_gather — the operands are bit-identical to the two-launch sequence, which
 // wrote the fp32 clip (4 B/px) and read it back (4 B/px).
-#include <stdlib.h>
-
 #include "common.hpp"
 
 namespace kvq {
@@ -225,8 +223,7 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
 
 template <typename E_, int CM, int KS>
 static int launch_embed(const EmbedParams& p, hipStream_t st) {
-  static const int pad = [] { const char* e = getenv("KVQ_EMBED_LDS_PAD"); return e ? atoi(e) : 0; }();      // experiment: occupancy
-  const size_t lds = (size_t)CM * KS * 1024 + (size_t)5 * 32 * CM * 4 + 1024 + (p.x ? 0 : 4 * 256 * 4) + pad;
+  const size_t lds = (size_t)CM * KS * 1024 + (size_t)5 * 32 * CM * 4 + 1024 + (p.x ? 0 : 4 * 256 * 4);
   const long total = (long)p.B * p.D0 * p.H0 * p.W0;
   dim3 grid((unsigned)((total + 127) / 128)), block(256);
   if (p.x == nullptr) {
