@@ -778,8 +778,8 @@ def _fragment_source(seed, n_clips, T=16, Hs=270, Ws=480, grid=7, fs=32, aligned
     vids = [torch.randint(0, 256, (3, T, Hs, Ws), dtype=torch.uint8, generator=g).to(DEV) for _ in range(n_clips)]
     gh = torch.tensor([min(Hs // grid * i, Hs - fs) for i in range(grid)]).view(grid, 1, 1)
     gw = torch.tensor([min(Ws // grid * i, Ws - fs) for i in range(grid)]).view(1, grid, 1)
-    hs = [(torch.randint(Hs // grid - fs, (grid, grid, T // aligned), generator=g) + gh).int().to(DEV) for _ in range(n_clips)]
-    ws = [(torch.randint(Ws // grid - fs, (grid, grid, T // aligned), generator=g) + gw).int().to(DEV) for _ in range(n_clips)]
+    hs = [(torch.randint(max(1, Hs // grid - fs), (grid, grid, T // aligned), generator=g) + gh).int().to(DEV) for _ in range(n_clips)]
+    ws = [(torch.randint(max(1, Ws // grid - fs), (grid, grid, T // aligned), generator=g) + gw).int().to(DEV) for _ in range(n_clips)]
     mean, std = ((123.675, 116.28, 103.53), (58.395, 57.12, 57.375)) if normalise else (None, None)
     return kernels.FragmentSource(vids, hs, ws, grid, grid, fs, fs, aligned, mean=mean, std=std)
 
@@ -815,6 +815,38 @@ def test_patch_embed_reads_through_the_sampler(normalise, emit, half):
     assert torch.equal(out_a, out_b)
     if emit:
         assert torch.equal(nxt_a, nxt_b)
+
+
+@pytest.mark.parametrize("geom", [dict(T=8, Hs=300, Ws=420, grid=8, fs=32, aligned=8),      # Swin-B's 256 x 256 canvas, E = 128
+                                  dict(T=4, Hs=90, Ws=130, grid=5, fs=16, aligned=2),      # 16-pixel mini-patches, frame groups of 2
+                                  dict(T=6, Hs=64, Ws=64, grid=2, fs=32, aligned=1),       # the source IS the canvas; a draw per frame
+                                  dict(T=16, Hs=80, Ws=100, grid=2, fs=32, aligned=4)])    # cut in two along time: clips as views
+def test_patch_embed_reads_through_the_sampler_geometries(geom, half):
+    """other grids / mini-patch sizes / frame groups, E = 128 (four channel tiles), clips that are frame runs of a longer video"""
+    E = 128
+    src = _fragment_source(41 + geom["grid"], 2, **geom)
+    g = rng(6)
+    w = dev(torch.from_numpy((g.standard_normal((E, 96)) * 0.1).astype(np.float32)), half)
+    b = dev(torch.from_numpy((g.standard_normal(E) * 0.2).astype(np.float32)))
+    lw = dev(torch.from_numpy((1 + 0.2 * g.standard_normal(E)).astype(np.float32)))
+    lb = dev(torch.from_numpy((0.2 * g.standard_normal(E)).astype(np.float32)))
+    L0 = (geom["T"] // 2) * (geom["grid"] * geom["fs"] // 4) ** 2
+    if L0 % 32:
+        assert src.c_struct() is not None
+        with pytest.raises(_abi.KvqError, match="does not fit the fused read"):
+            kernels.patch_embed(src, w, b, lw, lb, (2, 4, 4))
+        return
+    out_a, _ = kernels.patch_embed(src.materialise(), w, b, lw, lb, (2, 4, 4))
+    out_b, _ = kernels.patch_embed(src, w, b, lw, lb, (2, 4, 4))
+    assert torch.equal(out_a, out_b)
+    if geom["T"] % (2 * geom["aligned"]) == 0:          # the same clips cut in two along time: views, channel stride of the parent
+        halves = src.split_clips(2)
+        assert halves.shape[0] == 4 and halves.shape[2] == geom["T"] // 2 and not halves.videos[1].is_contiguous()
+        th = geom["T"] // 2
+        if th % 2 == 0 and ((th // 2) * (geom["grid"] * geom["fs"] // 4) ** 2) % 32 == 0:
+            o_view, _ = kernels.patch_embed(halves, w, b, lw, lb, (2, 4, 4))
+            o_mat, _ = kernels.patch_embed(halves.materialise(), w, b, lw, lb, (2, 4, 4))
+            assert torch.equal(o_view, o_mat)
 
 
 def test_patch_embed_fragment_source_guards():
