@@ -57,6 +57,11 @@ class LaneGraphs:
     def run(self, lane: int, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Enqueue fn(inputs) on lane's stream.  The returned tensor is the graph's static output: consume it on the same
         stream before the lane's next ``run`` (stream order makes that safe without host synchronisation)."""
+        if any(hasattr(v, "materialise") for v in inputs.values()):
+            # a recorded forward reads fixed addresses: a lazily sampled view (kernels.FragmentSource: per-video frame / draw
+            # pointers inside the launch parameters) becomes its fp32 tensor first, on the lane's stream
+            with torch.cuda.stream(self.lanes[lane]):
+                inputs = {k: (v.materialise() if hasattr(v, "materialise") else v) for k, v in inputs.items()}
         sig = _signature(inputs)
         if sig not in self._graphs[lane] and len(self._graphs[lane]) < self.max_signatures:
             self._record(lane, sig, inputs)

@@ -308,6 +308,40 @@ def test_hipgraph_replay_is_bit_identical_to_eager(kind):
     assert lg.replays == 5 and lg.eager_runs == 0 and all(len(g) == 1 for g in lg._graphs)
 
 
+def test_hipgraph_replay_takes_a_lazily_sampled_view():
+    """A FragmentSource input (per-video frame / draw pointers) is materialised into the recording's static buffer: replay
+    gives the eager fused forward's scores bit for bit."""
+    from kvq_amd import kernels
+    from kvq_amd.graph import LaneGraphs
+    from kvq_amd.models import VQA_Network
+    net = VQA_Network({"model": {"args": {"swin_tiny_grpb": {"head": {"in_channels": 768, "hidden_channels": 64}}}}})
+    sd = {"swin_tiny_grpb_backbone." + k: torch.from_numpy(v) for k, v in synth.synth_swin_weights(synth.SWIN_T_GRPB, 3, "stress").items()}
+    sd.update({"swin_tiny_grpb_head." + k: torch.from_numpy(v) for k, v in synth.synth_vqa_head_weights(768, 64, 3, "stress").items()})
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    srcs = []
+    for _ in range(2):
+        vids = [torch.randint(0, 256, (3, 8, 96, 120), dtype=torch.uint8, generator=g).cuda() for _ in range(2)]
+        hs = [torch.randint(0, 96 - 64 + 1 - 32, (2, 2, 1), generator=g).int().cuda() + torch.tensor([0, 48]).view(2, 1, 1).int().cuda() for _ in range(2)]
+        ws = [torch.randint(0, 28, (2, 2, 1), generator=g).int().cuda() + torch.tensor([0, 60]).view(1, 2, 1).int().cuda() for _ in range(2)]
+        srcs.append(kernels.FragmentSource(vids, hs, ws, 2, 2, 32, 32, 8, mean=KVQ_MEAN, std=KVQ_STD))
+    fn = lambda d: net(inputs=dict(d), reduce_scores=True)     # noqa: E731
+    with torch.no_grad():
+        eager = [fn({"technical": s}).clone() for s in srcs]
+        lanes = [torch.cuda.Stream()]
+        lg = LaneGraphs(fn, lanes)
+        got = []
+        for j in (0, 1, 0):
+            out = lg.run(0, {"technical": srcs[j]})
+            with torch.cuda.stream(lanes[0]):
+                got.append((j, out.clone()))
+        torch.cuda.synchronize()
+    assert not torch.equal(eager[0], eager[1]) and lg.replays == 3
+    for j, o in got:
+        assert torch.equal(o, eager[j])
+
+
 def test_hipgraph_capture_failure_falls_back_to_eager_launches():
     """A forward with a host synchronisation inside cannot be recorded: LaneGraphs warns once and runs that signature with
     eager launches (same kernels), instead of failing the job."""
