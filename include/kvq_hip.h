@@ -100,6 +100,8 @@ typedef struct {            /* PatchMerging (swin_backbone.py:527-531) */
   const float* norm_w;      /* [4C] */
   const float* norm_b;
   const uint16_t* red_w;    /* [2C][4C], no bias */
+  const void* merge_pack;   /* optional, derived: kvq_patch_merge_pack image; non-NULL (and kvq_patch_merge_supported(C)) ->
+                               the merge's LayerNorm + GEMM (+ the next block's norm1) run as ONE launch */
 } KvqSwinMergeW;
 
 typedef struct {
@@ -191,7 +193,7 @@ int kvq_swin3d_bias_dense_build(const KvqSwinPlan* plan, int block, const float*
  * launch with hipEvents on the launch stream; enable with kvq_swin3d_profile(plan, 1). */
 enum {
   KVQ_K_IM2COL = 0, KVQ_K_LAYERNORM, KVQ_K_GEMM_QKV, KVQ_K_ATTN, KVQ_K_GEMM_PROJ, KVQ_K_GEMM_FC1,
-  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_TAIL, KVQ_K_EMBED, KVQ_K_COUNT
+  KVQ_K_GEMM_FC2, KVQ_K_GEMM_MERGE, KVQ_K_GEMM_EMBED, KVQ_K_TAIL, KVQ_K_EMBED, KVQ_K_MERGE, KVQ_K_COUNT
 };
 typedef struct {
   int32_t kind;     /* KVQ_K_*                                                                    */
@@ -309,6 +311,31 @@ size_t kvq_patch_embed_pack_bytes(int embed_dim, int K);
 int kvq_patch_embed_pack(const void* w, const float* bias, const float* ln_w, const float* ln_b, int embed_dim, int K,
                          void* pack, void* stream);
 int kvq_patch_embed(const KvqPatchEmbedArgs* host_args, void* stream);
+
+/* PatchMerging (swin_backbone.py:533-556) as one launch, token-per-lane MFMA (csrc/merge.hip), C = 96: the 4-neighbour concat
+ * (x0 x1 x2 x3 = (h,w) (h+1,w) (h,w+1) (h+1,w+1), F.pad zeros for odd H / W), LayerNorm(4C) and Linear(4C -> 2C, no bias),
+ * optionally + the next stage's first norm1 in its window order.  LayerNorm is folded around the GEMM:
+ * W (gamma (x - mean) rstd + beta) = rstd (W diag(gamma)) (x - mean) + W beta; the pack holds W diag(gamma) (16-bit MFMA fragments)
+ * and W beta (fp32).  kvq_patch_merge_pack reads the fp32 weights. */
+typedef struct {
+  const float* x;              /* fp32 [B*L][C] residual stream                                        */
+  const int32_t* merge_map;    /* int32 [Ln][4]: token (within a clip) of each neighbour, -1 = padding  */
+  int32_t B, L, Ln, C;
+  const void* pack;            /* kvq_patch_merge_pack image                                            */
+  float* out;                  /* fp32 [B*Ln][2C]                                                       */
+  const float* next_norm_w;    /* the following four: only with next_ln != NULL                         */
+  const float* next_norm_b;
+  const int32_t* next_dst;     /* merged token -> row of the next block's window order (no padding)     */
+  void* next_ln;               /* 16-bit [B*next_rows][2C]                                              */
+  int32_t next_rows;
+  float eps;
+  int32_t dtype;
+} KvqPatchMergeArgs;
+int kvq_patch_merge_supported(int C);
+size_t kvq_patch_merge_pack_bytes(int C);
+int kvq_patch_merge_pack(const float* red_w /* fp32 [2C][4C] */, const float* norm_w, const float* norm_b, int C,
+                         int dtype /*KvqDtype*/, void* pack, void* stream);
+int kvq_patch_merge(const KvqPatchMergeArgs* host_args, void* stream);
 
 /* Fused post-attention half of SwinTransformerBlock3D, one launch, token-per-lane MFMA (csrc/tail.hip):
  *   x <- x + window_reverse(roll(proj(attn)))        (swin_backbone.py:323, :472-488, :509)

@@ -14,7 +14,7 @@ from . import _build
 
 MAX_STAGES = 4
 K_NAMES = ["im2col", "layernorm", "gemm_qkv", "attn", "gemm_proj", "gemm_fc1", "gemm_fc2", "gemm_merge",
-           "gemm_embed", "tail", "embed"]
+           "gemm_embed", "tail", "embed", "merge"]
 K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
@@ -53,7 +53,7 @@ class KvqSwinBlockW(C.Structure):
 
 
 class KvqSwinMergeW(C.Structure):
-    _fields_ = [(n, p_void) for n in ("norm_w", "norm_b", "red_w")]
+    _fields_ = [(n, p_void) for n in ("norm_w", "norm_b", "red_w", "merge_pack")]
 
 
 class KvqSwinWeights(C.Structure):
@@ -127,6 +127,12 @@ class KvqPatchEmbedArgs(C.Structure):
                 ("eps", C.c_float), ("dtype", C.c_int32), ("frag", C.POINTER(KvqFragmentSource))]
 
 
+class KvqPatchMergeArgs(C.Structure):
+    _fields_ = [("x", p_void), ("merge_map", p_void), ("B", C.c_int32), ("L", C.c_int32), ("Ln", C.c_int32), ("C", C.c_int32),
+                ("pack", p_void), ("out", p_void), ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void),
+                ("next_ln", p_void), ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
+
+
 class KvqProfRecord(C.Structure):
     _fields_ = [("kind", C.c_int32), ("variant", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -187,6 +193,10 @@ SYMBOLS = {
     "kvq_patch_embed_pack_bytes": (sz, [i32, i32]),
     "kvq_patch_embed_pack": (i32, [p_void, p_void, p_void, p_void, i32, i32, p_void, p_void]),
     "kvq_patch_embed": (i32, [C.POINTER(KvqPatchEmbedArgs), p_void]),
+    "kvq_patch_merge_supported": (i32, [i32]),
+    "kvq_patch_merge_pack_bytes": (sz, [i32]),
+    "kvq_patch_merge_pack": (i32, [p_void, p_void, p_void, i32, i32, p_void, p_void]),
+    "kvq_patch_merge": (i32, [C.POINTER(KvqPatchMergeArgs), p_void]),
     "kvq_block_tail_supported": (i32, [i32, i32]),
     "kvq_block_tail_pack_bytes": (sz, [i32, i32]),
     "kvq_block_tail_pack": (i32, [p_void, p_void, p_void, p_void, p_void, p_void, p_void, p_void, i32, i32, p_void,

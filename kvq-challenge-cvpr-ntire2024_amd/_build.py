@@ -14,12 +14,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkvq_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "kvq_hip.h")
-SOURCES = ["common.cpp", "gemm.hip", "gemm256.hip", "ln.hip", "attn.hip", "attn32.hip", "misc.hip", "plan.hip", "conv.hip", "tail.hip", "tailmm.hip", "embed.hip", "vit.hip", "convnet.hip", "bottleneck.hip", "slowneck.hip"]
+SOURCES = ["common.cpp", "gemm.hip", "gemm256.hip", "ln.hip", "attn.hip", "attn32.hip", "misc.hip", "plan.hip", "conv.hip", "tail.hip", "tailmm.hip", "embed.hip", "merge.hip", "vit.hip", "convnet.hip", "bottleneck.hip", "slowneck.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 # attn.hip is VALU-bound: SLP packing of adjacent f32 ops into v_pk_* costs more v_mov than it saves, and
 # NaN-honouring fmaxf inserts a canonicalising v_max per MFMA output (no NaN can arise: -inf only).
-EXTRA = {"attn.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "attn32.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "tail.hip": ["-fno-slp-vectorize"], "tailmm.hip": ["-fno-slp-vectorize"], "embed.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"attn.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "attn32.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "tail.hip": ["-fno-slp-vectorize"], "tailmm.hip": ["-fno-slp-vectorize"], "embed.hip": ["-fno-slp-vectorize"], "merge.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -494,10 +494,12 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   int blk = 0;
   for (int i = 0; i < stage_lo; ++i) blk += pl->st[i].depth;
   size_t out_elems = 0;           // size of the residual stream behind the last stage run
+  bool merged_ln1_ready = false;  // the fused merge launch of the previous stage wrote the first norm1 rows of this one
   for (int i = stage_lo; i <= stage_hi; ++i) {
     const StageGeom& g = pl->st[i];
     const int C = g.C, M = B * g.Lp, ML = B * g.L;
-    bool ln1_ready = i == 0 && first_ln1_ready;   // the producer (embed / previous tail) already wrote this block's norm1 rows
+    bool ln1_ready = (i == 0 && first_ln1_ready) || merged_ln1_ready;   // the producer (embed / previous tail / merge) already wrote this block's norm1 rows
+    merged_ln1_ready = false;
     if (i == stage_lo && i > 0) cur = xa, oth = xb;
     for (int b = 0; b < g.depth; ++b, ++blk) {
       const KvqSwinBlockW& bw = w->blocks[blk];
@@ -603,9 +605,27 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       const KvqSwinMergeW& mw = w->merges[i];
       KVQ_REQUIRE(mw.norm_w && mw.norm_b && mw.red_w, KVQ_ERR_NULL, "kvq_swin3d_forward: merge %d weights missing", i);
       const int Ln = g.Dn * g.Hn * g.Wn;
-      KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr));
-      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
-                   oth));
+      if (mw.merge_pack && kvq_patch_merge_supported(C)) {
+        // concat + LayerNorm(4C) + reduction [+ the next stage's first norm1 in its window order] as one launch (csrc/merge.hip)
+        KvqPatchMergeArgs ma{};
+        ma.x = cur; ma.merge_map = g.d_merge; ma.B = B; ma.L = g.L; ma.Ln = Ln; ma.C = C; ma.pack = mw.merge_pack; ma.out = oth;
+        ma.eps = 1e-5f; ma.dtype = pl->dtype;
+        if (i + 1 <= stage_hi) {
+          const StageGeom& gn = pl->st[i + 1];
+          const KvqSwinBlockW& nb = w->blocks[blk];           // blk: the first block of stage i + 1
+          if (gn.Lp == gn.L && gn.d_dst[0] && nb.norm1_w && nb.norm1_b) {
+            ma.next_norm_w = nb.norm1_w; ma.next_norm_b = nb.norm1_b; ma.next_dst = gn.d_dst[0]; ma.next_ln = bln; ma.next_rows = gn.Lp;
+            merged_ln1_ready = true;
+          }
+        }
+        Bracket br(pl, st, KVQ_K_MERGE, merged_ln1_ready ? 1 : 0, 2.0 * B * Ln * (double)(2 * C) * (4 * C),
+                   (double)B * Ln * 4 * C * 4.0 + (double)B * Ln * 2 * C * (4.0 + (merged_ln1_ready ? 2.0 : 0.0)));
+        KVQ_TRY(kvq_patch_merge(&ma, st));
+      } else {
+        KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr));
+        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
+                     oth));
+      }
       float* t = cur; cur = oth; oth = t;
       out_elems = (size_t)B * Ln * 2 * C;
     } else {

@@ -759,6 +759,34 @@ def patch_embed(x, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, 
     return out, nxt
 
 
+def patch_merge(x: torch.Tensor, merge_map: torch.Tensor, n_batch: int, red_w: torch.Tensor, norm_w, norm_b, out_dtype=torch.float16, *,
+                next_norm=None, next_dst=None, next_rows=0, eps=1e-5):
+    """PatchMerging as one launch (C = 96): x fp32 [n_batch*L, C], merge_map int32 [Ln, 4] (-1 = zero padding), red_w fp32 [2C, 4C]
+    -> fp32 [n_batch*Ln, 2C] (+ the next block's norm1 rows, ``out_dtype``, when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
+    _need_gpu(x, merge_map, red_w, norm_w, norm_b, next_dst)
+    assert x.dtype == torch.float32 and x.is_contiguous() and merge_map.dtype == torch.int32 and merge_map.is_contiguous()
+    assert red_w.dtype == torch.float32 and red_w.is_contiguous()
+    Cc = x.shape[1]
+    L, Ln = x.shape[0] // n_batch, merge_map.shape[0]
+    nb = lib().kvq_patch_merge_pack_bytes(Cc)
+    if not nb:
+        raise _abi.KvqError("kvq_patch_merge: unsupported width (use layernorm_rows + gemm)")
+    pack = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib().kvq_patch_merge_pack(ptr(red_w), ptr(norm_w), ptr(norm_b), Cc, dtype_code(out_dtype), ptr(pack), current_stream()),
+          "kvq_patch_merge_pack")
+    out = torch.empty(n_batch * Ln, 2 * Cc, dtype=torch.float32, device=x.device)
+    a = _abi.KvqPatchMergeArgs()
+    a.x, a.merge_map, a.B, a.L, a.Ln, a.C, a.pack, a.out = ptr(x), ptr(merge_map), n_batch, L, Ln, Cc, ptr(pack), ptr(out)
+    a.eps, a.dtype = eps, dtype_code(out_dtype)
+    nxt = None
+    if next_norm is not None:
+        nxt = torch.empty(n_batch * next_rows, 2 * Cc, dtype=out_dtype, device=x.device)
+        a.next_norm_w, a.next_norm_b, a.next_dst, a.next_ln, a.next_rows = (ptr(next_norm[0]), ptr(next_norm[1]), ptr(next_dst),
+                                                                            ptr(nxt), next_rows)
+    check(lib().kvq_patch_merge(C.byref(a), current_stream()), "kvq_patch_merge")
+    return out, nxt
+
+
 def stem_mfma_pack_weight(w_kc: torch.Tensor, kernel, cin: int, out_dtype):
     """[K][Cout] fp32 stem weight (K ordered kd,kh,kw,c; Cout <= 8, kw = 7, cin <= 4) -> the 16-bit [kd*kh][16][32] image of
     ``kvq_conv_stem_mfma``: k = tap * 4 + c, zero rows / taps / channels as padding."""

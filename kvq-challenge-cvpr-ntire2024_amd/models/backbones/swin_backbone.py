@@ -35,6 +35,8 @@ def _rel_pos_index(window) -> torch.Tensor:
 # test hook: False -> a FragmentSource batch is materialised (kvq_fragment_gather per clip) before the forward instead of
 # being read through the sampler by the embedding launch; the two sequencings are bit-identical (tests/test_gpu_e2e.py)
 FUSE_SAMPLER = True
+# test hook: False -> PatchMerging runs as gather-LayerNorm + GEMM (+ the next block's LayerNorm launch) at every width
+FUSE_MERGE = os.environ.get("KVQ_FUSE_MERGE", "1") != "0"
 
 
 class _Affine(nn.Module):
@@ -239,7 +241,7 @@ class SwinTransformer3D(nn.Module):
     def _weights(self, device) -> KvqSwinWeights:
         """bf16 copies of the GEMM weights + a KvqSwinWeights of raw pointers; rebuilt whenever a
         parameter was modified in place or moved (tracked through tensor versions / data_ptr)."""
-        sig = (self.operand_dtype, self.fused_tail) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        sig = (self.operand_dtype, self.fused_tail, FUSE_MERGE) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._wcache is not None and self._wcache[0] == sig:
             return self._wcache[1]
         keep = []
@@ -312,6 +314,14 @@ class SwinTransformer3D(nn.Module):
                 m = w.merges[i]
                 m.norm_w, m.norm_b = f32(layer.downsample.norm.weight), f32(layer.downsample.norm.bias)
                 m.red_w = bf16(layer.downsample.reduction.weight)
+                Cm = layer.downsample.reduction.weight.shape[1] // 4
+                nbytes = lib().kvq_patch_merge_pack_bytes(Cm) if self.fused_tail and FUSE_MERGE else 0
+                if nbytes:      # concat + LayerNorm + reduction (+ the next norm1) as one launch for this width (csrc/merge.hip)
+                    mp = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                    check(lib().kvq_patch_merge_pack(f32(layer.downsample.reduction.weight), m.norm_w, m.norm_b, Cm, self.operand_dtype,
+                                                     ptr(mp), current_stream()), "kvq_patch_merge_pack")
+                    keep.append(mp)
+                    m.merge_pack = ptr(mp)
         w.blocks = C.cast(blocks, C.POINTER(KvqSwinBlockW))
         w.norm_w, w.norm_b = f32(self.norm.weight), f32(self.norm.bias)
         keep.append(blocks)
@@ -523,6 +533,8 @@ class SwinTransformer3D(nn.Module):
             elif kind == "embed":
                 sym = (f"patch_embed_kernel<{ename}, {self.embed_dim // 32}, 6, {str(bool(r.variant & 1)).lower()}, "
                        f"{str(bool(r.variant & 2)).lower()}>")          # ..., + norm1 of block 0, reads through the sampler
+            elif kind == "merge":
+                sym = f"patch_merge_kernel<{ename}, {str(bool(r.variant)).lower()}>"
             elif kind == "tail":
                 cm = r.variant // 10
                 emit = str(bool(r.variant % 10)).lower()

@@ -285,6 +285,75 @@ def test_layernorm_window_gather(dims, shift):
     assert torch.all(out.cpu()[pad] == 0)            # pad AFTER the norm: exact zeros, not beta
 
 
+def _merge_map(D, H, W):
+    Hn, Wn = (H + 1) // 2, (W + 1) // 2
+    mp = np.full((D, Hn, Wn, 4), -1, np.int32)
+    for d in range(D):
+        for h2 in range(Hn):
+            for w2 in range(Wn):
+                for part, (dh, dw) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):      # concat order x0 x1 x2 x3 (swin_backbone.py:546-550)
+                    hh, ww = 2 * h2 + dh, 2 * w2 + dw
+                    if hh < H and ww < W:
+                        mp[d, h2, w2, part] = (d * H + hh) * W + ww
+    return mp.reshape(-1, 4), Hn, Wn
+
+
+@pytest.mark.parametrize("dims,emit", [((2, 4, 8, 8), True), ((2, 3, 5, 7), False), ((3, 8, 14, 14), True)])
+def test_patch_merge_fused_vs_oracle(dims, emit, half):
+    """PatchMerging as one launch (concat + LayerNorm(4C) folded around the reduction GEMM [+ the next norm1 in window order])
+    against the fp32 oracle: the launch rounds (x - mean) and W diag(gamma) to 16 bits where the reference rounds nothing, so the
+    bound is the operand rounding over K = 384 terms — and against the three-launch sequence, which rounds LN(x) and W."""
+    B, D, H, W = dims
+    C = 96
+    g = rng(sum(dims))
+    x = torch.from_numpy((g.standard_normal((B, D, H, W, C)) * 1.5 + 0.3 * g.standard_normal((1, 1, 1, 1, C))).astype(np.float32))
+    # the launch's statistics are a shifted one-pass: tokens far from zero with a small spread, and constant tokens, must hold
+    x[:, 0, :2] = 50.0 + 0.05 * x[:, 0, :2]
+    x[:, -1, -2:, -2:] = -3.25
+    p = {"m.norm.weight": torch.from_numpy((1 + 0.2 * g.standard_normal(4 * C)).astype(np.float32)),
+         "m.norm.bias": torch.from_numpy((0.2 * g.standard_normal(4 * C)).astype(np.float32)),
+         "m.reduction.weight": torch.from_numpy((g.standard_normal((2 * C, 4 * C)) / np.sqrt(4 * C)).astype(np.float32))}
+    ref = O.patch_merge(x, p, "m.")                                        # (B, D, Hn, Wn, 2C) fp32
+    mp, Hn, Wn = _merge_map(D, H, W)
+    Ln = D * Hn * Wn
+    kw = {}
+    if emit:
+        lay = O.window_layout(D, Hn, Wn, (8, 7, 7), (0, 0, 0))
+        if (lay["src"] < 0).any():
+            kw = {}
+            emit = False
+        else:
+            dst = np.empty(Ln, np.int32)
+            dst[lay["src"]] = np.arange(Ln, dtype=np.int32)
+            gn = torch.from_numpy((1 + 0.2 * g.standard_normal(2 * C)).astype(np.float32))
+            bn = torch.from_numpy((0.2 * g.standard_normal(2 * C)).astype(np.float32))
+            kw = dict(next_norm=(dev(gn), dev(bn)), next_dst=dev(torch.from_numpy(dst)), next_rows=Ln)
+    out, nxt = kernels.patch_merge(dev(x.reshape(-1, C)), dev(torch.from_numpy(mp)), B, dev(p["m.reduction.weight"]),
+                                   dev(p["m.norm.weight"]), dev(p["m.norm.bias"]), out_dtype=half, **kw)
+    refm = ref.reshape(-1, 2 * C)
+    scale = max(1.0, refm.abs().max().item())
+    assert (out.cpu() - refm).abs().max().item() <= 4 * EPS[half] * scale
+    # the three launches it replaces: gather-LayerNorm (16-bit) -> GEMM on 16-bit weights
+    ln = kernels.layernorm_rows(dev(x.reshape(-1, C)), dev(p["m.norm.weight"]), dev(p["m.norm.bias"]), index_map=dev(torch.from_numpy(mp)),
+                                nparts=4, n_batch=B, rows_out=Ln, out_dtype=half)
+    chain = kernels.gemm(ln, dev(p["m.reduction.weight"], half), None, _abi.EPI_STORE_F32)
+    assert (out - chain).abs().max().item() <= 4 * EPS[half] * scale
+    if emit:
+        lnn = torch.nn.functional.layer_norm(out.cpu(), (2 * C,), gn, bn).reshape(B, D, Hn, Wn, 2 * C)
+        ref_ln = O.gather_windows(lnn, lay).reshape(-1, 2 * C)
+        assert (nxt.float().cpu() - ref_ln).abs().max().item() <= 2 * EPS[half] * ref_ln.abs().max().item() + 1e-5
+    # a token's result does not depend on the batch around it
+    one, _ = kernels.patch_merge(dev(x[1:2].reshape(-1, C)), dev(torch.from_numpy(mp)), 1, dev(p["m.reduction.weight"]),
+                                 dev(p["m.norm.weight"]), dev(p["m.norm.bias"]), out_dtype=half)
+    assert torch.equal(one, out[Ln:2 * Ln])
+
+
+def test_patch_merge_rejects_other_widths():
+    with pytest.raises(_abi.KvqError, match="unsupported width"):
+        kernels.patch_merge(torch.zeros(16, 192, device=DEV), torch.zeros(4, 4, dtype=torch.int32, device=DEV), 1,
+                            torch.zeros(384, 768, device=DEV), torch.ones(768, device=DEV), torch.zeros(768, device=DEV))
+
+
 def test_layernorm_merge_gather_odd_dims():
     g = rng(9)
     B, D, H, W, C = 2, 3, 5, 7, 96
