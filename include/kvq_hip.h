@@ -312,7 +312,7 @@ int kvq_patch_embed_pack(const void* w, const float* bias, const float* ln_w, co
                          void* pack, void* stream);
 int kvq_patch_embed(const KvqPatchEmbedArgs* host_args, void* stream);
 
-/* PatchMerging (swin_backbone.py:533-556) as one launch, token-per-lane MFMA (csrc/merge.hip), C = 96: the 4-neighbour concat
+/* PatchMerging (swin_backbone.py:533-556) as one launch, token-per-lane MFMA (csrc/merge.hip), C = 96 / 128 / 192: the 4-neighbour concat
  * (x0 x1 x2 x3 = (h,w) (h+1,w) (h,w+1) (h+1,w+1), F.pad zeros for odd H / W), LayerNorm(4C) and Linear(4C -> 2C, no bias),
  * optionally + the next stage's first norm1 in its window order.  LayerNorm is folded around the GEMM:
  * W (gamma (x - mean) rstd + beta) = rstd (W diag(gamma)) (x - mean) + W beta; the pack holds W diag(gamma) (16-bit MFMA fragments)

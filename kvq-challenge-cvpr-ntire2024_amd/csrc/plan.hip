@@ -605,8 +605,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       const KvqSwinMergeW& mw = w->merges[i];
       KVQ_REQUIRE(mw.norm_w && mw.norm_b && mw.red_w, KVQ_ERR_NULL, "kvq_swin3d_forward: merge %d weights missing", i);
       const int Ln = g.Dn * g.Hn * g.Wn;
-      if (mw.merge_pack && kvq_patch_merge_supported(C)) {
-        // concat + LayerNorm(4C) + reduction [+ the next stage's first norm1 in its window order] as one launch (csrc/merge.hip)
+      if (mw.merge_pack && kvq_patch_merge_supported(C) && C <= 128) {
+        // concat + LayerNorm(4C) + reduction [+ the next stage's first norm1 in its window order] as one launch (csrc/merge.hip).
+        // C = 96: 37.5 us against 26.3 + 25.6 + 15.9 (Swin-T, 4 clips); C = 128: +0.5-1 % on C5.  C = 192 exists and is tested, but
+        // the 576 KB matrix streams through LDS for 98 workgroups of one wave per SIMD: 66.9 us against 16.2 + 24.8 + 15.3 - not taken
         KvqPatchMergeArgs ma{};
         ma.x = cur; ma.merge_map = g.d_merge; ma.B = B; ma.L = g.L; ma.Ln = Ln; ma.C = C; ma.pack = mw.merge_pack; ma.out = oth;
         ma.eps = 1e-5f; ma.dtype = pl->dtype;

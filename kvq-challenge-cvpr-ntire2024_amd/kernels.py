@@ -761,7 +761,7 @@ def patch_embed(x, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, 
 
 def patch_merge(x: torch.Tensor, merge_map: torch.Tensor, n_batch: int, red_w: torch.Tensor, norm_w, norm_b, out_dtype=torch.float16, *,
                 next_norm=None, next_dst=None, next_rows=0, eps=1e-5):
-    """PatchMerging as one launch (C = 96): x fp32 [n_batch*L, C], merge_map int32 [Ln, 4] (-1 = zero padding), red_w fp32 [2C, 4C]
+    """PatchMerging as one launch (C = 96 / 128 / 192): x fp32 [n_batch*L, C], merge_map int32 [Ln, 4] (-1 = zero padding), red_w fp32 [2C, 4C]
     -> fp32 [n_batch*Ln, 2C] (+ the next block's norm1 rows, ``out_dtype``, when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
     _need_gpu(x, merge_map, red_w, norm_w, norm_b, next_dst)
     assert x.dtype == torch.float32 and x.is_contiguous() and merge_map.dtype == torch.int32 and merge_map.is_contiguous()

@@ -298,14 +298,15 @@ def _merge_map(D, H, W):
     return mp.reshape(-1, 4), Hn, Wn
 
 
-@pytest.mark.parametrize("dims,emit", [((2, 4, 8, 8), True), ((2, 3, 5, 7), False), ((3, 8, 14, 14), True)])
-def test_patch_merge_fused_vs_oracle(dims, emit, half):
+@pytest.mark.parametrize("dims,emit,C", [((2, 4, 8, 8), True, 96), ((2, 3, 5, 7), False, 96), ((3, 8, 14, 14), True, 96),
+                                         ((2, 8, 14, 14), True, 192), ((2, 2, 9, 6), False, 192), ((2, 8, 14, 14), True, 128), ((2, 3, 5, 7), False, 128)])
+def test_patch_merge_fused_vs_oracle(dims, emit, C, half):
     """PatchMerging as one launch (concat + LayerNorm(4C) folded around the reduction GEMM [+ the next norm1 in window order])
-    against the fp32 oracle: the launch rounds (x - mean) and W diag(gamma) to 16 bits where the reference rounds nothing, so the
-    bound is the operand rounding over K = 384 terms — and against the three-launch sequence, which rounds LN(x) and W."""
+    against the fp32 oracle: the launch rounds (x - K) and W diag(gamma) to 16 bits where the reference rounds nothing, so the
+    bound is the operand rounding over K = 4C terms — and against the three-launch sequence, which rounds LN(x) and W.  C = 96: the
+    matrix is LDS-resident; C = 128 / 192: it streams through two chunk buffers (4 / 8 chunks)."""
     B, D, H, W = dims
-    C = 96
-    g = rng(sum(dims))
+    g = rng(sum(dims) + C)
     x = torch.from_numpy((g.standard_normal((B, D, H, W, C)) * 1.5 + 0.3 * g.standard_normal((1, 1, 1, 1, C))).astype(np.float32))
     # the launch's statistics are a shifted one-pass: tokens far from zero with a small spread, and constant tokens, must hold
     x[:, 0, :2] = 50.0 + 0.05 * x[:, 0, :2]
@@ -350,8 +351,8 @@ def test_patch_merge_fused_vs_oracle(dims, emit, half):
 
 def test_patch_merge_rejects_other_widths():
     with pytest.raises(_abi.KvqError, match="unsupported width"):
-        kernels.patch_merge(torch.zeros(16, 192, device=DEV), torch.zeros(4, 4, dtype=torch.int32, device=DEV), 1,
-                            torch.zeros(384, 768, device=DEV), torch.ones(768, device=DEV), torch.zeros(768, device=DEV))
+        kernels.patch_merge(torch.zeros(16, 256, device=DEV), torch.zeros(4, 4, dtype=torch.int32, device=DEV), 1,
+                            torch.zeros(512, 1024, device=DEV), torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV))
 
 
 def test_layernorm_merge_gather_odd_dims():
