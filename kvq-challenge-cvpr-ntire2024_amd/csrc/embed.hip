@@ -203,21 +203,30 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
   if (EMIT) {
     float mean, rstd;
     stats(mean, rstd);
-    if (live) {
-      const long drow = (long)b * p.next_rows + p.next_dst[tl];
-      uint16_t* o = p.next_ln + (size_t)drow * E + 4 * h;
+    // 16 bytes per lane: the lane pair (h = 0 | 1) of a token exchanges the 8-byte pieces of (q, q + 1) by v_permlane32_swap, lane h
+    // then owns channels 8 (2 t + h) .. + 7 of a tile — half the row-divergent store instructions (one row per cycle in the addresser)
+    const long drow = (long)b * p.next_rows + p.next_dst[tl];
+    uint16_t* o = p.next_ln + (size_t)drow * E;
 #pragma unroll
-      for (int i = 0; i < CM; ++i)
+    for (int i = 0; i < CM; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      for (int t = 0; t < 2; ++t) {
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = 2 * t + u;
           const f32x4 g = *reinterpret_cast<const f32x4*>(s_nn + 32 * i + 8 * q + 4 * h);
           const f32x4 be = *reinterpret_cast<const f32x4*>(s_nn + E + 32 * i + 8 * q + 4 * h);
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mean) * rstd * g[e] + be[e];
-          *reinterpret_cast<u32x2*>(o + 32 * i + 8 * q) = (u32x2){E_::pack2(y[0], y[1]), E_::pack2(y[2], y[3])};
+          pk[u][0] = E_::pack2(y[0], y[1]);
+          pk[u][1] = E_::pack2(y[2], y[3]);
         }
-    }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        if (live) *reinterpret_cast<u32x4*>(o + 32 * i + 8 * (2 * t + h)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+      }
   }
 }
 

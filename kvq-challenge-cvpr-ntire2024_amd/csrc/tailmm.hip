@@ -434,23 +434,33 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
     const f32x2 mean = sum * (1.0f / (float)C);
     const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
     const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+    // 16 bytes per lane: the lane pair (half = 0 | 1) of a token exchanges the 8-byte pieces of (q, q + 1) by v_permlane32_swap, lane
+    // `half` then owns features 8 (2 t + half) .. + 7 of a tile — half the row-divergent store instructions
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-      if (live[tt]) {
-        const long drow = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
-        uint16_t* o = p.next_ln + (size_t)drow * C + FW * wave + 4 * half;
+    for (int tt = 0; tt < 2; ++tt) {
+      const long drow = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
+      uint16_t* o = p.next_ln + (size_t)drow * C + FW * wave;
 #pragma unroll
-        for (int ft = 0; ft < CF; ++ft)
+      for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+        for (int t = 0; t < 2; ++t) {
+          uint32_t pk[2][2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int q = 2 * t + u;
             const int f0 = FW * wave + 32 * ft + 8 * q + 4 * half;
             const f32x4 gm = *reinterpret_cast<const f32x4*>(p.nn_w + f0), be = *reinterpret_cast<const f32x4*>(p.nn_b + f0);
             float y[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] = (acc[ft][tt][4 * q + i] - mean[tt]) * rstd[tt] * gm[i] + be[i];
-            *reinterpret_cast<u32x2*>(o + 32 * ft + 8 * q) = (u32x2){E::pack2(y[0], y[1]), E::pack2(y[2], y[3])};
+            pk[u][0] = E::pack2(y[0], y[1]);
+            pk[u][1] = E::pack2(y[2], y[3]);
           }
-      }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+          if (live[tt]) *reinterpret_cast<u32x4*>(o + 32 * ft + 8 * (2 * t + half)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        }
+    }
   }
 #ifdef KVQ_TAIL_TRACE
   if (tr) {
