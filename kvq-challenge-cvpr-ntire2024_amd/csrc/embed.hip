@@ -63,10 +63,18 @@ __global__ void embed_pack_kernel(const uint16_t* w, const float* bias, const fl
   }
 }
 
+// LDS: [weights CM*KS KB][bias | ln_w | ln_b, whole KB][next norm1 gamma | beta][FRAG: 4 x 256 table][STAGED: 4 waves x 32 rows]
+__host__ __device__ constexpr int embed_stage_off(int CM, int KS) { return CM * KS * 1024 + 5 * 32 * CM * 4 + 1024 + 4 * 256 * 4; }
+// the x0 rows leave through an LDS tile at E = 96 (76 KB per workgroup: two per CU, which measures like five; hipEvent-bracketed
+// launch: 52.1 -> 49.8 us reading through the sampler, 48.4 -> 43.3 reading the fp32 clip); at E = 128 the tile would leave one
+// workgroup per CU — the accumulator-layout stores stay
+__host__ __device__ constexpr bool embed_staged(int CM, bool) { return CM == 3; }
+
 template <typename E_, int CM, int KS, bool EMIT, bool FRAG>
-__global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
+__global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_embed_kernel(EmbedParams p) {
   fp16_saturate_mode();
   constexpr int E = 32 * CM, WBYTES = CM * KS * 1024;
+  constexpr bool STAGED = embed_staged(CM, FRAG);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E_::v8;
   float* prm = reinterpret_cast<float*>(lds + WBYTES);       // [bias][ln_w][ln_b][nn_w][nn_b]
@@ -191,7 +199,29 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
         for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = (acc[i][4 * q + e] - mean) * rstd * g[e] + be[e];
       }
   }
-  if (live) {
+  if constexpr (STAGED) {
+    // The wave's 32 tokens are 32 consecutive rows of the residual stream: one contiguous 32 * E * 4 bytes.  Stored from the
+    // accumulator layout every store instruction touches 64 different rows (64 cycles in the texture addresser, 24 of them per
+    // wave at E = 96: most of this launch's memory-pipe time); through a wave-private LDS tile (row pitch + 16 B: the 32 lanes
+    // of a half spread over the banks) the same bytes leave as 1 KB lines.  A wave's LDS accesses complete in order: no barrier.
+    constexpr int RP = E * 4 + 16;
+    unsigned char* stg = lds + embed_stage_off(CM, KS) + wave * 32 * RP;
+    unsigned char* mine = stg + (lane & 31) * RP + 16 * h;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(mine + 128 * i + 32 * q) = (f32x4){acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+    const long row0 = (long)blockIdx.x * 128 + wave * 32;
+    const int nrow = (int)(total - row0 < 32 ? total - row0 : 32);        // <= 0: nothing of this wave is live
+    unsigned char* gb = reinterpret_cast<unsigned char*>(p.out + (size_t)row0 * E);
+#pragma unroll
+    for (int k = 0; k < 32 * E * 4 / 1024; ++k) {
+      const int off = k * 1024 + lane * 16, t = off / (E * 4), w = off - t * (E * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + t * RP + w);
+      if (t < nrow) *reinterpret_cast<f32x4*>(gb + off) = v;
+    }
+  } else if (live) {
     float* o = p.out + (size_t)rc * E + 4 * h;
 #pragma unroll
     for (int i = 0; i < CM; ++i)
@@ -232,16 +262,19 @@ __global__ __launch_bounds__(256, 3) void patch_embed_kernel(EmbedParams p) {
 
 template <typename E_, int CM, int KS>
 static int launch_embed(const EmbedParams& p, hipStream_t st) {
-  const size_t lds = (size_t)CM * KS * 1024 + (size_t)5 * 32 * CM * 4 + 1024 + (p.x ? 0 : 4 * 256 * 4);
+  const int lds = embed_stage_off(CM, KS) + (embed_staged(CM, p.x == nullptr) ? 4 * 32 * (32 * CM * 4 + 16) : 0);
   const long total = (long)p.B * p.D0 * p.H0 * p.W0;
   dim3 grid((unsigned)((total + 127) / 128)), block(256);
-  if (p.x == nullptr) {
-    if (p.next_ln) hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, true, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, false, true>), grid, block, lds, st, p);
-  } else {
-    if (p.next_ln) hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, true, false>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((patch_embed_kernel<E_, CM, KS, false, false>), grid, block, lds, st, p);
-  }
+  auto go = [&](auto k) -> int {
+    static LdsOptIn opt;                      // one per instantiation of the lambda, i.e. per kernel
+    if (int rc = opt.ensure(reinterpret_cast<const void*>(k), lds)) return rc;
+    hipLaunchKernelGGL(k, grid, block, lds, st, p);
+    return KVQ_OK;
+  };
+  int rc;
+  if (p.x == nullptr) rc = p.next_ln ? go(patch_embed_kernel<E_, CM, KS, true, true>) : go(patch_embed_kernel<E_, CM, KS, false, true>);
+  else rc = p.next_ln ? go(patch_embed_kernel<E_, CM, KS, true, false>) : go(patch_embed_kernel<E_, CM, KS, false, false>);
+  if (rc) return rc;
   KVQ_CHECK_LAUNCH("patch_embed_kernel");
   return KVQ_OK;
 }
