@@ -16,8 +16,8 @@
 //      (zero outside the image: conv_b's padding);
 //   b: 7 column tiles of output pixels; a B fragment half = the 8 channels of one tap's neighbour pixel, one ds_read_b128;
 //   c: conv_b's accumulators are packed straight into the B operand (k order = accumulator order, folded into the packed
-//      weights), + the shortcut (8-byte loads of the lane's own pixel, or one more MFMA over the input channels), ReLU, 8-byte
-//      stores.
+//      weights), + the shortcut (16-byte loads of the lane's own pixel, the lane pair exchanging 8-byte pieces by v_permlane32_swap,
+//      or one more MFMA over the input channels), ReLU, 16-byte stores through the same exchange.
 // Rounding points are those of the unfused launches (16-bit a, b and block output; fp32 accumulation and shortcut add).
 #include "common.hpp"
 
@@ -148,10 +148,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void fast_bottleneck_kern
         sx[s] = __builtin_bit_cast(V8, v);
       }
     } else {
+      // 16 bytes per lane (channels 8 (2 u + h) .. + 7 of the lane's pixel), then the lane pair of a pixel exchanges 8-byte pieces
+      // by v_permlane32_swap into the accumulator layout (4 + 4 channels of every 8): half the pixel-divergent load instructions
 #pragma unroll
-      for (int i = 0; i < L::RT * 4; ++i) {
-        idn[i] = (u32x2){0u, 0u};
-        if (live) idn[i] = *reinterpret_cast<const u32x2*>(xb + pix * CIN + 8 * i + 4 * h);      // CIN == COUT
+      for (int u = 0; u < L::RT * 2; ++u) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (live) v = *reinterpret_cast<const u32x4*>(xb + pix * CIN + 8 * (2 * u + h));       // CIN == COUT
+        const auto s0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+        idn[2 * u] = (u32x2){s0[0], s1[0]};             // q = 2 u:     channels 8 q + 4 h .. + 3
+        idn[2 * u + 1] = (u32x2){s0[1], s1[1]};         // q = 2 u + 1
       }
     }
     f32x16 accb;
@@ -196,21 +202,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void fast_bottleneck_kern
           acc = E::mfma32(*reinterpret_cast<const V8*>(lds + L::OFF_S + (rt * L::KSS + s) * 1024 + lane * 16), sx[s], acc);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bc = *reinterpret_cast<const f32x4*>(s_bc + 32 * rt + 8 * q + 4 * h);
-        float v[4];
+      for (int u = 0; u < 2; ++u) {
+        uint32_t pk[2][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e] + bc[e];
-        if (!SC) {
-          const u32x2 r2 = idn[rt * 4 + q];
-          v[0] += E::to_f32((uint16_t)(r2[0] & 0xffffu));
-          v[1] += E::to_f32((uint16_t)(r2[0] >> 16));
-          v[2] += E::to_f32((uint16_t)(r2[1] & 0xffffu));
-          v[3] += E::to_f32((uint16_t)(r2[1] >> 16));
+        for (int w = 0; w < 2; ++w) {
+          const int q = 2 * u + w;
+          const f32x4 bc = *reinterpret_cast<const f32x4*>(s_bc + 32 * rt + 8 * q + 4 * h);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e] + bc[e];
+          if (!SC) {
+            const u32x2 r2 = idn[rt * 4 + q];
+            v[0] += E::to_f32((uint16_t)(r2[0] & 0xffffu));
+            v[1] += E::to_f32((uint16_t)(r2[0] >> 16));
+            v[2] += E::to_f32((uint16_t)(r2[1] & 0xffffu));
+            v[3] += E::to_f32((uint16_t)(r2[1] >> 16));
+          }
+          pk[w][0] = E::pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+          pk[w][1] = E::pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
         }
-        if (live)
-          *reinterpret_cast<u32x2*>(orow + 32 * rt + 8 * q + 4 * h) =
-              (u32x2){E::pack2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)), E::pack2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))};
+        // the pair's 8-byte pieces of (q, q + 1) -> 16 bytes per lane: lane h stores channels 8 (2 u + h) .. + 7
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        if (live) *reinterpret_cast<u32x4*>(orow + 32 * rt + 8 * (2 * u + h)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
       }
     }
   }
