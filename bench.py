@@ -153,11 +153,9 @@ class Source:
         return self._fs[key]
 
     def sample_into(self, x, first):
-        """K1: clips first .. first+B-1 (mod pool) -> the (B, 3, 32, 224, 224) fp32 batch tensor ``x``, normalised."""
-        from kvq_amd import kernels
-        for b in range(x.shape[0]):
-            i = (first + b) % self.n
-            kernels.fragment_gather(self.clips[i], self.hoff[i], self.woff[i], 7, 7, 32, 32, 8, MEAN, STD, out=x[b])
+        """K1 as its own launch: clips first .. first+B-1 (mod pool) -> the (B, 3, 32, 224, 224) fp32 batch tensor ``x``, normalised
+        (``kvq_fragment_gather_batch``: one launch for the batch)."""
+        self.fragments(first, x.shape[0]).materialise(out=x)
 
 
 def run_lanes(lanes, n, fn):
@@ -753,7 +751,7 @@ def main():
                                       if sampler_on else ", pre-sampled fp32 clips (K1 outside the step)"),
                        "clips_per_gpu_per_step": B, "operand_dtype": args.dtype, "accumulate": "fp32",
                        "sampler_in_step": sampler_on,
-                       "sampler": ("kvq_fragment_gather per clip, then the forward" if args.two_launch_sampler or not sampler_on
+                       "sampler": ("kvq_fragment_gather_batch (one launch per batch), then the forward" if args.two_launch_sampler or not sampler_on
                                    else "kvq_swin3d_forward_fragments (K1 fused into the embedding's operand read; bit-identical scores)"),
                        "source_pool_clips": src.n, "distinct_clips_per_step": True,
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
@@ -783,8 +781,8 @@ def main():
                 out["two_launch_sampler"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt4, "unit": "videos/s",
                                              "ms_per_step": 1e3 * dt4 / args.steps, "steps": args.steps, "repeats": st4["repeats"],
                                              "scores_equal_headline": bool(torch.equal(s4, fp_scores)),
-                                             "note": "the same steps with K1 as its own launches (kvq_fragment_gather per clip writes the "
-                                                     "fp32 batch tensor, the forward reads it back): rounds 2-4's step"}
+                                             "note": "the same steps with K1 as its own launch (kvq_fragment_gather_batch writes the fp32 batch tensor, the "
+                                                     "forward reads it back): rounds 2-4's step (which launched K1 once per clip)"}
             if "bf16" in legs and args.dtype == "fp16":
                 bb.operand_dtype = _abi.dtype_code("bf16")
                 for st in lanes:

@@ -472,6 +472,9 @@ int kvq_simple_vqa_head(const float* feat, int B, int T, int Cin, const float* w
 int kvq_fragment_gather(const void* video, int src_is_u8, int C, int T, int H, int W, const int32_t* hoff,
                         const int32_t* woff, int Fh, int Fw, int fs_h, int fs_w, int aligned,
                         const float* host_mean, const float* host_std, float* out, void* stream);
+/* The same for every clip of a KvqFragmentSource in ONE launch (uint8 or fp32 frames, clips may be frame runs of a longer
+ * video: chan_stride): out fp32 (n_clips, C, T, Fh*fs_h, Fw*fs_w).  What FragmentSource.materialise() runs. */
+int kvq_fragment_gather_batch(const KvqFragmentSource* src, int C, int T, float* out, void* stream);
 
 /* torchvision Resize on a tensor (= bilinear, align_corners=False, no antialias; get_resize_function,
  * fusion_datasets.py:229-241) + crop + (v-mean)/std: get_resized_video (:244-252), get_resizecrop_video

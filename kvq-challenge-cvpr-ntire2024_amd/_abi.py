@@ -233,6 +233,7 @@ SYMBOLS = {
     "kvq_pool_nd_strided": (i32, [p_void, i32, C.POINTER(i32 * 5), C.POINTER(i32 * 3), C.POINTER(i32 * 3), C.POINTER(i32 * 3),
                                   i32, p_void, i32, i32, p_void]),
     "kvq_mean_std_pool": (i32, [p_void, i32, i32, i32, i32, p_void, i64, i32, i32, p_void]),
+    "kvq_fragment_gather_batch": (i32, [C.POINTER(KvqFragmentSource), i32, i32, p_void, p_void]),
     "kvq_fragment_gather": (i32, [p_void, i32, i32, i32, i32, i32, p_void, p_void, i32, i32, i32, i32, i32,
                                   C.POINTER(f32), C.POINTER(f32), p_void, p_void]),
 }

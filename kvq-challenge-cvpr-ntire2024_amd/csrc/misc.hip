@@ -277,6 +277,14 @@ struct FragParams {
   float mean[4], std[4];
   int normalise;
   float* out;
+  long chan_stride;          // elements between the channel planes of a clip (T * H * W when contiguous)
+};
+
+// a batch of clips in one launch (blockIdx.z = clip): per-clip frames / draws, outputs out + z * C * T * OH * OW
+struct FragBatch {
+  const void* video[KVQ_FRAG_MAX_CLIPS];
+  const int32_t* hoff[KVQ_FRAG_MAX_CLIPS];
+  const int32_t* woff[KVQ_FRAG_MAX_CLIPS];
 };
 
 // One thread = VW consecutive output pixels of one row of one (channel, frame) plane (VW = 4 when the patch width is a multiple of
@@ -284,8 +292,13 @@ struct FragParams {
 // blockIdx.y, so the per-pixel index arithmetic is two small divisions per thread instead of five 64-bit ones per pixel — the
 // one-pixel-per-thread form of rounds 1-2 spent 30 us per clip on 24 MB of traffic).  (v - mean) / std stays the IEEE fp32 divide:
 // bit-equal to the reference's normalisation (fusion_datasets.py:1017-1020).
-template <int VW>
-__global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p) {
+template <int VW, bool BATCH>
+__global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p, FragBatch fb) {
+  if (BATCH) {
+    const int z = blockIdx.z;                        // wave-uniform: scalar loads of the clip's pointers
+    p.video = fb.video[z]; p.hoff = fb.hoff[z]; p.woff = fb.woff[z];
+    p.out += (size_t)z * p.C * p.T * (p.Fh * p.fsh) * (size_t)(p.Fw * p.fsw);
+  }
   const int OH = p.Fh * p.fsh, OW = p.Fw * p.fsw, QW = OW / VW;
   const int nt = p.T / p.aligned;
   const int q = blockIdx.x * 256 + threadIdx.x;
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(256) void fragment_gather_kernel(FragParams p) {
   const int fi = oy / p.fsh, fj = ox / p.fsw;
   const int o = (fi * p.Fw + fj) * nt + t / p.aligned;
   const int sy = p.hoff[o] + (oy - fi * p.fsh), sx = p.woff[o] + (ox - fj * p.fsw);
-  const size_t src = (((size_t)c * p.T + t) * p.H + sy) * p.W + sx;
+  const size_t src = (size_t)c * p.chan_stride + ((size_t)t * p.H + sy) * p.W + sx;
   float v[VW];
   if (p.src_is_u8) {
     const uint8_t* s8 = reinterpret_cast<const uint8_t*>(p.video) + src;
@@ -471,8 +484,41 @@ extern "C" int kvq_fragment_gather(const void* video, int src_is_u8, int C, int 
   const long plane = (long)Fh * fs_h * Fw * fs_w;
   KVQ_REQUIRE(plane < (1L << 30) && (long)C * T < 65536, KVQ_ERR_SHAPE, "kvq_fragment_gather: output plane / plane count too large");
   const bool vec = fs_w % 4 == 0 && ((size_t)out & 15) == 0;
-  if (vec) hipLaunchKernelGGL(fragment_gather_kernel<4>, dim3((unsigned)((plane / 4 + 255) / 256), (unsigned)(C * T)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(fragment_gather_kernel<1>, dim3((unsigned)((plane + 255) / 256), (unsigned)(C * T)), dim3(256), 0, (hipStream_t)stream, p);
+  p.chan_stride = (long)T * H * W;
+  FragBatch none{};
+  if (vec) hipLaunchKernelGGL((fragment_gather_kernel<4, false>), dim3((unsigned)((plane / 4 + 255) / 256), (unsigned)(C * T)), dim3(256), 0, (hipStream_t)stream, p, none);
+  else hipLaunchKernelGGL((fragment_gather_kernel<1, false>), dim3((unsigned)((plane + 255) / 256), (unsigned)(C * T)), dim3(256), 0, (hipStream_t)stream, p, none);
+  KVQ_CHECK_LAUNCH("fragment_gather_kernel");
+  return KVQ_OK;
+}
+
+extern "C" int kvq_fragment_gather_batch(const KvqFragmentSource* f, int C, int T, float* out, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(f && out, KVQ_ERR_NULL, "kvq_fragment_gather_batch: NULL pointer");
+  KVQ_REQUIRE(f->n_clips > 0 && f->n_clips <= KVQ_FRAG_MAX_CLIPS && C > 0 && C <= 4 && T > 0 && f->Fh > 0 && f->Fw > 0 && f->fs_h > 0 &&
+                  f->fs_w > 0 && f->aligned > 0, KVQ_ERR_SHAPE, "kvq_fragment_gather_batch: bad shape");
+  KVQ_REQUIRE(T % f->aligned == 0, KVQ_ERR_SHAPE, "Please provide match vclip and align index");
+  KVQ_REQUIRE(f->Hs >= f->Fh * f->fs_h && f->Ws >= f->Fw * f->fs_w, KVQ_ERR_UNSUPPORTED,
+              "kvq_fragment_gather_batch: source %dx%d smaller than the %dx%d canvas (upsample fallback not in the hot path)", f->Hs, f->Ws,
+              f->Fh * f->fs_h, f->Fw * f->fs_w);
+  KVQ_REQUIRE(f->chan_stride == 0 || f->chan_stride >= (int64_t)T * f->Hs * f->Ws, KVQ_ERR_SHAPE, "kvq_fragment_gather_batch: channel stride");
+  FragParams p{};
+  FragBatch fb{};
+  for (int b = 0; b < f->n_clips; ++b) {
+    KVQ_REQUIRE(f->video[b] && f->hoff[b] && f->woff[b], KVQ_ERR_NULL, "kvq_fragment_gather_batch: clip %d has a NULL pointer", b);
+    fb.video[b] = f->video[b]; fb.hoff[b] = f->hoff[b]; fb.woff[b] = f->woff[b];
+  }
+  p.src_is_u8 = f->src_is_u8; p.C = C; p.T = T; p.H = f->Hs; p.W = f->Ws;
+  p.Fh = f->Fh; p.Fw = f->Fw; p.fsh = f->fs_h; p.fsw = f->fs_w; p.aligned = f->aligned;
+  p.normalise = f->normalise;
+  for (int c = 0; c < C; ++c) { p.mean[c] = f->normalise ? f->mean[c] : 0.f; p.std[c] = f->normalise ? f->std[c] : 1.f; }
+  p.out = out;
+  p.chan_stride = f->chan_stride ? f->chan_stride : (long)T * f->Hs * f->Ws;
+  const long plane = (long)f->Fh * f->fs_h * f->Fw * f->fs_w;
+  KVQ_REQUIRE(plane < (1L << 30) && (long)C * T < 65536, KVQ_ERR_SHAPE, "kvq_fragment_gather_batch: output plane / plane count too large");
+  const bool vec = f->fs_w % 4 == 0 && ((size_t)out & 15) == 0;
+  if (vec) hipLaunchKernelGGL((fragment_gather_kernel<4, true>), dim3((unsigned)((plane / 4 + 255) / 256), (unsigned)(C * T), (unsigned)f->n_clips), dim3(256), 0, (hipStream_t)stream, p, fb);
+  else hipLaunchKernelGGL((fragment_gather_kernel<1, true>), dim3((unsigned)((plane + 255) / 256), (unsigned)(C * T), (unsigned)f->n_clips), dim3(256), 0, (hipStream_t)stream, p, fb);
   KVQ_CHECK_LAUNCH("fragment_gather_kernel");
   return KVQ_OK;
 }

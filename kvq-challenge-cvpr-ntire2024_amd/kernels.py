@@ -302,10 +302,11 @@ class FragmentSource:
         for t in self.videos + self.hoffs + self.woffs:
             t.record_stream(stream)
 
-    def c_struct(self):
-        """KvqFragmentSource, or None when the batch has more clips than the struct holds / the frames are not uint8."""
+    def c_struct(self, any_dtype=False):
+        """KvqFragmentSource, or None when the batch has more clips than the struct holds / the frames are not uint8 (the fused
+        read; ``any_dtype``: fp32 frames too — the batched gather takes them)."""
         v0 = self.videos[0]
-        if len(self.videos) > _abi.FRAG_MAX_CLIPS or v0.dtype != torch.uint8:
+        if len(self.videos) > _abi.FRAG_MAX_CLIPS or (v0.dtype != torch.uint8 and not any_dtype):
             return None
         if self._c is not None:
             return self._c
@@ -313,7 +314,7 @@ class FragmentSource:
         for i, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
             f.video[i], f.hoff[i], f.woff[i] = ptr(v), ptr(h), ptr(w)
         f.chan_stride = v0.stride(0)
-        f.n_clips, f.src_is_u8, f.Hs, f.Ws = len(self.videos), 1, v0.shape[2], v0.shape[3]
+        f.n_clips, f.src_is_u8, f.Hs, f.Ws = len(self.videos), int(v0.dtype == torch.uint8), v0.shape[2], v0.shape[3]
         f.Fh, f.Fw, f.fs_h, f.fs_w, f.aligned = self.geometry
         f.normalise = int(self.mean is not None)
         if self.mean is not None:
@@ -323,9 +324,16 @@ class FragmentSource:
         return f
 
     def materialise(self, out=None):
-        """the fp32 (B,C,T,H,W) batch: one ``fragment_gather`` per clip"""
+        """the fp32 (B,C,T,H,W) batch: ``kvq_fragment_gather_batch`` — one launch for up to 16 clips (views included), else one
+        ``fragment_gather`` per clip"""
         if out is None:
             out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        assert tuple(out.shape) == tuple(self.shape) and out.dtype == torch.float32 and out.is_contiguous()
+        f = self.c_struct(any_dtype=True)
+        if f is not None:
+            check(lib().kvq_fragment_gather_batch(C.byref(f), self.shape[1], self.shape[2], ptr(out), current_stream()),
+                  "kvq_fragment_gather_batch")
+            return out
         for b, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
             fragment_gather(v.contiguous(), h, w, *self.geometry, mean=self.mean, std=self.std, out=out[b])
         return out

@@ -919,6 +919,23 @@ def test_patch_embed_reads_through_the_sampler_geometries(geom, half):
             assert torch.equal(o_view, o_mat)
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_fragment_gather_batch_equals_per_clip_gather(f32):
+    """FragmentSource.materialise() is ONE launch (kvq_fragment_gather_batch): bit-equal to kvq_fragment_gather clip by clip
+    (which is pinned to get_spatial_fragments), for uint8 and fp32 frames, contiguous clips and frame-run views of a longer video."""
+    src = _fragment_source(21, 3, T=16, Hs=150, Ws=190, grid=4, fs=32, aligned=4)
+    if f32:
+        src = kernels.FragmentSource([v.float() for v in src.videos], src.hoffs, src.woffs, *src.geometry, mean=src.mean, std=src.std)
+    for s_ in (src, src.split_clips(2)):
+        per_clip = torch.stack([kernels.fragment_gather(v.contiguous(), h, w, *s_.geometry, mean=s_.mean, std=s_.std)
+                                for v, h, w in zip(s_.videos, s_.hoffs, s_.woffs)])
+        assert torch.equal(s_.materialise(), per_clip)
+    raw = kernels.FragmentSource(src.videos, src.hoffs, src.woffs, *src.geometry)          # no normalisation: the pixel values
+    assert torch.equal(raw.materialise()[2, 1, 5, :32, :32].cpu(),
+                       src.videos[2][1, 5, int(src.hoffs[2][0, 0, 1]):int(src.hoffs[2][0, 0, 1]) + 32,
+                                     int(src.woffs[2][0, 0, 1]):int(src.woffs[2][0, 0, 1]) + 32].float().cpu())
+
+
 def test_patch_embed_fragment_source_guards():
     """no fused read: mini-patches that do not hold whole 4 x 4 patches, fp32 frames, a source smaller than the canvas"""
     src = _fragment_source(3, 1, T=8, Hs=100, Ws=120, grid=2, fs=32, aligned=8)
