@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 27
+#define KVQ_ABI_VERSION 28
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -137,10 +137,10 @@ int kvq_swin3d_out_dims(const KvqSwinPlan* plan, int32_t out4[4]);
  * (B,3,T,H,W) clip (4 B/pixel written, 4 B/pixel read back) never exists. */
 typedef struct {
   const void* video[KVQ_FRAG_MAX_CLIPS];     /* clip b: uint8 (C, T, Hs, Ws), device; frames contiguous, channel planes
-                                                chan_stride bytes apart (a clip may be a run of frames of a longer video) */
+                                                chan_stride ELEMENTS apart (a clip may be a run of frames of a longer video) */
   const int32_t* hoff[KVQ_FRAG_MAX_CLIPS];   /* clip b: int32 [Fh][Fw][T/aligned] absolute patch origins, device    */
   const int32_t* woff[KVQ_FRAG_MAX_CLIPS];
-  int64_t chan_stride;                       /* 0 = T * Hs * Ws (contiguous clips)                                   */
+  int64_t chan_stride;                       /* in ELEMENTS of the frame type; 0 = T * Hs * Ws (contiguous clips)    */
   int32_t n_clips, src_is_u8, Hs, Ws, Fh, Fw, fs_h, fs_w, aligned;
   int32_t normalise;                         /* 0: raw pixel values                                                  */
   float mean[4], std[4];
@@ -483,6 +483,13 @@ int kvq_fragment_gather_batch(const KvqFragmentSource* src, int C, int T, float*
 int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int T, int H, int W, int rh, int rw, int cy,
                         int cx, int oh, int ow, int round_u8, const float* host_mean, const float* host_std,
                         float* out, void* stream);
+
+/* get_spatial_fragments' fallback for sources smaller than the canvas (fusion_datasets.py:43-50): F.interpolate(video / 255.0,
+ * scale_factor = s, mode = "bilinear") * 255.0 cast back to the frame type (uint8: truncation), with ATen's CPU arithmetic to the
+ * bit.  video u8|fp32 (C,T,H,W) -> out of the same type (C,T,floor(H*s),floor(W*s)) — kvq_upsample_frames_out_dims gives the size. */
+int kvq_upsample_frames_out_dims(int H, int W, double scale_factor, int32_t out2[2]);
+int kvq_upsample_frames(const void* video, int src_is_u8, int C, int T, int H, int W, double scale_factor, void* out,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution front-ends (2D ResNet-50 of SimpleVQA, simpleVQA_model.py:220-264; SlowFast-R50 3D convs,

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 def dtype_code(dt) -> int:
@@ -216,6 +216,8 @@ SYMBOLS = {
                                   p_void]),
     "kvq_resize_bilinear": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32),
                                   C.POINTER(f32), p_void, p_void]),
+    "kvq_upsample_frames_out_dims": (i32, [i32, i32, C.c_double, C.POINTER(i32 * 2)]),
+    "kvq_upsample_frames": (i32, [p_void, i32, i32, i32, i32, i32, C.c_double, p_void, p_void]),
     "kvq_im2col_nd": (i32, [p_void, i32, i32, C.POINTER(i64 * 5), C.POINTER(i32 * 5), C.POINTER(i32 * 3),
                             C.POINTER(i32 * 3), C.POINTER(i32 * 3), i32, p_void, p_void]),
     "kvq_pack_channels_last8": (i32, [p_void, C.POINTER(i32 * 5), C.POINTER(i64 * 5), i32, p_void, p_void]),

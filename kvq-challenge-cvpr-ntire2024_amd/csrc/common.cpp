@@ -3,6 +3,10 @@
 
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace kvq {
 static thread_local char g_err[512] = "";
 
@@ -17,13 +21,19 @@ int hip_fail(hipError_t e, const char* what) {
   set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
   return KVQ_ERR_HIP;
 }
+// Keyed by (kernel address, device ordinal), not by the call site: a generic lambda `go(auto k)` over kernels that all decay to the same
+// pointer type is instantiated ONCE, so a `static LdsOptIn` inside it is shared by every kernel passed through it (embed.hip, conv.hip,
+// slowneck.hip) — the first kernel's opt-in must not stand for the others.
 int LdsOptIn::ensure(const void* kernel, int want) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> granted;
   int dev = 0;
   KVQ_CHECK_HIP(hipGetDevice(&dev));
-  const bool known = dev >= 0 && dev < 16;
-  if (known && bytes[dev] >= want) return KVQ_OK;
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = granted[std::make_pair(kernel, dev)];
+  if (have >= want) return KVQ_OK;
   KVQ_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want));
-  if (known) bytes[dev] = want;
+  have = want;
   return KVQ_OK;
 }
 }  // namespace kvq

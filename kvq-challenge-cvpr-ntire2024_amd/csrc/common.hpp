@@ -169,10 +169,11 @@ int gemm_variant(int M, int N, int K);
 // true: kvq_gemm_bf16 takes the 256 x 256 x 64 eight-phase kernel for this shape (gemm256.hip); profile records carry tile code 4464
 bool gemm8p_wanted(int M, int N, int K);
 
-// The opt-in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel:
-// one `LdsOptIn` per kernel instantiation remembers, per device ordinal, the largest request made so far.
+// The opt-in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE property of a KERNEL:
+// the largest request granted so far is remembered per (kernel address, device ordinal) in one table (common.cpp) — the object itself
+// carries no state, so it does not matter how many kernels share one call site (a generic lambda over kernels of one pointer type
+// is a single instantiation).
 struct LdsOptIn {
-  int bytes[16] = {};
   int ensure(const void* kernel, int want);      // KVQ_OK, or the HIP failure
 };
 

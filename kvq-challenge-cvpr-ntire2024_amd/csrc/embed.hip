@@ -266,7 +266,7 @@ static int launch_embed(const EmbedParams& p, hipStream_t st) {
   const long total = (long)p.B * p.D0 * p.H0 * p.W0;
   dim3 grid((unsigned)((total + 127) / 128)), block(256);
   auto go = [&](auto k) -> int {
-    static LdsOptIn opt;                      // one per instantiation of the lambda, i.e. per kernel
+    LdsOptIn opt;                             // the opt-in is remembered per (kernel, device) in common.cpp
     if (int rc = opt.ensure(reinterpret_cast<const void*>(k), lds)) return rc;
     hipLaunchKernelGGL(k, grid, block, lds, st, p);
     return KVQ_OK;

@@ -8,7 +8,7 @@
 //     W (gamma * (x - mean) * rstd + beta)  =  rstd * (W diag(gamma)) (x - mean)  +  W beta
 // W' = W diag(gamma) (16-bit), its row sums and W beta (fp32) are built once by kvq_patch_merge_pack.  The launch is bound by the
 // per-lane row accesses (a wave-load of 64 different rows costs the texture addresser 64 cycles, not 16), so the rows are read
-// ONCE: the B operand is d = x - K in 16 bits with K = the token's first value (a shift inside the row's own range, shared by the
+// ONCE: the B operand is d = x - K in 16 bits with K = the mean of the token's first 96 channels (a shift inside the row's own range that one outlier channel cannot drag away, shared by the
 // lane pair of a token), read straight from the residual stream — k-step s is 16 channels of neighbour s / 6, lane half h takes 8
 // of them, two 16-byte loads — and sum(d), sum(d^2) accumulate on the way (shifted one-pass variance: with K inside the data the
 // subtraction sum(d^2)/n - mean_d^2 loses a few bits at most).  mean - K leaves the GEMM through the row sums:
@@ -132,7 +132,16 @@ __global__ __launch_bounds__(64 * MGc<C_>::WAVES, 1) void patch_merge_kernel(Mer
   for (int s = 0; s < PF; ++s) piece(s, ring[s]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first two weight chunks, and the first row pieces behind them
   __syncthreads();
-  const float shift = __shfl(ring[0][0][0], j);            // K: channel 0 of neighbour 0, from the h = 0 lane of the token
+  // K: the mean of the token's first PF k-steps (PF x 8 values in each lane of the pair = 96 channels of neighbour 0).  A single
+  // value (channel 0, rounds 4's choice) is not robust: one massive-activation channel there puts every one of the 4C operands near
+  // |K|, where the 16-bit ulp is the operand's whole signal; a mean over 96 channels moves by outlier / 96.
+  float shift = 0.f;
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) shift += ring[s][0][e] + ring[s][1][e];
+  shift += __shfl_xor(shift, 32);
+  shift *= 1.0f / (float)(PF * 16);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (NCH > 2 && s > 0 && s % KC == 0) {

@@ -398,6 +398,88 @@ extern "C" int kvq_resize_bilinear(const void* video, int src_is_u8, int C, int 
   return KVQ_OK;
 }
 
+namespace kvq {
+
+// ------------------------------------------------------------------------------------------------
+// get_spatial_fragments' fallback for sources smaller than the canvas (fusion_datasets.py:43-50):
+//   video = F.interpolate(video / 255.0, scale_factor = 1 / ratio, mode = "bilinear");  video = (video * 255.0).type_as(ovideo)
+// i.e. ATen's upsample_bilinear2d (align_corners = False) on the (C, T, H, W) tensor with the SCALE FACTOR handed to the op (the
+// source coordinate uses float(1 / scale_factor), not in / out), then a truncating cast back to the frame type.  The arithmetic
+// follows ATen's CPU kernel of the image's torch build to the bit, contractions included (found by enumeration against
+// F.interpolate, tests/test_gpu_harness.py): src = fma(scale, dst + 0.5, -0.5) clamped at 0, lambda0 = 1 - lambda1,
+// row = fma(v0, lx0, v1 * lx1), out = fma(row0, ly0, row1 * ly1).  A flat region must come back as itself or one grey level
+// lower exactly where the reference's does — (100 / 255) * 255 truncates to 99 or 100 depending on these roundings.
+// ------------------------------------------------------------------------------------------------
+struct UpsampleParams {
+  const void* video;
+  void* out;
+  int src_is_u8, C, T, H, W, OH, OW;
+  float scale;               // float(1.0 / scale_factor)
+};
+
+__global__ __launch_bounds__(256) void upsample_frames_kernel(UpsampleParams p) {
+  const long total = (long)p.C * p.T * p.OH * p.OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int ox = (int)(r % p.OW); r /= p.OW;
+    const int oy = (int)(r % p.OH);
+    const long ct = r / p.OH;
+    const float fy = fmaxf(__fmaf_rn(p.scale, (float)oy + 0.5f, -0.5f), 0.f);
+    const float fx = fmaxf(__fmaf_rn(p.scale, (float)ox + 0.5f, -0.5f), 0.f);
+    const int y0 = min((int)floorf(fy), p.H - 1), x0 = min((int)floorf(fx), p.W - 1);
+    const int y1 = y0 + (y0 < p.H - 1 ? 1 : 0), x1 = x0 + (x0 < p.W - 1 ? 1 : 0);
+    const float ly1 = fminf(fmaxf(__fsub_rn(fy, (float)y0), 0.f), 1.f), lx1 = fminf(fmaxf(__fsub_rn(fx, (float)x0), 0.f), 1.f);
+    const float ly0 = __fsub_rn(1.f, ly1), lx0 = __fsub_rn(1.f, lx1);
+    const size_t base = (size_t)ct * (size_t)p.H * p.W;
+    float v00, v01, v10, v11;
+    if (p.src_is_u8) {
+      const uint8_t* s = reinterpret_cast<const uint8_t*>(p.video) + base;
+      v00 = s[(size_t)y0 * p.W + x0]; v01 = s[(size_t)y0 * p.W + x1];
+      v10 = s[(size_t)y1 * p.W + x0]; v11 = s[(size_t)y1 * p.W + x1];
+    } else {
+      const float* s = reinterpret_cast<const float*>(p.video) + base;
+      v00 = s[(size_t)y0 * p.W + x0]; v01 = s[(size_t)y0 * p.W + x1];
+      v10 = s[(size_t)y1 * p.W + x0]; v11 = s[(size_t)y1 * p.W + x1];
+    }
+    v00 = __fdiv_rn(v00, 255.0f); v01 = __fdiv_rn(v01, 255.0f); v10 = __fdiv_rn(v10, 255.0f); v11 = __fdiv_rn(v11, 255.0f);
+    const float r0 = __fmaf_rn(v00, lx0, __fmul_rn(v01, lx1));
+    const float r1 = __fmaf_rn(v10, lx0, __fmul_rn(v11, lx1));
+    const float v = __fmul_rn(__fmaf_rn(r0, ly0, __fmul_rn(r1, ly1)), 255.0f);
+    if (p.src_is_u8) reinterpret_cast<uint8_t*>(p.out)[i] = (uint8_t)(int)v;          // .type_as(uint8): truncation
+    else reinterpret_cast<float*>(p.out)[i] = v;
+  }
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_upsample_frames_out_dims(int H, int W, double scale_factor, int32_t out2[2]) {
+  using namespace kvq;
+  KVQ_REQUIRE(out2, KVQ_ERR_NULL, "kvq_upsample_frames_out_dims: NULL");
+  KVQ_REQUIRE(H > 0 && W > 0 && scale_factor > 0.0, KVQ_ERR_SHAPE, "kvq_upsample_frames_out_dims: bad shape / scale");
+  // torch.nn.functional.interpolate: math.floor(float(size * scale_factor)) in double
+  out2[0] = (int32_t)floor((double)H * scale_factor);
+  out2[1] = (int32_t)floor((double)W * scale_factor);
+  return KVQ_OK;
+}
+
+extern "C" int kvq_upsample_frames(const void* video, int src_is_u8, int C, int T, int H, int W, double scale_factor, void* out,
+                                   void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(video && out, KVQ_ERR_NULL, "kvq_upsample_frames: NULL pointer");
+  KVQ_REQUIRE(C > 0 && T > 0 && H > 0 && W > 0 && scale_factor > 0.0, KVQ_ERR_SHAPE, "kvq_upsample_frames: bad shape / scale");
+  int32_t od[2];
+  if (int rc = kvq_upsample_frames_out_dims(H, W, scale_factor, od)) return rc;
+  KVQ_REQUIRE(od[0] > 0 && od[1] > 0, KVQ_ERR_SHAPE, "kvq_upsample_frames: empty output");
+  UpsampleParams p{};
+  p.video = video; p.out = out; p.src_is_u8 = src_is_u8; p.C = C; p.T = T; p.H = H; p.W = W; p.OH = od[0]; p.OW = od[1];
+  p.scale = (float)(1.0 / scale_factor);
+  const long total = (long)C * T * p.OH * p.OW;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(upsample_frames_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  KVQ_CHECK_LAUNCH("upsample_frames_kernel");
+  return KVQ_OK;
+}
+
 extern "C" int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd, int ph, int pw,
                                 int dtype, uint16_t* out, void* stream) {
   using namespace kvq;

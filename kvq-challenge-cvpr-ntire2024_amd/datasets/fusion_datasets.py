@@ -49,8 +49,17 @@ def get_spatial_fragments(video, fragments_h=7, fragments_w=7, fsize_h=32, fsize
     if video.shape[1] == 1:
         aligned = 1
     T, H, W = video.shape[-3:]
-    if min(H / (fragments_h * fsize_h), W / (fragments_w * fsize_w)) < 1:
-        raise NotImplementedError("bilinear upsample fallback for sources smaller than the canvas (:43-50)")
+    ratio = min(H / (fragments_h * fsize_h), W / (fragments_w * fsize_w))
+    if ratio < 1:
+        if fallback_type != "upsample":
+            raise NotImplementedError(f"fallback_type {fallback_type!r}: the reference only knows 'upsample' (:43)")
+        if H < fsize_h or W < fsize_w:
+            raise ValueError(f"a {H}x{W} source is smaller than one {fsize_h}x{fsize_w} mini-patch (the reference indexes it "
+                             "with negative offsets, :63-68)")
+        # The reference upsamples the frames (F.interpolate(video / 255, scale_factor = 1 / ratio, bilinear) * 255, cast back,
+        # :43-50) but keeps res_h / res_w of the ORIGINAL frames (:41) for the grid and the draws below: the patches are cut from
+        # the upsampled frames at the small source's offsets.  Reproduced as it is; kvq_upsample_frames is ATen-CPU-exact.
+        video = kernels.upsample_frames(video.contiguous(), 1 / ratio)
     assert T % aligned == 0, "Please provide match vclip and align index"
     nt = T // aligned
     hl, wl = H // fragments_h, W // fragments_w

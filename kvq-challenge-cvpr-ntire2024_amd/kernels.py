@@ -693,6 +693,20 @@ def resize_bilinear(video: torch.Tensor, rh: int, rw: int, crop=None, mean=None,
     return out
 
 
+def upsample_frames(video: torch.Tensor, scale_factor: float):
+    """get_spatial_fragments' small-source fallback (fusion_datasets.py:43-50): F.interpolate(video / 255.0, scale_factor,
+    mode="bilinear") * 255.0 cast back to the frame type, ATen-CPU-exact.  video u8|fp32 (C,T,H,W) -> same type, upsampled."""
+    _need_gpu(video)
+    assert video.dtype in (torch.uint8, torch.float32) and video.is_contiguous()
+    Cc, T, H, W = video.shape
+    od = (C.c_int32 * 2)()
+    check(lib().kvq_upsample_frames_out_dims(H, W, float(scale_factor), od), "kvq_upsample_frames_out_dims")
+    out = torch.empty(Cc, T, od[0], od[1], dtype=video.dtype, device=video.device)
+    check(lib().kvq_upsample_frames(ptr(video), int(video.dtype == torch.uint8), Cc, T, H, W, float(scale_factor), ptr(out),
+                                    stream_of(video)), "kvq_upsample_frames")
+    return out
+
+
 def block_tail_pack(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b):
     """Weight image of the fused proj+norm2+Mlp launch (include/kvq_hip.h: kvq_block_tail_pack)."""
     _need_gpu(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b)

@@ -415,8 +415,11 @@ class SwinTransformer3D(nn.Module):
             # the batch is still (frames, sampler draws): the embedding launch reads through the sampler when it can
             B, _, T, H, W = x.shape
             frag = x.c_struct() if self.fused_tail and FUSE_SAMPLER else None
-            if frag is not None and not lib().kvq_patch_embed_fragments_supported(
-                    C.byref(frag), B, self.in_chans, self.patch_size[0], T, H, W):
+            # both gates: the source fits the fused read AND the plan takes the fused embedding launch at all (embed_dim 96 / 128,
+            # patch (2,4,4)); otherwise swin_run would reach the im2col branch and refuse the fragment source
+            if frag is not None and not (lib().kvq_patch_embed_fragments_supported(
+                    C.byref(frag), B, self.in_chans, self.patch_size[0], T, H, W)
+                    and lib().kvq_patch_embed_supported(self.in_chans, *self.patch_size, self.embed_dim, T, H, W)):
                 frag = None
             if frag is None:
                 x = x.materialise()

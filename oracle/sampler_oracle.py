@@ -43,16 +43,54 @@ def draw_fragment_offsets(T: int, H: int, W: int, fragments_h=7, fragments_w=7, 
     return rh.numpy().astype(np.int32), rw.numpy().astype(np.int32)
 
 
+def _fma32(a, b, c):
+    """fp32 fused multiply-add of fp32 arrays (exact product + sum in float64, one rounding: |a b| < 2^48 ulp-wise)."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def upsample_fallback(video: np.ndarray, scale_factor: float) -> np.ndarray:
+    """``F.interpolate(video / 255.0, scale_factor=s, mode="bilinear")`` then ``(v * 255.0).type_as(video)``
+    (fusion_datasets.py:43-50) for a (C,T,H,W) uint8 or float32 array.  ATen's upsample_bilinear2d, align_corners=False, with
+    the scale factor handed to the op: output size floor(size * s), source coordinate float(1 / s) * (dst + 0.5) - 0.5 clamped
+    at 0, weights (1 - l, l).  The roundings are those of ATen's CPU kernel as built in this image (fused multiply-adds where
+    its compiler contracts them) — pinned bit-exactly by tests/golden/make_golden.py; the cast back to uint8 truncates."""
+    import math
+    C, T, H, W = video.shape
+    OH, OW = math.floor(float(H * scale_factor)), math.floor(float(W * scale_factor))
+    scale = np.float32(1.0 / scale_factor)
+    x = (video.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+    def axis(n_out, n_in):
+        i = np.arange(n_out, dtype=np.float32)
+        real = np.maximum(_fma32(scale, i + np.float32(0.5), np.float32(-0.5)), np.float32(0))
+        i0 = np.minimum(np.floor(real).astype(np.int64), n_in - 1)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = np.clip((real - i0.astype(np.float32)).astype(np.float32), 0, 1).astype(np.float32)
+        return i0, i1, (np.float32(1) - l1).astype(np.float32), l1
+
+    y0, y1, ly0, ly1 = axis(OH, H)
+    x0, x1, lx0, lx1 = axis(OW, W)
+    lx0, lx1 = lx0[None, None, None, :], lx1[None, None, None, :]
+    ly0, ly1 = ly0[None, None, :, None], ly1[None, None, :, None]
+    top, bot = x[:, :, y0], x[:, :, y1]
+    r0 = _fma32(top[..., x0], lx0, (top[..., x1] * lx1).astype(np.float32))
+    r1 = _fma32(bot[..., x0], lx0, (bot[..., x1] * lx1).astype(np.float32))
+    out = (_fma32(r0, ly0, (r1 * ly1).astype(np.float32)) * np.float32(255.0)).astype(np.float32)
+    return out.astype(np.uint8) if video.dtype == np.uint8 else out
+
+
 def spatial_fragments(video: np.ndarray, rnd_h: np.ndarray, rnd_w: np.ndarray, fragments_h=7,
                       fragments_w=7, fsize_h=32, fsize_w=32, aligned=32) -> np.ndarray:
     """video (C,T,H,W) -> (C,T,Fh*fs,Fw*fs); patch (i,j) of t-block t is copied from
-    origin (hgrid[i]+rnd_h[i,j,t], wgrid[j]+rnd_w[i,j,t]).  The bilinear-upsample fallback
-    for inputs smaller than the canvas (:43-50) is not restated (inputs must be >= canvas)."""
+    origin (hgrid[i]+rnd_h[i,j,t], wgrid[j]+rnd_w[i,j,t]).  Sources smaller than the canvas take the
+    bilinear-upsample fallback (:43-50, ``upsample_fallback``) first — and, as the reference (:41 before :43),
+    keep the ORIGINAL frame size for the grid: the patches are cut from the upsampled frames at the small source's offsets."""
     C, T, H, W = video.shape
     if T == 1:
         aligned = 1
-    if min(H / (fragments_h * fsize_h), W / (fragments_w * fsize_w)) < 1:
-        raise NotImplementedError("upsample fallback (fusion_datasets.py:43-50) is out of the hot path")
+    ratio = min(H / (fragments_h * fsize_h), W / (fragments_w * fsize_w))
+    if ratio < 1:
+        video = upsample_fallback(video, 1 / ratio)
     assert T % aligned == 0, "Please provide match vclip and align index"
     hg, wg = fragment_grid(H, fragments_h, fsize_h), fragment_grid(W, fragments_w, fsize_w)
     out = np.zeros((C, T, fragments_h * fsize_h, fragments_w * fsize_w), video.dtype)

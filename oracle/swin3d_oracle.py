@@ -212,8 +212,7 @@ def attention_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], w
 
 
 def image_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], window, layout) -> torch.Tensor:
-    """The additive term as the HIP kernels' pre-built bias image stores it (csrc/attn.hip bias_dense_build_kernel, csrc/attn32.hip
-    bias_stream_build_kernel): per query row the table bias minus its maximum over the un-masked keys, masked entries REPLACED by
+    """The additive term as the HIP kernels' pre-built bias image stores it (csrc/attn32.hip bias32_build_kernel): per query row the table bias minus its maximum over the un-masked keys, masked entries REPLACED by
     -100 (minus the same shift), everything rounded to fp16.  Softmax is invariant to the per-row shift, so what this emulates is the
     image's 2^-11 relative rounding of (bias - row maximum) — test infrastructure for the kernels' tolerance, not a reference path."""
     N, nW, nH = layout["N"], layout["nW"], rpb_table.shape[1]

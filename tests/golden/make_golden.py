@@ -213,6 +213,26 @@ def sec_sampler(ref):
                     / torch.FloatTensor(synth.KVQ_STD)).permute(3, 0, 1, 2).numpy()   # fusion_datasets.py:1017-1020
         assert np.array_equal(SO.normalize(out, synth.KVQ_MEAN, synth.KVQ_STD), norm_ref)
         put(d, f"frag/{tag}/norm", samples(norm_ref, 1024))
+    # (a') sources smaller than the canvas: the bilinear-upsample fallback (fusion_datasets.py:43-50), uint8 and fp32 frames,
+    # incl. flat regions (where (v / 255) * 255 truncates to v or v - 1 depending on the kernel's roundings)
+    for tag, (T, H, W, Fh, Fw, fs, al, seed, u8) in {
+        "up_u8": (8, 200, 300, 7, 7, 32, 4, 111, 1),
+        "up_f32": (4, 180, 224, 7, 7, 32, 4, 112, 0),
+        "up_k9": (4, 250, 270, 9, 9, 32, 2, 113, 1),
+    }.items():
+        g = np.random.Generator(np.random.PCG64(seed))
+        video = g.integers(0, 256, size=(3, T, H, W)).astype(np.uint8)
+        video[:, :, :40, :48] = 100
+        video[:, :, 50:90] = 37
+        video = video if u8 else video.astype(np.float32)
+        torch.manual_seed(seed)
+        out_ref = fd.get_spatial_fragments(torch.from_numpy(video), Fh, Fw, fs, fs, aligned=al).numpy()
+        torch.manual_seed(seed)
+        rh, rw = SO.draw_fragment_offsets(T, H, W, Fh, Fw, fs, fs, al)
+        out = SO.spatial_fragments(video, rh, rw, Fh, Fw, fs, fs, al)
+        assert out.shape == out_ref.shape and np.array_equal(out.astype(np.float32), out_ref), tag
+        d[f"frag/{tag}/meta"] = np.asarray([T, H, W, Fh, Fw, fs, al, seed, u8])
+        d[f"frag/{tag}/sha"] = np.frombuffer(bytes.fromhex(sha(out_ref.astype(np.float32))), np.uint8)
     # (b) temporal sampler: KSVQE val call (32, 3, 4) x1 clip and SimpleVQA (1, 8, 10, 1)
     for tag, (n, fs_t, ft, iv, nc, seed) in {"ksvqe": (300, 32, 3, 4, 1, 7), "simple": (300, 1, 8, 10, 1, 8),
                                                "short": (90, 32, 3, 4, 1, 9), "clips3": (500, 32, 1, 2, 3, 10)}.items():

@@ -31,6 +31,34 @@ def test_get_spatial_fragments_replays_reference_rng(golden):
         assert np.array_equal(sha, g[f"frag/{tag}/sha"]), tag
 
 
+def test_get_spatial_fragments_upsample_fallback(golden):
+    """Sources smaller than the canvas take the reference's bilinear-upsample fallback (fusion_datasets.py:43-50): the HIP launch
+    (kvq_upsample_frames) reproduces ATen's CPU arithmetic to the bit — golden sha of the REFERENCE's own output, uint8 and fp32
+    frames, flat regions included — and agrees with F.interpolate run here; the lazy form reads through the upsampled frames."""
+    import hashlib
+    from kvq_amd import kernels
+    g = golden("sampler.npz")
+    for tag in ("up_u8", "up_f32", "up_k9"):
+        T, H, W, Fh, Fw, fs, al, seed, u8 = (int(v) for v in g[f"frag/{tag}/meta"])
+        video = np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(3, T, H, W)).astype(np.uint8)
+        video[:, :, :40, :48] = 100
+        video[:, :, 50:90] = 37
+        vt = torch.from_numpy(video if u8 else video.astype(np.float32))
+        ratio = min(H / (Fh * fs), W / (Fw * fs))
+        up = kernels.upsample_frames(vt.cuda(), 1 / ratio).cpu()
+        ref = (torch.nn.functional.interpolate(vt / 255.0, scale_factor=1 / ratio, mode="bilinear") * 255.0).type_as(vt)
+        assert up.shape == ref.shape and torch.equal(up, ref), tag
+        torch.manual_seed(seed)
+        out = get_spatial_fragments(vt.cuda(), Fh, Fw, fs, fs, aligned=al).cpu().numpy()
+        sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(out.astype(np.float32)).tobytes()).digest(), np.uint8)
+        assert np.array_equal(sha, g[f"frag/{tag}/sha"]), tag
+        torch.manual_seed(seed)
+        lazy = get_spatial_fragments(vt.cuda(), Fh, Fw, fs, fs, aligned=al, lazy=True).materialise()[0].cpu().numpy()
+        assert np.array_equal(lazy, out), tag
+    with pytest.raises(ValueError, match="smaller than one"):
+        get_spatial_fragments(torch.zeros(3, 4, 20, 300, device="cuda"), aligned=4)
+
+
 def test_cli_drop_in_scores_match_oracle(tmp_path):
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "kwai_swin_grpb_synthetic_test.yml")))
     a = cfg["data"]["val"]["args"]

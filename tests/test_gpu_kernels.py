@@ -349,6 +349,35 @@ def test_patch_merge_fused_vs_oracle(dims, emit, C, half):
     assert torch.equal(one, out[Ln:2 * Ln])
 
 
+@pytest.mark.parametrize("C", [96, 128])
+def test_patch_merge_fused_outlier_channel(C, half):
+    """A massive-activation channel (x[..., 0] = 50 on otherwise N(0, 1.5) tokens) must not cost the other 4C - 1 operands their
+    precision: the shift K of the one-pass statistics is a 96-channel mean, not the token's first value.  Same bound as
+    the three-launch sequence holds against the fp32 oracle."""
+    B, D, H, W = 2, 4, 8, 8
+    g = rng(77 + C)
+    x = torch.from_numpy((g.standard_normal((B, D, H, W, C)) * 1.5).astype(np.float32))
+    x[..., 0] = 50.0
+    x[0, 0, 0, 0, 0] = -80.0
+    p = {"m.norm.weight": torch.from_numpy((1 + 0.2 * g.standard_normal(4 * C)).astype(np.float32)),
+         "m.norm.bias": torch.from_numpy((0.2 * g.standard_normal(4 * C)).astype(np.float32)),
+         "m.reduction.weight": torch.from_numpy((g.standard_normal((2 * C, 4 * C)) / np.sqrt(4 * C)).astype(np.float32))}
+    ref = O.patch_merge(x, p, "m.").reshape(-1, 2 * C)
+    mp, Hn, Wn = _merge_map(D, H, W)
+    Ln = D * Hn * Wn
+    out, _ = kernels.patch_merge(dev(x.reshape(-1, C)), dev(torch.from_numpy(mp)), B, dev(p["m.reduction.weight"]),
+                                 dev(p["m.norm.weight"]), dev(p["m.norm.bias"]), out_dtype=half)
+    ln = kernels.layernorm_rows(dev(x.reshape(-1, C)), dev(p["m.norm.weight"]), dev(p["m.norm.bias"]), index_map=dev(torch.from_numpy(mp)),
+                                nparts=4, n_batch=B, rows_out=Ln, out_dtype=half)
+    chain = kernels.gemm(ln, dev(p["m.reduction.weight"], half), None, _abi.EPI_STORE_F32)
+    scale = max(1.0, ref.abs().max().item())
+    e_fused = (out.cpu() - ref).abs().max().item()
+    e_chain = (chain.cpu() - ref).abs().max().item()
+    # the outlier itself is rounded at |50| in both forms; everything else must stay at the operand-rounding level
+    assert e_fused <= 4 * EPS[half] * scale, (e_fused, e_chain)
+    assert e_fused <= 3 * e_chain + 1e-4, (e_fused, e_chain)
+
+
 def test_patch_merge_rejects_other_widths():
     with pytest.raises(_abi.KvqError, match="unsupported width"):
         kernels.patch_merge(torch.zeros(16, 256, device=DEV), torch.zeros(4, 4, dtype=torch.int32, device=DEV), 1,

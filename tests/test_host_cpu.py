@@ -37,8 +37,13 @@ def test_fragment_sampler_host_asserts():
     v = torch.zeros(3, 10, 224, 224)
     with pytest.raises(AssertionError, match="Please provide match vclip and align index"):
         get_spatial_fragments(v, aligned=8)
-    with pytest.raises(NotImplementedError):
+    from kvq_amd import _abi
+    with pytest.raises(_abi.KvqError):                 # the upsample fallback (fusion_datasets.py:43-50) is a HIP launch: no CPU path
         get_spatial_fragments(torch.zeros(3, 8, 100, 100), aligned=8)
+    with pytest.raises(NotImplementedError, match="fallback_type"):
+        get_spatial_fragments(torch.zeros(3, 8, 100, 100), aligned=8, fallback_type="pad")
+    with pytest.raises(ValueError, match="smaller than one"):
+        get_spatial_fragments(torch.zeros(3, 8, 20, 100), aligned=8)
 
 
 # ------------------------------------------------------------------ checkpoint formats

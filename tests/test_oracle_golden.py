@@ -98,6 +98,27 @@ def test_fragment_sampler(golden):
         assert np.array_equal(rh, g[f"frag/{tag}/rnd_h"]) and np.array_equal(rw, g[f"frag/{tag}/rnd_w"])
 
 
+def _small_source(meta):
+    T, H, W, Fh, Fw, fs, al, seed, u8 = (int(v) for v in meta)
+    video = np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(3, T, H, W)).astype(np.uint8)
+    video[:, :, :40, :48] = 100
+    video[:, :, 50:90] = 37
+    return (video if u8 else video.astype(np.float32)), (T, H, W, Fh, Fw, fs, al, seed)
+
+
+def test_fragment_sampler_upsample_fallback(golden):
+    """Sources smaller than the canvas (fusion_datasets.py:43-50): the restated ATen bilinear + truncating cast reproduces the
+    reference's fragments bit-exactly (uint8 and fp32 frames, flat regions included)."""
+    g = golden("sampler.npz")
+    for tag in ("up_u8", "up_f32", "up_k9"):
+        video, (T, H, W, Fh, Fw, fs, al, seed) = _small_source(g[f"frag/{tag}/meta"])
+        torch.manual_seed(seed)
+        rh, rw = SO.draw_fragment_offsets(T, H, W, Fh, Fw, fs, fs, al)
+        out = SO.spatial_fragments(video, rh, rw, Fh, Fw, fs, fs, al)
+        assert out.shape == (3, T, Fh * fs, Fw * fs)
+        assert np.array_equal(_sha(out.astype(np.float32)), g[f"frag/{tag}/sha"]), tag
+
+
 def test_fragment_sampler_rejects_misaligned():
     v = np.zeros((3, 10, 224, 224), np.float32)
     with pytest.raises(AssertionError, match="Please provide match vclip and align index"):
