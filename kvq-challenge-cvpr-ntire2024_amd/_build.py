@@ -12,7 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libkvq_hip.so")
+# KVQ_BUILD_TAG=<tag> (diagnostics: same-box A/B runs of a compile-time kernel variant, tools/ab_bench.sh) builds and loads
+# libkvq_hip_<tag>.so from build_<tag>/ with the extra flags recorded in build_<tag>/flags.txt (KVQ_EXTRA_HIPCC_FLAGS when the
+# variant is first built); unset = the product library.
+TAG = os.environ.get("KVQ_BUILD_TAG", "")
+LIB = os.path.join(PKG, f"libkvq_hip_{TAG}.so" if TAG else "libkvq_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "kvq_hip.h")
 SOURCES = ["common.cpp", "gemm.hip", "gemm256.hip", "ln.hip", "attn.hip", "attn32.hip", "misc.hip", "plan.hip", "conv.hip", "tail.hip", "tailmm.hip", "embed.hip", "merge.hip", "vit.hip", "convnet.hip", "bottleneck.hip", "slowneck.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -48,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     import fcntl
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, f"build_{TAG}" if TAG else "build")
     os.makedirs(objdir, exist_ok=True)
     with open(os.path.join(objdir, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -62,6 +66,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(force: bool, verbose: bool, objdir: str) -> str:
     cc = _hipcc()
+    extra_flags = os.environ.get("KVQ_EXTRA_HIPCC_FLAGS", "").split()
+    if TAG:                                     # a variant remembers its flags: a rebuild elsewhere reproduces the same variant
+        fpath = os.path.join(objdir, "flags.txt")
+        if extra_flags or not os.path.exists(fpath):
+            with open(fpath, "w") as f:
+                f.write(" ".join(extra_flags))
+        extra_flags = open(fpath).read().split()
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -70,7 +81,7 @@ def _build_locked(force: bool, verbose: bool, objdir: str) -> str:
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj
         tmp = f"{obj}.{os.getpid()}.tmp"          # never leave a half-written object under the final name
-        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), []) + os.environ.get("KVQ_EXTRA_HIPCC_FLAGS", "").split()
+        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), []) + extra_flags
                + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", tmp])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

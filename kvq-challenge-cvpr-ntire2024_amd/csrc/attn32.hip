@@ -35,6 +35,9 @@
 #ifndef A32_ABL
 #define A32_ABL 0           // diagnostic builds (tools/ubench/attn32_loop.hip), bit mask: 1 no bias stream, 2 no exponentials, 4 no P V MFMAs,
 #endif                      // 8 no growth check, 16 no LDS fragment reads, 32 no v_fma_mix, 64 no row sums, 128 no row-maximum chain
+#ifndef A32_SUM
+#define A32_SUM 0           // row sums: 0 = v_dot2c on the packed probabilities, 1 = v_pk_add_f32 on the fp32 exponentials (round 5: loop bench 399 -> 392 cycles per block, standalone -1..3 %, 4-lane bench line unchanged; the error against the fp32 softmax grows 1.5x: not taken)
+#endif
 #if (A32_ABL & 2)
 #define A32_EXP(x) ((x) * 0.001f + 1.0f)
 #else
@@ -119,6 +122,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
 #pragma unroll
   for (int r = 0; r < 16; ++r) O[r] = 0.f;
   float ls = 0.f, ls1 = 0.f, nm = 0.f;                                        // nm = -(running maximum), log2 units
+  f32x2 lv0 = {0.f, 0.f}, lv1 = {0.f, 0.f};                                   // A32_SUM == 1: the row sum as two packed fp32 chains
 
   braw[T0 % BR][0] = pre[0]; braw[T0 % BR][1] = pre[1];        // block T0: requested while the previous q-block was computed
 #pragma unroll
@@ -179,6 +183,8 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
         for (int r = 0; r < 16; ++r) O[r] *= f;
         ls *= f;
         ls1 *= f;
+        lv0 *= f;
+        lv1 *= f;
       }
       nm -= d;
     }
@@ -187,6 +193,24 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
       const f32x16 cn = mix(t + 1, nm);
       S[nxt] = E::mfma32(kn0, qf0, cn);
     }
+#if A32_SUM == 1
+    // row sums on the fp32 exponentials, two per v_pk_add_f32, two chains (the v_dot2c form on the packed pairs cost 53 of the body's
+    // 400 cycles per block in the loop bench).  The normaliser is then the sum of the UN-rounded probabilities: against the sum of the
+    // rounded ones it differs by the mean of N independent 16-bit roundings, 2^-12 / sqrt(N) relative for fp16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 e = {A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1])};
+      P[cur][i] = E::pack2_raw(e[0], e[1]);
+      if (!(A32_ABL & 64) || i == 0) { if (i & 1) lv1 += e; else lv0 += e; }
+    }
+    if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
+#pragma unroll
+    for (int i = 4; i < 8; ++i) {
+      const f32x2 e = {A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1])};
+      P[cur][i] = E::pack2_raw(e[0], e[1]);
+      if (!(A32_ABL & 64)) { if (i & 1) lv1 += e; else lv0 += e; }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) P[cur][i] = E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1]));
     if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
@@ -197,6 +221,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
       ls = E::dot2(P[cur][i], one2, ls);
       ls1 = E::dot2(P[cur][i + 1], one2, ls1);
     }
+#endif
     if (t + 1 < T1) {
       __builtin_amdgcn_sched_group_barrier(0x002, 16, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
@@ -209,6 +234,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
   // interleaved with the partner lane's.  Two v_permlane32_swap per dword pair hand lane q features 0..15 and lane q + 32 features
   // 16..31: two 16-byte stores of 32 contiguous bytes per lane instead of four 8-byte ones (the store tail is issue-bound) ----
   ls += ls1;
+  if (A32_SUM == 1) ls = (lv0[0] + lv0[1]) + (lv1[0] + lv1[1]);
   ls = a32_pair_sum(ls);
   const float inv = __builtin_amdgcn_rcpf(ls);          // >= 2^-THR-ish and finite: the row maximum contributes >= 2^-THR
   uint32_t pk[4][2];

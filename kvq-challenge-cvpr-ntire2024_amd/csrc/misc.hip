@@ -551,9 +551,9 @@ extern "C" int kvq_fragment_gather(const void* video, int src_is_u8, int C, int 
               "kvq_fragment_gather: bad shape");
   // reference: assert dur_t % aligned == 0, "Please provide match vclip and align index" (fusion_datasets.py:60)
   KVQ_REQUIRE(T % aligned == 0, KVQ_ERR_SHAPE, "Please provide match vclip and align index");
-  KVQ_REQUIRE(H >= Fh * fs_h && W >= Fw * fs_w, KVQ_ERR_UNSUPPORTED,
-              "kvq_fragment_gather: source %dx%d smaller than the %dx%d canvas (upsample fallback not in the hot path)",
-              H, W, Fh * fs_h, Fw * fs_w);
+  // a source smaller than the canvas is legal (the caller ran the upsample fallback, fusion_datasets.py:43-50, whose output may
+  // stay one pixel short of the canvas: floor(H * scale)); what must hold is that a mini-patch fits
+  KVQ_REQUIRE(H >= fs_h && W >= fs_w, KVQ_ERR_UNSUPPORTED, "kvq_fragment_gather: source %dx%d smaller than one %dx%d mini-patch", H, W, fs_h, fs_w);
   FragParams p{};
   p.video = video; p.src_is_u8 = src_is_u8; p.C = C; p.T = T; p.H = H; p.W = W;
   p.hoff = hoff; p.woff = woff; p.Fh = Fh; p.Fw = Fw; p.fsh = fs_h; p.fsw = fs_w; p.aligned = aligned;
@@ -580,9 +580,8 @@ extern "C" int kvq_fragment_gather_batch(const KvqFragmentSource* f, int C, int 
   KVQ_REQUIRE(f->n_clips > 0 && f->n_clips <= KVQ_FRAG_MAX_CLIPS && C > 0 && C <= 4 && T > 0 && f->Fh > 0 && f->Fw > 0 && f->fs_h > 0 &&
                   f->fs_w > 0 && f->aligned > 0, KVQ_ERR_SHAPE, "kvq_fragment_gather_batch: bad shape");
   KVQ_REQUIRE(T % f->aligned == 0, KVQ_ERR_SHAPE, "Please provide match vclip and align index");
-  KVQ_REQUIRE(f->Hs >= f->Fh * f->fs_h && f->Ws >= f->Fw * f->fs_w, KVQ_ERR_UNSUPPORTED,
-              "kvq_fragment_gather_batch: source %dx%d smaller than the %dx%d canvas (upsample fallback not in the hot path)", f->Hs, f->Ws,
-              f->Fh * f->fs_h, f->Fw * f->fs_w);
+  KVQ_REQUIRE(f->Hs >= f->fs_h && f->Ws >= f->fs_w, KVQ_ERR_UNSUPPORTED,
+              "kvq_fragment_gather_batch: source %dx%d smaller than one %dx%d mini-patch", f->Hs, f->Ws, f->fs_h, f->fs_w);
   KVQ_REQUIRE(f->chan_stride == 0 || f->chan_stride >= (int64_t)T * f->Hs * f->Ws, KVQ_ERR_SHAPE, "kvq_fragment_gather_batch: channel stride");
   FragParams p{};
   FragBatch fb{};

@@ -35,34 +35,48 @@ namespace kvq {
 typedef __attribute__((address_space(3))) void* mm_lds_t;
 typedef __attribute__((address_space(1))) const void* mm_gbl_t;
 
-constexpr int MM_TOK = 64, MM_HC = 256, MM_KS_H = MM_HC / 16;   // tokens per workgroup, hidden chunk (16 k-steps)
+constexpr int MM_TOK = 64;          // tokens per workgroup
 // Geometry by CF = C / 128 = 32-feature tiles per wave: 3 (C = 384: stage 2 of Swin-T / -S) or 4 (C = 512: stage 2 of Swin-B,
-// register ring only — its 64 KB activation tile leaves no room for an LDS weight ring)
-template <int CF>
+// register ring only — its 64 KB activation tile leaves no room for an LDS weight ring), and by HC = hidden units per MLP chunk:
+//   HC = 256: a wave's fc1 slice is 64 units (two tiles): 512 VGPRs, 94 KB of LDS, ONE workgroup per CU (rounds 2-4);
+//   HC = 128: 32 units (one tile) and a 12-fragment ring: <= 256 VGPRs, 77 KB of LDS at C = 384 — TWO workgroups per CU, i.e. two
+//             independent instruction streams per SIMD: one workgroup's serial phases (row loads, LayerNorm exchanges, GELU, barriers,
+//             the store tail) run under the other's MFMAs (round 5; the per-CU weight stream per token is unchanged).
+template <int CF, int HC_ = 256>
 struct MMc {
   static constexpr int C = 128 * CF, H = 4 * C, W = 32 * CF;            // channels, hidden units, features per wave
-  static constexpr int NCH = H / MM_HC, KS_C = C / 16;                  // hidden chunks, k-steps over C
-  static constexpr int NF_PROJ = KS_C * CF, NF_FC1 = KS_C * 2, NF_FC2 = MM_KS_H * CF;
+  static constexpr int HC = HC_, KS_H = HC / 16, HT = HC / 128;         // hidden chunk, its k-steps, fc1 tiles per wave
+  static constexpr int NCH = H / HC, KS_C = C / 16;                     // hidden chunks, k-steps over C
+  static constexpr int NF_PROJ = KS_C * CF, NF_FC1 = KS_C * HT, NF_FC2 = KS_H * CF;
   static constexpr int NF = NF_PROJ + NCH * (NF_FC1 + NF_FC2);          // fragments per wave: 648 / 1152
   static constexpr int OFF_X = 0;                                       // [KS_C k-steps][2 token tiles][64 lanes][16 B] = 48 / 64 KB
-  static constexpr int OFF_G = OFF_X + KS_C * 2 * 1024;                 // [16][2][64][16 B] = 32 KB
-  static constexpr int OFF_PRM = OFF_G + MM_KS_H * 2 * 1024;            // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
+  static constexpr int OFF_G = OFF_X + KS_C * 2 * 1024;                 // [KS_H][2][64][16 B] = 32 / 16 KB
+  static constexpr int OFF_PRM = OFF_G + KS_H * 2 * 1024;               // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
   static constexpr int PRM_FLOATS = H + 4 * C;
   static constexpr int OFF_RED = OFF_PRM + PRM_FLOATS * 4;              // [4 waves][64 tokens] fp32
   static constexpr int LDS = OFF_RED + 4 * MM_TOK * 4;
+  static constexpr int WG_PER_CU = HC == 128 && 2 * LDS <= 163840 ? 2 : 1;
   // packed image: 4 waves x NF KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
   static constexpr size_t PACK_FRAG_BYTES = (size_t)4 * NF * 1024;
   // register ring: every phase consumes a multiple of VR_R fragments (72 | 48 | 48 of 24; 128 | 64 | 64 of 16 — 32 slots at C = 512
-  // spill: 128 + 64 accumulator registers are there already)
-  static constexpr int VR_R = CF == 3 ? 24 : 16, VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
+  // spill: 128 + 64 accumulator registers are there already; HC = 128: 72 | 24 | 24 of 12)
+  static constexpr int VR_R = HC == 128 ? (CF == 3 ? 12 : 8) : (CF == 3 ? 24 : 16), VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
   static_assert(NF_PROJ % VR_R == 0 && NF_FC1 % VR_R == 0 && NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
   static_assert(LDS <= 163840, "LDS");
 };
 
+// KVQ_TAILMM_HC=256 takes rounds 2-4's one-workgroup-per-CU form at C = 384 (A/B runs); read once — the packed image and the launch
+// must agree.  C = 256 / 512 keep HC = 256 (C = 512: 2 x 97 KB does not fit; C = 256 is not on any benchmarked path).
+static int tailmm_hc(int C) {
+  static const int env = getenv("KVQ_TAILMM_HC") ? atoi(getenv("KVQ_TAILMM_HC")) : 128;
+  return C == 384 && env == 128 ? 128 : 256;
+}
+
 bool tailmm_supported(int C, int hidden) { return (C == 256 || C == 384 || C == 512) && hidden == 4 * C; }
 size_t tailmm_pack_bytes(int C, int hidden) {
   if (!tailmm_supported(C, hidden)) return 0;
-  const size_t frag = C == 384 ? MMc<3>::PACK_FRAG_BYTES : C == 512 ? MMc<4>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
+  const size_t frag = C == 384 ? (tailmm_hc(C) == 128 ? MMc<3, 128>::PACK_FRAG_BYTES : MMc<3>::PACK_FRAG_BYTES)
+                      : C == 512 ? MMc<4>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
   return frag + (((size_t)(hidden + 4 * C) * 4 + 255) & ~(size_t)255);
 }
 
@@ -70,11 +84,12 @@ size_t tailmm_pack_bytes(int C, int hidden) {
 // (token, half) holds, per 32-row tile, rows 8q + 4 half + i; quads (q even, q odd) of one 16-row half are one slot
 __host__ __device__ inline int mm_kperm(int g, int e) { return e < 4 ? 4 * g + e : 8 + 4 * g + (e - 4); }
 
-template <int CF>
+template <int CF, int HC>
 __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w,
                                    const float* n2b, const float* b1, const float* b2, unsigned char* out) {
-  using K = MMc<CF>;
+  using K = MMc<CF, HC>;
   constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_NF = K::NF, MM_NF_PROJ = K::NF_PROJ, MM_NF_FC1 = K::NF_FC1, MM_NF_FC2 = K::NF_FC2;
+  constexpr int MM_HC = K::HC, HT = K::HT;
   constexpr int MM_PACK_PRM_FLOATS = K::PRM_FLOATS;
   constexpr size_t MM_PACK_FRAG_BYTES = K::PACK_FRAG_BYTES;
   const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,10 +105,12 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
         const int ks = f / CF, ft = f % CF;
         v = wp[(size_t)(K::W * w + 32 * ft + i) * MM_C + 16 * ks + 8 * g + e];
       } else {
-        // consumption order behind proj: fc1(0); then fc1(c+1), fc2(c) for c = 0..4; then fc2(5)
+        // consumption order behind proj: fc1(0); then fc1(c+1), fc2(c) for c = 0..4; then fc2(5) — the wave's software pipeline
         const int r = f - MM_NF_PROJ;
         int c, q;
-        if (r < MM_NF_FC1) { c = 0; q = r; }
+        if (K::WG_PER_CU == 2) {                             // not software-pipelined: fc1(c), fc2(c), fc1(c + 1), ...
+          c = r / (MM_NF_FC1 + MM_NF_FC2); q = r % (MM_NF_FC1 + MM_NF_FC2);
+        } else if (r < MM_NF_FC1) { c = 0; q = r; }
         else {
           const int r2 = r - MM_NF_FC1, blk = r2 / (MM_NF_FC1 + MM_NF_FC2), o2 = r2 % (MM_NF_FC1 + MM_NF_FC2);
           if (blk >= MM_NCH - 1) { c = MM_NCH - 1; q = MM_NF_FC1 + (r2 - (MM_NCH - 1) * (MM_NF_FC1 + MM_NF_FC2)); }
@@ -101,8 +118,8 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
           else { c = blk; q = o2; }
         }
         if (q < MM_NF_FC1) {                                 // fc1 rows of chunk c, k = channel in accumulator order
-          const int ks = q / 2, ft = q % 2;
-          v = w1[(size_t)(MM_HC * c + 64 * w + 32 * ft + i) * MM_C + 16 * ks + mm_kperm(g, e)];
+          const int ks = q / HT, ft = q % HT;
+          v = w1[(size_t)(MM_HC * c + 32 * HT * w + 32 * ft + i) * MM_C + 16 * ks + mm_kperm(g, e)];
         } else {                                             // fc2: all C outputs, k = hidden unit of chunk c in accumulator order
           const int q2 = q - MM_NF_FC1, ks = q2 / CF, ft = q2 % CF;
           v = w2[(size_t)(K::W * w + 32 * ft + i) * MM_H + MM_HC * c + 16 * ks + mm_kperm(g, e)];
@@ -122,18 +139,19 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
   }
 }
 
+template <int CF, int HC>
+static void launch_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
+                        const float* b1, const float* b2, unsigned char* out, hipStream_t st) {
+  const long total = (long)4 * MMc<CF, HC>::NF * 64 + MMc<CF, HC>::PRM_FLOATS;
+  hipLaunchKernelGGL((tailmm_pack_kernel<CF, HC>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
+}
+
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st) {
-  if (C == 512) {
-    const long total = (long)4 * MMc<4>::NF * 64 + MMc<4>::PRM_FLOATS;
-    hipLaunchKernelGGL(tailmm_pack_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
-  } else if (C == 256) {
-    const long total = (long)4 * MMc<2>::NF * 64 + MMc<2>::PRM_FLOATS;
-    hipLaunchKernelGGL(tailmm_pack_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
-  } else {
-    const long total = (long)4 * MMc<3>::NF * 64 + MMc<3>::PRM_FLOATS;
-    hipLaunchKernelGGL(tailmm_pack_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wp, w1, w2, proj_b, n2w, n2b, b1, b2, out);
-  }
+  if (C == 512) launch_pack<4, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
+  else if (C == 256) launch_pack<2, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
+  else if (tailmm_hc(C) == 128) launch_pack<3, 128>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
+  else launch_pack<3, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   KVQ_CHECK_LAUNCH("tailmm_pack_kernel");
   return KVQ_OK;
 }
@@ -146,10 +164,11 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
 // load is unsafe under this register pressure (the allocator splits the live range of a value it believes ready; the late data lands
 // in a register handed on).  (Round 2 also carried an LDS-ring form of the stream and ablation builds of it — no weight stream 65 us,
 // no MFMAs 57, neither 43 of 78 — removed in round 3: 79 -> 73 us with the next norm1, 73 -> 64 without, bit-identical.)
-template <typename E, bool EMIT, int CF = 3>
-__global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
-  using K = MMc<CF>;
+template <typename E, bool EMIT, int CF = 3, int HC = 256>
+__global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_kernel(TailParams p) {
+  using K = MMc<CF, HC>;
   constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_KS_C = K::KS_C, MM_NF = K::NF, VR_R = K::VR_R, VR_PF = K::VR_PF, FW = K::W;
+  constexpr int MM_HC = K::HC, MM_KS_H = K::KS_H, HT = K::HT;
   constexpr int MM_OFF_X = K::OFF_X, MM_OFF_G = K::OFF_G, MM_OFF_PRM = K::OFF_PRM, MM_OFF_RED = K::OFF_RED;
   constexpr int MM_PRM_FLOATS = K::PRM_FLOATS;
   constexpr size_t MM_PACK_FRAG_BYTES = K::PACK_FRAG_BYTES;
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   // and NR new weight fragments requested BETWEEN the MFMAs of body s, one at a time: a wave's LDS / VMEM issue hides under its own
   // MFMAs only ~10 cycles at a time (tools/ubench/pipe_share.hip) — a burst of 5 reads in front of 6 MFMAs does not hide at all.
   auto gemm_phase = [&](auto na_tag, auto nk_tag, const unsigned char* bbuf, auto&& mm, auto&& between) __attribute__((always_inline)) {
-    constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : 1, NR = NA * KU;
+    constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : 1, NR = NA * KU;     // (NA = 1: two MFMAs per body)
     constexpr int NM = 2 * NA * KU;                               // MFMAs per body
     static_assert(nk % KU == 0, "k-steps per body");
     V8 b[2][KU][2];                      // activation fragments of two bodies: the one in use and the one being read
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   using KC = std::integral_constant<int, MM_KS_C>;
   using KH = std::integral_constant<int, MM_KS_H>;
   auto nothing = [](int) {};
-  using T2 = std::integral_constant<int, 2>;
+  using T2 = std::integral_constant<int, HT>;          // fc1 tiles per wave
   using T3 = std::integral_constant<int, CF>;          // weight tiles per wave in proj / fc2
 
   // ---- proj: acc (= x + bias) += Wp . attn^T -------------------------------------------------------------------------
@@ -366,14 +385,14 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   // ---- MLP over 6 chunks of 256 hidden units: fc1 (wave: 64 units x 64 tokens) -> GELU -> LDS -> fc2 partial.  Software
   // pipeline: fc1 of chunk c+1 runs first, then the GELU of chunk c+1 is evaluated BETWEEN the MFMAs of fc2(chunk c) — one pair
   // per three MFMAs — so that the VALU stream no longer stops the weight stream ----------
-  f32x16 hacc[2][2];
-  u32x4 gp[2][2][2];                                  // GELU outputs of a chunk, packed: [weight tile][k-step half][token tile]
+  f32x16 hacc[HT][2];
+  u32x4 gp[HT][2][2];                                 // GELU outputs of a chunk, packed: [weight tile][k-step half][token tile]
   auto fc1 = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(prm + MM_HC * c + 64 * wave + 32 * ft + 8 * q + 4 * half);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(prm + MM_HC * c + 32 * HT * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
       }
     gemm_phase(T2{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) { hacc[ft][tt] = E::mfma32(a, b, hacc[ft][tt]); }, nothing);
   };
-  auto gelu_pair = [&](int pi) __attribute__((always_inline)) {      // pi = ((ft * 2 + hp) * 2 + tt) * 4 + i, 0..31
+  auto gelu_pair = [&](int pi) __attribute__((always_inline)) {      // pi = ((ft * 2 + hp) * 2 + tt) * 4 + i, 0..16 HT - 1
     const int i = pi & 3, tt = (pi >> 2) & 1, hp = (pi >> 3) & 1, ft = pi >> 4;
     const int r = 8 * hp + 2 * (i & 1) + 4 * (i >> 1);              // pairs (r, r+1): i = 0,1 -> quad 2hp; i = 2,3 -> quad 2hp+1
     const f32x2 gv = gelu_fast2(f32x2{hacc[ft][tt][r], hacc[ft][tt][r + 1]});
@@ -391,29 +410,44 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   };
   auto write_gelu = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
-          *reinterpret_cast<u32x4*>(lds + MM_OFF_G + ((4 * wave + 2 * ft + hp) * 2 + tt) * 1024 + lane * 16) = gp[ft][hp][tt];
+          *reinterpret_cast<u32x4*>(lds + MM_OFF_G + ((2 * HT * wave + 2 * ft + hp) * 2 + tt) * 1024 + lane * 16) = gp[ft][hp][tt];
   };
-  fc1(0);
+  if constexpr (K::WG_PER_CU == 2) {
+    // two workgroups per CU: the other workgroup's MFMAs run under this one's GELU, so the chunks are NOT software-pipelined in the
+    // wave (fc1(c + 1) ahead of fc2(c) keeps acc + hacc + the packed GELU outputs + the ring + two bodies of fragments live at
+    // once: 64 registers past the 256 of two waves per SIMD, spilled and reloaded in the loop)
+    for (int c = 0; c < MM_NCH; ++c) {
+      fc1(c);
 #pragma unroll
-  for (int pi = 0; pi < 32; ++pi) gelu_pair(pi);
-  write_gelu();
-  MM_BARRIER();                                      // GELU rows of chunk 0 complete
-  for (int c = 0; c < MM_NCH; ++c) {
-    const bool more = c + 1 < MM_NCH;
-    if (more) {
-      fc1(c + 1);
-      gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); },
-                 [&](int m) { if (m % CF == 0) gelu_pair(m / CF); });      // 32 pairs over the 32 CF MFMAs
-      MM_BARRIER();                                  // everybody has finished fc2 of chunk c: its GELU rows may go
+      for (int pi = 0; pi < 16 * HT; ++pi) gelu_pair(pi);
+      if (c > 0) MM_BARRIER();                         // everybody has finished fc2 of chunk c - 1: its GELU rows may go
       write_gelu();
-      MM_BARRIER();                                  // GELU rows of chunk c + 1 complete
-    } else {
+      MM_BARRIER();                                    // GELU rows of chunk c complete
       gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+    }
+  } else {
+    fc1(0);
+  #pragma unroll
+    for (int pi = 0; pi < 16 * HT; ++pi) gelu_pair(pi);
+    write_gelu();
+    MM_BARRIER();                                      // GELU rows of chunk 0 complete
+    for (int c = 0; c < MM_NCH; ++c) {
+      const bool more = c + 1 < MM_NCH;
+      if (more) {
+        fc1(c + 1);
+        gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); },
+                   [&](int m) { if (m % CF == 0) gelu_pair(m / CF); });      // 16 HT pairs over the 16 HT CF MFMAs
+        MM_BARRIER();                                  // everybody has finished fc2 of chunk c: its GELU rows may go
+        write_gelu();
+        MM_BARRIER();                                  // GELU rows of chunk c + 1 complete
+      } else {
+        gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+      }
     }
   }
 
@@ -472,17 +506,17 @@ __global__ __launch_bounds__(256, 1) void block_tailmm_kernel(TailParams p) {
   MM_STAMP(4);
 }
 
-template <typename E, int CF>
+template <typename E, int CF, int HC = 256>
 static int launch_mm_cf(const TailParams& p, hipStream_t st) {
-  constexpr int LDS = MMc<CF>::LDS;
+  constexpr int LDS = MMc<CF, HC>::LDS;
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
   if (p.next_ln) {
-    auto k = block_tailmm_kernel<E, true, CF>;
+    auto k = block_tailmm_kernel<E, true, CF, HC>;
     static LdsOptIn opt;
     if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
   } else {
-    auto k = block_tailmm_kernel<E, false, CF>;
+    auto k = block_tailmm_kernel<E, false, CF, HC>;
     static LdsOptIn opt;
     if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
@@ -495,6 +529,7 @@ int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
   if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
   if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
+  if (tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3, 128>(p, st) : launch_mm_cf<Bf16, 3, 128>(p, st);
   return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3>(p, st) : launch_mm_cf<Bf16, 3>(p, st);
 }
 
