@@ -591,7 +591,8 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
               "kvq_window_attention32: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
   const int units = BW * num_heads, nqb = (N + 31) / 32;
   int qsplit = units >= 768 ? 1 : 768 / units;        // 768 = 256 CUs x 3 resident workgroups
-  qsplit = qsplit > 4 ? 4 : qsplit;
+  static const int qsplit_max = getenv("KVQ_ATTN_QSPLIT_MAX") ? atoi(getenv("KVQ_ATTN_QSPLIT_MAX")) : 4;      // A/B knob (results do not depend on it)
+  qsplit = qsplit > qsplit_max ? qsplit_max : qsplit;
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
                      a->dsplit_from < 0 ? -1 : a->dsplit_from};

@@ -47,6 +47,12 @@ __host__ __device__ constexpr int tail_bpc(int C, int NW) { return (C == 96 ? 12
 __host__ __device__ constexpr int tail_ring(int C, int NW) {                            // ring slots: what LDS allows, <= 4
   return (163840 / tail_bpc(C, NW) - 8192) / tail_slot_bytes(C) >= 4 ? 4 : 3;
 }
+// Row staging (round 5): the x / attention / norm1 rows of a wave travel global <-> LDS as 128-byte row segments (8 rows per wave-load:
+// 8 cache lines per access instead of 32 lane-rows) through a 4 KB tile per wave and are transposed there to the token-per-lane layout.
+// Prologue: the tile lives in the LAST ring slot (empty until the first item is consumed) + TAIL_STAGE_EXTRA bytes behind the ring where
+// a slot is smaller than the four tiles; epilogue: in the slots the ring has left.
+constexpr int TAIL_STG = 4096;
+__host__ __device__ constexpr int tail_stage_extra(int C, int NW) { return NW * TAIL_STG > tail_slot_bytes(C) ? NW * TAIL_STG - tail_slot_bytes(C) : 0; }
 static size_t tail_items(int C, int hidden) { return (size_t)tail_proj_items(C) + 1 + hidden / 32; }
 static size_t tail_param_bytes(int C, int hidden) { return (((size_t)(4 * C + hidden) * 4) + 4095) & ~(size_t)4095; }
 
@@ -117,7 +123,7 @@ __global__ void tail_pack_kernel(const uint16_t* wp, const uint16_t* w1, const u
 // 82 / 76, NW = 6 136 / -, NW = 8 - / 76, NW = 12 124 / -: the L2 -> LDS weight stream (1.7 KB per token at NW = 4) is
 // NOT the bound — the wider barrier domain costs more than the halved stream saves — so workgroups stay at 4 waves,
 // 3 (C = 96, <= 168 VGPRs) or 2 of them per CU.
-template <typename E, int CM, int NW, bool EMIT>
+template <typename E, int CM, int NW, bool EMIT, bool STAGED>
 __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_kernel(TailParams p) {
   fp16_saturate_mode();
   constexpr int C = 32 * CM, KS = 2 * CM, PANEL = 64 * C, SLOT = 2 * PANEL, LPW = SLOT / 1024 / NW;
@@ -126,7 +132,8 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   static_assert(NST == 3 || NST == 4, "wait ladder below");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
-  float* prm = reinterpret_cast<float*>(lds + NST * SLOT);
+  constexpr int XTRA = tail_stage_extra(C, NW), PRM_OFF = NST * SLOT + XTRA;
+  float* prm = reinterpret_cast<float*>(lds + PRM_OFF);
   const float* s_pb = prm;
   const float* s_g2 = prm + C;
   const float* s_b2n = prm + 2 * C;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NJ = p.hidden >> 5, NI = NPI + 1 + NJ;
   const int NQ = ((4 * C + p.hidden) * 4 + 1023) >> 10;              // 1 KB wave-loads that carry the parameters
-  float* s_nn = reinterpret_cast<float*>(lds + NST * SLOT + NQ * 1024);   // [norm1_next_w C][norm1_next_b C] (EMIT)
+  float* s_nn = reinterpret_cast<float*>(lds + PRM_OFF + NQ * 1024);   // [norm1_next_w C][norm1_next_b C] (EMIT)
 #ifdef KVQ_TAIL_TRACE   // diagnostic build only: the stamps cost registers and scheduling freedom
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
 #define KVQ_STAMP(i) if (tr) p.trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter()
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     const unsigned char* src = p.pack + (size_t)NI * SLOT;
     for (int q = wave; q < NQ; q += NW)      // uneven per wave is fine: these are OLDER than every counted item
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + q * 1024 + lane * 16),
-                                       (lds_ptr_t)(lds + NST * SLOT + q * 1024), 16, 0, 0);
+                                       (lds_ptr_t)(lds + PRM_OFF + q * 1024), 16, 0, 0);
   }
   // this lane's token: row = a window row (through `map` to its token) or, with `gather`, a token (through it to its window row)
   const long row = (long)blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
@@ -176,7 +183,13 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   const long orig = (long)tb * p.out_rows + tloc;
   V8 bx[KS];
   f32x16 acc[CM];
-  {
+  // row-major role of this lane in a staged 128-byte-per-row tile: row 8 g + rrow (g = 0..3), 16-byte piece rp; piece p of row r sits
+  // in slot 8 r + (p ^ ((r >> 1) & 7)) — both the row-major and the token-per-lane accesses are bank-conflict-free
+  const int rrow = lane >> 3, rp = lane & 7, tj = lane & 31;
+  auto stg_at = [](unsigned char* base, int row, int piece) __attribute__((always_inline)) -> unsigned char* {
+    return base + ((row * 8 + (piece ^ ((row >> 1) & 7))) << 4);
+  };
+  if (!STAGED) {
     const uint16_t* ar = p.attn + (size_t)rc * C + 8 * h;
 #pragma unroll
     for (int s = 0; s < KS; ++s) bx[s] = *reinterpret_cast<const V8*>(ar + 16 * s);
@@ -208,6 +221,62 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i) issue(i, i);
   if (EMIT && tid < C / 2) *reinterpret_cast<f32x4*>(s_nn + 4 * tid) = nn_reg;
+  if (STAGED) {
+    // the wave's 4 KB tile in the last ring slot (+ the extra bytes behind the ring): free until the first item has been consumed — the
+    // first next_item() below fills that slot only after its barrier, which every wave reaches with its prologue behind it
+    unsigned char* stg = lds + (NST - 1) * SLOT + wave * TAIL_STG;
+    int rowx[4], rowa[4];          // residual-stream row / attention row of the tile rows 8 g + rrow
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      rowx[g] = __shfl((int)orig, 8 * g + rrow);
+      rowa[g] = __shfl((int)rc, 8 * g + rrow);
+    }
+    // ---- attention rows (16-bit): 64 channels = 128 bytes of a row per tile = 4 k-steps; C % 64 == 32: a last half tile ----
+    constexpr int AT = C / 64, AH = (C % 64) / 32;
+    u32x4 va[AT + AH][4];
+#pragma unroll
+    for (int t = 0; t < AT + AH; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        va[t][g] = (u32x4){0u, 0u, 0u, 0u};
+        if (t < AT || rp < 4) va[t][g] = *reinterpret_cast<const u32x4*>(p.attn + (size_t)rowa[g] * C + 64 * t + 8 * rp);
+      }
+    // ---- residual rows (fp32): 32 channels = 128 bytes per tile ----
+    const float* pbg = reinterpret_cast<const float*>(p.pack + (size_t)NI * SLOT) + 4 * h;
+    constexpr int XB = CM > 3 ? 3 : CM;                 // tiles requested at once (12 x 16 B per lane in flight)
+#pragma unroll
+    for (int i0 = 0; i0 < CM; i0 += XB) {
+      f32x4 vx[XB][4];
+#pragma unroll
+      for (int i = i0; i < i0 + XB && i < CM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          vx[i - i0][g] = *reinterpret_cast<const f32x4*>(p.x + (size_t)rowx[g] * C + 32 * i + 4 * rp);
+        }
+      if (i0 == 0) {
+#pragma unroll
+        for (int t = 0; t < AT + AH; ++t) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x4*>(stg_at(stg, 8 * g + rrow, rp)) = va[t][g];
+#pragma unroll
+          for (int k = 0; k < (t < AT ? 4 : 2); ++k)
+            bx[4 * t + k] = __builtin_bit_cast(V8, *reinterpret_cast<const u32x4*>(stg_at(stg, tj, 2 * k + h)));
+        }
+      }
+#pragma unroll
+      for (int i = i0; i < i0 + XB && i < CM; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(stg_at(stg, 8 * g + rrow, rp)) = vx[i - i0][g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(stg_at(stg, tj, 2 * q + h));
+          const f32x4 b = *reinterpret_cast<const f32x4*>(pbg + 32 * i + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = v[e] + b[e];
+        }
+      }
+    }
+  }
   int it = 0, slot = 0;
   // item `it` visible to every wave; everybody has left item it-1, whose slot takes item it+NST-1
 #ifdef KVQ_TAIL_TRACE
@@ -372,7 +441,26 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
       for (int e = 0; e < 4; ++e) acc[i][4 * q + e] += fb[e];
       if (q & 1) __builtin_amdgcn_sched_barrier(0);
     }
-  if (live) {
+  // STAGED: the wave's tile in slots the ring has left — the last item sits in slot (NI - 1) % NST, every other slot is free (the barrier
+  // of the last next_item() lies behind every wave's last read of the item before it); launch_tail checks that four tiles fit
+  const int s_last = (NI - 1) % NST;
+  unsigned char* stg2 = lds + ((NST - 1 - s_last) * SLOT + XTRA >= NW * TAIL_STG ? (s_last + 1) * SLOT : 0) + wave * TAIL_STG;
+  if (STAGED) {
+    int rowx[4];                   // residual-stream row of the tile rows 8 g + rrow, < 0: not stored (re-derived: nothing of the prologue stays live)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rowx[g] = __shfl(live ? (int)orig : -1, 8 * g + rrow);
+#pragma unroll
+    for (int i = 0; i < CM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(stg_at(stg2, tj, 2 * q + h)) = (f32x4){acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stg_at(stg2, 8 * g + rrow, rp));
+        if (rowx[g] >= 0) *reinterpret_cast<f32x4*>(p.x + (size_t)rowx[g] * C + 32 * i + 4 * rp) = t;
+      }
+    }
+  } else if (live) {
     float* xr = p.x + (size_t)orig * C + 4 * h;
 #pragma unroll
     for (int i = 0; i < CM; ++i)
@@ -405,8 +493,13 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     // then owns channels 8 (2 t + h) .. + 7 of a tile — half the row-divergent store instructions (one row per cycle in the addresser)
     const long drow = (long)tb * p.next_rows + p.next_dst[tloc];
     uint16_t* o = p.next_ln + (size_t)drow * C;
+    int rowd[4];
+    if (STAGED) {
 #pragma unroll
-    for (int i = 0; i < CM; ++i)
+      for (int g = 0; g < 4; ++g) rowd[g] = __shfl(live ? (int)drow : -1, 8 * g + rrow);
+    }
+#pragma unroll
+    for (int i = 0; i < CM; ++i) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         uint32_t pk[2][2];
@@ -423,9 +516,19 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
         }
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-        if (live) *reinterpret_cast<u32x4*>(o + 32 * i + 8 * (2 * t + h)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        const u32x4 piece = {s0[0], s1[0], s0[1], s1[1]};
+        if (STAGED) *reinterpret_cast<u32x4*>(stg_at(stg2, tj, 4 * (i & 1) + 2 * t + h)) = piece;      // 128-byte row tile = channel tiles (i, i + 1)
+        else if (live) *reinterpret_cast<u32x4*>(o + 32 * i + 8 * (2 * t + h)) = piece;
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (STAGED && ((i & 1) || i == CM - 1)) {          // a row tile is complete: 8 rows x 128 (or a last 64) bytes per wave-store
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stg_at(stg2, 8 * g + rrow, rp));
+          if (rowd[g] >= 0 && ((i & 1) || rp < 4)) *reinterpret_cast<u32x4*>(p.next_ln + (size_t)rowd[g] * C + 64 * (i >> 1) + 8 * rp) = v;
+        }
+      }
+    }
   }
 #ifdef KVQ_TAIL_TRACE
   __builtin_amdgcn_s_waitcnt(0);
@@ -439,20 +542,28 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
 
 template <typename E, int CM, int NW>
 static int launch_tail(const TailParams& p, hipStream_t st) {
-  constexpr int C = 32 * CM;
-  const size_t lds = (size_t)tail_ring(C, NW) * tail_slot_bytes(C) +
-                     ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
+  constexpr int C = 32 * CM, NST = tail_ring(C, NW), SLOT = tail_slot_bytes(C), XTRA = tail_stage_extra(C, NW);
+  const size_t lds = (size_t)NST * SLOT + XTRA + ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
   KVQ_REQUIRE(lds <= (size_t)163840 / tail_bpc(C, NW), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
+  // KVQ_TAIL_STAGED=1: the x / attention / norm1 rows travel as 128-byte row segments through an LDS transpose (round 5, the review's
+  // "coalesced row traffic"; bit-identical results).  Built, tested and measured — and OFF by default: the C = 96 launches take 97.6 /
+  // 88.5 us against 93.1 / 87.5, the C = 192 ones 86.3 / 77.6 against 87.4 / 80.3, the 4-lane C2 line 355.7 / 358.6 against 360.0 /
+  // 360.7 videos/s (profiles/r05_tail_staged_ab.txt): a quarter of the row-divergent global accesses per wave buys nothing, so the
+  // lane-per-row accesses are NOT what these launches wait for (round 4's reading of the merge launch does not carry over).
+  static const bool staged_on = getenv("KVQ_TAIL_STAGED") && atoi(getenv("KVQ_TAIL_STAGED")) == 1;
+  // the epilogue's four tiles need NW * 4 KB of ring slots (+ the extra bytes) that do not hold the last item
+  const int NI = tail_proj_items(C) + 1 + p.hidden / 32, s_last = (NI - 1) % NST;
+  const bool staged = staged_on && ((NST - 1 - s_last) * SLOT + XTRA >= NW * TAIL_STG || s_last * SLOT >= NW * TAIL_STG);
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, 32 * NW)), block(64 * NW);
-  if (p.next_ln) {
-    auto k = block_tail_kernel<E, CM, NW, true>;
+  auto go = [&](auto k) -> int {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, block, lds, st, p);
-  } else {
-    auto k = block_tail_kernel<E, CM, NW, false>;
-    KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, st, p);
-  }
+    return KVQ_OK;
+  };
+  int rc;
+  if (p.next_ln) rc = staged ? go(block_tail_kernel<E, CM, NW, true, true>) : go(block_tail_kernel<E, CM, NW, true, false>);
+  else rc = staged ? go(block_tail_kernel<E, CM, NW, false, true>) : go(block_tail_kernel<E, CM, NW, false, false>);
+  if (rc) return rc;
   KVQ_CHECK_LAUNCH("block_tail_kernel");
   return KVQ_OK;
 }
