@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams consecutive steps alternate over (independent batches fill each other's launch gaps; "
                          "measured 1 / 2 / 3 / 4 / 5 / 6 streams: 2.12 / 1.77 / 1.76 / 1.745 / 1.84 / 1.71-1.84 ms per step)")
+    ap.add_argument("--cu-mask", default="none", choices=["none", "blocks", "interleave", "xcd"],
+                    help="experiment: give every stream lane its own share of the CUs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
     ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,two_launch,bf16,bf16_init,batch8,c3,c5,ksvqe ('all', 'c2' = none)")
@@ -158,18 +160,51 @@ class Source:
         self.fragments(first, x.shape[0]).materialise(out=x)
 
 
+def masked_lanes(n, mode, device):
+    """Experiment (round 5): one HIP stream per lane restricted to its own share of the CUs (hipExtStreamCreateWithCUMask) — spatial
+    partitioning of the chip between the lanes instead of time-multiplexing.  mode: 'blocks' = lane k takes mask bits [k*256/n, (k+1)*256/n),
+    'interleave' = bits with index % n == k, 'xcd' = bits with (index % 8) * n // 8 == k (whole XCDs if bits go round-robin over the XCDs)."""
+    import ctypes
+    import glob
+    import torch
+    hip = ctypes.CDLL(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64*"))[0])
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    out = []
+    for k in range(n):
+        bits = [0] * ncu
+        for i in range(ncu):
+            if mode == "blocks":
+                on = i * n // ncu == k
+            elif mode == "interleave":
+                on = i % n == k
+            else:
+                on = (i % 8) * n // 8 == k
+            bits[i] = 1 if on else 0
+        words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
+        for i, b in enumerate(bits):
+            if b:
+                words[i // 32] |= 1 << (i % 32)
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), words)
+        if rc != 0:
+            sys.exit(f"bench.py: hipExtStreamCreateWithCUMask failed ({rc})")
+        out.append(torch.cuda.ExternalStream(st.value, device=device))
+    return out
+
+
 def run_lanes(lanes, n, fn):
     """consecutive steps (whole batches, independent of each other) go to alternating HIP streams; all n steps are enqueued,
     the caller synchronises.  fn(step, lane_index) enqueues one step on the CURRENT stream and returns its output."""
     import torch
     main = torch.cuda.current_stream()
-    for st in lanes[1:]:
+    others = [st for st in lanes if st != main]
+    for st in others:
         st.wait_stream(main)
     outs = []
     for s in range(n):
         with torch.cuda.stream(lanes[s % len(lanes)]):
             outs.append(fn(s, s % len(lanes)))
-    for st in lanes[1:]:
+    for st in others:
         main.wait_stream(st)
     return outs
 
@@ -647,6 +682,8 @@ def main():
     B = args.batch
     nstream = max(1, args.streams)
     lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
+    if args.cu_mask != "none":
+        lanes = masked_lanes(nstream, args.cu_mask, device)
     legs = {"no_sampler", "two_launch", "bf16", "bf16_init", "batch8", "c3", "c5", "ksvqe"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
     if world > 1:
         legs = set()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 28
+#define KVQ_ABI_VERSION 29
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -90,6 +90,8 @@ typedef struct {
   const void* tail_pack;   /* optional, derived: kvq_block_tail_pack image of (proj, norm2, fc1, fc2).  Non-NULL (and
                               C in {96,128,192}) -> proj+residual+norm2+Mlp+residual run as ONE launch
                               (kvq_block_tail); NULL -> GEMM/LayerNorm launches */
+  const void* qkv_pack;    /* optional, derived: kvq_block_tail_qkv_pack image of THIS block's qkv_w.  Non-NULL -> the fused tail launch
+                              of the PREVIOUS block of the stage writes this block's q | k | v itself (no norm1 rows, no qkv GEMM launch) */
   const void* bias_dense;  /* optional, derived, valid ONLY with the plan it was built for
                               (kvq_swin3d_bias_dense_build): the block's attention bias per (window type, head), gate,
                               shift mask and padding included.  Non-NULL -> kvq_window_attention32; NULL -> the
@@ -362,6 +364,14 @@ typedef struct {
                                   the real tokens).  When set the launch walks the n_batch*out_rows TOKENS and fetches each one's
                                   attention row through it, instead of walking the M window rows: padded geometries (Swin-B at
                                   256x256: 1.2x .. 3x the rows) then do no work on padding rows.  scatter_map is not read. */
+  /* Instead of next_ln (leave it NULL; next_norm_w / _b / next_dst / next_rows as above): the NEXT block's q | k | v (swin_backbone.py:
+   * 252-260), head-major [3][num_heads][n_batch*next_rows][32] in its window order, q scaled by q_scale — what the qkv GEMM's
+   * KVQ_EPI_QKV_BF16 epilogue writes.  C with kvq_block_tail_qkv_pack_bytes(C, hidden) > 0 only (128 / 192 / 256 / 384 / 512). */
+  const void* next_qkv_pack;   /* kvq_block_tail_qkv_pack image of the next block's qkv weight               */
+  const float* next_qkv_b;     /* [3C]                                                                       */
+  void* qkv_out;               /* 16-bit; non-NULL selects this form                                         */
+  float q_scale;
+  int32_t num_heads;
 } KvqBlockTailArgs;
 /* Padded window partitions (Swin-B at 256x256, KSVQE at 288x288): the q|k|v of a PADDING row is qkv(0) = bias (the reference pads after
  * norm1, swin_backbone.py:416-449) and takes part in the softmax of its window as a key.  Instead of multiplying zero rows, the qkv
@@ -375,6 +385,9 @@ size_t kvq_block_tail_pack_bytes(int C, int hidden);             /* 0 when unsup
 int kvq_block_tail_pack(const void* proj_w, const float* proj_b, const float* norm2_w, const float* norm2_b,
                         const void* fc1_w, const float* fc1_b, const void* fc2_w, const float* fc2_b, int C, int hidden,
                         void* pack, void* stream);
+/* qkv_w [3C][C] 16-bit (rows q | k | v, head-major): the image the fused tail of the PREVIOUS block streams to emit q | k | v. */
+size_t kvq_block_tail_qkv_pack_bytes(int C, int hidden);         /* 0: this width's tail cannot emit q | k | v */
+int kvq_block_tail_qkv_pack(const void* qkv_w, int C, int hidden, void* pack, void* stream);
 int kvq_block_tail(const KvqBlockTailArgs* host_args, void* stream);
 
 /* WindowAttention3D core (swin_backbone.py:261-322) for head_dim 32: S = q k^T + bias, where

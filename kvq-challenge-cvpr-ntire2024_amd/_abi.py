@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 def dtype_code(dt) -> int:
@@ -49,7 +49,7 @@ class KvqSwinCfg(C.Structure):
 
 class KvqSwinBlockW(C.Structure):
     _fields_ = [(n, p_void) for n in ("norm1_w", "norm1_b", "rpb_table", "fpb_table", "bias_pack", "qkv_w", "qkv_b", "proj_w",
-                                      "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "tail_pack", "bias_dense")]
+                                      "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "tail_pack", "qkv_pack", "bias_dense")]
 
 
 class KvqSwinMergeW(C.Structure):
@@ -106,7 +106,8 @@ class KvqBlockTailArgs(C.Structure):
     _fields_ = [("attn", p_void), ("x", p_void), ("scatter_map", p_void), ("map_rows", C.c_int32),
                 ("out_rows", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("pack", p_void),
                 ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void),
-                ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32), ("attn_gather", p_void)]
+                ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32), ("attn_gather", p_void),
+                ("next_qkv_pack", p_void), ("next_qkv_b", p_void), ("qkv_out", p_void), ("q_scale", C.c_float), ("num_heads", C.c_int32)]
 
 
 FRAG_MAX_CLIPS = 16
@@ -201,6 +202,8 @@ SYMBOLS = {
     "kvq_block_tail_pack_bytes": (sz, [i32, i32]),
     "kvq_block_tail_pack": (i32, [p_void, p_void, p_void, p_void, p_void, p_void, p_void, p_void, i32, i32, p_void,
                                   p_void]),
+    "kvq_block_tail_qkv_pack_bytes": (sz, [i32, i32]),
+    "kvq_block_tail_qkv_pack": (i32, [p_void, i32, i32, p_void, p_void]),
     "kvq_block_tail": (i32, [C.POINTER(KvqBlockTailArgs), p_void]),
     "kvq_window_attention": (i32, [p_void, p_void, p_void, p_void, p_void, i32, i32, i32, i32, i32, i32, i32, i32, p_void,
                                    p_void]),

@@ -16,6 +16,15 @@
 
 #include "common.hpp"
 
+// KVQ_SKIP (diagnostic, tools/skip_ablation.sh): bit mask of launch families the forward leaves out — the scores are garbage, the point is the
+// marginal cost of a family in the multi-lane bench line (what the step would gain if the family were free), which the per-launch times
+// of a one-stream step do not tell.  1 attention, 2 fused tails C <= 192, 4 fused tails C >= 256, 8 qkv GEMMs, 16 LayerNorm launches,
+// 32 every launch of the last stage, 64 patch embedding, 128 patch merging (all forms).
+static int skip_mask() {
+  static const int m = getenv("KVQ_SKIP") ? atoi(getenv("KVQ_SKIP")) : 0;
+  return m;
+}
+
 namespace kvq {
 
 struct StageGeom {
@@ -384,6 +393,7 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
 static int ln(KvqSwinPlan* pl, hipStream_t st, const float* x, const int32_t* map, int nparts, int rows_in,
               int rows_out, int Cin, const float* g, const float* b, uint16_t* obf, float* of32) {
   const double elems = (double)pl->B * rows_out * nparts * Cin;
+  if (skip_mask() & 16) return KVQ_OK;
   Bracket br(pl, st, KVQ_K_LAYERNORM, of32 ? 1 : 0, 0.0, elems * (4.0 + (of32 ? 4.0 : 2.0)));
   return kvq_layernorm_rows(x, map, nparts, pl->B, rows_in, rows_out, Cin, g, b, 1e-5f, obf, pl->dtype, of32, st);
 }
@@ -394,6 +404,11 @@ static int ln(KvqSwinPlan* pl, hipStream_t st, const float* x, const int32_t* ma
   do {                     \
     int _rc = (expr);      \
     if (_rc) return _rc;   \
+  } while (0)
+
+#define KVQ_TRY_UNLESS(bits, expr) \
+  do {                             \
+    if (!(skip_mask() & (bits))) KVQ_TRY(expr); \
   } while (0)
 
 extern "C" int kvq_swin3d_set_taps(KvqSwinPlan* pl, float* const* taps) {
@@ -467,7 +482,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     const double px = (double)B * L0 * pl->K0;
     Bracket br(pl, st, KVQ_K_EMBED, (first_ln1_ready ? 1 : 0) + (frag ? 2 : 0), 2.0 * B * L0 * (double)E * pl->K0,
                px * (frag ? 1.0 : 4.0) + (double)B * L0 * E * (4.0 + (first_ln1_ready ? 2.0 : 0.0)));
-    KVQ_TRY(kvq_patch_embed(&ea, st));
+    KVQ_TRY_UNLESS(64, kvq_patch_embed(&ea, st));
   } else {
     KVQ_REQUIRE(!frag, KVQ_ERR_UNSUPPORTED, "kvq_swin3d_forward_fragments: this plan does not take the fused patch-embedding launch");
     {
@@ -499,6 +514,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     const StageGeom& g = pl->st[i];
     const int C = g.C, M = B * g.Lp, ML = B * g.L;
     bool ln1_ready = (i == 0 && first_ln1_ready) || merged_ln1_ready;   // the producer (embed / previous tail / merge) already wrote this block's norm1 rows
+    bool qkv_ready = false;                                             // the previous block's tail already wrote this block's q | k | v
     merged_ln1_ready = false;
     if (i == stage_lo && i > 0) cur = xa, oth = xb;
     for (int b = 0; b < g.depth; ++b, ++blk) {
@@ -526,12 +542,13 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         // reads them from the buffer
         if (!(bw.bias_dense && g.d_padmask[par]))
           KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, qs, pl->dtype, st));
-      } else {
+      } else if (!qkv_ready) {
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
         if (!fuse_qkv)
-          KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH, qs));
+          KVQ_TRY_UNLESS(8 | (i == cfg.num_stages - 1 ? 32 : 0), gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH, qs));
       }
       ln1_ready = false;
+      qkv_ready = false;
       if (bw.bias_dense) {
         // + the dense bias once per step: 4 B per score of every (window, head)
         Bracket br(pl, st, KVQ_K_ATTN, 4 + par, 4.0 * M * g.N * C + (fuse_qkv ? 6.0 * M * C * C : 0.0),
@@ -545,7 +562,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
                              ? g.nW - g.nW / slabs : -1;
         if (fuse_qkv) { aa.x_ln = bln; aa.w_qkv = bw.qkv_w; aa.b_qkv = bw.qkv_b; aa.q_scale = qs; }
         if (g.Lp != g.L && bw.qkv_b && g.d_padmask[par]) { aa.pad_mask = (const uint32_t*)g.d_padmask[par]; aa.b_qkv = bw.qkv_b; }
-        KVQ_TRY(kvq_window_attention32(&aa, st));
+        KVQ_TRY_UNLESS(1 | (i == cfg.num_stages - 1 ? 32 : 0), kvq_window_attention32(&aa, st));
       } else {
         // 4*Lp*N*C flops per block; bytes: q,k,v in + o out (16-bit)
         Bracket br(pl, st, KVQ_K_ATTN, (cfg.frag_bias[i] ? 2 : 0) + par, 4.0 * M * g.N * C, 2.0 * 4.0 * M * C);
@@ -572,13 +589,23 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         if (b + 1 < g.depth && nmap) {
           const KvqSwinBlockW& nb = w->blocks[blk + 1];
           KVQ_REQUIRE(nb.norm1_w && nb.norm1_b, KVQ_ERR_NULL, "kvq_swin3d_forward: block %d norm1 missing", blk + 1);
-          ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = nmap; ta.next_ln = bln;
+          ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = nmap;
           ta.next_rows = g.Lp == g.L ? g.Lp : g.L;
-          ln1_ready = true;
+          // the next block's q | k | v straight from this launch (C = 128 / 192 / 256 / 384 / 512, un-padded partitions, the image path's q scale):
+          // no norm1 rows, no qkv GEMM launch.  By geometry and weights only, never by batch.  KVQ_TAIL_QKV=0: rounds 1-4's sequence.
+          static const bool tail_qkv = !(getenv("KVQ_TAIL_QKV") && atoi(getenv("KVQ_TAIL_QKV")) == 0);
+          const bool next_fuses = nb.bias_dense && nb.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // its attention launch projects q | k | v itself
+          if (tail_qkv && !next_fuses && nb.qkv_pack && nb.qkv_b && nb.bias_dense && g.Lp == g.L && kvq_block_tail_qkv_pack_bytes(C, hidden) > 0) {
+            ta.next_qkv_pack = nb.qkv_pack; ta.next_qkv_b = nb.qkv_b; ta.qkv_out = bbig; ta.q_scale = kQScaleLog2; ta.num_heads = g.nH;
+            qkv_ready = true;
+          } else {
+            ta.next_ln = bln;
+            ln1_ready = true;
+          }
         }
-        Bracket br(pl, st, KVQ_K_TAIL, (C / 32) * 10 + (ln1_ready ? 1 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden,
-                   (double)M * C * 2.0 + (double)ML * C * (8.0 + (ln1_ready ? 2.0 : 0.0)));
-        KVQ_TRY(kvq_block_tail(&ta, st));
+        Bracket br(pl, st, KVQ_K_TAIL, (C / 32) * 10 + (ln1_ready ? 1 : 0) + (qkv_ready ? 2 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden + (qkv_ready ? 6.0 * M * C * C : 0.0),
+                   (double)M * C * 2.0 + (double)ML * C * (8.0 + (ln1_ready ? 2.0 : 0.0) + (qkv_ready ? 6.0 : 0.0)));
+        KVQ_TRY_UNLESS(C <= 192 ? 2 : 4, kvq_block_tail(&ta, st));
         continue;
       }
       // proj + window_reverse + roll back + crop + residual.  Padded partition: over the tokens (A rows gathered through token ->
@@ -591,21 +618,22 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
                    2.0 * ((double)ML * C + (double)C * C) + 8.0 * ML * C);
         KVQ_TRY(kvq_gemm_bf16(&pa, st));
       } else {
-        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,
+        KVQ_TRY_UNLESS(i == cfg.num_stages - 1 ? 32 : 0, gemm(pl, st, KVQ_K_GEMM_PROJ, bo, bw.proj_w, bw.proj_b, M, C, C, KVQ_EPI_RESID_F32, nullptr, cur, 0, 1.f,
                      g.d_src[par], g.Lp, g.L));
       }
       // norm2 + fc1 + GELU + fc2 + residual
       KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm2_w, bw.norm2_b, bln, nullptr));
-      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_FC1, bln, bw.fc1_w, bw.fc1_b, ML, cfg.mlp_ratio * C, C, KVQ_EPI_GELU_BF16, bbig,
+      KVQ_TRY_UNLESS(i == cfg.num_stages - 1 ? 32 : 0, gemm(pl, st, KVQ_K_GEMM_FC1, bln, bw.fc1_w, bw.fc1_b, ML, cfg.mlp_ratio * C, C, KVQ_EPI_GELU_BF16, bbig,
                    nullptr));
-      KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_FC2, bbig, bw.fc2_w, bw.fc2_b, ML, C, cfg.mlp_ratio * C, KVQ_EPI_RESID_F32,
+      KVQ_TRY_UNLESS(i == cfg.num_stages - 1 ? 32 : 0, gemm(pl, st, KVQ_K_GEMM_FC2, bbig, bw.fc2_w, bw.fc2_b, ML, C, cfg.mlp_ratio * C, KVQ_EPI_RESID_F32,
                    nullptr, cur));
     }
     if (i < cfg.num_stages - 1) {
       const KvqSwinMergeW& mw = w->merges[i];
       KVQ_REQUIRE(mw.norm_w && mw.norm_b && mw.red_w, KVQ_ERR_NULL, "kvq_swin3d_forward: merge %d weights missing", i);
       const int Ln = g.Dn * g.Hn * g.Wn;
-      if (mw.merge_pack && kvq_patch_merge_supported(C) && C <= 128) {
+      static const int merge_maxc = getenv("KVQ_MERGE_MAXC") ? atoi(getenv("KVQ_MERGE_MAXC")) : 192;      // 128 = rounds 4's gate (the C = 192 merge as three launches)
+      if (mw.merge_pack && kvq_patch_merge_supported(C) && C <= merge_maxc) {
         // concat + LayerNorm(4C) + reduction [+ the next stage's first norm1 in its window order] as one launch (csrc/merge.hip).
         // C = 96: 37.5 us against 26.3 + 25.6 + 15.9 (Swin-T, 4 clips); C = 128: +0.5-1 % on C5.  C = 192 exists and is tested, but
         // the 576 KB matrix streams through LDS for 98 workgroups of one wave per SIMD: 66.9 us against 16.2 + 24.8 + 15.3 - not taken
@@ -622,10 +650,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         }
         Bracket br(pl, st, KVQ_K_MERGE, merged_ln1_ready ? 1 : 0, 2.0 * B * Ln * (double)(2 * C) * (4 * C),
                    (double)B * Ln * 4 * C * 4.0 + (double)B * Ln * 2 * C * (4.0 + (merged_ln1_ready ? 2.0 : 0.0)));
-        KVQ_TRY(kvq_patch_merge(&ma, st));
+        KVQ_TRY_UNLESS(128, kvq_patch_merge(&ma, st));
       } else {
         KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr));
-        KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
+        KVQ_TRY_UNLESS(128, gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
                      oth));
       }
       float* t = cur; cur = oth; oth = t;

@@ -123,8 +123,9 @@ __global__ void tail_pack_kernel(const uint16_t* wp, const uint16_t* w1, const u
 // 82 / 76, NW = 6 136 / -, NW = 8 - / 76, NW = 12 124 / -: the L2 -> LDS weight stream (1.7 KB per token at NW = 4) is
 // NOT the bound — the wider barrier domain costs more than the halved stream saves — so workgroups stay at 4 waves,
 // 3 (C = 96, <= 168 VGPRs) or 2 of them per CU.
-template <typename E, int CM, int NW, bool EMIT, bool STAGED>
+template <typename E, int CM, int NW, int MODE, bool STAGED>      // MODE 0: x only; 1: + the next block's norm1 rows; 2: + the next block's q | k | v
 __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_kernel(TailParams p) {
+  constexpr bool EMIT = MODE != 0, QKV = MODE == 2;
   fp16_saturate_mode();
   constexpr int C = 32 * CM, KS = 2 * CM, PANEL = 64 * C, SLOT = 2 * PANEL, LPW = SLOT / 1024 / NW;
   constexpr int NST = tail_ring(C, NW), NPI = tail_proj_items(C);
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NJ = p.hidden >> 5, NI = NPI + 1 + NJ;
+  constexpr int NQI = QKV ? (3 * C / 32) / 2 : 0;      // QKV: the next block's qkv weight as 3C / 32 more panels (W1 layout), two per item, in p.qkv_pack
+  const int NI_ALL = NI + NQI;
   const int NQ = ((4 * C + p.hidden) * 4 + 1023) >> 10;              // 1 KB wave-loads that carry the parameters
   float* s_nn = reinterpret_cast<float*>(lds + PRM_OFF + NQ * 1024);   // [norm1_next_w C][norm1_next_b C] (EMIT)
 #ifdef KVQ_TAIL_TRACE   // diagnostic build only: the stamps cost registers and scheduling freedom
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
 
   auto issue = [&](int item, int slot) {
     unsigned char* dst = lds + slot * SLOT;
-    const unsigned char* src = p.pack + (size_t)item * SLOT;
+    const unsigned char* src = QKV && item >= NI ? p.qkv_pack + (size_t)(item - NI) * SLOT : p.pack + (size_t)item * SLOT;
 #pragma unroll
     for (int l = 0; l < LPW; ++l) {
       const int q = l * NW + wave;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   unsigned long long wait_dma = 0, wait_bar = 0;
 #endif
   auto next_item = [&]() -> const unsigned char* {
-    const int younger = NI - 1 - it;
+    const int younger = NI_ALL - 1 - it;
 #ifdef KVQ_TAIL_TRACE
     const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     wait_bar += __builtin_readcyclecounter() - t1;
 #endif
     const int fill = slot == 0 ? NST - 1 : slot - 1;
-    if (it + NST - 1 < NI) issue(it + NST - 1, fill);
+    if (it + NST - 1 < NI_ALL) issue(it + NST - 1, fill);
     const unsigned char* st = lds + slot * SLOT + lane * 16;
     ++it;
     slot = slot + 1 == NST ? 0 : slot + 1;
@@ -492,6 +495,62 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     // 16 bytes per lane: the lane pair (h = 0 | 1) of a token exchanges the 8-byte pieces of (q, q + 1) by v_permlane32_swap, lane h
     // then owns channels 8 (2 t + h) .. + 7 of a tile — half the row-divergent store instructions (one row per cycle in the addresser)
     const long drow = (long)tb * p.next_rows + p.next_dst[tloc];
+    if (QKV) {
+      // ---- the next block's q | k | v (swin_backbone.py:252-260 of block b + 1): its norm1 row becomes the B operand in registers (k order
+      // = accumulator order, as norm2's), then one 32-channel panel = one head of q, k or v at a time from 3C / 32 more ring panels ----
+#pragma unroll
+      for (int i = 0; i < CM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(s_nn + 32 * i + 8 * q + 4 * h);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(s_nn + C + 32 * i + 8 * q + 4 * h);
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mu_n) * rs * g[e] + be[e];
+          u32x4 w = __builtin_bit_cast(u32x4, bx[2 * i + (q >> 1)]);
+          w[2 * (q & 1)] = E::pack2(y[0], y[1]);
+          w[2 * (q & 1) + 1] = E::pack2(y[2], y[3]);
+          bx[2 * i + (q >> 1)] = __builtin_bit_cast(V8, w);
+          if (q & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      const int nH = C / 32;
+#pragma unroll 1
+      for (int j = 0; j < 3 * C / 32; j += 2) {
+        const unsigned char* sp = next_item();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pj = j + u, which = pj / nH, head = pj - which * nH;
+          f32x16 ha;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.qkv_b + 32 * pj + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ha[4 * q + e] = b[e];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) {
+            ha = E::mfma32(*reinterpret_cast<const V8*>(sp + u * PANEL + s2 * 1024), bx[s2], ha);
+            if (s2 % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+          const float sc = which == 0 ? p.q_scale : 1.f;
+          uint16_t* o = p.qkv_out + ((size_t)(which * nH + head) * p.qkv_rows + (size_t)drow) * 32;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+              const int q = 2 * t + v;
+              pk[v][0] = E::pack2(ha[4 * q] * sc, ha[4 * q + 1] * sc);
+              pk[v][1] = E::pack2(ha[4 * q + 2] * sc, ha[4 * q + 3] * sc);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            if (live) *reinterpret_cast<u32x4*>(o + 8 * (2 * t + h)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+      }
+    }
     uint16_t* o = p.next_ln + (size_t)drow * C;
     int rowd[4];
     if (STAGED) {
@@ -499,7 +558,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
       for (int g = 0; g < 4; ++g) rowd[g] = __shfl(live ? (int)drow : -1, 8 * g + rrow);
     }
 #pragma unroll
-    for (int i = 0; i < CM; ++i) {
+    for (int i = 0; i < (QKV ? 0 : CM); ++i) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         uint32_t pk[2][2];
@@ -561,8 +620,11 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
     return KVQ_OK;
   };
   int rc;
-  if (p.next_ln) rc = staged ? go(block_tail_kernel<E, CM, NW, true, true>) : go(block_tail_kernel<E, CM, NW, true, false>);
-  else rc = staged ? go(block_tail_kernel<E, CM, NW, false, true>) : go(block_tail_kernel<E, CM, NW, false, false>);
+  if (p.qkv_out) {
+    KVQ_REQUIRE(!staged && (3 * C / 32) % 2 == 0, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: q | k | v emission with staged rows / an odd panel count");
+    rc = go(block_tail_kernel<E, CM, NW, 2, false>);
+  } else if (p.next_ln) rc = staged ? go(block_tail_kernel<E, CM, NW, 1, true>) : go(block_tail_kernel<E, CM, NW, 1, false>);
+  else rc = staged ? go(block_tail_kernel<E, CM, NW, 0, true>) : go(block_tail_kernel<E, CM, NW, 0, false>);
   if (rc) return rc;
   KVQ_CHECK_LAUNCH("block_tail_kernel");
   return KVQ_OK;
@@ -617,6 +679,41 @@ extern "C" int kvq_block_tail_pack(const void* proj_w, const float* proj_b, cons
   return KVQ_OK;
 }
 
+namespace kvq {
+// qkv weight as 3C / 32 panels of 32 output channels in the W1 panel layout (k = channel in accumulator order), two panels per ring item
+__global__ void tail_qkv_pack_kernel(const uint16_t* wq, int C, unsigned char* out, long n_chunks) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_chunks) return;
+  const int KS = C / 16;
+  const int panel = (int)(g / (KS * 64)), rem = (int)(g % (KS * 64));
+  const int f = rem >> 6, lane = rem & 63, m = lane & 31, h = lane >> 5;
+  uint16_t* o = reinterpret_cast<uint16_t*>(out + g * 16);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = 32 * (f >> 1) + 8 * (2 * (f & 1) + (e >> 2)) + 4 * h + (e & 3);
+    o[e] = wq[(size_t)(32 * panel + m) * C + ch];
+  }
+}
+}  // namespace kvq
+
+extern "C" size_t kvq_block_tail_qkv_pack_bytes(int C, int hidden) {
+  if (use_tailmm(C, hidden)) return kvq::tailmm_qkv_pack_bytes(C, hidden);
+  if (!kvq_block_tail_supported(C, hidden) || (3 * C / 32) % 2) return 0;
+  return (size_t)(3 * C / 32) * 64 * C;           // 3C / 32 panels of 64 C bytes
+}
+
+extern "C" int kvq_block_tail_qkv_pack(const void* qkv_w, int C, int hidden, void* pack, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(qkv_w && pack, KVQ_ERR_NULL, "kvq_block_tail_qkv_pack: NULL pointer");
+  KVQ_REQUIRE(kvq_block_tail_qkv_pack_bytes(C, hidden) > 0, KVQ_ERR_UNSUPPORTED, "kvq_block_tail_qkv_pack: C=%d hidden=%d", C, hidden);
+  if (use_tailmm(C, hidden)) return tailmm_qkv_pack((const uint16_t*)qkv_w, C, hidden, (unsigned char*)pack, (hipStream_t)stream);
+  const long n_chunks = (long)kvq_block_tail_qkv_pack_bytes(C, hidden) / 16;
+  hipLaunchKernelGGL(tail_qkv_pack_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv_w, C,
+                     (unsigned char*)pack, n_chunks);
+  KVQ_CHECK_LAUNCH("tail_qkv_pack_kernel");
+  return KVQ_OK;
+}
+
 extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(a && a->attn && a->x && a->pack, KVQ_ERR_NULL, "kvq_block_tail: NULL pointer");
@@ -631,6 +728,14 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
   p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;
+  if (a->qkv_out) {
+    KVQ_REQUIRE(kvq_block_tail_qkv_pack_bytes(a->C, a->hidden) > 0, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d cannot emit q | k | v", a->C);
+    KVQ_REQUIRE(!a->next_ln && a->next_qkv_pack && a->next_qkv_b && a->next_norm_w && a->next_norm_b && a->next_dst && a->next_rows > 0 &&
+                    a->num_heads * 32 == a->C, KVQ_ERR_NULL, "kvq_block_tail: qkv_out needs next_qkv_pack / next_qkv_b / next norm / map, heads of 32, and no next_ln");
+    const long nb = a->attn_gather ? a->M / a->map_rows : (a->scatter_map ? a->M / a->map_rows : a->M / a->out_rows);
+    p.qkv_pack = (const unsigned char*)a->next_qkv_pack; p.qkv_b = a->next_qkv_b; p.qkv_out = (uint16_t*)a->qkv_out;
+    p.q_scale = a->q_scale; p.num_heads = a->num_heads; p.qkv_rows = nb * a->next_rows;
+  }
   if (a->attn_gather) {
     KVQ_REQUIRE(a->map_rows > 0 && a->M % a->map_rows == 0, KVQ_ERR_SHAPE, "kvq_block_tail: attn_gather needs M = n_batch * map_rows");
     p.gather = a->attn_gather; p.n_tok = a->M / a->map_rows * a->out_rows; p.map = nullptr;

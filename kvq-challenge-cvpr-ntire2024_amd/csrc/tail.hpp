@@ -18,6 +18,13 @@ struct TailParams {
   const int32_t* next_dst;   // token -> window row of the next block's partition
   uint16_t* next_ln;         // [n_batch*next_rows][C]
   int next_rows;
+  // instead of next_ln: the next block's q | k | v, head-major [3][nH][n_batch*next_rows][32] in ITS window order (tailmm.hip, round 5)
+  const unsigned char* qkv_pack;   // kvq_block_tail_qkv_pack image of the NEXT block's qkv weight
+  const float* qkv_b;              // [3C]
+  uint16_t* qkv_out;
+  float q_scale;
+  int num_heads;
+  long qkv_rows;                   // n_batch * next_rows
   float eps;
   unsigned long long* trace;   // diagnostic stamps (kvq_debug_gemm_trace; -DKVQ_TAIL_TRACE builds only)
   int trace_blocks;
@@ -29,5 +36,7 @@ size_t tailmm_pack_bytes(int C, int hidden);
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st);
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st);
+size_t tailmm_qkv_pack_bytes(int C, int hidden);      // 0: this width cannot emit q | k | v
+int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out, hipStream_t st);
 
 }  // namespace kvq

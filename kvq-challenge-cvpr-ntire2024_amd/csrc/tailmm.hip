@@ -156,6 +156,40 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
   return KVQ_OK;
 }
 
+// q | k | v of the NEXT block from this launch (round 5): its qkv weight as a fourth fragment list per wave — [which = q, k, v][k-step]
+// [feature tile], the wave's feature slice of each third, k in accumulator order (the norm1 rows reach LDS from the accumulators, like
+// norm2's) — consumed behind the MLP by the same register ring.
+template <int CF>
+__global__ void tailmm_qkv_pack_kernel(const uint16_t* wq, unsigned char* out) {
+  using K = MMc<CF>;
+  const long gi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NFQ = 3 * K::NF_PROJ;
+  if (gi >= (long)4 * NFQ * 64) return;
+  const int lane = (int)(gi & 63), i = lane & 31, g = lane >> 5;
+  const int f = (int)((gi >> 6) % NFQ), w = (int)((gi >> 6) / NFQ);
+  const int which = f / K::NF_PROJ, r = f % K::NF_PROJ, ks = r / CF, ft = r % CF;
+  uint16_t* o = reinterpret_cast<uint16_t*>(out + gi * 16);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = wq[(size_t)(which * K::C + K::W * w + 32 * ft + i) * K::C + 16 * ks + mm_kperm(g, e)];
+}
+
+size_t tailmm_qkv_pack_bytes(int C, int hidden) {
+  if (!tailmm_supported(C, hidden)) return 0;
+  const int CF = C / 128;
+  return (size_t)4 * 3 * (C / 16) * CF * 1024;
+}
+
+int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out, hipStream_t st) {
+  KVQ_REQUIRE(tailmm_supported(C, hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail_qkv_pack: C=%d hidden=%d", C, hidden);
+  const long total = (long)tailmm_qkv_pack_bytes(C, hidden) / 16;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (C == 512) hipLaunchKernelGGL(tailmm_qkv_pack_kernel<4>, grid, block, 0, st, qkv_w, out);
+  else if (C == 256) hipLaunchKernelGGL(tailmm_qkv_pack_kernel<2>, grid, block, 0, st, qkv_w, out);
+  else hipLaunchKernelGGL(tailmm_qkv_pack_kernel<3>, grid, block, 0, st, qkv_w, out);
+  KVQ_CHECK_LAUNCH("tailmm_qkv_pack_kernel");
+  return KVQ_OK;
+}
+
 // The weight stream: a wave's weight fragments are PRIVATE to it, and plain VGPR loads stream as fast as LDS-DMA
 // (tools/ubench/l2_stream.hip), so the fragments go global -> VGPR and are the MFMA A operand as they arrive: a REGISTER ring of
 // VR_R fragments per wave, VR_PF in flight (80 KB per CU at C = 384), no weight reads from LDS.  Slots are compile-time: every phase
@@ -164,8 +198,9 @@ int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, cons
 // load is unsafe under this register pressure (the allocator splits the live range of a value it believes ready; the late data lands
 // in a register handed on).  (Round 2 also carried an LDS-ring form of the stream and ablation builds of it — no weight stream 65 us,
 // no MFMAs 57, neither 43 of 78 — removed in round 3: 79 -> 73 us with the next norm1, 73 -> 64 without, bit-identical.)
-template <typename E, bool EMIT, int CF = 3, int HC = 256>
+template <typename E, int MODE, int CF = 3, int HC = 256>      // MODE 0: x only; 1: + the next block's norm1 rows; 2: + the next block's q | k | v
 __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_kernel(TailParams p) {
+  constexpr bool EMIT = MODE == 1, QKV = MODE == 2;
   using K = MMc<CF, HC>;
   constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_KS_C = K::KS_C, MM_NF = K::NF, VR_R = K::VR_R, VR_PF = K::VR_PF, FW = K::W;
   constexpr int MM_HC = K::HC, MM_KS_H = K::KS_H, HT = K::HT;
@@ -198,9 +233,12 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_ke
   // stays uniform and the loop bodies stay branch-free)
   int issued = 0;
   typename E::v8 wr[VR_R];
+  constexpr int NFQ = QKV ? 3 * K::NF_PROJ : 0, NF_ALL = MM_NF + NFQ;      // QKV: the next block's qkv fragments follow the list
+  const unsigned char* wq = QKV ? p.qkv_pack + (size_t)wave * NFQ * 1024 + lane * 16 : nullptr;
   auto vload = [&](int slot) __attribute__((always_inline)) {        // list position `issued` -> register slot (compile-time after unrolling)
-    const int src = issued < MM_NF ? issued : MM_NF - 1;
-    wr[slot] = *reinterpret_cast<const typename E::v8*>(wsrc + (size_t)src * 1024);
+    const int src = issued < NF_ALL ? issued : NF_ALL - 1;
+    const unsigned char* a = QKV && src >= MM_NF ? wq + (size_t)(src - MM_NF) * 1024 : wsrc + (size_t)src * 1024;
+    wr[slot] = *reinterpret_cast<const typename E::v8*>(a);
     ++issued;
   };
 
@@ -463,6 +501,55 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_ke
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(xr + 32 * ft + 8 * q) = (f32x4){acc[ft][tt][4 * q], acc[ft][tt][4 * q + 1], acc[ft][tt][4 * q + 2], acc[ft][tt][4 * q + 3]};
     }
+  if (QKV) {
+    // ---- the next block's q | k | v (swin_backbone.py:252-260 of block b + 1): norm1 rows -> B fragments in the activation tile (every
+    // wave is past its last read of the norm2 rows: the barrier behind the last fc1), then three passes of the proj-shaped GEMM phase
+    // over the wave's feature slice of q, k and v; a 32-feature tile is one head.  Rows leave head-major in the next block's window order.
+    const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
+    const f32x2 mean = sum * (1.0f / (float)C);
+    const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
+    const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+    write_norm(mean, rstd, p.nn_w, p.nn_b, lds + MM_OFF_X);
+    long drow[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) drow[tt] = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
+    MM_BARRIER();                                      // norm1 rows complete
+#pragma unroll 1
+    for (int which = 0; which < 3; ++which) {
+#pragma unroll
+      for (int ft = 0; ft < CF; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 qb = *reinterpret_cast<const f32x4*>(p.qkv_b + which * C + FW * wave + 32 * ft + 8 * q + 4 * half);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[ft][tt][4 * q + i] = qb[i];
+        }
+      gemm_phase(T3{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+      const float sc = which == 0 ? p.q_scale : 1.f;
+      // as the norm1 rows below: the lane pair of a token swaps 8-byte pieces, lane `half` then owns head dims 8 (2 t + half) .. + 7
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int ft = 0; ft < CF; ++ft) {
+          uint16_t* o = p.qkv_out + ((size_t)(which * p.num_heads + CF * wave + ft) * p.qkv_rows + (size_t)drow[tt]) * 32;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int q = 2 * t + u;
+              pk[u][0] = E::pack2(acc[ft][tt][4 * q] * sc, acc[ft][tt][4 * q + 1] * sc);
+              pk[u][1] = E::pack2(acc[ft][tt][4 * q + 2] * sc, acc[ft][tt][4 * q + 3] * sc);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            if (live[tt]) *reinterpret_cast<u32x4*>(o + 8 * (2 * t + half)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+    }
+  }
   if (EMIT) {
     const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
     const f32x2 mean = sum * (1.0f / (float)C);
@@ -510,17 +597,17 @@ template <typename E, int CF, int HC = 256>
 static int launch_mm_cf(const TailParams& p, hipStream_t st) {
   constexpr int LDS = MMc<CF, HC>::LDS;
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
-  if (p.next_ln) {
-    auto k = block_tailmm_kernel<E, true, CF, HC>;
-    static LdsOptIn opt;
+  auto go = [&](auto k) -> int {
+    LdsOptIn opt;
     if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
     hipLaunchKernelGGL(k, grid, block, LDS, st, p);
-  } else {
-    auto k = block_tailmm_kernel<E, false, CF, HC>;
-    static LdsOptIn opt;
-    if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
-    hipLaunchKernelGGL(k, grid, block, LDS, st, p);
-  }
+    return KVQ_OK;
+  };
+  int rc;
+  if (p.qkv_out) rc = go(block_tailmm_kernel<E, 2, CF, HC>);
+  else if (p.next_ln) rc = go(block_tailmm_kernel<E, 1, CF, HC>);
+  else rc = go(block_tailmm_kernel<E, 0, CF, HC>);
+  if (rc) return rc;
   KVQ_CHECK_LAUNCH("block_tailmm_kernel");
   return KVQ_OK;
 }

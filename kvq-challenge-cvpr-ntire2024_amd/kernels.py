@@ -722,10 +722,25 @@ def block_tail_pack(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b
     return pack
 
 
+def block_tail_qkv_pack(qkv_w: torch.Tensor, hidden: int):
+    """Image of a block's qkv weight (16-bit [3C][C]) that the PREVIOUS block's fused tail streams to emit q | k | v
+    (include/kvq_hip.h: kvq_block_tail_qkv_pack); None when this width's tail cannot."""
+    _need_gpu(qkv_w)
+    assert qkv_w.dtype in HALF_TYPES and qkv_w.is_contiguous()
+    Cc = qkv_w.shape[1]
+    nbytes = lib().kvq_block_tail_qkv_pack_bytes(Cc, hidden)
+    if not nbytes:
+        return None
+    pack = torch.empty(nbytes, dtype=torch.uint8, device=qkv_w.device)
+    check(lib().kvq_block_tail_qkv_pack(ptr(qkv_w), Cc, hidden, ptr(pack), current_stream()), "kvq_block_tail_qkv_pack")
+    return pack
+
+
 def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: int, *, scatter_map=None, map_rows=0,
-               out_rows=0, next_norm=None, next_dst=None, next_rows=0, eps=1e-5, attn_gather=None):
+               out_rows=0, next_norm=None, next_dst=None, next_rows=0, eps=1e-5, attn_gather=None, next_qkv=None):
     """x (fp32 [n_batch*out_rows, C], in place) += proj(attn) scattered; x += Mlp(norm2(x)).
-    ``next_norm=(gamma, beta)`` + ``next_dst`` additionally returns norm1_next(x) in the next window order."""
+    ``next_norm=(gamma, beta)`` + ``next_dst`` additionally returns norm1_next(x) in the next window order — or, with
+    ``next_qkv=(qkv_pack, qkv_bias, q_scale)``, the next block's q | k | v, head-major [3][C/32][n_batch*next_rows][32]."""
     _need_gpu(attn, x, pack, scatter_map, next_dst)
     assert attn.dtype in HALF_TYPES and attn.is_contiguous() and x.dtype == torch.float32 and x.is_contiguous()
     M, Cc = attn.shape
@@ -736,9 +751,13 @@ def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: 
     nxt = None
     if next_norm is not None:
         n_batch = x.shape[0] // a.out_rows
-        nxt = torch.empty(n_batch * next_rows, Cc, dtype=attn.dtype, device=x.device)
-        a.next_norm_w, a.next_norm_b, a.next_dst, a.next_ln, a.next_rows = (ptr(next_norm[0]), ptr(next_norm[1]),
-                                                                            ptr(next_dst), ptr(nxt), next_rows)
+        a.next_norm_w, a.next_norm_b, a.next_dst, a.next_rows = ptr(next_norm[0]), ptr(next_norm[1]), ptr(next_dst), next_rows
+        if next_qkv is not None:
+            nxt = torch.empty(3, Cc // 32, n_batch * next_rows, 32, dtype=attn.dtype, device=x.device)
+            a.next_qkv_pack, a.next_qkv_b, a.qkv_out, a.q_scale, a.num_heads = ptr(next_qkv[0]), ptr(next_qkv[1]), ptr(nxt), float(next_qkv[2]), Cc // 32
+        else:
+            nxt = torch.empty(n_batch * next_rows, Cc, dtype=attn.dtype, device=x.device)
+            a.next_ln = ptr(nxt)
     check(lib().kvq_block_tail(C.byref(a), current_stream()), "kvq_block_tail")
     return nxt
 

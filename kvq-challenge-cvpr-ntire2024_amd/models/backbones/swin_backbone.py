@@ -310,6 +310,12 @@ class SwinTransformer3D(nn.Module):
                                                     b.fc2_b, Cb, hid, ptr(tp), current_stream()), "kvq_block_tail_pack")
                     keep.append(tp)
                     b.tail_pack = ptr(tp)
+                nbytes = lib().kvq_block_tail_qkv_pack_bytes(Cb, hid) if self.fused_tail else 0
+                if nbytes:      # this block's qkv weight as the image the PREVIOUS block's tail streams to emit q | k | v (csrc/tailmm.hip)
+                    qp = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                    check(lib().kvq_block_tail_qkv_pack(b.qkv_w, Cb, hid, ptr(qp), current_stream()), "kvq_block_tail_qkv_pack")
+                    keep.append(qp)
+                    b.qkv_pack = ptr(qp)
             if layer.downsample is not None:
                 m = w.merges[i]
                 m.norm_w, m.norm_b = f32(layer.downsample.norm.weight), f32(layer.downsample.norm.bias)

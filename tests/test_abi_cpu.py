@@ -23,14 +23,14 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in kvq_hip.h but not exported"
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
-    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 28
+    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 29
 
 
 def test_struct_layouts_match_header_sizes():
     import ctypes as C
     assert C.sizeof(_abi.KvqSwinCfg) == 4 * (3 + 1 + 1 + 1 + 4 + 4 + 3 + 1 + 4)
-    assert C.sizeof(_abi.KvqSwinBlockW) == 17 * 8
-    assert C.sizeof(_abi.KvqBlockTailArgs) == 112
+    assert C.sizeof(_abi.KvqSwinBlockW) == 18 * 8
+    assert C.sizeof(_abi.KvqBlockTailArgs) == 144
     assert C.sizeof(_abi.KvqSwinWeights) == 5 * 8 + 8 + 3 * 4 * 8 + 2 * 8
     assert C.sizeof(_abi.KvqPatchMergeArgs) == 96
     assert C.sizeof(_abi.KvqPatchEmbedArgs) == 128

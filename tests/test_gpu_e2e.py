@@ -426,6 +426,10 @@ def test_forward_stages_equals_whole_forward(golden):
         s = bb.forward_stages(s, 2, 2, geometry=(T, H, W))
         s, feat = bb.forward_stages(s, 3, 3, geometry=(T, H, W), want_feat=True)
         allin, feat2 = bb.forward_stages(x, 0, 3, want_feat=True)
-    assert torch.equal(feat, whole) and torch.equal(feat2, whole) and torch.equal(s, allin)
+    assert torch.equal(feat2, whole)
+    # entering at a stage whose first norm1 the whole forward takes from the fused PatchMerging launch (C = 96 / 128 / 192, csrc/merge.hip:
+    # two-pass statistics in the lane pair) recomputes it with the LayerNorm launch (the caller may have changed the stream in between):
+    # the same fp32 arithmetic in another summation order -> the last bits of the 16-bit rows, not more
+    assert (feat - whole).abs().max().item() <= 2e-3 * whole.abs().max().item() and (s - allin).abs().max().item() <= 2e-3 * allin.abs().max().item()
     with pytest.raises(_abi.KvqError, match="expects"):
         bb.forward_stages(torch.zeros(B, 5, 1, 1, 1, device=DEV), 2, 2, geometry=(T, H, W))

@@ -815,6 +815,53 @@ def test_block_tail(C, dims, shift, nxt_shift, half):
         assert d <= 2 * EPS[half] * ref_ln.abs().max().item() + 1e-5, d
 
 
+@pytest.mark.parametrize("C,dims,shift,nxt_shift", [(384, (8, 14, 14), (0, 0, 0), (4, 3, 3)), (384, (16, 14, 14), (4, 3, 3), (0, 0, 0)),
+                                                    (256, (8, 7, 7), (0, 0, 0), (0, 0, 0)), (512, (8, 14, 7), (0, 0, 0), (4, 3, 0)),
+                                                    (192, (8, 14, 14), (0, 0, 0), (4, 3, 3)), (192, (16, 28, 28), (4, 3, 3), (0, 0, 0)),
+                                                    (128, (8, 14, 7), (0, 0, 0), (4, 3, 0))])
+def test_block_tail_emits_next_qkv(C, dims, shift, nxt_shift, half):
+    """The fused tail (C = 128 / 192: token per lane; C = 256 / 384 / 512: feature-sliced) writing the NEXT block's q | k | v itself (swin_backbone.py:252-260 of block b + 1:
+    norm1 -> qkv Linear -> head split, q scaled) against LayerNorm + the qkv GEMM launch on the launch's own residual output: the
+    same 16-bit operands (norm1 rows, weights), so the two agree to the rounding of one 16-bit result; and x is what the launch
+    without the emission leaves."""
+    g = rng(C + sum(dims) + 5)
+    D, H, W = dims
+    B, hidden, nH = 2, 4 * C, C // 32
+    lay = O.window_layout(D, H, W, (8, 7, 7), shift)
+    lay2 = O.window_layout(D, H, W, (8, 7, 7), nxt_shift)
+    Lp, L = lay["nW"] * lay["N"], D * H * W
+    assert Lp == L and (lay2["src"] >= 0).all()
+    t = lambda *s, sc=1.0: torch.from_numpy((g.standard_normal(s) * sc).astype(np.float32))
+    A, x = rnd(t(B * Lp, C), half), t(B * L, C, sc=2.0)
+    Wp, W1, W2 = rnd(t(C, C, sc=0.15), half), rnd(t(hidden, C, sc=0.15), half), rnd(t(C, hidden, sc=0.08), half)
+    bp, b1, b2, g2, b2n = t(C, sc=0.3), t(hidden, sc=0.3), t(C, sc=0.3), 1 + 0.2 * t(C), 0.2 * t(C)
+    Wq, bq = rnd(t(3 * C, C, sc=0.1), half), t(3 * C, sc=0.3)
+    gn, bn = 1 + 0.2 * t(C), 0.2 * t(C)
+    qs = 0.25
+    pack = kernels.block_tail_pack(dev(Wp, half), dev(bp), dev(g2), dev(b2n), dev(W1, half), dev(b1), dev(W2, half), dev(b2))
+    qpack = kernels.block_tail_qkv_pack(dev(Wq, half), hidden)
+    assert qpack is not None
+    dst = np.empty(L, np.int32)
+    dst[lay2["src"]] = np.arange(L, dtype=np.int32)
+    common = dict(scatter_map=dev(torch.from_numpy(lay["src"].astype(np.int32))), map_rows=Lp, out_rows=L,
+                  next_norm=(dev(gn), dev(bn)), next_dst=dev(torch.from_numpy(dst)), next_rows=L)
+    x_ln, x_qkv = dev(x.clone()), dev(x.clone())
+    ln_rows = kernels.block_tail(dev(A, half), x_ln, pack, hidden, **common)
+    qkv = kernels.block_tail(dev(A, half), x_qkv, pack, hidden, next_qkv=(qpack, dev(bq), qs), **common)
+    assert torch.equal(x_ln, x_qkv)
+    assert qkv.shape == (3, nH, B * L, 32)
+    ref = kernels.gemm(ln_rows, dev(Wq, half), dev(bq), _abi.EPI_QKV_BF16, num_heads=nH, q_scale=qs).reshape(3, nH, B * L, 32)
+    d = (qkv.float() - ref.float()).abs().max().item()
+    assert d <= 2 * EPS[half] * ref.float().abs().max().item() + 1e-5, d
+    # and against the fp32 composition on the launch's residual output
+    ln = torch.nn.functional.layer_norm(x_qkv.cpu(), (C,), gn, bn).reshape(B, D, H, W, C)
+    rows = rnd(O.gather_windows(ln, lay2).reshape(-1, C), half)
+    full = rows @ Wq.t() + bq
+    full[:, :C] *= qs
+    want = full.reshape(B * L, 3, nH, 32).permute(1, 2, 0, 3)
+    assert (qkv.float().cpu() - want).abs().max().item() <= 6 * EPS[half] * want.abs().max().item() + 1e-4
+
+
 def test_block_tail_identity_map_and_unsupported(half):
     g = rng(77)
     C, hidden, M = 96, 384, 333

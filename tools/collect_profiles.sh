@@ -8,7 +8,7 @@
 #   pmc_sq.txt             rocprofv3 --pmc SQ_* (separate pass) of the same command
 #   c3_*, c5_*             the same for the C3 probe (bench.py --probe c3) and the C5 probe (bench.py --probe c5)
 #   gemm_sweep.txt, slowfast_layers.txt, attention / bias-build probes, embed_sampler_pmc.txt (HBM bytes of K1 + embedding, both sequencings)
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
