@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-Wno-unused-variable"]
 # attn.hip is VALU-bound: SLP packing of adjacent f32 ops into v_pk_* costs more v_mov than it saves, and
 # NaN-honouring fmaxf inserts a canonicalising v_max per MFMA output (no NaN can arise: -inf only).
-EXTRA = {"attn.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "attn32.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "tail.hip": ["-fno-slp-vectorize"], "tailmm.hip": ["-fno-slp-vectorize"], "embed.hip": ["-fno-slp-vectorize"], "merge.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"attn.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "attn32.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "tail.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "tailmm.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "embed.hip": ["-fno-slp-vectorize"], "merge.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
