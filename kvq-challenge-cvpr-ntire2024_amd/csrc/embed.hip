@@ -68,7 +68,13 @@ __host__ __device__ constexpr int embed_stage_off(int CM, int KS) { return CM * 
 // the x0 rows leave through an LDS tile at E = 96 (76 KB per workgroup: two per CU, which measures like five; hipEvent-bracketed
 // launch: 52.1 -> 49.8 us reading through the sampler, 48.4 -> 43.3 reading the fp32 clip); at E = 128 the tile would leave one
 // workgroup per CU — the accumulator-layout stores stay
-__host__ __device__ constexpr bool embed_staged(int CM, bool) { return CM == 3; }
+// Round 5: OFF.  The tile makes the launch 2-5 us faster ALONE (above) and costs the 4-lane bench line 0.8 % (380.9 / 380.4 -> 384.8 / 382.8
+// videos/s without it, same box, alternating): a memory-bound launch whose workgroups hold 76 KB of LDS keeps the other lanes' workgroups
+// off its CUs; at 25 KB three of them leave room for an attention or tail workgroup.  -DKVQ_EMBED_STAGED=1 builds the tile form.
+#ifndef KVQ_EMBED_STAGED
+#define KVQ_EMBED_STAGED 0
+#endif
+__host__ __device__ constexpr bool embed_staged(int CM, bool) { return CM == 3 && KVQ_EMBED_STAGED; }
 
 template <typename E_, int CM, int KS, bool EMIT, bool FRAG>
 __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_embed_kernel(EmbedParams p) {

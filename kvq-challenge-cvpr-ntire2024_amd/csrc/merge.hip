@@ -38,12 +38,17 @@ typedef __attribute__((address_space(1))) const void* mg_gbl_t;
 
 // geometry by width.  The weight image is cut into chunks of KC k-steps (all 2C / 32 row tiles of those k-steps: <= 72 KB) that
 // stream through two LDS buffers; at C = 96 the two chunks ARE the matrix (both requested at the start, nothing refilled).
+#ifndef KVQ_MERGE96_SMALL
+#define KVQ_MERGE96_SMALL 0
+#endif
 template <int C_>
 struct MGc {
   static constexpr int C = C_, K = 4 * C, N = 2 * C, CM = N / 32, KS = K / 16, QS = C / 16;      // QS: k-steps per neighbour
-  static constexpr int KC = C == 96 ? 12 : C == 128 ? 8 : 6;
+  // KVQ_MERGE96_SMALL (round 5 A/B): at C = 96 stream the matrix through two 36 KB chunk buffers for 4 waves (75 KB of LDS: two workgroups
+  // per CU, room for another lane's workgroup) instead of keeping all 144 KB resident for 8 waves
+  static constexpr int KC = C == 96 ? (KVQ_MERGE96_SMALL ? 6 : 12) : C == 128 ? 8 : 6;
   static constexpr int NCH = KS / KC, CHUNK = CM * KC * 1024, WBYTES = CM * KS * 1024;
-  static constexpr int WAVES = C == 96 ? 8 : 4, TOK = 32 * WAVES;       // wider rows: one wave per SIMD (the accumulators alone are 128 / 192 registers)
+  static constexpr int WAVES = C == 96 && !KVQ_MERGE96_SMALL ? 8 : 4, TOK = 32 * WAVES;       // wider rows: one wave per SIMD (the accumulators alone are 128 / 192 registers)
   static constexpr int TAIL = ((2 * N * 4) + 1023) & ~1023;               // fp32 W beta [2C] | row sums of W' [2C], whole KB
   static constexpr int PACK_BYTES = WBYTES + TAIL;
   static constexpr int LDS = 2 * CHUNK + TAIL + 2 * N * 4;                // + the next norm1's gamma | beta
@@ -80,7 +85,7 @@ __global__ void merge_pack_kernel(const float* w, const float* gamma, const floa
 }
 
 template <typename E, bool EMIT, int C_>
-__global__ __launch_bounds__(64 * MGc<C_>::WAVES, 1) void patch_merge_kernel(MergeParams p) {
+__global__ __launch_bounds__(64 * MGc<C_>::WAVES, (2 * MGc<C_>::LDS <= 163840 ? 2 : 1)) void patch_merge_kernel(MergeParams p) {
   using G = MGc<C_>;
   constexpr int C = G::C, K = G::K, N = G::N, CM = G::CM, KS = G::KS, QS = G::QS, KC = G::KC, NCH = G::NCH, CHUNK = G::CHUNK, WAVES = G::WAVES;
   fp16_saturate_mode();

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   static_assert(NST == 3 || NST == 4, "wait ladder below");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using V8 = typename E::v8;
-  constexpr int XTRA = tail_stage_extra(C, NW), PRM_OFF = NST * SLOT + XTRA;
+  constexpr int XTRA = STAGED ? tail_stage_extra(C, NW) : 0, PRM_OFF = NST * SLOT + XTRA;      // the lane-per-row form asks for no staging bytes
   float* prm = reinterpret_cast<float*>(lds + PRM_OFF);
   const float* s_pb = prm;
   const float* s_g2 = prm + C;
@@ -170,16 +170,18 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   const long nrows = p.gather ? p.n_tok : p.M;
   long rc = row < nrows ? row : nrows - 1;
   int tb, tloc;
+  // 32-bit unsigned divisions (row counts are int32 at the boundary): a 64-bit one is ~100 VALU instructions of a VALU-bound launch
+  const unsigned rcu = (unsigned)rc;
   if (p.gather) {
-    tb = (int)(rc / p.out_rows);
-    tloc = (int)(rc - (long)tb * p.out_rows);
+    tb = (int)(rcu / (unsigned)p.out_rows);
+    tloc = (int)(rcu - (unsigned)tb * (unsigned)p.out_rows);
     rc = (long)tb * p.map_rows + p.gather[tloc];           // the attention row of this token
   } else if (p.map) {
-    tb = (int)(rc / p.map_rows);
-    tloc = p.map[rc - (long)tb * p.map_rows];
+    tb = (int)(rcu / (unsigned)p.map_rows);
+    tloc = p.map[rcu - (unsigned)tb * (unsigned)p.map_rows];
   } else {
-    tb = (int)(rc / p.out_rows);
-    tloc = (int)(rc - (long)tb * p.out_rows);
+    tb = (int)(rcu / (unsigned)p.out_rows);
+    tloc = (int)(rcu - (unsigned)tb * (unsigned)p.out_rows);
   }
   const bool live = row < nrows && tloc >= 0;
   tloc = tloc < 0 ? 0 : tloc;
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     const float rstd = rsqrtf(sq / (float)C + p.eps);
     float mean_n = mean;
     asm volatile("" : "+v"(mean_n));   // an opaque copy: CSE with the variance pass would keep C/2 differences live (spills)
+    const float nmr = -mean_n * rstd;
     // normalised row -> B operands of fc1 (k order = accumulator order, see tail_pack_kernel); x1 stays in acc
 #pragma unroll
     for (int i = 0; i < CM; ++i)
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
         const f32x4 be = *reinterpret_cast<const f32x4*>(s_b2n + 32 * i + 8 * q + 4 * h);
         float y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mean_n) * rstd * g[e] + be[e];
+        for (int e = 0; e < 4; ++e) y[e] = fmaf(fmaf(acc[i][4 * q + e], rstd, nmr), g[e], be[e]);      // two fma per value: (x rstd - mean rstd) g + b
         u32x4 w = __builtin_bit_cast(u32x4, bx[2 * i + (q >> 1)]);
         w[2 * (q & 1)] = E::pack2(y[0], y[1]);
         w[2 * (q & 1) + 1] = E::pack2(y[2], y[3]);
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     const float rs = rsqrtf(sq / (float)C + p.eps);
     float mu_n = mu;
     asm volatile("" : "+v"(mu_n));
+    const float nmr2 = -mu_n * rs;
     // 16 bytes per lane: the lane pair (h = 0 | 1) of a token exchanges the 8-byte pieces of (q, q + 1) by v_permlane32_swap, lane h
     // then owns channels 8 (2 t + h) .. + 7 of a tile — half the row-divergent store instructions (one row per cycle in the addresser)
     const long drow = (long)tb * p.next_rows + p.next_dst[tloc];
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
           const f32x4 be = *reinterpret_cast<const f32x4*>(s_nn + C + 32 * i + 8 * q + 4 * h);
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mu_n) * rs * g[e] + be[e];
+          for (int e = 0; e < 4; ++e) y[e] = fmaf(fmaf(acc[i][4 * q + e], rs, nmr2), g[e], be[e]);
           u32x4 w = __builtin_bit_cast(u32x4, bx[2 * i + (q >> 1)]);
           w[2 * (q & 1)] = E::pack2(y[0], y[1]);
           w[2 * (q & 1) + 1] = E::pack2(y[2], y[3]);
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
           const f32x4 be = *reinterpret_cast<const f32x4*>(s_nn + C + 32 * i + 8 * q + 4 * h);
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (acc[i][4 * q + e] - mu_n) * rs * g[e] + be[e];
+          for (int e = 0; e < 4; ++e) y[e] = fmaf(fmaf(acc[i][4 * q + e], rs, nmr2), g[e], be[e]);
           pk[u][0] = E::pack2(y[0], y[1]);
           pk[u][1] = E::pack2(y[2], y[3]);
         }
@@ -602,8 +606,6 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
 template <typename E, int CM, int NW>
 static int launch_tail(const TailParams& p, hipStream_t st) {
   constexpr int C = 32 * CM, NST = tail_ring(C, NW), SLOT = tail_slot_bytes(C), XTRA = tail_stage_extra(C, NW);
-  const size_t lds = (size_t)NST * SLOT + XTRA + ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
-  KVQ_REQUIRE(lds <= (size_t)163840 / tail_bpc(C, NW), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
   // KVQ_TAIL_STAGED=1: the x / attention / norm1 rows travel as 128-byte row segments through an LDS transpose (round 5, the review's
   // "coalesced row traffic"; bit-identical results).  Built, tested and measured — and OFF by default: the C = 96 launches take 97.6 /
   // 88.5 us against 93.1 / 87.5, the C = 192 ones 86.3 / 77.6 against 87.4 / 80.3, the 4-lane C2 line 355.7 / 358.6 against 360.0 /
@@ -613,6 +615,8 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
   // the epilogue's four tiles need NW * 4 KB of ring slots (+ the extra bytes) that do not hold the last item
   const int NI = tail_proj_items(C) + 1 + p.hidden / 32, s_last = (NI - 1) % NST;
   const bool staged = staged_on && ((NST - 1 - s_last) * SLOT + XTRA >= NW * TAIL_STG || s_last * SLOT >= NW * TAIL_STG);
+  const size_t lds = (size_t)NST * SLOT + (staged ? XTRA : 0) + ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
+  KVQ_REQUIRE(lds <= (size_t)163840 / tail_bpc(C, NW), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, 32 * NW)), block(64 * NW);
   auto go = [&](auto k) -> int {
     KVQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

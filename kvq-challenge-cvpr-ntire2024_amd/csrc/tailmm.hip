@@ -253,16 +253,17 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_ke
     const long rc = row < nrows ? row : nrows - 1;
     arow[tt] = rc;
     int tb, tloc;
+    const unsigned rcu = (unsigned)rc;                 // 32-bit unsigned divisions: row counts are int32 at the boundary
     if (p.gather) {
-      tb = (int)(rc / p.out_rows);
-      tloc = (int)(rc - (long)tb * p.out_rows);
+      tb = (int)(rcu / (unsigned)p.out_rows);
+      tloc = (int)(rcu - (unsigned)tb * (unsigned)p.out_rows);
       arow[tt] = (long)tb * p.map_rows + p.gather[tloc];
     } else if (p.map) {
-      tb = (int)(rc / p.map_rows);
-      tloc = p.map[rc - (long)tb * p.map_rows];
+      tb = (int)(rcu / (unsigned)p.map_rows);
+      tloc = p.map[rcu - (unsigned)tb * (unsigned)p.map_rows];
     } else {
-      tb = (int)(rc / p.out_rows);
-      tloc = (int)(rc - (long)tb * p.out_rows);
+      tb = (int)(rcu / (unsigned)p.out_rows);
+      tloc = (int)(rcu - (unsigned)tb * (unsigned)p.out_rows);
     }
     live[tt] = row < nrows && tloc >= 0;
     tloc = tloc < 0 ? 0 : tloc;
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_ke
         for (int tt = 0; tt < 2; ++tt) {
           float y[8];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            y[i] = (acc[ft][tt][8 * hp + i] - mean[tt]) * rstd[tt] * g0[i] + e0[i];
-            y[4 + i] = (acc[ft][tt][8 * hp + 4 + i] - mean[tt]) * rstd[tt] * g1[i] + e1[i];
+          for (int i = 0; i < 4; ++i) {                // two fma per value: (x rstd - mean rstd) g + b
+            const float nmr = -mean[tt] * rstd[tt];
+            y[i] = fmaf(fmaf(acc[ft][tt][8 * hp + i], rstd[tt], nmr), g0[i], e0[i]);
+            y[4 + i] = fmaf(fmaf(acc[ft][tt][8 * hp + 4 + i], rstd[tt], nmr), g1[i], e1[i]);
           }
           const u32x4 w = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3]), E::pack2(y[4], y[5]), E::pack2(y[6], y[7])};
           const int ks = 2 * CF * wave + 2 * ft + hp;
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_ke
             const f32x4 gm = *reinterpret_cast<const f32x4*>(p.nn_w + f0), be = *reinterpret_cast<const f32x4*>(p.nn_b + f0);
             float y[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = (acc[ft][tt][4 * q + i] - mean[tt]) * rstd[tt] * gm[i] + be[i];
+            for (int i = 0; i < 4; ++i) y[i] = fmaf(fmaf(acc[ft][tt][4 * q + i], rstd[tt], -mean[tt] * rstd[tt]), gm[i], be[i]);
             pk[u][0] = E::pack2(y[0], y[1]);
             pk[u][1] = E::pack2(y[2], y[3]);
           }
