@@ -88,7 +88,7 @@ typedef struct {
   const uint16_t* fc2_w;   /* [C][4C] */
   const float* fc2_b;
   const void* tail_pack;   /* optional, derived: kvq_block_tail_pack image of (proj, norm2, fc1, fc2).  Non-NULL (and
-                              C in {96,128,192}) -> proj+residual+norm2+Mlp+residual run as ONE launch
+                              a fused width: kvq_block_tail_supported) -> proj+residual+norm2+Mlp+residual run as ONE launch
                               (kvq_block_tail); NULL -> GEMM/LayerNorm launches */
   const void* qkv_pack;    /* optional, derived: kvq_block_tail_qkv_pack image of THIS block's qkv_w.  Non-NULL -> the fused tail launch
                               of the PREVIOUS block of the stage writes this block's q | k | v itself (no norm1 rows, no qkv GEMM launch) */
@@ -351,7 +351,7 @@ typedef struct {
   float* x;                    /* fp32 [n_batch*out_rows][C] residual stream, updated in place           */
   const int32_t* scatter_map;  /* window row -> token within the batch element, <0 = padding; NULL = id. */
   int32_t map_rows, out_rows;  /* rows per batch element in the map / in x                               */
-  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192} (hidden % 64 == 0), 256, 384 or 512 (hidden = 4 C) */
+  int32_t M, C, hidden;        /* M = n_batch*map_rows window rows; C in {96,128,192} (hidden % 64 == 0), 256, 384, 512 or 768 (hidden = 4 C) */
   const void* pack;            /* kvq_block_tail_pack image                                              */
   const float* next_norm_w;    /* the following four: only with next_ln != NULL                          */
   const float* next_norm_b;
@@ -366,7 +366,7 @@ typedef struct {
                                   256x256: 1.2x .. 3x the rows) then do no work on padding rows.  scatter_map is not read. */
   /* Instead of next_ln (leave it NULL; next_norm_w / _b / next_dst / next_rows as above): the NEXT block's q | k | v (swin_backbone.py:
    * 252-260), head-major [3][num_heads][n_batch*next_rows][32] in its window order, q scaled by q_scale — what the qkv GEMM's
-   * KVQ_EPI_QKV_BF16 epilogue writes.  C with kvq_block_tail_qkv_pack_bytes(C, hidden) > 0 only (128 / 192 / 256 / 384 / 512). */
+   * KVQ_EPI_QKV_BF16 epilogue writes.  C with kvq_block_tail_qkv_pack_bytes(C, hidden) > 0 only (128 / 192 / 256 / 384 / 512 / 768). */
   const void* next_qkv_pack;   /* kvq_block_tail_qkv_pack image of the next block's qkv weight               */
   const float* next_qkv_b;     /* [3C]                                                                       */
   void* qkv_out;               /* 16-bit; non-NULL selects this form                                         */

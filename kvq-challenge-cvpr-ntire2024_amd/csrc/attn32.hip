@@ -591,7 +591,10 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
               "kvq_window_attention32: depth-split windows need the (8,7,7) window (N = 392); got N=%d from=%d", N, a->dsplit_from);
   const int units = BW * num_heads, nqb = (N + 31) / 32;
   int qsplit = units >= 768 ? 1 : 768 / units;        // 768 = 256 CUs x 3 resident workgroups
-  static const int qsplit_max = getenv("KVQ_ATTN_QSPLIT_MAX") ? atoi(getenv("KVQ_ATTN_QSPLIT_MAX")) : 4;      // A/B knob (results do not depend on it)
+  // Round 5: no q-split by default.  Splitting a (window, head) unit over 2-4 workgroups fills the chip when the launch is alone on it
+  // (stages 2-3: 384 / 192 units) and re-stages K | V in every part; in the 4-lane bench line the un-split form is +1.2 % (397.6 -> 402.2
+  // videos/s, three alternating pairs, profiles/r05_qsplit_streams_ab.txt): what counts there is CU x time.  KVQ_ATTN_QSPLIT_MAX=4: rounds 3-4.
+  static const int qsplit_max = getenv("KVQ_ATTN_QSPLIT_MAX") ? atoi(getenv("KVQ_ATTN_QSPLIT_MAX")) : 1;      // (results do not depend on it)
   qsplit = qsplit > qsplit_max ? qsplit_max : qsplit;
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,

@@ -56,11 +56,12 @@ struct MMc {
   static constexpr int OFF_RED = OFF_PRM + PRM_FLOATS * 4;              // [4 waves][64 tokens] fp32
   static constexpr int LDS = OFF_RED + 4 * MM_TOK * 4;
   static constexpr int WG_PER_CU = HC == 128 && 2 * LDS <= 163840 ? 2 : 1;
+  static constexpr bool PIPE = HC != 128;          // the MLP chunks software-pipelined in the wave (fc1 of chunk c + 1 ahead of fc2 of chunk c): the HC = 256 forms
   // packed image: 4 waves x NF KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
   static constexpr size_t PACK_FRAG_BYTES = (size_t)4 * NF * 1024;
   // register ring: every phase consumes a multiple of VR_R fragments (72 | 48 | 48 of 24; 128 | 64 | 64 of 16 — 32 slots at C = 512
   // spill: 128 + 64 accumulator registers are there already; HC = 128: 72 | 24 | 24 of 12)
-  static constexpr int VR_R = HC == 128 ? (CF == 3 ? 12 : 8) : (CF == 3 ? 24 : 16), VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
+  static constexpr int VR_R = HC == 128 ? (CF == 3 ? 12 : CF == 6 ? 16 : 8) : (CF == 3 ? 24 : 16), VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
   static_assert(NF_PROJ % VR_R == 0 && NF_FC1 % VR_R == 0 && NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
   static_assert(LDS <= 163840, "LDS");
 };
@@ -72,11 +73,20 @@ static int tailmm_hc(int C) {
   return C == 384 && env == 128 ? 128 : 256;
 }
 
-bool tailmm_supported(int C, int hidden) { return (C == 256 || C == 384 || C == 512) && hidden == 4 * C; }
+// C = 768 (round 5: stage 3 of Swin-T / -S; CF = 6, HC = 128, one workgroup per CU: 137 KB of LDS, 192 accumulator registers per wave).  At
+// 4 clips it is a launch of 49 workgroups that takes 193-254 us where the GEMM / LayerNorm launches it replaces take 115 us ALONE on the
+// chip — and the 4-lane bench line gains 4.5 % (370.9 / 373.3 / 368.3 -> 389.5 / 386.4 / 386.1 videos/s, same box, alternating;
+// profiles/r05_tail768_ab.txt): in the mix what a launch costs is CU x time, not its latency, and 49 busy CUs for 250 us are a third of
+// five thin launches spread over the chip.  KVQ_TAILMM_768=0: the GEMM chain.
+static bool tailmm_768() {
+  static const bool on = !(getenv("KVQ_TAILMM_768") && atoi(getenv("KVQ_TAILMM_768")) == 0);
+  return on;
+}
+bool tailmm_supported(int C, int hidden) { return (C == 256 || C == 384 || C == 512 || (C == 768 && tailmm_768())) && hidden == 4 * C; }
 size_t tailmm_pack_bytes(int C, int hidden) {
   if (!tailmm_supported(C, hidden)) return 0;
   const size_t frag = C == 384 ? (tailmm_hc(C) == 128 ? MMc<3, 128>::PACK_FRAG_BYTES : MMc<3>::PACK_FRAG_BYTES)
-                      : C == 512 ? MMc<4>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
+                      : C == 512 ? MMc<4>::PACK_FRAG_BYTES : C == 768 ? MMc<6, 128>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
   return frag + (((size_t)(hidden + 4 * C) * 4 + 255) & ~(size_t)255);
 }
 
@@ -108,7 +118,7 @@ __global__ void tailmm_pack_kernel(const uint16_t* wp, const uint16_t* w1, const
         // consumption order behind proj: fc1(0); then fc1(c+1), fc2(c) for c = 0..4; then fc2(5) — the wave's software pipeline
         const int r = f - MM_NF_PROJ;
         int c, q;
-        if (K::WG_PER_CU == 2) {                             // not software-pipelined: fc1(c), fc2(c), fc1(c + 1), ...
+        if (!K::PIPE) {                                       // not software-pipelined: fc1(c), fc2(c), fc1(c + 1), ...
           c = r / (MM_NF_FC1 + MM_NF_FC2); q = r % (MM_NF_FC1 + MM_NF_FC2);
         } else if (r < MM_NF_FC1) { c = 0; q = r; }
         else {
@@ -149,6 +159,7 @@ static void launch_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* 
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st) {
   if (C == 512) launch_pack<4, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
+  else if (C == 768) launch_pack<6, 128>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   else if (C == 256) launch_pack<2, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   else if (tailmm_hc(C) == 128) launch_pack<3, 128>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   else launch_pack<3, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
@@ -184,6 +195,7 @@ int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out
   const long total = (long)tailmm_qkv_pack_bytes(C, hidden) / 16;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (C == 512) hipLaunchKernelGGL(tailmm_qkv_pack_kernel<4>, grid, block, 0, st, qkv_w, out);
+  else if (C == 768) hipLaunchKernelGGL(tailmm_qkv_pack_kernel<6>, grid, block, 0, st, qkv_w, out);
   else if (C == 256) hipLaunchKernelGGL(tailmm_qkv_pack_kernel<2>, grid, block, 0, st, qkv_w, out);
   else hipLaunchKernelGGL(tailmm_qkv_pack_kernel<3>, grid, block, 0, st, qkv_w, out);
   KVQ_CHECK_LAUNCH("tailmm_qkv_pack_kernel");
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_ke
         for (int tt = 0; tt < 2; ++tt)
           *reinterpret_cast<u32x4*>(lds + MM_OFF_G + ((2 * HT * wave + 2 * ft + hp) * 2 + tt) * 1024 + lane * 16) = gp[ft][hp][tt];
   };
-  if constexpr (K::WG_PER_CU == 2) {
+  if constexpr (!K::PIPE) {
     // two workgroups per CU: the other workgroup's MFMAs run under this one's GELU, so the chunks are NOT software-pipelined in the
     // wave (fc1(c + 1) ahead of fc2(c) keeps acc + hacc + the packed GELU outputs + the ring + two bodies of fragments live at
     // once: 64 registers past the 256 of two waves per SIMD, spilled and reloaded in the loop)
@@ -617,6 +629,7 @@ static int launch_mm_cf(const TailParams& p, hipStream_t st) {
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
   if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
+  if (C == 768) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 6, 128>(p, st) : launch_mm_cf<Bf16, 6, 128>(p, st);
   if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
   if (tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3, 128>(p, st) : launch_mm_cf<Bf16, 3, 128>(p, st);
   return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3>(p, st) : launch_mm_cf<Bf16, 3>(p, st);

@@ -1,6 +1,8 @@
 """GPU parity, kernel by kernel: every C-ABI entry point against the CPU oracle on the same
 seeded inputs.  Tolerances are stated per test: integer/byte work is bit-exact; bf16-operand
 MFMA work is compared against fp32 math on the *same bf16-rounded operands*."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -769,7 +771,8 @@ def _tail_reference(A, x, wts, half, lay, B, dims):
                                                    (256, (8, 14, 7), (4, 3, 3), (0, 0, 0)),    # stage 1 of Swin-B: tailmm, CF = 2
                                                    (256, (4, 10, 9), (4, 3, 3), None),
                                                    (512, (8, 14, 7), (0, 0, 0), (4, 3, 3)),    # stage 2 of Swin-B: tailmm, CF = 4
-                                                   (512, (4, 10, 9), (4, 3, 3), None)])
+                                                   (512, (4, 10, 9), (4, 3, 3), None),
+                                                   (768, (16, 7, 7), (0, 0, 0), (4, 0, 0))])
 def test_block_tail(C, dims, shift, nxt_shift, half):
     g = rng(C + sum(dims))
     D, H, W = dims
@@ -818,7 +821,8 @@ def test_block_tail(C, dims, shift, nxt_shift, half):
 @pytest.mark.parametrize("C,dims,shift,nxt_shift", [(384, (8, 14, 14), (0, 0, 0), (4, 3, 3)), (384, (16, 14, 14), (4, 3, 3), (0, 0, 0)),
                                                     (256, (8, 7, 7), (0, 0, 0), (0, 0, 0)), (512, (8, 14, 7), (0, 0, 0), (4, 3, 0)),
                                                     (192, (8, 14, 14), (0, 0, 0), (4, 3, 3)), (192, (16, 28, 28), (4, 3, 3), (0, 0, 0)),
-                                                    (128, (8, 14, 7), (0, 0, 0), (4, 3, 0))])
+                                                    (128, (8, 14, 7), (0, 0, 0), (4, 3, 0)),
+                                                    (768, (16, 7, 7), (0, 0, 0), (4, 0, 0))])
 def test_block_tail_emits_next_qkv(C, dims, shift, nxt_shift, half):
     """The fused tail (C = 128 / 192: token per lane; C = 256 / 384 / 512: feature-sliced) writing the NEXT block's q | k | v itself (swin_backbone.py:252-260 of block b + 1:
     norm1 -> qkv Linear -> head split, q scaled) against LayerNorm + the qkv GEMM launch on the launch's own residual output: the
@@ -874,10 +878,10 @@ def test_block_tail_identity_map_and_unsupported(half):
     kernels.block_tail(dev(A, half), xd, pack, hidden)
     ref = _tail_reference(A, x, (Wp, bp, g2, b2n, W1, b1, W2, b2), half, None, 1, None)
     assert (xd.cpu() - ref).abs().max().item() <= 6 * EPS[half] * ref.abs().max().item() + 1e-4
-    assert _abi.lib().kvq_block_tail_pack_bytes(768, 3072) == 0
+    assert _abi.lib().kvq_block_tail_pack_bytes(1024, 4096) == 0
     with pytest.raises(_abi.KvqError, match="unsupported"):
         kernels.block_tail_pack(*(dev(torch.zeros(s), half if len(s) == 2 else None) for s in
-                                  [(768, 768), (768,), (768,), (768,), (3072, 768), (3072,), (768, 3072), (768,)]))
+                                  [(1024, 1024), (1024,), (1024,), (1024,), (4096, 1024), (4096,), (1024, 4096), (1024,)]))
 
 
 # ------------------------------------------------------------------ fused PatchEmbed3D (embed.hip)
