@@ -13,6 +13,8 @@
 // fs_h x fs_w mini-patch, so its rows are two 4-byte runs of a source row) and is normalised in registers with the same
 // IEEE fp32 (v - mean) / std as kvq_fragment_gather — the operands are bit-identical to the two-launch sequence, which
 // wrote the fp32 clip (4 B/px) and read it back (4 B/px).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace kvq {
@@ -93,9 +95,12 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
   for (int q = wave; q < NQ; q += 4)
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.pack + q * 1024 + lane * 16), (lds_ptr_t)(lds + q * 1024), 16, 0, 0);
 
-  // this lane's token and its patch rows
+  // a workgroup walks tiles of 128 tokens blockIdx.x, + gridDim.x, ... (round 5: a launch of fewer, longer-lived workgroups — the weights
+  // reach LDS once per workgroup, and in the multi-lane mix the launch holds fewer CU slots while it streams its 200 MB)
   const long L0 = (long)p.D0 * p.H0 * p.W0, total = (long)p.B * L0;
-  const long row = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+  for (long tile = blockIdx.x; tile * 128 < total; tile += gridDim.x) {
+  const bool first_tile = tile == (long)blockIdx.x;
+  const long row = tile * 128 + wave * 32 + (lane & 31);
   const long rc = row < total ? row : total - 1;
   const int b = (int)(rc / L0);
   const int tl = (int)(rc - (long)b * L0);
@@ -126,7 +131,8 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
     }
     // a pixel is one of 256 bytes: (v - mean) / std — the IEEE fp32 divide of fragment_gather_kernel — once per byte value
     // and channel (Cin divides per thread) instead of once per pixel (8 * KS per lane); looked up below, behind the barrier
-    for (int c = 0; c < p.Cin; ++c) s_tab[c * 256 + tid] = ((float)tid - f.mean[c]) / f.std[c];
+    if (first_tile)
+      for (int c = 0; c < p.Cin; ++c) s_tab[c * 256 + tid] = ((float)tid - f.mean[c]) / f.std[c];
   } else {
     const size_t plane = (size_t)p.H * p.W;
     const float* base = p.x + (size_t)b * p.Cin * p.T * plane + (size_t)(d * p.pd) * plane + (size_t)(hh * 4 + 2 * h) * p.W + ww * 4;
@@ -140,9 +146,11 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
       bx[s] = __builtin_bit_cast(V8, w);
     }
   }
-  if (EMIT && tid < E / 2) *reinterpret_cast<f32x4*>(s_nn + 4 * tid) = nn_reg;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (first_tile) {
+    if (EMIT && tid < E / 2) *reinterpret_cast<f32x4*>(s_nn + 4 * tid) = nn_reg;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if constexpr (FRAG) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(mine + 128 * i + 32 * q) = (f32x4){acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-    const long row0 = (long)blockIdx.x * 128 + wave * 32;
+    const long row0 = tile * 128 + wave * 32;
     const int nrow = (int)(total - row0 < 32 ? total - row0 : 32);        // <= 0: nothing of this wave is live
     unsigned char* gb = reinterpret_cast<unsigned char*>(p.out + (size_t)row0 * E);
 #pragma unroll
@@ -264,13 +272,17 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
         if (live) *reinterpret_cast<u32x4*>(o + 32 * i + 8 * (2 * t + h)) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
       }
   }
+  }      // tiles
 }
 
 template <typename E_, int CM, int KS>
 static int launch_embed(const EmbedParams& p, hipStream_t st) {
   const int lds = embed_stage_off(CM, KS) + (embed_staged(CM, p.x == nullptr) ? 4 * 32 * (32 * CM * 4 + 16) : 0);
   const long total = (long)p.B * p.D0 * p.H0 * p.W0;
-  dim3 grid((unsigned)((total + 127) / 128)), block(256);
+  // KVQ_EMBED_WGS: workgroups of the launch (each walks tiles of 128 tokens); 0 = one per tile (rounds 1-4)
+  static const long wgs = getenv("KVQ_EMBED_WGS") ? atol(getenv("KVQ_EMBED_WGS")) : 0;
+  const long ntile = (total + 127) / 128;
+  dim3 grid((unsigned)(wgs > 0 && wgs < ntile ? wgs : ntile)), block(256);
   auto go = [&](auto k) -> int {
     LdsOptIn opt;                             // the opt-in is remembered per (kernel, device) in common.cpp
     if (int rc = opt.ensure(reinterpret_cast<const void*>(k), lds)) return rc;
