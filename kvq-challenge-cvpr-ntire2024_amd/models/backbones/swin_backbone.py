@@ -546,10 +546,10 @@ class SwinTransformer3D(nn.Module):
                 sym = f"patch_merge_kernel<{ename}, {str(bool(r.variant)).lower()}>"
             elif kind == "tail":
                 cm = r.variant // 10
-                emit = str(bool(r.variant % 10)).lower()
-                sym = f"block_tail_kernel<{ename}, {cm}, 4, {emit}>"
-                if cm in (8, 12, 16):     # C = 256 / 384 / 512: csrc/tailmm.hip (feature-sliced GEMM chain, register weight ring)
-                    sym = f"block_tailmm_kernel<{ename}, {emit}, {cm // 4}>"
+                mode = r.variant % 10          # 0: x only, 1: + the next block's norm1 rows, 2: + the next block's q | k | v
+                sym = f"block_tail_kernel<{ename}, {cm}, 4, {mode}, false>"
+                if cm in (8, 12, 16, 24):     # C = 256 / 384 / 512 / 768: csrc/tailmm.hip (feature-sliced GEMM chain, register weight ring)
+                    sym = f"block_tailmm_kernel<{ename}, {mode}, {cm // 4}, {128 if cm in (12, 24) else 256}>"
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))
