@@ -594,7 +594,7 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
   // Round 5: no q-split by default.  Splitting a (window, head) unit over 2-4 workgroups fills the chip when the launch is alone on it
   // (stages 2-3: 384 / 192 units) and re-stages K | V in every part; in the 4-lane bench line the un-split form is +1.2 % (397.6 -> 402.2
   // videos/s, three alternating pairs, profiles/r05_qsplit_streams_ab.txt): what counts there is CU x time.  KVQ_ATTN_QSPLIT_MAX=4: rounds 3-4.
-  static const int qsplit_max = getenv("KVQ_ATTN_QSPLIT_MAX") ? atoi(getenv("KVQ_ATTN_QSPLIT_MAX")) : 1;      // (results do not depend on it)
+  static const int qsplit_max = getenv("KVQ_ATTN_QSPLIT_MAX") ? atoi(getenv("KVQ_ATTN_QSPLIT_MAX")) : (latency_mode() ? 4 : 1);      // (results do not depend on it)
   qsplit = qsplit > qsplit_max ? qsplit_max : qsplit;
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,

@@ -1,6 +1,7 @@
 // Host-side error plumbing + misc C-ABI entry points.
 #include "common.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -35,6 +36,10 @@ int LdsOptIn::ensure(const void* kernel, int want) {
   KVQ_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want));
   have = want;
   return KVQ_OK;
+}
+bool latency_mode() {
+  static const bool on = getenv("KVQ_LATENCY") && atoi(getenv("KVQ_LATENCY")) == 1;
+  return on;
 }
 }  // namespace kvq
 

@@ -157,6 +157,12 @@ struct LdsOptIn {
   int ensure(const void* kernel, int want);      // KVQ_OK, or the HIP failure
 };
 
+// KVQ_LATENCY=1: the launch geometries that are fastest for ONE step alone on the chip (q-split attention at the late stages, the
+// stage-3 GEMM chain, the C = 384 tail at one 512-VGPR workgroup per CU) instead of the defaults, which minimise CU x time for several
+// steps in flight on HIP streams (one stream 279 -> 245 videos/s, four lanes 356 -> 407).  Results are identical up to the
+// rounding points that differ between a fused tail and the GEMM chain; each choice also has its own knob.
+bool latency_mode();
+
 // shape limits of the fused fast-pathway stem (conv.hip::kvq_conv_stem_pool), pointer alignment aside
 bool stem_pool_shape_ok(int B, int T, int H, int W, int kd);
 

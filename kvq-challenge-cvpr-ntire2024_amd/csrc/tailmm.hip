@@ -69,7 +69,7 @@ struct MMc {
 // KVQ_TAILMM_HC=256 takes rounds 2-4's one-workgroup-per-CU form at C = 384 (A/B runs); read once — the packed image and the launch
 // must agree.  C = 256 / 512 keep HC = 256 (C = 512: 2 x 97 KB does not fit; C = 256 is not on any benchmarked path).
 static int tailmm_hc(int C) {
-  static const int env = getenv("KVQ_TAILMM_HC") ? atoi(getenv("KVQ_TAILMM_HC")) : 128;
+  static const int env = getenv("KVQ_TAILMM_HC") ? atoi(getenv("KVQ_TAILMM_HC")) : (latency_mode() ? 256 : 128);
   return C == 384 && env == 128 ? 128 : 256;
 }
 
@@ -79,7 +79,7 @@ static int tailmm_hc(int C) {
 // profiles/r05_tail768_ab.txt): in the mix what a launch costs is CU x time, not its latency, and 49 busy CUs for 250 us are a third of
 // five thin launches spread over the chip.  KVQ_TAILMM_768=0: the GEMM chain.
 static bool tailmm_768() {
-  static const bool on = !(getenv("KVQ_TAILMM_768") && atoi(getenv("KVQ_TAILMM_768")) == 0);
+  static const bool on = getenv("KVQ_TAILMM_768") ? atoi(getenv("KVQ_TAILMM_768")) != 0 : !latency_mode();
   return on;
 }
 bool tailmm_supported(int C, int hidden) { return (C == 256 || C == 384 || C == 512 || (C == 768 && tailmm_768())) && hidden == 4 * C; }

@@ -15,6 +15,7 @@ void set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(std
 int hip_fail(hipError_t e, const char* w) { fprintf(stderr, "HIP %s: %s\n", w, hipGetErrorString(e)); return -1; }
 int LdsOptIn::ensure(const void* kernel, int want) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess ? 0 : -1; }
 bool stem_pool_shape_ok(int, int, int, int, int) { return false; }
+bool latency_mode() { return false; }
 unsigned long long* g_trace = nullptr;
 int g_trace_blocks = 0;
 }
