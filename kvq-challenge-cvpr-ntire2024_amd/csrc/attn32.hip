@@ -50,7 +50,7 @@ constexpr int A32_KB = 13;                         // 32-key blocks: 416 key pos
 constexpr int A32_ROWS = 400;                      // key rows the LDS images hold; rows 400..415 of the 13th block come from the zero block
 constexpr int A32_K_BYTES = A32_ROWS * 64;         // 25 600: K rows (XOR-swizzled 16-B chunks), then as many of V (row-major)
 constexpr int A32_SLOT = 2 * A32_K_BYTES;
-constexpr int A32_WAVES = 4;
+constexpr int A32_WAVES_DEFAULT = 4;
 constexpr int A32_OFF_ZERO = A32_SLOT;             // 1 KB of zeros, then the q-block ticket
 constexpr int A32_OFF_CTR = A32_OFF_ZERO + 1024;
 constexpr int A32_LDS = A32_OFF_CTR + 16;          // 52 240 B: three workgroups per CU
@@ -279,7 +279,7 @@ struct Attn32Params {
 // v_mfma_f32_16x16x32 — a lane ends up with 4 consecutive features of one row: + bias (q: x q_scale), the 16-bit rounding the qkv GEMM's
 // epilogue applies, then 8 bytes into the K image (rows of 64 B, 16-B chunks XOR-swizzled by (row >> 2) & 3), the V image (plain rows) or
 // the q scratch.  Wave w takes row tiles w, w + 4, ...; all six 16-feature column tiles (q0 q1 k0 k1 v0 v1) in one pass over the rows.
-template <typename E, int KS>
+template <typename E, int KS, int NW>
 __device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned char* slot, int bw, int h, int N) {
   using V8 = typename E::v8;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
@@ -307,13 +307,13 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned ch
     for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
   }
 #pragma unroll 1
-  for (int rt = wave; rt < nrt; rt += A32_WAVES) {
+  for (int rt = wave; rt < nrt; rt += NW) {
     const int row = 16 * rt + j;
     V8 xf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = xn[ks];
-    if (rt + A32_WAVES < nrt) {                                   // the next tile's rows are requested before this one is multiplied
-      const int rowc = min(row + 16 * A32_WAVES, N - 1);
+    if (rt + NW < nrt) {                                   // the next tile's rows are requested before this one is multiplied
+      const int rowc = min(row + 16 * NW, N - 1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) xn[ks] = *reinterpret_cast<const V8*>(xw + (size_t)rowc * C + 32 * ks + 8 * g);
     }
@@ -339,8 +339,12 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned ch
   }
 }
 
-template <typename E, bool FUSED, bool DSPLIT>
-__global__ __launch_bounds__(A32_WAVES * 64, 3) void window_attention32_kernel(Attn32Params p) {
+// NW = 4: three workgroups per CU (rounds 4-5).  NW = 8 (round 5 experiment, KVQ_ATTN_WAVES): one workgroup of eight waves per CU — the 13
+// q-blocks of a unit spread over twice the waves (half the latency of a unit without re-staging K | V, as a q-split would), 52 KB of LDS per
+// CU instead of 156; the register budget stays that of three waves per SIMD so that another kernel's waves fit beside it.
+template <typename E, bool FUSED, bool DSPLIT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_waves_per_eu(3, 3))) void window_attention32_kernel(Attn32Params p) {
+  constexpr int A32_WAVES = NW;
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* ticket = reinterpret_cast<int*>(smem + A32_OFF_CTR);
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(A32_WAVES * 64, 3) void window_attention32_kernel(A
     // rows N..399 of both images: zeros (the projection writes rows < N only)
     for (int i = tid; i < (A32_ROWS - N) * 8; i += A32_WAVES * 64)
       *reinterpret_cast<u32x4*>(smem + (i & 4 ? A32_K_BYTES : 0) + (N + (i >> 3)) * 64 + (i & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
-    a32_fused_qkv<E, 3>(p, smem, bw, h, N);
+    a32_fused_qkv<E, 3, NW>(p, smem, bw, h, N);
   } else {
     // K | V by buffer-resource LDS-DMA (rows past N read zeros): K with its 16-B chunks XOR-swizzled by (row >> 2) & 3, V as it lies
     const uint16_t* Kg = p.qkv + ((size_t)(1 * p.nH + h) * Mtot + (size_t)bw * N) * 32;
@@ -537,17 +541,28 @@ __global__ __launch_bounds__(256) void bias32_build_kernel(Bias32BuildParams p) 
   }
 }
 
-template <typename E, bool FUSED, bool DSPLIT>
-static int launch_attn32(const Attn32Params& p, hipStream_t st) {
-  auto kern = window_attention32_kernel<E, FUSED, DSPLIT>;
+template <typename E, bool FUSED, bool DSPLIT, int NW>
+static int launch_attn32_nw(const Attn32Params& p, hipStream_t st) {
+  auto kern = window_attention32_kernel<E, FUSED, DSPLIT, NW>;
+  // KVQ_ATTN_LDS_PAD (A/B knob): extra dynamic LDS bytes per workgroup — 2048 makes it two workgroups per CU instead of three
+  static const int lds_pad = getenv("KVQ_ATTN_LDS_PAD") ? atoi(getenv("KVQ_ATTN_LDS_PAD")) : 0;
+  const int lds_bytes = A32_LDS + lds_pad;
   static LdsOptIn opt;
-  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), A32_LDS)) return rc;
+  if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes)) return rc;
   const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH;
   unsigned grid = (unsigned)(8 * ceil_div(npair, 8) * nclip * nrep * p.qsplit);
   if (FUSED) grid = (unsigned)(8 * ceil_div(p.n_types, 8) * p.nH * nclip * nrep);      // XCDs take whole window types
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(A32_WAVES * 64), A32_LDS, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, st, p);
   KVQ_CHECK_LAUNCH("window_attention32_kernel");
   return KVQ_OK;
+}
+
+template <typename E, bool FUSED, bool DSPLIT>
+static int launch_attn32(const Attn32Params& p, hipStream_t st) {
+  // KVQ_ATTN_WAVES: 4 (default) | 8 | 0 = eight waves where the launch holds fewer than 768 units (stages 2-3 at 4 clips)
+  static const int nw_env = getenv("KVQ_ATTN_WAVES") ? atoi(getenv("KVQ_ATTN_WAVES")) : 4;
+  const bool eight = nw_env == 8 || (nw_env == 0 && (long)p.BW * p.nH < 768);
+  return eight ? launch_attn32_nw<E, FUSED, DSPLIT, 8>(p, st) : launch_attn32_nw<E, FUSED, DSPLIT, 4>(p, st);
 }
 
 template <typename E>

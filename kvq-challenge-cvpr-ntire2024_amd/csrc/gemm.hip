@@ -508,7 +508,8 @@ static int launch_maybe_split(const GemmParams& p, hipStream_t st) {
   long tiles;
   int nk, bk;
   variant_tiles(p.M, p.N, p.K, CONV, &tiles, &nk, &bk);
-  const int S = (EPI != KVQ_EPI_QKV_BF16 && p.sk_ws) ? splitk_factor(tiles, nk, bk) : 1;
+  static const bool splitk_on = !(getenv("KVQ_SPLITK") && atoi(getenv("KVQ_SPLITK")) == 0);      // A/B knob (round 5): 0 = never split K
+  const int S = (splitk_on && EPI != KVQ_EPI_QKV_BF16 && p.sk_ws) ? splitk_factor(tiles, nk, bk) : 1;
   if (S > 1 && (size_t)S * p.M * p.N * sizeof(float) <= p.sk_bytes) {
     GemmParams q = p;
     q.bias = nullptr; q.out_f32 = p.sk_ws; q.out_h = nullptr; q.scatter_map = nullptr; q.resid_h = nullptr; q.resid_f32 = nullptr;
