@@ -56,20 +56,28 @@ struct MMc {
   static constexpr int OFF_RED = OFF_PRM + PRM_FLOATS * 4;              // [4 waves][64 tokens] fp32
   static constexpr int LDS = OFF_RED + 4 * MM_TOK * 4;
   static constexpr int WG_PER_CU = HC == 128 && 2 * LDS <= 163840 ? 2 : 1;
+  // register budget in waves per SIMD: the HC = 128 forms up to C = 512 keep to 256 VGPRs so that another workgroup (C = 384: of this launch;
+  // C = 512, 97 KB of LDS: of another lane's launch) fits beside them; C = 768 needs 192 accumulator registers and takes the whole file
+  static constexpr int REG_WAVES = HC == 128 && CF <= 4 ? 2 : 1;
   static constexpr bool PIPE = HC != 128;          // the MLP chunks software-pipelined in the wave (fc1 of chunk c + 1 ahead of fc2 of chunk c): the HC = 256 forms
   // packed image: 4 waves x NF KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
   static constexpr size_t PACK_FRAG_BYTES = (size_t)4 * NF * 1024;
   // register ring: every phase consumes a multiple of VR_R fragments (72 | 48 | 48 of 24; 128 | 64 | 64 of 16 — 32 slots at C = 512
   // spill: 128 + 64 accumulator registers are there already; HC = 128: 72 | 24 | 24 of 12)
-  static constexpr int VR_R = HC == 128 ? (CF == 3 ? 12 : CF == 6 ? 16 : 8) : (CF == 3 ? 24 : 16), VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
+  static constexpr int VR_R = HC == 128 ? (CF == 3 ? 12 : CF >= 4 ? 16 : 8) : (CF == 3 ? 24 : 16), VR_PF = VR_R - 4;      // (C = 256: 32 | 32 | 32 fragments per phase)
   static_assert(NF_PROJ % VR_R == 0 && NF_FC1 % VR_R == 0 && NF_FC2 % VR_R == 0, "every phase starts at register slot 0");
   static_assert(LDS <= 163840, "LDS");
 };
 
 // KVQ_TAILMM_HC=256 takes rounds 2-4's one-workgroup-per-CU form at C = 384 (A/B runs); read once — the packed image and the launch
-// must agree.  C = 256 / 512 keep HC = 256 (C = 512: 2 x 97 KB does not fit; C = 256 is not on any benchmarked path).
+// must agree.  C = 512 (Swin-B stage 2, the C5 line) takes HC = 128 too: 2 x 97 KB of LDS do not fit, so it is still one workgroup of
+// this launch per CU, but at 256 registers and no spills (HC = 256 at C = 512: 512 registers, 8 / 17 / 115 spilled by MODE) a workgroup
+// of another lane's launch fits beside it — C5 22.98 -> 23.46 videos/s, same box, alternating (profiles/r05_hc512_ab.txt);
+// KVQ_TAILMM_HC512=256 is the old form.  C = 256 keeps HC = 256 (not on any benchmarked path).
 static int tailmm_hc(int C) {
   static const int env = getenv("KVQ_TAILMM_HC") ? atoi(getenv("KVQ_TAILMM_HC")) : (latency_mode() ? 256 : 128);
+  static const int env512 = getenv("KVQ_TAILMM_HC512") ? atoi(getenv("KVQ_TAILMM_HC512")) : (latency_mode() ? 256 : 128);
+  if (C == 512) return env512 == 128 ? 128 : 256;
   return C == 384 && env == 128 ? 128 : 256;
 }
 
@@ -86,7 +94,7 @@ bool tailmm_supported(int C, int hidden) { return (C == 256 || C == 384 || C == 
 size_t tailmm_pack_bytes(int C, int hidden) {
   if (!tailmm_supported(C, hidden)) return 0;
   const size_t frag = C == 384 ? (tailmm_hc(C) == 128 ? MMc<3, 128>::PACK_FRAG_BYTES : MMc<3>::PACK_FRAG_BYTES)
-                      : C == 512 ? MMc<4>::PACK_FRAG_BYTES : C == 768 ? MMc<6, 128>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
+                      : C == 512 ? (tailmm_hc(C) == 128 ? MMc<4, 128>::PACK_FRAG_BYTES : MMc<4>::PACK_FRAG_BYTES) : C == 768 ? MMc<6, 128>::PACK_FRAG_BYTES : MMc<2>::PACK_FRAG_BYTES;
   return frag + (((size_t)(hidden + 4 * C) * 4 + 255) & ~(size_t)255);
 }
 
@@ -158,7 +166,8 @@ static void launch_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* 
 
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st) {
-  if (C == 512) launch_pack<4, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
+  if (C == 512 && tailmm_hc(C) == 128) launch_pack<4, 128>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
+  else if (C == 512) launch_pack<4, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   else if (C == 768) launch_pack<6, 128>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   else if (C == 256) launch_pack<2, 256>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
   else if (tailmm_hc(C) == 128) launch_pack<3, 128>(wp, w1, w2, proj_b, n2w, n2b, b1, b2, out, st);
@@ -211,7 +220,7 @@ int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out
 // in a register handed on).  (Round 2 also carried an LDS-ring form of the stream and ablation builds of it — no weight stream 65 us,
 // no MFMAs 57, neither 43 of 78 — removed in round 3: 79 -> 73 us with the next norm1, 73 -> 64 without, bit-identical.)
 template <typename E, int MODE, int CF = 3, int HC = 256>      // MODE 0: x only; 1: + the next block's norm1 rows; 2: + the next block's q | k | v
-__global__ __launch_bounds__(256, (MMc<CF, HC>::WG_PER_CU)) void block_tailmm_kernel(TailParams p) {
+__global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_kernel(TailParams p) {
   constexpr bool EMIT = MODE == 1, QKV = MODE == 2;
   using K = MMc<CF, HC>;
   constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_KS_C = K::KS_C, MM_NF = K::NF, VR_R = K::VR_R, VR_PF = K::VR_PF, FW = K::W;
@@ -628,6 +637,7 @@ static int launch_mm_cf(const TailParams& p, hipStream_t st) {
 
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
+  if (C == 512 && tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4, 128>(p, st) : launch_mm_cf<Bf16, 4, 128>(p, st);
   if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
   if (C == 768) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 6, 128>(p, st) : launch_mm_cf<Bf16, 6, 128>(p, st);
   if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
