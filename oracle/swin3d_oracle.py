@@ -181,16 +181,22 @@ def scatter_windows(o: torch.Tensor, layout, B: int, D: int, H: int, W: int) -> 
 
 
 def window_attention(xw: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, num_heads: int,
-                     window, layout, chunk: int = 64, q=_ident) -> torch.Tensor:
-    """xw (B*nW,N,C) -> (B*nW,N,C).  Implements SURVEY.md App. A item 3.  ``q`` = operand rounding."""
+                     window, layout, chunk: int = 64, q=_ident, kernel_order: bool = False) -> torch.Tensor:
+    """xw (B*nW,N,C) -> (B*nW,N,C).  Implements SURVEY.md App. A item 3.  ``q`` = operand rounding; ``kernel_order`` (emulation only):
+    the softmax at csrc/attn32.hip's rounding points (``attention_core_kernel_order``)."""
     BW, N, C = xw.shape
     hd = C // num_heads
     qkv = F.linear(xw, q(p[pre + "qkv.weight"]), p[pre + "qkv.bias"]).reshape(BW, N, 3, num_heads, hd)
-    qq = q(qkv[:, :, 0].permute(0, 2, 1, 3) * (hd ** -0.5))
     k = q(qkv[:, :, 1].permute(0, 2, 1, 3))
     v = q(qkv[:, :, 2].permute(0, 2, 1, 3))
-    out = q(attention_core(qq, k, v, p[pre + "relative_position_bias_table"],
-                           p.get(pre + "fragment_position_bias_table"), window, layout, chunk, q))
+    if kernel_order:
+        qq = q(qkv[:, :, 0].permute(0, 2, 1, 3) * np.float32(hd ** -0.5 * 1.4426950408889634))
+        out = q(attention_core_kernel_order(qq, k, v, p[pre + "relative_position_bias_table"],
+                                            p.get(pre + "fragment_position_bias_table"), window, layout, q, chunk))
+    else:
+        qq = q(qkv[:, :, 0].permute(0, 2, 1, 3) * (hd ** -0.5))
+        out = q(attention_core(qq, k, v, p[pre + "relative_position_bias_table"],
+                               p.get(pre + "fragment_position_bias_table"), window, layout, chunk, q))
     return F.linear(out, q(p[pre + "proj.weight"]), p[pre + "proj.bias"])
 
 
@@ -253,12 +259,49 @@ def attention_core(q, k, v, rpb_table, fpb_table, window, layout, chunk: int = 6
     return out
 
 
-def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift, q=_ident) -> torch.Tensor:
+def attention_core_kernel_order(qk2, k, v, rpb_table, fpb_table, window, layout, rq, chunk: int = 64,
+                                block: int = 32, thr: float = 8.0) -> torch.Tensor:
+    """The softmax core at the ROUNDING POINTS of csrc/attn32.hip (test infrastructure for the bf16 / fp16 emulation, not a reference
+    path): scores in log2 units (``qk2`` = q * head_dim^-0.5 * log2(e), rounded as the qkv epilogue rounds it), the bias as the fp16
+    row-max-shifted image times log2(e), keys taken in blocks of 32 against a RUNNING row maximum with the deferred rescale (the
+    row's first block is shifted by its exact maximum, a later block only when it grows more than 2^thr past the running one), the
+    un-normalised probabilities rounded by ``rq`` at that scale, the normaliser the sum of the ROUNDED probabilities.  At which scale a
+    probability is rounded decides which way each 8-bit (bf16) rounding falls: an emulation that rounds exp(a - exact maximum)
+    carries the same amount of rounding noise but a different draw of it."""
+    LOG2E = 1.4426950408889634
+    BW, nH, N, hd = qk2.shape
+    nW = layout["nW"]
+    img = image_bias(rpb_table, fpb_table, window, layout) * LOG2E                     # (nW | 1, nH, N, N), log2 units
+    out = torch.empty(BW, N, nH * hd, dtype=qk2.dtype)
+    widx = torch.arange(BW) % nW if img.shape[0] == nW else torch.zeros(BW, dtype=torch.long)
+    for s in range(0, BW, chunk):
+        e = min(BW, s + chunk)
+        a = qk2[s:e] @ k[s:e].transpose(-2, -1) + img[widx[s:e]]                     # relative to nm = 0
+        O = torch.zeros(e - s, nH, N, hd)
+        l = torch.zeros(e - s, nH, N, 1)
+        nm = torch.zeros(e - s, nH, N, 1)                                            # -(running maximum)
+        for t0 in range(0, N, block):
+            S = a[..., t0:t0 + block] + nm
+            mr = S.max(-1, keepdim=True).values
+            d = mr if t0 == 0 else torch.where(mr > thr, mr, torch.zeros_like(mr))
+            S = S - d
+            if t0:
+                f = torch.exp2(-d)
+                O, l = O * f, l * f
+            nm = nm - d
+            P = rq(torch.exp2(S))
+            l = l + P.sum(-1, keepdim=True)
+            O = O + P @ v[s:e, :, t0:t0 + block]
+        out[s:e] = (O / l).transpose(1, 2).reshape(e - s, N, nH * hd)
+    return out
+
+
+def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift, q=_ident, kernel_order: bool = False) -> torch.Tensor:
     """x (B,D,H,W,C) channels-last residual stream (always fp32)."""
     B, D, H, W, C = x.shape
     lay = window_layout(D, H, W, window, shift)
     h = q(F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
-    o = window_attention(gather_windows(h, lay), p, pre + "attn.", num_heads, window, lay, q=q)
+    o = window_attention(gather_windows(h, lay), p, pre + "attn.", num_heads, window, lay, q=q, kernel_order=kernel_order)
     x = x + scatter_windows(o, lay, B, D, H, W)
     h = q(F.layer_norm(x, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
     h = F.linear(h, q(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"])
@@ -275,11 +318,30 @@ def patch_merge(x: torch.Tensor, p, pre: str, q=_ident) -> torch.Tensor:
     return F.linear(cat, q(p[pre + "reduction.weight"]))
 
 
-def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, operand_dtype=None):
+def patch_merge_kernel_order(x: torch.Tensor, p, pre: str, q, eps: float = 1e-5) -> torch.Tensor:
+    """PatchMerging at the ROUNDING POINTS of csrc/merge.hip (C <= 192; emulation only, as ``attention_core_kernel_order``): the launch
+    folds the LayerNorm around the GEMM — W (gamma (x - mean) rstd + beta) = rstd (W diag(gamma)) (x - mean) + W beta — so its 16-bit
+    operands are W' = W diag(gamma) and d = x - K (K = the mean of the concatenated row's first 96 channels), not W and the normalised
+    row; the statistics come from the un-rounded d, mean - K leaves through the row sums of the ROUNDED W', W beta stays fp32."""
+    B, D, H, W, C = x.shape
+    x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+    g, b, w = p[pre + "norm.weight"], p[pre + "norm.bias"], p[pre + "reduction.weight"]
+    d = cat - cat[..., :96].mean(-1, keepdim=True)
+    md = d.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((d * d).mean(-1, keepdim=True) - md * md).clamp(min=0.0) + eps)
+    wg = q(w * g[None, :])
+    return (F.linear(q(d), wg) - md * wg.sum(1)) * rstd + F.linear(b[None], w)[0]
+
+
+def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, operand_dtype=None, kernel_order: bool = False,
+                 merge_fold_max_c: int = 192):
     """x (B,3,T,H,W) fp32 -> (B,C_out,D,H/32,W/32) like the reference trunk.  ``cfg`` is a
     ``kvq_amd.utils.synth.SwinCfg``-shaped object (patch, depths, num_heads, window).
     ``operand_dtype`` None = the reference's fp32 arithmetic (this is THE oracle); torch.float16 /
-    torch.bfloat16 = emulate the HIP path's MFMA-operand rounding (diagnostic only)."""
+    torch.bfloat16 = emulate the HIP path's MFMA-operand rounding (diagnostic only); ``kernel_order`` (with an operand dtype) also
+    takes the attention kernel's softmax order and scales (``attention_core_kernel_order``) and the fused merge launch's operands
+    (``patch_merge_kernel_order``, widths up to ``merge_fold_max_c``)."""
     p = {k: _t(v).float() for k, v in params.items()}
     q = operand_rounding(operand_dtype)
     shift = tuple(w // 2 for w in cfg.window)
@@ -288,9 +350,12 @@ def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, oper
     for i in range(len(cfg.depths)):
         for b in range(cfg.depths[i]):
             y = swin_block(y, p, f"layers.{i}.blocks.{b}.", cfg.num_heads[i], cfg.window,
-                           (0, 0, 0) if b % 2 == 0 else shift, q)
+                           (0, 0, 0) if b % 2 == 0 else shift, q, kernel_order and operand_dtype is not None)
         if i < len(cfg.depths) - 1:
-            y = patch_merge(y, p, f"layers.{i}.downsample.", q)
+            if kernel_order and operand_dtype is not None and y.shape[-1] <= merge_fold_max_c:      # csrc/merge.hip (plan.hip KVQ_MERGE_MAXC)
+                y = patch_merge_kernel_order(y, p, f"layers.{i}.downsample.", q)
+            else:
+                y = patch_merge(y, p, f"layers.{i}.downsample.", q)
         stages.append(y)
     y = F.layer_norm(y, (y.shape[-1],), p["norm.weight"], p["norm.bias"])
     out = y.permute(0, 4, 1, 2, 3).contiguous()

@@ -88,8 +88,12 @@ def test_trunk_and_score_vs_reference_golden(golden, case, dtype):
 
 @pytest.mark.parametrize("case", ["t_grpb_stress_8x80", "t_grpb_stress_16x64"])
 def test_bf16_path_matches_bf16_emulation(golden, case):
-    """The bf16 kernels against an fp32 emulation of bf16 operand rounding: within the 1e-3 gate,
-    i.e. what remains vs the reference at bf16 is the format, not the kernels."""
+    """The bf16 kernels against an fp32 emulation of bf16 operand rounding AT THE KERNELS' ROUNDING POINTS (oracle
+    ``kernel_order=True``: the attention launch's log2-unit scores, fp16 bias image, running row maximum per 32 keys and
+    probabilities rounded at that scale; the fused PatchMerging launch's folded LayerNorm — operands W diag(gamma) and x - K):
+    what remains vs the reference at bf16 is the format, not the kernels.  Rounds 2-4 compared against an emulation with the same
+    AMOUNT of rounding but the reference's operand order (2.5e-3 bar, a different draw of every 8-bit rounding in the softmax and
+    the merges); the kernel-order form lands within the 1e-3 gate of the HIP scores."""
     g = golden("trunk.npz")
     wseed, cseed, B, T, H, W = (int(v) for v in g[f"{case}/meta"])
     cfg = synth.SWIN_T_GRPB
@@ -98,11 +102,65 @@ def test_bf16_path_matches_bf16_emulation(golden, case):
     with torch.no_grad():
         score = net(inputs={"technical": x.to(DEV)}, reduce_scores=True).cpu()
         emu = O.vqa_head(O.swin3d_trunk(x, synth.synth_swin_weights(cfg, wseed, "stress"), cfg,
-                                        operand_dtype=torch.bfloat16),
+                                        operand_dtype=torch.bfloat16, kernel_order=True),
                          synth.synth_vqa_head_weights(768, 64, wseed, "stress"))
-    # the emulation cannot reproduce fp32 summation order, and a flipped bf16 rounding moves a score by
-    # ~1e-3 here: same-order agreement (vs 1.5e-3..3e-3 to the fp32 reference) is what this shows
-    assert (score - emu).abs().max().item() <= 2.5e-3, (score.ravel(), emu.ravel())
+    print(case, "bf16 HIP vs kernel-order emulation", (score - emu).abs().max().item(), "vs golden", (score.numpy() - g[f"{case}/score"]).max())
+    # fp32 summation order still differs (MFMA accumulation, two-pass vs one-pass statistics): where that flips an 8-bit rounding the
+    # flip is amplified by the blocks after it, so whole-network agreement stays a fraction of the format's error, not zero
+    assert (score - emu).abs().max().item() <= SCORE_TOL, (score.ravel(), emu.ravel())
+
+
+def _emulated_stage(y, p, cfg, i, q, kernel_order):
+    """Stage i of the trunk (its blocks + PatchMerging) from the oracle's pieces, started from ``y`` (B,D,H,W,C)."""
+    shift = tuple(w // 2 for w in cfg.window)
+    for b in range(cfg.depths[i]):
+        y = O.swin_block(y, p, f"layers.{i}.blocks.{b}.", cfg.num_heads[i], cfg.window, (0, 0, 0) if b % 2 == 0 else shift, q, kernel_order)
+    if i < len(cfg.depths) - 1:
+        merge = O.patch_merge_kernel_order if kernel_order and y.shape[-1] <= 192 else O.patch_merge
+        y = merge(y, p, f"layers.{i}.downsample.", q)
+    return y
+
+
+@pytest.mark.parametrize("variant", ["full", "merge_only"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_stages_follow_the_kernel_order_emulation(dtype, variant):
+    """Teacher-forced, stage by stage: every stage of the HIP trunk (taps of ONE forward) against the emulation of its 16-bit
+    rounding points started from the HIP path's OWN stage input, so rounding flips compound over one stage's blocks only.  A
+    kernel whose rounding points are the emulation's lands well inside the format's own error (HIP vs the exact fp32 stage); a
+    kernel bug of the size of that error — what the whole-network bf16 bar of 8e-3 could hide — does not.  ``merge_only`` zeroes
+    every block's proj and fc2 (a block is then the identity): what is left of a stage is its PatchMerging launch alone, one GEMM deep
+    — there the emulation is followed to fp32 summation order."""
+    cfg = synth.SWIN_T_GRPB
+    wseed, cseed, B, T, H, W = 3, 4, 1, 16, 64, 64
+    w = synth.synth_swin_weights(cfg, wseed, "stress")
+    if variant == "merge_only":
+        for k in list(w):
+            if k.endswith(("attn.proj.weight", "attn.proj.bias", "mlp.fc2.weight", "mlp.fc2.bias")):
+                w[k] = np.zeros_like(w[k])
+    net = VQA_Network({"model": {"args": {"swin_tiny_grpb": {"backbone": {}, "head": {"in_channels": 768, "hidden_channels": 64}}}}})
+    net.load_state_dict({f"swin_tiny_grpb_backbone.{k}": torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    bb = net.swin_tiny_grpb_backbone
+    bb.operand_dtype = _abi.dtype_code(dtype)
+    net = net.to(DEV).eval()
+    p = {k: torch.from_numpy(v).float() for k, v in w.items()}
+    q = O.operand_rounding(torch.bfloat16 if dtype == "bf16" else torch.float16)
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B))
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()   # noqa: E731
+    with torch.no_grad():
+        taps = [bb({"technical": x.to(DEV)}, layer=i).cpu().permute(0, 2, 3, 4, 1).contiguous() for i in range(5)]
+        assert rel(taps[0], O.patch_embed(x, p, cfg.patch, q)) <= 2e-6                  # the embedding: one GEMM + LayerNorm deep
+        for i in range(4):
+            exact = _emulated_stage(taps[i], p, cfg, i, O._ident, False)
+            emu = _emulated_stage(taps[i], p, cfg, i, q, True)
+            fmt, d = rel(taps[i + 1], exact), rel(taps[i + 1], emu)
+            print(dtype, variant, "stage", i, "HIP vs exact %.2e  HIP vs emulation %.2e" % (fmt, d))
+            if variant == "merge_only":
+                assert d <= 2e-5, (i, d)                         # (stage 3 has no merge: 0 == 0)
+            else:
+                # 2 blocks (+ merge) per stage, 6 at stage 2: observed 0.54 / 0.53 / 0.83 / 0.36 of the format's error at bf16,
+                # 0.63 / 0.59 / 0.81 / 0.52 at fp16 (a flipped rounding is amplified by every block after it; the reference-order
+                # emulation of rounds 2-4 sits at 0.9-1.1 in stages 0-1, i.e. an independent draw)
+                assert d <= (0.95 if i == 2 else 0.8) * fmt, (i, d, fmt)
 
 
 def test_large_bias_tables_take_the_exact_gather_path_per_block():
