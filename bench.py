@@ -381,7 +381,7 @@ def setup_c3(args, device, net, src):
     from kvq_amd.models.backbones.slowfast_model import slowfast
     sf = slowfast(operand_dtype=args.dtype, two_lanes=False).to(device).eval()     # the trunk already fills the chip from its stream
     B = 8
-    nl = 2
+    nl = max(1, int(os.environ.get("KVQ_C3_LANES", "2")))      # lane pairs (a Swin stream + a SlowFast stream each)
     swin_st = [torch.cuda.Stream(device=device) for _ in range(nl)]
     sf_st = [torch.cuda.Stream(device=device) for _ in range(nl)]
     xs = [torch.empty(B, 3, 32, 224, 224, device=device) for _ in range(nl)]

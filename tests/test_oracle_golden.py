@@ -67,6 +67,32 @@ def test_trunk_small(golden, case):
     assert np.abs(score.numpy() - g[f"{case}/score"]).max() <= 1e-6
 
 
+def test_kernel_order_emulation_is_the_same_function(golden):
+    """The emulation's kernel-order pieces (``attention_core_kernel_order``: log2-unit scores, fp16 bias image, running maximum per 32
+    keys; ``patch_merge_kernel_order``: LayerNorm folded around the GEMM) computed WITHOUT operand rounding are the reference's
+    functions up to fp32 summation order and the image's fp16 rounding — what the 16-bit emulation adds is rounding points only."""
+    g = golden("trunk.npz")
+    case = "t_grpb_stress_8x80"
+    wseed, cseed, B, T, H, W = (int(v) for v in g[f"{case}/meta"])
+    cfg = synth.SWIN_T_GRPB
+    p = {k: torch.from_numpy(v).float() for k, v in synth.synth_swin_weights(cfg, wseed, "stress").items()}
+    gen = torch.Generator().manual_seed(3)
+    y = torch.randn(1, 4, 9, 10, 96, generator=gen) * 2 + 0.5                  # odd H: the zero-padded neighbours take d = -K
+    a, b = O.patch_merge(y, p, "layers.0.downsample."), O.patch_merge_kernel_order(y, p, "layers.0.downsample.", O._ident)
+    assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
+    for shift in ((0, 0, 0), (4, 3, 3)):
+        lay = O.window_layout(8, 14, 14, cfg.window, shift)
+        BW, N, nH = lay["nW"], lay["N"], 3
+        q, k, v = (torch.randn(BW, nH, N, 32, generator=gen) for _ in range(3))
+        pre = "layers.0.blocks.1.attn."
+        tabs = (p[pre + "relative_position_bias_table"], p[pre + "fragment_position_bias_table"])
+        ref = O.attention_core(q * 32 ** -0.5, k, v, *tabs, cfg.window, lay)
+        got = O.attention_core_kernel_order(q * (32 ** -0.5 * 1.4426950408889634), k, v, *tabs, cfg.window, lay, O._ident)
+        assert (ref - got).abs().max().item() <= 2e-3 * ref.abs().max().item()          # the image: 2^-11 x (bias - row maximum)
+        img = O.attention_core(q * 32 ** -0.5, k, v, *tabs, cfg.window, lay, image=True)
+        assert (img - got).abs().max().item() <= 2e-5 * ref.abs().max().item()          # same image: summation order only
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("case", ["t_grpb_stress_32x224", "t_grpb_init_32x224"])
 def test_trunk_full_size(golden, case):
