@@ -213,6 +213,8 @@ class CONTRIQUE_model(_HipModule):  # noqa: N801
             raise TypeError("encoder must be the network get_network('resnet50') returns")
         self.encoder = nn.Sequential(*list(encoder.children())[:-2])
         object.__setattr__(self, "_net", encoder)              # the same modules, kept for their HIP forward (not re-registered)
+        # KVQ_CONTRIQUE_R16=0: the trunk's residual stream in fp32 (rounds 3-5); default: 16-bit (the 1x1 convs that carry it are HBM-bound)
+        encoder.residual16 = os.environ.get("KVQ_CONTRIQUE_R16", "1") != "0"
         self.projector = nn.Sequential(nn.Linear(n_features, n_features, bias=False), nn.BatchNorm1d(n_features), nn.ReLU(),
                                        nn.Linear(n_features, projection_dim, bias=False), nn.BatchNorm1d(projection_dim))
 

@@ -80,6 +80,9 @@ class ResNet(nn.Module):
         # unused by forward but part of the reference's state_dict (simpleVQA_model.py:167)
         self.quality = nn.Sequential(_Affine((128, 4096 + 2048 + 1024 + 2048 + 256), (128,)), _Affine((1, 128), (1,)))
         self._wcache = None
+        # features() only: carry the stream between bottlenecks in 16 bits (CONTRIQUE_model switches it on; forward() — the SimpleVQA
+        # path pinned to the reference by |dscore| <= 1e-3 — always keeps the fp32 stream)
+        self.residual16 = False
 
     def _make_layer(self, planes, blocks, stride):
         layers = [Bottleneck(self.inplanes, planes, stride, downsample=(stride != 1 or self.inplanes != planes * 4))]
@@ -150,19 +153,26 @@ class ResNet(nn.Module):
         n = x16.shape[0]
         out = self._conv_relu(x16, w[key + "1"], 1, 1, 0)
         out = self._conv_relu(out, w[key + "2"], 3, blk.stride, 1)
+        r16 = self.residual16
         if blk.downsample is None:
-            identity = x32.reshape(-1, x32.shape[-1])
-        else:                                                   # 1x1/stride conv + BN, no ReLU, kept in fp32
+            identity = (x16 if r16 else x32).reshape(-1, x16.shape[-1])
+        else:                                                   # 1x1/stride conv + BN, no ReLU, kept in fp32 (16-bit with residual16)
             wd, bd = w[key + "d"]
             nb, hb, wb_, cb = x16.shape
             if IMPLICIT_CONV and blk.stride != 1 and cb % 8 == 0 and x16.is_contiguous():
                 identity = kernels.conv_implicit(x16.reshape(nb, 1, hb, wb_, cb), wd, bd, (1, 1, 1), (1, blk.stride, blk.stride),
-                                                 (0, 0, 0), False, store_f32=True)
+                                                 (0, 0, 0), False, store_f32=not r16)
+                identity = identity.reshape(-1, identity.shape[-1])
             else:
                 a, _ = self._cols(x16, 1, blk.stride, 0, wd.shape[1])
-                identity = kernels.gemm(a, wd, bd, _abi.EPI_STORE_F32)
+                identity = kernels.gemm(a, wd, bd, _abi.EPI_BIAS_BF16 if r16 else _abi.EPI_STORE_F32)
         ho, wo = out.shape[1], out.shape[2]
         w3, b3 = w[key + "3"]
+        if r16:
+            # 16-bit residual stream (as slowfast_model's default): per output element the launch reads 2 B and writes 2 B instead of
+            # reading 4 and writing 4 + 2 — these 1x1 convs are HBM-bound; one more 16-bit rounding per block
+            y16 = kernels.conv_gemm(out.reshape(n * ho * wo, -1), w3, b3, True, resid=identity)
+            return y16.reshape(n, ho, wo, -1), None
         y16, y32 = kernels.conv_gemm(out.reshape(n * ho * wo, -1), w3, b3, True, resid_f32=identity, want_f32=True)
         return y16.reshape(n, ho, wo, -1), y32.reshape(n, ho, wo, -1)        # relu(bn3(conv3) + identity)
 
@@ -297,7 +307,7 @@ class ResNet(nn.Module):
         for li, layer_mod in enumerate((self.layer1, self.layer2, self.layer3, self.layer4), 1):
             for bi, blk in enumerate(layer_mod):
                 y, y32 = self._bottleneck(y, y32, w, f"l{li}.{bi}.", blk)
-        return y, y32
+        return y, (y.to(torch.float32) if y32 is None else y32)
 
     def _stem(self, x, dims5, strides5, w, half):
         """conv1 7x7/2 + bn1 + ReLU on the fp32 input, frames addressed as (b, t) through element strides (b,t,c,h,w):
