@@ -532,7 +532,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       // head_dim^-0.5.  Which one a block takes depends on its weights and geometry only, never on the batch.
       const float qs = bw.bias_dense ? kQScaleLog2 : kQScale;
       // norm1 + pad + roll + window_partition
-      if (g.Lp != g.L && bw.qkv_b) {
+      if (g.Lp != g.L && bw.qkv_b && qkv_ready) {
+        // padded partition whose q | k | v rows the previous block's tail wrote (window rows of the tokens; the padding rows are the
+        // attention launch's: pad_mask)
+      } else if (g.Lp != g.L && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
         // (rows scattered to their window rows by the epilogue); the padding rows' q | k | v = qkv(0) = bias
         if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
@@ -585,22 +588,30 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         // partitions could take them in token order (through an identity map; measured on C5: 19 LayerNorm launches / 0.51 ms saved,
         // but the emitting form of the C = 512 tail costs +25 us per launch (it spills): 12.9 vs 13.0 ms serial, 20.9 vs 21.2-22.0
         // videos/s with two steps in flight) — not taken.
-        const int32_t* nmap = g.Lp == g.L ? g.d_dst[npar] : nullptr;
+        // Round 5: a padded partition takes the next block's q | k | v from this launch too (token -> window row of the NEXT partition,
+        // rows of Lp per clip; the padding rows are written by the attention launch, pad_mask) — the LayerNorm launch, the qkv GEMM and
+        // the norm1 round trip of every block of Swin-B at 64 x 256 x 256 are gone (C5 23.8 -> 25.05 videos/s, +5.2 %, same box alternating: profiles/r05_padded_qkv_ab.txt);
+        // the C = 512 tail in hidden chunks of 128 emits without the spills the comment above met.  KVQ_TAIL_QKV_PADDED=0: the old sequence.
+        static const bool tail_qkv_padded = !(getenv("KVQ_TAIL_QKV_PADDED") && atoi(getenv("KVQ_TAIL_QKV_PADDED")) == 0);
+        const bool padded_qkv = g.Lp != g.L && tail_qkv_padded && b + 1 < g.depth && g.d_dst[npar] && g.d_padmask[npar] && w->blocks[blk + 1].bias_dense;
+        const int32_t* nmap = (g.Lp == g.L || padded_qkv) ? g.d_dst[npar] : nullptr;
         if (b + 1 < g.depth && nmap) {
           const KvqSwinBlockW& nb = w->blocks[blk + 1];
           KVQ_REQUIRE(nb.norm1_w && nb.norm1_b, KVQ_ERR_NULL, "kvq_swin3d_forward: block %d norm1 missing", blk + 1);
           ta.next_norm_w = nb.norm1_w; ta.next_norm_b = nb.norm1_b; ta.next_dst = nmap;
-          ta.next_rows = g.Lp == g.L ? g.Lp : g.L;
+          ta.next_rows = g.Lp;
           // the next block's q | k | v straight from this launch (C = 128 / 192 / 256 / 384 / 512, un-padded partitions, the image path's q scale):
           // no norm1 rows, no qkv GEMM launch.  By geometry and weights only, never by batch.  KVQ_TAIL_QKV=0: rounds 1-4's sequence.
           static const bool tail_qkv = !(getenv("KVQ_TAIL_QKV") && atoi(getenv("KVQ_TAIL_QKV")) == 0);
           const bool next_fuses = nb.bias_dense && nb.qkv_b && g.Lp == g.L && C == 96 && g.N <= 400;      // its attention launch projects q | k | v itself
-          if (tail_qkv && !next_fuses && nb.qkv_pack && nb.qkv_b && nb.bias_dense && g.Lp == g.L && kvq_block_tail_qkv_pack_bytes(C, hidden) > 0) {
+          if (tail_qkv && !next_fuses && nb.qkv_pack && nb.qkv_b && nb.bias_dense && (g.Lp == g.L || padded_qkv) && kvq_block_tail_qkv_pack_bytes(C, hidden) > 0) {
             ta.next_qkv_pack = nb.qkv_pack; ta.next_qkv_b = nb.qkv_b; ta.qkv_out = bbig; ta.q_scale = kQScaleLog2; ta.num_heads = g.nH;
             qkv_ready = true;
-          } else {
+          } else if (g.Lp == g.L) {
             ta.next_ln = bln;
             ln1_ready = true;
+          } else {                      // padded partition without the emission: the tail writes x only
+            ta.next_norm_w = nullptr; ta.next_norm_b = nullptr; ta.next_dst = nullptr; ta.next_rows = 0;
           }
         }
         Bracket br(pl, st, KVQ_K_TAIL, (C / 32) * 10 + (ln1_ready ? 1 : 0) + (qkv_ready ? 2 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden + (qkv_ready ? 6.0 * M * C * C : 0.0),
