@@ -99,12 +99,28 @@ def cpu_baseline(cfg, wts, hw, n_clips):
     from oracle import swin3d_oracle as O
     # 32 threads is the measured optimum on the 256-thread host (8: 3.13, 32: 2.78, 64: 3.38, 128: 8.7 s/clip)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    import numpy as np
+    from oracle import sampler_oracle as S
+    # the same workload as the GPU step: K1 (fragment sampler + normalise, fusion_datasets.py:22-107, :1017-1020) on uint8 post-decode
+    # frames that are resident before the timed region, then trunk + head
+    rng = np.random.default_rng(1234)
+    pool = [rng.integers(0, 256, (3, 32, SRC_H, SRC_W), dtype=np.uint8) for _ in range(4)]
+
+    def sampled_clip(i):
+        g = torch.Generator().manual_seed(123400003 + i)
+        rh, rw = S.draw_fragment_offsets(32, SRC_H, SRC_W, 7, 7, 32, 32, aligned=8, generator=g)
+        frag = S.spatial_fragments(pool[i % len(pool)], rh, rw, 7, 7, 32, 32, aligned=8)
+        return torch.from_numpy(S.normalize(frag, MEAN, STD)[None])
+
     x = torch.from_numpy(synth.synth_clip(1000, 32, 224, 224, batch=1))
     with torch.no_grad():
         O.vqa_head(O.swin3d_trunk(x[:, :, :8, :64, :64].contiguous(), wts, cfg), hw)    # warm the allocator/threads
         t0 = time.perf_counter()
+        ts = 0.0
         for i in range(n_clips):
-            x = torch.from_numpy(synth.synth_clip(1001 + i, 32, 224, 224, batch=1))
+            t1 = time.perf_counter()
+            x = sampled_clip(i)
+            ts += time.perf_counter() - t1
             O.vqa_head(O.swin3d_trunk(x, wts, cfg), hw)
         dt = time.perf_counter() - t0
     model = ""
@@ -117,7 +133,8 @@ def cpu_baseline(cfg, wts, hw, n_clips):
         pass
     return {"value": n_clips / CLIPS_PER_VIDEO / dt, "unit": "videos/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{n_clips} clips of 3x32x224x224 (= {n_clips / CLIPS_PER_VIDEO:g} videos), "
-            f"B=1 per forward, fp32 torch CPU oracle, trunk + head (the CPU sampler is not in it), {dt:.1f} s", "cpu": model}
+            f"B=1 per forward, CPU oracle: fragment sampler + normalise on uint8 3x32x{SRC_H}x{SRC_W} frames (numpy, {1e3 * ts / n_clips:.1f} ms per clip) "
+            f"+ fp32 torch trunk + head = the GPU step's workload, {dt:.1f} s", "cpu": model}
 
 
 class Source:
@@ -201,8 +218,11 @@ def run_lanes(lanes, n, fn):
     for st in others:
         st.wait_stream(main)
     outs = []
+    stagger = int(os.environ.get("KVQ_LANE_STAGGER_CYCLES", "0"))      # experiment: lane i starts i * stagger clock ticks late
     for s in range(n):
         with torch.cuda.stream(lanes[s % len(lanes)]):
+            if stagger and 0 < s < len(lanes):
+                torch.cuda._sleep(stagger * s)
             outs.append(fn(s, s % len(lanes)))
     for st in others:
         main.wait_stream(st)
