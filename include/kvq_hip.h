@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 29
+#define KVQ_ABI_VERSION 30
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -470,6 +470,15 @@ int kvq_patch_im2col(const float* x, int B, int Cin, int T, int H, int W, int pd
 int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l,
                  int64_t stride_c, const float* w1t, const float* w1, const float* b1, int hidden, const float* w2,
                  const float* b2, float* scratch, float* score, void* stream);
+
+/* VQAHead.forward's other branches (models/head.py:60-68; no reference config sets them): pre_pool != 0 averages the token grid
+ * first (AdaptiveAvgPool3d((1,1,1)), head.py:61-62); num_class > 1 applies nn.Softmax() — implicit dim 1 = the classes — to
+ * fc_last's outputs per token (head.py:66-67) before the mean over the tokens (head.py:68).
+ *   w1t fp32 [C][hidden], w2 fp32 [num_class][hidden], b2 fp32 [num_class]; score fp32 [B][num_class];
+ *   scratch fp32 [B*L*num_class] (pre_pool: [B*C + B*num_class]).  num_class == 1: no softmax, as the reference. */
+int kvq_vqa_head_classes(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l, int64_t stride_c,
+                         const float* w1t, const float* b1, int hidden, const float* w2, const float* b2, int num_class,
+                         int pre_pool, float* scratch, float* score, void* stream);
 
 /* simpleVQAHead.forward (models/head.py:28-31): Linear(Cin->hidden) -> Linear(hidden->1), mean over
  * frames.  feat fp32 [B][T][Cin]; score fp32 [B]; scratch fp32 [B*T]. */

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 def dtype_code(dt) -> int:
@@ -215,6 +215,8 @@ SYMBOLS = {
     "kvq_patch_im2col": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, p_void, p_void]),
     "kvq_vqa_head": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, p_void, i32, p_void, p_void, p_void,
                            p_void, p_void]),
+    "kvq_vqa_head_classes": (i32, [p_void, i32, i32, i32, i64, i64, i64, p_void, p_void, i32, p_void, p_void, i32, i32, p_void,
+                                   p_void, p_void]),
     "kvq_simple_vqa_head": (i32, [p_void, i32, i32, i32, p_void, p_void, i32, p_void, p_void, p_void, p_void,
                                   p_void]),
     "kvq_resize_bilinear": (i32, [p_void, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32),

@@ -140,6 +140,39 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // two values: plain scalar code (a packed v_pk_fma_f32 occupies the VALU for two plain instructions on gfx950: nothing to gain)
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return f32x2{gelu_fast(x[0]), gelu_fast(x[1])}; }
 
+// GELU of two values straight into the packed 16-bit MFMA operand of the fused tails (fc1 accumulator -> fc2 operand).
+// bf16: the fp32 form, then one pack.  fp16 (round 5, KVQ_GELU_PK16=1): the SAME polynomial evaluated on the packed pair —
+// v_cvt_pk_f16_f32, v_and (|x|), 5 v_pk_fma_f16, 2 v_exp_f16 (the high half by SDWA), v_pack_b32_f16, v_pk_max_f16,
+// v_pk_fma_f16 = 10 full-rate + 2 quarter-rate instructions per PAIR against 17 + 2: the result is a 16-bit operand either way,
+// the evaluation adds the rounding of x and of the Horner steps (rms error of the operand x 1.6-1.8 at |x| <= 1, level past
+// |x| ~ 4: tools/diag/gelu_pk16_error.py); MODE.FP16_OVFL (fp16_saturate_mode) clamps every overflow on the way — P5 -> -65504,
+// exp2 -> 0 — so no NaN can form.  -DKVQ_GELU_PK16=0 builds the fp32 evaluation.
+#ifndef KVQ_GELU_PK16
+#define KVQ_GELU_PK16 0
+#endif
+template <class E>
+__device__ __forceinline__ uint32_t gelu_pack2(float lo, float hi) {
+  return E::pack2(gelu_fast(lo), gelu_fast(hi));
+}
+#if KVQ_GELU_PK16
+template <>
+__device__ __forceinline__ uint32_t gelu_pack2<Fp16>(float lo, float hi) {
+  const f16x2 x = {(_Float16)lo, (_Float16)hi};                                  // one v_cvt_pk_f16_f32 (saturating mode)
+  const f16x2 a = __builtin_bit_cast(f16x2, __builtin_bit_cast(uint32_t, x) & 0x7fff7fffu);
+  auto c = [](float v) { return f16x2{(_Float16)v, (_Float16)v}; };
+  f16x2 p = __builtin_elementwise_fma(c(-4.7330835272e-04f), a, c(7.0845445981e-03f));
+  p = __builtin_elementwise_fma(p, a, c(-5.1827334402e-02f));
+  p = __builtin_elementwise_fma(p, a, c(-4.5999251338e-01f));
+  p = __builtin_elementwise_fma(p, a, c(-1.1507878060e+00f));
+  p = __builtin_elementwise_fma(p, a, c(-1.0f));
+  const f16x2 e2 = __builtin_elementwise_exp2(p);      // two v_exp_f16 (the high half by SDWA) + v_pack_b32_f16; the compiler places
+                                                       // gfx950's trans-result wait states (hand-written SDWA into one register read stale data)
+  const f16x2 m = __builtin_elementwise_max(x, f16x2{(_Float16)0.f, (_Float16)0.f});
+  const f16x2 r = __builtin_elementwise_fma(-a, e2, m);
+  return __builtin_bit_cast(uint32_t, r);
+}
+#endif
+
 // diagnostic stamp buffer (kvq_debug_gemm_trace): 8 uint64 per workgroup, NULL = off
 extern unsigned long long* g_trace;
 extern int g_trace_blocks;

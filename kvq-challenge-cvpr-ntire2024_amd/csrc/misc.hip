@@ -527,6 +527,105 @@ extern "C" int kvq_vqa_head(const float* feat, int B, int L, int C, int64_t stri
   return KVQ_OK;
 }
 
+namespace kvq {
+// ------------------------------------------------------------------------------------------------
+// VQAHead's other two branches (models/head.py:60-68): pre_pool (AdaptiveAvgPool3d((1,1,1)) in front of the MLP) and
+// num_class > 1 (nn.Softmax() with its implicit dim — dim 1, the classes, for a 5-D input — over fc_last's K outputs, then the
+// mean over the token grid).  No reference config sets either, so this is a plain fp32 VALU path: lane j owns hidden unit j
+// (W1 transposed, one coalesced row per channel), one wave per token, the K logits meet in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void feat_mean_kernel(const float* __restrict__ feat, int L, int C, long sb, long sl, long sc,
+                                                        float* __restrict__ pooled) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* f = feat + b * sb + c * sc;
+  float s = 0.f;
+  for (int l = 0; l < L; ++l) s += f[l * sl];                 // sequential in l: the order of a plain sum, deterministic
+  pooled[(size_t)b * C + c] = s / (float)L;
+}
+
+__global__ __launch_bounds__(64) void vqa_head_classes_kernel(const float* __restrict__ feat, int L, int C, long sb, long sl, long sc,
+                                                              const float* __restrict__ w1t, const float* __restrict__ b1, int hidden,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2, int K,
+                                                              float* __restrict__ tok_prob) {
+  extern __shared__ float logit[];                            // [K]
+  const int lane = threadIdx.x;
+  const long tk = blockIdx.x;
+  const long b = tk / L, l = tk - b * L;
+  const float* row = feat + b * sb + l * sl;
+  for (int k = lane; k < K; k += 64) logit[k] = 0.f;
+  __syncthreads();
+  for (int j0 = 0; j0 < hidden; j0 += 64) {
+    const int j = j0 + lane;
+    const bool live = j < hidden;
+    const int jc = live ? j : hidden - 1;
+    float d = 0.f;
+    for (int c = 0; c < C; ++c) d = fmaf(row[c * sc], w1t[(size_t)c * hidden + jc], d);
+    const float h = live ? gelu_erf(d + b1[jc]) : 0.f;
+    for (int k = 0; k < K; ++k) {
+      float v = live ? w2[(size_t)k * hidden + jc] * h : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) logit[k] += v;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float* out = tok_prob + tk * K;
+    if (K == 1) {
+      out[0] = logit[0] + b2[0];
+    } else {
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, logit[k] + b2[k]);
+      float z = 0.f;
+      for (int k = 0; k < K; ++k) z += expf(logit[k] + b2[k] - m);
+      for (int k = 0; k < K; ++k) out[k] = expf(logit[k] + b2[k] - m) / z;
+    }
+  }
+}
+
+// score[b][k] = mean_l tok_prob[(b*L + l)*K + k]
+__global__ __launch_bounds__(256) void mean_classes_kernel(const float* __restrict__ v, int L, int K, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, k = blockIdx.y;
+  float s = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) s += v[((size_t)b * L + l) * K + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(size_t)b * K + k] = red[0] / (float)L;
+}
+
+}  // namespace kvq
+
+extern "C" int kvq_vqa_head_classes(const float* feat, int B, int L, int C, int64_t stride_b, int64_t stride_l, int64_t stride_c,
+                                    const float* w1t, const float* b1, int hidden, const float* w2, const float* b2, int num_class,
+                                    int pre_pool, float* scratch, float* score, void* stream) {
+  using namespace kvq;
+  KVQ_REQUIRE(feat && w1t && b1 && w2 && b2 && scratch && score, KVQ_ERR_NULL, "kvq_vqa_head_classes: NULL pointer");
+  KVQ_REQUIRE(B > 0 && L > 0 && C > 0 && hidden > 0 && num_class > 0 && num_class <= 4096, KVQ_ERR_SHAPE,
+              "kvq_vqa_head_classes: bad shape");
+  long sb = stride_b, sl = stride_l, sc = stride_c;
+  int Lh = L;
+  float* tok = scratch;
+  if (pre_pool) {                     // scratch = pooled [B][C] | token probabilities [B][num_class]
+    hipLaunchKernelGGL(feat_mean_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feat, L, C, sb, sl, sc, scratch);
+    KVQ_CHECK_LAUNCH("feat_mean_kernel");
+    feat = scratch;
+    tok = scratch + (size_t)B * C;
+    sb = C, sl = 0, sc = 1, Lh = 1;
+  }
+  hipLaunchKernelGGL(vqa_head_classes_kernel, dim3((unsigned)((long)B * Lh)), dim3(64), num_class * sizeof(float), (hipStream_t)stream,
+                     feat, Lh, C, sb, sl, sc, w1t, b1, hidden, w2, b2, num_class, tok);
+  KVQ_CHECK_LAUNCH("vqa_head_classes_kernel");
+  hipLaunchKernelGGL(mean_classes_kernel, dim3(B, num_class), dim3(256), 0, (hipStream_t)stream, tok, Lh, num_class, score);
+  KVQ_CHECK_LAUNCH("mean_classes_kernel");
+  return KVQ_OK;
+}
+
 extern "C" int kvq_simple_vqa_head(const float* feat, int B, int T, int Cin, const float* w1, const float* b1,
                                    int hidden, const float* w2, const float* b2, float* scratch, float* score,
                                    void* stream) {

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
   };
   // GELU of accumulator registers 2g, 2g+1 -> dword g of the packed B operand pair
   auto gelu_pair = [&](const f32x16& ha, u32x4 (&hb)[2], int g) {
-    uint32_t w = E::pack2(gelu_fast(ha[2 * g]), gelu_fast(ha[2 * g + 1]));
+    uint32_t w = gelu_pack2<E>(ha[2 * g], ha[2 * g + 1]);
     asm volatile("" : "+v"(w));      // pins the evaluation HERE (between two MFMAs): IR-level sinking would otherwise
     hb[g >> 2][g & 3] = w;           // move the whole GELU next to its first use, after the MFMA stream
   };

@@ -464,8 +464,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   auto gelu_pair = [&](int pi) __attribute__((always_inline)) {      // pi = ((ft * 2 + hp) * 2 + tt) * 4 + i, 0..16 HT - 1
     const int i = pi & 3, tt = (pi >> 2) & 1, hp = (pi >> 3) & 1, ft = pi >> 4;
     const int r = 8 * hp + 2 * (i & 1) + 4 * (i >> 1);              // pairs (r, r+1): i = 0,1 -> quad 2hp; i = 2,3 -> quad 2hp+1
-    const f32x2 gv = gelu_fast2(f32x2{hacc[ft][tt][r], hacc[ft][tt][r + 1]});
-    uint32_t w = E::pack2(gv[0], gv[1]);
+    uint32_t w = gelu_pack2<E>(hacc[ft][tt][r], hacc[ft][tt][r + 1]);
     asm volatile("" : "+v"(w));                        // pins the evaluation where it is placed
     gp[ft][hp][tt][i] = w;
   };

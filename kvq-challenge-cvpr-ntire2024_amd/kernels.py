@@ -211,6 +211,30 @@ def vqa_head(feat: torch.Tensor, w1, b1, w2, b2, w1t=None):
     return score.reshape(B, 1)
 
 
+def vqa_head_classes(feat: torch.Tensor, w1, b1, w2, b2, pre_pool=False):
+    """VQAHead's pre_pool / num_class > 1 branches (head.py:60-68): feat fp32 (B,C,D,H,W) with any strides over a dense token grid,
+    ``w1`` [hidden,C], ``w2`` [num_class,hidden], ``b2`` [num_class] -> fp32 [B,num_class] (softmax over the classes per token when
+    num_class > 1, then the mean over the tokens; ``pre_pool``: the token grid is averaged first)."""
+    _need_gpu(feat, w1, b1, w2, b2)
+    assert feat.dtype == torch.float32 and feat.dim() == 5
+    B, Cc, D, H, W = feat.shape
+    L = D * H * W
+    sb, sc, sd, sh, sw = feat.stride()
+    if not (sh == W * sw and sd == H * sh):
+        feat = feat.contiguous()
+        sb, sc, sd, sh, sw = feat.stride()
+    w1t = w1.reshape(w1.shape[0], -1).t().contiguous()
+    hidden = w1t.shape[1]
+    w2 = w2.reshape(w2.shape[0], -1).contiguous()
+    K = w2.shape[0]
+    assert w2.shape[1] == hidden and b2.numel() == K and w1t.shape[0] == Cc
+    scratch = torch.empty(B * Cc + B * K if pre_pool else B * L * K, dtype=torch.float32, device=feat.device)
+    score = torch.empty(B, K, dtype=torch.float32, device=feat.device)
+    check(lib().kvq_vqa_head_classes(ptr(feat), B, L, Cc, sb, sw, sc, ptr(w1t), ptr(b1), hidden, ptr(w2), ptr(b2), K,
+                                     1 if pre_pool else 0, ptr(scratch), ptr(score), current_stream()), "kvq_vqa_head_classes")
+    return score
+
+
 def simple_vqa_head(feat: torch.Tensor, w1, b1, w2, b2):
     _need_gpu(feat, w1, b1, w2, b2)
     assert feat.dtype == torch.float32

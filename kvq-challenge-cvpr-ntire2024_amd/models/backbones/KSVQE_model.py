@@ -110,8 +110,11 @@ class KSVQE(SwinTransformer3D):
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
-        if multi or layer > -1 or adaptive_window_size:
-            raise NotImplementedError("feature taps / adaptive windows of KSVQE: no caller sets them")
+        if adaptive_window_size:
+            raise NotImplementedError("adaptive windows of KSVQE (KSVQE_model.py:1394-1397): no caller sets them")
+        want_taps = bool(multi) or layer > -1
+        if layer > self.num_layers:
+            raise IndexError("list index out of range")              # feats[layer] in the reference (:1497)
         revideo, fragment, dis_label = x["resize_video"], x["fragment"], x["dis_label"]
         if not fragment.is_cuda:
             raise _abi.KvqError("KSVQE.forward needs its inputs on a HIP device; there is no CPU path")
@@ -140,14 +143,39 @@ class KSVQE(SwinTransformer3D):
         loss = distortion_contrastive_supervised(dist, dis_label) if self.aux_loss else None
         geom = tuple(x_sel_ori.shape[2:])
         n_st = self.num_layers
-        x_sel = self.forward_stages(x_sel_ori, 0, min(self.tuning_stage, n_st) - 1) if self.tuning_stage > 0 else x_sel_ori
+        feats = {}                                                   # the reference's ``feats`` list (:1430, :1484), filled on request
+        if self.tuning_stage > 0:
+            hi = min(self.tuning_stage, n_st) - 1
+            if want_taps:
+                x_sel, feats = self.forward_stages(x_sel_ori, 0, hi, taps=range(hi + 2))
+            else:
+                x_sel = self.forward_stages(x_sel_ori, 0, hi)
+        else:
+            x_sel = x_sel_ori
         for l in range(self.tuning_stage, n_st):
-            x_sel = self.forward_stages(x_sel if l > 0 else x_sel_ori, l, l, geometry=geom)
+            if want_taps and l == 0:
+                x_sel, feats = self.forward_stages(x_sel_ori, 0, 0, geometry=geom, taps=(0,))
+            else:
+                x_sel = self.forward_stages(x_sel if l > 0 else x_sel_ori, l, l, geometry=geom)
             x_sel = self._modulate(l - self.tuning_stage, x_sel, patch_tokens, dist, half)
+            feats[l + 1] = x_sel                                     # a tuned stage's entry is the MODULATED stream (:1482-1484)
         n, c, d, hh, ww = x_sel.shape
         rows = x_sel.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
         feat = kernels.layernorm_rows(rows, self.norm.weight.detach().to(dev, torch.float32), self.norm.bias.detach().to(dev, torch.float32),
                                       out_dtype=torch.float32)
+        if multi:
+            # torch.cat([F.interpolate(xi, size=final (d, h, w), mode="trilinear") for xi in feats[:-1]], 1) (:1489-1495)
+            srcs = [feats[i].permute(0, 2, 3, 4, 1).contiguous() for i in range(n_st)]
+            ctot = sum(t.shape[-1] for t in srcs)
+            out = torch.empty(n, d, hh, ww, ctot, dtype=torch.float32, device=dev)
+            off = 0
+            for t in srcs:
+                _abi.check(_abi.lib().kvq_resize_trilinear_cl(_abi.ptr(t), n, t.shape[1], t.shape[2], t.shape[3], t.shape[4], _abi.ptr(out),
+                                                             d, hh, ww, ctot, off, _abi.current_stream()), "kvq_resize_trilinear_cl")
+                off += t.shape[4]
+            return out.permute(0, 4, 1, 2, 3)
+        if layer > -1:
+            return feats[layer]                                      # :1496-1498
         return feat.reshape(n, d, hh, ww, c).permute(0, 4, 1, 2, 3), loss
 
     def _modulate(self, k, x_sel, patch_tokens, dist, half):

@@ -476,12 +476,14 @@ class SwinTransformer3D(nn.Module):
             return taps[layer].permute(0, 4, 1, 2, 3)
         return feat.permute(0, 4, 1, 2, 3)      # channels-last storage, reference's (B,C,D,H,W) view
 
-    def forward_stages(self, x, stage_lo, stage_hi, geometry=None, want_feat=False):
+    def forward_stages(self, x, stage_lo, stage_hi, geometry=None, want_feat=False, taps=()):
         """Stages ``stage_lo..stage_hi`` only (what KSVQE.forward interleaves its modulation with, KSVQE_model.py:1433-1486).
         ``stage_lo == 0``: x is the clip (B,3,T,H,W); otherwise x is the residual stream in front of ``stage_lo`` in the
         reference's layout (B, C, D, H', W') and ``geometry`` = the clip's (T, H, W).  Returns the stream behind
         ``stage_hi`` as (B, C, D, H', W') — the permuted view of the channels-last result — and, with ``want_feat`` on the
-        last stage, the final-norm feature map as ``forward`` returns it."""
+        last stage, the final-norm feature map as ``forward`` returns it.  ``taps``: indices of the reference's ``feats`` list
+        (0 = behind the embedding, i + 1 = behind stage i) this run passes; they are copied out by the same run and returned as
+        a third / second value ``{index: (B, C, D, H', W') tensor}``."""
         if not x.is_cuda:
             raise _abi.KvqError("SwinTransformer3D.forward_stages needs its input on a HIP device; there is no CPU path")
         if stage_lo == 0:
@@ -505,12 +507,31 @@ class SwinTransformer3D(nn.Module):
                 io = torch.empty(src.numel(), dtype=torch.float32, device=x.device)
             io.reshape(-1)[: src.numel()].copy_(src.reshape(-1))
         feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device) if want_feat else None
-        check(lib().kvq_swin3d_forward_stages(handle, C.byref(w), ptr(x) if stage_lo == 0 else None, stage_lo, stage_hi, ptr(io),
-                                              ptr(feat), ptr(ws), ws.numel(), current_stream()), "kvq_swin3d_forward_stages")
+        tapped = {}
+        if taps:
+            arr = (C.c_void_p * (self.num_layers + 1))()
+            for i in taps:
+                if not ((stage_lo == 0 and i == 0) or stage_lo < i <= stage_hi + 1):
+                    raise IndexError(f"feats[{i}] is not produced by stages {stage_lo}..{stage_hi}")
+                t4 = (C.c_int32 * 4)()
+                check(lib().kvq_swin3d_tap_dims(handle, i, C.byref(t4)), "kvq_swin3d_tap_dims")
+                tapped[i] = torch.empty(B, t4[1], t4[2], t4[3], t4[0], dtype=torch.float32, device=x.device)
+                arr[i] = ptr(tapped[i])
+            check(lib().kvq_swin3d_set_taps(handle, arr), "kvq_swin3d_set_taps")
+        try:
+            check(lib().kvq_swin3d_forward_stages(handle, C.byref(w), ptr(x) if stage_lo == 0 else None, stage_lo, stage_hi, ptr(io),
+                                                  ptr(feat), ptr(ws), ws.numel(), current_stream()), "kvq_swin3d_forward_stages")
+        finally:
+            if taps:
+                check(lib().kvq_swin3d_set_taps(handle, None), "kvq_swin3d_set_taps")
         check(lib().kvq_swin3d_tap_dims(handle, stage_hi + 1, C.byref(d4)), "kvq_swin3d_tap_dims")
         n = B * d4[0] * d4[1] * d4[2] * d4[3]
         out = io.reshape(-1)[:n].reshape(B, d4[1], d4[2], d4[3], d4[0]).permute(0, 4, 1, 2, 3)
-        return (out, feat.permute(0, 4, 1, 2, 3)) if want_feat else out
+        res = (out, feat.permute(0, 4, 1, 2, 3)) if want_feat else out
+        if taps:
+            tapped = {i: t.permute(0, 4, 1, 2, 3) for i, t in tapped.items()}
+            return (res + (tapped,)) if want_feat else (res, tapped)
+        return res
 
     # profiling hooks used by bench.py ------------------------------------------------------
     def profile(self, B, T, H, W, device, enable: bool):

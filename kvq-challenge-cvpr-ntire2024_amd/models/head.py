@@ -14,8 +14,6 @@ class VQAHead(nn.Module):
     def __init__(self, in_channels=768, hidden_channels=64, num_class=1, dropout_ratio=0.5, pre_pool=False,
                  **kwargs):
         super().__init__()
-        if num_class != 1 or pre_pool:
-            raise NotImplementedError("VQAHead: only num_class=1, pre_pool=False is used by the reference configs")
         self.in_channels, self.hidden_channels, self.num_class = in_channels, hidden_channels, num_class
         self.dropout_ratio, self.pre_pool = dropout_ratio, pre_pool
         self.fc_hid = _Affine((hidden_channels, in_channels, 1, 1, 1), (hidden_channels,))
@@ -37,8 +35,11 @@ class VQAHead(nn.Module):
         return self._cache[1]
 
     def forward(self, x, rois=None):
-        """x (B, C, D, H, W) fp32 (any strides) -> (B, 1)."""
+        """x (B, C, D, H, W) fp32 (any strides) -> (B, num_class)."""
         w1t, b1, w2, b2, w1 = self._prepared(x.device)
+        if self.num_class != 1 or self.pre_pool:      # head.py:61-62, :66-67 — no reference config takes these branches
+            return kernels.vqa_head_classes(x.to(torch.float32), w1, b1, w2.reshape(self.num_class, -1), b2,
+                                            pre_pool=self.pre_pool)
         return kernels.vqa_head(x.to(torch.float32), w1, b1, w2, b2, w1t=w1t)
 
 

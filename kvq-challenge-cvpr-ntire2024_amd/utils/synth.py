@@ -102,12 +102,12 @@ def swin_param_shapes(cfg: SwinCfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return s
 
 
-def vqa_head_param_shapes(in_channels=768, hidden=64) -> "OrderedDict[str, Tuple[int, ...]]":
+def vqa_head_param_shapes(in_channels=768, hidden=64, num_class=1) -> "OrderedDict[str, Tuple[int, ...]]":
     return OrderedDict([
         ("fc_hid.weight", (hidden, in_channels, 1, 1, 1)),
         ("fc_hid.bias", (hidden,)),
-        ("fc_last.weight", (1, hidden, 1, 1, 1)),
-        ("fc_last.bias", (1,)),
+        ("fc_last.weight", (num_class, hidden, 1, 1, 1)),
+        ("fc_last.bias", (num_class,)),
     ])
 
 
@@ -368,8 +368,8 @@ def synth_ksvqe_inputs(seed: int = 0, b: int = 2, t: int = 32):
             "dis_label": np.arange(b, dtype=np.int64) % 2}
 
 
-def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress"):
-    return synth_params(vqa_head_param_shapes(in_channels, hidden), seed, scheme, prefix="head.")
+def synth_vqa_head_weights(in_channels=768, hidden=64, seed: int = 0, scheme: str = "stress", num_class=1):
+    return synth_params(vqa_head_param_shapes(in_channels, hidden, num_class), seed, scheme, prefix="head.")
 
 
 def synth_simple_head_weights(in_channels=9472, hidden=128, seed: int = 0, scheme: str = "stress"):

@@ -147,9 +147,11 @@ def contrastive_supervised(feat, dis_label):
     return torch.mean(torch.log(torch.sum(torch.exp(sim) * off, dim=1)) - torch.sum(sim * pos, dim=1) / torch.sum(pos, dim=1))
 
 
-def ksvqe_forward(inputs, params, cfg, clip_location=8, tuning_stage=2):
+def ksvqe_forward(inputs, params, cfg, clip_location=8, tuning_stage=2, multi=False, layer=-1):
     """KSVQE.forward (:1389-1500), eval: inputs = {resize_video (b,3,t,112,112), fragment (b,3,t,288,288), dis_label (b,)};
-    params = the model's state_dict (numpy / tensors); cfg = the trunk's SwinCfg.  Returns (features (b, 768, t/2, 7, 7), loss)."""
+    params = the model's state_dict (numpy / tensors); cfg = the trunk's SwinCfg.  Returns (features (b, 768, t/2, 7, 7), loss);
+    ``multi``: the trilinear-resized concat of feats[:-1] instead (:1489-1495); ``layer`` > -1: feats[layer] (:1496-1498) — feats =
+    [behind the embedding, behind every stage (a tuned stage: after its modulation)]."""
     from . import clip_oracle as CO
     from . import swin3d_oracle as O
     p = {k: ((v if torch.is_tensor(v) else torch.from_numpy(v))) for k, v in params.items()}
@@ -169,6 +171,7 @@ def ksvqe_forward(inputs, params, cfg, clip_location=8, tuning_stage=2):
     loss = contrastive_supervised(dist, dis_label)
     shift = tuple(w // 2 for w in cfg.window)
     y = O.patch_embed(x_ori, p, cfg.patch)
+    feats = [y]
     for i in range(len(cfg.depths)):
         for blk in range(cfg.depths[i]):
             y = O.swin_block(y, p, f"layers.{i}.blocks.{blk}.", cfg.num_heads[i], cfg.window, (0, 0, 0) if blk % 2 == 0 else shift)
@@ -190,5 +193,12 @@ def ksvqe_forward(inputs, params, cfg, clip_location=8, tuning_stage=2):
             de = de.reshape(n, hh * ww, tt, c).permute(0, 3, 2, 1).reshape(n, c, tt, hh, ww)
             x_d = dist_transformation3(de, y.reshape(n, tt * hh * ww, c), sub(f"distortion_mod.{k}.")).reshape(n, tt, hh, ww, c)
             y = (p["a1"][k] * x_d + p["a2"][k] * x_s) / 2
+        feats.append(y)
+    cf5 = lambda v: v.permute(0, 4, 1, 2, 3).contiguous()                                  # noqa: E731
+    if multi:
+        size = tuple(y.shape[1:4])
+        return torch.cat([F.interpolate(cf5(f), size=size, mode="trilinear") for f in feats[:-1]], 1)
+    if layer > -1:
+        return cf5(feats[layer])
     y = F.layer_norm(y, (y.shape[-1],), p["norm.weight"], p["norm.bias"])
     return y.permute(0, 4, 1, 2, 3).contiguous(), loss

@@ -362,13 +362,19 @@ def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, oper
     return (out, stages) if return_stages else out
 
 
-def vqa_head(feat: torch.Tensor, hp) -> torch.Tensor:
-    """feat (B,C,D,H,W) -> (B,1): mean over tokens of w2·GELU(W1 f + b1) + b2 (head.py:60-68, eval)."""
+def vqa_head(feat: torch.Tensor, hp, pre_pool: bool = False) -> torch.Tensor:
+    """feat (B,C,D,H,W) -> (B,num_class): mean over tokens of w2·GELU(W1 f + b1) + b2 (head.py:60-68, eval); ``pre_pool``: the token
+    grid is averaged first (:61-62); num_class > 1: nn.Softmax() — implicit dim 1, the classes — per token before the mean (:66-67)."""
     p = {k: _t(v).float() for k, v in hp.items()}
     B, C = feat.shape[:2]
     f = feat.reshape(B, C, -1).transpose(1, 2)
+    if pre_pool:
+        f = f.mean(dim=1, keepdim=True)
+    K = p["fc_last.weight"].shape[0]
     h = F.gelu(F.linear(f, p["fc_hid.weight"].reshape(-1, C), p["fc_hid.bias"]))
-    s = F.linear(h, p["fc_last.weight"].reshape(1, -1), p["fc_last.bias"])
+    s = F.linear(h, p["fc_last.weight"].reshape(K, -1), p["fc_last.bias"])
+    if K > 1:
+        s = torch.softmax(s, dim=-1)
     return s.mean(dim=1)
 
 

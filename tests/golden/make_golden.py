@@ -177,6 +177,18 @@ def sec_heads(ref):
         s_ref = head(torch.from_numpy(feat)).numpy()
     assert np.abs(O.vqa_head(torch.from_numpy(feat), hw).numpy() - s_ref).max() < 1e-6
     d["vqa/score"] = s_ref
+    # the branches no config takes (head.py:61-62 pre_pool, :66-67 num_class > 1 with nn.Softmax()'s implicit dim)
+    import warnings
+    for tag, K, pool in (("pool", 1, True), ("k3", 3, False), ("k5pool", 5, True)):
+        hk = synth.synth_vqa_head_weights(768, 64, 6, "stress", num_class=K)
+        hd = ref.head.VQAHead(in_channels=768, hidden_channels=64, num_class=K, pre_pool=pool).eval()
+        hd.load_state_dict({k: torch.from_numpy(v) for k, v in hk.items()})
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = hd(torch.from_numpy(feat)).numpy()
+        assert sk.shape == (3, K)
+        assert np.abs(O.vqa_head(torch.from_numpy(feat), hk, pre_pool=pool).numpy() - sk).max() < 1e-6
+        d[f"vqa/{tag}/score"] = sk
     f2 = g.standard_normal((2, 8, 9472)).astype(np.float32)
     sw = synth.synth_simple_head_weights(9472, 128, 5, "stress")
     sh = ref.head.simpleVQAHead(9472, 128).eval()
@@ -510,6 +522,17 @@ def sec_ksvqe(ref):
     assert e <= 5e-4 and abs(float(l) - float(l_ref)) <= 1e-4
     d = {"loss": np.float64(l_ref)}
     put(d, "feat", samples(f_ref.numpy(), 8192))
+    # the feature taps no caller asks for (:1489-1498): multi = resized concat of feats[:-1]; layer = feats[layer]
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        taps_ref = {"multi": m(inp, multi=True), "layer0": m(inp, layer=0), "layer2": m(inp, layer=2), "layer4": m(inp, layer=4)}
+        taps_orc = {"multi": KO.ksvqe_forward(inp, wts, synth.SWIN_T_GRPB, multi=True)}
+        for k in (0, 2, 4):
+            taps_orc[f"layer{k}"] = KO.ksvqe_forward(inp, wts, synth.SWIN_T_GRPB, layer=k)
+    for k, v in taps_ref.items():
+        e = float((taps_orc[k] - v).abs().max())
+        print(f"ksvqe {k}: {tuple(v.shape)} |oracle-ref| {e:.2e} (max {float(v.abs().max()):.2f})")
+        assert taps_orc[k].shape == v.shape and e <= 5e-4 * max(1.0, float(v.abs().max()))
+        put(d, k, samples(v.numpy(), 4096))
     save("ksvqe.npz", d)
 
 

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in kvq_hip.h but not exported"
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
-    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 29
+    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 30
 
 
 def test_struct_layouts_match_header_sizes():

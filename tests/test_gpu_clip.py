@@ -229,6 +229,29 @@ def test_ksvqe_end_to_end_vs_reference_golden(golden, dtype):
     assert (scores.float().cpu() - s_or).abs().max().item() <= 1e-3
 
 
+def test_ksvqe_feature_taps_vs_reference_golden(golden):
+    """KSVQE.forward(multi=True) / (layer=k) (KSVQE_model.py:1489-1498; no caller asks for them): feats = [behind the embedding,
+    behind every stage — a tuned stage after its CDM], against the reference's stored outputs."""
+    from kvq_amd.models.backbones.KSVQE_model import KSVQE
+    g = golden("ksvqe.npz")
+    bb = KSVQE(num_samples=1, sample_type="topkpertubation", CLIP_location=8, cls_use=True, tuning_stage=2, a1=1, a2=0, frozen_stages=-1)
+    bb.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_ksvqe_weights(3).items()}, strict=False)
+    bb.operand_dtype = _abi.dtype_code("fp16")
+    bb = bb.to(DEV).eval()
+    inp = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_ksvqe_inputs(4, b=2).items()}
+    with torch.no_grad():
+        outs = {"multi": bb(dict(inp), multi=True), "layer0": bb(dict(inp), layer=0), "layer2": bb(dict(inp), layer=2),
+                "layer4": bb(dict(inp), layer=4)}
+        with pytest.raises(IndexError):
+            bb(dict(inp), layer=5)
+    for k, v in outs.items():
+        f = np.ascontiguousarray(v.float().cpu().numpy())
+        assert f.shape == tuple(g[f"{k}/shape"]), (k, f.shape)
+        got, ref = f.reshape(-1)[g[f"{k}/idx"]], g[f"{k}/val"]
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel <= (2e-3 if k == "layer0" else 1e-2), (k, rel)
+
+
 def test_crop_regions_scalar_and_vector_paths():
     """kvq_crop_regions against the same gather written with slices: 6-pixel anchors (scalar kernel) and 32-pixel ones (16-byte
     kernel) — copy work, bit-exact."""

@@ -707,6 +707,27 @@ def test_vqa_head_layouts(shape, hidden):
     assert torch.equal(one, out_cl[-1:])
 
 
+@pytest.mark.parametrize("K,pool,hidden", [(1, True, 64), (3, False, 64), (5, True, 64), (4, False, 96)])
+def test_vqa_head_pre_pool_and_classes(K, pool, hidden, golden):
+    """VQAHead's pre_pool / num_class > 1 branches (head.py:61-62, :66-67) through the module with the reference's constructor
+    arguments: against the oracle on both feature layouts, and (64 hidden units) against the reference's own stored outputs."""
+    from kvq_amd.models.head import VQAHead
+    g = rng(77)
+    feat = torch.from_numpy(g.standard_normal((3, 768, 4, 7, 7)).astype(np.float32))
+    hw = synth.synth_vqa_head_weights(768, hidden, 6, "stress", num_class=K)
+    ref = O.vqa_head(feat, hw, pre_pool=pool)
+    head = VQAHead(in_channels=768, hidden_channels=hidden, num_class=K, pre_pool=pool).eval()
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()})
+    head = head.to("cuda")
+    out_cf = head(dev(feat))
+    out_cl = head(dev(feat).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3))
+    assert out_cf.shape == (3, K)
+    assert (out_cf.cpu() - ref).abs().max().item() <= 2e-5 and (out_cl.cpu() - ref).abs().max().item() <= 2e-5
+    tag = {(1, True): "pool", (3, False): "k3", (5, True): "k5pool"}.get((K, pool))
+    if tag and hidden == 64:
+        assert np.abs(out_cf.cpu().numpy() - golden("heads.npz")[f"vqa/{tag}/score"]).max() <= 2e-5
+
+
 def test_simple_vqa_head():
     g = rng(78)
     feat = torch.from_numpy(g.standard_normal((2, 8, 9472)).astype(np.float32))

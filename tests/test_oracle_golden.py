@@ -105,6 +105,9 @@ def test_heads(golden):
     feat = rng.standard_normal((3, 768, 4, 7, 7)).astype(np.float32)
     s = O.vqa_head(torch.from_numpy(feat), synth.synth_vqa_head_weights(768, 64, 5, "stress"))
     assert np.abs(s.numpy() - g["vqa/score"]).max() < 1e-6
+    for tag, K, pool in (("pool", 1, True), ("k3", 3, False), ("k5pool", 5, True)):      # head.py:61-62, :66-67
+        sk = O.vqa_head(torch.from_numpy(feat), synth.synth_vqa_head_weights(768, 64, 6, "stress", num_class=K), pre_pool=pool)
+        assert sk.shape == (3, K) and np.abs(sk.numpy() - g[f"vqa/{tag}/score"]).max() < 1e-6
     f2 = rng.standard_normal((2, 8, 9472)).astype(np.float32)
     s2 = O.simple_vqa_head(torch.from_numpy(f2), synth.synth_simple_head_weights(9472, 128, 5, "stress"))
     assert np.abs(s2.numpy() - g["simple/score"]).max() < 1e-5
@@ -258,6 +261,11 @@ def test_ksvqe_forward_end_to_end(golden):
     assert tuple(g["feat/shape"]) == a.shape == (2, 768, 16, 7, 7)
     assert np.abs(a.reshape(-1)[g["feat/idx"]] - g["feat/val"]).max() <= 5e-4
     assert abs(float(l) - float(g["loss"])) <= 1e-4
+    # the feature taps (KSVQE_model.py:1489-1498): the resized concat of feats[:-1] covers every entry but the last
+    with torch.no_grad():
+        mt = KO.ksvqe_forward(inp, synth.synth_ksvqe_weights(3), synth.SWIN_T_GRPB, multi=True).numpy()
+    assert tuple(g["multi/shape"]) == mt.shape == (2, 96 + 192 + 384 + 768, 16, 7, 7)
+    assert np.abs(mt.reshape(-1)[g["multi/idx"]] - g["multi/val"]).max() <= 5e-4 * float(np.abs(g["multi/val"]).max())
 
 
 def test_ksvqe_state_dict_surface():

@@ -1,0 +1,7 @@
+#!/bin/bash
+# packed-fp16 GELU in the fused tails: kernel + end-to-end parity tests, then same-box alternating A/B against the fp32 evaluation (KVQ_BUILD_TAG=pk0)
+out=gpurun_out/r05b; mkdir -p $out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py -m gpu -x -q > $out/gelu_tests.log 2>&1; echo "pytest rc $?" >> $out/gelu_tests.log
+tail -4 $out/gelu_tests.log
+bash tools/ab_bench.sh $out/gelu_pk16_ab.txt 3 "KVQ_BUILD_TAG=pk0" "KVQ_GELU_VARIANT=pk16" --legs c5 --steps 20 --warmup 5 --profile-steps 0
