@@ -209,21 +209,42 @@ def masked_lanes(n, mode, device):
     return out
 
 
+_LANE_POOL = None
+
+
 def run_lanes(lanes, n, fn):
     """consecutive steps (whole batches, independent of each other) go to alternating HIP streams; all n steps are enqueued,
-    the caller synchronises.  fn(step, lane_index) enqueues one step on the CURRENT stream and returns its output."""
+    the caller synchronises.  fn(step, lane_index) enqueues one step on the CURRENT stream and returns its output.
+    KVQ_LANE_THREADS=1 (experiment): one host thread per lane enqueues that lane's steps, so the lanes of a block start together
+    instead of one step's enqueue time apart."""
     import torch
+    global _LANE_POOL
     main = torch.cuda.current_stream()
     others = [st for st in lanes if st != main]
     for st in others:
         st.wait_stream(main)
-    outs = []
-    stagger = int(os.environ.get("KVQ_LANE_STAGGER_CYCLES", "0"))      # experiment: lane i starts i * stagger clock ticks late
-    for s in range(n):
-        with torch.cuda.stream(lanes[s % len(lanes)]):
-            if stagger and 0 < s < len(lanes):
-                torch.cuda._sleep(stagger * s)
-            outs.append(fn(s, s % len(lanes)))
+    outs = [None] * n
+    if os.environ.get("KVQ_LANE_THREADS", "0") == "1" and len(lanes) > 1 and n >= len(lanes):
+        from concurrent.futures import ThreadPoolExecutor
+        if _LANE_POOL is None or _LANE_POOL._max_workers < len(lanes):
+            _LANE_POOL = ThreadPoolExecutor(max_workers=len(lanes))
+        dev = torch.cuda.current_device()
+
+        def lane_job(ln):
+            torch.cuda.set_device(dev)                 # device, grad mode and current stream are per-thread state
+            with torch.no_grad(), torch.cuda.stream(lanes[ln]):
+                for s in range(ln, n, len(lanes)):
+                    outs[s] = fn(s, ln)
+
+        for f in [_LANE_POOL.submit(lane_job, ln) for ln in range(len(lanes))]:
+            f.result()
+    else:
+        stagger = int(os.environ.get("KVQ_LANE_STAGGER_CYCLES", "0"))      # experiment: lane i starts i * stagger clock ticks late
+        for s in range(n):
+            with torch.cuda.stream(lanes[s % len(lanes)]):
+                if stagger and 0 < s < len(lanes):
+                    torch.cuda._sleep(stagger * s)
+                outs[s] = fn(s, s % len(lanes))
     for st in others:
         main.wait_stream(st)
     return outs
