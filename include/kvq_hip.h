@@ -65,6 +65,11 @@ typedef struct {
   int32_t window[3];                 /* (8,7,7) */
   int32_t mlp_ratio;                 /* 4 */
   int32_t frag_bias[KVQ_MAX_STAGES]; /* 1,1,1,0 for the GRPB trunk; 0,0,0,0 for swin_3d_tiny */
+  int32_t adaptive_window[3];        /* ABI 30.  (0,0,0): off.  Otherwise forward(adaptive_window_size=True)'s resized window
+                                      * (swin_backbone.py:54-61, :1050-1055; each entry <= window[]): every stage partitions by
+                                      * it (clamped per stage as usual, :408-413, :667-671) while the shift stays window[]/2, and
+                                      * a token's bias index is its coordinate INSIDE the resized window
+                                      * (relative_position_index[:d,:h,:w,:d,:h,:w], :266-271) instead of the [:N,:N] slice */
 } KvqSwinCfg;
 
 /* Weights of one SwinTransformerBlock3D (swin_backbone.py:385-405).  GEMM weights are bf16

@@ -44,7 +44,7 @@ class KvqSwinCfg(C.Structure):
     _fields_ = [("patch", C.c_int32 * 3), ("in_chans", C.c_int32), ("embed_dim", C.c_int32),
                 ("num_stages", C.c_int32), ("depths", C.c_int32 * MAX_STAGES),
                 ("num_heads", C.c_int32 * MAX_STAGES), ("window", C.c_int32 * 3), ("mlp_ratio", C.c_int32),
-                ("frag_bias", C.c_int32 * MAX_STAGES)]
+                ("frag_bias", C.c_int32 * MAX_STAGES), ("adaptive_window", C.c_int32 * 3)]
 
 
 class KvqSwinBlockW(C.Structure):

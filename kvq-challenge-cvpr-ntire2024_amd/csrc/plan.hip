@@ -101,9 +101,12 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
   const KvqSwinCfg& cfg = pl->cfg;
   const int dims[3] = {g.D, g.H, g.W};
   int ws[3], ss[3];
+  // forward(adaptive_window_size=True): the resized window partitions, the block's shift stays that of the configured one
+  const bool adaptive = cfg.adaptive_window[0] > 0;
   for (int a = 0; a < 3; ++a) {
-    const bool clamp = dims[a] <= cfg.window[a];
-    ws[a] = clamp ? dims[a] : cfg.window[a];
+    const int wa = adaptive ? cfg.adaptive_window[a] : cfg.window[a];
+    const bool clamp = dims[a] <= wa;
+    ws[a] = clamp ? dims[a] : wa;
     ss[a] = (clamp || par == 0) ? 0 : cfg.window[a] / 2;
   }
   if (par == 0) {
@@ -133,7 +136,8 @@ static int build_stage_maps(KvqSwinPlan* pl, StageGeom& g, int par) {
               src[r] = valid ? (ud * g.H + uh) * g.W + uw : -1;
               // bias code: raster coordinate of index n in the CONFIGURED window (reference slices
               // relative_position_index[:N,:N], swin_backbone.py:263-264)
-              const int cd = n / (Wh * Ww), ch = (n / Ww) % Wh, cw = n % Ww;
+              // adaptive windows index the table by the token's own coordinate in the resized window (:266-271)
+              const int cd = adaptive ? ld : n / (Wh * Ww), ch = adaptive ? lh : (n / Ww) % Wh, cw = adaptive ? lw : n % Ww;
               const int code = cd * (2 * Wh - 1) * (2 * Ww - 1) + ch * (2 * Ww - 1) + cw;
               const int fh = nearest_src(uh, ws[1], g.Hp), fw = nearest_src(uw, ws[2], g.Wp);
               const int region = axis_region(sd, g.Dp, ws[0], ss[0]) * 9 + axis_region(sh, g.Hp, ws[1], ss[1]) * 3 +
@@ -214,6 +218,11 @@ extern "C" int kvq_swin3d_plan_create(const KvqSwinCfg* cfg, int B, int T, int H
               KVQ_ERR_UNSUPPORTED, "embed_dim and in_chans*prod(patch) must be multiples of 32");
   KVQ_REQUIRE(cfg->window[0] * cfg->window[1] * cfg->window[2] <= 400, KVQ_ERR_UNSUPPORTED,
               "window of more than 400 tokens unsupported");
+  if (cfg->adaptive_window[0] || cfg->adaptive_window[1] || cfg->adaptive_window[2])
+    for (int a = 0; a < 3; ++a)       // the reference's relative_position_index[:d,:h,:w,...] slice needs d <= Wd etc. (:266-271)
+      KVQ_REQUIRE(cfg->adaptive_window[a] >= 1 && cfg->adaptive_window[a] <= cfg->window[a], KVQ_ERR_SHAPE,
+                  "adaptive window (%d,%d,%d) must lie inside the configured one", cfg->adaptive_window[0], cfg->adaptive_window[1],
+                  cfg->adaptive_window[2]);
   for (int i = 0; i < cfg->num_stages; ++i)
     KVQ_REQUIRE(cfg->num_heads[i] * 32 == (cfg->embed_dim << i), KVQ_ERR_UNSUPPORTED,
                 "stage %d: head_dim must be 32 (C=%d, heads=%d)", i, cfg->embed_dim << i, cfg->num_heads[i]);

@@ -111,7 +111,8 @@ class KSVQE(SwinTransformer3D):
     # ------------------------------------------------------------------ forward
     def forward(self, x, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
         if adaptive_window_size:
-            raise NotImplementedError("adaptive windows of KSVQE (KSVQE_model.py:1394-1397): no caller sets them")
+            # the reference's own branch reads ``x.shape`` of the input DICT (KSVQE_model.py:1394-1397) and raises AttributeError
+            raise AttributeError("'dict' object has no attribute 'shape'")
         want_taps = bool(multi) or layer > -1
         if layer > self.num_layers:
             raise IndexError("list index out of range")              # feats[layer] in the reference (:1497)

@@ -228,7 +228,7 @@ class SwinTransformer3D(nn.Module):
         clean = {k: v for k, v in clean.items() if k not in own or own[k].shape == v.shape}
         return self.load_state_dict(clean, strict=strict)
 
-    def cfg_struct(self) -> KvqSwinCfg:
+    def cfg_struct(self, aw=None) -> KvqSwinCfg:
         c = KvqSwinCfg()
         c.patch[:] = self.patch_size
         c.in_chans, c.embed_dim, c.num_stages = self.in_chans, self.embed_dim, self.num_layers
@@ -236,6 +236,7 @@ class SwinTransformer3D(nn.Module):
             c.depths[i], c.num_heads[i], c.frag_bias[i] = self.depths[i], self.heads[i], int(self.frag_biases[i])
         c.window[:] = self.window_size
         c.mlp_ratio = self.mlp_ratio
+        c.adaptive_window[:] = aw if aw else (0, 0, 0)
         return c
 
     def _weights(self, device) -> KvqSwinWeights:
@@ -336,7 +337,7 @@ class SwinTransformer3D(nn.Module):
         torch.cuda.synchronize(device)       # the packs were built on THIS stream; other streams may run the forward
         return w
 
-    def _set_dense_bias(self, handle, geom, device, batch):
+    def _set_dense_bias(self, handle, geom, device, batch, aw=None):
         """Point every block at the dense attention bias of this plan geometry (built on first use).  The bias is read
         from HBM once per step whatever the batch, so it pays when enough windows share an image (one image per window TYPE and
         head): Swin-T at 32x224x224 pays at any batch, Swin-B at 64x256x256 (3.2 GB of images) pays from one clip on with the
@@ -352,7 +353,7 @@ class SwinTransformer3D(nn.Module):
             for k in range(nblk):
                 blocks[k].bias_dense = None
             return
-        key = geom + (str(device), self.operand_dtype)
+        key = geom + (str(device), self.operand_dtype, aw)
         bufs = self._dense.get(key)
         if bufs is None:
             sizes = [lib().kvq_swin3d_bias_dense_bytes(handle, k) for k in range(nblk)]
@@ -375,14 +376,14 @@ class SwinTransformer3D(nn.Module):
         for k in range(nblk):
             blocks[k].bias_dense = ptr(bufs[k])
 
-    def _plan(self, B, T, H, W, device):
+    def _plan(self, B, T, H, W, device, aw=None):
         # one plan + workspace per (shape, stream): forwards issued on different streams may overlap
-        key = (B, T, H, W, str(device), self.operand_dtype, current_stream())
+        key = (B, T, H, W, str(device), self.operand_dtype, current_stream(), aw)
         hit = self._plans.get(key)
         if hit is not None:
             return hit
         handle = C.c_void_p()
-        cfg = self.cfg_struct()
+        cfg = self.cfg_struct(aw)
         check(lib().kvq_swin3d_plan_create(C.byref(cfg), B, T, H, W, self.operand_dtype, C.byref(handle)),
               "kvq_swin3d_plan_create")
         dims = (C.c_int32 * 4)()
@@ -411,9 +412,14 @@ class SwinTransformer3D(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, batch, multi=False, layer=-1, adaptive_window_size=False, **kwargs):
         """``batch['technical']``: fp32 (B,3,T,H,W) on a HIP device -> (B, C_out, T/2, H/32, W/32)."""
-        if adaptive_window_size:
-            raise NotImplementedError("adaptive windows (swin_backbone.py:1051-1054): no caller sets them")
         x = batch["technical"]
+        aw = None
+        if adaptive_window_size:
+            # get_adaptive_window_size (swin_backbone.py:54-61, :1050-1053): the window scales with the clip against base_x_size
+            aw = tuple((w * xs) // bs for w, xs, bs in zip(self.window_size, tuple(x.shape[2:]), self.base_x_size))
+            if any(a < 1 or a > w for a, w in zip(aw, self.window_size)):
+                # the reference's relative_position_index[:d,:h,:w,:d,:h,:w] slice (:266-271) cannot serve such a window either
+                raise ValueError(f"adaptive window {aw} of a {tuple(x.shape[2:])} clip does not lie inside {tuple(self.window_size)}")
         if not x.is_cuda:
             raise _abi.KvqError("SwinTransformer3D.forward needs the clip on a HIP device; there is no CPU path")
         frag = None
@@ -432,9 +438,9 @@ class SwinTransformer3D(nn.Module):
         else:
             x = x.to(torch.float32).contiguous()
         B, _, T, H, W = x.shape
-        handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device)
+        handle, (Cout, D, Hh, Ww), ws = self._plan(B, T, H, W, x.device, aw)
         w = self._weights(x.device)
-        self._set_dense_bias(handle, (T, H, W), x.device, B)
+        self._set_dense_bias(handle, (T, H, W), x.device, B, aw)
         feat = torch.empty(B, D, Hh, Ww, Cout, dtype=torch.float32, device=x.device)
         taps = None
         if multi or layer > -1:

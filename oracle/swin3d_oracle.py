@@ -50,7 +50,7 @@ def _nearest_src(dst: np.ndarray, in_size: int, out_size: int) -> np.ndarray:
     return np.minimum(np.floor(dst.astype(np.float32) * scale).astype(np.int64), in_size - 1)
 
 
-def window_layout(D: int, H: int, W: int, window: Sequence[int], shift: Sequence[int]):
+def window_layout(D: int, H: int, W: int, window: Sequence[int], shift: Sequence[int], adaptive: Optional[Sequence[int]] = None):
     """All index maps of one (stage, block-parity) for a (D,H,W) token grid.
 
     Returns a dict with
@@ -60,8 +60,11 @@ def window_layout(D: int, H: int, W: int, window: Sequence[int], shift: Sequence
                     (after pad + roll(-ss) + partition), or -1 for a zero pad row
       frag          (nW*N, 2) int64: fragment ids (h, w) of each windowed row (global_position_index)
       region        (nW*N,) int64: shift-mask region id of each windowed row (compute_mask)
+      sub           None, or — ``adaptive`` = forward(adaptive_window_size=True)'s resized window (swin_backbone.py:54-61, :1050-1055):
+                    the resized window partitions (clamped as usual, :408-413) while ``shift`` stays the configured block's — the
+                    clamped resized window, whose own coordinates index the bias tables (:266-271)
     """
-    ws, ss = clamp_window((D, H, W), window, shift)
+    ws, ss = clamp_window((D, H, W), window if adaptive is None else adaptive, shift)
     Dp = -(-D // ws[0]) * ws[0]
     Hp = -(-H // ws[1]) * ws[1]
     Wp = -(-W // ws[2]) * ws[2]
@@ -94,18 +97,25 @@ def window_layout(D: int, H: int, W: int, window: Sequence[int], shift: Sequence
         return r
     region = (axis_region(sd, Dp, ws[0], ss[0]) * 9 + axis_region(sh, Hp, ws[1], ss[1]) * 3
               + axis_region(sw, Wp, ws[2], ss[2])).astype(np.int64)
-    return dict(ws=ws, ss=ss, Dp=Dp, Hp=Hp, Wp=Wp, nW=nW, N=N, src=src, frag=frag, region=region)
+    return dict(ws=ws, ss=ss, Dp=Dp, Hp=Hp, Wp=Wp, nW=nW, N=N, src=src, frag=frag, region=region,
+                sub=None if adaptive is None else tuple(ws))
 
 
-def rel_pos_index(window: Sequence[int], N: Optional[int] = None) -> np.ndarray:
+def rel_pos_index(window: Sequence[int], N: Optional[int] = None, sub: Optional[Sequence[int]] = None) -> np.ndarray:
     """(N,N) index into the bias tables.  Token n takes the raster coordinate of the
     *configured* window (the reference slices the full table ``[:N,:N]`` when the window
-    was clamped, swin_backbone.py:263-264)."""
+    was clamped, swin_backbone.py:263-264).  ``sub`` (adaptive windows, :266-271): the index is
+    ``relative_position_index.reshape(*window, *window)[:d,:h,:w,:d,:h,:w]`` — token n's coordinate in the (d,h,w) sub-window."""
     Wd, Wh, Ww = window
     full = Wd * Wh * Ww
-    N = full if N is None else N
-    n = np.arange(N)
-    cd, ch, cw = n // (Wh * Ww), (n // Ww) % Wh, n % Ww
+    if sub is not None:
+        N = sub[0] * sub[1] * sub[2]
+        n = np.arange(N)
+        cd, ch, cw = n // (sub[1] * sub[2]), (n // sub[2]) % sub[1], n % sub[2]
+    else:
+        N = full if N is None else N
+        n = np.arange(N)
+        cd, ch, cw = n // (Wh * Ww), (n // Ww) % Wh, n % Ww
     dd = cd[:, None] - cd[None, :] + (Wd - 1)
     dh = ch[:, None] - ch[None, :] + (Wh - 1)
     dw = cw[:, None] - cw[None, :] + (Ww - 1)
@@ -203,7 +213,7 @@ def window_attention(xw: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, num
 def attention_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], window, layout) -> torch.Tensor:
     """(nW,nH,N,N) additive term: gated table bias (+ shift mask)."""
     N, nW, nH = layout["N"], layout["nW"], rpb_table.shape[1]
-    rpi = _t(rel_pos_index(window, N)).reshape(-1)
+    rpi = _t(rel_pos_index(window, N, layout.get("sub"))).reshape(-1)
     rpb = rpb_table[rpi].reshape(N, N, nH).permute(2, 0, 1)
     g = _t(frag_gate(layout)).to(torch.float32)                     # (nW,N,N)
     if fpb_table is not None:
@@ -222,7 +232,7 @@ def image_bias(rpb_table: torch.Tensor, fpb_table: Optional[torch.Tensor], windo
     -100 (minus the same shift), everything rounded to fp16.  Softmax is invariant to the per-row shift, so what this emulates is the
     image's 2^-11 relative rounding of (bias - row maximum) — test infrastructure for the kernels' tolerance, not a reference path."""
     N, nW, nH = layout["N"], layout["nW"], rpb_table.shape[1]
-    rpi = _t(rel_pos_index(window, N)).reshape(-1)
+    rpi = _t(rel_pos_index(window, N, layout.get("sub"))).reshape(-1)
     rpb = rpb_table[rpi].reshape(N, N, nH).permute(2, 0, 1)
     if fpb_table is not None:
         g = _t(frag_gate(layout)).to(torch.float32)
@@ -296,10 +306,11 @@ def attention_core_kernel_order(qk2, k, v, rpb_table, fpb_table, window, layout,
     return out
 
 
-def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift, q=_ident, kernel_order: bool = False) -> torch.Tensor:
+def swin_block(x: torch.Tensor, p, pre: str, num_heads: int, window, shift, q=_ident, kernel_order: bool = False,
+               adaptive=None) -> torch.Tensor:
     """x (B,D,H,W,C) channels-last residual stream (always fp32)."""
     B, D, H, W, C = x.shape
-    lay = window_layout(D, H, W, window, shift)
+    lay = window_layout(D, H, W, window, shift, adaptive)
     h = q(F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
     o = window_attention(gather_windows(h, lay), p, pre + "attn.", num_heads, window, lay, q=q, kernel_order=kernel_order)
     x = x + scatter_windows(o, lay, B, D, H, W)
@@ -335,13 +346,14 @@ def patch_merge_kernel_order(x: torch.Tensor, p, pre: str, q, eps: float = 1e-5)
 
 
 def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, operand_dtype=None, kernel_order: bool = False,
-                 merge_fold_max_c: int = 192):
+                 merge_fold_max_c: int = 192, adaptive_window=None):
     """x (B,3,T,H,W) fp32 -> (B,C_out,D,H/32,W/32) like the reference trunk.  ``cfg`` is a
     ``kvq_amd.utils.synth.SwinCfg``-shaped object (patch, depths, num_heads, window).
     ``operand_dtype`` None = the reference's fp32 arithmetic (this is THE oracle); torch.float16 /
     torch.bfloat16 = emulate the HIP path's MFMA-operand rounding (diagnostic only); ``kernel_order`` (with an operand dtype) also
     takes the attention kernel's softmax order and scales (``attention_core_kernel_order``) and the fused merge launch's operands
-    (``patch_merge_kernel_order``, widths up to ``merge_fold_max_c``)."""
+    (``patch_merge_kernel_order``, widths up to ``merge_fold_max_c``).  ``adaptive_window``: forward(adaptive_window_size=True)'s
+    resized window (``window * clip size // base_x_size``, swin_backbone.py:54-61), see ``window_layout``."""
     p = {k: _t(v).float() for k, v in params.items()}
     q = operand_rounding(operand_dtype)
     shift = tuple(w // 2 for w in cfg.window)
@@ -350,7 +362,7 @@ def swin3d_trunk(x: torch.Tensor, params, cfg, return_stages: bool = False, oper
     for i in range(len(cfg.depths)):
         for b in range(cfg.depths[i]):
             y = swin_block(y, p, f"layers.{i}.blocks.{b}.", cfg.num_heads[i], cfg.window,
-                           (0, 0, 0) if b % 2 == 0 else shift, q, kernel_order and operand_dtype is not None)
+                           (0, 0, 0) if b % 2 == 0 else shift, q, kernel_order and operand_dtype is not None, adaptive_window)
         if i < len(cfg.depths) - 1:
             if kernel_order and operand_dtype is not None and y.shape[-1] <= merge_fold_max_c:      # csrc/merge.hip (plan.hip KVQ_MERGE_MAXC)
                 y = patch_merge_kernel_order(y, p, f"layers.{i}.downsample.", q)

@@ -166,6 +166,44 @@ def sec_trunk(ref):
     save("trunk.npz", d)
 
 
+ADAPTIVE_CASES = [
+    # forward(adaptive_window_size=True) (swin_backbone.py:1050-1055): window = (8,7,7) * clip // (32,224,224)
+    ("t_grpb_stress_adaptive_16x160", "SWIN_T_GRPB", "stress", 0, 21, 1, 16, 160, 160),        # window (4,5,5), no padding
+    ("t_grpb_stress_adaptive_24x128x176", "SWIN_T_GRPB", "stress", 2, 22, 2, 24, 128, 176),    # window (6,4,5), W padded 44 -> 45
+]
+
+
+def sec_adaptive(ref):
+    """The reference trunk with adaptive_window_size=True — the branch no caller takes."""
+    import contextlib
+    import io
+    d = {}
+    names = []
+    for name, cfgn, scheme, wseed, cseed, B, T, H, W in ADAPTIVE_CASES:
+        cfg = getattr(synth, cfgn)
+        wts = synth.synth_swin_weights(cfg, wseed, scheme)
+        m = _ref_trunk(ref, cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in wts.items()}, strict=False)
+        x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B))
+        aw = tuple((w * xs) // bs for w, xs, bs in zip(cfg.window, (T, H, W), (32, 224, 224)))
+        with torch.no_grad():
+            with contextlib.redirect_stdout(io.StringIO()):
+                feat_ref = m({"technical": x}, adaptive_window_size=True)
+                feat_plain = m({"technical": x})
+            feat = O.swin3d_trunk(x, wts, cfg, adaptive_window=aw)
+        err = float((feat - feat_ref).abs().max())
+        print(f"{name}: window {aw} feat {tuple(feat_ref.shape)} |oracle-ref| {err:.2e}; |adaptive - plain| {float((feat_ref - feat_plain).abs().max()):.2e}")
+        assert err <= 2e-5 and float((feat_ref - feat_plain).abs().max()) > 1e-2
+        put(d, f"{name}/feat", samples(feat_ref.numpy()))
+        d[f"{name}/meta"] = np.asarray([wseed, cseed, B, T, H, W])
+        d[f"{name}/window"] = np.asarray(aw)
+        d[f"{name}/cfg"] = np.asarray(cfgn)
+        d[f"{name}/scheme"] = np.asarray(scheme)
+        names.append(name)
+    d["cases"] = np.asarray(names)
+    save("adaptive.npz", d)
+
+
 def sec_heads(ref):
     d = {}
     g = np.random.Generator(np.random.PCG64(77))
@@ -658,7 +696,7 @@ def sec_sfclips(ref):
     save("sfclips.npz", d)
 
 
-SECTIONS = {"sfclips": sec_sfclips, "ksvqe": sec_ksvqe, "contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler}
+SECTIONS = {"sfclips": sec_sfclips, "ksvqe": sec_ksvqe, "contrique": sec_contrique, "qrs": sec_qrs, "cdm": sec_cdm, "clip": sec_clip, "taps": sec_taps, "ckpt": sec_ckpt, "resnet": sec_resnet, "layout": sec_layout, "trunk": sec_trunk, "heads": sec_heads, "sampler": sec_sampler, "adaptive": sec_adaptive}
 
 
 def main():

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     import ctypes as C
-    assert C.sizeof(_abi.KvqSwinCfg) == 4 * (3 + 1 + 1 + 1 + 4 + 4 + 3 + 1 + 4)
+    assert C.sizeof(_abi.KvqSwinCfg) == 4 * (3 + 1 + 1 + 1 + 4 + 4 + 3 + 1 + 4 + 3)
     assert C.sizeof(_abi.KvqSwinBlockW) == 18 * 8
     assert C.sizeof(_abi.KvqBlockTailArgs) == 144
     assert C.sizeof(_abi.KvqSwinWeights) == 5 * 8 + 8 + 3 * 4 * 8 + 2 * 8

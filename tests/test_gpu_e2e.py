@@ -86,6 +86,40 @@ def test_trunk_and_score_vs_reference_golden(golden, case, dtype):
     assert d <= tol, (d, score.cpu().numpy().ravel(), g[f"{case}/score"].ravel())
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", ["t_grpb_stress_adaptive_16x160", "t_grpb_stress_adaptive_24x128x176"])
+def test_trunk_adaptive_window_vs_reference_golden(golden, case, dtype):
+    """SwinTransformer3D.forward(adaptive_window_size=True) (swin_backbone.py:1050-1055; no caller sets it): the window scales with
+    the clip (``KvqSwinCfg.adaptive_window``), the shift stays the configured block's, the bias index is the token's coordinate in
+    the resized window — against the reference's stored features, and the scores of the HIP features against the oracle's."""
+    g = golden("adaptive.npz")
+    wseed, cseed, B, T, H, W = (int(v) for v in g[f"{case}/meta"])
+    cfgn, scheme = str(g[f"{case}/cfg"]), str(g[f"{case}/scheme"])
+    cfg = getattr(synth, cfgn)
+    net, key = build_network(cfgn, wseed, scheme, dtype)
+    bb = getattr(net, key + "_backbone")
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B)).to(DEV)
+    with torch.no_grad():
+        feat = bb({"technical": x}, adaptive_window_size=True)
+        plain = bb({"technical": x})
+        again = bb({"technical": x}, adaptive_window_size=True)              # the two plans of one geometry do not mix
+    assert torch.equal(feat, again) and not torch.equal(feat, plain)
+    f = np.ascontiguousarray(feat.cpu().numpy())
+    assert tuple(g[f"{case}/feat/shape"]) == f.shape
+    got, ref_vals = f.reshape(-1)[g[f"{case}/feat/idx"]], g[f"{case}/feat/val"]
+    rel = np.linalg.norm(got - ref_vals) / np.linalg.norm(ref_vals)
+    assert rel <= FEAT_REL_L2[dtype], rel
+    hw = synth.synth_vqa_head_weights(cfg.num_features, 64, wseed, scheme)
+    aw = tuple(int(v) for v in g[f"{case}/window"])
+    with torch.no_grad():
+        s_or = O.vqa_head(O.swin3d_trunk(x.cpu(), synth.synth_swin_weights(cfg, wseed, scheme), cfg, adaptive_window=aw), hw)
+        s_hip = O.vqa_head(feat.cpu().contiguous(), hw)
+    tol = SCORE_TOL if dtype == "fp16" else BF16_STRESS_TOL
+    assert (s_hip - s_or).abs().max().item() <= tol
+    with pytest.raises(ValueError):                                           # a clip larger than base_x_size: the window would grow
+        bb({"technical": torch.zeros(1, 3, 48, 224, 224, device=DEV)}, adaptive_window_size=True)
+
+
 @pytest.mark.parametrize("case", ["t_grpb_stress_8x80", "t_grpb_stress_16x64"])
 def test_bf16_path_matches_bf16_emulation(golden, case):
     """The bf16 kernels against an fp32 emulation of bf16 operand rounding AT THE KERNELS' ROUNDING POINTS (oracle

@@ -67,6 +67,20 @@ def test_trunk_small(golden, case):
     assert np.abs(score.numpy() - g[f"{case}/score"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("case", ["t_grpb_stress_adaptive_16x160", "t_grpb_stress_adaptive_24x128x176"])
+def test_trunk_adaptive_window(golden, case):
+    """forward(adaptive_window_size=True) (swin_backbone.py:54-61, :1050-1055, the sub-window bias index :266-271): the oracle's
+    ``adaptive_window`` against the reference's stored features."""
+    g = golden("adaptive.npz")
+    wseed, cseed, B, T, H, W = (int(v) for v in g[f"{case}/meta"])
+    cfg = getattr(synth, str(g[f"{case}/cfg"]))
+    aw = tuple(int(v) for v in g[f"{case}/window"])
+    assert aw == tuple((w * xs) // bs for w, xs, bs in zip(cfg.window, (T, H, W), (32, 224, 224)))
+    x = torch.from_numpy(synth.synth_clip(cseed, T, H, W, batch=B))
+    feat = O.swin3d_trunk(x, synth.synth_swin_weights(cfg, wseed, str(g[f"{case}/scheme"])), cfg, adaptive_window=aw)
+    _check_samples(g, f"{case}/feat", feat.numpy(), 2e-5)
+
+
 def test_kernel_order_emulation_is_the_same_function(golden):
     """The emulation's kernel-order pieces (``attention_core_kernel_order``: log2-unit scores, fp16 bias image, running maximum per 32
     keys; ``patch_merge_kernel_order``: LayerNorm folded around the GEMM) computed WITHOUT operand rounding are the reference's
