@@ -61,8 +61,10 @@ def parse():
                          "measured 1 / 2 / 3 / 4 / 5 / 6 streams: 2.12 / 1.77 / 1.76 / 1.745 / 1.84 / 1.71-1.84 ms per step)")
     ap.add_argument("--cu-mask", default="none", choices=["none", "blocks", "interleave", "xcd"],
                     help="experiment: give every stream lane its own share of the CUs (hipExtStreamCreateWithCUMask)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="1: capture one step per stream in a hipGraph (pre-sampled clips only) and replay it")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: every lane replays ONE recorded forward (kvq_amd/graph.py); a step still reads its own clips - the recorded "
+                         "embedding launch takes their addresses from a device table (kernels.FragmentSlot).  0: eager launches.  "
+                         "-1 (default): 1 on several lanes with the sampler fused into the step, else 0")
     ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,two_launch,bf16,bf16_init,batch8,c3,c5,ksvqe ('all', 'c2' = none)")
     ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -752,7 +754,7 @@ def main():
 
     # pre-sampled clips for the --no-sampler definition: K1 run once, outside the timed region, distinct per step
     pre = None
-    if args.no_sampler or "no_sampler" in legs or args.graph:
+    if args.no_sampler or "no_sampler" in legs:
         npre = min(need, src.n) // B
         pre = [torch.empty(B, 3, 32, 224, 224, device=device) for _ in range(max(1, npre))]
         for i, t in enumerate(pre):
@@ -762,46 +764,52 @@ def main():
     def step_presampled(s, ln):
         return net(inputs={"technical": pre[s % len(pre)]}, reduce_scores=True)
 
-    graphs = []
-    if args.graph:            # one hipGraph per lane over a STATIC pre-sampled batch (replay measures launch overhead only)
-        with torch.no_grad():
-            for cap in [torch.cuda.Stream(device=device) for _ in range(nstream)]:
-                cap.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(cap):
-                    for _ in range(2):
-                        net(inputs={"technical": pre[0]}, reduce_scores=True)
-                cap.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap):
-                    o = net(inputs={"technical": pre[0]}, reduce_scores=True)
-                graphs.append((g, o, cap))
-            torch.cuda.synchronize()
+    sampler_on = not args.no_sampler
+    # --graph 1 (below): every lane replays ONE recorded forward (kvq_amd/graph.py, the harness's own replay path); a step still reads its own
+    # clips — the recorded embedding launch takes the frames' and draws' addresses from a 384-byte device table
+    # (kernels.FragmentSlot / KvqFragmentSource.indirect) that is rewritten on the lane's stream in front of the replay
+    glanes = None
+    graphable = {}            # step function -> the input of step s, for the definitions a recorded forward can serve
 
     def steps_of(step_fn):
-        def run(n, first):
-            if graphs:
-                glanes = [g[2] for g in graphs]
+        """run(n, first): enqueue steps first .. first+n-1 of this definition over the lanes (eager launches; --graph 1: replays of a
+        forward recorded HERE, i.e. with the weights / operand type in force when the leg starts)"""
+        if args.graph and step_fn in graphable:
+            from kvq_amd.graph import LaneGraphs
+            graph_input = graphable[step_fn]
+            graphs = LaneGraphs(lambda inp: net(inputs=inp, reduce_scores=True), glanes)
+            with torch.no_grad():
+                for ln in range(nstream):          # record every lane before anything is timed
+                    graphs.run(ln, graph_input(ln))
+                torch.cuda.synchronize()
+            assert graphs.eager_runs == 0, "a lane's forward was not recorded"
+
+            def run(n, first):
                 main = torch.cuda.current_stream()
                 for st in glanes:
                     st.wait_stream(main)
                 outs = []
                 for s in range(n):
-                    g, o, st = graphs[s % len(graphs)]
-                    with torch.cuda.stream(st):
-                        g.replay()
-                        outs.append(o.clone())
+                    ln = s % nstream
+                    o = graphs.run(ln, graph_input(first + s))
+                    with torch.cuda.stream(glanes[ln]):
+                        outs.append(o.clone())            # the graph's static output is overwritten by the lane's next replay
                 for st in glanes:
                     main.wait_stream(st)
                 return outs
-            return run_lanes(lanes, n, lambda s, ln: step_fn(first + s, ln))
-        return run
+            return run
+        return lambda n, first: run_lanes(lanes, n, lambda s, ln: step_fn(first + s, ln))
 
     def finish(outs):
         # the path's one exchange step: all-gather of the per-rank score vectors (trainer_ddp.py:259-267)
         local = torch.cat([o.reshape(-1) for o in outs])
         return kd.gather_scores(local, local.numel() * world, rank, world) if world > 1 else local
 
-    sampler_on = not (args.no_sampler or args.graph)
+    if args.graph < 0:
+        args.graph = int(nstream > 1 and sampler_on and not args.two_launch_sampler and args.cu_mask == "none")
+    if args.graph and glanes is None:
+        glanes = [torch.cuda.Stream(device=device) for _ in range(nstream)]
+    graphable[step_fused] = lambda s: {"technical": src.fragments(s * B, B)}       # pre-sampled / two-launch definitions stay eager
     with torch.no_grad():
         dt, outs, allscores, tstats = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
                                             args.warmup, finish, min_s=args.min_timed_s)
@@ -835,7 +843,12 @@ def main():
                                    else "kvq_swin3d_forward_fragments (K1 fused into the embedding's operand read; bit-identical scores)"),
                        "source_pool_clips": src.n, "distinct_clips_per_step": True,
                        "sharding": f"videos[rank::{world}], one all-gather of scores at the end",
-                       "streams": nstream, "overlap": "steps" if nstream > 1 else "none", "hipgraph": bool(args.graph)},
+                       "streams": nstream, "overlap": "steps" if nstream > 1 else "none",
+                       "hipgraph": bool(args.graph and step_sampled in graphable),
+                       "launches": ("one recorded forward per lane, replayed (kvq_amd/graph.py LaneGraphs, the harness's path for lazy samples); "
+                                    "each step's frame / draw addresses reach the recorded embedding launch through a 384-byte device table "
+                                    "(kernels.FragmentSlot) rewritten on the lane's stream in front of the replay"
+                                    if args.graph and step_sampled in graphable else "eager, one C call per step")},
             "repeats": tstats["repeats"], "ms_per_step_min": tstats["ms_per_step_min"], "ms_per_step_max": tstats["ms_per_step_max"],
             "timed_s": tstats["timed_s"], "timing": "median of `repeats` blocks of exactly `steps` steps, each bracketed by barrier + "
                                                     "synchronize and reduced to the max over ranks",
@@ -853,7 +866,7 @@ def main():
                 out["no_sampler"] = {"value": args.steps * B / CLIPS_PER_VIDEO / dt2, "unit": "videos/s",
                                      "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps, "repeats": st2["repeats"],
                                      "note": "same steps on pre-sampled fp32 clips (K1 outside the timed region, distinct clips per "
-                                             "step): the round-1 definition of the step"}
+                                             "step): the round-1 definition of the step; eager launches"}
             if "two_launch" in legs and sampler_on and not args.two_launch_sampler:
                 dt4, outs4, _, st4 = timed(kd, device, steps_of(step_two_launch), args.steps, min(args.warmup, 5), first=args.warmup,
                                            min_s=args.min_timed_s)
@@ -918,7 +931,7 @@ def main():
                     with torch.cuda.stream(st):
                         bb.prepare(B, 32, 224, 224, device)
                 torch.cuda.synchronize()
-            if "batch8" in legs and sampler_on and not graphs:
+            if "batch8" in legs and sampler_on:
                 # information only: the same step at one whole video (8 clips) per step.  The headline stays at BASELINE configs[1]'s batch = 4.
                 B8 = 2 * B
                 xs8 = [torch.empty(B8, 3, 32, 224, 224, device=device) for _ in range(nstream)]
@@ -933,7 +946,9 @@ def main():
                     src.sample_into(xs8[ln], s * B8)
                     return net(inputs={"technical": xs8[ln]}, reduce_scores=True)
                 k8 = max(4, args.steps // 2)
-                dt8, _, _, st8 = timed(kd, device, lambda n, first: run_lanes(lanes, n, lambda s, ln: step8(first + s, ln)), k8,
+                if not args.two_launch_sampler:
+                    graphable[step8] = lambda s: {"technical": src.fragments(s * B8, B8)}
+                dt8, _, _, st8 = timed(kd, device, steps_of(step8), k8,
                                        min(args.warmup, 4), min_s=args.min_timed_s)
                 out["batch8"] = {"value": k8 * B8 / CLIPS_PER_VIDEO / dt8, "unit": "videos/s", "ms_per_step": 1e3 * dt8 / k8, "steps": k8,
                                  "repeats": st8["repeats"], "clips_per_step": B8,

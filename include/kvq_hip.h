@@ -151,6 +151,11 @@ typedef struct {
   int32_t n_clips, src_is_u8, Hs, Ws, Fh, Fw, fs_h, fs_w, aligned;
   int32_t normalise;                         /* 0: raw pixel values                                                  */
   float mean[4], std[4];
+  const void* const* indirect;               /* ABI 30.  NULL, or a DEVICE array of 3 * KVQ_FRAG_MAX_CLIPS pointers — video[16] | hoff[16] |
+                                                woff[16] — that the embedding launch reads INSTEAD of the three arrays above (which may
+                                                then stay NULL): the launch parameters no longer carry per-video addresses, so a recorded
+                                                hipGraph of the forward serves every video — the caller rewrites the 384-byte table on the
+                                                stream in front of each replay.  kvq_fragment_gather_batch refuses it. */
 } KvqFragmentSource;
 
 /* SwinTransformer3D.forward (swin_backbone.py:1044-1080), multi=False, layer=-1.

@@ -117,7 +117,7 @@ class KvqFragmentSource(C.Structure):
     _fields_ = [("video", p_void * FRAG_MAX_CLIPS), ("hoff", p_void * FRAG_MAX_CLIPS), ("woff", p_void * FRAG_MAX_CLIPS),
                 ("chan_stride", C.c_int64), ("n_clips", C.c_int32), ("src_is_u8", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Fh", C.c_int32),
                 ("Fw", C.c_int32), ("fs_h", C.c_int32), ("fs_w", C.c_int32), ("aligned", C.c_int32), ("normalise", C.c_int32),
-                ("mean", C.c_float * 4), ("std", C.c_float * 4)]
+                ("mean", C.c_float * 4), ("std", C.c_float * 4), ("indirect", p_void)]
 
 
 class KvqPatchEmbedArgs(C.Structure):

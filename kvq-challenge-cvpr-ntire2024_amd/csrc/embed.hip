@@ -26,6 +26,7 @@ struct FragSrc {
   long chan_stride;
   int Hs, Ws, Fw, fsh, fsw, aligned;
   float mean[4], std[4];
+  const void* const* table;   // KvqFragmentSource.indirect: video[16] | hoff[16] | woff[16] in device memory, or nullptr
 };
 
 struct EmbedParams {
@@ -117,10 +118,14 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
     const int oy = hh * 4 + 2 * h, ox = ww * 4;
     const int fi = oy / f.fsh, fj = ox / f.fsw;
     const int nt = p.T / f.aligned;
-    const int32_t* ho = f.hoff[bu] + (fi * f.Fw + fj) * nt;
-    const int32_t* wo = f.woff[bu] + (fi * f.Fw + fj) * nt;
+    // the clip's three pointers: launch parameters, or (a recorded forward that serves every video) one scalar load each from
+    // the caller's table
+    const int32_t* hb = f.table ? (const int32_t*)f.table[KVQ_FRAG_MAX_CLIPS + bu] : f.hoff[bu];
+    const int32_t* wb = f.table ? (const int32_t*)f.table[2 * KVQ_FRAG_MAX_CLIPS + bu] : f.woff[bu];
+    const int32_t* ho = hb + (fi * f.Fw + fj) * nt;
+    const int32_t* wo = wb + (fi * f.Fw + fj) * nt;
     const size_t plane = (size_t)f.Hs * f.Ws;
-    const uint8_t* vb = f.video[bu];
+    const uint8_t* vb = f.table ? (const uint8_t*)f.table[bu] : f.video[bu];
     typedef uint32_t __attribute__((aligned(1))) u32u;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -349,7 +354,8 @@ extern "C" int kvq_patch_embed(const KvqPatchEmbedArgs* a, void* stream) {
     KVQ_REQUIRE(kvq_patch_embed_fragments_supported(f, a->B, a->in_chans, a->pd, a->T, a->H, a->W), KVQ_ERR_UNSUPPORTED,
                 "kvq_patch_embed: fragment source (%d clips, u8=%d, %dx%d patches of %dx%d, aligned %d) does not fit the fused read "
                 "of a %dx%dx%dx%d batch", f->n_clips, f->src_is_u8, f->Fh, f->Fw, f->fs_h, f->fs_w, f->aligned, a->B, a->T, a->H, a->W);
-    for (int b = 0; b < a->B; ++b) {
+    p.frag.table = f->indirect;
+    for (int b = 0; b < a->B && !f->indirect; ++b) {
       KVQ_REQUIRE(f->video[b] && f->hoff[b] && f->woff[b], KVQ_ERR_NULL, "kvq_patch_embed: fragment source clip %d has a NULL pointer", b);
       p.frag.video[b] = (const uint8_t*)f->video[b]; p.frag.hoff[b] = f->hoff[b]; p.frag.woff[b] = f->woff[b];
     }

@@ -676,6 +676,7 @@ extern "C" int kvq_fragment_gather(const void* video, int src_is_u8, int C, int 
 extern "C" int kvq_fragment_gather_batch(const KvqFragmentSource* f, int C, int T, float* out, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(f && out, KVQ_ERR_NULL, "kvq_fragment_gather_batch: NULL pointer");
+  KVQ_REQUIRE(!f->indirect, KVQ_ERR_UNSUPPORTED, "kvq_fragment_gather_batch: a source with an indirect pointer table (the fused read's form)");
   KVQ_REQUIRE(f->n_clips > 0 && f->n_clips <= KVQ_FRAG_MAX_CLIPS && C > 0 && C <= 4 && T > 0 && f->Fh > 0 && f->Fw > 0 && f->fs_h > 0 &&
                   f->fs_w > 0 && f->aligned > 0, KVQ_ERR_SHAPE, "kvq_fragment_gather_batch: bad shape");
   KVQ_REQUIRE(T % f->aligned == 0, KVQ_ERR_SHAPE, "Please provide match vclip and align index");

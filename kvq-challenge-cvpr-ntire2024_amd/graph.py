@@ -18,8 +18,18 @@ from typing import Callable, Dict, List, Tuple
 import torch
 
 
+def _is_lazy(v) -> bool:
+    return hasattr(v, "materialise")
+
+
+def _slot_ok(v) -> bool:
+    """a lazily sampled batch (kernels.FragmentSource) the fused embedding read can take through a pointer table"""
+    return _is_lazy(v) and hasattr(v, "pointer_table") and v.c_struct() is not None
+
+
 def _signature(inputs: Dict[str, torch.Tensor]) -> Tuple:
-    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(inputs.items()))
+    return tuple((k, tuple(v.shape), v.dtype) + ((v.geometry, tuple(v.videos[0].shape), v.videos[0].stride(0)) if _is_lazy(v) else ())
+                 for k, v in sorted(inputs.items()))
 
 
 class LaneGraphs:
@@ -34,7 +44,8 @@ class LaneGraphs:
     def _record(self, lane: int, sig: Tuple, inputs: Dict[str, torch.Tensor]):
         st = self.lanes[lane]
         with torch.cuda.stream(st):
-            static = {k: v.clone() for k, v in inputs.items()}
+            from .kernels import FragmentSlot
+            static = {k: (FragmentSlot(v) if _is_lazy(v) else v.clone()) for k, v in inputs.items()}
             for _ in range(self.warmup):                       # plans, workspaces, weight images, tap tables: created eagerly
                 self.fn(dict(static))
         st.synchronize()
@@ -57,11 +68,12 @@ class LaneGraphs:
     def run(self, lane: int, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Enqueue fn(inputs) on lane's stream.  The returned tensor is the graph's static output: consume it on the same
         stream before the lane's next ``run`` (stream order makes that safe without host synchronisation)."""
-        if any(hasattr(v, "materialise") for v in inputs.values()):
-            # a recorded forward reads fixed addresses: a lazily sampled view (kernels.FragmentSource: per-video frame / draw
-            # pointers inside the launch parameters) becomes its fp32 tensor first, on the lane's stream
+        if any(_is_lazy(v) and not _slot_ok(v) for v in inputs.values()):
+            # a recorded forward reads fixed addresses.  A lazily sampled view (kernels.FragmentSource: per-video frame / draw
+            # pointers) stays lazy — the recorded forward reads them from a device table (kernels.FragmentSlot) that is rewritten in
+            # front of each replay; one the fused read cannot take (fp32 frames, > 16 clips) becomes its fp32 tensor first
             with torch.cuda.stream(self.lanes[lane]):
-                inputs = {k: (v.materialise() if hasattr(v, "materialise") else v) for k, v in inputs.items()}
+                inputs = {k: (v.materialise() if _is_lazy(v) and not _slot_ok(v) else v) for k, v in inputs.items()}
         sig = _signature(inputs)
         if sig not in self._graphs[lane] and len(self._graphs[lane]) < self.max_signatures:
             self._record(lane, sig, inputs)
@@ -73,7 +85,10 @@ class LaneGraphs:
         g, static, out = rec
         with torch.cuda.stream(self.lanes[lane]):
             for k, v in inputs.items():
-                static[k].copy_(v, non_blocking=True)
+                if _is_lazy(v):
+                    static[k].load(v)
+                else:
+                    static[k].copy_(v, non_blocking=True)
             g.replay()
         self.replays += 1
         return out

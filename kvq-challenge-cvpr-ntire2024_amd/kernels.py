@@ -347,6 +347,18 @@ class FragmentSource:
         self._c = f
         return f
 
+    def pointer_table(self):
+        """the batch's device pointers as the table ``KvqFragmentSource.indirect`` names: int64 [3 * 16] = video | hoff | woff,
+        on the device (made once; what a ``FragmentSlot`` is loaded from)"""
+        if getattr(self, "_table", None) is None:
+            n = _abi.FRAG_MAX_CLIPS
+            assert len(self.videos) <= n
+            host = torch.zeros(3 * n, dtype=torch.int64)
+            for i, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
+                host[i], host[n + i], host[2 * n + i] = ptr(v), ptr(h), ptr(w)
+            self._table = host.to(self.device)
+        return self._table
+
     def materialise(self, out=None):
         """the fp32 (B,C,T,H,W) batch: ``kvq_fragment_gather_batch`` — one launch for up to 16 clips (views included), else one
         ``fragment_gather`` per clip"""
@@ -361,6 +373,56 @@ class FragmentSource:
         for b, (v, h, w) in enumerate(zip(self.videos, self.hoffs, self.woffs)):
             fragment_gather(v.contiguous(), h, w, *self.geometry, mean=self.mean, std=self.std, out=out[b])
         return out
+
+
+class FragmentSlot(FragmentSource):
+    """A ``FragmentSource`` whose per-video addresses live in a 384-byte DEVICE table instead of the launch parameters
+    (``KvqFragmentSource.indirect``): a forward recorded into a hipGraph through a slot serves every later batch of the same
+    geometry — ``load(source)`` rewrites the table on the current stream (one small device-to-device copy) in front of the replay.
+    Same kernels, same arithmetic: scores are bit-identical to the forward on the source itself."""
+
+    def __init__(self, source: FragmentSource):
+        assert type(source) is FragmentSource and source.c_struct() is not None, "uint8 frames, at most 16 clips"
+        self.geometry, self.mean, self.std = source.geometry, source.mean, source.std
+        self.device, self.is_cuda, self.dtype, self.shape = source.device, True, source.dtype, source.shape
+        self._frame_shape, self._frame_stride = tuple(source.videos[0].shape), source.videos[0].stride(0)
+        self.table = torch.zeros(3 * _abi.FRAG_MAX_CLIPS, dtype=torch.int64, device=self.device)
+        self._c = None
+        self.load(source)
+
+    def load(self, source: FragmentSource):
+        """point the slot at ``source`` (same geometry, frame shape and normalisation), in stream order"""
+        assert (source.geometry == self.geometry and source.shape == self.shape and source.mean == self.mean and source.std == self.std
+                and tuple(source.videos[0].shape) == self._frame_shape and source.videos[0].stride(0) == self._frame_stride
+                and source.videos[0].dtype == torch.uint8), "a slot serves one geometry"
+        self.table.copy_(source.pointer_table(), non_blocking=True)
+        self.current = source                      # keeps the frames alive while the table names them
+        self.videos, self.hoffs, self.woffs = source.videos, source.hoffs, source.woffs
+
+    def c_struct(self, any_dtype=False):
+        if self._c is None:
+            f = _abi.KvqFragmentSource()
+            f.chan_stride = self._frame_stride
+            f.n_clips, f.src_is_u8, f.Hs, f.Ws = self.shape[0], 1, self._frame_shape[2], self._frame_shape[3]
+            f.Fh, f.Fw, f.fs_h, f.fs_w, f.aligned = self.geometry
+            f.normalise = int(self.mean is not None)
+            if self.mean is not None:
+                for c in range(self._frame_shape[0]):
+                    f.mean[c], f.std[c] = self.mean[c], self.std[c]
+            f.indirect = ptr(self.table)
+            self._c = f
+        return self._c
+
+    def materialise(self, out=None):
+        # the two-step form reads the loaded source's own addresses: inside a recording that would freeze THIS video's pointers
+        # into the graph, so a forward that cannot take the fused read fails its capture (LaneGraphs then runs it eagerly)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FragmentSlot.materialise() inside a hipGraph capture: this forward does not read the batch through the sampler")
+        return self.current.materialise(out)
+
+    def split_clips(self, num_clips):
+        assert num_clips == 1, "split the source, then load it"
+        return self
 
 
 # ------------------------------------------------------------------------------------------------

@@ -123,7 +123,15 @@ class Trainer:
         # SimpleVQA (~70 launches for 8 frames), which are enqueue-bound (tools/harness_probe*.py: 101 vs 62 and 283 vs 213
         # videos/s end to end); the Swin trunk alone is not (+1 %).  KVQ_GRAPH=1 / 0 forces it on / off for any model
         want = str(self.config.get("hipgraph", "auto")).lower()
-        use_graph = want in ("1", "true", "on") or (want == "auto" and self.config["model"]["type"] in ("KSVQE", "simpleVQA"))
+        # ... and, since a recorded forward can read a LAZY sample through a pointer table (kernels.FragmentSlot: no fp32 copy of the
+        # batch into a static buffer), the Swin trunk on lazy samples: +2 % on 4 lanes of 4-clip batches (bench.py, same-box A/B) and
+        # a fifth of the host time per video
+        try:
+            st_cfg = self.config["data"]["val"]["args"].get("sample_types", {})
+            lazy = any(isinstance(v, dict) and bool(v.get("lazy", False)) for v in st_cfg.values())
+        except (KeyError, AttributeError, TypeError):
+            lazy = False
+        use_graph = want in ("1", "true", "on") or (want == "auto" and (self.config["model"]["type"] in ("KSVQE", "simpleVQA") or lazy))
         # lanes: 3 eager streams; 4 graph lanes = one per hardware queue (measured, tools/harness_probe.py: 2 / 3 / 4 / 5 lanes ->
         # 238 / 270 / 284 / 240 videos/s on 96-frame KSVQE samples: a fifth lane shares a queue and its graph serialises)
         nstream = max(1, int(self.config.get("streams", os.environ.get("KVQ_STREAMS", 4 if use_graph else 3))))

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_abi.KvqSwinWeights) == 5 * 8 + 8 + 3 * 4 * 8 + 2 * 8
     assert C.sizeof(_abi.KvqPatchMergeArgs) == 96
     assert C.sizeof(_abi.KvqPatchEmbedArgs) == 128
-    assert C.sizeof(_abi.KvqFragmentSource) == 3 * 16 * 8 + 8 + 10 * 4 + 2 * 16
+    assert C.sizeof(_abi.KvqFragmentSource) == 3 * 16 * 8 + 8 + 10 * 4 + 2 * 16 + 8
     assert C.sizeof(_abi.KvqAttnDenseArgs) == 104
     assert C.sizeof(_abi.KvqGemmArgs) == 144
     assert C.sizeof(_abi.KvqConvArgs) == 160

@@ -313,6 +313,50 @@ def test_forward_on_a_fragment_source_equals_sampler_then_forward():
     assert torch.equal(parts.materialise(), src.materialise())
 
 
+def test_recorded_forward_reads_each_video_through_a_fragment_slot():
+    """hipGraph replay of the fused-sampler forward: the recorded embedding launch takes the frames' / draws' addresses from a
+    device table (kernels.FragmentSlot, KvqFragmentSource.indirect), so ONE recording serves every batch of the geometry — the
+    scores of eager forwards on the sources themselves, bit for bit, through a slot alone and through LaneGraphs (two lanes)."""
+    from kvq_amd import kernels
+    from kvq_amd.graph import LaneGraphs
+    g = torch.Generator().manual_seed(78)
+    Hs, Ws, n = 300, 420, 2
+    gh = torch.tensor([min(Hs // 7 * i, Hs - 32) for i in range(7)]).view(7, 1, 1)
+    gw = torch.tensor([min(Ws // 7 * i, Ws - 32) for i in range(7)]).view(1, 7, 1)
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+
+    def batch():
+        vids = [torch.randint(0, 256, (3, 32, Hs, Ws), dtype=torch.uint8, generator=g).to(DEV) for _ in range(n)]
+        hs = [(torch.randint(Hs // 7 - 32, (7, 7, 4), generator=g) + gh).int().to(DEV) for _ in range(n)]
+        ws = [(torch.randint(Ws // 7 - 32, (7, 7, 4), generator=g) + gw).int().to(DEV) for _ in range(n)]
+        return kernels.FragmentSource(vids, hs, ws, 7, 7, 32, 32, 8, mean=mean, std=std)
+
+    srcs = [batch() for _ in range(5)]
+    net, key = build_network("SWIN_T_GRPB", 0, "stress", "fp16")
+    with torch.no_grad():
+        eager = [net(inputs={"technical": s}, reduce_scores=True).clone() for s in srcs]
+        assert not torch.equal(eager[0], eager[1])
+        slot = kernels.FragmentSlot(srcs[0])
+        for i in (0, 3, 1):
+            slot.load(srcs[i])
+            assert torch.equal(net(inputs={"technical": slot}, reduce_scores=True), eager[i])
+        assert torch.equal(slot.materialise(), srcs[1].materialise())
+        with pytest.raises(_abi.KvqError):                                    # the batched gather takes by-value pointers only
+            _abi.check(_abi.lib().kvq_fragment_gather_batch(slot.c_struct(), 3, 32, _abi.ptr(torch.empty(n, 3, 32, 224, 224, device=DEV)),
+                                                            _abi.current_stream()), "kvq_fragment_gather_batch")
+        lanes = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+        graphs = LaneGraphs(lambda inp: net(inputs=inp, reduce_scores=True), lanes)
+        outs = []
+        for i, s in enumerate(srcs):
+            o = graphs.run(i % 2, {"technical": s})
+            with torch.cuda.stream(lanes[i % 2]):
+                outs.append(o.clone())
+        torch.cuda.synchronize()
+    assert graphs.replays == len(srcs) and graphs.eager_runs == 0
+    for o, e in zip(outs, eager):
+        assert torch.equal(o, e)
+
+
 def test_forward_structure_matches_reference_api():
     """VQA_Network.forward return structure (models/model.py:105-121)."""
     net, key = build_network("SWIN_T_GRPB", 0, "init")
