@@ -812,7 +812,8 @@ def main():
     if args.graph < 0:
         args.graph = int(nstream > 1 and sampler_on and not args.two_launch_sampler and args.cu_mask == "none")
     if args.graph and glanes is None:
-        glanes = [torch.cuda.Stream(device=device) for _ in range(nstream)]
+        prio = [int(v) for v in os.environ.get("KVQ_LANE_PRIO", "").split(",") if v.strip()]       # experiment: per-lane stream priority
+        glanes = [torch.cuda.Stream(device=device, priority=prio[i % len(prio)] if prio else 0) for i in range(nstream)]
     graphable[step_fused] = lambda s: {"technical": src.fragments(s * B, B)}       # pre-sampled / two-launch definitions stay eager
     with torch.no_grad():
         dt, outs, allscores, tstats = timed(kd, device, steps_of(step_sampled if sampler_on else step_presampled), args.steps,
