@@ -603,8 +603,12 @@ def setup_c5(args, device):
         woff.append((torch.randint(SRC_W // 8 - 32, (8, 8, 8), generator=cg) + gw).int().to(device))
     # KVQ_C5_LANES (default 4; 2 in rounds 2-4: 23.2 -> 23.4 videos/s): stream lanes of the C5 leg (each owns a plan + 5.5 GiB workspace)
     n_lanes = max(1, int(os.environ.get("KVQ_C5_LANES", "4")))
-    lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(n_lanes - 1)]
-    xs = [torch.empty(B, 3, 64, 256, 256, device=device) for _ in lanes]
+    # replay (as the C2 line: one recorded forward per lane, the clips' addresses through a kernels.FragmentSlot) unless the sampler runs as
+    # its own launches or eager launches were asked for
+    replay = args.graph == 1 and not args.two_launch_sampler and n_lanes > 1          # (-1 = unresolved: the --probe path, eager)
+    lanes = ([torch.cuda.Stream(device=device) for _ in range(n_lanes)] if replay else
+             [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(n_lanes - 1)])
+    xs = [torch.empty(B, 3, 64, 256, 256, device=device) if (args.two_launch_sampler or i == 0) else None for i in range(n_lanes)]
     with torch.no_grad():
         for st in lanes:
             with torch.cuda.stream(st):
@@ -624,13 +628,45 @@ def setup_c5(args, device):
             kernels.fragment_gather(clips[i], hoff[i], woff[i], 8, 8, 32, 32, 8, MEAN, STD, out=xs[ln][b])
         return head(bb({"technical": xs[ln]}))
 
+    graphs = None
+    if replay:
+        from kvq_amd.graph import LaneGraphs
+        graphs = LaneGraphs(lambda inp: head(bb(inp)), lanes)
+
+        def source(s):
+            idx = [(s * B + b) % npool for b in range(B)]
+            if idx[0] not in frs:
+                frs[idx[0]] = kernels.FragmentSource([clips[i] for i in idx], [hoff[i] for i in idx], [woff[i] for i in idx],
+                                                     8, 8, 32, 32, 8, mean=MEAN, std=STD)
+            return {"technical": frs[idx[0]]}
+
+        with torch.no_grad():
+            for ln in range(n_lanes):
+                graphs.run(ln, source(ln))
+            torch.cuda.synchronize()
+        if graphs.eager_runs:
+            graphs = None
+
     def steps(n, first):
-        return run_lanes(lanes, n, lambda s, ln: one(first + s, ln))
+        if graphs is None:
+            return run_lanes(lanes, n, lambda s, ln: one(first + s, ln))
+        main = torch.cuda.current_stream()
+        for st in lanes:
+            st.wait_stream(main)
+        outs = []
+        for s in range(n):
+            o = graphs.run(s % n_lanes, source(first + s))
+            with torch.cuda.stream(lanes[s % n_lanes]):
+                outs.append(o.clone())
+        for st in lanes:
+            main.wait_stream(st)
+        return outs
 
     def serial(n):
         for s in range(n):
             one(s, 0)
 
+    steps.replay = graphs is not None
     return bb, head, B, xs, steps, serial
 
 
@@ -648,7 +684,7 @@ def leg_c5(args, device, kd, pmc):
         attach_traffic(roof, pmc)
     out = {"workload": "C5: K1 (8x8 grid of 32x32 patches out of uint8 3x64x540x960) + Swin-B(GRPB) trunk + VQAHead, 3x64x256x256 clips, "
            "fp16 operands, video = 16 clips", "value": B * k / 16.0 / dt,
-           "unit": "videos/s", "steps": k, "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": "fp16",
+           "unit": "videos/s", "steps": k, "ms_per_step": 1e3 * dt / k, "clips_per_step": B, "dtype": "fp16", "hipgraph": bool(getattr(steps, "replay", False)),
            "finite": bool(torch.isfinite(torch.cat([o.reshape(-1) for o in outs])).all()),
            "alg_gflop_per_clip": SWIN_B_GFLOP_PER_CLIP,
            "whole_step": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
