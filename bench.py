@@ -34,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/fp16, MI355X_MICROARCH.md chip table
+N_SIMDS = 1024                     # 256 CUs x 4
+MFMA_CLOCK_HZ = 2.4e9              # the clock the dense peak is quoted at (2.5 PFLOP/s = 1024 SIMDs x 1024 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
 CLIPS_PER_VIDEO = 8
 SWIN_T_GFLOP_PER_CLIP = 175.53   # SURVEY.md §8d (2*MAC, GEMM-only, padding as the reference pads)
@@ -65,12 +67,12 @@ def parse():
                     help="1: every lane replays ONE recorded forward (kvq_amd/graph.py); a step still reads its own clips - the recorded "
                          "embedding launch takes their addresses from a device table (kernels.FragmentSlot).  0: eager launches.  "
                          "-1 (default): 1 on several lanes with the sampler fused into the step, else 0")
-    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,two_launch,bf16,bf16_init,batch8,c3,c5,ksvqe ('all', 'c2' = none)")
+    ap.add_argument("--legs", default="all", help="comma list of extra legs at N=1: no_sampler,two_launch,bf16,bf16_init,batch8,one_stream,latency,in_mix,c3,c5,ksvqe ('all', 'c2' = none)")
     ap.add_argument("--src-pool", type=int, default=64, help="distinct uint8 source clips kept in HBM (49.8 MB each)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the K-step block until this many seconds are timed")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic fields = null)")
-    ap.add_argument("--probe", default=None, choices=["c2", "c3", "c5", "ksvqe", "ksvqe96"],
+    ap.add_argument("--probe", default=None, choices=["c2", "c2mix", "c3", "c5", "ksvqe", "ksvqe96"],
                     help="internal: run --probe-steps serial steps of one leg and exit (the command the --pmc passes profile)")
     ap.add_argument("--probe-steps", type=int, default=2)
     return ap.parse_args()
@@ -354,6 +356,110 @@ def pmc_traffic(leg, steps, dtype, batch):
     return {"per_kernel": per, "step_bytes": total / steps, "steps": steps,
             "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE in separate child passes of `bench.py --probe "
                       f"{leg}` ({steps} serial steps); one-time builder / torch kernels excluded"}
+
+
+def family_of(name):
+    """launch family of a kernel symbol — the rows of the KVQ_SKIP ablation (profiles/r0N_skip_ablation*.txt)"""
+    b = kernel_base(name)
+    if b.startswith("window_attention"):
+        return "attention"
+    if b == "block_tailmm_kernel":
+        return "tails C>=256"
+    if b == "block_tail_kernel":
+        return "tails C<=192"
+    if b.startswith("patch_merge"):
+        return "merge"
+    if b.startswith("patch_embed"):
+        return "embed"
+    if b.startswith("gemm"):
+        return "gemm"
+    if b.startswith("layernorm"):
+        return "layernorm"
+    if b.startswith("vqa_head"):
+        return "head"
+    return "other"
+
+
+def in_mix_evidence(args, B, nstream, ms_per_step):
+    """What the launches cost IN THE TIMED REGIME: two child passes of this file under rocprofv3 —
+    (1) --kernel-trace of `--probe c2mix` (the headline's steps: one recorded forward per lane replayed on `nstream` lanes; the probe marks
+        the timed steps with a 60 ms idle gap): per launch family, launches per step, average duration of a launch while the other lanes'
+        launches share the chip, and the sum per step (= CU-time share: the sums add up to ~nstream x the step);
+    (2) --pmc SQ_VALU_MFMA_BUSY_CYCLES of `--probe c2` (the same launches, one after the other: the counter is a per-dispatch sum of
+        matrix-pipe busy cycles over all SIMDs, 32 per v_mfma_f32_32x32x16 — it does not depend on what shares the chip): busy cycles per
+        step / (1024 SIMDs x clock x ms_per_step of the TIMED 4-lane region) = the MFMA-busy fraction of the timed region.
+    Returns a dict for roofline["in_mix"] (or {"error": ...})."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="kvq_mix_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(var, None)
+    K = 24
+    res = {}
+    try:
+        out = os.path.join(tmp, "trace")
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--probe", "c2mix",
+               "--probe-steps", str(K), "--dtype", args.dtype, "--batch", str(B), "--streams", str(nstream)]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        files = glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"error": f"rocprofv3 --kernel-trace failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"}
+        rows = [(int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"]) for x in csv.DictReader(open(files[0]))]
+        rows.sort()
+        # the timed steps come behind the LAST idle gap >= 40 ms (the probe sleeps 60 ms in front of them)
+        cut, last_end = 0, rows[0][1]
+        for i, (st, en, _) in enumerate(rows):
+            if st - last_end >= 40_000_000:
+                cut = i
+            last_end = max(last_end, en)
+        rows = [x for x in rows[cut:] if not any(k in x[2] for k in ONE_TIME_KERNELS)]
+        span_ms = (max(x[1] for x in rows) - rows[0][0]) / 1e6
+        fam = {}
+        for st, en, name in rows:
+            f = fam.setdefault(family_of(name), {"n": 0, "us": 0.0})
+            f["n"] += 1
+            f["us"] += (en - st) / 1e3
+        res["families"] = {k: {"launches_per_step": round(v["n"] / K, 2), "avg_launch_us_in_mix": round(v["us"] / v["n"], 2),
+                               "sum_us_per_step": round(v["us"] / K, 1)} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["us"])}
+        res["traced_steps"] = K
+        res["traced_ms_per_step"] = span_ms / K
+        res["sum_of_launch_ms_per_step"] = sum(v["us"] for v in fam.values()) / K / 1e3
+        res["avg_concurrent_launches"] = res["sum_of_launch_ms_per_step"] / res["traced_ms_per_step"]
+        out = os.path.join(tmp, "pmc")
+        psteps = 2
+        cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "--output-format", "csv", "-d", out, "-o", "c", "--", sys.executable, os.path.abspath(__file__),
+               "--probe", "c2", "--probe-steps", str(psteps), "--dtype", args.dtype, "--batch", str(B)]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            res["mfma_busy_error"] = f"rocprofv3 --pmc failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            return res
+        busy, byfam = 0.0, {}
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] != "SQ_VALU_MFMA_BUSY_CYCLES" or any(k in row["Kernel_Name"] for k in ONE_TIME_KERNELS):
+                continue
+            busy += float(row["Counter_Value"])
+            byfam[family_of(row["Kernel_Name"])] = byfam.get(family_of(row["Kernel_Name"]), 0.0) + float(row["Counter_Value"])
+        busy /= psteps
+        res["mfma_busy_cycles_per_step"] = busy
+        res["mfma_busy_frac_of_timed_region"] = busy / (N_SIMDS * MFMA_CLOCK_HZ * ms_per_step * 1e-3)
+        res["mfma_issued_over_algorithmic_flops"] = busy * 1024.0 / (SWIN_T_GFLOP_PER_CLIP * 1e9 * B)
+        res["mfma_busy_ms_per_step_by_family"] = {k: round(v / psteps / (N_SIMDS * MFMA_CLOCK_HZ) * 1e3, 4) for k, v in sorted(byfam.items(), key=lambda kv: -kv[1])}
+        res["method"] = ("families: rocprofv3 --kernel-trace of `bench.py --probe c2mix` (recorded forwards replayed on the headline's lanes); "
+                         "MFMA busy: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES of `bench.py --probe c2` (per-dispatch sums over all SIMDs, 32 cycles per "
+                         f"32x32x16 MFMA) / ({N_SIMDS} SIMDs x {MFMA_CLOCK_HZ / 1e9:.1f} GHz x the timed ms_per_step)")
+    except Exception as e:  # noqa: BLE001
+        res["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 def attach_traffic(roof, pmc):
@@ -749,9 +855,29 @@ def run_probe(args):
             serial(args.probe_steps)       # (the one-time builder kernels of the first forward are excluded by name, ONE_TIME_KERNELS)
         else:
             net, *_ = build_net(args.dtype, device)
-            B = args.batch if args.probe == "c2" else 8
-            src = Source(max(B, 2 * B), device, 1234)
-            if args.probe == "c2":
+            B = args.batch if args.probe in ("c2", "c2mix") else 8
+            src = Source(max(B, 2 * B) if args.probe != "c2mix" else 16 * B, device, 1234)
+            if args.probe == "c2mix":
+                # the headline's timed regime for the kernel-trace child pass: one recorded forward per lane, replayed; the traced steps
+                # come behind a 60 ms idle gap (in_mix_evidence cuts there)
+                import time as _t
+                from kvq_amd.graph import LaneGraphs
+                n = max(1, args.streams)
+                glanes = [torch.cuda.Stream(device=device) for _ in range(n)]
+                for st in glanes:
+                    with torch.cuda.stream(st):
+                        net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
+                torch.cuda.synchronize()
+                graphs = LaneGraphs(lambda inp: net(inputs=inp, reduce_scores=True), glanes)
+                for s in range(2 * n):
+                    graphs.run(s % n, {"technical": src.fragments(s * B, B)})
+                torch.cuda.synchronize()
+                assert graphs.eager_runs == 0, "the c2mix probe must replay"
+                _t.sleep(0.06)
+                for s in range(args.probe_steps):
+                    graphs.run(s % n, {"technical": src.fragments(s * B, B)})
+                torch.cuda.synchronize()
+            elif args.probe == "c2":
                 net.swin_tiny_grpb_backbone.prepare(B, 32, 224, 224, device)
                 x = torch.empty(B, 3, 32, 224, 224, device=device)
                 for s in range(args.probe_steps):
@@ -803,7 +929,7 @@ def main():
     lanes = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(nstream - 1)]
     if args.cu_mask != "none":
         lanes = masked_lanes(nstream, args.cu_mask, device)
-    legs = {"no_sampler", "two_launch", "bf16", "bf16_init", "batch8", "c3", "c5", "ksvqe"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
+    legs = {"no_sampler", "two_launch", "bf16", "bf16_init", "batch8", "one_stream", "latency", "in_mix", "c3", "c5", "ksvqe"} if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "c2"}
     if world > 1:
         legs = set()
 
@@ -1036,6 +1162,29 @@ def main():
                                          "batch = 4, reported beside it"}
                 del xs8
                 torch.cuda.empty_cache()
+            if "one_stream" in legs and sampler_on and nstream > 1:
+                # the same steps, the same (default) launch geometries, eager launches on ONE stream: what the multi-lane geometries of
+                # rounds 5-6 cost a deployment that runs one video at a time (the launches are shaped for CU x time, not for latency)
+                k1 = max(4, args.steps // 2)
+                one = lambda n, first: run_lanes(lanes[:1], n, lambda s_, ln: step_sampled(first + s_, 0))      # noqa: E731
+                dt6, _, _, st6 = timed(kd, device, one, k1, min(args.warmup, 3), min_s=min(args.min_timed_s, 0.5))
+                out["one_stream"] = {"value": k1 * B / CLIPS_PER_VIDEO / dt6, "unit": "videos/s", "ms_per_step": 1e3 * dt6 / k1, "steps": k1,
+                                     "repeats": st6["repeats"], "note": "the headline's steps one after the other on one stream (eager launches, "
+                                     "the default multi-lane launch geometries)"}
+            if "latency" in legs and sampler_on:
+                # KVQ_LATENCY=1 selects the geometries that are fastest for ONE step alone on the chip (q-split attention, the stage-3 GEMM
+                # chain, the one-workgroup-per-CU C = 384 tail); the library reads it once, so the leg is a child run of this file
+                import subprocess
+                env = dict(os.environ, KVQ_LATENCY="1")
+                cmd = [sys.executable, os.path.abspath(__file__), "--legs", "c2", "--streams", "1", "--no-cpu-baseline", "--no-pmc", "--profile-steps", "0",
+                       "--steps", str(max(4, args.steps // 2)), "--warmup", "3", "--min-timed-s", "0.5", "--dtype", args.dtype, "--batch", str(B)]
+                try:
+                    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+                    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                    out["latency"] = {"value": d["value"], "unit": "videos/s", "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                                      "note": "KVQ_LATENCY=1 on one stream (child run): the launch geometries for one video at a time"}
+                except Exception as e:  # noqa: BLE001
+                    out["latency"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         for name, fn in (("c3", lambda pm: leg_c3(args, device, net, src, kd, pm)), ("c5", lambda pm: leg_c5(args, device, kd, pm)),
                          ("ksvqe", lambda pm: leg_ksvqe(args, device, kd, pm, 32)), ("ksvqe96", lambda pm: leg_ksvqe(args, device, kd, pm, 96))):
             if name in legs or (name == "ksvqe96" and "ksvqe" in legs):
@@ -1045,6 +1194,21 @@ def main():
                 except Exception as e:  # noqa: BLE001  (an extra leg must not take the headline line down with it)
                     out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 torch.cuda.empty_cache()
+        if "in_mix" in legs and want_pmc and out.get("roofline") is not None and headline_graph:
+            out["roofline"]["in_mix"] = in_mix_evidence(args, B, nstream, out["ms_per_step"])
+        # numbers of the extra legs where a record that keeps `config` and drops unknown top-level keys still holds them
+        brief = {}
+        for k in ("bf16_init", "bf16", "one_stream", "latency", "no_sampler", "two_launch_sampler", "batch8", "c3", "c5", "ksvqe", "ksvqe96"):
+            v = out.get(k)
+            if isinstance(v, dict) and "value" in v:
+                brief[k] = {"value": round(v["value"], 2), "ms_per_step": round(v["ms_per_step"], 4)}
+                for kk in ("max_abs_dscore_vs_reference_golden", "parity_ok", "max_abs_dscore_vs_fp16"):
+                    if kk in v:
+                        brief[k][kk] = v[kk]
+                ws = v.get("whole_step") or {}
+                if "frac" in ws:
+                    brief[k]["whole_step_frac"] = round(ws["frac"], 4)
+        out["config"]["legs"] = brief
         out["parity_pins"] = ("Swin3D trunk / heads / sampler / ResNet-50: oracle bit-pinned to the imported reference; UNPINNED by "
                               "necessity (packages absent here): SlowFast-R50 (pytorchvideo), torchvision Resize, CONTRIQUE's "
                               "torchvision resnet50 (stand-in = the reference's own Bottleneck)")

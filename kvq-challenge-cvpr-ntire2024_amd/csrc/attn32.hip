@@ -611,6 +611,7 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
   // videos/s, three alternating pairs, profiles/r05_qsplit_streams_ab.txt): what counts there is CU x time.  KVQ_ATTN_QSPLIT_MAX=4: rounds 3-4.
   static const int qsplit_max = getenv("KVQ_ATTN_QSPLIT_MAX") ? atoi(getenv("KVQ_ATTN_QSPLIT_MAX")) : (latency_mode() ? 4 : 1);      // (results do not depend on it)
   qsplit = qsplit > qsplit_max ? qsplit_max : qsplit;
+  qsplit = qsplit < 1 ? 1 : qsplit;                   // (KVQ_ATTN_QSPLIT_MAX=0 must not give an empty grid)
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
                      a->dsplit_from < 0 ? -1 : a->dsplit_from};

@@ -15,15 +15,26 @@
 #include <vector>
 
 #include "common.hpp"
+#include "tail.hpp"
 
 // KVQ_SKIP (diagnostic, tools/skip_ablation.sh): bit mask of launch families the forward leaves out — the scores are garbage, the point is the
 // marginal cost of a family in the multi-lane bench line (what the step would gain if the family were free), which the per-launch times
 // of a one-stream step do not tell.  1 attention, 2 fused tails C <= 192, 4 fused tails C >= 256, 8 qkv GEMMs, 16 LayerNorm launches,
 // 32 every launch of the last stage, 64 patch embedding, 128 patch merging (all forms).
+// Diagnostic BUILDS only (-DKVQ_DIAG: `KVQ_BUILD_TAG=diag KVQ_EXTRA_HIPCC_FLAGS=-DKVQ_DIAG`): the product library ignores the variable, so an
+// inherited environment can never make kvq_swin3d_forward return KVQ_OK with garbage scores; a diagnostic build says so once on stderr.
+#ifdef KVQ_DIAG
 static int skip_mask() {
-  static const int m = getenv("KVQ_SKIP") ? atoi(getenv("KVQ_SKIP")) : 0;
+  static const int m = [] {
+    const int v = getenv("KVQ_SKIP") ? atoi(getenv("KVQ_SKIP")) : 0;
+    if (v) fprintf(stderr, "libkvq_hip (KVQ_DIAG build): KVQ_SKIP=%d leaves launch families out - scores are GARBAGE, timing only\n", v);
+    return v;
+  }();
   return m;
 }
+#else
+static constexpr int skip_mask() { return 0; }
+#endif
 
 namespace kvq {
 
@@ -623,7 +634,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
             ta.next_norm_w = nullptr; ta.next_norm_b = nullptr; ta.next_dst = nullptr; ta.next_rows = 0;
           }
         }
-        Bracket br(pl, st, KVQ_K_TAIL, (C / 32) * 10 + (ln1_ready ? 1 : 0) + (qkv_ready ? 2 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden + (qkv_ready ? 6.0 * M * C * C : 0.0),
+        Bracket br(pl, st, KVQ_K_TAIL, kvq::tailmm_geometry_code(C, hidden) * 1000 + (C / 32) * 10 + (ln1_ready ? 1 : 0) + (qkv_ready ? 2 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden + (qkv_ready ? 6.0 * M * C * C : 0.0),
                    (double)M * C * 2.0 + (double)ML * C * (8.0 + (ln1_ready ? 2.0 : 0.0) + (qkv_ready ? 6.0 : 0.0)));
         KVQ_TRY_UNLESS(C <= 192 ? 2 : 4, kvq_block_tail(&ta, st));
         continue;
@@ -656,7 +667,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       if (mw.merge_pack && kvq_patch_merge_supported(C) && C <= merge_maxc) {
         // concat + LayerNorm(4C) + reduction [+ the next stage's first norm1 in its window order] as one launch (csrc/merge.hip).
         // C = 96: 37.5 us against 26.3 + 25.6 + 15.9 (Swin-T, 4 clips); C = 128: +0.5-1 % on C5.  C = 192 exists and is tested, but
-        // the 576 KB matrix streams through LDS for 98 workgroups of one wave per SIMD: 66.9 us against 16.2 + 24.8 + 15.3 - not taken
+        // the 576 KB matrix streams through LDS for 98 workgroups of one wave per SIMD: 66.9 us against 16.2 + 24.8 + 15.3 alone on the chip;
+        // taken since round 5 (merge_maxc = 192): level on the 4-lane line with two launches fewer (profiles/r05_lane_experiments.txt)
         KvqPatchMergeArgs ma{};
         ma.x = cur; ma.merge_map = g.d_merge; ma.B = B; ma.L = g.L; ma.Ln = Ln; ma.C = C; ma.pack = mw.merge_pack; ma.out = oth;
         ma.eps = 1e-5f; ma.dtype = pl->dtype;

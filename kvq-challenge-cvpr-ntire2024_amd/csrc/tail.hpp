@@ -36,6 +36,7 @@ size_t tailmm_pack_bytes(int C, int hidden);
 int tailmm_pack(const uint16_t* wp, const uint16_t* w1, const uint16_t* w2, const float* proj_b, const float* n2w, const float* n2b,
                 const float* b1, const float* b2, int C, int hidden, unsigned char* out, hipStream_t st);
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st);
+int tailmm_geometry_code(int C, int hidden);           // 0: not a tailmm width; else (hidden chunk / 128) * 10 + token tiles of 32 per workgroup (profile records)
 size_t tailmm_qkv_pack_bytes(int C, int hidden);      // 0: this width cannot emit q | k | v
 int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out, hipStream_t st);
 

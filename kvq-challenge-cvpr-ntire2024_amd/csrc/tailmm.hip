@@ -30,35 +30,47 @@
 #include "common.hpp"
 #include "tail.hpp"
 
+#ifndef MM_ABL
+#define MM_ABL 0            // study builds (tools/tailmm_variant.sh), bit mask: 1 no activation-fragment LDS reads past a phase's first body,
+#endif                      // 2 no weight stream past the first ring fill, 8 GELU replaced by a pack, 16 fc1's MFMAs skipped, 32 fc2's MFMAs skipped
+                            // (profiles/r06_tailmm_study.txt: where a C = 384 workgroup's cycles go)
+
 namespace kvq {
 
 typedef __attribute__((address_space(3))) void* mm_lds_t;
 typedef __attribute__((address_space(1))) const void* mm_gbl_t;
 
-constexpr int MM_TOK = 64;          // tokens per workgroup
 // Geometry by CF = C / 128 = 32-feature tiles per wave: 3 (C = 384: stage 2 of Swin-T / -S) or 4 (C = 512: stage 2 of Swin-B,
 // register ring only — its 64 KB activation tile leaves no room for an LDS weight ring), and by HC = hidden units per MLP chunk:
 //   HC = 256: a wave's fc1 slice is 64 units (two tiles): 512 VGPRs, 94 KB of LDS, ONE workgroup per CU (rounds 2-4);
 //   HC = 128: 32 units (one tile) and a 12-fragment ring: <= 256 VGPRs, 77 KB of LDS at C = 384 — TWO workgroups per CU, i.e. two
 //             independent instruction streams per SIMD: one workgroup's serial phases (row loads, LayerNorm exchanges, GELU, barriers,
 //             the store tail) run under the other's MFMAs (round 5; the per-CU weight stream per token is unchanged).
-template <int CF, int HC_ = 256>
+//   TT = 4 (round 6): 128 tokens per workgroup — every weight fragment of the register ring feeds FOUR MFMAs (token tiles) instead of two, which
+//             halves the L1 -> VGPR weight stream per MFMA (1 KB per two 32x32x16 is 64 B / clk per CU, the path's limit, at full matrix rate).
+//             192 + 64 accumulator registers: ONE wave per SIMD, 142 KB of LDS at C = 384 (HC = 128).
+template <int CF, int HC_ = 256, int TT_ = 2>
 struct MMc {
+  static constexpr int TT = TT_, TOK = 32 * TT_;                        // token tiles of 32, tokens per workgroup
   static constexpr int C = 128 * CF, H = 4 * C, W = 32 * CF;            // channels, hidden units, features per wave
   static constexpr int HC = HC_, KS_H = HC / 16, HT = HC / 128;         // hidden chunk, its k-steps, fc1 tiles per wave
   static constexpr int NCH = H / HC, KS_C = C / 16;                     // hidden chunks, k-steps over C
   static constexpr int NF_PROJ = KS_C * CF, NF_FC1 = KS_C * HT, NF_FC2 = KS_H * CF;
   static constexpr int NF = NF_PROJ + NCH * (NF_FC1 + NF_FC2);          // fragments per wave: 648 / 1152
   static constexpr int OFF_X = 0;                                       // [KS_C k-steps][2 token tiles][64 lanes][16 B] = 48 / 64 KB
-  static constexpr int OFF_G = OFF_X + KS_C * 2 * 1024;                 // [KS_H][2][64][16 B] = 32 / 16 KB
-  static constexpr int OFF_PRM = OFF_G + KS_H * 2 * 1024;               // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
+  static constexpr int OFF_G = OFF_X + KS_C * TT * 1024;                 // [KS_H][2][64][16 B] = 32 / 16 KB
+  static constexpr int OFF_PRM = OFF_G + KS_H * TT * 1024;               // b1[H] g2[C] b2n[C] proj_b[C] b2[C] fp32
   static constexpr int PRM_FLOATS = H + 4 * C;
   static constexpr int OFF_RED = OFF_PRM + PRM_FLOATS * 4;              // [4 waves][64 tokens] fp32
-  static constexpr int LDS = OFF_RED + 4 * MM_TOK * 4;
+  static constexpr int LDS = OFF_RED + 4 * TOK * 4;
   static constexpr int WG_PER_CU = HC == 128 && 2 * LDS <= 163840 ? 2 : 1;
   // register budget in waves per SIMD: the HC = 128 forms up to C = 512 keep to 256 VGPRs so that another workgroup (C = 384: of this launch;
   // C = 512, 97 KB of LDS: of another lane's launch) fits beside them; C = 768 needs 192 accumulator registers and takes the whole file
-  static constexpr int REG_WAVES = HC == 128 && CF <= 4 ? 2 : 1;
+  static constexpr int REG_WAVES = HC == 128 && CF <= 4 && TT == 2 ? 2 : 1;
+#ifndef KVQ_TAILMM_KU1
+#define KVQ_TAILMM_KU1 1
+#endif
+  static constexpr int KU1 = HC == 128 ? KVQ_TAILMM_KU1 : 1;            // k-steps per loop body where a wave owns ONE weight tile (fc1 at HC = 128)
   static constexpr bool PIPE = HC != 128;          // the MLP chunks software-pipelined in the wave (fc1 of chunk c + 1 ahead of fc2 of chunk c): the HC = 256 forms
   // packed image: 4 waves x NF KB of fragments, then fp32 parameters b1 | g2 | b2n | proj_b | b2
   static constexpr size_t PACK_FRAG_BYTES = (size_t)4 * NF * 1024;
@@ -79,6 +91,12 @@ static int tailmm_hc(int C) {
   static const int env512 = getenv("KVQ_TAILMM_HC512") ? atoi(getenv("KVQ_TAILMM_HC512")) : (latency_mode() ? 256 : 128);
   if (C == 512) return env512 == 128 ? 128 : 256;
   return C == 384 && env == 128 ? 128 : 256;
+}
+
+// KVQ_TAILMM_TOK=128 (round 6): the 128-token workgroup at C = 384, HC = 128 (same packed image: the fragment lists do not depend on it)
+static int tailmm_tok(int C) {
+  static const int env = getenv("KVQ_TAILMM_TOK") ? atoi(getenv("KVQ_TAILMM_TOK")) : 64;
+  return C == 384 && env == 128 ? 128 : 64;
 }
 
 // C = 768 (round 5: stage 3 of Swin-T / -S; CF = 6, HC = 128, one workgroup per CU: 137 KB of LDS, 192 accumulator registers per wave).  At
@@ -219,10 +237,14 @@ int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out
 // load is unsafe under this register pressure (the allocator splits the live range of a value it believes ready; the late data lands
 // in a register handed on).  (Round 2 also carried an LDS-ring form of the stream and ablation builds of it — no weight stream 65 us,
 // no MFMAs 57, neither 43 of 78 — removed in round 3: 79 -> 73 us with the next norm1, 73 -> 64 without, bit-identical.)
-template <typename E, int MODE, int CF = 3, int HC = 256>      // MODE 0: x only; 1: + the next block's norm1 rows; 2: + the next block's q | k | v
-__global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_kernel(TailParams p) {
+template <int N> struct TokVec { float v[N]; __device__ __forceinline__ float operator[](int i) const { return v[i]; } };
+
+template <typename E, int MODE, int CF = 3, int HC = 256, int TT = 2>      // MODE 0: x only; 1: + the next block's norm1 rows; 2: + the next block's q | k | v
+__global__ __launch_bounds__(256, (MMc<CF, HC, TT>::REG_WAVES)) void block_tailmm_kernel(TailParams p) {
   constexpr bool EMIT = MODE == 1, QKV = MODE == 2;
-  using K = MMc<CF, HC>;
+  using K = MMc<CF, HC, TT>;
+  constexpr int MM_TOK = K::TOK;
+  using TV = TokVec<TT>;                             // one value per token tile of the lane
   constexpr int MM_C = K::C, MM_H = K::H, MM_NCH = K::NCH, MM_KS_C = K::KS_C, MM_NF = K::NF, VR_R = K::VR_R, VR_PF = K::VR_PF, FW = K::W;
   constexpr int MM_HC = K::HC, MM_KS_H = K::KS_H, HT = K::HT;
   constexpr int MM_OFF_X = K::OFF_X, MM_OFF_G = K::OFF_G, MM_OFF_PRM = K::OFF_PRM, MM_OFF_RED = K::OFF_RED;
@@ -240,11 +262,15 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   const float* gprm = reinterpret_cast<const float*>(p.pack + MM_PACK_FRAG_BYTES);
 #ifdef KVQ_TAIL_TRACE   // diagnostic build only (tools/tail_trace.py): per-workgroup shader-clock stamps of wave 0
   const bool tr = p.trace && tid == 0 && (int)blockIdx.x < p.trace_blocks;
-  unsigned long long wait_dma = 0, wait_bar = 0;
+  unsigned long long wait_dma = 0, wait_bar = 0, t_gelu = 0, t_fc2 = 0, t_mark = 0;
+#define MM_T0() t_mark = __builtin_readcyclecounter()
+#define MM_T1(acc_) { const unsigned long long t1_ = __builtin_readcyclecounter(); acc_ += t1_ - t_mark; t_mark = t1_; }
 #define MM_STAMP(i) if (tr) p.trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter()
 #define MM_BARRIER() { const unsigned long long t0_ = __builtin_readcyclecounter(); __syncthreads(); wait_bar += __builtin_readcyclecounter() - t0_; }
 #else
 #define MM_STAMP(i)
+#define MM_T0()
+#define MM_T1(acc_)
 #define MM_BARRIER() __syncthreads()
 #endif
   MM_STAMP(0);
@@ -264,12 +290,12 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   };
 
   // ---- this workgroup's rows: token tt*32 + j of 64, window order -> token of the residual stream ----
-  long orig[2], arow[2];
-  bool live[2];
-  int tloc_[2], tb_[2];
+  long orig[TT], arow[TT];
+  bool live[TT];
+  int tloc_[TT], tb_[TT];
   const long nrows = p.gather ? p.n_tok : p.M;     // window rows, or (gather) tokens: no work on padding rows
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
+  for (int tt = 0; tt < TT; ++tt) {
     const long row = (long)blockIdx.x * MM_TOK + 32 * tt + j;
     const long rc = row < nrows ? row : nrows - 1;
     arow[tt] = rc;
@@ -293,9 +319,11 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   }
   // ---- attention rows -> B fragments [k-step][token tile] by LDS-DMA (lane (j, half) fetches row j's k 16ks + 8 half ..+7) ----
   {
-    for (int fr = wave; fr < MM_KS_C * 2; fr += 4) {
-      const int ks = fr >> 1, tt = fr & 1;
-      const long row = tt ? arow[1] : arow[0];
+    for (int fr = wave; fr < MM_KS_C * TT; fr += 4) {
+      const int ks = fr / TT, tt = fr % TT;
+      long row = arow[0];
+#pragma unroll
+      for (int u = 1; u < TT; ++u) row = tt == u ? arow[u] : row;
       __builtin_amdgcn_global_load_lds((mm_gbl_t)(p.attn + (size_t)row * C + 16 * ks + 8 * half), (mm_lds_t)(lds + MM_OFF_X + fr * 1024), 16, 0, 0);
     }
     for (int q = wave; q < (MM_PRM_FLOATS * 4) / 1024; q += 4)      // b1 | g2 | b2n | proj_b | b2: 12 KB
@@ -305,15 +333,15 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   for (int q = 0; q < VR_PF; ++q) vload(q);          // VR_PF fragments of the weight list in flight from here on
   // ---- accumulators = x + proj bias: tile (ft, tt), register r <-> feature 96 wave + 32 ft + (r&3) + 8 (r>>2) + 4 half ----
   // all 24 row pieces of a lane are requested before anything waits (they queue behind the DMA requests above: one drain)
-  f32x16 acc[CF][2];
+  f32x16 acc[CF][TT];
   {
-    f32x4 xv[CF][4][2];
+    f32x4 xv[CF][4][TT];
 #pragma unroll
     for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < TT; ++tt)
           xv[ft][q][tt] = *reinterpret_cast<const f32x4*>(p.x + (size_t)orig[tt] * C + FW * wave + 32 * ft + 8 * q + 4 * half);
     __builtin_amdgcn_sched_barrier(0);
     // everything requested so far has landed (the row loads were issued last: vmcnt(0) covers the DMA before them too)
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
       for (int q = 0; q < 4; ++q) {
         const f32x4 pb = *reinterpret_cast<const f32x4*>(prm + MM_H + 2 * MM_C + FW * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[ft][tt][4 * q + i] = xv[ft][q][tt][i] + pb[i];
       }
@@ -338,28 +366,31 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   // and NR new weight fragments requested BETWEEN the MFMAs of body s, one at a time: a wave's LDS / VMEM issue hides under its own
   // MFMAs only ~10 cycles at a time (tools/ubench/pipe_share.hip) — a burst of 5 reads in front of 6 MFMAs does not hide at all.
   auto gemm_phase = [&](auto na_tag, auto nk_tag, const unsigned char* bbuf, auto&& mm, auto&& between) __attribute__((always_inline)) {
-    constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : 1, NR = NA * KU;     // (NA = 1: two MFMAs per body)
-    constexpr int NM = 2 * NA * KU;                               // MFMAs per body
+    // k-steps per body.  One weight tile per wave (fc1 at HC = 128) is ONE MFMA per activation fragment read and a body of TT MFMAs; bodies of
+    // KU1 = 2 / 4 k-steps (the fragments requested 128 / 256 cycles ahead) were measured in round 6 and change nothing — alone on the chip or
+    // on the 4-lane line (profiles/r06_tailmm_study.txt): the phase does not wait for its LDS reads.  -DKVQ_TAILMM_KU1=2 builds them.
+    constexpr int NA = decltype(na_tag)::value, nk = decltype(nk_tag)::value, KU = NA == 2 ? 2 : NA == 1 ? K::KU1 : 1, NR = NA * KU;
+    constexpr int NM = TT * NA * KU;                              // MFMAs per body
     static_assert(nk % KU == 0, "k-steps per body");
-    V8 b[2][KU][2];                      // activation fragments of two bodies: the one in use and the one being read
+    V8 b[2][KU][TT];                     // activation fragments of two bodies: the one in use and the one being read
     auto rdb = [&](int buf, int ks, int q) __attribute__((always_inline)) {
-      const int k = q >> 1, tt = q & 1;
-      b[buf][k][tt] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * 2 + tt) * 1024 + lane * 16);
+      const int k = q / TT, tt = q % TT;
+      b[buf][k][tt] = *reinterpret_cast<const V8*>(bbuf + ((ks + k) * TT + tt) * 1024 + lane * 16);
     };
     auto body_vr = [&](int s, bool more) __attribute__((always_inline)) {
       const int u = (s / KU) & 1, base = (s / KU) * NR;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        const int k = m / (2 * NA), t = (m % (2 * NA)) >> 1, tt = m & 1;
+        const int k = m / (TT * NA), t = (m % (TT * NA)) / TT, tt = m % TT;
         mm(t, tt, wr[(base + k * NA + t) % VR_R], b[u][k][tt]);
-        if (more && m < 2 * KU) rdb(u ^ 1, s + KU, m);
-        if (m >= NM - NR) vload((base + VR_PF + (m - (NM - NR))) % VR_R);
-        between(s * 2 * NA + m);                        // VALU work of the caller, placed between two MFMAs
+        if (more && m < TT * KU && !((MM_ABL & 1) && s >= 2 * KU)) rdb(u ^ 1, s + KU, m);
+        if (m >= NM - NR && !(MM_ABL & 2)) vload((base + VR_PF + (m - (NM - NR))) % VR_R);
+        between(s * TT * NA + m);                       // VALU work of the caller, placed between two MFMAs
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 #pragma unroll
-    for (int q = 0; q < 2 * KU; ++q) rdb(0, 0, q);
+    for (int q = 0; q < TT * KU; ++q) rdb(0, 0, q);
 #pragma unroll
     for (int s = 0; s + KU < nk; s += KU) body_vr(s, true);
     body_vr(nk - KU, false);
@@ -375,30 +406,39 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
 
   // ---- LayerNorm statistics of a token over the 4 waves' slices: in-lane + lane^32 + LDS exchange; two passes -----------
   auto token_sums = [&](auto&& term) __attribute__((always_inline)) {       // term(ft, tt, r) -> sum over all 384 features, per tt
-    float s[2];
+    TV s;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
       float v = 0.f;
 #pragma unroll
       for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
         for (int r = 0; r < 16; ++r) v += term(ft, tt, r);
       v += __shfl_xor(v, 32);
-      s[tt] = v;
+      s.v[tt] = v;
     }
     __syncthreads();                               // the previous use of `red` has been read by everybody
     if (half == 0) {
-      red[wave * MM_TOK + j] = s[0];
-      red[wave * MM_TOK + 32 + j] = s[1];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) red[wave * MM_TOK + 32 * tt + j] = s.v[tt];
     }
     __syncthreads();
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-      s[tt] = (red[0 * MM_TOK + 32 * tt + j] + red[1 * MM_TOK + 32 * tt + j]) + (red[2 * MM_TOK + 32 * tt + j] + red[3 * MM_TOK + 32 * tt + j]);
-    return f32x2{s[0], s[1]};
+    for (int tt = 0; tt < TT; ++tt)
+      s.v[tt] = (red[0 * MM_TOK + 32 * tt + j] + red[1 * MM_TOK + 32 * tt + j]) + (red[2 * MM_TOK + 32 * tt + j] + red[3 * MM_TOK + 32 * tt + j]);
+    return s;
+  };
+  // mean and 1 / sqrt(var + eps) of the lane's tokens from the accumulators (two passes, as the LayerNorm launch)
+  auto token_stats = [&](TV& mean, TV& rstd) __attribute__((always_inline)) {
+    const TV sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) mean.v[tt] = sum.v[tt] * (1.0f / (float)C);
+    const TV sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean.v[tt]; return d * d; });
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) rstd.v[tt] = rsqrtf(sq.v[tt] / (float)C + p.eps);
   };
   // (acc - mean) * rstd * gamma + beta, 16-bit, written as B fragments: tile ft covers k-steps kbase + 2 ft + {0, 1}
-  auto write_norm = [&](const f32x2 mean, const f32x2 rstd, const float* gam, const float* bet, unsigned char* dst) __attribute__((always_inline)) {
+  auto write_norm = [&](const TV& mean, const TV& rstd, const float* gam, const float* bet, unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
     for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
@@ -407,7 +447,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + f0), g1 = *reinterpret_cast<const f32x4*>(gam + f0 + 8);
         const f32x4 e0 = *reinterpret_cast<const f32x4*>(bet + f0), e1 = *reinterpret_cast<const f32x4*>(bet + f0 + 8);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
           float y[8];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {                // two fma per value: (x rstd - mean rstd) g + b
@@ -417,15 +457,13 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
           }
           const u32x4 w = {E::pack2(y[0], y[1]), E::pack2(y[2], y[3]), E::pack2(y[4], y[5]), E::pack2(y[6], y[7])};
           const int ks = 2 * CF * wave + 2 * ft + hp;
-          *reinterpret_cast<u32x4*>(dst + (ks * 2 + tt) * 1024 + lane * 16) = w;
+          *reinterpret_cast<u32x4*>(dst + (ks * TT + tt) * 1024 + lane * 16) = w;
         }
       }
   };
   {
-    const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
-    const f32x2 mean = sum * (1.0f / (float)C);
-    const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
-    const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+    TV mean, rstd;
+    token_stats(mean, rstd);
     // every wave is past its last read of the attention tile (two barriers ago): norm2 rows take its place
     write_norm(mean, rstd, prm + MM_H, prm + MM_H + MM_C, lds + MM_OFF_X);
   }
@@ -436,7 +474,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
     for (int q = 0; q < 4; ++q) {
       const f32x4 b2 = *reinterpret_cast<const f32x4*>(prm + MM_H + 3 * MM_C + FW * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[ft][tt][4 * q + i] += b2[i];
     }
@@ -446,8 +484,8 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   // ---- MLP over 6 chunks of 256 hidden units: fc1 (wave: 64 units x 64 tokens) -> GELU -> LDS -> fc2 partial.  Software
   // pipeline: fc1 of chunk c+1 runs first, then the GELU of chunk c+1 is evaluated BETWEEN the MFMAs of fc2(chunk c) — one pair
   // per three MFMAs — so that the VALU stream no longer stops the weight stream ----------
-  f32x16 hacc[HT][2];
-  u32x4 gp[HT][2][2];                                 // GELU outputs of a chunk, packed: [weight tile][k-step half][token tile]
+  f32x16 hacc[HT][TT];
+  u32x4 gp[HT][2][TT];                                // GELU outputs of a chunk, packed: [weight tile][k-step half][token tile]
   auto fc1 = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int ft = 0; ft < HT; ++ft)
@@ -455,16 +493,18 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
       for (int q = 0; q < 4; ++q) {
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(prm + MM_HC * c + 32 * HT * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) hacc[ft][tt][4 * q + i] = b1[i];
       }
-    gemm_phase(T2{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) { hacc[ft][tt] = E::mfma32(a, b, hacc[ft][tt]); }, nothing);
+    gemm_phase(T2{}, KC{}, lds + MM_OFF_X, [&](int ft, int tt, V8 a, V8 b) {
+      if (MM_ABL & 16) { asm volatile("" :: "v"(a), "v"(b)); return; }
+      hacc[ft][tt] = E::mfma32(a, b, hacc[ft][tt]); }, nothing);
   };
-  auto gelu_pair = [&](int pi) __attribute__((always_inline)) {      // pi = ((ft * 2 + hp) * 2 + tt) * 4 + i, 0..16 HT - 1
-    const int i = pi & 3, tt = (pi >> 2) & 1, hp = (pi >> 3) & 1, ft = pi >> 4;
+  auto gelu_pair = [&](int pi) __attribute__((always_inline)) {      // pi = ((ft * 2 + hp) * TT + tt) * 4 + i, 0..8 TT HT - 1
+    const int i = pi & 3, tt = (pi >> 2) % TT, hp = ((pi >> 2) / TT) & 1, ft = (pi >> 2) / (2 * TT);
     const int r = 8 * hp + 2 * (i & 1) + 4 * (i >> 1);              // pairs (r, r+1): i = 0,1 -> quad 2hp; i = 2,3 -> quad 2hp+1
-    uint32_t w = gelu_pack2<E>(hacc[ft][tt][r], hacc[ft][tt][r + 1]);
+    uint32_t w = (MM_ABL & 8) ? E::pack2(hacc[ft][tt][r], hacc[ft][tt][r + 1]) : gelu_pack2<E>(hacc[ft][tt][r], hacc[ft][tt][r + 1]);
     asm volatile("" : "+v"(w));                        // pins the evaluation where it is placed
     gp[ft][hp][tt][i] = w;
   };
@@ -474,23 +514,31 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-          *reinterpret_cast<u32x4*>(lds + MM_OFF_G + ((2 * HT * wave + 2 * ft + hp) * 2 + tt) * 1024 + lane * 16) = gp[ft][hp][tt];
+        for (int tt = 0; tt < TT; ++tt)
+          *reinterpret_cast<u32x4*>(lds + MM_OFF_G + ((2 * HT * wave + 2 * ft + hp) * TT + tt) * 1024 + lane * 16) = gp[ft][hp][tt];
   };
   if constexpr (!K::PIPE) {
     // two workgroups per CU: the other workgroup's MFMAs run under this one's GELU, so the chunks are NOT software-pipelined in the
     // wave (fc1(c + 1) ahead of fc2(c) keeps acc + hacc + the packed GELU outputs + the ring + two bodies of fragments live at
     // once: 64 registers past the 256 of two waves per SIMD, spilled and reloaded in the loop)
     for (int c = 0; c < MM_NCH; ++c) {
+      MM_T0();
       fc1(c);
+      MM_T1(wait_dma);                                 // (trace builds: slot 5 = cycles in fc1, slot 7 = in the GELU, slot 6 = in barriers)
 #pragma unroll
-      for (int pi = 0; pi < 16 * HT; ++pi) gelu_pair(pi);
+      for (int pi = 0; pi < 8 * TT * HT; ++pi) gelu_pair(pi);
+      MM_T1(t_gelu);
       if (c > 0) MM_BARRIER();                         // everybody has finished fc2 of chunk c - 1: its GELU rows may go
       write_gelu();
       MM_BARRIER();                                    // GELU rows of chunk c complete
-      gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) { acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+      MM_T0();
+      gemm_phase(T3{}, KH{}, lds + MM_OFF_G, [&](int ft, int tt, V8 a, V8 b) {
+        if (MM_ABL & 32) { asm volatile("" :: "v"(a), "v"(b)); return; }
+        acc[ft][tt] = E::mfma32(a, b, acc[ft][tt]); }, nothing);
+      MM_T1(t_fc2);
     }
   } else {
+    static_assert(TT == 2, "the software-pipelined chunks are the 64-token form");
     fc1(0);
   #pragma unroll
     for (int pi = 0; pi < 16 * HT; ++pi) gelu_pair(pi);
@@ -514,7 +562,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
   MM_STAMP(3);
   // ---- write the residual stream back; optionally the next block's norm1 rows in ITS window order ----------------------
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int tt = 0; tt < TT; ++tt)
     if (live[tt]) {
       float* xr = p.x + (size_t)orig[tt] * C + FW * wave + 4 * half;
 #pragma unroll
@@ -527,14 +575,12 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
     // ---- the next block's q | k | v (swin_backbone.py:252-260 of block b + 1): norm1 rows -> B fragments in the activation tile (every
     // wave is past its last read of the norm2 rows: the barrier behind the last fc1), then three passes of the proj-shaped GEMM phase
     // over the wave's feature slice of q, k and v; a 32-feature tile is one head.  Rows leave head-major in the next block's window order.
-    const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
-    const f32x2 mean = sum * (1.0f / (float)C);
-    const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
-    const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+    TV mean, rstd;
+    token_stats(mean, rstd);
     write_norm(mean, rstd, p.nn_w, p.nn_b, lds + MM_OFF_X);
-    long drow[2];
+    long drow[TT];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) drow[tt] = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
+    for (int tt = 0; tt < TT; ++tt) drow[tt] = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
     MM_BARRIER();                                      // norm1 rows complete
 #pragma unroll 1
     for (int which = 0; which < 3; ++which) {
@@ -544,7 +590,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
         for (int q = 0; q < 4; ++q) {
           const f32x4 qb = *reinterpret_cast<const f32x4*>(p.qkv_b + which * C + FW * wave + 32 * ft + 8 * q + 4 * half);
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
+          for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[ft][tt][4 * q + i] = qb[i];
         }
@@ -552,7 +598,7 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
       const float sc = which == 0 ? p.q_scale : 1.f;
       // as the norm1 rows below: the lane pair of a token swaps 8-byte pieces, lane `half` then owns head dims 8 (2 t + half) .. + 7
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int ft = 0; ft < CF; ++ft) {
           uint16_t* o = p.qkv_out + ((size_t)(which * p.num_heads + CF * wave + ft) * p.qkv_rows + (size_t)drow[tt]) * 32;
@@ -573,14 +619,12 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
     }
   }
   if (EMIT) {
-    const f32x2 sum = token_sums([&](int ft, int tt, int r) { return acc[ft][tt][r]; });
-    const f32x2 mean = sum * (1.0f / (float)C);
-    const f32x2 sq = token_sums([&](int ft, int tt, int r) { const float d = acc[ft][tt][r] - mean[tt]; return d * d; });
-    const f32x2 rstd = {rsqrtf(sq[0] / (float)C + p.eps), rsqrtf(sq[1] / (float)C + p.eps)};
+    TV mean, rstd;
+    token_stats(mean, rstd);
     // 16 bytes per lane: the lane pair (half = 0 | 1) of a token exchanges the 8-byte pieces of (q, q + 1) by v_permlane32_swap, lane
     // `half` then owns features 8 (2 t + half) .. + 7 of a tile — half the row-divergent store instructions
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
       const long drow = (long)tb_[tt] * p.next_rows + p.next_dst[tloc_[tt]];
       uint16_t* o = p.next_ln + (size_t)drow * C + FW * wave;
 #pragma unroll
@@ -610,15 +654,16 @@ __global__ __launch_bounds__(256, (MMc<CF, HC>::REG_WAVES)) void block_tailmm_ke
     __builtin_amdgcn_s_waitcnt(0);
     p.trace[blockIdx.x * 8 + 5] = wait_dma;
     p.trace[blockIdx.x * 8 + 6] = wait_bar;
+    p.trace[blockIdx.x * 8 + 7] = t_fc2;             // (the GELU's VALU work has no memory dependence: the compiler places it behind the clock read)
   }
 #endif
   MM_STAMP(4);
 }
 
-template <typename E, int CF, int HC = 256>
+template <typename E, int CF, int HC = 256, int TT = 2>
 static int launch_mm_cf(const TailParams& p, hipStream_t st) {
-  constexpr int LDS = MMc<CF, HC>::LDS;
-  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MM_TOK)), block(256);
+  constexpr int LDS = MMc<CF, HC, TT>::LDS;
+  dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, MMc<CF, HC, TT>::TOK)), block(256);
   auto go = [&](auto k) -> int {
     LdsOptIn opt;
     if (int rc = opt.ensure(reinterpret_cast<const void*>(k), LDS)) return rc;
@@ -626,22 +671,33 @@ static int launch_mm_cf(const TailParams& p, hipStream_t st) {
     return KVQ_OK;
   };
   int rc;
-  if (p.qkv_out) rc = go(block_tailmm_kernel<E, 2, CF, HC>);
-  else if (p.next_ln) rc = go(block_tailmm_kernel<E, 1, CF, HC>);
-  else rc = go(block_tailmm_kernel<E, 0, CF, HC>);
+  if (p.qkv_out) rc = go(block_tailmm_kernel<E, 2, CF, HC, TT>);
+  else if (p.next_ln) rc = go(block_tailmm_kernel<E, 1, CF, HC, TT>);
+  else rc = go(block_tailmm_kernel<E, 0, CF, HC, TT>);
   if (rc) return rc;
   KVQ_CHECK_LAUNCH("block_tailmm_kernel");
   return KVQ_OK;
 }
 
+int tailmm_geometry_code(int C, int hidden) {
+  if (!tailmm_supported(C, hidden)) return 0;
+  const int hc = C == 768 ? 128 : (C == 384 || C == 512) ? tailmm_hc(C) : 256;
+  return (hc / 128) * 10 + (hc == 128 && tailmm_tok(C) == 128 ? 4 : 2);
+}
+
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
+#ifdef KVQ_TAILMM_FOCUS     // compile-time study builds (register / ISA inspection of one form in seconds instead of minutes): the 128-token C = 384 form only
+  return launch_mm_cf<Fp16, KVQ_TAILMM_FOCUS / 1000, (KVQ_TAILMM_FOCUS / 10) % 100 * 128 / 10, KVQ_TAILMM_FOCUS % 10>(p, st);      // e.g. 3102: CF 3, HC 128, TT 2
+#else
   if (C == 512 && tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4, 128>(p, st) : launch_mm_cf<Bf16, 4, 128>(p, st);
   if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
   if (C == 768) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 6, 128>(p, st) : launch_mm_cf<Bf16, 6, 128>(p, st);
   if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
+  if (tailmm_hc(C) == 128 && tailmm_tok(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3, 128, 4>(p, st) : launch_mm_cf<Bf16, 3, 128, 4>(p, st);
   if (tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3, 128>(p, st) : launch_mm_cf<Bf16, 3, 128>(p, st);
   return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3>(p, st) : launch_mm_cf<Bf16, 3>(p, st);
+#endif
 }
 
 }  // namespace kvq

@@ -28,8 +28,17 @@ def _slot_ok(v) -> bool:
 
 
 def _signature(inputs: Dict[str, torch.Tensor]) -> Tuple:
-    return tuple((k, tuple(v.shape), v.dtype) + ((v.geometry, tuple(v.videos[0].shape), v.videos[0].stride(0)) if _is_lazy(v) else ())
-                 for k, v in sorted(inputs.items()))
+    """what a recording is valid for: tensor shapes / dtypes; for a lazily sampled batch also everything the embedding launch bakes
+    into its parameters — sampler geometry, source frame shape / stride / dtype and the normalisation constants"""
+    def lazy_part(v):
+        v0 = v.videos[0]
+        return (v.geometry, tuple(v0.shape), v0.stride(0), v0.dtype, None if v.mean is None else tuple(v.mean),
+                None if v.std is None else tuple(v.std))
+    return tuple((k, tuple(v.shape), v.dtype) + (lazy_part(v) if _is_lazy(v) else ()) for k, v in sorted(inputs.items()))
+
+
+def _has_lazy(inputs) -> bool:
+    return any(_is_lazy(v) for v in inputs.values())
 
 
 class LaneGraphs:
@@ -39,6 +48,7 @@ class LaneGraphs:
         default stream).  At most ``max_signatures`` input signatures are recorded per lane; further ones run eagerly."""
         self.fn, self.lanes, self.max_signatures, self.warmup = fn, lanes, max_signatures, warmup
         self._graphs: List[Dict[Tuple, Tuple]] = [dict() for _ in lanes]
+        self._slot_fails = False            # a lazy batch could not be recorded through a FragmentSlot: later ones are sampled first
         self.replays = self.eager_runs = 0
 
     def _record(self, lane: int, sig: Tuple, inputs: Dict[str, torch.Tensor]):
@@ -65,6 +75,12 @@ class LaneGraphs:
             return
         self._graphs[lane][sig] = (g, static, out)
 
+    def _materialised(self, lane: int, inputs):
+        """the lazy views of ``inputs`` as their fp32 tensors (on the lane's stream): a signature that no longer depends on the source
+        resolution, stride or dtype"""
+        with torch.cuda.stream(self.lanes[lane]):
+            return {k: (v.materialise() if _is_lazy(v) else v) for k, v in inputs.items()}
+
     def run(self, lane: int, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Enqueue fn(inputs) on lane's stream.  The returned tensor is the graph's static output: consume it on the same
         stream before the lane's next ``run`` (stream order makes that safe without host synchronisation)."""
@@ -74,14 +90,34 @@ class LaneGraphs:
             # front of each replay; one the fused read cannot take (fp32 frames, > 16 clips) becomes its fp32 tensor first
             with torch.cuda.stream(self.lanes[lane]):
                 inputs = {k: (v.materialise() if _is_lazy(v) and not _slot_ok(v) else v) for k, v in inputs.items()}
+        graphs = self._graphs[lane]
+        if self._slot_fails and _has_lazy(inputs):
+            inputs = self._materialised(lane, inputs)
         sig = _signature(inputs)
-        if sig not in self._graphs[lane] and len(self._graphs[lane]) < self.max_signatures:
+        lazy_sigs = sum(1 for s_ in graphs if any(len(part) > 3 for part in s_))
+        if sig not in graphs and _has_lazy(inputs) and lazy_sigs >= self.max_signatures:
+            # the budget of per-resolution recordings is spent (a dataset of many source resolutions): the least recently replayed
+            # one makes room — its graph, static slot and the frames the slot kept alive are released
+            victim = next(s_ for s_ in graphs if any(len(part) > 3 for part in s_))
+            del graphs[victim]
+        if sig not in graphs and (_has_lazy(inputs) or len(graphs) - lazy_sigs < self.max_signatures):
             self._record(lane, sig, inputs)
-        rec = self._graphs[lane].get(sig)
+        rec = graphs.get(sig)
+        if rec is None and _has_lazy(inputs):
+            # a lazy batch whose forward cannot be recorded through the slot (a model that materialises it: the fused read off, an
+            # embedding width without it, the upsample fallback): sample first into a STATIC fp32 tensor and record the forward on
+            # that — one recording whatever the source resolution, instead of eager launches on the replay configuration
+            self._slot_fails = True
+            inputs = self._materialised(lane, inputs)
+            sig = _signature(inputs)
+            if sig not in graphs and len(graphs) - lazy_sigs < self.max_signatures:
+                self._record(lane, sig, inputs)
+            rec = graphs.get(sig)
         if rec is None:                                        # beyond max_signatures, or a signature whose capture failed
             self.eager_runs += 1
             with torch.cuda.stream(self.lanes[lane]):
                 return self.fn(inputs)
+        graphs[sig] = graphs.pop(sig)                          # most recently used last
         g, static, out = rec
         with torch.cuda.stream(self.lanes[lane]):
             for k, v in inputs.items():
@@ -90,5 +126,8 @@ class LaneGraphs:
                 else:
                     static[k].copy_(v, non_blocking=True)
             g.replay()
+            for k, v in inputs.items():
+                if _is_lazy(v):
+                    static[k].release(self.lanes[lane])        # the frames live as long as the replay that reads them, not longer
         self.replays += 1
         return out

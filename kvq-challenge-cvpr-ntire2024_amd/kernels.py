@@ -382,7 +382,8 @@ class FragmentSlot(FragmentSource):
     Same kernels, same arithmetic: scores are bit-identical to the forward on the source itself."""
 
     def __init__(self, source: FragmentSource):
-        assert type(source) is FragmentSource and source.c_struct() is not None, "uint8 frames, at most 16 clips"
+        if not (type(source) is FragmentSource and source.c_struct() is not None):
+            raise ValueError("FragmentSlot: uint8 frames, at most 16 clips")
         self.geometry, self.mean, self.std = source.geometry, source.mean, source.std
         self.device, self.is_cuda, self.dtype, self.shape = source.device, True, source.dtype, source.shape
         self._frame_shape, self._frame_stride = tuple(source.videos[0].shape), source.videos[0].stride(0)
@@ -392,12 +393,29 @@ class FragmentSlot(FragmentSource):
 
     def load(self, source: FragmentSource):
         """point the slot at ``source`` (same geometry, frame shape and normalisation), in stream order"""
-        assert (source.geometry == self.geometry and source.shape == self.shape and source.mean == self.mean and source.std == self.std
+        if not (source.geometry == self.geometry and source.shape == self.shape and source.mean == self.mean and source.std == self.std
                 and tuple(source.videos[0].shape) == self._frame_shape and source.videos[0].stride(0) == self._frame_stride
-                and source.videos[0].dtype == torch.uint8), "a slot serves one geometry"
+                and source.videos[0].dtype == torch.uint8):
+            # a real exception (not an assert: python -O must not replay a graph recorded with other constants)
+            raise ValueError("FragmentSlot.load: a slot serves one sampler geometry, frame shape / stride, uint8 frames and one "
+                             f"normalisation; got geometry {source.geometry} frames {tuple(source.videos[0].shape)} {source.videos[0].dtype}")
         self.table.copy_(source.pointer_table(), non_blocking=True)
         self.current = source                      # keeps the frames alive while the table names them
         self.videos, self.hoffs, self.woffs = source.videos, source.hoffs, source.woffs
+
+    def release(self, stream=None):
+        """drop the slot's reference to the loaded source once the launch that reads it has been ENQUEUED on ``stream``: the caching
+        allocator keeps the frames' memory until that stream passes this point (record_stream), the Python objects go now"""
+        cur = getattr(self, "current", None)
+        if cur is None:
+            return
+        if stream is not None:
+            cur.record_stream(stream)
+            tab = getattr(cur, "_table", None)
+            if tab is not None:
+                tab.record_stream(stream)
+        self.current = None
+        self.videos = self.hoffs = self.woffs = None
 
     def c_struct(self, any_dtype=False):
         if self._c is None:
@@ -418,6 +436,8 @@ class FragmentSlot(FragmentSource):
         # into the graph, so a forward that cannot take the fused read fails its capture (LaneGraphs then runs it eagerly)
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("FragmentSlot.materialise() inside a hipGraph capture: this forward does not read the batch through the sampler")
+        if getattr(self, "current", None) is None:
+            raise RuntimeError("FragmentSlot.materialise(): no source loaded (load() one first)")
         return self.current.materialise(out)
 
     def split_clips(self, num_clips):

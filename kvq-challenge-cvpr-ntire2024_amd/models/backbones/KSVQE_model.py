@@ -44,13 +44,13 @@ def distortion_contrastive_supervised(distortion_feature, dis_label):
 
 class KSVQE(SwinTransformer3D):
     def __init__(self, pretrained=None, pretrained2d=False, num_samples=500, sample_type="topkpertubation", CLIP_location=10,
-                 cls_use=True, tuning_stage=2, a1=1, a2=0, checkpoint=None, qls_swin=None, frozen3D=None, **trunk):
+                 cls_use=True, tuning_stage=2, a1=1, a2=0, checkpoint=None, qls_swin=None, frozen3D=None, contrique_residual16=None, **trunk):
         trunk.setdefault("frag_biases", (True, True, True, False))
         super().__init__(pretrained=pretrained, pretrained2d=pretrained2d, **trunk)
         depths, heads, E = self.depths, self.heads, self.embed_dim
         self.N_key = 5                                   # reference attribute; four frames are actually used (:1357-1361)
         self.CLIP_tool = build_CLIPmodel_basedadapter_cls(CLIP_location=CLIP_location, cls_use=cls_use)
-        self.distortion_tool = KM.CONTRIQUE_model(KM.get_network("resnet50"), 2048)
+        self.distortion_tool = KM.CONTRIQUE_model(KM.get_network("resnet50"), 2048, residual16=contrique_residual16)
         self.dist_adapter = _adapter(128, 32, 128)
         self.spa_patchnet = KM.RegionNet_CLIP(k=7 * 7, anchor_size=32, stride=1, num_samples=num_samples, sample_type=sample_type)
         self.sigma_max = self.sigma = 0.5

@@ -206,15 +206,18 @@ class CONTRIQUE_model(_HipModule):  # noqa: N801
     2048-vector is L2-normalised and projected (Linear -> BatchNorm1d -> ReLU -> Linear -> BatchNorm1d, eval statistics
     folded into the two GEMMs) to ``projection_dim``: returns (b, t, patches per frame, projection_dim) fp32."""
 
-    def __init__(self, encoder, n_features, anchor_size=32, patch_dim=(2, 2), normalize=True, projection_dim=128):
+    def __init__(self, encoder, n_features, anchor_size=32, patch_dim=(2, 2), normalize=True, projection_dim=128, residual16=None):
+        """``residual16`` (build option, not a reference argument): the ResNet trunk's residual stream in 16 bits (True: one more 16-bit
+        rounding per bottleneck, the HBM-bound 1x1 convs move half the bytes — +9 % on the KSVQE forward) or in fp32 (False: rounds
+        3-5).  None: KVQ_CONTRIQUE_R16 (default 1).  Both are pinned to the reference's stored output (tests/test_gpu_clip.py)."""
         super().__init__()
         self.anchor_size, self.normalize, self.n_features, self.patch_dim = anchor_size, normalize, n_features, patch_dim
         if not hasattr(encoder, "features"):
             raise TypeError("encoder must be the network get_network('resnet50') returns")
         self.encoder = nn.Sequential(*list(encoder.children())[:-2])
         object.__setattr__(self, "_net", encoder)              # the same modules, kept for their HIP forward (not re-registered)
-        # KVQ_CONTRIQUE_R16=0: the trunk's residual stream in fp32 (rounds 3-5); default: 16-bit (the 1x1 convs that carry it are HBM-bound)
-        encoder.residual16 = os.environ.get("KVQ_CONTRIQUE_R16", "1") != "0"
+        self.residual16 = (os.environ.get("KVQ_CONTRIQUE_R16", "1") != "0") if residual16 is None else bool(residual16)
+        encoder.residual16 = self.residual16                   # the encoder object is this model's own (get_network builds one per call)
         self.projector = nn.Sequential(nn.Linear(n_features, n_features, bias=False), nn.BatchNorm1d(n_features), nn.ReLU(),
                                        nn.Linear(n_features, projection_dim, bias=False), nn.BatchNorm1d(projection_dim))
 

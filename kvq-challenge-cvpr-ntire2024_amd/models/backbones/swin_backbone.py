@@ -572,11 +572,11 @@ class SwinTransformer3D(nn.Module):
             elif kind == "merge":
                 sym = f"patch_merge_kernel<{ename}, {str(bool(r.variant)).lower()}>"
             elif kind == "tail":
-                cm = r.variant // 10
-                mode = r.variant % 10          # 0: x only, 1: + the next block's norm1 rows, 2: + the next block's q | k | v
+                geom, rest = divmod(r.variant, 1000)       # geom (from the library): (hidden chunk / 128) * 10 + token tiles per workgroup
+                cm, mode = divmod(rest, 10)                # mode 0: x only, 1: + the next block's norm1 rows, 2: + the next block's q | k | v
                 sym = f"block_tail_kernel<{ename}, {cm}, 4, {mode}, false>"
-                if cm in (8, 12, 16, 24):     # C = 256 / 384 / 512 / 768: csrc/tailmm.hip (feature-sliced GEMM chain, register weight ring)
-                    sym = f"block_tailmm_kernel<{ename}, {mode}, {cm // 4}, {128 if cm in (12, 24) else 256}>"
+                if geom:                      # C = 256 / 384 / 512 / 768: csrc/tailmm.hip (feature-sliced GEMM chain, register weight ring)
+                    sym = f"block_tailmm_kernel<{ename}, {mode}, {cm // 4}, {128 * (geom // 10)}, {geom % 10}>"
             else:
                 sym = "patch_im2col_kernel"
             out.append(dict(kind=kind, kernel=sym, ms=float(r.ms), flops=float(r.flops), bytes=float(r.bytes)))

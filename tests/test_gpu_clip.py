@@ -175,13 +175,15 @@ def test_keyframes_and_qrs_vs_reference_golden(golden):
         KM.RegionNet_CLIP(k=49, anchor_size=32, stride=1, sample_type="random").eval()(xd, sd, 0.5, gid)
 
 
+@pytest.mark.parametrize("residual16", [True, False])
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-def test_contrique_vs_reference_golden(golden, dtype):
+def test_contrique_vs_reference_golden(golden, dtype, residual16):
     """KSVQE's distortion branch on the HIP conv stack (implicit-GEMM ResNet-50 trunk on 32x32 patches, kvq_l2_normalize_rows,
     the BatchNorm-folded projector GEMMs) against the reference's stored output."""
     from kvq_amd.models.backbones import ksvqe_modules as KM
     z_ref = golden("contrique.npz")["z"]
-    m = KM.CONTRIQUE_model(KM.get_network("resnet50"), 2048)
+    m = KM.CONTRIQUE_model(KM.get_network("resnet50"), 2048, residual16=residual16)     # both residual-stream widths stay pinned
+    assert m.residual16 is residual16 and m._net.residual16 is residual16
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_contrique_weights(13).items()}, strict=True)
     m.operand_dtype = _abi.dtype_code(dtype)
     m = m.to(DEV).eval()

@@ -32,13 +32,16 @@ def run(M, C, emit=False):
     for i, name in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print(f"   {name:26} mean {d.mean():9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f} ticks")
-    for i, name in ((5, "  of which: DMA waits"), (6, "  of which: barrier waits")):
+    wide = C >= 256            # csrc/tailmm.hip: slot 5 = cycles in fc1 (all chunks), slot 7 = in fc2
+    for i, name in ((5, "  of which: fc1" if wide else "  of which: DMA waits"), (6, "  of which: barrier waits")) + (((7, "  of which: fc2"),) if wide else ()):
         print(f"   {name:26} mean {t[:, i].mean():9.0f}  p10 {np.percentile(t[:, i],10):9.0f}  p90 {np.percentile(t[:, i],90):9.0f} ticks (wave 0, all items)")
     d = t[:, 4] - t[:, 0]
     print(f"   {'lifetime':26} mean {d.mean():9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f} ticks")
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 3:
+        run(int(sys.argv[1]), int(sys.argv[2]), bool(int(sys.argv[3])))
+    elif len(sys.argv) > 2:
         run(int(sys.argv[1]), int(sys.argv[2]), True)
     else:
         run(200704, 96); run(200704, 96, True); run(50176, 192); run(50176, 192, True)
