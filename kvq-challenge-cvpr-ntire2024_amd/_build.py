@@ -42,7 +42,15 @@ def is_stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + [HEADER] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    if any(os.path.getmtime(d) > t for d in deps if os.path.exists(d)):
+        return True
+    # a source edited WHILE a build ran is newer than its object yet older than the library that build linked: the objects are checked too
+    objdir = os.path.join(PKG, f"build_{TAG}" if TAG else "build")
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if os.path.exists(obj) and os.path.getmtime(src) > os.path.getmtime(obj):
+            return True
+    return False
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

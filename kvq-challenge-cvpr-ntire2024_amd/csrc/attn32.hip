@@ -75,7 +75,11 @@ __device__ __forceinline__ float a32_pair_sum(float x) {
 
 // One 32-query block against the key blocks [T0, T1) of the LDS images at `slot`.  Compile-time range: the score / probability /
 // bias registers rotate through statically indexed sets.
-template <typename E, int T0, int T1>
+// SHORT (round 6; N = 385..392, i.e. the (8,7,7) window): the 13th key block holds 8 valid keys, and they are registers 0..3 of both lane halves
+// (key = 384 + (r & 3) + 8 (r >> 2) + 4 hi) — its bias widening, row maximum, exponentials, packs and row sums run on those four registers only
+// (16 of the block's 56 VALU instructions; the MFMAs are whole tiles either way).  A KERNEL-level template argument: a launch holds one form of
+// the body (round 5's run-time select between both forms in one kernel cost more in code size than the short block saved).
+template <typename E, int T0, int T1, bool SHORT = false>
 __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int zero, const u32x4* bd, const typename E::v8 qf0,
                                            const typename E::v8 qf1, const u32x4 (&pre)[2], uint16_t* orow, const bool store) {
   using V8 = typename E::v8;
@@ -91,19 +95,22 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
   const uint32_t one2 = (uint32_t)E::cvt(1.0f) * 0x10001u;
 
   constexpr int BR = A32_BDEPTH + 1;
+  constexpr int LASTB = A32_KB - 1;
+#define A32_NR(t) ((SHORT && (t) == LASTB) ? 4 : 16)      // live score registers of key block t
   u32x4 braw[BR][2];
   auto load_bias = [&](int t) __attribute__((always_inline)) {
 #if (A32_ABL & 1)     // diagnostic: no bias stream (one tile, loaded once per q-block)
     if (t != T0) { braw[t % BR][0] = braw[T0 % BR][0]; braw[t % BR][1] = braw[T0 % BR][1]; return; }
 #endif
     braw[t % BR][0] = bd[t * 128];
-    braw[t % BR][1] = bd[t * 128 + 64];
+    if (A32_NR(t) > 8) braw[t % BR][1] = bd[t * 128 + 64];
   };
   // C operand of block t: bias * log2(e) - m, straight from the packed fp16 pairs (v_fma_mix_f32)
-  auto mix = [&](int t, float nm) __attribute__((always_inline)) -> f32x16 {
+  auto mix = [&](int t, float nm, const f32x16& stale) __attribute__((always_inline)) -> f32x16 {
     f32x16 c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      if (r >= A32_NR(t)) { c[r] = stale[r]; continue; }      // rows of padding keys, never read: whatever the destination registers hold (no moves)
       const uint32_t u = braw[t % BR][r >> 3][(r & 7) >> 1];
       const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((r & 1) ? (u >> 16) : (u & 0xffffu)));
       c[r] = (A32_ABL & 32) ? nm : __builtin_fmaf((float)hv, kLog2e, nm);
@@ -130,7 +137,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     if (T0 + a < T1) load_bias(T0 + a);
   {
     const V8 k0 = kfrag(T0, 0), k1 = kfrag(T0, 1);
-    const f32x16 c = mix(T0, 0.f);
+    const f32x16 c = mix(T0, 0.f, O);
     S[T0 & 1] = E::mfma32(k0, qf0, c);
     S[T0 & 1] = E::mfma32(k1, qf1, S[T0 & 1]);
   }
@@ -158,8 +165,8 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     if (t < T1) {
       mx = fmaxf(fmaxf(S[cur][0], S[cur][1]), S[cur][2]);
 #pragma unroll
-      for (int r = 3; r < ((A32_ABL & 128) ? 4 : 15); r += 2) mx = fmaxf(fmaxf(mx, S[cur][r]), S[cur][r + 1]);
-      mx = fmaxf(mx, S[cur][15]);
+      for (int r = 3; r < ((A32_ABL & 128) ? 4 : A32_NR(t) - 1); r += 2) mx = fmaxf(fmaxf(mx, S[cur][r]), S[cur][r + 1]);
+      mx = fmaxf(mx, S[cur][A32_NR(t) - 1]);
     }
     if (t > T0 && t - 1 != A32_KB - 1 && !(A32_ABL & 4))
       O = E::mfma32(__builtin_bit_cast(V8, __builtin_shufflevector(vf[(A32_ABL & 16) ? (T0 & 1) : nxt][2], vf[(A32_ABL & 16) ? (T0 & 1) : nxt][3], 0, 1, 2, 3, 4, 5, 6, 7)),
@@ -176,7 +183,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
       const float mr = a32_pair_max(mx);                            // the row lives in lanes q and q + 32
       const float d = (t == T0 || mr > A32_THR) ? mr : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[cur][r] -= d;
+      for (int r = 0; r < A32_NR(t); ++r) S[cur][r] -= d;
       if (t != T0) {                       // the first block: O = l = 0, and 2^-d may be infinite (a masked row start)
         const float f = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
@@ -190,7 +197,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     }
     // ---- the score block t+1 in the matrix pipe under exp / pack / row sum of block t ----
     if (t + 1 < T1) {
-      const f32x16 cn = mix(t + 1, nm);
+      const f32x16 cn = mix(t + 1, nm, S[nxt]);
       S[nxt] = E::mfma32(kn0, qf0, cn);
     }
 #if A32_SUM == 1
@@ -212,12 +219,12 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     }
 #else
 #pragma unroll
-    for (int i = 0; i < 4; ++i) P[cur][i] = E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1]));
+    for (int i = 0; i < 4; ++i) P[cur][i] = 2 * i < A32_NR(t) ? E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1])) : 0u;
     if (t + 1 < T1) S[nxt] = E::mfma32(kn1, qf1, S[nxt]);
 #pragma unroll
-    for (int i = 4; i < 8; ++i) P[cur][i] = E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1]));
+    for (int i = 4; i < 8; ++i) P[cur][i] = 2 * i < A32_NR(t) ? E::pack2_raw(A32_EXP(S[cur][2 * i]), A32_EXP(S[cur][2 * i + 1])) : 0u;
 #pragma unroll
-    for (int i = 0; i < ((A32_ABL & 64) ? 1 : 8); i += 2) {          // two chains: v_dot2c accumulates in place
+    for (int i = 0; i < ((A32_ABL & 64) ? 1 : A32_NR(t) / 2); i += 2) {          // two chains: v_dot2c accumulates in place
       ls = E::dot2(P[cur][i], one2, ls);
       ls1 = E::dot2(P[cur][i + 1], one2, ls1);
     }
@@ -257,6 +264,7 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     *reinterpret_cast<u32x4*>(orow + 16 * hi) = w0;
     *reinterpret_cast<u32x4*>(orow + 16 * hi + 8) = w1;
   }
+#undef A32_NR
 }
 
 struct Attn32Params {
@@ -342,7 +350,7 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned ch
 // NW = 4: three workgroups per CU (rounds 4-5).  NW = 8 (round 5 experiment, KVQ_ATTN_WAVES): one workgroup of eight waves per CU — the 13
 // q-blocks of a unit spread over twice the waves (half the latency of a unit without re-staging K | V, as a q-split would), 52 KB of LDS per
 // CU instead of 156; the register budget stays that of three waves per SIMD so that another kernel's waves fit beside it.
-template <typename E, bool FUSED, bool DSPLIT, int NW = 4>
+template <typename E, bool FUSED, bool DSPLIT, int NW = 4, bool SHORT = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_waves_per_eu(3, 3))) void window_attention32_kernel(Attn32Params p) {
   constexpr int A32_WAVES = NW;
   fp16_saturate_mode();
@@ -446,9 +454,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_wav
     // depth-split window (N = 392, halves of 196 tokens): q-blocks 0..5 see key blocks 0..6, 7..12 see 6..12, q-block 6 all of them
     if (dsplit && qb != 6) {
       if (qb < 6) a32_qblock<E, 0, 7>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
-      else a32_qblock<E, 6, A32_KB>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
+      else a32_qblock<E, 6, A32_KB, SHORT>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
     } else {
-      a32_qblock<E, 0, A32_KB>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
+      a32_qblock<E, 0, A32_KB, SHORT>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
     }
   };
   Req ra, rb;
@@ -541,13 +549,13 @@ __global__ __launch_bounds__(256) void bias32_build_kernel(Bias32BuildParams p) 
   }
 }
 
-template <typename E, bool FUSED, bool DSPLIT, int NW>
+template <typename E, bool FUSED, bool DSPLIT, int NW, bool SHORT>
 static int launch_attn32_nw(const Attn32Params& p, hipStream_t st) {
-  auto kern = window_attention32_kernel<E, FUSED, DSPLIT, NW>;
+  auto kern = window_attention32_kernel<E, FUSED, DSPLIT, NW, SHORT>;
   // KVQ_ATTN_LDS_PAD (A/B knob): extra dynamic LDS bytes per workgroup — 2048 makes it two workgroups per CU instead of three
   static const int lds_pad = getenv("KVQ_ATTN_LDS_PAD") ? atoi(getenv("KVQ_ATTN_LDS_PAD")) : 0;
   const int lds_bytes = A32_LDS + lds_pad;
-  static LdsOptIn opt;
+  LdsOptIn opt;
   if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes)) return rc;
   const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH;
   unsigned grid = (unsigned)(8 * ceil_div(npair, 8) * nclip * nrep * p.qsplit);
@@ -562,7 +570,10 @@ static int launch_attn32(const Attn32Params& p, hipStream_t st) {
   // KVQ_ATTN_WAVES: 4 (default) | 8 | 0 = eight waves where the launch holds fewer than 768 units (stages 2-3 at 4 clips)
   static const int nw_env = getenv("KVQ_ATTN_WAVES") ? atoi(getenv("KVQ_ATTN_WAVES")) : 4;
   const bool eight = nw_env == 8 || (nw_env == 0 && (long)p.BW * p.nH < 768);
-  return eight ? launch_attn32_nw<E, FUSED, DSPLIT, 8>(p, st) : launch_attn32_nw<E, FUSED, DSPLIT, 4>(p, st);
+  // KVQ_ATTN_SHORT=0: the generic 13th key block for every N (A/B runs; results agree to the last bit: the skipped registers are padding keys)
+  static const bool short_ok = getenv("KVQ_ATTN_SHORT") ? atoi(getenv("KVQ_ATTN_SHORT")) != 0 : true;
+  if (short_ok && !eight && p.N > 384 && p.N <= 392) return launch_attn32_nw<E, FUSED, DSPLIT, 4, true>(p, st);
+  return eight ? launch_attn32_nw<E, FUSED, DSPLIT, 8, false>(p, st) : launch_attn32_nw<E, FUSED, DSPLIT, 4, false>(p, st);
 }
 
 template <typename E>

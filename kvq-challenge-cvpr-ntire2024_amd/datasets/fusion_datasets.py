@@ -12,7 +12,8 @@ The reference draws its random offsets inside the functions from global RNG stat
 (``torch.randint`` :87-98, ``np.random.randint`` :632-635).  The same calls are made here, in the
 same order, so a seeded run draws the same offsets (SURVEY.md §0 trap 6); every function also accepts
 the offsets explicitly, which is what the parity tests use.
-Video *decode* (decord / cv2, :379-431) is outside the hot path: frames enter
+Video *decode* (decord / cv2, :379-431) is outside the hot path (the reader selection incl. the cv2 fallback's
+padding rule is reproduced, the codecs themselves are not part of this image): frames enter
 as uint8/fp32 (C,T,H,W) tensors.
 """
 from __future__ import annotations
@@ -260,20 +261,67 @@ class NpyFrameReader:
         np.take(self.frames, np.asarray(indices, np.int64), axis=0, out=out)
 
 
+class Cv2FrameReader:
+    """The reference's OpenCV fallback (fusion_datasets.py:398-431) as a frame reader: every frame of the file read in order by
+    ``cv2.VideoCapture.read()`` and kept AS cv2 RETURNS IT (BGR — the reference stacks ``frame`` without a colour conversion, so the
+    fallback path feeds BGR where decord feeds RGB; reproduced, not fixed), and a video of 130 frames or fewer padded with copies of
+    its LAST frame until it holds 131 (``while len(video_frame_array) <= 130``, :413-415).  A file cv2 cannot read a single frame
+    from makes the reference fail in ``np.stack`` on ``None``; here it is a ValueError naming the file.
+    ``cv2`` is imported lazily (it is not part of this image: the logic is exercised in tests with a stand-in module)."""
+    MIN_FRAMES = 131
+
+    def __init__(self, path, cv2_module=None):
+        if cv2_module is None:
+            import cv2 as cv2_module  # noqa: N813
+        cap = cv2_module.VideoCapture(path)
+        frames, last = [], None
+        while True:
+            ret, frame = cap.read()
+            if not ret:
+                break
+            last = frame
+            frames.append(frame)
+        if hasattr(cap, "release"):
+            cap.release()
+        if last is None:
+            raise ValueError(f"{path}: OpenCV could not decode a single frame")
+        while len(frames) < self.MIN_FRAMES:                 # 'too short' (:413-415)
+            frames.append(last)
+        self.frames = np.stack(frames, axis=0)
+        if self.frames.dtype != np.uint8 or self.frames.ndim != 4:
+            raise ValueError(f"{path}: expected uint8 (H, W, 3) frames from OpenCV, got {self.frames.dtype} {self.frames.shape[1:]}")
+
+    def __len__(self):
+        return self.frames.shape[0]
+
+    def __getitem__(self, i):
+        return self.frames[int(i)]
+
+    def read_into(self, indices, out):
+        np.take(self.frames, np.asarray(indices, np.int64), axis=0, out=out)
+
+
 def open_video(path):
-    """Frame reader for ``path``: ``<path>`` itself or ``<path>.npy`` as a frame stack, else decord.VideoReader
-    (fusion_datasets.py:381-383).  The cv2 fallback of the reference (:398-431) is not reproduced."""
+    """Frame reader for ``path``: ``<path>`` itself or ``<path>.npy`` as a frame stack (this build's decode-free entry), else
+    decord.VideoReader (fusion_datasets.py:381-383), else — decord missing, or failing on this file: the reference wraps the decord
+    branch in a bare ``try`` — the OpenCV fallback (:398-431, ``Cv2FrameReader``)."""
     import os
     if path.endswith(".npy"):
         return NpyFrameReader(path)
     if os.path.exists(path + ".npy"):
         return NpyFrameReader(path + ".npy")
+    decord_error = None
     try:
         from decord import VideoReader
+        return VideoReader(path)
+    except Exception as e:  # noqa: BLE001  (the reference: ``except:`` around the whole decord branch)
+        decord_error = e
+    try:
+        return Cv2FrameReader(path)
     except ImportError as e:
-        raise ImportError(f"cannot read {path}: video decode needs decord (not built here: SURVEY.md §8 f2) — or "
-                          f"provide the decoded frames as a uint8 [T,H,W,3] array in {path}.npy") from e
-    return VideoReader(path)
+        raise ImportError(f"cannot read {path}: video decode needs decord or OpenCV (neither is part of this image: SURVEY.md §8 f2; "
+                          f"decord: {type(decord_error).__name__}: {decord_error}) — or provide the decoded frames as a uint8 "
+                          f"[T,H,W,3] array in {path}.npy") from e
 
 
 class _Staging:

@@ -153,3 +153,65 @@ def test_pack_pathway_output_provenance_tag():
     slow2, fast2 = sf.pack_pathway_output(frames)
     fast2.add_(1.0)
     assert not sf._is_packed_pair(slow2, fast2)
+
+
+def test_open_video_reader_order_and_cv2_fallback_padding(tmp_path, monkeypatch):
+    """``spatial_temporal_view_decomposition``'s reader selection (fusion_datasets.py:379-431): decord first, and when decord is missing or
+    fails on the file, OpenCV — every frame kept as cv2 returns it (BGR, no conversion), a video of <= 130 frames padded with its LAST frame
+    to 131 (:413-415).  Neither codec is part of this image: a stand-in ``cv2`` module serves synthetic frames (the logic is what is pinned)."""
+    import sys
+    import types
+
+    import numpy as np
+    import pytest
+
+    import kvq_amd  # noqa: F401
+    from kvq_amd.datasets import fusion_datasets as FD
+
+    rng = np.random.Generator(np.random.PCG64(5))
+    clips = {"short.mp4": rng.integers(0, 256, size=(17, 6, 8, 3), dtype=np.uint8),
+             "long.mp4": rng.integers(0, 256, size=(140, 6, 8, 3), dtype=np.uint8), "empty.mp4": np.zeros((0, 6, 8, 3), np.uint8)}
+
+    class Capture:
+        def __init__(self, path=None):
+            self.frames, self.i = clips[str(path).split("/")[-1]], 0
+
+        def read(self):
+            if self.i >= len(self.frames):
+                return False, None
+            self.i += 1
+            return True, self.frames[self.i - 1]
+
+        def release(self):
+            pass
+
+    fake = types.ModuleType("cv2")
+    fake.VideoCapture = Capture
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    monkeypatch.setitem(sys.modules, "decord", None)                 # `from decord import VideoReader` -> ImportError -> the fallback
+    short = FD.open_video(str(tmp_path / "short.mp4"))
+    assert isinstance(short, FD.Cv2FrameReader) and len(short) == 131
+    assert np.array_equal(short.frames[:17], clips["short.mp4"])                       # BGR kept as delivered
+    assert all(np.array_equal(short[i], clips["short.mp4"][-1]) for i in (17, 60, 130))  # padded with the LAST frame
+    long = FD.open_video(str(tmp_path / "long.mp4"))
+    assert len(long) == 140 and np.array_equal(long.frames, clips["long.mp4"])
+    out = np.empty((3, 6, 8, 3), np.uint8)
+    long.read_into([0, 139, 7], out)
+    assert np.array_equal(out, clips["long.mp4"][[0, 139, 7]])
+    with pytest.raises(ValueError, match="could not decode"):
+        FD.open_video(str(tmp_path / "empty.mp4"))
+    # a decord that FAILS on the file falls through to OpenCV as well (the reference's bare `except:` around the decord branch)
+    broken = types.ModuleType("decord")
+
+    def _raise(path):
+        raise RuntimeError("decord: unsupported stream")
+    broken.VideoReader = _raise
+    monkeypatch.setitem(sys.modules, "decord", broken)
+    assert len(FD.open_video(str(tmp_path / "short.mp4"))) == 131
+    # the decode-free entry of this build still wins, and with neither codec the error says what to provide
+    np.save(tmp_path / "x.mp4.npy", clips["short.mp4"])
+    assert isinstance(FD.open_video(str(tmp_path / "x.mp4")), FD.NpyFrameReader)
+    monkeypatch.setitem(sys.modules, "cv2", None)
+    monkeypatch.setitem(sys.modules, "decord", None)
+    with pytest.raises(ImportError, match="decord or OpenCV"):
+        FD.open_video(str(tmp_path / "short.mp4"))

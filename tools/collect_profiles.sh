@@ -8,7 +8,7 @@
 #   pmc_sq.txt             rocprofv3 --pmc SQ_* (separate pass) of the same command
 #   c3_*, c5_*             the same for the C3 probe (bench.py --probe c3) and the C5 probe (bench.py --probe c5)
 #   gemm_sweep.txt, slowfast_layers.txt, attention / bias-build probes, embed_sampler_pmc.txt (HBM bytes of K1 + embedding, both sequencings)
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -43,6 +43,16 @@ for s in 0 1; do
   rm -rf /tmp/tr_attn; TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_attn -o t -- $C2 --steps 8 --warmup 2 --min-timed-s 0 > /dev/null 2>&1
   python tools/attn_launches.py /tmp/tr_attn >> $out/attn_launches.txt 2>&1
 done
+# per-launch HBM traffic of one C2 step (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes) and the family ablation of the 4-lane line
+# (KVQ_SKIP is honoured by the -DKVQ_DIAG variant only: built on the build host, see tools/skip_ablation.sh)
+timeout 900 python tools/step_traffic.py > $out/step_traffic.txt 2>&1
+[ -f kvq-challenge-cvpr-ntire2024_amd/libkvq_hip_diag.so ] && timeout 1500 bash tools/skip_ablation.sh $out/skip_ablation.txt > /dev/null 2>&1
+# the timed regime under a kernel trace: per-queue gaps, concurrency histogram, per-family launch durations in the mix
+rm -rf /tmp/tr_mix; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_mix -o t -- python $OLDPWD/bench.py --probe c2mix --probe-steps 24 --streams 4 > /dev/null 2>&1)
+python tools/mix_timeline.py /tmp/tr_mix 24 > $out/mix_timeline.txt 2>&1
+# KSVQE forward: kernel statistics of 3 serial forwards (the one-time builders of the first forward included)
+rm -rf /tmp/tr_ks; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_ks -o t -- python bench.py --probe ksvqe --probe-steps 3 > /dev/null 2>&1
+db=$(find /tmp/tr_ks -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/ksvqe_kernel_stats.txt
 find $out -name "*.db" -size +20M -delete
 find $out -name "*counter_collection.csv" -size +20M -delete
 ls $out
