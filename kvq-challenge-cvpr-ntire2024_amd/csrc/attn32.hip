@@ -54,6 +54,24 @@ constexpr int A32_WAVES_DEFAULT = 4;
 constexpr int A32_OFF_ZERO = A32_SLOT;             // 1 KB of zeros, then the q-block ticket
 constexpr int A32_OFF_CTR = A32_OFF_ZERO + 1024;
 constexpr int A32_LDS = A32_OFF_CTR + 16;          // 52 240 B: three workgroups per CU
+// The co-operative last q-block (round 6, SHORT launches: N = 385..392, 4 waves, no q-split).  13 q-blocks over 4 waves are 4 + 3 + 3 + 3: one
+// wave works a fourth round on a block that holds 8 valid rows while three idle — and the workgroups of a launch run in lock-step, so every
+// SIMD of the chip is down to one wave at once.  Instead the 12 full q-blocks go out 3 per wave and the LAST one is cut along the KEYS into four
+// ranges (tickets 12..15: key blocks 0-3 | 4-6 | 7-9 | 10-12); the first three finishers leave their un-normalised (O, l, m) of the 8 rows
+// in LDS, the fourth merges (the flash-attention merge: everything moves to the largest maximum) and stores.  The partials (1 KB each: 8 rows
+// x 2 lane halves x 16 fp32) live where nothing that is READ FOR A USED VALUE lives: the zero block and the K image's rows 392..399 (in a SHORT
+// launch the 13th key block only uses the accumulator rows of keys 384..391: what rows 392..415 hold reaches dead registers only; V's rows are
+// NOT touched: P = 0 times a NaN would not be 0) and 1.5 KB behind the ticket.  52 240 + 1 744 B = 53 984: still three workgroups per CU.
+constexpr int A32_COOP_PARTS = 4;
+constexpr int A32_OFF_DONE = A32_OFF_CTR + 4;                          // arrivals of the key ranges
+constexpr int A32_OFF_ML = A32_OFF_CTR + 16;                            // [3 slots][8 rows][nm, ls] fp32 = 192 B
+constexpr int A32_OFF_PT = A32_OFF_ML + 192;                            // 3 x 512 B
+constexpr int A32_LDS_COOP = A32_OFF_PT + 1536;                         // 53 984 B
+// half `hh` (lane half) of partial slot `sl`: 8 rows x 64 B
+__device__ __forceinline__ int a32_part_off(int sl, int hh) {
+  const int u = 2 * sl + hh;                                            // 0, 1: the zero block; 2: K rows 392..399; 3..5: behind the ticket
+  return u < 2 ? A32_OFF_ZERO + 512 * u : u == 2 ? 392 * 64 : A32_OFF_PT + 512 * (u - 3);
+}
 constexpr int A32_BDEPTH = 2;                      // bias tiles requested ahead of the block being multiplied (3 / 5 / 7 measured: no gain)
 constexpr float A32_THR = 8.0f;                    // log2 units: a block is exponentiated against a maximum at most 2^8 too small
 constexpr float A32_OFF = -60000.0f;               // padding keys: exp2 underflows to exactly 0
@@ -79,9 +97,47 @@ __device__ __forceinline__ float a32_pair_sum(float x) {
 // (key = 384 + (r & 3) + 8 (r >> 2) + 4 hi) — its bias widening, row maximum, exponentials, packs and row sums run on those four registers only
 // (16 of the block's 56 VALU instructions; the MFMAs are whole tiles either way).  A KERNEL-level template argument: a launch holds one form of
 // the body (round 5's run-time select between both forms in one kernel cost more in code size than the short block saved).
-template <typename E, int T0, int T1, bool SHORT = false>
+// The un-normalised state of a row after the key blocks [T0, T1): O (this lane's 16 features), the row sum of THIS lane's keys (the lane
+// pair's halves still apart) and nm = -(the maximum the state is scaled by), log2 units.
+struct A32State {
+  f32x16 O;
+  float ls, nm;
+};
+
+// normalise + store.  Lane (query q, half hi) holds features 8j + 4hi .. +3, j = 0..3: four 8-byte pieces of the row's 64 bytes,
+// interleaved with the partner lane's.  Two v_permlane32_swap per dword pair hand lane q features 0..15 and lane q + 32 features
+// 16..31: two 16-byte stores of 32 contiguous bytes per lane instead of four 8-byte ones (the store tail is issue-bound).
+// `ls` = the ROW's sum (both halves).
+template <typename E>
+__device__ __forceinline__ void a32_finish(const f32x16& O, float ls, uint16_t* orow, const bool store) {
+  const int hi = (threadIdx.x & 63) >> 5;
+  const float inv = __builtin_amdgcn_rcpf(ls);          // >= 2^-THR-ish and finite: the row maximum contributes >= 2^-THR
+  uint32_t pk[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pk[j][0] = E::pack2(O[4 * j] * inv, O[4 * j + 1] * inv);
+    pk[j][1] = E::pack2(O[4 * j + 2] * inv, O[4 * j + 3] * inv);
+  }
+  u32x4 w0, w1;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    // swap(vdst = piece j, vsrc = piece j + 2): low lanes end with {own piece j, partner's piece j}, high lanes with {partner's piece
+    // j + 2, own piece j + 2} — in both cases consecutive features
+    const auto a = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[2][d], false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(pk[1][d], pk[3][d], false, false);
+    w0[d] = a[0]; w0[2 + d] = a[1];
+    w1[d] = b[0]; w1[2 + d] = b[1];
+  }
+  if (store) {
+    *reinterpret_cast<u32x4*>(orow + 16 * hi) = w0;
+    *reinterpret_cast<u32x4*>(orow + 16 * hi + 8) = w1;
+  }
+}
+
+template <typename E, int T0, int T1, bool SHORT = false, bool PARTIAL = false>
 __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int zero, const u32x4* bd, const typename E::v8 qf0,
-                                           const typename E::v8 qf1, const u32x4 (&pre)[2], uint16_t* orow, const bool store) {
+                                           const typename E::v8 qf1, const u32x4 (&pre)[2], uint16_t* orow, const bool store,
+                                           A32State* part = nullptr) {
   using V8 = typename E::v8;
   static_assert(T0 >= 0 && T0 < T1 && T1 <= A32_KB, "key block range");
   const int lane = threadIdx.x & 63, q = lane & 31, hi = lane >> 5;
@@ -237,33 +293,14 @@ __device__ __forceinline__ void a32_qblock(const unsigned char* slot, const int 
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // ---- normalise + store.  Lane (query q, half hi) holds features 8j + 4hi .. +3, j = 0..3: four 8-byte pieces of the row's 64 bytes,
-  // interleaved with the partner lane's.  Two v_permlane32_swap per dword pair hand lane q features 0..15 and lane q + 32 features
-  // 16..31: two 16-byte stores of 32 contiguous bytes per lane instead of four 8-byte ones (the store tail is issue-bound) ----
   ls += ls1;
   if (A32_SUM == 1) ls = (lv0[0] + lv0[1]) + (lv1[0] + lv1[1]);
-  ls = a32_pair_sum(ls);
-  const float inv = __builtin_amdgcn_rcpf(ls);          // >= 2^-THR-ish and finite: the row maximum contributes >= 2^-THR
-  uint32_t pk[4][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    pk[j][0] = E::pack2(O[4 * j] * inv, O[4 * j + 1] * inv);
-    pk[j][1] = E::pack2(O[4 * j + 2] * inv, O[4 * j + 3] * inv);
+  ls = a32_pair_sum(ls);                                 // the row lives in lanes q and q + 32
+  if (PARTIAL) {                                         // the key range of a co-operatively computed q-block: the caller merges the ranges
+    part->O = O; part->ls = ls; part->nm = nm;
+    return;
   }
-  u32x4 w0, w1;
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    // swap(vdst = piece j, vsrc = piece j + 2): low lanes end with {own piece j, partner's piece j}, high lanes with {partner's piece
-    // j + 2, own piece j + 2} — in both cases consecutive features
-    const auto a = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[2][d], false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(pk[1][d], pk[3][d], false, false);
-    w0[d] = a[0]; w0[2 + d] = a[1];
-    w1[d] = b[0]; w1[2 + d] = b[1];
-  }
-  if (store) {
-    *reinterpret_cast<u32x4*>(orow + 16 * hi) = w0;
-    *reinterpret_cast<u32x4*>(orow + 16 * hi + 8) = w1;
-  }
+  a32_finish<E>(O, ls, orow, store);
 #undef A32_NR
 }
 
@@ -281,6 +318,7 @@ struct Attn32Params {
   float q_scale;               // head_dim^-0.5 * log2(e)
   uint16_t* q_out;             // = the q third of qkv
   const uint32_t* pad_mask;    // optional [nW][13]: bit r & 31 of word r >> 5 = window row r is a padding row (k | v = b_qkv's thirds, q = 0)
+  bool coop_ok;                // no launch of this process splits a unit over workgroups (qsplit_max == 1): the co-operative last q-block may be chosen
 };
 
 // q | k | v of one (window, head) from the window's norm1 rows (C = 32 KS): D^T[feature][row] = W[feature][:] . x[row][:] on
@@ -350,8 +388,9 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned ch
 // NW = 4: three workgroups per CU (rounds 4-5).  NW = 8 (round 5 experiment, KVQ_ATTN_WAVES): one workgroup of eight waves per CU — the 13
 // q-blocks of a unit spread over twice the waves (half the latency of a unit without re-staging K | V, as a q-split would), 52 KB of LDS per
 // CU instead of 156; the register budget stays that of three waves per SIMD so that another kernel's waves fit beside it.
-template <typename E, bool FUSED, bool DSPLIT, int NW = 4, bool SHORT = false>
+template <typename E, bool FUSED, bool DSPLIT, int NW = 4, bool SHORT = false, bool COOP = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_waves_per_eu(3, 3))) void window_attention32_kernel(Attn32Params p) {
+  static_assert(!COOP || (SHORT && NW == 4), "the co-operative last q-block is built for SHORT launches of 4 waves");
   constexpr int A32_WAVES = NW;
   fp16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -399,7 +438,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_wav
     }
   }
   const int q_lo = part * nqb / p.qsplit, q_hi = (part + 1) * nqb / p.qsplit;
-  if (tid == 0) *ticket = q_lo;
+  if (tid == 0) {
+    *ticket = q_lo;
+    if (COOP) *reinterpret_cast<int*>(smem + A32_OFF_DONE) = 0;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!FUSED && p.pad_mask) {
@@ -421,20 +463,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_wav
 
   const int q = lane & 31, hi = lane >> 5;
   const uint32_t skip = p.tile_skip ? p.tile_skip[w] : 0u;
+  const bool dsplit = DSPLIT && p.dsplit_from >= 0 && w >= p.dsplit_from;
+  // COOP: tickets 0 .. nqb-2 are whole q-blocks, nqb-1 .. nqb+2 the four key ranges of the last one (a depth-split window's last q-block
+  // sees 7 key blocks only: it stays whole)
+  const bool coop = COOP && !dsplit && p.qsplit == 1;
+  const int n_tickets = coop ? nqb - 1 + A32_COOP_PARTS : q_hi;
+  auto block_of = [&](int t_) -> int { return coop && t_ >= nqb - 1 ? nqb - 1 : t_; };
   auto take = [&]() -> int {
-    int t_;
+    int t_, qb_;
     do {                                                        // q-blocks whose two 16-row tiles are padding only are passed over
       t_ = 0;
       if (lane == 0) t_ = atomicAdd(ticket, 1);
       t_ = __builtin_amdgcn_readfirstlane(t_);
-    } while (t_ < q_hi && ((skip >> (2 * t_)) & 1u) && (((skip >> (2 * t_ + 1)) & 1u) || 32 * t_ + 16 >= N));
+      qb_ = block_of(t_);
+    } while (t_ < n_tickets && ((skip >> (2 * qb_)) & 1u) && (((skip >> (2 * qb_ + 1)) & 1u) || 32 * qb_ + 16 >= N));
     return t_;
   };
-  const bool dsplit = DSPLIT && p.dsplit_from >= 0 && w >= p.dsplit_from;
   const u32x4* img = p.image + (size_t)pair * nqb * (A32_KB * 128) + lane;
   // the ticket, the q fragments and the first bias tile of the NEXT q-block are requested while this one is computed
   struct Req { V8 qf0, qf1; u32x4 pre[2]; };
-  auto request = [&](int qb, Req& r) __attribute__((always_inline)) {
+  auto request = [&](int t_, Req& r) __attribute__((always_inline)) {
+    const int qb = block_of(t_), part = t_ - (nqb - 1);
     const int qrow = min(32 * qb + q, N - 1);
     r.qf0 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 8 * hi);
     r.qf1 = *reinterpret_cast<const V8*>(Qg + (size_t)qrow * 32 + 16 + 8 * hi);
@@ -442,15 +491,76 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_wav
       r.qf0 = __builtin_bit_cast(V8, (u32x4){0u, 0u, 0u, 0u});
       r.qf1 = r.qf0;
     }
-    const int t0 = (dsplit && qb > 6) ? 6 : 0;
+    const int t0 = (dsplit && qb > 6) ? 6 : (coop && part > 0) ? 1 + 3 * part : 0;        // first key block of what will run
     const u32x4* bd = img + (size_t)min(qb, nqb - 1) * (A32_KB * 128) + t0 * 128;
     r.pre[0] = bd[0]; r.pre[1] = bd[64];
   };
-  auto run = [&](int qb, const Req& r) __attribute__((always_inline)) {
+  auto run = [&](int t_, const Req& r) __attribute__((always_inline)) {
+    const int qb = block_of(t_);
     const u32x4* bd = img + (size_t)qb * (A32_KB * 128);
     uint16_t* orow = p.out + ((size_t)bw * N + 32 * qb + q) * C + h * 32;
     const bool store = 32 * qb + q < N;
     const int zero = A32_OFF_ZERO >> 4;
+    if (COOP && coop && t_ >= nqb - 1) {
+      // one key range of the last q-block, then: park the partial state (the first three to arrive) or merge all four and store
+      A32State st;
+      const int part = t_ - (nqb - 1);
+      if (part == 0) a32_qblock<E, 0, 4, false, true>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store, &st);
+      else if (part == 1) a32_qblock<E, 4, 7, false, true>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store, &st);
+      else if (part == 2) a32_qblock<E, 7, 10, false, true>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store, &st);
+      else a32_qblock<E, 10, A32_KB, SHORT, true>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store, &st);
+      // ranges 0..2 park their state in the slot of their INDEX and count themselves; range 3 (the last ticket: as a rule the last to finish)
+      // waits for the three and merges in index order — the result does not depend on which wave ran which range or on who finished first
+      int* done = reinterpret_cast<int*>(smem + A32_OFF_DONE);
+      float* ml = reinterpret_cast<float*>(smem + A32_OFF_ML);
+      const bool row_ok = q < 8;                                   // rows 384 + q of the window: at most 8 are tokens
+      if (part < A32_COOP_PARTS - 1) {
+        if (row_ok) {
+          float* po = reinterpret_cast<float*>(smem + a32_part_off(part, hi) + q * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(po + 4 * j) = (f32x4){st.O[4 * j], st.O[4 * j + 1], st.O[4 * j + 2], st.O[4 * j + 3]};
+          if (hi == 0) *reinterpret_cast<f32x2*>(ml + (part * 8 + q) * 2) = (f32x2){st.nm, st.ls};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        if (lane == 0) while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < A32_COOP_PARTS - 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float nmin = st.nm;
+        float onm[A32_COOP_PARTS - 1], ols[A32_COOP_PARTS - 1];
+#pragma unroll
+        for (int sl = 0; sl < A32_COOP_PARTS - 1; ++sl) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(ml + (sl * 8 + (q & 7)) * 2);
+          onm[sl] = v[0]; ols[sl] = v[1];
+          nmin = fminf(nmin, v[0]);
+        }
+        // O_p is scaled by 2^-m_p = 2^nm_p: everything moves to the largest maximum m = -nmin by 2^(nmin - nm_p) <= 1; ranges in index order
+        float ls = 0.f;
+        f32x16 O;
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) O[r2] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < A32_COOP_PARTS - 1; ++sl) {
+          const float f = __builtin_amdgcn_exp2f(nmin - onm[sl]);
+          ls = fmaf(ols[sl], f, ls);
+          const float* po = reinterpret_cast<const float*>(smem + a32_part_off(sl, hi) + (q & 7) * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(po + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) O[4 * j + e] = fmaf(v[e], f, O[4 * j + e]);
+          }
+        }
+        {
+          const float f = __builtin_amdgcn_exp2f(nmin - st.nm);
+          ls = fmaf(st.ls, f, ls);
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2) O[r2] = fmaf(st.O[r2], f, O[r2]);
+        }
+        a32_finish<E>(O, ls, orow, store && row_ok);
+      }
+      return;
+    }
     // depth-split window (N = 392, halves of 196 tokens): q-blocks 0..5 see key blocks 0..6, 7..12 see 6..12, q-block 6 all of them
     if (dsplit && qb != 6) {
       if (qb < 6) a32_qblock<E, 0, 7>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
@@ -459,17 +569,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_wav
       a32_qblock<E, 0, A32_KB, SHORT>(smem, zero, bd, r.qf0, r.qf1, r.pre, orow, store);
     }
   };
-  Req ra, rb;
-  int qa = take(), qbn;
-  if (qa < q_hi) request(qa, ra);
-  while (qa < q_hi) {
-    qbn = take();
-    if (qbn < q_hi) request(qbn, rb);
-    run(qa, ra);
-    if (qbn >= q_hi) break;
-    qa = take();
-    if (qa < q_hi) request(qa, ra);
-    run(qbn, rb);
+  // ONE inlined body per kind of ticket (rounds 4-5 unrolled the loop twice to rotate two request sets; the copy below is 16 moves per q-block)
+  Req cur, nxt;
+  int ta = take();
+  if (ta < n_tickets) request(ta, cur);
+  while (ta < n_tickets) {
+    const int tn = take();
+    if (tn < n_tickets) request(tn, nxt);
+    run(ta, cur);
+    ta = tn;
+    cur = nxt;
   }
 }
 
@@ -549,12 +658,12 @@ __global__ __launch_bounds__(256) void bias32_build_kernel(Bias32BuildParams p) 
   }
 }
 
-template <typename E, bool FUSED, bool DSPLIT, int NW, bool SHORT>
+template <typename E, bool FUSED, bool DSPLIT, int NW, bool SHORT, bool COOP = false>
 static int launch_attn32_nw(const Attn32Params& p, hipStream_t st) {
-  auto kern = window_attention32_kernel<E, FUSED, DSPLIT, NW, SHORT>;
+  auto kern = window_attention32_kernel<E, FUSED, DSPLIT, NW, SHORT, COOP>;
   // KVQ_ATTN_LDS_PAD (A/B knob): extra dynamic LDS bytes per workgroup — 2048 makes it two workgroups per CU instead of three
   static const int lds_pad = getenv("KVQ_ATTN_LDS_PAD") ? atoi(getenv("KVQ_ATTN_LDS_PAD")) : 0;
-  const int lds_bytes = A32_LDS + lds_pad;
+  const int lds_bytes = (COOP ? A32_LDS_COOP : A32_LDS) + lds_pad;
   LdsOptIn opt;
   if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), lds_bytes)) return rc;
   const int nclip = p.BW / p.nW, nrep = p.nW / p.n_types, npair = p.n_types * p.nH;
@@ -572,7 +681,20 @@ static int launch_attn32(const Attn32Params& p, hipStream_t st) {
   const bool eight = nw_env == 8 || (nw_env == 0 && (long)p.BW * p.nH < 768);
   // KVQ_ATTN_SHORT=0: the generic 13th key block for every N (A/B runs; results agree to the last bit: the skipped registers are padding keys)
   static const bool short_ok = getenv("KVQ_ATTN_SHORT") ? atoi(getenv("KVQ_ATTN_SHORT")) != 0 : true;
-  if (short_ok && !eight && p.N > 384 && p.N <= 392) return launch_attn32_nw<E, FUSED, DSPLIT, 4, true>(p, st);
+  // KVQ_ATTN_COOP=0: the last q-block as one ticket (rounds 4-5); results differ by the fp32 rounding of the four-way merge on its <= 8 rows
+  // The co-operative last q-block is OFF by default: built, pinned (tests/test_gpu_kernels.py::test_window_attention32_cooperative_last_qblock)
+  // and measured in round 6 (profiles/r06_attn_coop_ab.txt).  Alone on the chip it shortens the launches that are ONE round of workgroups
+  // (stages 2-3, their duration is a workgroup's lifetime: 33.7 -> 31.7, 26.3 -> 24.1 us) and lengthens those of several rounds, whose
+  // workgroups run out of step anyway (stage 0: 95 -> 104 us: four range prologues + the merge instead of one q-block); on the 4-lane line
+  // both choices are level with the plain form (400.4 / 400.1 / 400.2 videos/s, same box, alternating).  KVQ_ATTN_COOP=1: where one clip
+  // holds <= 96 (window, head) units; 2: every SHORT launch.  A window's rows differ between the forms by the fp32 rounding of the merge,
+  // so the choice follows nW x nH (the units of ONE clip), never the batch.
+  static const int coop_env = getenv("KVQ_ATTN_COOP") ? atoi(getenv("KVQ_ATTN_COOP")) : 0;
+  if (short_ok && !eight && p.N > 384 && p.N <= 392) {
+    const bool coop = coop_env >= 2 || (coop_env == 1 && p.nW * p.nH <= 96);
+    if (coop && p.coop_ok && p.qsplit == 1) return launch_attn32_nw<E, FUSED, DSPLIT, 4, true, true>(p, st);
+    return launch_attn32_nw<E, FUSED, DSPLIT, 4, true>(p, st);
+  }
   return eight ? launch_attn32_nw<E, FUSED, DSPLIT, 8, false>(p, st) : launch_attn32_nw<E, FUSED, DSPLIT, 4, false>(p, st);
 }
 
@@ -626,6 +748,7 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
                      a->dsplit_from < 0 ? -1 : a->dsplit_from};
+  p.coop_ok = qsplit_max == 1;       // (a q-split that follows the batch would make the form, hence a window's rounding, follow the batch)
   if (a->pad_mask) {
     KVQ_REQUIRE(a->b_qkv && !a->x_ln, KVQ_ERR_NULL, "kvq_window_attention32: pad_mask needs b_qkv (and excludes the fused projection)");
     p.pad_mask = a->pad_mask; p.b_qkv = a->b_qkv;

@@ -421,6 +421,19 @@ def _tok_table(lay, window):
     return tok, center
 
 
+def test_window_attention32_cooperative_last_qblock():
+    """KVQ_ATTN_COOP=2 (csrc/attn32.hip, round 6: the 13th q-block of an N = 392 window cut along the keys into four ranges, merged in range
+    order through LDS) holds the same oracle gates, tile_skip semantics and run-to-run bit-equality as the default form: the library reads
+    the variable once, so the attention tests run again in a child interpreter with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, KVQ_ATTN_COOP="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "window_attention32_vs_oracle or window_attention32_fused or padded_partition"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
 @pytest.mark.parametrize("dims,window,shifted,gated,nH", [
     ((8, 14, 14), (8, 7, 7), False, True, 3),
     ((8, 14, 14), (8, 7, 7), True, True, 3),
@@ -471,6 +484,19 @@ def test_window_attention_softmax_extremes(half):
                                    N, True).float().cpu()
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() <= 6.4 * EPS[half]
+
+
+def test_window_attention32_cooperative_last_qblock():
+    """KVQ_ATTN_COOP=2 (csrc/attn32.hip, round 6: the 13th q-block of an N = 392 window cut along the keys into four ranges, merged in range
+    order through LDS) holds the same oracle gates, tile_skip semantics and run-to-run bit-equality as the default form: the library reads
+    the variable once, so the attention tests run again in a child interpreter with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, KVQ_ATTN_COOP="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "window_attention32_vs_oracle or window_attention32_fused or padded_partition"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
 
 
 @pytest.mark.parametrize("dims,window,shifted,gated,nH", [
