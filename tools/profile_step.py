@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-launch table of one forward step (hipEvent brackets inside libkvq_hip.so): kernel, time,
 achieved TFLOP/s and GB/s on the ALGORITHMIC flops/bytes of each launch.
-    python tools/profile_step.py [--batch 4] [--dtype fp16] [--steps 3]"""
+    python tools/profile_step.py [--batch 4] [--dtype bf16] [--weights init] [--steps 3]   (defaults = the bench headline)"""
 import argparse
 import os
 import sys
@@ -15,13 +15,14 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--dtype", default=os.environ.get("KVQ_BENCH_DTYPE", "bf16"))
+    ap.add_argument("--weights", default=None)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--clip-tensor", action="store_true", help="feed a pre-sampled fp32 clip instead of (uint8 frames, sampler draws)")
     a = ap.parse_args()
     from kvq_amd.utils import synth
     dev = torch.device("cuda", 0)
-    net, cfg, wts, hw = bench.build_net(a.dtype, dev)
+    net, cfg, wts, hw = bench.build_net(a.dtype, dev, a.weights or ("init" if a.dtype == "bf16" else "stress"))
     if a.clip_tensor:
         x = torch.from_numpy(synth.synth_clip(1234, 32, 224, 224, batch=a.batch)).to(dev)
     else:       # the bench's step: the embedding launch reads through the fragment sampler
