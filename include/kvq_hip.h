@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KVQ_ABI_VERSION 30
+#define KVQ_ABI_VERSION 31
 #define KVQ_MAX_STAGES 4
 
 /* 16-bit MFMA operand type of every uint16_t buffer below (activations AND weights of one call must
@@ -313,6 +313,7 @@ typedef struct {
   float eps;
   int32_t dtype;
   const KvqFragmentSource* frag; /* host struct or NULL: read the clip through the sampler (T, H, W = the sampled clip's) */
+  int32_t out_f16;             /* ABI 31: `out` receives the residual stream as fp16 [B*D0*H0*W0][E] (2 E bytes per row) instead of fp32 */
 } KvqPatchEmbedArgs;
 int kvq_patch_embed_supported(int in_chans, int pd, int ph, int pw, int embed_dim, int T, int H, int W);
 /* 1 when the fused read applies to a (B, in_chans, T, H, W) batch sampled from src: uint8 frames, 4 x 4 patches inside the
@@ -342,6 +343,7 @@ typedef struct {
   int32_t next_rows;
   float eps;
   int32_t dtype;
+  int32_t x_f16, out_f16;      /* ABI 31: x / out are fp16 residual streams (rows of 2 C / 4 C bytes) instead of fp32                */
 } KvqPatchMergeArgs;
 int kvq_patch_merge_supported(int C);
 size_t kvq_patch_merge_pack_bytes(int C);
@@ -382,6 +384,7 @@ typedef struct {
   void* qkv_out;               /* 16-bit; non-NULL selects this form                                         */
   float q_scale;
   int32_t num_heads;
+  int32_t x_f16;               /* ABI 31: x is the residual stream kept in fp16 (C <= 192 only): rows of 2 C bytes, read and written in place */
 } KvqBlockTailArgs;
 /* Padded window partitions (Swin-B at 256x256, KSVQE at 288x288): the q|k|v of a PADDING row is qkv(0) = bias (the reference pads after
  * norm1, swin_backbone.py:416-449) and takes part in the softmax of its window as a key.  Instead of multiplying zero rows, the qkv

@@ -19,7 +19,7 @@ K_COUNT = len(K_NAMES)
 
 EPI_BIAS_BF16, EPI_GELU_BF16, EPI_QKV_BF16, EPI_RESID_F32, EPI_STORE_F32, EPI_RELU_BF16, EPI_QGELU_BF16 = range(7)
 DT_BF16, DT_FP16 = 0, 1
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 
 def dtype_code(dt) -> int:
@@ -107,7 +107,8 @@ class KvqBlockTailArgs(C.Structure):
                 ("out_rows", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("pack", p_void),
                 ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void),
                 ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32), ("attn_gather", p_void),
-                ("next_qkv_pack", p_void), ("next_qkv_b", p_void), ("qkv_out", p_void), ("q_scale", C.c_float), ("num_heads", C.c_int32)]
+                ("next_qkv_pack", p_void), ("next_qkv_b", p_void), ("qkv_out", p_void), ("q_scale", C.c_float), ("num_heads", C.c_int32),
+                ("x_f16", C.c_int32)]
 
 
 FRAG_MAX_CLIPS = 16
@@ -125,13 +126,13 @@ class KvqPatchEmbedArgs(C.Structure):
                 ("W", C.c_int32), ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32), ("embed_dim", C.c_int32),
                 ("pack", p_void), ("has_norm", C.c_int32), ("out", p_void), ("next_norm_w", p_void),
                 ("next_norm_b", p_void), ("next_dst", p_void), ("next_ln", p_void), ("next_rows", C.c_int32),
-                ("eps", C.c_float), ("dtype", C.c_int32), ("frag", C.POINTER(KvqFragmentSource))]
+                ("eps", C.c_float), ("dtype", C.c_int32), ("frag", C.POINTER(KvqFragmentSource)), ("out_f16", C.c_int32)]
 
 
 class KvqPatchMergeArgs(C.Structure):
     _fields_ = [("x", p_void), ("merge_map", p_void), ("B", C.c_int32), ("L", C.c_int32), ("Ln", C.c_int32), ("C", C.c_int32),
                 ("pack", p_void), ("out", p_void), ("next_norm_w", p_void), ("next_norm_b", p_void), ("next_dst", p_void),
-                ("next_ln", p_void), ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32)]
+                ("next_ln", p_void), ("next_rows", C.c_int32), ("eps", C.c_float), ("dtype", C.c_int32), ("x_f16", C.c_int32), ("out_f16", C.c_int32)]
 
 
 class KvqProfRecord(C.Structure):

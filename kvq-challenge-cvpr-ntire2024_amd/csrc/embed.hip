@@ -36,6 +36,7 @@ struct EmbedParams {
   const unsigned char* pack; // kvq_patch_embed_pack image
   int has_ln;                // patch_embed.norm present
   float* out;                // [B*L0][E] fp32
+  int out16;                 // round 6: the residual stream leaves as fp16 rows of 2 E bytes (same pointer)
   const float* nn_w;         // first block's norm1 (EMIT)
   const float* nn_b;
   const int32_t* next_dst;   // token -> window row
@@ -240,6 +241,14 @@ __global__ __launch_bounds__(256, embed_staged(CM, FRAG) ? 2 : 3) void patch_emb
       const f32x4 v = *reinterpret_cast<const f32x4*>(stg + t * RP + w);
       if (t < nrow) *reinterpret_cast<f32x4*>(gb + off) = v;
     }
+  } else if (live && p.out16) {
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (size_t)rc * E + 4 * h;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<u32x2*>(o + 32 * i + 8 * q) =
+            (u32x2){Fp16::pack2(acc[i][4 * q], acc[i][4 * q + 1]), Fp16::pack2(acc[i][4 * q + 2], acc[i][4 * q + 3])};
   } else if (live) {
     float* o = p.out + (size_t)rc * E + 4 * h;
 #pragma unroll
@@ -365,7 +374,7 @@ extern "C" int kvq_patch_embed(const KvqPatchEmbedArgs* a, void* stream) {
   }
   p.x = a->x; p.B = a->B; p.Cin = a->in_chans; p.T = a->T; p.H = a->H; p.W = a->W; p.pd = a->pd;
   p.D0 = a->T / a->pd; p.H0 = a->H / 4; p.W0 = a->W / 4;
-  p.pack = (const unsigned char*)a->pack; p.has_ln = a->has_norm; p.out = a->out; p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b;
+  p.pack = (const unsigned char*)a->pack; p.has_ln = a->has_norm; p.out = a->out; p.out16 = a->out_f16; p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b;
   p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln; p.next_rows = a->next_rows; p.eps = a->eps;
   hipStream_t st = (hipStream_t)stream;
   if (a->embed_dim == 96)

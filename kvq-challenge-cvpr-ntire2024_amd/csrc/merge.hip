@@ -25,6 +25,7 @@ struct MergeParams {
   int B, L, Ln;
   const unsigned char* pack;
   float* out;                // [B*Ln][2C]
+  int x16, out16;            // round 6: x / out are fp16 residual streams (rows of 2 C / 4 C bytes behind the same pointers)
   const float* nn_w;         // next block's norm1 (EMIT)
   const float* nn_b;
   const int32_t* next_dst;   // merged token -> window row
@@ -127,11 +128,28 @@ __global__ __launch_bounds__(64 * MGc<C_>::WAVES, (2 * MGc<C_>::LDS <= 163840 ? 
   float sq = 0.f, s1 = 0.f;
   constexpr int PF = 6;                                   // k-steps of row pieces in flight (two 16-byte loads each)
   f32x4 ring[PF][2];
+  // fp16 stream (x16): the 8 channels of a piece are ONE 16-byte load; it stays raw in v[0] (widened where it is used: a conversion here
+  // would wait for the load and undo the PF k-steps of prefetch)
   auto piece = [&](int s, f32x4 (&v)[2]) __attribute__((always_inline)) {       // k-step s = neighbour s / QS, channels 16 (s % QS) + 8 h ..
     const int n = s / QS, q = s - n * QS;
+    if (p.x16) {
+      v[0] = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.x) + (src[n] - p.x) + 16 * q));
+      if (nb[n] < 0) v[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     v[0] = *reinterpret_cast<const f32x4*>(src[n] + 16 * q);
     v[1] = *reinterpret_cast<const f32x4*>(src[n] + 16 * q + 4);
     if (nb[n] < 0) v[0] = v[1] = (f32x4){0.f, 0.f, 0.f, 0.f};       // F.pad zeros take part in the statistics (swin_backbone.py:541-544)
+  };
+  auto widen = [&](const f32x4 (&v)[2], float (&o)[8]) __attribute__((always_inline)) {      // the 8 channels of a piece as fp32
+    if (p.x16) {
+      const f16x8 hv = __builtin_bit_cast(f16x8, v[0]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (float)hv[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = v[0][e]; o[4 + e] = v[1][e]; }
+    }
   };
 #pragma unroll
   for (int s = 0; s < PF; ++s) piece(s, ring[s]);
@@ -142,9 +160,12 @@ __global__ __launch_bounds__(64 * MGc<C_>::WAVES, (2 * MGc<C_>::LDS <= 163840 ? 
   // |K|, where the 16-bit ulp is the operand's whole signal; a mean over 96 channels moves by outlier / 96.
   float shift = 0.f;
 #pragma unroll
-  for (int s = 0; s < PF; ++s)
+  for (int s = 0; s < PF; ++s) {
+    float o8[8];
+    widen(ring[s], o8);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) shift += ring[s][0][e] + ring[s][1][e];
+    for (int e = 0; e < 4; ++e) shift += o8[e] + o8[4 + e];
+  }
   shift += __shfl_xor(shift, 32);
   shift *= 1.0f / (float)(PF * 16);
 #pragma unroll
@@ -157,11 +178,9 @@ __global__ __launch_bounds__(64 * MGc<C_>::WAVES, (2 * MGc<C_>::LDS <= 163840 ? 
       if (s / KC + 1 < NCH) issue_chunk(s / KC + 1);
     }
     float d[8];
+    widen(ring[s % PF], d);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      d[e] = ring[s % PF][0][e] - shift;
-      d[4 + e] = ring[s % PF][1][e] - shift;
-    }
+    for (int e = 0; e < 8; ++e) d[e] -= shift;
     if (s + PF < KS) piece(s + PF, ring[s % PF]);          // the slot just read takes the piece PF k-steps ahead
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -203,7 +222,8 @@ __global__ __launch_bounds__(64 * MGc<C_>::WAVES, (2 * MGc<C_>::LDS <= 163840 ? 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = outv(i, q);
-        if (live) *reinterpret_cast<f32x4*>(o + 32 * i + 8 * q) = v;
+        if (live && p.out16) *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)rc * N + 4 * h + 32 * i + 8 * q) = (u32x2){Fp16::pack2(v[0], v[1]), Fp16::pack2(v[2], v[3])};
+        else if (live) *reinterpret_cast<f32x4*>(o + 32 * i + 8 * q) = v;
         if (EMIT) t1 += (v[0] + v[1]) + (v[2] + v[3]);
         if (q == 3) __builtin_amdgcn_sched_barrier(0);
       }
@@ -328,7 +348,7 @@ extern "C" int kvq_patch_merge(const KvqPatchMergeArgs* a, void* stream) {
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_patch_merge: dtype %d", a->dtype);
   KVQ_REQUIRE((((size_t)a->x | (size_t)a->out | (size_t)a->merge_map) & 15) == 0, KVQ_ERR_SHAPE, "kvq_patch_merge: 16-byte aligned buffers");
   MergeParams p{};
-  p.x = a->x; p.map = a->merge_map; p.B = a->B; p.L = a->L; p.Ln = a->Ln; p.pack = (const unsigned char*)a->pack; p.out = a->out;
+  p.x = a->x; p.map = a->merge_map; p.B = a->B; p.L = a->L; p.Ln = a->Ln; p.pack = (const unsigned char*)a->pack; p.out = a->out; p.x16 = a->x_f16; p.out16 = a->out_f16;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln; p.next_rows = a->next_rows;
   p.eps = a->eps;
   return a->dtype == KVQ_DT_FP16 ? launch_merge_c<Fp16>(a->C, p, (hipStream_t)stream) : launch_merge_c<Bf16>(a->C, p, (hipStream_t)stream);

@@ -480,6 +480,43 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   uint16_t* bo = (uint16_t*)(ws + pl->off_o);
   pl->ev_used = pl->profile ? pl->ev_used : 0;
 
+  // ---- the residual stream of a stage in fp16 (round 6) --------------------------------------------------------------------------------
+  // x is written once and read once per block (8 C bytes per token in fp32): 41 % of the step's HBM traffic.  Where EVERY producer and
+  // consumer of a stage's stream is one of the token-per-lane launches (embedding / fused merge -> fused tails -> fused merge) the stream
+  // lives in fp16 — 2.9e-6 on the score of a 32 x 224 x 224 clip in an fp32 emulation, two orders below the 16-bit MFMA operands' own
+  // 3.6e-4 (tools/diag/resid16_probe.py): the stream carries 11 bits where every GEMM input is rounded to 8 or 11 anyway.  Decided by
+  // geometry and weights only (never by the batch); whole-trunk forwards only (taps / stage-split forwards / `io` keep fp32);
+  // the last stage and the C >= 256 stages keep fp32 (tailmm, the LayerNorm launches and the GEMM epilogues read and write fp32).
+  // KVQ_RESID16=0: fp32 everywhere (rounds 1-5).
+  static const bool resid16_on = !(getenv("KVQ_RESID16") && atoi(getenv("KVQ_RESID16")) == 0);
+  static const int tail_maxc_x = getenv("KVQ_TAIL_MAXC") ? atoi(getenv("KVQ_TAIL_MAXC")) : 1 << 30;
+  static const int merge_maxc_x = getenv("KVQ_MERGE_MAXC") ? atoi(getenv("KVQ_MERGE_MAXC")) : 192;
+  bool any_tap = false;
+  for (float* t : pl->taps) any_tap = any_tap || t != nullptr;
+  auto fused_merge = [&](int i) -> bool {                      // stage i -> i + 1 is the one-launch merge (csrc/merge.hip)
+    return i >= 0 && i < cfg.num_stages - 1 && w->merges[i].merge_pack && kvq_patch_merge_supported(pl->st[i].C) && pl->st[i].C <= merge_maxc_x;
+  };
+  const bool embed_fused = w->embed_pack && kvq_patch_embed_supported(cfg.in_chans, cfg.patch[0], cfg.patch[1], cfg.patch[2], cfg.embed_dim, pl->T, pl->H, pl->W);
+  bool x16[KVQ_MAX_STAGES] = {false, false, false, false};
+  if (resid16_on && stage_lo == 0 && stage_hi == cfg.num_stages - 1 && !io && !any_tap) {
+    int blk0 = 0;
+    for (int i = 0; i < cfg.num_stages - 1; blk0 += pl->st[i].depth, ++i) {
+      const StageGeom& g = pl->st[i];
+      bool ok = g.C <= 192 && g.C <= tail_maxc_x && g.Lp == g.L && g.d_dst[0] && fused_merge(i) && (i == 0 ? embed_fused : fused_merge(i - 1));
+      for (int b = 0; ok && b < g.depth; ++b) {
+        const KvqSwinBlockW& bw = w->blocks[blk0 + b];
+        const int par = (b & 1) && g.shifted_any ? 1 : 0;
+        ok = bw.tail_pack && kvq_block_tail_supported(g.C, cfg.mlp_ratio * g.C) && bw.norm1_w && bw.norm1_b && g.d_dst[par];
+      }
+      x16[i] = ok;
+    }
+  }
+  bool x16_cur = false;                                        // the stream `cur` holds right now
+  auto f32_only = [&](const char* what) -> int {               // a launch that reads or writes the stream as fp32 met an fp16 one: a bug above, never garbage
+    KVQ_REQUIRE(!x16_cur, KVQ_ERR_UNSUPPORTED, "kvq_swin3d_forward: internal: %s on an fp16 residual stream", what);
+    return KVQ_OK;
+  };
+
   // ---- PatchEmbed3D (swin_backbone.py:715-733): one fused launch, or im2col -> GEMM(+bias) -> LayerNorm ----
   const int L0 = pl->D0 * pl->H0 * pl->W0, E = cfg.embed_dim;
   float* cur = xa;
@@ -492,7 +529,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     KvqPatchEmbedArgs ea{};
     ea.x = x; ea.frag = frag; ea.B = B; ea.in_chans = cfg.in_chans; ea.T = pl->T; ea.H = pl->H; ea.W = pl->W;
     ea.pd = cfg.patch[0]; ea.ph = cfg.patch[1]; ea.pw = cfg.patch[2]; ea.embed_dim = E; ea.pack = w->embed_pack;
-    ea.has_norm = w->embed_ln_w ? 1 : 0; ea.out = xa; ea.eps = 1e-5f; ea.dtype = pl->dtype;
+    ea.has_norm = w->embed_ln_w ? 1 : 0; ea.out = xa; ea.eps = 1e-5f; ea.dtype = pl->dtype; ea.out_f16 = x16[0] ? 1 : 0;
+    x16_cur = x16[0];
     const StageGeom& g0 = pl->st[0];
     if (g0.Lp == g0.L && g0.d_dst[0] && w->blocks[0].norm1_w && w->blocks[0].norm1_b) {     // + norm1 / partition of the first block
       ea.next_norm_w = w->blocks[0].norm1_w; ea.next_norm_b = w->blocks[0].norm1_b; ea.next_dst = g0.d_dst[0];
@@ -501,7 +539,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     }
     const double px = (double)B * L0 * pl->K0;
     Bracket br(pl, st, KVQ_K_EMBED, (first_ln1_ready ? 1 : 0) + (frag ? 2 : 0), 2.0 * B * L0 * (double)E * pl->K0,
-               px * (frag ? 1.0 : 4.0) + (double)B * L0 * E * (4.0 + (first_ln1_ready ? 2.0 : 0.0)));
+               px * (frag ? 1.0 : 4.0) + (double)B * L0 * E * ((x16[0] ? 2.0 : 4.0) + (first_ln1_ready ? 2.0 : 0.0)));
     KVQ_TRY_UNLESS(64, kvq_patch_embed(&ea, st));
   } else {
     KVQ_REQUIRE(!frag, KVQ_ERR_UNSUPPORTED, "kvq_swin3d_forward_fragments: this plan does not take the fused patch-embedding launch");
@@ -521,6 +559,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   }
   auto tap = [&](int idx, size_t elems) -> int {          // feats[idx] of the reference's forward (multi / layer)
     if (pl->taps.empty() || !pl->taps[idx]) return KVQ_OK;
+    KVQ_TRY(f32_only("a feature tap"));
     KVQ_CHECK_HIP(hipMemcpyAsync(pl->taps[idx], cur, elems * sizeof(float), hipMemcpyDeviceToDevice, st));
     return KVQ_OK;
   };
@@ -558,7 +597,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       } else if (g.Lp != g.L && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
         // (rows scattered to their window rows by the epilogue); the padding rows' q | k | v = qkv(0) = bias
-        if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+        if (!ln1_ready) {
+          KVQ_TRY(f32_only("the norm1 launch of a padded partition"));
+          KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+        }
         KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, ML, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                      qs, g.d_dst[par], g.L, g.Lp));
         // the padding rows' q | k | v = qkv(0) = bias: attention32 writes them into its own K | V images (pad_mask); the gather path
@@ -566,7 +608,10 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         if (!(bw.bias_dense && g.d_padmask[par]))
           KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, qs, pl->dtype, st));
       } else if (!qkv_ready) {
-        if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+        if (!ln1_ready) {
+          KVQ_TRY(f32_only("the norm1 launch"));
+          KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
+        }
         if (!fuse_qkv)
           KVQ_TRY_UNLESS(8 | (i == cfg.num_stages - 1 ? 32 : 0), gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH, qs));
       }
@@ -602,6 +647,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         KvqBlockTailArgs ta{};
         ta.attn = bo; ta.x = cur; ta.scatter_map = g.d_src[par]; ta.map_rows = g.Lp; ta.out_rows = g.L;
         ta.M = M; ta.C = C; ta.hidden = hidden; ta.pack = bw.tail_pack; ta.eps = 1e-5f; ta.dtype = pl->dtype;
+        ta.x_f16 = x16_cur ? 1 : 0;
         const int npar = ((b + 1) & 1) && g.shifted_any ? 1 : 0;
         if (g.Lp != g.L) ta.attn_gather = g.d_dst[par];      // padded windows: walk the tokens, not the window rows
         // the next block's norm1 rows in ITS window order (un-padded partitions: token -> window row is a bijection).  Padded
@@ -635,10 +681,11 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
           }
         }
         Bracket br(pl, st, KVQ_K_TAIL, kvq::tailmm_geometry_code(C, hidden) * 1000 + (C / 32) * 10 + (ln1_ready ? 1 : 0) + (qkv_ready ? 2 : 0), 2.0 * M * C * C + 4.0 * (double)ML * C * hidden + (qkv_ready ? 6.0 * M * C * C : 0.0),
-                   (double)M * C * 2.0 + (double)ML * C * (8.0 + (ln1_ready ? 2.0 : 0.0) + (qkv_ready ? 6.0 : 0.0)));
+                   (double)M * C * 2.0 + (double)ML * C * ((x16_cur ? 4.0 : 8.0) + (ln1_ready ? 2.0 : 0.0) + (qkv_ready ? 6.0 : 0.0)));
         KVQ_TRY_UNLESS(C <= 192 ? 2 : 4, kvq_block_tail(&ta, st));
         continue;
       }
+      KVQ_TRY(f32_only("the proj / MLP GEMM chain"));
       // proj + window_reverse + roll back + crop + residual.  Padded partition: over the tokens (A rows gathered through token ->
       // window row, output in place in token order) instead of over the window rows with the padding rows dropped in the epilogue
       if (g.Lp != g.L) {
@@ -671,7 +718,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         // taken since round 5 (merge_maxc = 192): level on the 4-lane line with two launches fewer (profiles/r05_lane_experiments.txt)
         KvqPatchMergeArgs ma{};
         ma.x = cur; ma.merge_map = g.d_merge; ma.B = B; ma.L = g.L; ma.Ln = Ln; ma.C = C; ma.pack = mw.merge_pack; ma.out = oth;
-        ma.eps = 1e-5f; ma.dtype = pl->dtype;
+        ma.eps = 1e-5f; ma.dtype = pl->dtype; ma.x_f16 = x16_cur ? 1 : 0; ma.out_f16 = x16[i + 1] ? 1 : 0;
         if (i + 1 <= stage_hi) {
           const StageGeom& gn = pl->st[i + 1];
           const KvqSwinBlockW& nb = w->blocks[blk];           // blk: the first block of stage i + 1
@@ -681,9 +728,11 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
           }
         }
         Bracket br(pl, st, KVQ_K_MERGE, merged_ln1_ready ? 1 : 0, 2.0 * B * Ln * (double)(2 * C) * (4 * C),
-                   (double)B * Ln * 4 * C * 4.0 + (double)B * Ln * 2 * C * (4.0 + (merged_ln1_ready ? 2.0 : 0.0)));
+                   (double)B * Ln * 4 * C * (x16_cur ? 2.0 : 4.0) + (double)B * Ln * 2 * C * ((x16[i + 1] ? 2.0 : 4.0) + (merged_ln1_ready ? 2.0 : 0.0)));
         KVQ_TRY_UNLESS(128, kvq_patch_merge(&ma, st));
+        x16_cur = x16[i + 1];
       } else {
+        KVQ_TRY(f32_only("the un-fused PatchMerging"));
         KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr));
         KVQ_TRY_UNLESS(128, gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
                      oth));
@@ -695,8 +744,12 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     }
     KVQ_TRY(tap(i + 1, out_elems));
   }
-  if (io) KVQ_CHECK_HIP(hipMemcpyAsync(io, cur, out_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (io) {
+    KVQ_TRY(f32_only("the stage-split output copy"));
+    KVQ_CHECK_HIP(hipMemcpyAsync(io, cur, out_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
   if (feat && stage_hi == cfg.num_stages - 1) {
+    KVQ_TRY(f32_only("the final LayerNorm"));
     const StageGeom& gl = pl->st.back();
     KVQ_TRY(ln(pl, st, cur, nullptr, 1, gl.L, gl.L, gl.C, w->norm_w, w->norm_b, nullptr, feat));
   }

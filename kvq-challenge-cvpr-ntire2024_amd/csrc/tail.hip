@@ -203,15 +203,34 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
     // would make the register allocator shuffle / spill the 16-register tuples.
     const float* xr = p.x + (size_t)orig * C + 4 * h;
     const float* pbg = reinterpret_cast<const float*>(p.pack + (size_t)NI * SLOT) + 4 * h;
+    if (p.x16) {
+      // fp16 residual stream (round 6): 8 bytes per lane and quad instead of 16; every piece requested before the first is widened
+      typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+      const uint16_t* xr16 = reinterpret_cast<const uint16_t*>(p.x) + (size_t)orig * C + 4 * h;
+      f16x4_t u[CM][4];
 #pragma unroll
-    for (int i = 0; i < CM; ++i)
+      for (int i = 0; i < CM; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 32 * i + 8 * q);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(pbg + 32 * i + 8 * q);
+        for (int q = 0; q < 4; ++q) u[i][q] = *reinterpret_cast<const f16x4_t*>(xr16 + 32 * i + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = v[e] + b[e];
-      }
+      for (int i = 0; i < CM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(pbg + 32 * i + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = (float)u[i][q][e] + b[e];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 32 * i + 8 * q);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(pbg + 32 * i + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = v[e] + b[e];
+        }
+    }
   }
 
   auto issue = [&](int item, int slot) {
@@ -466,6 +485,14 @@ __global__ __launch_bounds__(64 * NW, tail_bpc(32 * CM, NW)) void block_tail_ker
         if (rowx[g] >= 0) *reinterpret_cast<f32x4*>(p.x + (size_t)rowx[g] * C + 32 * i + 4 * rp) = t;
       }
     }
+  } else if (live && p.x16) {
+    uint16_t* xr = reinterpret_cast<uint16_t*>(p.x) + (size_t)orig * C + 4 * h;
+#pragma unroll
+    for (int i = 0; i < CM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<u32x2*>(xr + 32 * i + 8 * q) =
+            (u32x2){Fp16::pack2(acc[i][4 * q], acc[i][4 * q + 1]), Fp16::pack2(acc[i][4 * q + 2], acc[i][4 * q + 3])};
   } else if (live) {
     float* xr = p.x + (size_t)orig * C + 4 * h;
 #pragma unroll
@@ -614,7 +641,7 @@ static int launch_tail(const TailParams& p, hipStream_t st) {
   static const bool staged_on = getenv("KVQ_TAIL_STAGED") && atoi(getenv("KVQ_TAIL_STAGED")) == 1;
   // the epilogue's four tiles need NW * 4 KB of ring slots (+ the extra bytes) that do not hold the last item
   const int NI = tail_proj_items(C) + 1 + p.hidden / 32, s_last = (NI - 1) % NST;
-  const bool staged = staged_on && ((NST - 1 - s_last) * SLOT + XTRA >= NW * TAIL_STG || s_last * SLOT >= NW * TAIL_STG);
+  const bool staged = staged_on && !p.x16 && ((NST - 1 - s_last) * SLOT + XTRA >= NW * TAIL_STG || s_last * SLOT >= NW * TAIL_STG);
   const size_t lds = (size_t)NST * SLOT + (staged ? XTRA : 0) + ((((size_t)(4 * C + p.hidden) * 4) + 1023) & ~(size_t)1023) + (size_t)2 * C * 4;
   KVQ_REQUIRE(lds <= (size_t)163840 / tail_bpc(C, NW), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: %zu B of LDS", lds);
   dim3 grid((unsigned)ceil_div(p.gather ? p.n_tok : p.M, 32 * NW)), block(64 * NW);
@@ -728,7 +755,8 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
               "kvq_block_tail: next_ln without its norm / map");
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: dtype %d", a->dtype);
   TailParams p{};
-  p.attn = (const uint16_t*)a->attn; p.x = a->x; p.map = a->scatter_map; p.map_rows = a->map_rows; p.out_rows = a->out_rows;
+  KVQ_REQUIRE(!a->x_f16 || a->C <= 192, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: the fp16 residual stream is built for C <= 192 (C=%d)", a->C);
+  p.attn = (const uint16_t*)a->attn; p.x = a->x; p.x16 = a->x_f16; p.map = a->scatter_map; p.map_rows = a->map_rows; p.out_rows = a->out_rows;
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;
   p.next_rows = a->next_rows; p.eps = a->eps; p.trace = g_trace; p.trace_blocks = g_trace_blocks;

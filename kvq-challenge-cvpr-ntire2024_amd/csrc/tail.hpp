@@ -7,7 +7,8 @@ namespace kvq {
 
 struct TailParams {
   const uint16_t* attn;      // [M][C] 16-bit, window order
-  float* x;                  // [n_batch*out_rows][C] fp32, in place
+  float* x;                  // [n_batch*out_rows][C] fp32, in place (x16: the same rows as fp16, 2 C bytes each)
+  int x16;                   // round 6: the residual stream of this stage is kept in fp16 (csrc/tail.hip, C <= 192)
   const int32_t* map;        // window row -> token of the batch element (or <0 = padding); NULL = identity
   const int32_t* gather;     // token -> window row (attn_gather): the launch walks n_tok tokens instead of M window rows
   int n_tok;

@@ -844,13 +844,15 @@ def block_tail_qkv_pack(qkv_w: torch.Tensor, hidden: int):
 
 def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: int, *, scatter_map=None, map_rows=0,
                out_rows=0, next_norm=None, next_dst=None, next_rows=0, eps=1e-5, attn_gather=None, next_qkv=None):
-    """x (fp32 [n_batch*out_rows, C], in place) += proj(attn) scattered; x += Mlp(norm2(x)).
+    """x (fp32 [n_batch*out_rows, C], in place — or fp16 at C <= 192: the round-6 residual stream of stages 0-1, ``x_f16``)
+    += proj(attn) scattered; x += Mlp(norm2(x)).
     ``next_norm=(gamma, beta)`` + ``next_dst`` additionally returns norm1_next(x) in the next window order — or, with
     ``next_qkv=(qkv_pack, qkv_bias, q_scale)``, the next block's q | k | v, head-major [3][C/32][n_batch*next_rows][32]."""
     _need_gpu(attn, x, pack, scatter_map, next_dst)
-    assert attn.dtype in HALF_TYPES and attn.is_contiguous() and x.dtype == torch.float32 and x.is_contiguous()
+    assert attn.dtype in HALF_TYPES and attn.is_contiguous() and x.dtype in (torch.float32, torch.float16) and x.is_contiguous()
     M, Cc = attn.shape
     a = _abi.KvqBlockTailArgs()
+    a.x_f16 = int(x.dtype == torch.float16)
     a.attn, a.x, a.scatter_map, a.attn_gather = ptr(attn), ptr(x), ptr(scatter_map), ptr(attn_gather)
     a.map_rows, a.out_rows = (map_rows, out_rows) if (scatter_map is not None or attn_gather is not None) else (M, M)
     a.M, a.C, a.hidden, a.pack, a.eps, a.dtype = M, Cc, hidden, ptr(pack), eps, dtype_code(attn.dtype)
@@ -869,7 +871,7 @@ def block_tail(attn: torch.Tensor, x: torch.Tensor, pack: torch.Tensor, hidden: 
 
 
 def patch_embed(x, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, next_dst=None, next_rows=0,
-                eps=1e-5):
+                eps=1e-5, out_f16=False):
     """PatchEmbed3D as one launch: x fp32 (B,Cin,T,H,W) or a ``FragmentSource``, w 16-bit [E][Cin*pd*ph*pw] -> fp32
     [B*D0*H0*W0, E] (+ the first block's norm1 rows when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
     frag = None
@@ -891,8 +893,9 @@ def patch_embed(x, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, 
     check(lib().kvq_patch_embed_pack(ptr(w), ptr(bias), ptr(ln_w), ptr(ln_b), Ed, K, ptr(pack), current_stream()),
           "kvq_patch_embed_pack")
     L0 = (T // pd) * (H // ph) * (W // pw)
-    out = torch.empty(B * L0, Ed, dtype=torch.float32, device=x.device)
+    out = torch.empty(B * L0, Ed, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)      # out_f16: the fp16 residual stream
     a = _abi.KvqPatchEmbedArgs()
+    a.out_f16 = int(out_f16)
     a.x, a.B, a.in_chans, a.T, a.H, a.W, a.pd, a.ph, a.pw, a.embed_dim = (None if frag else ptr(x)), B, Cin, T, H, W, pd, ph, pw, Ed
     if frag is not None:
         a.frag = C.pointer(frag)
@@ -907,11 +910,11 @@ def patch_embed(x, w: torch.Tensor, bias, ln_w, ln_b, patch, *, next_norm=None, 
 
 
 def patch_merge(x: torch.Tensor, merge_map: torch.Tensor, n_batch: int, red_w: torch.Tensor, norm_w, norm_b, out_dtype=torch.float16, *,
-                next_norm=None, next_dst=None, next_rows=0, eps=1e-5):
-    """PatchMerging as one launch (C = 96 / 128 / 192): x fp32 [n_batch*L, C], merge_map int32 [Ln, 4] (-1 = zero padding), red_w fp32 [2C, 4C]
+                next_norm=None, next_dst=None, next_rows=0, eps=1e-5, out_f16=False):
+    """PatchMerging as one launch (C = 96 / 128 / 192): x fp32 (or fp16: the round-6 residual stream; ``out_f16``: the merged one too) [n_batch*L, C], merge_map int32 [Ln, 4] (-1 = zero padding), red_w fp32 [2C, 4C]
     -> fp32 [n_batch*Ln, 2C] (+ the next block's norm1 rows, ``out_dtype``, when ``next_norm=(gamma, beta)`` / ``next_dst`` are given)."""
     _need_gpu(x, merge_map, red_w, norm_w, norm_b, next_dst)
-    assert x.dtype == torch.float32 and x.is_contiguous() and merge_map.dtype == torch.int32 and merge_map.is_contiguous()
+    assert x.dtype in (torch.float32, torch.float16) and x.is_contiguous() and merge_map.dtype == torch.int32 and merge_map.is_contiguous()
     assert red_w.dtype == torch.float32 and red_w.is_contiguous()
     Cc = x.shape[1]
     L, Ln = x.shape[0] // n_batch, merge_map.shape[0]
@@ -921,8 +924,9 @@ def patch_merge(x: torch.Tensor, merge_map: torch.Tensor, n_batch: int, red_w: t
     pack = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib().kvq_patch_merge_pack(ptr(red_w), ptr(norm_w), ptr(norm_b), Cc, dtype_code(out_dtype), ptr(pack), current_stream()),
           "kvq_patch_merge_pack")
-    out = torch.empty(n_batch * Ln, 2 * Cc, dtype=torch.float32, device=x.device)
+    out = torch.empty(n_batch * Ln, 2 * Cc, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
     a = _abi.KvqPatchMergeArgs()
+    a.x_f16, a.out_f16 = int(x.dtype == torch.float16), int(out_f16)
     a.x, a.merge_map, a.B, a.L, a.Ln, a.C, a.pack, a.out = ptr(x), ptr(merge_map), n_batch, L, Ln, Cc, ptr(pack), ptr(out)
     a.eps, a.dtype = eps, dtype_code(out_dtype)
     nxt = None

@@ -23,17 +23,17 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in kvq_hip.h but not exported"
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
-    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 30
+    assert handle.kvq_abi_version() == _abi.ABI_VERSION == 31
 
 
 def test_struct_layouts_match_header_sizes():
     import ctypes as C
     assert C.sizeof(_abi.KvqSwinCfg) == 4 * (3 + 1 + 1 + 1 + 4 + 4 + 3 + 1 + 4 + 3)
     assert C.sizeof(_abi.KvqSwinBlockW) == 18 * 8
-    assert C.sizeof(_abi.KvqBlockTailArgs) == 144
+    assert C.sizeof(_abi.KvqBlockTailArgs) == 152          # ABI 31: + x_f16
     assert C.sizeof(_abi.KvqSwinWeights) == 5 * 8 + 8 + 3 * 4 * 8 + 2 * 8
-    assert C.sizeof(_abi.KvqPatchMergeArgs) == 96
-    assert C.sizeof(_abi.KvqPatchEmbedArgs) == 128
+    assert C.sizeof(_abi.KvqPatchMergeArgs) == 104         # ABI 31: + x_f16, out_f16
+    assert C.sizeof(_abi.KvqPatchEmbedArgs) == 136         # ABI 31: + out_f16
     assert C.sizeof(_abi.KvqFragmentSource) == 3 * 16 * 8 + 8 + 10 * 4 + 2 * 16 + 8
     assert C.sizeof(_abi.KvqAttnDenseArgs) == 104
     assert C.sizeof(_abi.KvqGemmArgs) == 144

@@ -1153,3 +1153,110 @@ def test_conv_implicit_rejects_bad_shapes(half):
     x = dev(torch.zeros(1, 1, 4, 4, 12), half)           # C % 8 != 0
     with pytest.raises(_abi.KvqError, match="C % 8"):
         kernels.conv_implicit(x, dev(torch.zeros(8, 128), half), dev(torch.zeros(8)), (1, 3, 3), (1, 1, 1), (0, 1, 1), True)
+
+
+# ------------------------------------------------------------------------------- the fp16 residual stream of stages 0-1 (round 6, ABI 31)
+@pytest.mark.parametrize("C,dims,shift,nxt_shift,qkv", [(96, (8, 14, 14), (0, 0, 0), (4, 3, 3), False), (96, (8, 14, 7), (4, 3, 3), None, False),
+                                                        (192, (8, 14, 14), (0, 0, 0), (4, 3, 3), True), (192, (8, 7, 7), (0, 0, 0), None, False),
+                                                        (128, (8, 14, 7), (0, 0, 0), (4, 3, 0), True)])
+def test_block_tail_fp16_residual_stream(C, dims, shift, nxt_shift, qkv, half):
+    """``x_f16`` (C <= 192): the launch reads and writes the residual stream as fp16 rows.  Its arithmetic is the fp32-stream launch's on the
+    widened input: the result is that launch's result on fp32(fp16(x)) rounded ONCE to fp16 — bit for bit — and the emitted norm1 rows / next
+    q | k | v (computed from the un-rounded accumulators in both forms) are identical."""
+    g = rng(7 * C + sum(dims))
+    D, H, W = dims
+    B, hidden = 2, 4 * C
+    lay = O.window_layout(D, H, W, (8, 7, 7), shift)
+    Lp, L = lay["nW"] * lay["N"], D * H * W
+    t = lambda *s, sc=1.0: torch.from_numpy((g.standard_normal(s) * sc).astype(np.float32))      # noqa: E731
+    A = rnd(t(B * Lp, C), half)
+    x16 = t(B * L, C, sc=2.0).to(torch.float16)
+    x16[0, :4] = torch.tensor([70000.0, -70000.0, 65504.0, 1e-7]).to(torch.float16)               # inf, -inf (a saturated producer never writes them), max, a subnormal
+    x16[0, :2] = torch.tensor([60000.0, -60000.0]).to(torch.float16)
+    Wp, W1, W2 = rnd(t(C, C, sc=0.15), half), rnd(t(hidden, C, sc=0.15), half), rnd(t(C, hidden, sc=0.08), half)
+    bp, b1, b2, g2, b2n = t(C, sc=0.3), t(hidden, sc=0.3), t(C, sc=0.3), 1 + 0.2 * t(C), 0.2 * t(C)
+    pack = kernels.block_tail_pack(dev(Wp, half), dev(bp), dev(g2), dev(b2n), dev(W1, half), dev(b1), dev(W2, half), dev(b2))
+    kw = {}
+    if nxt_shift is not None:
+        lay2 = O.window_layout(D, H, W, (8, 7, 7), nxt_shift)
+        dst = np.empty(L, np.int32)
+        dst[lay2["src"]] = np.arange(L, dtype=np.int32)
+        kw = dict(next_norm=(dev(1 + 0.2 * t(C)), dev(0.2 * t(C))), next_dst=dev(torch.from_numpy(dst)), next_rows=L)
+        if qkv:
+            wq = rnd(t(3 * C, C, sc=0.1), half)
+            kw["next_qkv"] = (kernels.block_tail_qkv_pack(dev(wq, half), hidden), dev(t(3 * C, sc=0.2)), 0.25)
+    smap = dev(torch.from_numpy(lay["src"].astype(np.int32)))
+    x32 = dev(x16.float())
+    n32 = kernels.block_tail(dev(A, half), x32, pack, hidden, scatter_map=smap, map_rows=Lp, out_rows=L, **kw)
+    xh = dev(x16.clone())
+    n16 = kernels.block_tail(dev(A, half), xh, pack, hidden, scatter_map=smap, map_rows=Lp, out_rows=L, **kw)
+    assert xh.dtype == torch.float16 and torch.equal(xh, x32.clamp(-65504.0, 65504.0).to(torch.float16))
+    assert torch.isfinite(xh.float()).all()
+    if n32 is not None:
+        assert torch.equal(n16, n32)
+    with pytest.raises(_abi.KvqError, match="fp16 residual stream"):
+        kernels.block_tail(torch.zeros(64, 384, dtype=half, device=DEV), torch.zeros(64, 384, dtype=torch.float16, device=DEV),
+                           kernels.block_tail_pack(*[torch.zeros(s_, dtype=d_, device=DEV) for s_, d_ in
+                                                     (((384, 384), half), ((384,), torch.float32), ((384,), torch.float32), ((384,), torch.float32),
+                                                      ((1536, 384), half), ((1536,), torch.float32), ((384, 1536), half), ((384,), torch.float32))]), 1536)
+
+
+@pytest.mark.parametrize("C,dims,emit", [(96, (2, 4, 14, 14), True), (96, (1, 3, 5, 7), False), (192, (2, 8, 14, 14), True), (128, (1, 4, 8, 8), False)])
+def test_patch_merge_fp16_residual_stream(C, dims, emit, half):
+    """``x_f16`` / ``out_f16``: the merge launch on an fp16 stream equals the fp32-stream launch on the widened input (bit for bit: same
+    operands, same statistics), its fp16 output is that result rounded once; the emitted norm1 rows are identical."""
+    B, D, H, W = dims
+    g = rng(sum(dims) + 3 * C)
+    x16 = torch.from_numpy((g.standard_normal((B * D * H * W, C)) * 1.5).astype(np.float32)).to(torch.float16)
+    wts = (dev(torch.from_numpy((g.standard_normal((2 * C, 4 * C)) / np.sqrt(4 * C)).astype(np.float32))),
+           dev(torch.from_numpy((1 + 0.2 * g.standard_normal(4 * C)).astype(np.float32))), dev(torch.from_numpy((0.2 * g.standard_normal(4 * C)).astype(np.float32))))
+    mp, Hn, Wn = _merge_map(D, H, W)
+    Ln = D * Hn * Wn
+    kw = {}
+    if emit:
+        lay = O.window_layout(D, Hn, Wn, (8, 7, 7), (0, 0, 0))
+        assert not (lay["src"] < 0).any()
+        dst = np.empty(Ln, np.int32)
+        dst[lay["src"]] = np.arange(Ln, dtype=np.int32)
+        kw = dict(next_norm=(dev(torch.from_numpy((1 + 0.2 * g.standard_normal(2 * C)).astype(np.float32))),
+                             dev(torch.from_numpy((0.2 * g.standard_normal(2 * C)).astype(np.float32)))), next_dst=dev(torch.from_numpy(dst)), next_rows=Ln)
+    mpd = dev(torch.from_numpy(mp))
+    o32, n32 = kernels.patch_merge(dev(x16.float()), mpd, B, *wts, out_dtype=half, **kw)
+    o_in16, n_in16 = kernels.patch_merge(dev(x16), mpd, B, *wts, out_dtype=half, **kw)                      # fp16 in, fp32 out (stage 1 -> 2)
+    o16, n16 = kernels.patch_merge(dev(x16), mpd, B, *wts, out_dtype=half, out_f16=True, **kw)              # fp16 in, fp16 out (stage 0 -> 1)
+    assert o_in16.dtype == torch.float32 and torch.equal(o_in16, o32)
+    assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))
+    if emit:
+        assert torch.equal(n_in16, n32) and torch.equal(n16, n32)
+
+
+@pytest.mark.parametrize("frag", [False, True])
+def test_patch_embed_fp16_residual_stream(frag, half):
+    """``out_f16``: the embedding launch writes the stream as fp16 = its fp32 result rounded once; the norm1 rows are the same rows."""
+    g = rng(404)
+    E, B, T, Hc, Wc = 96, 2, 8, 64, 96
+    w = rnd(torch.from_numpy((g.standard_normal((E, 3 * 2 * 4 * 4)) * 0.1).astype(np.float32)), half)
+    b, lw, lb = (torch.from_numpy((g.standard_normal(E) * s_ + o_).astype(np.float32)) for s_, o_ in ((0.2, 0.0), (0.2, 1.0), (0.2, 0.0)))
+    if frag:
+        from kvq_amd.datasets import KVQ_MEAN, KVQ_STD
+        F, Hs, Ws = 2, 150, 200
+        vids = [torch.from_numpy(g.integers(0, 256, size=(3, T, Hs, Ws)).astype(np.uint8)).to(DEV) for _ in range(B)]
+        gh, gw = SO.fragment_grid(Hs, F, 32).reshape(F, 1, 1), SO.fragment_grid(Ws, F, 32).reshape(1, F, 1)
+        ho = [dev(torch.from_numpy(np.ascontiguousarray(g.integers(0, Hs // F - 32, size=(F, F, T // 8)) + gh, dtype=np.int32))) for _ in range(B)]
+        wo = [dev(torch.from_numpy(np.ascontiguousarray(g.integers(0, Ws // F - 32, size=(F, F, T // 8)) + gw, dtype=np.int32))) for _ in range(B)]
+        x = kernels.FragmentSource(vids, ho, wo, F, F, 32, 32, 8, mean=KVQ_MEAN, std=KVQ_STD)
+        Hc = Wc = 64
+    else:
+        x = dev(torch.from_numpy((g.standard_normal((B, 3, T, Hc, Wc)) * 1.5).astype(np.float32)))
+    D0, H0, W0 = T // 2, Hc // 4, Wc // 4
+    lay = O.window_layout(D0, H0, W0, (8, 7, 7), (0, 0, 0))
+    kw = {}
+    if not (lay["src"] < 0).any():
+        dst = np.empty(D0 * H0 * W0, np.int32)
+        dst[lay["src"]] = np.arange(D0 * H0 * W0, dtype=np.int32)
+        kw = dict(next_norm=(dev(lw), dev(lb)), next_dst=dev(torch.from_numpy(dst)), next_rows=D0 * H0 * W0)
+    o32, n32 = kernels.patch_embed(x, dev(w, half), dev(b), dev(lw), dev(lb), (2, 4, 4), **kw)
+    o16, n16 = kernels.patch_embed(x, dev(w, half), dev(b), dev(lw), dev(lb), (2, 4, 4), out_f16=True, **kw)
+    assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))
+    if n32 is not None:
+        assert torch.equal(n16, n32)

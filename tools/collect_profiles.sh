@@ -37,6 +37,7 @@ if [ -x tools/ubench/attn32_bench.bin ]; then
   (cd tools/ubench && ./attn32_run.sh attn32_bench.bin) > $out/attn32_standalone.txt 2>&1
   (cd tools/ubench && for g in "128 3 4 392 64 20 -1" "32 6 4 392 32 20 16" "8 12 4 392 4 20 -1" "2 24 4 392 2 20 1"; do ./attn32_bench.bin $g 0 8 | tail -1; done) > $out/attn32_cold.txt 2>&1
   [ -x tools/ubench/attn32_loop.bin ] && tools/ubench/attn32_loop.bin 50 > $out/attn32_loop.txt 2>&1
+  [ -x tools/ubench/attn32_loop_short.bin ] && (echo "-- the N = 385..392 form of the 13th key block (round 6, -DA32_LOOP_SHORT=1): per block of the 13, i.e. x 13 / 12.25 per USEFUL block" >> $out/attn32_loop.txt; tools/ubench/attn32_loop_short.bin 50 >> $out/attn32_loop.txt 2>&1)
   bash tools/ubench/attn32_pmc.sh attn32_bench.bin "128 3 4 392 64" $tag > /dev/null 2>&1; cp gpurun_out/attn_pmc_$tag.txt $out/attn32_pmc.txt 2>/dev/null
 fi
 for s in 0 1; do

@@ -4,6 +4,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#ifndef A32_LOOP_SHORT
+#define A32_LOOP_SHORT 0          // 1: the N = 385..392 form of the 13th key block (round 6)
+#endif
 #include "attn32.hip"
 
 namespace kvq {
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(256 * W) void loop_kernel(Attn32Params p, int iters
   const u32x4 pre[2] = {bd[0], bd[64]};
   uint16_t* orow = p.out + (size_t)tid * 64;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int it = 0; it < iters; ++it) a32_qblock<Fp16, 0, A32_KB>(smem, A32_SLOT >> 4, bd, qf0, qf1, pre, orow, do_store != 0);
+  for (int it = 0; it < iters; ++it) a32_qblock<Fp16, 0, A32_KB, A32_LOOP_SHORT != 0>(smem, A32_SLOT >> 4, bd, qf0, qf1, pre, orow, do_store != 0);
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long t1 = __builtin_readcyclecounter();
   if (lane == 0) cyc[tid >> 6] = t1 - t0;
