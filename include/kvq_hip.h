@@ -384,7 +384,7 @@ typedef struct {
   void* qkv_out;               /* 16-bit; non-NULL selects this form                                         */
   float q_scale;
   int32_t num_heads;
-  int32_t x_f16;               /* ABI 31: x is the residual stream kept in fp16 (C <= 192 only): rows of 2 C bytes, read and written in place */
+  int32_t x_f16;               /* ABI 31: x is the residual stream kept in fp16: rows of 2 C bytes, read and written in place            */
 } KvqBlockTailArgs;
 /* Padded window partitions (Swin-B at 256x256, KSVQE at 288x288): the q|k|v of a PADDING row is qkv(0) = bias (the reference pads after
  * norm1, swin_backbone.py:416-449) and takes part in the softmax of its window as a key.  Instead of multiplying zero rows, the qkv

@@ -196,6 +196,10 @@ struct LdsOptIn {
 // rounding points that differ between a fused tail and the GEMM chain; each choice also has its own knob.
 bool latency_mode();
 
+// csrc/ln.hip: kvq_layernorm_rows on an fp32 (x_f16 = 0) or fp16 residual stream
+int layernorm_rows_stream(const float* x, int x_f16, const int32_t* map, int nparts, int n_batch, int rows_in, int rows_out, int Cin,
+                          const float* gamma, const float* beta, float eps, uint16_t* out_h, int dtype, float* out_f32, void* stream);
+
 // shape limits of the fused fast-pathway stem (conv.hip::kvq_conv_stem_pool), pointer alignment aside
 bool stem_pool_shape_ok(int B, int T, int H, int W, int kd);
 

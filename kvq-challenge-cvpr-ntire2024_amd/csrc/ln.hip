@@ -23,6 +23,7 @@ struct LnParams {
   float eps;
   uint16_t* out_h;
   float* out_f32;
+  int x16;          // round 6: x is an fp16 residual stream (rows of 2 Cin bytes behind the same pointer)
 };
 
 template <typename E, int G, int NV, int R>  // G lanes per row, NV float4 per lane (NV*G*4 >= C), R rows per group
@@ -49,9 +50,22 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnParams p) {
       if (c < C && !all_pad[j]) {
         const int part = c / p.Cin, cc = c - part * p.Cin;   // Cin % 4 == 0: a float4 never straddles parts
         const int s = p.map ? p.map[r * p.nparts + part] : r;
-        if (s >= 0) v[j][i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)b * p.rows_in + s) * p.Cin + cc);
+        if (s >= 0 && p.x16) {      // 8 bytes, kept RAW in the first two registers (widened below: a conversion here would wait for the load)
+          const uint64_t u = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(p.x) + ((size_t)b * p.rows_in + s) * p.Cin + cc);
+          v[j][i][0] = __uint_as_float((uint32_t)u); v[j][i][1] = __uint_as_float((uint32_t)(u >> 32));
+        } else if (s >= 0) v[j][i] = *reinterpret_cast<const f32x4*>(p.x + ((size_t)b * p.rows_in + s) * p.Cin + cc);
       }
     }
+  }
+  if (p.x16) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const f16x4_t hv = __builtin_bit_cast(f16x4_t, (uint64_t)__float_as_uint(v[j][i][0]) | ((uint64_t)__float_as_uint(v[j][i][1]) << 32));
+        v[j][i] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};      // (zero rows: raw 0 -> 0.0)
+      }
   }
   // gamma / beta of this lane's columns: requested with the rows (one latency, not one more behind the statistics), kept for all R rows
   constexpr bool HOIST = NV <= 3;      // (NV = 6, the 1536-wide merge rows: 48 more registers cost occupancy — 19.6 -> 35.6 us)
@@ -136,6 +150,13 @@ static int launch_ln(const LnParams& p, int dtype, hipStream_t st) {
 extern "C" int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts, int n_batch, int rows_in,
                                   int rows_out, int Cin, const float* gamma, const float* beta, float eps,
                                   uint16_t* out_h, int dtype, float* out_f32, void* stream) {
+  return kvq::layernorm_rows_stream(x, 0, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_h, dtype, out_f32, stream);
+}
+
+// x_f16 != 0 (csrc/plan.hip only): x is an fp16 residual stream
+int kvq::layernorm_rows_stream(const float* x, int x_f16, const int32_t* map, int nparts, int n_batch, int rows_in,
+                               int rows_out, int Cin, const float* gamma, const float* beta, float eps,
+                               uint16_t* out_h, int dtype, float* out_f32, void* stream) {
   using namespace kvq;
   KVQ_REQUIRE(x && gamma && beta, KVQ_ERR_NULL, "kvq_layernorm_rows: NULL input");
   KVQ_REQUIRE((out_h != nullptr) != (out_f32 != nullptr), KVQ_ERR_NULL,
@@ -147,7 +168,7 @@ extern "C" int kvq_layernorm_rows(const float* x, const int32_t* map, int nparts
   KVQ_REQUIRE(map || (nparts == 1 && rows_in == rows_out), KVQ_ERR_SHAPE,
               "kvq_layernorm_rows: identity map needs nparts==1 and rows_in==rows_out");
   const int C = nparts * Cin;
-  LnParams p{x, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_h, out_f32};
+  LnParams p{x, map, nparts, n_batch, rows_in, rows_out, Cin, gamma, beta, eps, out_h, out_f32, x_f16};
   hipStream_t st = (hipStream_t)stream;
   const int nvec = C / 4;
   // widths of the form 3 * 2^k (C = 96, 192, 384, 768, 1536) split exactly into G lanes x 3 (x 6) float4: no idle lanes

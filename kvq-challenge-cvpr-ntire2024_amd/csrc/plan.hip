@@ -411,11 +411,11 @@ static int gemm(KvqSwinPlan* pl, hipStream_t st, int kind, const uint16_t* A, co
 }
 
 static int ln(KvqSwinPlan* pl, hipStream_t st, const float* x, const int32_t* map, int nparts, int rows_in,
-              int rows_out, int Cin, const float* g, const float* b, uint16_t* obf, float* of32) {
+              int rows_out, int Cin, const float* g, const float* b, uint16_t* obf, float* of32, bool x16 = false) {
   const double elems = (double)pl->B * rows_out * nparts * Cin;
   if (skip_mask() & 16) return KVQ_OK;
-  Bracket br(pl, st, KVQ_K_LAYERNORM, of32 ? 1 : 0, 0.0, elems * (4.0 + (of32 ? 4.0 : 2.0)));
-  return kvq_layernorm_rows(x, map, nparts, pl->B, rows_in, rows_out, Cin, g, b, 1e-5f, obf, pl->dtype, of32, st);
+  Bracket br(pl, st, KVQ_K_LAYERNORM, of32 ? 1 : 0, 0.0, elems * ((x16 ? 2.0 : 4.0) + (of32 ? 4.0 : 2.0)));
+  return layernorm_rows_stream(x, x16 ? 1 : 0, map, nparts, pl->B, rows_in, rows_out, Cin, g, b, 1e-5f, obf, pl->dtype, of32, st);
 }
 
 }  // namespace kvq
@@ -485,10 +485,12 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   // consumer of a stage's stream is one of the token-per-lane launches (embedding / fused merge -> fused tails -> fused merge) the stream
   // lives in fp16 — 2.9e-6 on the score of a 32 x 224 x 224 clip in an fp32 emulation, two orders below the 16-bit MFMA operands' own
   // 3.6e-4 (tools/diag/resid16_probe.py): the stream carries 11 bits where every GEMM input is rounded to 8 or 11 anyway.  Decided by
-  // geometry and weights only (never by the batch); whole-trunk forwards only (taps / stage-split forwards / `io` keep fp32);
-  // the last stage and the C >= 256 stages keep fp32 (tailmm, the LayerNorm launches and the GEMM epilogues read and write fp32).
+  // geometry and weights only (never by the batch); whole-trunk forwards only (taps / stage-split forwards / `io` keep fp32).
+  // Consumers that take an fp16 stream: the fused tails of every width, the fused merge, the gather-LayerNorm of an un-fused merge;
+  // the last stage keeps fp32 (its stream comes out of a GEMM epilogue and feeds the final LayerNorm and the fp32 feature output).
   // KVQ_RESID16=0: fp32 everywhere (rounds 1-5).
   static const bool resid16_on = !(getenv("KVQ_RESID16") && atoi(getenv("KVQ_RESID16")) == 0);
+  static const int resid16_maxc = getenv("KVQ_RESID16_MAXC") ? atoi(getenv("KVQ_RESID16_MAXC")) : 1 << 30;      // 192: the token-per-lane stages only (A/B)
   static const int tail_maxc_x = getenv("KVQ_TAIL_MAXC") ? atoi(getenv("KVQ_TAIL_MAXC")) : 1 << 30;
   static const int merge_maxc_x = getenv("KVQ_MERGE_MAXC") ? atoi(getenv("KVQ_MERGE_MAXC")) : 192;
   bool any_tap = false;
@@ -502,7 +504,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     int blk0 = 0;
     for (int i = 0; i < cfg.num_stages - 1; blk0 += pl->st[i].depth, ++i) {
       const StageGeom& g = pl->st[i];
-      bool ok = g.C <= 192 && g.C <= tail_maxc_x && g.Lp == g.L && g.d_dst[0] && fused_merge(i) && (i == 0 ? embed_fused : fused_merge(i - 1));
+      bool ok = g.C <= tail_maxc_x && g.C <= resid16_maxc && g.Lp == g.L && g.d_dst[0] && (i == 0 ? embed_fused : fused_merge(i - 1));      // the producer writes fp16
       for (int b = 0; ok && b < g.depth; ++b) {
         const KvqSwinBlockW& bw = w->blocks[blk0 + b];
         const int par = (b & 1) && g.shifted_any ? 1 : 0;
@@ -732,8 +734,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         KVQ_TRY_UNLESS(128, kvq_patch_merge(&ma, st));
         x16_cur = x16[i + 1];
       } else {
-        KVQ_TRY(f32_only("the un-fused PatchMerging"));
-        KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr));
+        KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr, x16_cur));
+        x16_cur = false;                                       // the reduction GEMM writes the next stage's stream as fp32
         KVQ_TRY_UNLESS(128, gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
                      oth));
       }

@@ -755,7 +755,6 @@ extern "C" int kvq_block_tail(const KvqBlockTailArgs* a, void* stream) {
               "kvq_block_tail: next_ln without its norm / map");
   KVQ_REQUIRE(a->dtype == KVQ_DT_BF16 || a->dtype == KVQ_DT_FP16, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: dtype %d", a->dtype);
   TailParams p{};
-  KVQ_REQUIRE(!a->x_f16 || a->C <= 192, KVQ_ERR_UNSUPPORTED, "kvq_block_tail: the fp16 residual stream is built for C <= 192 (C=%d)", a->C);
   p.attn = (const uint16_t*)a->attn; p.x = a->x; p.x16 = a->x_f16; p.map = a->scatter_map; p.map_rows = a->map_rows; p.out_rows = a->out_rows;
   p.M = a->M; p.hidden = a->hidden; p.pack = (const unsigned char*)a->pack;
   p.nn_w = a->next_norm_w; p.nn_b = a->next_norm_b; p.next_dst = a->next_dst; p.next_ln = (uint16_t*)a->next_ln;

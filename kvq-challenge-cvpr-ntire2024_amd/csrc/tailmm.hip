@@ -336,18 +336,42 @@ __global__ __launch_bounds__(256, (MMc<CF, HC, TT>::REG_WAVES)) void block_tailm
   f32x16 acc[CF][TT];
   {
     f32x4 xv[CF][4][TT];
+    if (p.x16) {      // fp16 residual stream (round 6): 8 bytes per piece, raw in the first two registers until everything has landed
 #pragma unroll
-    for (int ft = 0; ft < CF; ++ft)
+      for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-          xv[ft][q][tt] = *reinterpret_cast<const f32x4*>(p.x + (size_t)orig[tt] * C + FW * wave + 32 * ft + 8 * q + 4 * half);
+          for (int tt = 0; tt < TT; ++tt) {
+            const uint64_t u = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(p.x) + (size_t)orig[tt] * C + FW * wave + 32 * ft + 8 * q + 4 * half);
+            xv[ft][q][tt][0] = __uint_as_float((uint32_t)u); xv[ft][q][tt][1] = __uint_as_float((uint32_t)(u >> 32));
+          }
+    } else {
+#pragma unroll
+      for (int ft = 0; ft < CF; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+            xv[ft][q][tt] = *reinterpret_cast<const f32x4*>(p.x + (size_t)orig[tt] * C + FW * wave + 32 * ft + 8 * q + 4 * half);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // everything requested so far has landed (the row loads were issued last: vmcnt(0) covers the DMA before them too)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     MM_STAMP(1);
+    if (p.x16) {
+      typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+#pragma unroll
+      for (int ft = 0; ft < CF; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            const f16x4_t hv = __builtin_bit_cast(f16x4_t, (uint64_t)__float_as_uint(xv[ft][q][tt][0]) | ((uint64_t)__float_as_uint(xv[ft][q][tt][1]) << 32));
+            xv[ft][q][tt] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+          }
+    }
 #pragma unroll
     for (int ft = 0; ft < CF; ++ft)
 #pragma unroll
@@ -561,6 +585,18 @@ __global__ __launch_bounds__(256, (MMc<CF, HC, TT>::REG_WAVES)) void block_tailm
 
   MM_STAMP(3);
   // ---- write the residual stream back; optionally the next block's norm1 rows in ITS window order ----------------------
+  if (p.x16) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      if (live[tt]) {
+        uint16_t* xr = reinterpret_cast<uint16_t*>(p.x) + (size_t)orig[tt] * C + FW * wave + 4 * half;
+#pragma unroll
+        for (int ft = 0; ft < CF; ++ft)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<u32x2*>(xr + 32 * ft + 8 * q) = (u32x2){Fp16::pack2(acc[ft][tt][4 * q], acc[ft][tt][4 * q + 1]), Fp16::pack2(acc[ft][tt][4 * q + 2], acc[ft][tt][4 * q + 3])};
+      }
+  } else
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
     if (live[tt]) {

@@ -547,7 +547,7 @@ def test_resize_trilinear_cl_matches_interpolate():
 
 def test_forward_stages_equals_whole_forward(golden):
     """The trunk run stage by stage through ``forward_stages`` (the stream leaves and re-enters the library between the
-    calls, as KSVQE's modulation needs) gives the whole forward's feature map bit for bit, and the taps' streams."""
+    calls, as KSVQE's modulation needs) gives the whole forward's feature map (to the fp16 residual stream's roundings), and the taps' streams bit for bit."""
     t = golden("trunk.npz")
     case = "t_grpb_stress_8x80"
     wseed, cseed, B, T, H, W = (int(v) for v in t[f"{case}/meta"])
@@ -562,7 +562,9 @@ def test_forward_stages_equals_whole_forward(golden):
         s = bb.forward_stages(s, 2, 2, geometry=(T, H, W))
         s, feat = bb.forward_stages(s, 3, 3, geometry=(T, H, W), want_feat=True)
         allin, feat2 = bb.forward_stages(x, 0, 3, want_feat=True)
-    assert torch.equal(feat2, whole)
+    # (round 6: the whole forward keeps the residual stream of its fused stages in fp16, a stage-split call hands the stream over in fp32 and
+    # keeps it fp32 — the two differ by the stream's 11-bit roundings, 3e-6 on a score; KVQ_RESID16=0 makes them bit-equal again)
+    assert (feat2 - whole).abs().max().item() <= 2e-3 * whole.abs().max().item()
     # entering at a stage whose first norm1 the whole forward takes from the fused PatchMerging launch (C = 96 / 128 / 192, csrc/merge.hip:
     # two-pass statistics in the lane pair) recomputes it with the LayerNorm launch (the caller may have changed the stream in between):
     # the same fp32 arithmetic in another summation order -> the last bits of the 16-bit rows, not more

@@ -1158,9 +1158,11 @@ def test_conv_implicit_rejects_bad_shapes(half):
 # ------------------------------------------------------------------------------- the fp16 residual stream of stages 0-1 (round 6, ABI 31)
 @pytest.mark.parametrize("C,dims,shift,nxt_shift,qkv", [(96, (8, 14, 14), (0, 0, 0), (4, 3, 3), False), (96, (8, 14, 7), (4, 3, 3), None, False),
                                                         (192, (8, 14, 14), (0, 0, 0), (4, 3, 3), True), (192, (8, 7, 7), (0, 0, 0), None, False),
-                                                        (128, (8, 14, 7), (0, 0, 0), (4, 3, 0), True)])
+                                                        (128, (8, 14, 7), (0, 0, 0), (4, 3, 0), True),
+                                                        (384, (8, 14, 14), (0, 0, 0), (4, 3, 3), True), (384, (8, 7, 7), (4, 3, 3), None, False),      # csrc/tailmm.hip
+                                                        (256, (8, 14, 7), (0, 0, 0), (4, 3, 0), True), (768, (8, 7, 7), (0, 0, 0), (0, 0, 0), True)])
 def test_block_tail_fp16_residual_stream(C, dims, shift, nxt_shift, qkv, half):
-    """``x_f16`` (C <= 192): the launch reads and writes the residual stream as fp16 rows.  Its arithmetic is the fp32-stream launch's on the
+    """``x_f16``: the launch reads and writes the residual stream as fp16 rows (token-per-lane tails and the wide feature-sliced ones).  Its arithmetic is the fp32-stream launch's on the
     widened input: the result is that launch's result on fp32(fp16(x)) rounded ONCE to fp16 — bit for bit — and the emitted norm1 rows / next
     q | k | v (computed from the un-rounded accumulators in both forms) are identical."""
     g = rng(7 * C + sum(dims))
@@ -1194,11 +1196,6 @@ def test_block_tail_fp16_residual_stream(C, dims, shift, nxt_shift, qkv, half):
     assert torch.isfinite(xh.float()).all()
     if n32 is not None:
         assert torch.equal(n16, n32)
-    with pytest.raises(_abi.KvqError, match="fp16 residual stream"):
-        kernels.block_tail(torch.zeros(64, 384, dtype=half, device=DEV), torch.zeros(64, 384, dtype=torch.float16, device=DEV),
-                           kernels.block_tail_pack(*[torch.zeros(s_, dtype=d_, device=DEV) for s_, d_ in
-                                                     (((384, 384), half), ((384,), torch.float32), ((384,), torch.float32), ((384,), torch.float32),
-                                                      ((1536, 384), half), ((1536,), torch.float32), ((384, 1536), half), ((384,), torch.float32))]), 1536)
 
 
 @pytest.mark.parametrize("C,dims,emit", [(96, (2, 4, 14, 14), True), (96, (1, 3, 5, 7), False), (192, (2, 8, 14, 14), True), (128, (1, 4, 8, 8), False)])
