@@ -486,7 +486,8 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   // lives in fp16 — 2.9e-6 on the score of a 32 x 224 x 224 clip in an fp32 emulation, two orders below the 16-bit MFMA operands' own
   // 3.6e-4 (tools/diag/resid16_probe.py): the stream carries 11 bits where every GEMM input is rounded to 8 or 11 anyway.  Decided by
   // geometry and weights only (never by the batch); whole-trunk forwards only (taps / stage-split forwards / `io` keep fp32).
-  // Consumers that take an fp16 stream: the fused tails of every width, the fused merge, the gather-LayerNorm of an un-fused merge;
+  // Consumers that take an fp16 stream: the fused tails of every width (padded partitions too), the fused merge, every LayerNorm launch
+  // (a first block's norm1, the gather-LayerNorm of an un-fused merge);
   // the last stage keeps fp32 (its stream comes out of a GEMM epilogue and feeds the final LayerNorm and the fp32 feature output).
   // KVQ_RESID16=0: fp32 everywhere (rounds 1-5).
   static const bool resid16_on = !(getenv("KVQ_RESID16") && atoi(getenv("KVQ_RESID16")) == 0);
@@ -504,7 +505,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     int blk0 = 0;
     for (int i = 0; i < cfg.num_stages - 1; blk0 += pl->st[i].depth, ++i) {
       const StageGeom& g = pl->st[i];
-      bool ok = g.C <= tail_maxc_x && g.C <= resid16_maxc && g.Lp == g.L && g.d_dst[0] && (i == 0 ? embed_fused : fused_merge(i - 1));      // the producer writes fp16
+      bool ok = g.C <= tail_maxc_x && g.C <= resid16_maxc && (i == 0 ? embed_fused : fused_merge(i - 1));      // the producer writes fp16
       for (int b = 0; ok && b < g.depth; ++b) {
         const KvqSwinBlockW& bw = w->blocks[blk0 + b];
         const int par = (b & 1) && g.shifted_any ? 1 : 0;
@@ -599,10 +600,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
       } else if (g.Lp != g.L && bw.qkv_b) {
         // padded partition: norm1 in TOKEN order (written by the previous block's tail when there is one), qkv over the tokens only
         // (rows scattered to their window rows by the epilogue); the padding rows' q | k | v = qkv(0) = bias
-        if (!ln1_ready) {
-          KVQ_TRY(f32_only("the norm1 launch of a padded partition"));
-          KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
-        }
+        if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, nullptr, 1, g.L, g.L, C, bw.norm1_w, bw.norm1_b, bln, nullptr, x16_cur));
         KVQ_TRY(gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, ML, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH,
                      qs, g.d_dst[par], g.L, g.Lp));
         // the padding rows' q | k | v = qkv(0) = bias: attention32 writes them into its own K | V images (pad_mask); the gather path
@@ -610,10 +608,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         if (!(bw.bias_dense && g.d_padmask[par]))
           KVQ_TRY(kvq_qkv_fill_pad(bbig, bw.qkv_b, g.d_pad[par], g.Lp - g.L, B, g.Lp, g.nH, qs, pl->dtype, st));
       } else if (!qkv_ready) {
-        if (!ln1_ready) {
-          KVQ_TRY(f32_only("the norm1 launch"));
-          KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr));
-        }
+        if (!ln1_ready) KVQ_TRY(ln(pl, st, cur, g.d_src[par], 1, g.L, g.Lp, C, bw.norm1_w, bw.norm1_b, bln, nullptr, x16_cur));
         if (!fuse_qkv)
           KVQ_TRY_UNLESS(8 | (i == cfg.num_stages - 1 ? 32 : 0), gemm(pl, st, KVQ_K_GEMM_QKV, bln, bw.qkv_w, bw.qkv_b, M, 3 * C, C, KVQ_EPI_QKV_BF16, bbig, nullptr, g.nH, qs));
       }
