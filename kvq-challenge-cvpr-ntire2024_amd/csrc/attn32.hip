@@ -44,6 +44,13 @@
 #define A32_EXP(x) __builtin_amdgcn_exp2f(x)
 #endif
 
+// timing probes of -DKVQ_DIAG builds (garbage scores; profiles/r06_traffic_probes.txt): compiled out of the product library
+#ifdef KVQ_DIAG
+#define A32_DIAG_FLAG(x) (x)
+#else
+#define A32_DIAG_FLAG(x) false
+#endif
+
 namespace kvq {
 
 constexpr int A32_KB = 13;                         // 32-key blocks: 416 key positions (N <= 400 supported, 392 used)
@@ -318,6 +325,8 @@ struct Attn32Params {
   float q_scale;               // head_dim^-0.5 * log2(e)
   uint16_t* q_out;             // = the q third of qkv
   const uint32_t* pad_mask;    // optional [nW][13]: bit r & 31 of word r >> 5 = window row r is a padding row (k | v = b_qkv's thirds, q = 0)
+  bool no_q_store;             // -DKVQ_DIAG timing probe (KVQ_NO_Q_STORE=1): the fused projection does not write q (garbage scores: the q scratch's write-back gone)
+  bool image_one;              // -DKVQ_DIAG timing probe (KVQ_IMAGE_ONE_TYPE=1): every window reads the images of type 0 — garbage scores, the images' traffic gone
   bool coop_ok;                // no launch of this process splits a unit over workgroups (qsplit_max == 1): the co-operative last q-block may be chosen
 };
 
@@ -374,7 +383,7 @@ __device__ __forceinline__ void a32_fused_qkv(const Attn32Params& p, unsigned ch
                        E::pack2((acc[2] + bias[c][2]) * sc, (acc[3] + bias[c][3]) * sc)};
       if (row < N) {
         if (which == 0) {
-          *reinterpret_cast<u32x2*>(qo + (size_t)row * 32 + half * 16 + 4 * g) = v;
+          if (!A32_DIAG_FLAG(p.no_q_store)) *reinterpret_cast<u32x2*>(qo + (size_t)row * 32 + half * 16 + 4 * g) = v;
         } else if (which == 1) {                                   // features 16 half + 4g ..: chunk 2 half + (g >> 1), 8 bytes into it
           *reinterpret_cast<u32x2*>(slot + row * 64 + (((2 * half + (g >> 1)) ^ ((row >> 2) & 3)) << 4) + (g & 1) * 8) = v;
         } else {
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) __attribute__((amdgpu_wav
     } while (t_ < n_tickets && ((skip >> (2 * qb_)) & 1u) && (((skip >> (2 * qb_ + 1)) & 1u) || 32 * qb_ + 16 >= N));
     return t_;
   };
-  const u32x4* img = p.image + (size_t)pair * nqb * (A32_KB * 128) + lane;
+  const u32x4* img = p.image + (size_t)(A32_DIAG_FLAG(p.image_one) ? h : pair) * nqb * (A32_KB * 128) + lane;
   // the ticket, the q fragments and the first bias tile of the NEXT q-block are requested while this one is computed
   struct Req { V8 qf0, qf1; u32x4 pre[2]; };
   auto request = [&](int t_, Req& r) __attribute__((always_inline)) {
@@ -748,6 +757,10 @@ extern "C" int kvq_window_attention32(const KvqAttnDenseArgs* a, void* stream) {
   qsplit = qsplit > nqb ? nqb : qsplit;
   Attn32Params p{a->qkv, (const u32x4*)a->bias_dense, BW, nW, N, num_heads, n_types, qsplit, a->out, a->tile_skip,
                      a->dsplit_from < 0 ? -1 : a->dsplit_from};
+#ifdef KVQ_DIAG
+  { static const bool one = getenv("KVQ_IMAGE_ONE_TYPE") && atoi(getenv("KVQ_IMAGE_ONE_TYPE")) == 1; p.image_one = one; }
+  { static const bool nq = getenv("KVQ_NO_Q_STORE") && atoi(getenv("KVQ_NO_Q_STORE")) == 1; p.no_q_store = nq; }
+#endif
   p.coop_ok = qsplit_max == 1;       // (a q-split that follows the batch would make the form, hence a window's rounding, follow the batch)
   if (a->pad_mask) {
     KVQ_REQUIRE(a->b_qkv && !a->x_ln, KVQ_ERR_NULL, "kvq_window_attention32: pad_mask needs b_qkv (and excludes the fused projection)");
