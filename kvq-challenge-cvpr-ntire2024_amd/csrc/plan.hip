@@ -485,7 +485,7 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   // consumer of a stage's stream is one of the token-per-lane launches (embedding / fused merge -> fused tails -> fused merge) the stream
   // lives in fp16 — 2.9e-6 on the score of a 32 x 224 x 224 clip in an fp32 emulation, two orders below the 16-bit MFMA operands' own
   // 3.6e-4 (tools/diag/resid16_probe.py): the stream carries 11 bits where every GEMM input is rounded to 8 or 11 anyway.  Decided by
-  // geometry and weights only (never by the batch); whole-trunk forwards only (taps / stage-split forwards / `io` keep fp32).
+  // geometry and weights only (never by the batch); forwards with feature taps keep fp32; a stage-split forward enters and leaves in fp32.
   // Consumers that take an fp16 stream: the fused tails of every width (padded partitions too), the fused merge, every LayerNorm launch
   // (a first block's norm1, the gather-LayerNorm of an un-fused merge);
   // the last stage keeps fp32 (its stream comes out of a GEMM epilogue and feeds the final LayerNorm and the fp32 feature output).
@@ -501,11 +501,15 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
   };
   const bool embed_fused = w->embed_pack && kvq_patch_embed_supported(cfg.in_chans, cfg.patch[0], cfg.patch[1], cfg.patch[2], cfg.embed_dim, pl->T, pl->H, pl->W);
   bool x16[KVQ_MAX_STAGES] = {false, false, false, false};
-  if (resid16_on && stage_lo == 0 && stage_hi == cfg.num_stages - 1 && !io && !any_tap) {
+  if (resid16_on && !any_tap) {
+    // a stage-split call (KSVQE: stages 0-1, modulation, stage 2, modulation, stage 3) takes its entry stream from `io` in fp32 and hands the
+    // stream behind its last merge back in fp32: the stages strictly inside the call follow the same rule as in a whole forward
     int blk0 = 0;
-    for (int i = 0; i < cfg.num_stages - 1; blk0 += pl->st[i].depth, ++i) {
+    for (int i = 0; i < cfg.num_stages - 1 && i <= stage_hi; blk0 += pl->st[i].depth, ++i) {
+      if (i < stage_lo) continue;
       const StageGeom& g = pl->st[i];
-      bool ok = g.C <= tail_maxc_x && g.C <= resid16_maxc && (i == 0 ? embed_fused : fused_merge(i - 1));      // the producer writes fp16
+      const bool produced16 = i == 0 ? (stage_lo == 0 && embed_fused) : (i > stage_lo && fused_merge(i - 1));      // the producer writes fp16
+      bool ok = g.C <= tail_maxc_x && g.C <= resid16_maxc && produced16;
       for (int b = 0; ok && b < g.depth; ++b) {
         const KvqSwinBlockW& bw = w->blocks[blk0 + b];
         const int par = (b & 1) && g.shifted_any ? 1 : 0;

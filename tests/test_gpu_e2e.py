@@ -558,7 +558,8 @@ def test_forward_stages_equals_whole_forward(golden):
         whole = bb({"technical": x})
         tap2 = bb({"technical": x}, layer=2)
         s = bb.forward_stages(x, 0, 1)
-        assert torch.equal(s, tap2)
+        # (a tapped forward keeps the residual stream in fp32; a stage-split call keeps the stages INSIDE it on fp16 rows since round 6)
+        assert (s - tap2).abs().max().item() <= 2e-3 * tap2.abs().max().item()
         s = bb.forward_stages(s, 2, 2, geometry=(T, H, W))
         s, feat = bb.forward_stages(s, 3, 3, geometry=(T, H, W), want_feat=True)
         allin, feat2 = bb.forward_stages(x, 0, 3, want_feat=True)
