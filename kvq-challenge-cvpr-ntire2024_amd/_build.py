@@ -33,8 +33,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm's hipcc to build libkvq_hip.so)")
 
 
+# sources compiled several times with -D<macro>=<part> (their instantiations split over translation units: tailmm.hip's 42 kernels take ~5
+# minutes in one unit, ~1.5 in four)
+PARTS = {"tailmm.hip": ("KVQ_TAILMM_PART", 4)}
+
+
 def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def units():
+    """(source path, object file name, extra flags) of every translation unit"""
+    out = []
+    for src in sources():
+        base = os.path.basename(src)
+        if base in PARTS:
+            macro, n = PARTS[base]
+            out += [(src, f"{base}.p{k}.o", [f"-D{macro}={k}"]) for k in range(n)]
+        else:
+            out.append((src, base + ".o", []))
+    return out
 
 
 def is_stale() -> bool:
@@ -46,8 +64,8 @@ def is_stale() -> bool:
         return True
     # a source edited WHILE a build ran is newer than its object yet older than the library that build linked: the objects are checked too
     objdir = os.path.join(PKG, f"build_{TAG}" if TAG else "build")
-    for src in sources():
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+    for src, oname, _ in units():
+        obj = os.path.join(objdir, oname)
         if os.path.exists(obj) and os.path.getmtime(src) > os.path.getmtime(obj):
             return True
     return False
@@ -82,14 +100,15 @@ def _build_locked(force: bool, verbose: bool, objdir: str) -> str:
                 f.write(" ".join(extra_flags))
         extra_flags = open(fpath).read().split()
 
-    def compile_one(src):
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+    def compile_one(unit):
+        src, oname, uflags = unit
+        obj = os.path.join(objdir, oname)
         hdrs = [HEADER] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
         if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj
         tmp = f"{obj}.{os.getpid()}.tmp"          # never leave a half-written object under the final name
-        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), []) + extra_flags
+        cmd = ([cc] + FLAGS + EXTRA.get(os.path.basename(src), []) + uflags + extra_flags
                + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", tmp])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -101,8 +120,9 @@ def _build_locked(force: bool, verbose: bool, objdir: str) -> str:
         os.replace(tmp, obj)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(sources()))) as ex:
-        objs = list(ex.map(compile_one, sources()))
+    todo = units()
+    with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+        objs = list(ex.map(compile_one, todo))
     tmp = f"{LIB}.{os.getpid()}.tmp"
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp],
                        capture_output=True, text=True)

@@ -30,6 +30,15 @@
 #include "common.hpp"
 #include "tail.hpp"
 
+// The 42 instantiations of the kernel take ~5 minutes in one translation unit: the build (_build.py) compiles this file FOUR times with
+// -DKVQ_TAILMM_PART=0..3 — part 0 holds the host side (packing, dispatch) and the C = 384 product form, parts 1-3 the other forms —
+// and links the four objects; without the macro (study builds, a plain `hipcc -c`) everything is one unit.
+#ifdef KVQ_TAILMM_PART
+#define MM_PART_HERE(k) (KVQ_TAILMM_PART == (k))
+#else
+#define MM_PART_HERE(k) 1
+#endif
+
 #ifndef MM_ABL
 #define MM_ABL 0            // study builds (tools/tailmm_variant.sh), bit mask: 1 no activation-fragment LDS reads past a phase's first body,
 #endif                      // 2 no weight stream past the first ring fill, 8 GELU replaced by a pack, 16 fc1's MFMAs skipped, 32 fc2's MFMAs skipped
@@ -81,6 +90,7 @@ struct MMc {
   static_assert(LDS <= 163840, "LDS");
 };
 
+#if MM_PART_HERE(0)
 // KVQ_TAILMM_HC=256 takes rounds 2-4's one-workgroup-per-CU form at C = 384 (A/B runs); read once — the packed image and the launch
 // must agree.  C = 512 (Swin-B stage 2, the C5 line) takes HC = 128 too: 2 x 97 KB of LDS do not fit, so it is still one workgroup of
 // this launch per CU, but at 256 registers and no spills (HC = 256 at C = 512: 512 registers, 8 / 17 / 115 spilled by MODE) a workgroup
@@ -228,6 +238,8 @@ int tailmm_qkv_pack(const uint16_t* qkv_w, int C, int hidden, unsigned char* out
   KVQ_CHECK_LAUNCH("tailmm_qkv_pack_kernel");
   return KVQ_OK;
 }
+
+#endif  // MM_PART_HERE(0)
 
 // The weight stream: a wave's weight fragments are PRIVATE to it, and plain VGPR loads stream as fast as LDS-DMA
 // (tools/ubench/l2_stream.hip), so the fragments go global -> VGPR and are the MFMA A operand as they arrive: a REGISTER ring of
@@ -715,6 +727,29 @@ static int launch_mm_cf(const TailParams& p, hipStream_t st) {
   return KVQ_OK;
 }
 
+// the forms, grouped by translation unit (see the top of the file)
+int tailmm_launch_part0(int form, const TailParams& p, int dtype, hipStream_t st);
+int tailmm_launch_part1(int form, const TailParams& p, int dtype, hipStream_t st);
+int tailmm_launch_part2(int form, const TailParams& p, int dtype, hipStream_t st);
+int tailmm_launch_part3(int form, const TailParams& p, int dtype, hipStream_t st);
+enum { MM_F_C512_H128, MM_F_C512_H256, MM_F_C768, MM_F_C256, MM_F_C384_T128, MM_F_C384_H128, MM_F_C384_H256 };
+#define MM_GO(CF, HC, TT) (dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, CF, HC, TT>(p, st) : launch_mm_cf<Bf16, CF, HC, TT>(p, st))
+#ifndef KVQ_TAILMM_FOCUS
+#if MM_PART_HERE(0)
+int tailmm_launch_part0(int form, const TailParams& p, int dtype, hipStream_t st) { return MM_GO(3, 128, 2); }                                 // C = 384: the C2 line's form
+#endif
+#if MM_PART_HERE(1)
+int tailmm_launch_part1(int form, const TailParams& p, int dtype, hipStream_t st) { return form == MM_F_C384_H256 ? MM_GO(3, 256, 2) : MM_GO(2, 256, 2); }
+#endif
+#if MM_PART_HERE(2)
+int tailmm_launch_part2(int form, const TailParams& p, int dtype, hipStream_t st) { return form == MM_F_C512_H128 ? MM_GO(4, 128, 2) : MM_GO(4, 256, 2); }
+#endif
+#if MM_PART_HERE(3)
+int tailmm_launch_part3(int form, const TailParams& p, int dtype, hipStream_t st) { return form == MM_F_C768 ? MM_GO(6, 128, 2) : MM_GO(3, 128, 4); }
+#endif
+#endif
+
+#if MM_PART_HERE(0)
 int tailmm_geometry_code(int C, int hidden) {
   if (!tailmm_supported(C, hidden)) return 0;
   const int hc = C == 768 ? 128 : (C == 384 || C == 512) ? tailmm_hc(C) : 256;
@@ -723,17 +758,17 @@ int tailmm_geometry_code(int C, int hidden) {
 
 int tailmm_launch(const TailParams& p, int C, int dtype, hipStream_t st) {
   KVQ_REQUIRE(tailmm_supported(C, p.hidden), KVQ_ERR_UNSUPPORTED, "kvq_block_tail: C=%d hidden=%d", C, p.hidden);
-#ifdef KVQ_TAILMM_FOCUS     // compile-time study builds (register / ISA inspection of one form in seconds instead of minutes): the 128-token C = 384 form only
-  return launch_mm_cf<Fp16, KVQ_TAILMM_FOCUS / 1000, (KVQ_TAILMM_FOCUS / 10) % 100 * 128 / 10, KVQ_TAILMM_FOCUS % 10>(p, st);      // e.g. 3102: CF 3, HC 128, TT 2
+#ifdef KVQ_TAILMM_FOCUS     // compile-time study builds (register / ISA inspection of one form in seconds instead of minutes), e.g. 3102: CF 3, HC 128, TT 2
+  return launch_mm_cf<Fp16, KVQ_TAILMM_FOCUS / 1000, (KVQ_TAILMM_FOCUS / 10) % 100 * 128 / 10, KVQ_TAILMM_FOCUS % 10>(p, st);
 #else
-  if (C == 512 && tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4, 128>(p, st) : launch_mm_cf<Bf16, 4, 128>(p, st);
-  if (C == 512) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 4>(p, st) : launch_mm_cf<Bf16, 4>(p, st);
-  if (C == 768) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 6, 128>(p, st) : launch_mm_cf<Bf16, 6, 128>(p, st);
-  if (C == 256) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 2>(p, st) : launch_mm_cf<Bf16, 2>(p, st);
-  if (tailmm_hc(C) == 128 && tailmm_tok(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3, 128, 4>(p, st) : launch_mm_cf<Bf16, 3, 128, 4>(p, st);
-  if (tailmm_hc(C) == 128) return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3, 128>(p, st) : launch_mm_cf<Bf16, 3, 128>(p, st);
-  return dtype == KVQ_DT_FP16 ? launch_mm_cf<Fp16, 3>(p, st) : launch_mm_cf<Bf16, 3>(p, st);
+  if (C == 512) return tailmm_launch_part2(tailmm_hc(C) == 128 ? MM_F_C512_H128 : MM_F_C512_H256, p, dtype, st);
+  if (C == 768) return tailmm_launch_part3(MM_F_C768, p, dtype, st);
+  if (C == 256) return tailmm_launch_part1(MM_F_C256, p, dtype, st);
+  if (tailmm_hc(C) == 128 && tailmm_tok(C) == 128) return tailmm_launch_part3(MM_F_C384_T128, p, dtype, st);
+  if (tailmm_hc(C) == 128) return tailmm_launch_part0(MM_F_C384_H128, p, dtype, st);
+  return tailmm_launch_part1(MM_F_C384_H256, p, dtype, st);
 #endif
 }
+#endif  // MM_PART_HERE(0)
 
 }  // namespace kvq

@@ -7,7 +7,7 @@ set -e
 tag=$1; shift
 pkg=kvq-challenge-cvpr-ntire2024_amd
 mkdir -p $pkg/build_$tag
-cp -p $pkg/build/*.o $pkg/build_$tag/
+cp -p $pkg/build/*.o $pkg/build_$tag/; rm -f $pkg/build_$tag/tailmm.hip.p*.o      # the variant compiles tailmm.hip as ONE unit
 echo "$@" > $pkg/build_$tag/flags.txt
 ( cd $pkg/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -fno-slp-vectorize -fno-honor-nans \
     "$@" -Rpass-analysis=kernel-resource-usage -c tailmm.hip -o ../build_$tag/tailmm.hip.o 2> ../build_$tag/tailmm.res.txt )
