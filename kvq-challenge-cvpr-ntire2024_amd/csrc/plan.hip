@@ -508,7 +508,9 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
     for (int i = 0; i < cfg.num_stages - 1 && i <= stage_hi; blk0 += pl->st[i].depth, ++i) {
       if (i < stage_lo) continue;
       const StageGeom& g = pl->st[i];
-      const bool produced16 = i == 0 ? (stage_lo == 0 && embed_fused) : (i > stage_lo && fused_merge(i - 1));      // the producer writes fp16
+      // the producer writes fp16: the embedding, the fused merge, or — fp16 OPERANDS only: its 16-bit store is then the stream's type — the
+      // reduction GEMM of an un-fused merge (Swin-B's stage 2, 18 of its 24 blocks, sits behind one)
+      const bool produced16 = i == 0 ? (stage_lo == 0 && embed_fused) : (i > stage_lo && (fused_merge(i - 1) || pl->dtype == KVQ_DT_FP16));
       bool ok = g.C <= tail_maxc_x && g.C <= resid16_maxc && produced16;
       for (int b = 0; ok && b < g.depth; ++b) {
         const KvqSwinBlockW& bw = w->blocks[blk0 + b];
@@ -734,8 +736,9 @@ static int swin_run(const KvqSwinPlan* cpl, const KvqSwinWeights* w, const float
         x16_cur = x16[i + 1];
       } else {
         KVQ_TRY(ln(pl, st, cur, g.d_merge, 4, g.L, Ln, C, mw.norm_w, mw.norm_b, bln, nullptr, x16_cur));
-        x16_cur = false;                                       // the reduction GEMM writes the next stage's stream as fp32
-        KVQ_TRY_UNLESS(128, gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
+        x16_cur = x16[i + 1];                                  // the reduction GEMM writes the next stage's stream: fp32, or fp16 rows (fp16 operands)
+        if (x16_cur) KVQ_TRY_UNLESS(128, gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_BIAS_BF16, reinterpret_cast<uint16_t*>(oth), nullptr));
+        else KVQ_TRY_UNLESS(128, gemm(pl, st, KVQ_K_GEMM_MERGE, bln, mw.red_w, nullptr, B * Ln, 2 * C, 4 * C, KVQ_EPI_STORE_F32, nullptr,
                      oth));
       }
       float* t = cur; cur = oth; oth = t;
